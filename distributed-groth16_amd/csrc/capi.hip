@@ -1,0 +1,257 @@
+// C ABI of libdg16 (include/dg16.h): argument checking, host<->device staging, error mapping.
+// All compute is in the HIP translation units next to this file; there is no CPU path.
+#include <string.h>
+
+#include "ctx.h"
+
+using namespace dg16;
+
+namespace dg16 {
+size_t fq_bytes(int curve) { return curve == DG16_BN254 ? 32 : 48; }
+size_t affine_bytes(int curve, int group) { return 2 * fq_bytes(curve) * (group == 2 ? 2 : 1); }
+static void check_curve_group(int curve, int group) {
+  DG_REQUIRE(curve >= 0 && curve <= 2, DG16_ERR_BAD_CURVE, "unknown curve id");
+  DG_REQUIRE(group == 1 || group == 2, DG16_ERR_BAD_ARG, "group must be 1 (G1) or 2 (G2)");
+  DG_REQUIRE(!(curve == DG16_BLS12_377 && group == 2), DG16_ERR_UNSUPPORTED,
+             "BLS12-377 G2 is not on the reference's path (only G1/Fr are used there)");
+}
+}  // namespace dg16
+
+extern "C" {
+
+int dg16_ctx_create(int device, dg16_ctx** out) {
+  if (!out) return DG16_ERR_BAD_ARG;
+  *out = nullptr;
+  dg16_ctx* ctx = new dg16_ctx();
+  int rc = guarded(ctx, [&] {
+    int count = 0;
+    DG_HIP(hipGetDeviceCount(&count));
+    DG_REQUIRE(count > 0, DG16_ERR_HIP, "no HIP device visible: libdg16 has no CPU path");
+    DG_REQUIRE(device >= 0 && device < count, DG16_ERR_BAD_ARG, "device index out of range");
+    DG_HIP(hipSetDevice(device));
+    hipDeviceProp_t p;
+    DG_HIP(hipGetDeviceProperties(&p, device));
+    ctx->device = device;
+    ctx->compute_units = p.multiProcessorCount;
+    ctx->name = p.gcnArchName;
+    for (int i = 0; i < kChannels; i++) {
+      DG_HIP(hipStreamCreateWithFlags(&ctx->ch[i].own, hipStreamNonBlocking));
+      ctx->ch[i].cur = ctx->ch[i].own;
+      for (int e = 0; e < 4; e++) DG_HIP(hipEventCreate(&ctx->ch[i].ev[e]));
+    }
+  });
+  if (rc != DG16_OK) {
+    // keep the message reachable for the caller that failed to get a context
+    static thread_local std::string last;
+    last = ctx->err;
+    delete ctx;
+    return rc;
+  }
+  *out = ctx;
+  return DG16_OK;
+}
+
+void dg16_ctx_destroy(dg16_ctx* ctx) {
+  if (!ctx) return;
+  hipSetDevice(ctx->device);
+  hipDeviceSynchronize();
+  for (int i = 0; i < kChannels; i++) {
+    for (int s = 0; s < kSlots; s++)
+      if (ctx->ch[i].slot[s]) hipFree(ctx->ch[i].slot[s]);
+    for (int e = 0; e < 4; e++)
+      if (ctx->ch[i].ev[e]) hipEventDestroy(ctx->ch[i].ev[e]);
+    if (ctx->ch[i].own) hipStreamDestroy(ctx->ch[i].own);
+  }
+  for (auto& kv : ctx->twiddles) {
+    hipFree(kv.second.lo);
+    hipFree(kv.second.hi);
+    if (kv.second.hi_scaled) hipFree(kv.second.hi_scaled);
+    hipFree(kv.second.small);
+    hipFree(kv.second.n_inv);
+  }
+  delete ctx;
+}
+
+const char* dg16_last_error(dg16_ctx* ctx) {
+  if (!ctx) return "null context";
+  std::lock_guard<std::mutex> g(ctx->mu);
+  static thread_local std::string copy;
+  copy = ctx->err;
+  return copy.c_str();
+}
+
+int dg16_set_stream(dg16_ctx* ctx, int channel, void* hip_stream) {
+  int rc = guard_channel(ctx, channel);
+  if (rc) return rc;
+  std::lock_guard<std::mutex> g(ctx->ch[channel].mu);
+  ctx->ch[channel].cur = hip_stream ? (hipStream_t)hip_stream : ctx->ch[channel].own;
+  return DG16_OK;
+}
+
+int dg16_sync(dg16_ctx* ctx, int channel) {
+  int rc = guard_channel(ctx, channel);
+  if (rc) return rc;
+  return guarded(ctx, [&] {
+    DG_HIP(hipSetDevice(ctx->device));
+    DG_HIP(hipStreamSynchronize(ctx->ch[channel].cur));
+  });
+}
+
+int dg16_device_info(dg16_ctx* ctx, char* name, size_t name_len, int* compute_units) {
+  if (!ctx) return DG16_ERR_BAD_ARG;
+  if (name && name_len) {
+    strncpy(name, ctx->name.c_str(), name_len - 1);
+    name[name_len - 1] = 0;
+  }
+  if (compute_units) *compute_units = ctx->compute_units;
+  return DG16_OK;
+}
+
+int dg16_last_kernel_ms(dg16_ctx* ctx, int channel, int which, float* ms) {
+  int rc = guard_channel(ctx, channel);
+  if (rc) return rc;
+  if (!ms || which < 0 || which > 1) return DG16_ERR_BAD_ARG;
+  return guarded(ctx, [&] {
+    Channel& c = ctx->ch[channel];
+    std::lock_guard<std::mutex> g(c.mu);
+    *ms = 0.f;
+    if (!c.ev_valid[which]) return;
+    DG_HIP(hipSetDevice(ctx->device));
+    hipEvent_t a = c.ev[which == 0 ? 0 : 2], b = c.ev[which == 0 ? 1 : 3];
+    DG_HIP(hipEventSynchronize(b));
+    DG_HIP(hipEventElapsedTime(ms, a, b));
+  });
+}
+
+int dg16_field_op(dg16_ctx* ctx, int field_id, int op, const void* a, const void* b, void* out,
+                  size_t n, unsigned flags, int channel) {
+  int rc = guard_channel(ctx, channel);
+  if (rc) return rc;
+  return guarded(ctx, [&] {
+    int curve = field_id & 15;
+    DG_REQUIRE((field_id & ~16) >= 0 && curve <= 2 && (field_id >> 4) <= 1, DG16_ERR_BAD_CURVE,
+               "field id must be curve (Fq) or 16 + curve (Fr)");
+    DG_REQUIRE(op >= 0 && op <= 7, DG16_ERR_BAD_ARG, "unknown field op");
+    DG_REQUIRE(a && out && (b || op >= 3), DG16_ERR_BAD_ARG, "null operand");
+    bool dev = flags & DG16_F_DEVICE_PTRS;
+    size_t eb = (field_id & 16) ? 32 : fq_bytes(curve);
+    Call k(ctx, channel);
+    const void* da = stage_in(k, 0, a, n * eb, dev);
+    const void* db = b ? stage_in(k, 1, b, n * eb, dev) : da;
+    void* dout = dev ? out : ws(k.c, 2, n * eb);
+    if (n) field_op_launch(k, field_id, op, da, db, dout, n);
+    if (!dev) stage_out(k, out, dout, n * eb, false);
+    k.finish();
+    if (!dev) DG_HIP(hipStreamSynchronize(k.s()));
+  });
+}
+
+int dg16_ntt(dg16_ctx* ctx, int curve, void* data, unsigned log_n, int inverse,
+             const void* coset_offset, unsigned flags, int channel) {
+  int rc = guard_channel(ctx, channel);
+  if (rc) return rc;
+  return guarded(ctx, [&] {
+    DG_REQUIRE(curve >= 0 && curve <= 2, DG16_ERR_BAD_CURVE, "unknown curve id");
+    DG_REQUIRE(data, DG16_ERR_BAD_ARG, "null data");
+    const unsigned two_adicity[3] = {28, 32, 47};
+    DG_REQUIRE(log_n <= two_adicity[curve] && log_n <= 30, DG16_ERR_BAD_ARG,
+               "domain larger than the field's 2-adic subgroup (PolynomialDegreeTooLarge)");
+    bool dev = flags & DG16_F_DEVICE_PTRS;
+    size_t bytes = ((size_t)32) << log_n;
+    Call k(ctx, channel);
+    void* d = dev ? data : ws(k.c, 0, bytes);
+    if (!dev) DG_HIP(hipMemcpyAsync(d, data, bytes, hipMemcpyHostToDevice, k.s()));
+    ntt_launch(k, curve, d, log_n, inverse, coset_offset);
+    if (!dev) stage_out(k, data, d, bytes, false);
+    k.finish();
+    if (!dev) DG_HIP(hipStreamSynchronize(k.s()));
+  });
+}
+
+int dg16_h_poly(dg16_ctx* ctx, int curve, const void* a, const void* b, const void* c,
+                unsigned log_m, void* out, unsigned flags, int channel) {
+  int rc = guard_channel(ctx, channel);
+  if (rc) return rc;
+  return guarded(ctx, [&] {
+    DG_REQUIRE(curve >= 0 && curve <= 2, DG16_ERR_BAD_CURVE, "unknown curve id");
+    DG_REQUIRE(a && b && c && out, DG16_ERR_BAD_ARG, "null operand");
+    const unsigned two_adicity[3] = {28, 32, 47};
+    DG_REQUIRE(log_m + 1 <= two_adicity[curve] && log_m <= 29, DG16_ERR_BAD_ARG,
+               "domain larger than the field's 2-adic subgroup (PolynomialDegreeTooLarge)");
+    bool dev = flags & DG16_F_DEVICE_PTRS;
+    size_t bytes = ((size_t)32) << log_m;
+    Call k(ctx, channel);
+    const void* da = stage_in(k, 0, a, bytes, dev);
+    const void* db = stage_in(k, 1, b, bytes, dev);
+    const void* dc = stage_in(k, 2, c, bytes, dev);
+    void* dout = dev ? out : ws(k.c, 3, bytes);
+    h_poly_launch(k, curve, da, db, dc, log_m, dout);
+    if (!dev) stage_out(k, out, dout, bytes, false);
+    k.finish();
+    if (!dev) DG_HIP(hipStreamSynchronize(k.s()));
+  });
+}
+
+int dg16_msm(dg16_ctx* ctx, int curve, int group, const void* bases, const void* scalars,
+             size_t n_bases, size_t n_scalars, unsigned flags, int channel, void* out) {
+  int rc = guard_channel(ctx, channel);
+  if (rc) return rc;
+  return guarded(ctx, [&] {
+    check_curve_group(curve, group);
+    DG_REQUIRE(n_bases == n_scalars, DG16_ERR_LENGTH_MISMATCH,
+               "bases and scalars differ in length (VariableBaseMSM::msm returns Err(min_len))");
+    DG_REQUIRE(out && (n_bases == 0 || (bases && scalars)), DG16_ERR_BAD_ARG, "null operand");
+    DG_REQUIRE(n_bases < ((size_t)1 << 30), DG16_ERR_BAD_ARG, "n must be < 2^30");
+    bool dev = flags & DG16_F_DEVICE_PTRS;
+    bool affine = flags & DG16_F_OUT_AFFINE;
+    size_t pb = affine_bytes(curve, group);
+    size_t ob = pb / 2 * (affine ? 2 : 3);
+    Call k(ctx, channel);
+    const void* dbases = stage_in(k, 0, bases, n_bases * pb, dev);
+    const void* dscal = stage_in(k, 1, scalars, n_bases * 32, dev);
+    void* dout = dev ? out : ws(k.c, 2, ob);
+    msm_launch(k, curve, group, dbases, dscal, n_bases, flags & DG16_F_SCALARS_MONT, affine, dout);
+    if (!dev) stage_out(k, out, dout, ob, false);
+    k.finish();
+    if (!dev) DG_HIP(hipStreamSynchronize(k.s()));
+  });
+}
+
+int dg16_gen_bases(dg16_ctx* ctx, int curve, int group, uint64_t seed, size_t n, void* out,
+                   unsigned flags, int channel) {
+  int rc = guard_channel(ctx, channel);
+  if (rc) return rc;
+  return guarded(ctx, [&] {
+    check_curve_group(curve, group);
+    DG_REQUIRE(out || n == 0, DG16_ERR_BAD_ARG, "null output");
+    bool dev = flags & DG16_F_DEVICE_PTRS;
+    size_t pb = affine_bytes(curve, group);
+    Call k(ctx, channel);
+    void* dout = dev ? out : ws(k.c, 0, n * pb);
+    if (n) gen_bases_launch(k, curve, group, seed, n, dout);
+    if (!dev) stage_out(k, out, dout, n * pb, false);
+    k.finish();
+    if (!dev) DG_HIP(hipStreamSynchronize(k.s()));
+  });
+}
+
+int dg16_to_affine(dg16_ctx* ctx, int curve, int group, const void* jac, void* out, size_t n,
+                   unsigned flags, int channel) {
+  int rc = guard_channel(ctx, channel);
+  if (rc) return rc;
+  return guarded(ctx, [&] {
+    check_curve_group(curve, group);
+    DG_REQUIRE((jac && out) || n == 0, DG16_ERR_BAD_ARG, "null operand");
+    bool dev = flags & DG16_F_DEVICE_PTRS;
+    size_t pb = affine_bytes(curve, group);
+    Call k(ctx, channel);
+    const void* din = stage_in(k, 0, jac, n * pb / 2 * 3, dev);
+    void* dout = dev ? out : ws(k.c, 1, n * pb);
+    if (n) to_affine_launch(k, curve, group, din, dout, n);
+    if (!dev) stage_out(k, out, dout, n * pb, false);
+    k.finish();
+    if (!dev) DG_HIP(hipStreamSynchronize(k.s()));
+  });
+}
+
+}  // extern "C"

@@ -1,0 +1,181 @@
+// Host-side context of libdg16: one per process and GPU, three channels (HIP stream + grow-only
+// device workspace each), mirroring MultiplexedStreamID::{Zero,One,Two} of the reference
+// (mpc-net/src/lib.rs:29-33).  Thread-safe per channel (callers are concurrent host threads, like
+// the reference's tokio tasks: mpc-net/src/multi.rs:305-314).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/dg16.h"
+
+namespace dg16 {
+
+constexpr int kChannels = 3;
+constexpr int kSlots = 24;
+
+struct Channel {
+  hipStream_t own = nullptr;
+  hipStream_t cur = nullptr;
+  std::mutex mu;
+  void* slot[kSlots] = {};
+  size_t slot_bytes[kSlots] = {};
+  hipEvent_t ev[4] = {};
+  bool ev_valid[2] = {false, false};  // [0] whole call (ev0..ev1), [1] dominant kernel (ev2..ev3)
+};
+
+struct TwiddleKey {
+  int curve;
+  unsigned log_n;
+  int inverse;
+  bool operator<(const TwiddleKey& o) const {
+    if (curve != o.curve) return curve < o.curve;
+    if (log_n != o.log_n) return log_n < o.log_n;
+    return inverse < o.inverse;
+  }
+};
+struct TwiddleSet {   // all device pointers, 32-byte Fr elements
+  void* lo = nullptr;        // w^j, j < 2^lb
+  void* hi = nullptr;        // w^(j << lb), j < 2^(log_n - lb)
+  void* hi_scaled = nullptr; // hi * n^-1 (inverse only)
+  void* small = nullptr;     // w_{2^sm}^t, t < 2^(sm-1)
+  void* n_inv = nullptr;     // one element
+  unsigned lb = 0, sm = 0;
+};
+
+}  // namespace dg16
+
+struct dg16_ctx {
+  int device = 0;
+  int compute_units = 0;
+  std::string name;
+  dg16::Channel ch[dg16::kChannels];
+  std::mutex mu;  // guards err + twiddle cache
+  std::string err;
+  std::map<dg16::TwiddleKey, dg16::TwiddleSet> twiddles;
+};
+
+namespace dg16 {
+
+struct StatusError {
+  int code;
+  std::string msg;
+};
+
+#define DG_HIP(expr)                                                                        \
+  do {                                                                                      \
+    hipError_t e_ = (expr);                                                                 \
+    if (e_ != hipSuccess)                                                                   \
+      throw dg16::StatusError{e_ == hipErrorOutOfMemory ? DG16_ERR_OOM : DG16_ERR_HIP,      \
+                              std::string(#expr) + ": " + hipGetErrorString(e_)};           \
+  } while (0)
+
+#define DG_REQUIRE(cond, code, text)                                                        \
+  do {                                                                                      \
+    if (!(cond)) throw dg16::StatusError{code, text};                                       \
+  } while (0)
+
+// grow-only workspace slot; contents are undefined after a grow
+inline void* ws(Channel& c, int slot, size_t bytes) {
+  if (bytes == 0) bytes = 16;
+  if (c.slot_bytes[slot] < bytes) {
+    if (c.slot[slot]) {
+      DG_HIP(hipStreamSynchronize(c.cur));
+      DG_HIP(hipFree(c.slot[slot]));
+      c.slot[slot] = nullptr;
+      c.slot_bytes[slot] = 0;
+    }
+    size_t want = bytes + bytes / 8;
+    DG_HIP(hipMalloc(&c.slot[slot], want));
+    c.slot_bytes[slot] = want;
+  }
+  return c.slot[slot];
+}
+
+// RAII: lock the channel, make the device current, record whole-call events
+struct Call {
+  dg16_ctx* ctx;
+  Channel& c;
+  std::unique_lock<std::mutex> lk;
+  Call(dg16_ctx* ctx_, int channel)
+      : ctx(ctx_), c(ctx_->ch[channel]), lk(ctx_->ch[channel].mu) {
+    DG_HIP(hipSetDevice(ctx->device));
+    c.ev_valid[0] = c.ev_valid[1] = false;
+    DG_HIP(hipEventRecord(c.ev[0], c.cur));
+  }
+  void begin_dominant() { DG_HIP(hipEventRecord(c.ev[2], c.cur)); }
+  void end_dominant() {
+    DG_HIP(hipEventRecord(c.ev[3], c.cur));
+    c.ev_valid[1] = true;
+  }
+  void finish() {
+    DG_HIP(hipEventRecord(c.ev[1], c.cur));
+    c.ev_valid[0] = true;
+  }
+  hipStream_t s() const { return c.cur; }
+};
+
+inline int guard_channel(dg16_ctx* ctx, int channel) {
+  if (!ctx) return DG16_ERR_BAD_ARG;
+  if (channel < 0 || channel >= kChannels) {
+    std::lock_guard<std::mutex> g(ctx->mu);
+    ctx->err = "channel must be 0..2";
+    return DG16_ERR_BAD_ARG;
+  }
+  return DG16_OK;
+}
+
+template <class Fn>
+int guarded(dg16_ctx* ctx, Fn&& fn) {
+  try {
+    fn();
+    return DG16_OK;
+  } catch (const StatusError& e) {
+    if (ctx) {
+      std::lock_guard<std::mutex> g(ctx->mu);
+      ctx->err = e.msg;
+    }
+    return e.code;
+  } catch (const std::exception& e) {
+    if (ctx) {
+      std::lock_guard<std::mutex> g(ctx->mu);
+      ctx->err = e.what();
+    }
+    return DG16_ERR_HIP;
+  } catch (...) {
+    return DG16_ERR_HIP;
+  }
+}
+
+// staging helpers: host-pointer calls copy through workspace slots
+inline const void* stage_in(Call& k, int slot, const void* p, size_t bytes, bool device_ptrs) {
+  if (device_ptrs || bytes == 0) return p;
+  void* d = ws(k.c, slot, bytes);
+  DG_HIP(hipMemcpyAsync(d, p, bytes, hipMemcpyHostToDevice, k.s()));
+  return d;
+}
+inline void stage_out(Call& k, void* host_dst, const void* dev_src, size_t bytes, bool device_ptrs) {
+  if (device_ptrs) {
+    if (host_dst != dev_src) DG_HIP(hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToDevice, k.s()));
+  } else {
+    DG_HIP(hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, k.s()));
+  }
+}
+
+// implemented in the .hip translation units
+void field_op_launch(Call& k, int field_id, int op, const void* a, const void* b, void* out, size_t n);
+void ntt_launch(Call& k, int curve, void* data, unsigned log_n, int inverse, const void* coset_host);
+void h_poly_launch(Call& k, int curve, const void* a, const void* b, const void* c, unsigned log_m,
+                   void* out);
+void msm_launch(Call& k, int curve, int group, const void* bases, const void* scalars, size_t n,
+                bool scalars_mont, bool out_affine, void* out_dev);
+void gen_bases_launch(Call& k, int curve, int group, uint64_t seed, size_t n, void* out_dev);
+void to_affine_launch(Call& k, int curve, int group, const void* jac, void* out, size_t n);
+size_t fq_bytes(int curve);
+size_t affine_bytes(int curve, int group);
+
+}  // namespace dg16

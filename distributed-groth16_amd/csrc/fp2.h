@@ -1,0 +1,45 @@
+// Quadratic extension Fq[u]/(u^2 + 1) (BN254 and BLS12-381 G2 coordinates; ark-bn254 /
+// ark-bls12-381 Fq2Config NONRESIDUE = -1).  Memory layout c0 || c1, each an Fp in Montgomery form,
+// i.e. the arkworks `QuadExtField { c0, c1 }` the reference passes for E::G2Affine at
+// groth16/src/prove.rs:62-85.
+#pragma once
+#include "fp.h"
+
+namespace dg16 {
+
+template <class F>
+struct Fp2 {
+  using Base = F;
+  F c0, c1;
+
+  DG_HD static Fp2 zero() { return {F::zero(), F::zero()}; }
+  DG_HD static Fp2 one() { return {F::one(), F::zero()}; }
+  DG_HD bool is_zero() const { return c0.is_zero() && c1.is_zero(); }
+  DG_HD bool operator==(const Fp2& o) const { return c0 == o.c0 && c1 == o.c1; }
+  DG_HD bool operator!=(const Fp2& o) const { return !(*this == o); }
+  DG_HD friend Fp2 operator+(const Fp2& a, const Fp2& b) { return {a.c0 + b.c0, a.c1 + b.c1}; }
+  DG_HD friend Fp2 operator-(const Fp2& a, const Fp2& b) { return {a.c0 - b.c0, a.c1 - b.c1}; }
+  DG_HD Fp2 neg() const { return {c0.neg(), c1.neg()}; }
+  DG_HD Fp2 dbl() const { return {c0.dbl(), c1.dbl()}; }
+  // Karatsuba: 3 base multiplications
+  DG_HD friend Fp2 operator*(const Fp2& a, const Fp2& b) {
+    F v0 = a.c0 * b.c0;
+    F v1 = a.c1 * b.c1;
+    F s = (a.c0 + a.c1) * (b.c0 + b.c1);
+    return {v0 - v1, s - v0 - v1};
+  }
+  // complex squaring: 2 base multiplications
+  DG_HD Fp2 sqr() const {
+    F t = c0 * c1;
+    return {(c0 + c1) * (c0 - c1), t.dbl()};
+  }
+  DG_HD Fp2 inv() const {
+    F n = (c0.sqr() + c1.sqr()).inv();
+    return {c0 * n, (c1 * n).neg()};
+  }
+  DG_HD static Fp2 select(bool c, const Fp2& a, const Fp2& b) {
+    return {F::select(c, a.c0, b.c0), F::select(c, a.c1, b.c1)};
+  }
+};
+
+}  // namespace dg16

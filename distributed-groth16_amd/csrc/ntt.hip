@@ -1,0 +1,389 @@
+// Radix-2 NTT over the scalar field for gfx950, natural order in and out
+// (ark-poly Radix2EvaluationDomain semantics as used at ark-circom/src/circom/qap.rs:64-85 and
+// dist-primitives/src/dfft/mod.rs:40,78-81).
+//
+// Decomposition (generalised Cooley-Tukey, no separate bit-reversal pass): N = N1*N2*N3 (1..3
+// steps of <= 2^9 points).  With input index n = N2N3*n1 + N3*n2 + n3 and output index
+// k = k1 + N1*k2 + N1N2*k3, step j views the array as [A][Nj][B] and, for every (a, b), does a
+// length-Nj DFT along the middle axis entirely inside LDS, multiplies by the inter-step twiddle
+// w_{Nj*B}^(b*k) and stores in place; the last step (B = 1) stores transposed to natural order.
+// A workgroup owns a tile of 2^s points x T lines (T contiguous in memory => T*32-byte coalesced
+// segments), TILE = 1024 elements = 32 KiB of LDS, 256 threads, 2 butterflies/thread/level.
+//
+// Roofline: 64 B/element algorithmic traffic, but ~13 Montgomery multiplications per element at
+// 2^22 (~360 VALU instructions each) -- the kernel is VALU-bound, not HBM-bound.
+#include "ctx.h"
+#include "types.h"
+
+namespace dg16 {
+
+constexpr unsigned kTileLog = 10;         // 1024 elements per workgroup
+constexpr unsigned kTile = 1u << kTileLog;
+constexpr unsigned kMaxStepLog = 9;       // sub-FFT size limit per step
+constexpr unsigned kLoBits = 11;          // twiddle table split
+
+template <class F>
+struct StepArgs {
+  const F* src;
+  F* dst;
+  unsigned log_n, s, log_a, log_b;
+  unsigned last;             // 1: B == 1, transposed store to natural order
+  unsigned log_n1, log_n2;   // last step: a = k1*N2 + k2, out = k1 + N1*k2 + N1N2*k
+  const F* small;            // w_{2^sm}^t, t < 2^(sm-1)
+  unsigned sm;
+  const F* tw_lo;            // inter-step twiddles: w^e = lo[e & mask] * hi[e >> lb]
+  const F* tw_hi;
+  unsigned lb;
+  const F* pre_lo;           // optional: x[i] *= g^i on load (first step)
+  const F* pre_hi;
+  const F* post_lo;          // optional: out[o] *= g^o on store (last step)
+  const F* post_hi;
+  unsigned plb;
+  const F* scale;            // optional: out *= *scale on store (last step)
+};
+
+__device__ __forceinline__ unsigned bitrev(unsigned v, unsigned bits) {
+  return bits ? (__brev(v) >> (32 - bits)) : 0;
+}
+
+template <class F>
+__global__ void __launch_bounds__(256) ntt_step_kernel(StepArgs<F> p) {
+  __shared__ F tile[kTile];
+  const unsigned tid = threadIdx.x;
+  const unsigned s = p.s;
+  const unsigned nj = 1u << s;
+  const unsigned log_t = (p.log_n < kTileLog ? p.log_n : kTileLog) - s;  // lines per tile
+  const unsigned T = 1u << log_t;
+  const unsigned elems = nj << log_t;
+  const size_t tile_id = blockIdx.x;
+
+  // tile origin
+  size_t a = 0, b0 = 0, k1_0 = 0, k2 = 0;
+  if (!p.last) {
+    const unsigned tiles_per_a_log = p.log_b - log_t;
+    a = tile_id >> tiles_per_a_log;
+    b0 = (tile_id & (((size_t)1 << tiles_per_a_log) - 1)) << log_t;
+  } else {
+    // lines a_t = (k1_0 + t) * N2 + k2
+    const unsigned k1_tiles_log = p.log_n1 - log_t;  // requires N1 >= T (host guarantees)
+    k2 = tile_id >> k1_tiles_log;
+    k1_0 = (tile_id & (((size_t)1 << k1_tiles_log) - 1)) << log_t;
+  }
+
+  // ---- load (bit-reversed rows so that in-place DIT yields natural order) ----
+  for (unsigned idx = tid; idx < elems; idx += 256) {
+    unsigned n, t;
+    size_t g;
+    if (!p.last) {
+      t = idx & (T - 1);
+      n = idx >> log_t;
+      g = ((((a << s) + n) << p.log_b) + b0 + t);
+    } else {
+      n = idx & (nj - 1);
+      t = idx >> s;
+      g = ((((k1_0 + t) << p.log_n2) + k2) << s) + n;
+    }
+    F v = p.src[g];
+    if (p.pre_lo) {
+      F w = p.pre_lo[g & ((1u << p.plb) - 1)] * p.pre_hi[g >> p.plb];
+      v = v * w;
+    }
+    tile[(bitrev(n, s) << log_t) + t] = v;
+  }
+
+  // ---- s radix-2 DIT levels in LDS ----
+  const unsigned nbf = elems >> 1;
+  for (unsigned lv = 1; lv <= s; lv++) {
+    __syncthreads();
+    const unsigned half = 1u << (lv - 1);
+    for (unsigned q = tid; q < nbf; q += 256) {
+      unsigned t = q & (T - 1);
+      unsigned pi = q >> log_t;
+      unsigned k = pi & (half - 1);
+      unsigned blk = pi >> (lv - 1);
+      unsigned i0 = ((((blk << lv) + k)) << log_t) + t;
+      unsigned i1 = i0 + (half << log_t);
+      F x = tile[i0];
+      F y = tile[i1];
+      if (lv > 1) y = y * p.small[k << (p.sm - lv)];
+      tile[i0] = x + y;
+      tile[i1] = x - y;
+    }
+  }
+  __syncthreads();
+
+  // ---- twiddle + store ----
+  for (unsigned idx = tid; idx < elems; idx += 256) {
+    unsigned t = idx & (T - 1);
+    unsigned k = idx >> log_t;
+    F v = tile[(k << log_t) + t];
+    size_t g;
+    if (!p.last) {
+      size_t b = b0 + t;
+      size_t e = (b * k) << p.log_a;   // < N
+      if (e) {
+        F w = p.tw_lo[e & ((1u << p.lb) - 1)] * p.tw_hi[e >> p.lb];
+        v = v * w;
+      } else if (p.scale) {
+        // inverse transform with the n^-1 factor folded into tw_hi: e == 0 still needs it
+        v = v * p.tw_hi[0];
+      }
+      g = ((((a << s) + k) << p.log_b) + b);
+    } else {
+      g = (k1_0 + t) + (k2 << p.log_n1) + ((size_t)k << (p.log_n1 + p.log_n2));
+      if (p.scale) v = v * *p.scale;
+      if (p.post_lo) {
+        F w = p.post_lo[g & ((1u << p.plb) - 1)] * p.post_hi[g >> p.plb];
+        v = v * w;
+      }
+    }
+    p.dst[g] = v;
+  }
+}
+
+// ---- twiddle tables -------------------------------------------------------------------------
+// out[j] = c * base^(j << shift), j < count.  base_log2 != 0: base = TWO_ADIC_ROOT^(2^(S-base_log2))
+// (or its inverse) instead of *base_ptr.
+template <class F>
+__global__ void powers_kernel(F* out, size_t count, unsigned shift, const F* base_ptr,
+                              unsigned root_log, int invert, const F* c_ptr) {
+  size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= count) return;
+  F base;
+  if (base_ptr) {
+    base = *base_ptr;
+  } else {
+    F w;
+#pragma unroll
+    for (int i = 0; i < F::NL; i++) w.l[i] = F::Params::TWO_ADIC_ROOT[i];
+    for (unsigned i = root_log; i < (unsigned)F::Params::TWO_ADICITY; i++) w = w.sqr();
+    // w has order 2^root_log; its inverse is w^(2^root_log - 1)
+    if (invert) {
+      F acc = F::one(), sq = w;
+      for (unsigned i = 0; i < root_log; i++) { acc = acc * sq; sq = sq.sqr(); }
+      w = acc;
+    }
+    base = w;
+  }
+  F r = base.pow_u64((uint64_t)j << shift);
+  if (c_ptr) r = r * *c_ptr;
+  out[j] = r;
+}
+
+// *out = (2^log_n)^-1
+template <class F>
+__global__ void n_inv_kernel(F* out, unsigned log_n) {
+  // inverse of 2 is (p+1)/2; computed as 2^-1 = (R-form) via Fermat once, then raised
+  F two = F::one() + F::one();
+  F half = two.inv();
+  *out = half.pow_u64(log_n);
+}
+
+template <class F>
+static const TwiddleSet& get_twiddles(Call& k, int curve, unsigned log_n, int inverse) {
+  std::lock_guard<std::mutex> g(k.ctx->mu);
+  TwiddleKey key{curve, log_n, inverse};
+  auto it = k.ctx->twiddles.find(key);
+  if (it != k.ctx->twiddles.end()) return it->second;
+  TwiddleSet ts;
+  ts.lb = log_n < kLoBits ? log_n : kLoBits;
+  ts.sm = log_n < kMaxStepLog ? (log_n ? log_n : 1) : kMaxStepLog;
+  size_t nlo = (size_t)1 << ts.lb, nhi = (size_t)1 << (log_n - ts.lb), nsm = (size_t)1 << (ts.sm - 1);
+  DG_HIP(hipMalloc(&ts.lo, nlo * sizeof(F)));
+  DG_HIP(hipMalloc(&ts.hi, nhi * sizeof(F)));
+  DG_HIP(hipMalloc(&ts.small, nsm * sizeof(F)));
+  DG_HIP(hipMalloc(&ts.n_inv, sizeof(F)));
+  hipStream_t s = k.s();
+  hipLaunchKernelGGL(n_inv_kernel<F>, dim3(1), dim3(1), 0, s, (F*)ts.n_inv, log_n);
+  hipLaunchKernelGGL(powers_kernel<F>, dim3((unsigned)((nlo + 255) / 256)), dim3(256), 0, s, (F*)ts.lo,
+                     nlo, 0u, (const F*)nullptr, log_n, inverse, (const F*)nullptr);
+  hipLaunchKernelGGL(powers_kernel<F>, dim3((unsigned)((nhi + 255) / 256)), dim3(256), 0, s, (F*)ts.hi,
+                     nhi, ts.lb, (const F*)nullptr, log_n, inverse, (const F*)nullptr);
+  if (inverse) {
+    DG_HIP(hipMalloc(&ts.hi_scaled, nhi * sizeof(F)));
+    hipLaunchKernelGGL(powers_kernel<F>, dim3((unsigned)((nhi + 255) / 256)), dim3(256), 0, s,
+                       (F*)ts.hi_scaled, nhi, ts.lb, (const F*)nullptr, log_n, inverse,
+                       (const F*)ts.n_inv);
+  }
+  // w_{2^sm}^t = w_N^(t << (log_n - sm)); for log_n == 0 the table is a single 1
+  hipLaunchKernelGGL(powers_kernel<F>, dim3((unsigned)((nsm + 255) / 256)), dim3(256), 0, s, (F*)ts.small,
+                     nsm, log_n >= ts.sm ? log_n - ts.sm : 0, (const F*)nullptr, log_n ? log_n : 1, inverse,
+                     (const F*)nullptr);
+  DG_HIP(hipGetLastError());
+  DG_HIP(hipStreamSynchronize(s));   // tables are shared by all channels from here on
+  return k.ctx->twiddles.emplace(key, ts).first->second;
+}
+
+// power tables for an arbitrary base g (coset offset): lo[j] = g^j, hi[j] = g^(j << lb)
+template <class F>
+static void build_power_tables(Call& k, const F* g_dev, unsigned log_n, F* lo, F* hi, unsigned lb) {
+  size_t nlo = (size_t)1 << lb, nhi = (size_t)1 << (log_n - lb);
+  hipLaunchKernelGGL(powers_kernel<F>, dim3((unsigned)((nlo + 255) / 256)), dim3(256), 0, k.s(), lo, nlo, 0u,
+                     g_dev, 0u, 0, (const F*)nullptr);
+  hipLaunchKernelGGL(powers_kernel<F>, dim3((unsigned)((nhi + 255) / 256)), dim3(256), 0, k.s(), hi, nhi, lb,
+                     g_dev, 0u, 0, (const F*)nullptr);
+  DG_HIP(hipGetLastError());
+}
+
+template <class F>
+__global__ void inv_one_kernel(F* out, const F* in) { *out = in->inv(); }
+
+struct Plan {
+  unsigned nsteps;
+  unsigned s[3];
+};
+static Plan make_plan(unsigned log_n) {
+  Plan pl{};
+  if (log_n <= kTileLog && log_n <= kMaxStepLog) {
+    pl.nsteps = 1;
+    pl.s[0] = log_n;
+  } else if (log_n <= 2 * kMaxStepLog) {
+    pl.nsteps = 2;
+    pl.s[0] = log_n / 2;
+    pl.s[1] = log_n - pl.s[0];
+  } else {
+    pl.nsteps = 3;
+    pl.s[0] = log_n / 3;
+    pl.s[1] = (log_n - pl.s[0]) / 2;
+    pl.s[2] = log_n - pl.s[0] - pl.s[1];
+  }
+  return pl;
+}
+
+// data <- transform(data); tmp is a scratch buffer of the same size (multi-step plans ping-pong).
+// pre_g / post_g: device pointers to one element each (or null); see StepArgs.
+template <class F>
+static void ntt_run(Call& k, int curve, F* data, F* tmp, unsigned log_n, int inverse,
+                    const F* pre_lo, const F* pre_hi, const F* post_lo, const F* post_hi, unsigned plb) {
+  DG_REQUIRE(log_n <= 3 * kMaxStepLog, DG16_ERR_UNSUPPORTED, "log_n > 27 not supported yet");
+  const TwiddleSet& ts = get_twiddles<F>(k, curve, log_n, inverse);
+  Plan pl = make_plan(log_n);
+  F* src = data;
+  unsigned consumed = 0;
+  for (unsigned j = 0; j < pl.nsteps; j++) {
+    StepArgs<F> a{};
+    a.log_n = log_n;
+    a.s = pl.s[j];
+    a.log_a = consumed;
+    a.log_b = log_n - consumed - pl.s[j];
+    a.last = (j == pl.nsteps - 1);
+    a.log_n1 = pl.nsteps >= 2 ? pl.s[0] : 0;
+    a.log_n2 = pl.nsteps == 3 ? pl.s[1] : 0;
+    a.small = (const F*)ts.small;
+    a.sm = ts.sm;
+    a.tw_lo = (const F*)ts.lo;
+    // n^-1 rides on the first step's twiddles when there is more than one step
+    bool fold_scale = inverse && pl.nsteps > 1 && j == 0;
+    a.tw_hi = (const F*)(fold_scale ? ts.hi_scaled : ts.hi);
+    a.lb = ts.lb;
+    a.scale = nullptr;
+    if (fold_scale) a.scale = (const F*)ts.n_inv;                  // marks "tw_hi carries n^-1"
+    if (inverse && pl.nsteps == 1) a.scale = (const F*)ts.n_inv;   // explicit multiply at the store
+    if (j == 0) { a.pre_lo = pre_lo; a.pre_hi = pre_hi; }
+    if (a.last) { a.post_lo = post_lo; a.post_hi = post_hi; }
+    a.plb = plb;
+    // ping-pong: first step data -> tmp (same layout), middle step in place, last step tmp -> data
+    F* dst;
+    if (pl.nsteps == 1) {
+      dst = data;  // a single workgroup holds the whole vector in LDS before storing
+    } else if (j == 0) {
+      dst = tmp;
+    } else if (a.last) {
+      dst = data;
+    } else {
+      dst = src;
+    }
+    a.src = src;
+    a.dst = dst;
+    unsigned log_tile = log_n < kTileLog ? log_n : kTileLog;
+    size_t blocks = (size_t)1 << (log_n - log_tile);
+    if (a.last && pl.nsteps > 1) {
+      unsigned log_t = log_tile - a.s;
+      DG_REQUIRE(a.log_n1 >= log_t, DG16_ERR_UNSUPPORTED, "plan violates N1 >= T");
+    } else if (!a.last) {
+      unsigned log_t = log_tile - a.s;
+      DG_REQUIRE(a.log_b >= log_t, DG16_ERR_UNSUPPORTED, "plan violates B >= T");
+    }
+    hipLaunchKernelGGL(ntt_step_kernel<F>, dim3((unsigned)blocks), dim3(256), 0, k.s(), a);
+    DG_HIP(hipGetLastError());
+    src = dst;
+    consumed += pl.s[j];
+  }
+}
+
+template <class F>
+static void ntt_typed(Call& k, int curve, void* data, unsigned log_n, int inverse, const void* coset_host) {
+  F* d = (F*)data;
+  F* tmp = (F*)ws(k.c, 8, sizeof(F) << log_n);
+  const F *pre_lo = nullptr, *pre_hi = nullptr, *post_lo = nullptr, *post_hi = nullptr;
+  unsigned plb = log_n < kLoBits ? log_n : kLoBits;
+  if (coset_host) {
+    F* g = (F*)ws(k.c, 9, 2 * sizeof(F));
+    DG_HIP(hipMemcpyAsync(g, coset_host, sizeof(F), hipMemcpyHostToDevice, k.s()));
+    F* lo = (F*)ws(k.c, 10, sizeof(F) << plb);
+    F* hi = (F*)ws(k.c, 11, sizeof(F) << (log_n - plb));
+    if (inverse) {
+      hipLaunchKernelGGL(inv_one_kernel<F>, dim3(1), dim3(1), 0, k.s(), g + 1, g);
+      build_power_tables<F>(k, g + 1, log_n, lo, hi, plb);
+      post_lo = lo; post_hi = hi;
+    } else {
+      build_power_tables<F>(k, g, log_n, lo, hi, plb);
+      pre_lo = lo; pre_hi = hi;
+    }
+  }
+  k.begin_dominant();
+  ntt_run<F>(k, curve, d, tmp, log_n, inverse, pre_lo, pre_hi, post_lo, post_hi, plb);
+  k.end_dominant();
+}
+
+void ntt_launch(Call& k, int curve, void* data, unsigned log_n, int inverse, const void* coset_host) {
+  switch (curve) {
+    case 0: ntt_typed<bn254_fr>(k, curve, data, log_n, inverse, coset_host); break;
+    case 1: ntt_typed<bls12_381_fr>(k, curve, data, log_n, inverse, coset_host); break;
+    default: ntt_typed<bls12_377_fr>(k, curve, data, log_n, inverse, coset_host); break;
+  }
+}
+
+// ---- h polynomial (ark-circom/src/circom/qap.rs:64-91) ------------------------------------------
+template <class F>
+__global__ void __launch_bounds__(256) mul_sub_kernel(const F* __restrict__ a, const F* __restrict__ b,
+                                                       const F* __restrict__ c, F* __restrict__ out, size_t n) {
+  size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    out[i] = a[i] * b[i] - c[i];
+}
+
+template <class F>
+static void h_poly_typed(Call& k, int curve, const void* a, const void* b, const void* c, unsigned log_m,
+                         void* out) {
+  size_t bytes = sizeof(F) << log_m;
+  F* v[3] = {(F*)ws(k.c, 12, bytes), (F*)ws(k.c, 13, bytes), (F*)ws(k.c, 14, bytes)};
+  F* tmp = (F*)ws(k.c, 8, bytes);
+  const void* in[3] = {a, b, c};
+  // shift tables: powers of w_{2m} (the forward 2m-domain root), applied on the iNTT's store
+  const TwiddleSet& t2 = get_twiddles<F>(k, curve, log_m + 1, 0);
+  // lo/hi of the 2m domain cover exponents < 2m; we only need o < m
+  k.begin_dominant();
+  for (int i = 0; i < 3; i++) {
+    DG_HIP(hipMemcpyAsync(v[i], in[i], bytes, hipMemcpyDeviceToDevice, k.s()));
+    ntt_run<F>(k, curve, v[i], tmp, log_m, 1, nullptr, nullptr, (const F*)t2.lo, (const F*)t2.hi, t2.lb);
+    ntt_run<F>(k, curve, v[i], tmp, log_m, 0, nullptr, nullptr, nullptr, nullptr, 0);
+  }
+  size_t n = (size_t)1 << log_m;
+  size_t blocks = (n + 255) / 256;
+  size_t cap = (size_t)k.ctx->compute_units * 8;
+  if (blocks > cap) blocks = cap;
+  hipLaunchKernelGGL(mul_sub_kernel<F>, dim3((unsigned)blocks), dim3(256), 0, k.s(), v[0], v[1], v[2], (F*)out, n);
+  DG_HIP(hipGetLastError());
+  k.end_dominant();
+}
+
+void h_poly_launch(Call& k, int curve, const void* a, const void* b, const void* c, unsigned log_m, void* out) {
+  switch (curve) {
+    case 0: h_poly_typed<bn254_fr>(k, curve, a, b, c, log_m, out); break;
+    case 1: h_poly_typed<bls12_381_fr>(k, curve, a, b, c, log_m, out); break;
+    default: h_poly_typed<bls12_377_fr>(k, curve, a, b, c, log_m, out); break;
+  }
+}
+
+}  // namespace dg16

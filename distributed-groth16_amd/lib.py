@@ -1,0 +1,210 @@
+"""ctypes binding of libdg16.so (C ABI: include/dg16.h).  Mirrors the reference-side seams:
+`Context.msm` <- G::msm (dist-primitives/src/dmsm/mod.rs:82), `Context.ntt` <- Radix2 fft/ifft
+(ark-circom/src/circom/qap.rs:64-85), `Context.h_poly` <- witness_map_from_matrices (qap.rs:64-91).
+
+Arrays cross this boundary as numpy uint64 arrays (host) or raw device pointers (ints, e.g.
+`torch.Tensor.data_ptr()`), in the byte layout documented in include/dg16.h.
+"""
+
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CURVES = {"bn254": 0, "bls12_381": 1, "bls12_377": 2}
+FQ_LIMBS64 = {"bn254": 4, "bls12_381": 6, "bls12_377": 6}
+
+F_SCALARS_MONT = 1
+F_DEVICE_PTRS = 2
+F_OUT_AFFINE = 4
+
+STATUS = {1: "LENGTH_MISMATCH", 2: "BAD_CURVE", 3: "BAD_ARG", 4: "OOM", 5: "HIP", 6: "NET",
+          7: "UNSUPPORTED"}
+
+
+class Dg16Error(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("dg16 status %d (%s): %s" % (code, STATUS.get(code, "?"), msg))
+        self.code = code
+
+
+def lib_path():
+    return os.path.join(_HERE, "libdg16.so")
+
+
+_lib = None
+
+
+def load():
+    """Loads libdg16.so; raises (never falls back) if the HIP extension has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise ImportError(
+            "libdg16.so is missing (%s): build it with `python -c 'import __graft_entry__ as g; "
+            "g.build()'` or `make -C distributed-groth16_amd/csrc`.  There is no CPU fallback." % path)
+    L = ctypes.CDLL(path)
+    vp, sz, i, u, u64 = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_uint, ctypes.c_uint64
+    L.dg16_ctx_create.argtypes = [i, ctypes.POINTER(vp)]
+    L.dg16_ctx_destroy.argtypes = [vp]
+    L.dg16_ctx_destroy.restype = None
+    L.dg16_last_error.argtypes = [vp]
+    L.dg16_last_error.restype = ctypes.c_char_p
+    L.dg16_set_stream.argtypes = [vp, i, vp]
+    L.dg16_sync.argtypes = [vp, i]
+    L.dg16_device_info.argtypes = [vp, ctypes.c_char_p, sz, ctypes.POINTER(i)]
+    L.dg16_field_op.argtypes = [vp, i, i, vp, vp, vp, sz, u, i]
+    L.dg16_ntt.argtypes = [vp, i, vp, u, i, vp, u, i]
+    L.dg16_h_poly.argtypes = [vp, i, vp, vp, vp, u, vp, u, i]
+    L.dg16_msm.argtypes = [vp, i, i, vp, vp, sz, sz, u, i, vp]
+    L.dg16_gen_bases.argtypes = [vp, i, i, u64, sz, vp, u, i]
+    L.dg16_to_affine.argtypes = [vp, i, i, vp, vp, sz, u, i]
+    L.dg16_last_kernel_ms.argtypes = [vp, i, i, ctypes.POINTER(ctypes.c_float)]
+    _lib = L
+    return L
+
+
+EXPORTED = ["dg16_ctx_create", "dg16_ctx_destroy", "dg16_last_error", "dg16_set_stream", "dg16_sync",
+            "dg16_device_info", "dg16_field_op", "dg16_ntt", "dg16_h_poly", "dg16_msm",
+            "dg16_gen_bases", "dg16_to_affine", "dg16_last_kernel_ms"]
+
+
+def _ptr(x):
+    """numpy array -> host pointer; int -> raw (device) pointer; None -> NULL."""
+    if x is None:
+        return None
+    if isinstance(x, np.ndarray):
+        return x.ctypes.data_as(ctypes.c_void_p)
+    return ctypes.c_void_p(int(x))
+
+
+class Context:
+    """One per process and GPU (dg16_ctx).  Host-array methods are synchronous; `*_dev` methods take
+    device pointers and are stream-ordered on the channel's stream."""
+
+    def __init__(self, device=0):
+        self.L = load()
+        h = ctypes.c_void_p()
+        rc = self.L.dg16_ctx_create(device, ctypes.byref(h))
+        if rc != 0:
+            raise Dg16Error(rc, "dg16_ctx_create failed (no GPU visible? libdg16 has no CPU path)")
+        self.h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.dg16_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise Dg16Error(rc, self.L.dg16_last_error(self.h).decode())
+
+    # ---- plumbing ------------------------------------------------------------------------------
+    def set_stream(self, channel, stream_ptr):
+        self._chk(self.L.dg16_set_stream(self.h, channel, ctypes.c_void_p(stream_ptr or 0)))
+
+    def sync(self, channel=0):
+        self._chk(self.L.dg16_sync(self.h, channel))
+
+    def device_info(self):
+        buf = ctypes.create_string_buffer(64)
+        cu = ctypes.c_int()
+        self._chk(self.L.dg16_device_info(self.h, buf, 64, ctypes.byref(cu)))
+        return buf.value.decode(), cu.value
+
+    def last_kernel_ms(self, channel=0, which=1):
+        ms = ctypes.c_float()
+        self._chk(self.L.dg16_last_kernel_ms(self.h, channel, which, ctypes.byref(ms)))
+        return ms.value
+
+    # ---- host-array API ---------------------------------------------------------------------------
+    def field_op(self, curve, kind, op, a, b=None, channel=0):
+        from_ops = {"add": 0, "sub": 1, "mul": 2, "sqr": 3, "inv": 4, "to_mont": 5, "from_mont": 6, "neg": 7}
+        a = np.ascontiguousarray(a, dtype=np.uint64)
+        b = None if b is None else np.ascontiguousarray(b, dtype=np.uint64)
+        out = np.empty_like(a)
+        fid = CURVES[curve] + (16 if kind == "fr" else 0)
+        self._chk(self.L.dg16_field_op(self.h, fid, from_ops[op], _ptr(a), _ptr(b), _ptr(out), a.shape[0], 0,
+                                       channel))
+        return out
+
+    def ntt(self, curve, data, inverse=False, coset=None, channel=0):
+        data = np.array(data, dtype=np.uint64, copy=True)
+        n = data.shape[0]
+        log_n = n.bit_length() - 1
+        if n == 0 or (1 << log_n) != n:
+            raise ValueError("NTT size must be a power of two")
+        coset = None if coset is None else np.ascontiguousarray(coset, dtype=np.uint64)
+        self._chk(self.L.dg16_ntt(self.h, CURVES[curve], _ptr(data), log_n, int(inverse), _ptr(coset), 0, channel))
+        return data
+
+    def h_poly(self, curve, a, b, c, channel=0):
+        a, b, c = (np.ascontiguousarray(v, dtype=np.uint64) for v in (a, b, c))
+        m = a.shape[0]
+        log_m = m.bit_length() - 1
+        if (1 << log_m) != m or b.shape != a.shape or c.shape != a.shape:
+            raise ValueError("a, b, c must have equal power-of-two length")
+        out = np.empty_like(a)
+        self._chk(self.L.dg16_h_poly(self.h, CURVES[curve], _ptr(a), _ptr(b), _ptr(c), log_m, _ptr(out), 0,
+                                     channel))
+        return out
+
+    def msm(self, curve, group, bases, scalars, scalars_mont=False, affine=False, channel=0):
+        bases = np.ascontiguousarray(bases, dtype=np.uint64)
+        scalars = np.ascontiguousarray(scalars, dtype=np.uint64)
+        nl = FQ_LIMBS64[curve] * (2 if group == 2 else 1)
+        out = np.zeros((1, nl * (2 if affine else 3)), dtype=np.uint64)
+        flags = (F_SCALARS_MONT if scalars_mont else 0) | (F_OUT_AFFINE if affine else 0)
+        self._chk(self.L.dg16_msm(self.h, CURVES[curve], group, _ptr(bases), _ptr(scalars), bases.shape[0],
+                                  scalars.shape[0], flags, channel, _ptr(out)))
+        return out
+
+    def gen_bases(self, curve, group, seed, n, channel=0):
+        nl = FQ_LIMBS64[curve] * 2 * (2 if group == 2 else 1)
+        out = np.zeros((n, nl), dtype=np.uint64)
+        self._chk(self.L.dg16_gen_bases(self.h, CURVES[curve], group, seed, n, _ptr(out), 0, channel))
+        return out
+
+    def to_affine(self, curve, group, jac, channel=0):
+        jac = np.ascontiguousarray(jac, dtype=np.uint64)
+        nl = FQ_LIMBS64[curve] * (2 if group == 2 else 1)
+        jac = jac.reshape(-1, 3 * nl)
+        out = np.zeros((jac.shape[0], 2 * nl), dtype=np.uint64)
+        self._chk(self.L.dg16_to_affine(self.h, CURVES[curve], group, _ptr(jac), _ptr(out), jac.shape[0], 0,
+                                        channel))
+        return out
+
+    # ---- device-pointer API (stream-ordered) ----------------------------------------------------------
+    def msm_dev(self, curve, group, bases_ptr, scalars_ptr, n, out_ptr, scalars_mont=False, affine=False,
+                channel=0, n_scalars=None):
+        flags = F_DEVICE_PTRS | (F_SCALARS_MONT if scalars_mont else 0) | (F_OUT_AFFINE if affine else 0)
+        self._chk(self.L.dg16_msm(self.h, CURVES[curve], group, _ptr(bases_ptr), _ptr(scalars_ptr), n,
+                                  n if n_scalars is None else n_scalars, flags, channel, _ptr(out_ptr)))
+
+    def ntt_dev(self, curve, data_ptr, log_n, inverse=False, coset=None, channel=0):
+        coset = None if coset is None else np.ascontiguousarray(coset, dtype=np.uint64)
+        self._chk(self.L.dg16_ntt(self.h, CURVES[curve], _ptr(data_ptr), log_n, int(inverse), _ptr(coset),
+                                  F_DEVICE_PTRS, channel))
+
+    def h_poly_dev(self, curve, a_ptr, b_ptr, c_ptr, log_m, out_ptr, channel=0):
+        self._chk(self.L.dg16_h_poly(self.h, CURVES[curve], _ptr(a_ptr), _ptr(b_ptr), _ptr(c_ptr), log_m,
+                                     _ptr(out_ptr), F_DEVICE_PTRS, channel))
+
+    def gen_bases_dev(self, curve, group, seed, n, out_ptr, channel=0):
+        self._chk(self.L.dg16_gen_bases(self.h, CURVES[curve], group, seed, n, _ptr(out_ptr), F_DEVICE_PTRS,
+                                        channel))
+
+    def field_op_dev(self, curve, kind, op, a_ptr, b_ptr, out_ptr, n, channel=0):
+        fid = CURVES[curve] + (16 if kind == "fr" else 0)
+        self._chk(self.L.dg16_field_op(self.h, fid, op, _ptr(a_ptr), _ptr(b_ptr), _ptr(out_ptr), n,
+                                       F_DEVICE_PTRS, channel))

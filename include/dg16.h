@@ -1,0 +1,126 @@
+/* dg16 -- C ABI of the MI355X (gfx950) Groth16 hot path: MSM, NTT, h-polynomial, prover glue.
+ *
+ * This is the drop-in boundary for zkHubHQ/distributed-groth16.  The reference has no FFI; the
+ * seams a maintainer re-points at this library are Rust call sites (INTEGRATION.md shows the
+ * `extern "C"` block and the feature-gated replacements):
+ *
+ *   dg16_msm            <- `G::msm(bases, scalars)`            dist-primitives/src/dmsm/mod.rs:82
+ *                          (also examples/msm_bench.rs:20, groth16/examples/local_groth_bench.rs:139-147)
+ *   dg16_ntt            <- `EvaluationDomain::{fft,ifft}_in_place` ark-circom/src/circom/qap.rs:64-85
+ *                          and the butterfly loops fft1/fft2_in_place  dist-primitives/src/dfft/mod.rs:98-182
+ *   dg16_h_poly         <- `CircomReduction::witness_map_from_matrices` (NTT part)
+ *                                                              ark-circom/src/circom/qap.rs:64-91
+ *   dg16_field_op       <- element-wise ark-ff ops (parity probe for the Montgomery kernels)
+ *   dg16_gen_bases      <- `PackedProvingKeyShare::rand`       groth16/src/proving_key.rs:112-155
+ *
+ * Conventions
+ *   - Field elements: little-endian limbs, 32 bytes (Fr of all curves, BN254 Fq) or 48 bytes
+ *     (BLS12-381 / BLS12-377 Fq), Montgomery form with R = 2^256 / 2^384 -- the arkworks in-memory
+ *     representation (pinned by ark-circom/src/zkey.rs:417-427).
+ *   - G1 affine point: x || y (64 / 96 bytes).  G2 affine: x.c0 || x.c1 || y.c0 || y.c1 (128 / 192
+ *     bytes).  Identity = all-zero bytes (ark-circom/src/zkey.rs:353-361).  No `infinity` flag
+ *     byte: the Rust shim repacks `Affine<P>`.
+ *   - Results of group operations are Jacobian (x, y, z) in Montgomery form (== ark-ec
+ *     `Projective` for short-Weierstrass curves); z = 0 encodes the identity.
+ *   - Scalars: 32 bytes each, canonical integers unless DG16_F_SCALARS_MONT is set.
+ *   - Pointers are host pointers unless DG16_F_DEVICE_PTRS is set (then ALL data pointers of the
+ *     call, inputs and outputs, are device pointers on the context's GPU).
+ *   - `channel` (0..2) mirrors `MultiplexedStreamID::{Zero,One,Two}` (mpc-net/src/lib.rs:29-33):
+ *     each channel owns a HIP stream and a workspace; calls on different channels may run
+ *     concurrently from different host threads, calls on one channel are serialised.
+ *   - Every function returns a dg16_status; nothing throws or aborts across this boundary.  The
+ *     Rust side maps non-zero to `MpcNetError::Generic` (mpc-net/src/lib.rs:15-27).
+ *   - The library owns device memory; the caller owns every buffer it passes and may free it on
+ *     return (host-pointer calls are synchronous; device-pointer calls are stream-ordered on the
+ *     channel's stream -- use dg16_sync or the stream you installed with dg16_set_stream).
+ */
+#ifndef DG16_H
+#define DG16_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct dg16_ctx dg16_ctx;
+
+enum dg16_curve { DG16_BN254 = 0, DG16_BLS12_381 = 1, DG16_BLS12_377 = 2 };
+
+enum dg16_status {
+  DG16_OK = 0,
+  DG16_ERR_LENGTH_MISMATCH = 1, /* mirrors Err(usize) of VariableBaseMSM::msm */
+  DG16_ERR_BAD_CURVE = 2,
+  DG16_ERR_BAD_ARG = 3,
+  DG16_ERR_OOM = 4,
+  DG16_ERR_HIP = 5,
+  DG16_ERR_NET = 6,
+  DG16_ERR_UNSUPPORTED = 7
+};
+
+enum dg16_flags {
+  DG16_F_SCALARS_MONT = 1u, /* scalars are in Montgomery form (arkworks memory) */
+  DG16_F_DEVICE_PTRS = 2u,  /* all data pointers are device pointers */
+  DG16_F_OUT_AFFINE = 4u    /* group result as affine x || y (one inversion on the device) */
+};
+
+/* field ids for dg16_field_op: curve for the base field Fq, 16 + curve for the scalar field Fr */
+enum dg16_field_opcode {
+  DG16_OP_ADD = 0, DG16_OP_SUB = 1, DG16_OP_MUL = 2, DG16_OP_SQR = 3, DG16_OP_INV = 4,
+  DG16_OP_TO_MONT = 5, DG16_OP_FROM_MONT = 6, DG16_OP_NEG = 7
+};
+
+/* ---- context ------------------------------------------------------------------------------- */
+int dg16_ctx_create(int device, dg16_ctx **out);
+void dg16_ctx_destroy(dg16_ctx *ctx);
+const char *dg16_last_error(dg16_ctx *ctx);
+/* Run `channel` on a caller-owned hipStream_t (e.g. torch's current stream). NULL restores the
+ * context's own stream. */
+int dg16_set_stream(dg16_ctx *ctx, int channel, void *hip_stream);
+int dg16_sync(dg16_ctx *ctx, int channel);
+/* Device name, CU count (for reports). */
+int dg16_device_info(dg16_ctx *ctx, char *name, size_t name_len, int *compute_units);
+
+/* ---- element-wise field arithmetic (parity probe) -------------------------------------------- */
+int dg16_field_op(dg16_ctx *ctx, int field_id, int op, const void *a, const void *b, void *out,
+                  size_t n, unsigned flags, int channel);
+
+/* ---- NTT ---------------------------------------------------------------------------------------
+ * In-place Radix2EvaluationDomain transform of 2^log_n Montgomery-form Fr elements, natural order
+ * in and out.  inverse != 0 scales by n^-1.  coset_offset: NULL, or a HOST pointer to the domain
+ * offset g (Montgomery form): forward multiplies coefficient i by g^i first, inverse multiplies
+ * output i by g^-i. */
+int dg16_ntt(dg16_ctx *ctx, int curve, void *data, unsigned log_n, int inverse,
+             const void *coset_offset, unsigned flags, int channel);
+
+/* h = NTT(shift(iNTT a)) * NTT(shift(iNTT b)) - NTT(shift(iNTT c)) on the size-2^log_m domain,
+ * shift = multiply coefficient i by w_{2m}^i.  a, b, c are not modified; out may alias a. */
+int dg16_h_poly(dg16_ctx *ctx, int curve, const void *a, const void *b, const void *c,
+                unsigned log_m, void *out, unsigned flags, int channel);
+
+/* ---- MSM ----------------------------------------------------------------------------------------
+ * out = sum_i scalars[i] * bases[i] in G1 (group = 1) or G2 (group = 2).
+ * n_bases != n_scalars returns DG16_ERR_LENGTH_MISMATCH.  out: Jacobian (3 field elements of the
+ * group's coordinate field) or affine with DG16_F_OUT_AFFINE. */
+int dg16_msm(dg16_ctx *ctx, int curve, int group, const void *bases, const void *scalars,
+             size_t n_bases, size_t n_scalars, unsigned flags, int channel, void *out);
+
+/* Synthetic bases P_i = (k0 + i*k1) * G (distinct, prime-order subgroup), written as affine points
+ * to `out` (device or host per flags). */
+int dg16_gen_bases(dg16_ctx *ctx, int curve, int group, uint64_t seed, size_t n, void *out,
+                   unsigned flags, int channel);
+
+/* Jacobian -> affine for n points (n inversions on the device, one thread each). */
+int dg16_to_affine(dg16_ctx *ctx, int curve, int group, const void *jac, void *out, size_t n,
+                   unsigned flags, int channel);
+
+/* Duration in milliseconds of the dominant kernel(s) of the most recent call on `channel`
+ * (HIP events recorded on the channel's stream); 0 if none.  which: 0 = whole call,
+ * 1 = bucket accumulation (MSM) / butterfly passes (NTT). */
+int dg16_last_kernel_ms(dg16_ctx *ctx, int channel, int which, float *ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DG16_H */

@@ -1,0 +1,78 @@
+// Test-only: instantiates the product's field / curve headers (distributed-groth16_amd/csrc/fp.h,
+// fp2.h, ec.h) with the HOST compiler so the formulas can be checked against the oracle without a
+// GPU (-m "not gpu").  The portable C++ multiply path runs here; the gfx950 asm path is checked on
+// the GPU by tests/test_gpu_field.py.  Never part of the product.
+#include <stdint.h>
+#include <string.h>
+#include "../../distributed-groth16_amd/csrc/consts_gen.h"
+#include "../../distributed-groth16_amd/csrc/ec.h"
+
+using namespace dg16;
+
+template <class F> static void field_op(int op, const F* a, const F* b, F* o, size_t n) {
+  for (size_t i = 0; i < n; i++) {
+    switch (op) {
+      case 0: o[i] = a[i] + b[i]; break;
+      case 1: o[i] = a[i] - b[i]; break;
+      case 2: o[i] = a[i] * b[i]; break;
+      case 3: o[i] = a[i].sqr(); break;
+      case 4: o[i] = a[i].inv(); break;
+      case 5: o[i] = a[i].to_mont(); break;
+      case 6: o[i] = a[i].from_mont(); break;
+      case 7: o[i] = a[i].neg(); break;
+    }
+  }
+}
+
+// op: 0 = xyzz(a).add(xyzz(b)) via general add, 1 = madd(a, b), 2 = madd(a, -b), 3 = dbl(a),
+//     4 = scalar_mul(a, k[8 words] in b's first 32 bytes); result -> affine
+template <class F> static void point_op(int op, const Affine<F>* a, const Affine<F>* b, Affine<F>* o, size_t n) {
+  for (size_t i = 0; i < n; i++) {
+    XYZZ<F> A = XYZZ<F>::from_affine(a[i]);
+    XYZZ<F> r;
+    switch (op) {
+      case 0: {
+        // go through a non-trivial ZZ by doubling-and-subtracting first so add-2008-s sees z != 1
+        XYZZ<F> B = XYZZ<F>::from_affine(b[i]);
+        XYZZ<F> A3 = A.dbl().add(A);          // 3a
+        XYZZ<F> B3 = B.dbl().add(B);          // 3b
+        r = A3.add(B3).add(A.dbl().neg()).add(B.dbl().neg());  // 3a + 3b - 2a - 2b
+        break;
+      }
+      case 1: r = A.dbl().madd(b[i], false).add(A.neg()); break;     // 2a + b - a
+      case 2: r = A.madd(b[i], true); break;
+      case 3: r = A.dbl(); break;
+      default: r = scalar_mul<F, 8>(A, (const uint32_t*)&b[i]); break;
+    }
+    Jacobian<F> j = r.to_jacobian();
+    o[i] = XYZZ<F>::from_jacobian(j).to_affine();
+  }
+}
+
+using bn_fq = Fp<bn254_fq_params>;      using bn_fr = Fp<bn254_fr_params>;
+using b381_fq = Fp<bls12_381_fq_params>; using b381_fr = Fp<bls12_381_fr_params>;
+using b377_fq = Fp<bls12_377_fq_params>; using b377_fr = Fp<bls12_377_fr_params>;
+
+extern "C" int ha_field_op(int fid, int op, const void* a, const void* b, void* o, size_t n) {
+  switch (fid) {
+    case 0: field_op<bn_fq>(op, (const bn_fq*)a, (const bn_fq*)b, (bn_fq*)o, n); break;
+    case 1: field_op<b381_fq>(op, (const b381_fq*)a, (const b381_fq*)b, (b381_fq*)o, n); break;
+    case 2: field_op<b377_fq>(op, (const b377_fq*)a, (const b377_fq*)b, (b377_fq*)o, n); break;
+    case 16: field_op<bn_fr>(op, (const bn_fr*)a, (const bn_fr*)b, (bn_fr*)o, n); break;
+    case 17: field_op<b381_fr>(op, (const b381_fr*)a, (const b381_fr*)b, (b381_fr*)o, n); break;
+    case 18: field_op<b377_fr>(op, (const b377_fr*)a, (const b377_fr*)b, (b377_fr*)o, n); break;
+    default: return 1;
+  }
+  return 0;
+}
+extern "C" int ha_point_op(int curve, int group, int op, const void* a, const void* b, void* o, size_t n) {
+  switch (curve * 2 + group - 1) {
+    case 0: point_op<bn_fq>(op, (const Affine<bn_fq>*)a, (const Affine<bn_fq>*)b, (Affine<bn_fq>*)o, n); break;
+    case 1: point_op<Fp2<bn_fq>>(op, (const Affine<Fp2<bn_fq>>*)a, (const Affine<Fp2<bn_fq>>*)b, (Affine<Fp2<bn_fq>>*)o, n); break;
+    case 2: point_op<b381_fq>(op, (const Affine<b381_fq>*)a, (const Affine<b381_fq>*)b, (Affine<b381_fq>*)o, n); break;
+    case 3: point_op<Fp2<b381_fq>>(op, (const Affine<Fp2<b381_fq>>*)a, (const Affine<Fp2<b381_fq>>*)b, (Affine<Fp2<b381_fq>>*)o, n); break;
+    case 4: point_op<b377_fq>(op, (const Affine<b377_fq>*)a, (const Affine<b377_fq>*)b, (Affine<b377_fq>*)o, n); break;
+    default: return 1;
+  }
+  return 0;
+}

@@ -1,0 +1,101 @@
+"""GPU parity: MSM through the C ABI vs the oracle, compared in affine form (bit-exact)."""
+
+import numpy as np
+import pytest
+
+from oracle import corc
+from oracle.pyref.fields import FR
+from gpu_util import ctx
+
+pytestmark = pytest.mark.gpu
+
+GROUPS = [("bn254", 1), ("bn254", 2), ("bls12_381", 1), ("bls12_381", 2), ("bls12_377", 1)]
+
+
+def check(curve, group, bases, scalars, **kw):
+    jac = ctx().msm(curve, group, bases, scalars, **kw)
+    got = corc.jac_to_affine(curve, group, jac)
+    exp = corc.msm(curve, group, bases, scalars, scalars_mont=kw.get("scalars_mont", False))
+    assert np.array_equal(got, exp)
+    return got
+
+
+@pytest.mark.parametrize("curve,group", GROUPS)
+@pytest.mark.parametrize("n", [1, 7, 100, 1 << 10, 1 << 13])
+def test_msm_matches_oracle(curve, group, n):
+    if (curve, group) != ("bn254", 1) and n in (7, 1 << 13):
+        pytest.skip("full sweep on bn254 G1 only")
+    bases = corc.gen_points(curve, group, 2 + n, n)
+    scalars = corc.rand_field(curve, "fr", 9 + n, n, mont=False)
+    check(curve, group, bases, scalars)
+
+
+def test_msm_edge_cases():
+    curve, group = "bn254", 1
+    r = FR[curve].p
+    n = 600
+    bases = corc.gen_points(curve, group, 4, n)
+    scalars = corc.rand_field(curve, "fr", 5, n, mont=False)
+    sc = corc.arr_to_ints(scalars)
+    sc[0], sc[1], sc[2], sc[3] = 0, 1, r - 1, r - 2
+    bases[10] = 0                 # identity point
+    bases[11] = 0
+    bases[21] = bases[20]         # duplicates with equal scalars (bucket doubling)
+    sc[21] = sc[20]
+    bases[31] = bases[30]
+    sc[31] = r - sc[30]           # P and -P
+    scalars = corc.ints_to_arr(sc, 4)
+    check(curve, group, bases, scalars)
+    # Montgomery-form scalars (arkworks memory)
+    check(curve, group, bases, corc.field_op(curve, "fr", "to_mont", scalars), scalars_mont=True)
+    # all scalars zero -> identity; all-identity bases -> identity
+    z = np.zeros_like(scalars)
+    assert not corc.jac_to_affine(curve, group, ctx().msm(curve, group, bases, z)).any()
+    assert not corc.jac_to_affine(curve, group, ctx().msm(curve, group, np.zeros_like(bases), scalars)).any()
+
+
+def test_msm_reference_degenerate_shape():
+    # dist-primitives/src/dmsm/mod.rs:155-159: M copies of one point, scalars all 1 (BLS12-377)
+    curve, group = "bls12_377", 1
+    M = 256
+    g = corc.generator(curve, group)
+    bases = np.repeat(g, M, axis=0)
+    scalars = corc.ints_to_arr([1] * M, 4)
+    got = check(curve, group, bases, scalars)
+    assert np.array_equal(got, corc.point_mul(curve, group, g, M))
+
+
+def test_msm_length_mismatch_and_affine_out():
+    import dg16_amd
+    curve, group = "bn254", 1
+    bases = corc.gen_points(curve, group, 1, 8)
+    scalars = corc.rand_field(curve, "fr", 1, 8, mont=False)
+    with pytest.raises(dg16_amd.Dg16Error) as e:
+        ctx().msm(curve, group, bases, scalars[:7])
+    assert e.value.code == 1       # DG16_ERR_LENGTH_MISMATCH, like Err(usize) from G::msm
+    aff = ctx().msm(curve, group, bases, scalars, affine=True)
+    assert np.array_equal(aff, corc.msm(curve, group, bases, scalars))
+    # empty MSM is the identity
+    e0 = ctx().msm(curve, group, bases[:0], scalars[:0])
+    assert not corc.jac_to_affine(curve, group, e0).any()
+
+
+def test_msm_2_16_config1():
+    # BASELINE configs[0]: BN254 G1, 2^16 points
+    curve, group, n = "bn254", 1, 1 << 16
+    bases = corc.gen_points(curve, group, 1, n)
+    scalars = corc.rand_field(curve, "fr", 1, n, mont=False)
+    check(curve, group, bases, scalars)
+
+
+def test_msm_2_20_config2_and_linearity():
+    # BASELINE configs[1]: BN254 G1, 2^20 points; oracle Pippenger needs a few seconds on all cores
+    curve, group, n = "bn254", 1, 1 << 20
+    bases = ctx().gen_bases(curve, group, 2, n)
+    scalars = corc.rand_field(curve, "fr", 2, n, mont=False)
+    full = check(curve, group, bases, scalars)
+    # size-independent property: MSM(first half) + MSM(second half) == MSM(all)
+    h = n // 2
+    a = corc.jac_to_affine(curve, group, ctx().msm(curve, group, bases[:h], scalars[:h]))
+    b = corc.jac_to_affine(curve, group, ctx().msm(curve, group, bases[h:], scalars[h:]))
+    assert np.array_equal(corc.point_add(curve, group, a, b), full)

@@ -1,0 +1,102 @@
+"""The product's field / curve headers (distributed-groth16_amd/csrc/{fp,fp2,ec}.h) instantiated with
+the host compiler and compared with the oracle -- catches formula bugs without a GPU.  The gfx950
+asm multiply is checked on the GPU (tests/test_gpu_field.py)."""
+
+import ctypes
+import os
+import random
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import corc
+from oracle.pyref.fields import FQ, FR
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "host_arith", "host_arith.cpp")
+SO = os.path.join(HERE, "host_arith", "libhost_arith.so")
+
+
+@pytest.fixture(scope="module")
+def ha():
+    hdrs = [os.path.join(HERE, "..", "distributed-groth16_amd", "csrc", f)
+            for f in ("fp.h", "fp2.h", "ec.h", "consts_gen.h")]
+    if not os.path.exists(SO) or any(os.path.getmtime(SO) < os.path.getmtime(p) for p in [SRC] + hdrs):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", SO, SRC])
+    L = ctypes.CDLL(SO)
+    vp, sz, i = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int
+    L.ha_field_op.argtypes = [i, i, vp, vp, vp, sz]
+    L.ha_point_op.argtypes = [i, i, i, vp, vp, vp, sz]
+    return L
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+@pytest.mark.parametrize("curve", ["bn254", "bls12_381", "bls12_377"])
+@pytest.mark.parametrize("kind", ["fq", "fr"])
+def test_field_ops(ha, curve, kind):
+    F = (FQ if kind == "fq" else FR)[curve]
+    nl = F.limbs64
+    n = 200
+    A = corc.rand_field(curve, kind, 1, n)
+    B = corc.rand_field(curve, kind, 2, n)
+    edge = corc.ints_to_arr([0, F.R, F.p - 1, 1, F.to_mont(F.p - 1)], nl)
+    A[:5] = edge
+    B[:5] = edge[::-1]
+    for op in ("add", "sub", "mul", "sqr", "neg", "from_mont", "inv"):
+        a = A if op != "inv" else A[:12]
+        b = B if op != "inv" else B[:12]
+        out = np.empty_like(a)
+        assert ha.ha_field_op(corc.fid(curve, kind), corc.OPS[op], _p(a), _p(b), _p(out), len(a)) == 0
+        exp = corc.field_op(curve, kind, op, a, b)
+        assert np.array_equal(out, exp), op
+    canon = corc.field_op(curve, kind, "from_mont", A)
+    out = np.empty_like(A)
+    ha.ha_field_op(corc.fid(curve, kind), corc.OPS["to_mont"], _p(canon), _p(canon), _p(out), n)
+    assert np.array_equal(out, A)
+
+
+@pytest.mark.parametrize("curve,group", [("bn254", 1), ("bn254", 2), ("bls12_381", 1),
+                                         ("bls12_381", 2), ("bls12_377", 1)])
+def test_point_ops(ha, curve, group):
+    cid = corc.CURVES[curve]
+    rng = random.Random(3)
+    r = FR[curve].p
+    n = 24
+    P = corc.gen_points(curve, group, 5, n)
+    Q = corc.gen_points(curve, group, 6, n)
+    Q[0] = P[0]            # doubling through the add path
+    Q[1] = 0               # identity operand
+    P[2] = 0
+    P[3] = 0; Q[3] = 0
+
+    def oracle_pairwise(f):
+        return np.concatenate([f(P[i:i + 1], Q[i:i + 1]) for i in range(n)])
+
+    out = np.empty_like(P)
+    # general add and mixed add must both equal P + Q
+    exp = oracle_pairwise(lambda a, b: corc.point_add(curve, group, a, b))
+    for op in (0, 1):
+        assert ha.ha_point_op(cid, group, op, _p(P), _p(Q), _p(out), n) == 0
+        assert np.array_equal(out, exp), op
+    # madd with negation: P - Q (index 0 gives the identity)
+    negQ = np.concatenate([corc.point_mul(curve, group, Q[i:i + 1], r - 1) for i in range(n)])
+    exp = np.concatenate([corc.point_add(curve, group, P[i:i + 1], negQ[i:i + 1]) for i in range(n)])
+    assert ha.ha_point_op(cid, group, 2, _p(P), _p(Q), _p(out), n) == 0
+    assert np.array_equal(out, exp)
+    assert not out[0].any()
+    # doubling
+    exp = np.concatenate([corc.point_add(curve, group, P[i:i + 1], P[i:i + 1]) for i in range(n)])
+    assert ha.ha_point_op(cid, group, 3, _p(P), _p(Q), _p(out), n) == 0
+    assert np.array_equal(out, exp)
+    # scalar multiplication by 256-bit integers (first 32 bytes of each Q slot hold k)
+    K = Q.copy()
+    ks = [rng.randrange(r) for _ in range(n)]
+    ks[4], ks[5] = 0, 1
+    K[:, :4] = corc.ints_to_arr(ks, 4)
+    exp = np.concatenate([corc.point_mul(curve, group, P[i:i + 1], ks[i]) for i in range(n)])
+    assert ha.ha_point_op(cid, group, 4, _p(P), _p(K), _p(out), n) == 0
+    assert np.array_equal(out, exp)
