@@ -48,7 +48,9 @@ struct XYZZ {
   DG_HD XYZZ neg() const { return {x, y.neg(), zz, zzz}; }
 
   // 2 * (affine p), p != identity                                   (mdbl-2008-s-1, a = 0)
-  static DG_COLD XYZZ dbl_affine(const F& px, const F& py) {
+  // (forceinline: a call here makes hipcc keep the loaded point in scratch memory -- the G2 bucket
+  // kernel then spent 7x its arithmetic time on scratch round trips at one wave per SIMD)
+  static DG_HD XYZZ dbl_affine(const F& px, const F& py) {
     F u = py.dbl();
     F v = u.sqr();
     F w = u * v;
@@ -93,7 +95,9 @@ struct XYZZ {
     return {x3, y3, zz * pp, zzz * ppp};
   }
   // this + o                                                           (add-2008-s)
-  DG_HD XYZZ add(const XYZZ& o) const {
+  // noinline: only the bucket-reduction / tail kernels use it, and inlining 14 multiplications at
+  // every call site multiplies compile time and code size for nothing
+  DG_COLD XYZZ add(const XYZZ& o) const {
     if (o.is_inf()) return *this;
     if (is_inf()) return o;
     F u1 = x * o.zz;

@@ -1,36 +1,32 @@
-// Curve dispatch for the group-valued entry points (per-curve instantiations live in msm_<curve>.hip
-// so they compile in parallel).
+// Curve / group dispatch for the group-valued entry points (one translation unit per (curve, group)
+// so the heavy template instantiations compile in parallel).
 #include "ctx.h"
 
 namespace dg16 {
-#define DECL(name)                                                                                          \
-  void msm_##name(Call&, int, const void*, const void*, size_t, bool, bool, void*);                         \
-  void gen_bases_##name(Call&, int, uint64_t, size_t, void*);                                               \
-  void to_affine_##name(Call&, int, const void*, void*, size_t);
-DECL(bn254)
-DECL(bls12_381)
-DECL(bls12_377)
+#define DECL(name)                                                                              \
+  void msm_##name(Call&, const void*, const void*, size_t, bool, bool, void*);                  \
+  void gen_bases_##name(Call&, uint64_t, size_t, void*);                                        \
+  void to_affine_##name(Call&, const void*, void*, size_t);
+DECL(bn254_g1) DECL(bn254_g2) DECL(bls12_381_g1) DECL(bls12_381_g2) DECL(bls12_377_g1)
+
+#define DISPATCH(fn, ...)                                                                       \
+  switch (curve * 2 + group - 1) {                                                              \
+    case 0: fn##_bn254_g1(__VA_ARGS__); break;                                                  \
+    case 1: fn##_bn254_g2(__VA_ARGS__); break;                                                  \
+    case 2: fn##_bls12_381_g1(__VA_ARGS__); break;                                              \
+    case 3: fn##_bls12_381_g2(__VA_ARGS__); break;                                              \
+    case 4: fn##_bls12_377_g1(__VA_ARGS__); break;                                              \
+    default: throw StatusError{DG16_ERR_UNSUPPORTED, "BLS12-377 G2 is not on the reference's path"}; \
+  }
 
 void msm_launch(Call& k, int curve, int group, const void* bases, const void* scalars, size_t n, bool mont,
                 bool affine, void* out) {
-  switch (curve) {
-    case 0: msm_bn254(k, group, bases, scalars, n, mont, affine, out); break;
-    case 1: msm_bls12_381(k, group, bases, scalars, n, mont, affine, out); break;
-    default: msm_bls12_377(k, group, bases, scalars, n, mont, affine, out); break;
-  }
+  DISPATCH(msm, k, bases, scalars, n, mont, affine, out)
 }
 void gen_bases_launch(Call& k, int curve, int group, uint64_t seed, size_t n, void* out) {
-  switch (curve) {
-    case 0: gen_bases_bn254(k, group, seed, n, out); break;
-    case 1: gen_bases_bls12_381(k, group, seed, n, out); break;
-    default: gen_bases_bls12_377(k, group, seed, n, out); break;
-  }
+  DISPATCH(gen_bases, k, seed, n, out)
 }
 void to_affine_launch(Call& k, int curve, int group, const void* jac, void* out, size_t n) {
-  switch (curve) {
-    case 0: to_affine_bn254(k, group, jac, out, n); break;
-    case 1: to_affine_bls12_381(k, group, jac, out, n); break;
-    default: to_affine_bls12_377(k, group, jac, out, n); break;
-  }
+  DISPATCH(to_affine, k, jac, out, n)
 }
 }  // namespace dg16

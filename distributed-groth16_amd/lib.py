@@ -63,13 +63,18 @@ def load():
     L.dg16_gen_bases.argtypes = [vp, i, i, u64, sz, vp, u, i]
     L.dg16_to_affine.argtypes = [vp, i, i, vp, vp, sz, u, i]
     L.dg16_last_kernel_ms.argtypes = [vp, i, i, ctypes.POINTER(ctypes.c_float)]
+    L.dg16_pk_create.argtypes = [vp, i, sz, sz, sz, vp, vp, vp, vp, vp, vp, u, ctypes.POINTER(vp)]
+    L.dg16_pk_destroy.argtypes = [vp]
+    L.dg16_pk_destroy.restype = None
+    L.dg16_groth16_prove.argtypes = [vp, vp, vp, vp, vp, vp, vp, u, vp]
     _lib = L
     return L
 
 
 EXPORTED = ["dg16_ctx_create", "dg16_ctx_destroy", "dg16_last_error", "dg16_set_stream", "dg16_sync",
             "dg16_device_info", "dg16_field_op", "dg16_ntt", "dg16_h_poly", "dg16_msm",
-            "dg16_gen_bases", "dg16_to_affine", "dg16_last_kernel_ms"]
+            "dg16_gen_bases", "dg16_to_affine", "dg16_last_kernel_ms", "dg16_pk_create", "dg16_pk_destroy",
+            "dg16_groth16_prove"]
 
 
 def _ptr(x):
@@ -79,6 +84,25 @@ def _ptr(x):
     if isinstance(x, np.ndarray):
         return x.ctypes.data_as(ctypes.c_void_p)
     return ctypes.c_void_p(int(x))
+
+
+class ProvingKey:
+    """Resident Groth16 proving key (dg16_pk)."""
+
+    def __init__(self, ctx, handle, curve, num_vars, num_inputs, domain_size):
+        self.ctx, self.h, self.curve = ctx, handle, curve
+        self.num_vars, self.num_inputs, self.domain_size = num_vars, num_inputs, domain_size
+
+    def close(self):
+        if self.h and self.ctx.h:
+            self.ctx.L.dg16_pk_destroy(self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class Context:
@@ -183,6 +207,37 @@ class Context:
         self._chk(self.L.dg16_to_affine(self.h, CURVES[curve], group, _ptr(jac), _ptr(out), jac.shape[0], 0,
                                         channel))
         return out
+
+    # ---- Groth16 prover ---------------------------------------------------------------------------------
+    def pk_create(self, curve, num_vars, num_inputs, domain_size, a_query, b_g1_query, b_g2_query, h_query,
+                  l_query, fixed_points, device_ptrs=False):
+        """Makes an arkworks-shaped ProvingKey resident (see include/dg16.h).  Arguments are numpy
+        arrays (host) or raw device pointers (device_ptrs=True)."""
+        h = ctypes.c_void_p()
+        args = [a_query, b_g1_query, b_g2_query, h_query, l_query, fixed_points]
+        if not device_ptrs:
+            args = [np.ascontiguousarray(x, dtype=np.uint64) for x in args]
+        self._chk(self.L.dg16_pk_create(self.h, CURVES[curve], num_vars, num_inputs, domain_size,
+                                        *[_ptr(x) for x in args], F_DEVICE_PTRS if device_ptrs else 0,
+                                        ctypes.byref(h)))
+        return ProvingKey(self, h, curve, num_vars, num_inputs, domain_size)
+
+    def prove(self, pk, a, b, c, full_assignment, r, s, scalars_mont=True):
+        """Host arrays in, (A, B, C) Jacobian arrays out."""
+        a, b, c, w = (np.ascontiguousarray(v, dtype=np.uint64) for v in (a, b, c, full_assignment))
+        rs = np.ascontiguousarray(np.concatenate([np.asarray(r, dtype=np.uint64).reshape(1, 4),
+                                                  np.asarray(s, dtype=np.uint64).reshape(1, 4)]))
+        nl = FQ_LIMBS64[pk.curve]
+        out = np.zeros(3 * nl + 6 * nl + 3 * nl, dtype=np.uint64)
+        self._chk(self.L.dg16_groth16_prove(self.h, pk.h, _ptr(a), _ptr(b), _ptr(c), _ptr(w), _ptr(rs),
+                                            F_SCALARS_MONT if scalars_mont else 0, _ptr(out)))
+        return out[:3 * nl].reshape(1, -1), out[3 * nl:9 * nl].reshape(1, -1), out[9 * nl:].reshape(1, -1)
+
+    def prove_dev(self, pk, a_ptr, b_ptr, c_ptr, w_ptr, rs_host, out_ptr, scalars_mont=True):
+        rs_host = np.ascontiguousarray(rs_host, dtype=np.uint64)
+        self._chk(self.L.dg16_groth16_prove(self.h, pk.h, _ptr(a_ptr), _ptr(b_ptr), _ptr(c_ptr), _ptr(w_ptr),
+                                            _ptr(rs_host), F_DEVICE_PTRS | (F_SCALARS_MONT if scalars_mont else 0),
+                                            _ptr(out_ptr)))
 
     # ---- device-pointer API (stream-ordered) ----------------------------------------------------------
     def msm_dev(self, curve, group, bases_ptr, scalars_ptr, n, out_ptr, scalars_mont=False, affine=False,

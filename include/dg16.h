@@ -12,6 +12,8 @@
  *                                                              ark-circom/src/circom/qap.rs:64-91
  *   dg16_field_op       <- element-wise ark-ff ops (parity probe for the Montgomery kernels)
  *   dg16_gen_bases      <- `PackedProvingKeyShare::rand`       groth16/src/proving_key.rs:112-155
+ *   dg16_groth16_prove  <- `create_proof_with_reduction_and_matrices`  groth16/examples/sha256.rs:159
+ *                          and the A/B/C assembly of groth16/src/prove.rs:21-136
  *
  * Conventions
  *   - Field elements: little-endian limbs, 32 bytes (Fr of all curves, BN254 Fq) or 48 bytes
@@ -114,6 +116,31 @@ int dg16_gen_bases(dg16_ctx *ctx, int curve, int group, uint64_t seed, size_t n,
 /* Jacobian -> affine for n points (n inversions on the device, one thread each). */
 int dg16_to_affine(dg16_ctx *ctx, int curve, int group, const void *jac, void *out, size_t n,
                    unsigned flags, int channel);
+
+/* ---- Groth16 prover (single prover; the value the n-party run must equal) ------------------------
+ * Replaces `Groth16::<E, CircomReduction>::create_proof_with_reduction_and_matrices` (third-party
+ * fork; call sites groth16/examples/sha256.rs:159, mpc-api/src/main.rs:393) from the point where
+ * the QAP evaluation vectors exist (groth16/src/qap.rs:44-91 produces a, b, c).
+ *
+ * dg16_pk_create makes the proving key resident in HBM.  Queries are the arkworks `ProvingKey`
+ * vectors, element 0 included: a_query, b_g1_query, b_g2_query have num_vars entries, l_query has
+ * num_vars - num_inputs, h_query has domain_size entries (CircomReduction::h_query_scalars,
+ * ark-circom/src/circom/qap.rs:94-110).  fixed_points = alpha_g1 | beta_g1 | delta_g1 (G1 affine)
+ * | beta_g2 | delta_g2 (G2 affine), contiguous.  The base-vector mapping follows
+ * groth16/src/proving_key.rs:48-65.  flags: DG16_F_DEVICE_PTRS if every pointer is a device pointer. */
+typedef struct dg16_pk dg16_pk;
+int dg16_pk_create(dg16_ctx *ctx, int curve, size_t num_vars, size_t num_inputs, size_t domain_size,
+                   const void *a_query, const void *b_g1_query, const void *b_g2_query,
+                   const void *h_query, const void *l_query, const void *fixed_points, unsigned flags,
+                   dg16_pk **out);
+void dg16_pk_destroy(dg16_pk *pk);
+
+/* a, b, c: QAP evaluation vectors (domain_size Montgomery Fr elements each); full_assignment:
+ * num_vars Fr elements [1, public.., witness..] (Montgomery iff DG16_F_SCALARS_MONT); r_s: HOST
+ * pointer to r || s (2 x 32 bytes, same form as the assignment).  proof_out: A (G1 Jacobian) |
+ * B (G2 Jacobian) | C (G1 Jacobian).  Uses all three channels. */
+int dg16_groth16_prove(dg16_ctx *ctx, const dg16_pk *pk, const void *a, const void *b, const void *c,
+                       const void *full_assignment, const void *r_s, unsigned flags, void *proof_out);
 
 /* Duration in milliseconds of the dominant kernel(s) of the most recent call on `channel`
  * (HIP events recorded on the channel's stream); 0 if none.  which: 0 = whole call,

@@ -66,11 +66,48 @@ __device__ __forceinline__ void mont_mul_B(uint32_t* r, const uint32_t* a, const
   final_sub(r, t, (uint32_t)acc);
 }
 
+
+// Variant C: column-parallel CIOS with lazy carries.  NL+1 live columns, each a 64-bit accumulator
+// plus a 32-bit overflow counter; the 8 MADCs of a row hit 8 different columns (ILP 8), so a single
+// wave is not bound by the mad->addc->mad dependency chain of variant B.
+__device__ __forceinline__ void mont_mul_C(uint32_t* r, const uint32_t* a, const uint32_t* b) {
+  uint64_t acc[NL + 1]; uint32_t cc[NL + 1];
+#pragma unroll
+  for (int j = 0; j <= NL; j++) { acc[j] = 0; cc[j] = 0; }
+#pragma unroll
+  for (int i = 0; i < NL; i++) {
+#pragma unroll
+    for (int j = 0; j < NL; j++) MADC(acc[j], cc[j], a[j], b[i]);
+    uint32_t m = (uint32_t)acc[0] * INV;
+#pragma unroll
+    for (int j = 0; j < NL; j++) MADC_S(acc[j], cc[j], m, Pk[j]);
+    // column 0 now has zero low word: fold its upper part into column 1 and shift the window
+    uint64_t up = (acc[0] >> 32) | ((uint64_t)cc[0] << 32);
+    uint64_t s1 = acc[1] + up;
+    cc[1] += (s1 < up) ? 1u : 0u;
+    acc[1] = s1;
+#pragma unroll
+    for (int j = 0; j < NL; j++) { acc[j] = acc[j + 1]; cc[j] = cc[j + 1]; }
+    acc[NL] = 0; cc[NL] = 0;
+  }
+  // resolve: value = sum_j (acc[j] + cc[j]*2^64) * 2^(32 j)
+  uint32_t t[NL]; uint64_t carry = 0; uint32_t top = 0;
+#pragma unroll
+  for (int j = 0; j < NL; j++) {
+    uint64_t lo = (acc[j] & 0xffffffffu) + (carry & 0xffffffffu);
+    t[j] = (uint32_t)lo;
+    // next carry = (acc[j] >> 32) + (cc[j] << 32) + (carry >> 32) + (lo >> 32)
+    carry = (acc[j] >> 32) + ((uint64_t)cc[j] << 32) + (carry >> 32) + (lo >> 32);
+  }
+  top = (uint32_t)carry;
+  final_sub(r, t, top);
+}
+
 template <int V> __global__ void chain(uint32_t* out, const uint32_t* in, int iters) {
   int tid = blockIdx.x * blockDim.x + threadIdx.x;
   uint32_t a[NL], b[NL];
   for (int i = 0; i < NL; i++) { a[i] = in[tid * 16 + i]; b[i] = in[tid * 16 + 8 + i]; }
-  for (int it = 0; it < iters; it++) { if (V == 0) mont_mul_A(a, a, b); else mont_mul_B(a, a, b); }
+  for (int it = 0; it < iters; it++) { if (V == 0) mont_mul_A(a, a, b); else if (V == 1) mont_mul_B(a, a, b); else mont_mul_C(a, a, b); }
   for (int i = 0; i < NL; i++) out[tid * 8 + i] = a[i];
 }
 // 4 independent chains per lane (ILP)
@@ -80,7 +117,7 @@ template <int V> __global__ void chain4(uint32_t* out, const uint32_t* in, int i
   for (int i = 0; i < NL; i++) { b[i] = in[tid * 16 + 8 + i]; for (int c = 0; c < 4; c++) a[c][i] = in[tid * 16 + i] ^ (c * 77); a[0][7] &= 0x0fffffff; a[1][7] &= 0x0fffffff; a[2][7] &= 0x0fffffff; a[3][7] &= 0x0fffffff; }
   for (int it = 0; it < iters; it++) {
 #pragma unroll
-    for (int c = 0; c < 4; c++) { if (V == 0) mont_mul_A(a[c], a[c], b); else mont_mul_B(a[c], a[c], b); }
+    for (int c = 0; c < 4; c++) { if (V == 0) mont_mul_A(a[c], a[c], b); else if (V == 1) mont_mul_B(a[c], a[c], b); else mont_mul_C(a[c], a[c], b); }
   }
   for (int i = 0; i < NL; i++) out[tid * 8 + i] = a[0][i] ^ a[1][i] ^ a[2][i] ^ a[3][i];
 }
@@ -101,6 +138,11 @@ int main() {
   CHECK(hipMemcpy(h_a.data(), d_out, (size_t)n * 32, hipMemcpyDeviceToHost));
   hipLaunchKernelGGL(chain<1>, dim3(blocks), dim3(threads), 0, 0, d_out, d_in, 5);
   CHECK(hipMemcpy(h_b.data(), d_out, (size_t)n * 32, hipMemcpyDeviceToHost));
+  std::vector<uint32_t> h_c((size_t)n * 8);
+  hipLaunchKernelGGL(chain<2>, dim3(blocks), dim3(threads), 0, 0, d_out, d_in, 5);
+  CHECK(hipMemcpy(h_c.data(), d_out, (size_t)n * 32, hipMemcpyDeviceToHost));
+  size_t badC = 0; for (size_t i = 0; i < h_c.size(); i++) if (h_c[i] != h_a[i]) badC++;
+  printf("correctness: C_dev vs A_dev mismatches %zu\n", badC);
   size_t badAB = 0, badH = 0;
   for (int t = 0; t < n; t++) {
     uint32_t a[8], b[8];
@@ -109,8 +151,9 @@ int main() {
     for (int i = 0; i < 8; i++) { if (h_a[(size_t)t * 8 + i] != h_b[(size_t)t * 8 + i]) badAB++; if (h_a[(size_t)t * 8 + i] != a[i]) badH++; }
   }
   printf("correctness: A_dev vs B_dev mismatches %zu ; A_dev vs A_host mismatches %zu (of %d words)\n", badAB, badH, n * 8);
-  auto timeit = [&](const char* name, void (*k)(uint32_t*, const uint32_t*, int), int mulsPerIter) {
+  auto timeit = [&](const char* name, void (*k)(uint32_t*, const uint32_t*, int), int mulsPerIter, int blocks_per_cu = 8) {
     const int iters = 2000;
+    const int blocks = cus * blocks_per_cu; const int n = blocks * threads;
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
     hipLaunchKernelGGL(k, dim3(blocks), dim3(threads), 0, 0, d_out, d_in, 10);
     CHECK(hipDeviceSynchronize());
@@ -119,11 +162,14 @@ int main() {
     CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
     float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
     double muls = (double)n * iters * mulsPerIter;
-    printf("%-28s %8.3f ms  %8.2f G montmul/s\n", name, ms, muls / (ms * 1e-3) * 1e-9);
+    printf("%-28s waves/SIMD %d  %8.3f ms  %8.2f G montmul/s\n", name, blocks_per_cu, ms, muls / (ms * 1e-3) * 1e-9);
   };
   timeit("A (C++ CIOS) chain", chain<0>, 1);
   timeit("B (asm product-scan) chain", chain<1>, 1);
   timeit("A x4 ILP", chain4<0>, 4);
   timeit("B x4 ILP", chain4<1>, 4);
+  timeit("C (column-parallel) chain", chain<2>, 1);
+  timeit("C x4 ILP", chain4<2>, 4);
+  for (int w : {1, 2, 3, 4}) { timeit("B chain", chain<1>, 1, w); timeit("C chain", chain<2>, 1, w); timeit("A chain", chain<0>, 1, w); }
   return 0;
 }
