@@ -1,0 +1,276 @@
+#!/usr/bin/env python3
+"""bench.py -- Groth16 proving throughput on MI355X (BASELINE.json metric: constraints/sec, BN254,
+2^20-constraint synthetic R1CS, at 1/2/4/8 GPUs).
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A step = one complete Groth16 proof (h-polynomial: 3 iNTT + 3 NTT of size 2^20 + pointwise; five
+MSMs: A, B1, L, H in G1 and B in G2; A/B/C assembly) with every input already resident in HBM.
+N > 1 is STRONG scaling of one proof: each rank owns a contiguous 1/N slice of every MSM's bases and
+scalars, the h-polynomial is replicated, and one RCCL all-gather of N x 480 B partial results precedes
+the assembly (distributed-groth16_amd/parallel.py).
+
+One JSON line is printed by rank 0.  `roofline` describes the dominant kernel (the G2 bucket
+accumulation): achieved = algorithmic bytes (160 B/point) / its HIP-event duration
+measured here on the stream it runs on -- against the 8 TB/s HBM roof this is small BY CONSTRUCTION:
+the kernel does ~28 x 10 Montgomery multiplications per 160 bytes and is integer-VALU-bound, so the
+honest second roof (`valu_roofline`: Montgomery multiplications per second against the measured
+chip rate of tools/ubench/montmul_rate) is printed next to it.  `cpu_baseline` times the oracle
+("port": arkworks-structured CPU restatement, NOT arkworks) on a bounded sample of the same workload
+on this box's host cores and doubles as a live parity check of the GPU proof.
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CURVE = "bn254"
+BN254_R_TOP = 0x30644E72E131A029   # top 64-bit limb of the BN254 scalar modulus
+MONTMUL_PEAK_G = 105.0             # G montmul/s, BN254 Fq, measured chip rate (gpurun_out/montmul_rate_r1b.txt)
+HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md
+
+
+def rand_fr(n, dev, gen):
+    """Uniform canonical scalars in [0, r_top * 2^192) (statistically uniform mod r for histograms)."""
+    lo = torch.randint(-2**63, 2**63 - 1, (n, 3), dtype=torch.int64, device=dev, generator=gen)
+    hi = torch.randint(0, BN254_R_TOP, (n, 1), dtype=torch.int64, device=dev, generator=gen)
+    return torch.cat([lo, hi], dim=1).contiguous()
+
+
+class Workload:
+    """Synthetic proving key (like PackedProvingKeyShare::rand, groth16/src/proving_key.rs:112-155) and
+    a synthetic satisfied-shape QAP instance of `log_m`: num_constraints = 2^log_m - 2, 2 instance
+    variables, 2^log_m wires."""
+
+    def __init__(self, ctx, dev, log_m, rank, world, seed=20):
+        import dg16_amd  # noqa: F401
+        self.ctx, self.dev = ctx, dev
+        self.m = 1 << log_m
+        self.log_m = log_m
+        self.ni = 2
+        self.nv = self.m
+        self.nc = self.m - self.ni
+        m, nv, ni = self.m, self.nv, self.ni
+
+        def bases(group, cnt, s):
+            t = torch.empty(cnt * 64 * group, dtype=torch.uint8, device=dev)
+            ctx.gen_bases_dev(CURVE, group, seed * 100 + s, cnt, t.data_ptr())
+            return t
+
+        self.aq, self.b1q, self.b2q = bases(1, nv, 1), bases(1, nv, 2), bases(2, nv, 3)
+        self.hq, self.lq = bases(1, m, 4), bases(1, nv - ni, 5)
+        self.fixed = torch.cat([bases(1, 3, 6), bases(2, 2, 7)])
+        ctx.sync(0)
+        self.pk = ctx.pk_create(CURVE, nv, ni, m, self.aq.data_ptr(), self.b1q.data_ptr(), self.b2q.data_ptr(),
+                                self.hq.data_ptr(), self.lq.data_ptr(), self.fixed.data_ptr(), device_ptrs=True,
+                                shard=rank, n_shards=world)
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(seed)
+        # QAP evaluation vectors in Montgomery form: a, b random on the constraint rows, c = a o b
+        # (what a satisfied R1CS gives, groth16/src/qap.rs:60-80), zero padding above.
+        self.a = rand_fr(m, dev, gen)
+        self.b = rand_fr(m, dev, gen)
+        self.a[self.nc + ni:] = 0
+        self.b[self.nc:] = 0
+        self.c = torch.zeros_like(self.a)
+        ctx.field_op_dev(CURVE, "fr", 2, self.a.data_ptr(), self.b.data_ptr(), self.c.data_ptr(), m)
+        ctx.sync(0)
+        self.c[self.nc:] = 0
+        self.w = rand_fr(nv, dev, gen)            # full assignment, canonical integers
+        self.rs = np.array([[3, 1, 4, 1], [5, 9, 2, 6]], dtype=np.uint64)   # r, s (canonical, nonzero)
+        torch.cuda.synchronize()
+
+
+def to_host_u64(t, cols):
+    return t.view(torch.uint8).cpu().numpy().view(np.uint64).reshape(-1, cols)
+
+
+def cpu_baseline_and_parity(ctx, dev, log_s):
+    """Oracle ("port") prove on a 2^log_s sample + comparison with the GPU proof of the same sample."""
+    from oracle import corc
+    wl = Workload(ctx, dev, log_s, 0, 1, seed=7)
+    m, nv, ni = wl.m, wl.nv, wl.ni
+    proof = torch.empty(96 * 2 + 192, dtype=torch.uint8, device=dev)
+    ctx.prove_dev(wl.pk, wl.a.data_ptr(), wl.b.data_ptr(), wl.c.data_ptr(), wl.w.data_ptr(), wl.rs, proof.data_ptr(),
+                  scalars_mont=False)
+    for ch in range(3):
+        ctx.sync(ch)
+    gp = proof.cpu().numpy().view(np.uint64)
+    gA = corc.jac_to_affine(CURVE, 1, gp[:12])
+    gB = corc.jac_to_affine(CURVE, 2, gp[12:36])
+    gC = corc.jac_to_affine(CURVE, 1, gp[36:48])
+    # host copies of the same inputs
+    aq, b1q, b2q = to_host_u64(wl.aq, 8), to_host_u64(wl.b1q, 8), to_host_u64(wl.b2q, 16)
+    hq, lq = to_host_u64(wl.hq, 8), to_host_u64(wl.lq, 8)
+    f1 = to_host_u64(wl.fixed[:192], 8)
+    f2 = to_host_u64(wl.fixed[192:], 16)
+    alpha, beta1, delta1 = f1[0:1], f1[1:2], f1[2:3]
+    beta2, delta2 = f2[0:1], f2[1:2]
+    a, b, c, w = (to_host_u64(t, 4) for t in (wl.a, wl.b, wl.c, wl.w))
+    r = int(sum(int(x) << (64 * i) for i, x in enumerate(wl.rs[0])))
+    s = int(sum(int(x) << (64 * i) for i, x in enumerate(wl.rs[1])))
+    threads = os.cpu_count() or 1
+    t0 = time.perf_counter()
+    h = corc.h_poly(CURVE, a, b, c, threads=threads)
+    h_canon = corc.field_op(CURVE, "fr", "from_mont", h)
+    msm = lambda g, bases, sc: corc.msm(CURVE, g, bases, sc, threads=threads)
+    mA = msm(1, aq[1:], w[1:])
+    mB1 = msm(1, b1q[1:], w[1:])
+    mB2 = msm(2, b2q[1:], w[1:])
+    mL = msm(1, lq, w[ni:])
+    mH = msm(1, hq, h_canon)
+    t_cpu = time.perf_counter() - t0
+    add = lambda g, p, q: corc.point_add(CURVE, g, p, q)
+    mul = lambda g, p, k: corc.point_mul(CURVE, g, p, k)
+    A = add(1, add(1, mA, aq[0:1]), add(1, alpha, mul(1, delta1, r)))
+    B1 = add(1, add(1, mB1, b1q[0:1]), add(1, beta1, mul(1, delta1, s)))
+    B = add(2, add(2, mB2, b2q[0:1]), add(2, beta2, mul(2, delta2, s)))
+    R = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+    C = add(1, add(1, mL, mH), add(1, add(1, mul(1, A, s), mul(1, B1, r)), mul(1, delta1, (R - r * s % R) % R)))
+    ok = bool(np.array_equal(A, gA) and np.array_equal(B, gB) and np.array_equal(C, gC))
+    wl.pk.close()
+    return {"value": (m - ni) / t_cpu, "unit": "constraints/s", "cores": threads, "kind": "port",
+            "sample": "one proof of a 2^%d-constraint instance of the same synthetic workload (h-poly + 5 MSMs; "
+                      "C oracle, OpenMP, Pippenger parallel over <=%d windows like arkworks): %.2f s"
+                      % (log_s, 19, t_cpu)}, ok
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--log-m", type=int, default=20)
+    ap.add_argument("--cpu-sample-log", type=int, default=16)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: libdg16 has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    import dg16_amd
+    from dg16_amd.parallel import DistributedProver, GpuEngine
+
+    ctx = dg16_amd.Context(local_rank)
+    wl = Workload(ctx, dev, args.log_m, rank, world)
+    prover = DistributedProver(GpuEngine(ctx, wl.pk, CURVE), dist, rank, world)
+
+    def step():
+        return prover.prove(wl.a, wl.b, wl.c, wl.w, wl.rs, scalars_mont=False)
+
+    def full_sync():
+        for ch in range(3):
+            ctx.sync(ch)
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    full_sync()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    full_sync()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    ms_per_step = elapsed / args.steps * 1e3
+    value = wl.nc * args.steps / elapsed
+
+    # ---- dominant kernel, measured live with HIP events on its own stream ----
+    n_g2 = wl.nv - 1
+    out = torch.empty(192, dtype=torch.uint8, device=dev)
+    acc_ms = []
+    for _ in range(3):
+        ctx.msm_dev(CURVE, 2, wl.b2q.data_ptr() + 128, wl.w.data_ptr() + 32, n_g2, out.data_ptr(), channel=2)
+        ctx.sync(2)
+        acc_ms.append(ctx.last_kernel_ms(2, 1))
+    g2_acc_ms = sum(acc_ms[1:]) / len(acc_ms[1:])
+    g1_ms = []
+    out1 = torch.empty(96, dtype=torch.uint8, device=dev)
+    for _ in range(3):
+        ctx.msm_dev(CURVE, 1, wl.aq.data_ptr() + 64, wl.w.data_ptr() + 32, n_g2, out1.data_ptr(), channel=1)
+        ctx.sync(1)
+        g1_ms.append((ctx.last_kernel_ms(1, 1), ctx.last_kernel_ms(1, 0)))
+    alg_bytes = 160.0 * n_g2
+    achieved = alg_bytes / (g2_acc_ms * 1e-3) / 1e9
+    # bucket additions of that launch: one mixed add (8M + 2S in Fq2 = 28 Fq multiplications) per nonzero digit
+    lg = n_g2.bit_length() - 1                      # msm_geometry() of csrc/msm_impl.h
+    cbits = min(max(lg - 4, 4), 16)
+    nwin = (254 + 1 + cbits - 1) // cbits
+    montmuls = 28.0 * n_g2 * nwin
+    valu_g = montmuls / (g2_acc_ms * 1e-3) / 1e9
+
+    res = {
+        "metric": "groth16_constraints_per_sec",
+        "value": value,
+        "unit": "constraints/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "u32",
+        "data": "synthetic",
+        "config": {"workload": "BN254 Groth16 prove, synthetic R1CS with 2^%d - 2 constraints, 2^%d wires, "
+                               "2 instance variables; r, s != 0 (4 G1 MSMs + 1 G2 MSM + 6 NTTs of 2^%d)"
+                               % (args.log_m, args.log_m, args.log_m),
+                   "curve": CURVE, "log_domain": args.log_m, "parallelism": "msm-shard x%d + all-gather" % world},
+        "roofline": {"bound": "hbm", "kernel": "msm_accumulate_kernel<Fp2<bn254_fq>> (G2 bucket accumulation)",
+                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": None, "kernel_ms": g2_acc_ms,
+                     "note": "160 B/point algorithmic; kernel is integer-VALU-bound (see valu_roofline)"},
+        "valu_roofline": {"unit": "G montmul/s", "achieved": valu_g, "peak": MONTMUL_PEAK_G,
+                          "frac": valu_g / MONTMUL_PEAK_G,
+                          "note": "28 Fq multiplications per G2 mixed add x n x %d windows / kernel time; peak = " % nwin +
+                                  "measured chip rate of the same multiply (tools/ubench/montmul_rate)"},
+        "msm_pts_per_s": {"g1_2^%d" % args.log_m: n_g2 / (g1_ms[-1][1] * 1e-3),
+                          "g1_accumulate_ms": g1_ms[-1][0], "g1_call_ms": g1_ms[-1][1]},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cb, ok = cpu_baseline_and_parity(ctx, dev, args.cpu_sample_log)
+        res["cpu_baseline"] = cb
+        res["parity_check"] = "pass" if ok else "FAIL"
+        if not ok:
+            print(json.dumps(res))
+            raise SystemExit("GPU proof differs from the oracle proof on the sample")
+    if rank == 0:
+        print(json.dumps(res))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -25,12 +25,14 @@ namespace dg16 {
 struct PkDev {
   int curve = 0;
   size_t num_vars = 0, num_inputs = 0, m = 0;
+  unsigned shard = 0, nshards = 1;   // this key holds slice `shard` of every MSM range (multi-GPU)
+  size_t ab_lo = 0, ab_hi = 0, l_lo = 0, l_hi = 0, h_lo = 0, h_hi = 0;
   // all device pointers
-  void* a_q = nullptr;    // a_query[1..] ++ delta_g1           (num_vars points, G1)
-  void* b1_q = nullptr;   // b_g1_query[1..] ++ delta_g1        (num_vars, G1)
-  void* b2_q = nullptr;   // b_g2_query[1..] ++ delta_g2        (num_vars, G2)
-  void* l_q = nullptr;    // l_query ++ delta_g1                (num_vars - num_inputs + 1, G1)
-  void* h_q = nullptr;    // h_query                            (m, G1)
+  void* a_q = nullptr;    // a_query[1..][ab_lo..ab_hi) ++ delta_g1        (G1)
+  void* b1_q = nullptr;   // b_g1_query[1..][ab_lo..ab_hi) ++ delta_g1     (G1)
+  void* b2_q = nullptr;   // b_g2_query[1..][ab_lo..ab_hi) ++ delta_g2     (G2)
+  void* l_q = nullptr;    // l_query[l_lo..l_hi) ++ delta_g1               (G1)
+  void* h_q = nullptr;    // h_query[h_lo..h_hi)                           (G1)
   void* fixed = nullptr;  // alpha_g1, a_query[0], beta_g1, b_g1_query[0] (G1 affine) | beta_g2, b_g2_query[0] (G2 affine)
 };
 
@@ -46,9 +48,11 @@ namespace dg16 {
 // scalars[n_w] = extra (the r / s / -rs slot that pairs with the appended delta base)
 template <class Fr>
 __global__ void prover_scalar_prep_kernel(const Fr* r_s, Fr* sc_a, Fr* sc_b1, Fr* sc_b2, Fr* sc_l, size_t n_ab,
-                                          size_t n_l, int mont) {
-  // r_s[0] = r, r_s[1] = s in the same form as the witness (Montgomery iff mont)
+                                          size_t n_l, int mont, int carries_delta) {
+  // r_s[0] = r, r_s[1] = s in the same form as the witness (Montgomery iff mont).  Only the last
+  // shard carries the delta pairs; the others multiply their delta slot by zero.
   Fr r = r_s[0], s = r_s[1];
+  if (!carries_delta) { r = Fr::zero(); s = Fr::zero(); }
   Fr rm = mont ? r : r.to_mont(), sm = mont ? s : s.to_mont();
   Fr nrs = (rm * sm).neg();                 // Montgomery form of -(r*s)
   sc_a[n_ab] = r;
@@ -96,98 +100,149 @@ __global__ void prover_stage2_kernel(const Jacobian<Fq>* msm_l, const Jacobian<F
   *out_c = c.to_jacobian();
 }
 
+// partial results of one shard: A, B1, L, H (G1 Jacobian) then B (G2 Jacobian)
 template <int CURVE>
-static void prove_typed(dg16_ctx* ctx, const PkDev& pk, const void* a, const void* b, const void* c,
-                        const void* witness, const void* r_s_host, bool mont, bool dev_ptrs, void* proof_out) {
+static size_t msm_results_bytes() {
+  using CT = CurveTypes<CURVE>;
+  return 4 * sizeof(Jacobian<typename CT::Fq>) + sizeof(Jacobian<typename CT::Fq2>);
+}
+
+// h-polynomial + the five MSMs of this key's shard.  res_out (device or host per dev_ptrs) receives
+// msm_results_bytes() bytes.  Uses all three channels; returns with the results stream-ordered on
+// channel 0.
+template <int CURVE>
+static void msms_typed(dg16_ctx* ctx, Call& k0, Call& k1, Call& k2, const PkDev& pk, const void* a, const void* b,
+                       const void* c, const void* witness, const void* r_s_host, bool mont, bool dev_ptrs,
+                       uint8_t* res_dev) {
   using CT = CurveTypes<CURVE>;
   using Fq = typename CT::Fq;
   using Fq2 = typename CT::Fq2;
   using Fr = typename CT::Fr;
   const size_t nv = pk.num_vars, ni = pk.num_inputs, m = pk.m;
-  const size_t n_ab = nv - 1;          // w[1..]
-  const size_t n_l = nv - ni;          // w[ni..]
+  const size_t n_ab = pk.ab_hi - pk.ab_lo;   // this shard's slice of w[1..]
+  const size_t n_l = pk.l_hi - pk.l_lo;      // ... of w[ni..]
+  const size_t n_h = pk.h_hi - pk.h_lo;      // ... of h
   unsigned log_m = 0;
   while (((size_t)1 << log_m) < m) log_m++;
+  const size_t g1j = sizeof(Jacobian<Fq>);
 
-  Call k0(ctx, 0), k1(ctx, 1), k2(ctx, 2);
-  const size_t g1j = sizeof(Jacobian<Fq>), g2j = sizeof(Jacobian<Fq2>);
-
-  // ---- stage operands on channel 0 ----
   const Fr* w_dev = (const Fr*)stage_in(k0, 18, witness, nv * sizeof(Fr), dev_ptrs);
   const void* a_dev = stage_in(k0, 19, a, m * sizeof(Fr), dev_ptrs);
   const void* b_dev = stage_in(k0, 20, b, m * sizeof(Fr), dev_ptrs);
   const void* c_dev = stage_in(k0, 21, c, m * sizeof(Fr), dev_ptrs);
-  uint8_t* small = (uint8_t*)ws(k0.c, 22, 4096);
-  Fr* r_s = (Fr*)small;                                        // 2 elements
-  Jacobian<Fq>* res_a = (Jacobian<Fq>*)(small + 64);
+  Fr* r_s = (Fr*)ws(k0.c, 22, 4096);
+  Jacobian<Fq>* res_a = (Jacobian<Fq>*)res_dev;
   Jacobian<Fq>* res_b1 = res_a + 1;
   Jacobian<Fq>* res_l = res_a + 2;
   Jacobian<Fq>* res_h = res_a + 3;
-  Jacobian<Fq2>* res_b2 = (Jacobian<Fq2>*)(small + 64 + 4 * g1j);
-  XYZZ<Fq>* s_a = (XYZZ<Fq>*)(small + 64 + 4 * g1j + g2j);
-  XYZZ<Fq>* r_b1 = s_a + 1;
-  uint8_t* proof_dev = small + 64 + 4 * g1j + g2j + 2 * sizeof(XYZZ<Fq>);   // A | B | C
+  Jacobian<Fq2>* res_b2 = (Jacobian<Fq2>*)(res_dev + 4 * g1j);
   DG_HIP(hipMemcpyAsync(r_s, r_s_host, 2 * sizeof(Fr), hipMemcpyHostToDevice, k0.s()));
   // scalar vectors with the extra slot (one per MSM that carries a delta pair)
-  Fr* sc_a = (Fr*)ws(k0.c, 23, (n_ab + 1) * sizeof(Fr) * 3 + (n_l + 1) * sizeof(Fr));
+  Fr* sc_a = (Fr*)ws(k0.c, 23, ((n_ab + 1) * 3 + (n_l + 1)) * sizeof(Fr));
   Fr* sc_b1 = sc_a + (n_ab + 1);
   Fr* sc_b2 = sc_b1 + (n_ab + 1);
   Fr* sc_l = sc_b2 + (n_ab + 1);
-  DG_HIP(hipMemcpyAsync(sc_a, w_dev + 1, n_ab * sizeof(Fr), hipMemcpyDeviceToDevice, k0.s()));
-  DG_HIP(hipMemcpyAsync(sc_b1, w_dev + 1, n_ab * sizeof(Fr), hipMemcpyDeviceToDevice, k0.s()));
-  DG_HIP(hipMemcpyAsync(sc_b2, w_dev + 1, n_ab * sizeof(Fr), hipMemcpyDeviceToDevice, k0.s()));
-  DG_HIP(hipMemcpyAsync(sc_l, w_dev + ni, n_l * sizeof(Fr), hipMemcpyDeviceToDevice, k0.s()));
+  DG_HIP(hipMemcpyAsync(sc_a, w_dev + 1 + pk.ab_lo, n_ab * sizeof(Fr), hipMemcpyDeviceToDevice, k0.s()));
+  DG_HIP(hipMemcpyAsync(sc_b1, w_dev + 1 + pk.ab_lo, n_ab * sizeof(Fr), hipMemcpyDeviceToDevice, k0.s()));
+  DG_HIP(hipMemcpyAsync(sc_b2, w_dev + 1 + pk.ab_lo, n_ab * sizeof(Fr), hipMemcpyDeviceToDevice, k0.s()));
+  DG_HIP(hipMemcpyAsync(sc_l, w_dev + ni + pk.l_lo, n_l * sizeof(Fr), hipMemcpyDeviceToDevice, k0.s()));
   hipLaunchKernelGGL(prover_scalar_prep_kernel<Fr>, dim3(1), dim3(1), 0, k0.s(), r_s, sc_a, sc_b1, sc_b2, sc_l,
-                     n_ab, n_l, (int)mont);
+                     n_ab, n_l, (int)mont, (int)(pk.shard + 1 == pk.nshards));
   DG_HIP(hipGetLastError());
-  hipEvent_t ready;
+  hipEvent_t ready, e1, e2;
   DG_HIP(hipEventCreateWithFlags(&ready, hipEventDisableTiming));
+  DG_HIP(hipEventCreateWithFlags(&e1, hipEventDisableTiming));
+  DG_HIP(hipEventCreateWithFlags(&e2, hipEventDisableTiming));
   DG_HIP(hipEventRecord(ready, k0.s()));
   DG_HIP(hipStreamWaitEvent(k1.s(), ready, 0));
   DG_HIP(hipStreamWaitEvent(k2.s(), ready, 0));
 
-  // ---- channel 1: A, B1, then the serial stage-1 kernel ----
-  // ---- channel 2: B (G2), L ----
-  // ---- channel 0: h-poly, H ----
+  // channel 0: h-poly, H | channel 1: A, B1 | channel 2: B (G2), L
   Fr* h_dev = (Fr*)ws(k0.c, 3, m * sizeof(Fr));
-  k0.begin_dominant();
   h_poly_launch(k0, CURVE, a_dev, b_dev, c_dev, log_m, h_dev);
   msm_launch(k1, CURVE, 1, pk.a_q, sc_a, n_ab + 1, mont, false, res_a);
   msm_launch(k2, CURVE, 2, pk.b2_q, sc_b2, n_ab + 1, mont, false, res_b2);
   msm_launch(k1, CURVE, 1, pk.b1_q, sc_b1, n_ab + 1, mont, false, res_b1);
-  msm_launch(k0, CURVE, 1, pk.h_q, h_dev, m, true, false, res_h);
+  msm_launch(k0, CURVE, 1, pk.h_q, h_dev + pk.h_lo, n_h, true, false, res_h);
   msm_launch(k2, CURVE, 1, pk.l_q, sc_l, n_l + 1, mont, false, res_l);
+  DG_HIP(hipEventRecord(e1, k1.s()));
+  DG_HIP(hipEventRecord(e2, k2.s()));
+  DG_HIP(hipStreamWaitEvent(k0.s(), e1, 0));
+  DG_HIP(hipStreamWaitEvent(k0.s(), e2, 0));
+  DG_HIP(hipEventDestroy(ready));
+  DG_HIP(hipEventDestroy(e1));
+  DG_HIP(hipEventDestroy(e2));
+}
 
-  hipEvent_t e_b2, e_l, e_s1;
-  DG_HIP(hipEventCreateWithFlags(&e_b2, hipEventDisableTiming));
-  DG_HIP(hipEventCreateWithFlags(&e_l, hipEventDisableTiming));
-  DG_HIP(hipEventCreateWithFlags(&e_s1, hipEventDisableTiming));
-  // stage 1 needs B (channel 2, first MSM there): record right after it would be ideal; the event
-  // after L is conservative but keeps one event per stream
-  DG_HIP(hipEventRecord(e_l, k2.s()));
-  DG_HIP(hipStreamWaitEvent(k1.s(), e_l, 0));
+// proof = assemble(sum of the shards' MSM results).  res_dev: msm_results_bytes() on the device.
+template <int CURVE>
+static void assemble_typed(Call& k0, const PkDev& pk, const uint8_t* res_dev, const void* r_s_host, bool mont,
+                           uint8_t* proof_dev) {
+  using CT = CurveTypes<CURVE>;
+  using Fq = typename CT::Fq;
+  using Fq2 = typename CT::Fq2;
+  using Fr = typename CT::Fr;
+  const size_t g1j = sizeof(Jacobian<Fq>), g2j = sizeof(Jacobian<Fq2>);
+  uint8_t* small = (uint8_t*)ws(k0.c, 22, 4096);
+  Fr* r_s = (Fr*)small;
+  XYZZ<Fq>* s_a = (XYZZ<Fq>*)(small + 64);
+  XYZZ<Fq>* r_b1 = s_a + 1;
+  DG_HIP(hipMemcpyAsync(r_s, r_s_host, 2 * sizeof(Fr), hipMemcpyHostToDevice, k0.s()));
+  const Jacobian<Fq>* res = (const Jacobian<Fq>*)res_dev;
   const Affine<Fq>* fixed_g1 = (const Affine<Fq>*)pk.fixed;
   const Affine<Fq2>* fixed_g2 = (const Affine<Fq2>*)((const uint8_t*)pk.fixed + 4 * sizeof(Affine<Fq>));
-  hipLaunchKernelGGL((prover_stage1_kernel<Fq, Fq2, Fr>), dim3(1), dim3(192), 0, k1.s(), res_a, res_b1, res_b2,
-                     fixed_g1, fixed_g2, r_s, (int)mont, (Jacobian<Fq>*)proof_dev,
-                     (Jacobian<Fq2>*)(proof_dev + g1j), s_a, r_b1);
-  DG_HIP(hipEventRecord(e_s1, k1.s()));
-  DG_HIP(hipStreamWaitEvent(k0.s(), e_s1, 0));
-  hipLaunchKernelGGL(prover_stage2_kernel<Fq>, dim3(1), dim3(1), 0, k0.s(), res_l, res_h, s_a, r_b1,
+  hipLaunchKernelGGL((prover_stage1_kernel<Fq, Fq2, Fr>), dim3(1), dim3(192), 0, k0.s(), res, res + 1,
+                     (const Jacobian<Fq2>*)(res_dev + 4 * g1j), fixed_g1, fixed_g2, r_s, (int)mont,
+                     (Jacobian<Fq>*)proof_dev, (Jacobian<Fq2>*)(proof_dev + g1j), s_a, r_b1);
+  hipLaunchKernelGGL(prover_stage2_kernel<Fq>, dim3(1), dim3(1), 0, k0.s(), res + 2, res + 3, s_a, r_b1,
                      (Jacobian<Fq>*)(proof_dev + g1j + g2j));
   DG_HIP(hipGetLastError());
+}
+
+template <int CURVE>
+static void prove_typed(dg16_ctx* ctx, const PkDev& pk, const void* a, const void* b, const void* c,
+                        const void* witness, const void* r_s_host, bool mont, bool dev_ptrs, void* proof_out) {
+  using CT = CurveTypes<CURVE>;
+  const size_t g1j = sizeof(Jacobian<typename CT::Fq>), g2j = sizeof(Jacobian<typename CT::Fq2>);
+  DG_REQUIRE(pk.nshards == 1, DG16_ERR_BAD_ARG, "dg16_groth16_prove needs an unsharded key; use _msms + _assemble");
+  Call k0(ctx, 0), k1(ctx, 1), k2(ctx, 2);
+  uint8_t* buf = (uint8_t*)ws(k0.c, 16, 8192);
+  uint8_t* res_dev = buf;
+  uint8_t* proof_dev = buf + 4096;
+  k0.begin_dominant();
+  msms_typed<CURVE>(ctx, k0, k1, k2, pk, a, b, c, witness, r_s_host, mont, dev_ptrs, res_dev);
+  assemble_typed<CURVE>(k0, pk, res_dev, r_s_host, mont, proof_dev);
   k0.end_dominant();
   stage_out(k0, proof_out, proof_dev, 2 * g1j + g2j, dev_ptrs);
   k0.finish();
   k1.finish();
   k2.finish();
-  (void)e_b2;
   if (!dev_ptrs) DG_HIP(hipStreamSynchronize(k0.s()));
-  // events are cheap but not free: destroy after the work has been enqueued (HIP defers the release)
-  DG_HIP(hipEventDestroy(ready));
-  DG_HIP(hipEventDestroy(e_b2));
-  DG_HIP(hipEventDestroy(e_l));
-  DG_HIP(hipEventDestroy(e_s1));
+}
+
+// out = sum of n Jacobian points (one lane; n is the number of GPUs)
+template <class F>
+__global__ void point_sum_kernel(const Jacobian<F>* in, size_t n, size_t stride_bytes, Jacobian<F>* out) {
+  XYZZ<F> acc = XYZZ<F>::inf();
+  for (size_t i = 0; i < n; i++)
+    acc = acc.add(XYZZ<F>::from_jacobian(*(const Jacobian<F>*)((const uint8_t*)in + i * stride_bytes)));
+  *out = acc.to_jacobian();
+}
+
+// gathered: n_shards records of msm_results_bytes(); out: one record with the per-MSM sums
+template <int CURVE>
+static void reduce_results_typed(Call& k, const uint8_t* gathered, size_t n_shards, uint8_t* out) {
+  using CT = CurveTypes<CURVE>;
+  using Fq = typename CT::Fq;
+  using Fq2 = typename CT::Fq2;
+  const size_t rec = msm_results_bytes<CURVE>(), g1j = sizeof(Jacobian<Fq>);
+  // the 1-lane adds of the five results are independent: one block each
+  for (int i = 0; i < 4; i++)
+    hipLaunchKernelGGL(point_sum_kernel<Fq>, dim3(1), dim3(1), 0, k.s(), (const Jacobian<Fq>*)(gathered + i * g1j),
+                       n_shards, rec, (Jacobian<Fq>*)(out + i * g1j));
+  hipLaunchKernelGGL(point_sum_kernel<Fq2>, dim3(1), dim3(1), 0, k.s(), (const Jacobian<Fq2>*)(gathered + 4 * g1j),
+                     n_shards, rec, (Jacobian<Fq2>*)(out + 4 * g1j));
+  DG_HIP(hipGetLastError());
 }
 
 // a_query etc. are given as full arkworks vectors (element 0 included); delta is appended here
@@ -201,12 +256,20 @@ static void pk_build(dg16_ctx* ctx, PkDev& d, const void* a_query, const void* b
   const size_t p1 = sizeof(Affine<Fq>), p2 = sizeof(Affine<Fq2>);
   const size_t nv = d.num_vars, ni = d.num_inputs, m = d.m;
   hipMemcpyKind kind = dev_ptrs ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+  auto slice = [&](size_t n, size_t& lo, size_t& hi) {
+    lo = n * d.shard / d.nshards;
+    hi = n * (d.shard + 1) / d.nshards;
+  };
+  slice(nv - 1, d.ab_lo, d.ab_hi);
+  slice(nv - ni, d.l_lo, d.l_hi);
+  slice(m, d.h_lo, d.h_hi);
+  const size_t n_ab = d.ab_hi - d.ab_lo, n_l = d.l_hi - d.l_lo, n_h = d.h_hi - d.h_lo;
   DG_HIP(hipSetDevice(ctx->device));
-  DG_HIP(hipMalloc(&d.a_q, nv * p1));
-  DG_HIP(hipMalloc(&d.b1_q, nv * p1));
-  DG_HIP(hipMalloc(&d.b2_q, nv * p2));
-  DG_HIP(hipMalloc(&d.l_q, (nv - ni + 1) * p1));
-  DG_HIP(hipMalloc(&d.h_q, m * p1));
+  DG_HIP(hipMalloc(&d.a_q, (n_ab + 1) * p1));
+  DG_HIP(hipMalloc(&d.b1_q, (n_ab + 1) * p1));
+  DG_HIP(hipMalloc(&d.b2_q, (n_ab + 1) * p2));
+  DG_HIP(hipMalloc(&d.l_q, (n_l + 1) * p1));
+  DG_HIP(hipMalloc(&d.h_q, (n_h ? n_h : 1) * p1));
   DG_HIP(hipMalloc(&d.fixed, 4 * p1 + 2 * p2));
   // fixed_host layout: alpha_g1, beta_g1, delta_g1 (G1 affine) | beta_g2, delta_g2 (G2 affine)
   const uint8_t* fx = (const uint8_t*)fixed_host;
@@ -214,15 +277,15 @@ static void pk_build(dg16_ctx* ctx, PkDev& d, const void* a_query, const void* b
   const uint8_t* b1 = (const uint8_t*)b_g1_query;
   const uint8_t* b2 = (const uint8_t*)b_g2_query;
   uint8_t* fixed = (uint8_t*)d.fixed;
-  DG_HIP(hipMemcpy(d.a_q, aq + p1, (nv - 1) * p1, kind));
-  DG_HIP(hipMemcpy((uint8_t*)d.a_q + (nv - 1) * p1, fx + 2 * p1, p1, kind));            // delta_g1
-  DG_HIP(hipMemcpy(d.b1_q, b1 + p1, (nv - 1) * p1, kind));
-  DG_HIP(hipMemcpy((uint8_t*)d.b1_q + (nv - 1) * p1, fx + 2 * p1, p1, kind));
-  DG_HIP(hipMemcpy(d.b2_q, b2 + p2, (nv - 1) * p2, kind));
-  DG_HIP(hipMemcpy((uint8_t*)d.b2_q + (nv - 1) * p2, fx + 3 * p1 + p2, p2, kind));      // delta_g2
-  DG_HIP(hipMemcpy(d.l_q, l_query, (nv - ni) * p1, kind));
-  DG_HIP(hipMemcpy((uint8_t*)d.l_q + (nv - ni) * p1, fx + 2 * p1, p1, kind));
-  DG_HIP(hipMemcpy(d.h_q, h_query, m * p1, kind));
+  DG_HIP(hipMemcpy(d.a_q, aq + (1 + d.ab_lo) * p1, n_ab * p1, kind));
+  DG_HIP(hipMemcpy((uint8_t*)d.a_q + n_ab * p1, fx + 2 * p1, p1, kind));            // delta_g1
+  DG_HIP(hipMemcpy(d.b1_q, b1 + (1 + d.ab_lo) * p1, n_ab * p1, kind));
+  DG_HIP(hipMemcpy((uint8_t*)d.b1_q + n_ab * p1, fx + 2 * p1, p1, kind));
+  DG_HIP(hipMemcpy(d.b2_q, b2 + (1 + d.ab_lo) * p2, n_ab * p2, kind));
+  DG_HIP(hipMemcpy((uint8_t*)d.b2_q + n_ab * p2, fx + 3 * p1 + p2, p2, kind));      // delta_g2
+  DG_HIP(hipMemcpy(d.l_q, (const uint8_t*)l_query + d.l_lo * p1, n_l * p1, kind));
+  DG_HIP(hipMemcpy((uint8_t*)d.l_q + n_l * p1, fx + 2 * p1, p1, kind));
+  if (n_h) DG_HIP(hipMemcpy(d.h_q, (const uint8_t*)h_query + d.h_lo * p1, n_h * p1, kind));
   DG_HIP(hipMemcpy(fixed, fx, p1, kind));                     // alpha_g1
   DG_HIP(hipMemcpy(fixed + p1, aq, p1, kind));                // a_query[0]
   DG_HIP(hipMemcpy(fixed + 2 * p1, fx + p1, p1, kind));       // beta_g1
@@ -246,6 +309,14 @@ extern "C" {
 int dg16_pk_create(dg16_ctx* ctx, int curve, size_t num_vars, size_t num_inputs, size_t domain_size,
                    const void* a_query, const void* b_g1_query, const void* b_g2_query, const void* h_query,
                    const void* l_query, const void* fixed_points, unsigned flags, dg16_pk** out) {
+  return dg16_pk_create_shard(ctx, curve, num_vars, num_inputs, domain_size, a_query, b_g1_query, b_g2_query,
+                              h_query, l_query, fixed_points, 0, 1, flags, out);
+}
+
+int dg16_pk_create_shard(dg16_ctx* ctx, int curve, size_t num_vars, size_t num_inputs, size_t domain_size,
+                         const void* a_query, const void* b_g1_query, const void* b_g2_query,
+                         const void* h_query, const void* l_query, const void* fixed_points, unsigned shard,
+                         unsigned n_shards, unsigned flags, dg16_pk** out) {
   if (!ctx || !out) return DG16_ERR_BAD_ARG;
   *out = nullptr;
   dg16_pk* pk = new dg16_pk{ctx, {}};
@@ -260,6 +331,9 @@ int dg16_pk_create(dg16_ctx* ctx, int curve, size_t num_vars, size_t num_inputs,
     pk->d.num_vars = num_vars;
     pk->d.num_inputs = num_inputs;
     pk->d.m = domain_size;
+    DG_REQUIRE(n_shards >= 1 && shard < n_shards, DG16_ERR_BAD_ARG, "shard index out of range");
+    pk->d.shard = shard;
+    pk->d.nshards = n_shards;
     bool dev = flags & DG16_F_DEVICE_PTRS;
     if (curve == DG16_BN254)
       pk_build<0>(ctx, pk->d, a_query, b_g1_query, b_g2_query, h_query, l_query, fixed_points, dev);
@@ -294,6 +368,63 @@ int dg16_groth16_prove(dg16_ctx* ctx, const dg16_pk* pk, const void* a, const vo
       prove_typed<0>(ctx, pk->d, a, b, c, full_assignment, r_s, mont, dev, proof_out);
     else
       prove_typed<1>(ctx, pk->d, a, b, c, full_assignment, r_s, mont, dev, proof_out);
+  });
+}
+
+size_t dg16_groth16_results_bytes(int curve) {
+  return curve == DG16_BN254 ? msm_results_bytes<0>() : curve == DG16_BLS12_381 ? msm_results_bytes<1>() : 0;
+}
+
+int dg16_groth16_msms(dg16_ctx* ctx, const dg16_pk* pk, const void* a, const void* b, const void* c,
+                      const void* full_assignment, const void* r_s, unsigned flags, void* results_out) {
+  if (!ctx || !pk) return DG16_ERR_BAD_ARG;
+  return guarded(ctx, [&] {
+    DG_REQUIRE(pk->ctx == ctx, DG16_ERR_BAD_ARG, "proving key belongs to another context");
+    DG_REQUIRE(a && b && c && full_assignment && r_s && results_out, DG16_ERR_BAD_ARG, "null operand");
+    bool mont = flags & DG16_F_SCALARS_MONT, dev = flags & DG16_F_DEVICE_PTRS;
+    Call k0(ctx, 0), k1(ctx, 1), k2(ctx, 2);
+    size_t rec = dg16_groth16_results_bytes(pk->d.curve);
+    uint8_t* res_dev = dev ? (uint8_t*)results_out : (uint8_t*)ws(k0.c, 16, 8192);
+    k0.begin_dominant();
+    if (pk->d.curve == DG16_BN254)
+      msms_typed<0>(ctx, k0, k1, k2, pk->d, a, b, c, full_assignment, r_s, mont, dev, res_dev);
+    else
+      msms_typed<1>(ctx, k0, k1, k2, pk->d, a, b, c, full_assignment, r_s, mont, dev, res_dev);
+    k0.end_dominant();
+    if (!dev) stage_out(k0, results_out, res_dev, rec, false);
+    k0.finish();
+    k1.finish();
+    k2.finish();
+    if (!dev) DG_HIP(hipStreamSynchronize(k0.s()));
+  });
+}
+
+int dg16_groth16_assemble(dg16_ctx* ctx, const dg16_pk* pk, const void* gathered_results, size_t n_shards,
+                          const void* r_s, unsigned flags, void* proof_out) {
+  if (!ctx || !pk) return DG16_ERR_BAD_ARG;
+  return guarded(ctx, [&] {
+    DG_REQUIRE(pk->ctx == ctx, DG16_ERR_BAD_ARG, "proving key belongs to another context");
+    DG_REQUIRE(gathered_results && r_s && proof_out && n_shards >= 1, DG16_ERR_BAD_ARG, "null operand");
+    bool mont = flags & DG16_F_SCALARS_MONT, dev = flags & DG16_F_DEVICE_PTRS;
+    Call k0(ctx, 0);
+    size_t rec = dg16_groth16_results_bytes(pk->d.curve);
+    const uint8_t* g = (const uint8_t*)stage_in(k0, 19, gathered_results, n_shards * rec, dev);
+    uint8_t* buf = (uint8_t*)ws(k0.c, 16, 8192);
+    uint8_t* summed = buf;
+    uint8_t* proof_dev = buf + 4096;
+    size_t proof_bytes;
+    if (pk->d.curve == DG16_BN254) {
+      reduce_results_typed<0>(k0, g, n_shards, summed);
+      assemble_typed<0>(k0, pk->d, summed, r_s, mont, proof_dev);
+      proof_bytes = 2 * sizeof(Jacobian<bn254_fq>) + sizeof(Jacobian<Fp2<bn254_fq>>);
+    } else {
+      reduce_results_typed<1>(k0, g, n_shards, summed);
+      assemble_typed<1>(k0, pk->d, summed, r_s, mont, proof_dev);
+      proof_bytes = 2 * sizeof(Jacobian<bls12_381_fq>) + sizeof(Jacobian<Fp2<bls12_381_fq>>);
+    }
+    stage_out(k0, proof_out, proof_dev, proof_bytes, dev);
+    k0.finish();
+    if (!dev) DG_HIP(hipStreamSynchronize(k0.s()));
   });
 }
 

@@ -67,6 +67,11 @@ def load():
     L.dg16_pk_destroy.argtypes = [vp]
     L.dg16_pk_destroy.restype = None
     L.dg16_groth16_prove.argtypes = [vp, vp, vp, vp, vp, vp, vp, u, vp]
+    L.dg16_pk_create_shard.argtypes = [vp, i, sz, sz, sz, vp, vp, vp, vp, vp, vp, u, u, u, ctypes.POINTER(vp)]
+    L.dg16_groth16_results_bytes.argtypes = [i]
+    L.dg16_groth16_results_bytes.restype = sz
+    L.dg16_groth16_msms.argtypes = [vp, vp, vp, vp, vp, vp, vp, u, vp]
+    L.dg16_groth16_assemble.argtypes = [vp, vp, vp, sz, vp, u, vp]
     _lib = L
     return L
 
@@ -74,7 +79,8 @@ def load():
 EXPORTED = ["dg16_ctx_create", "dg16_ctx_destroy", "dg16_last_error", "dg16_set_stream", "dg16_sync",
             "dg16_device_info", "dg16_field_op", "dg16_ntt", "dg16_h_poly", "dg16_msm",
             "dg16_gen_bases", "dg16_to_affine", "dg16_last_kernel_ms", "dg16_pk_create", "dg16_pk_destroy",
-            "dg16_groth16_prove"]
+            "dg16_groth16_prove", "dg16_pk_create_shard", "dg16_groth16_results_bytes", "dg16_groth16_msms",
+            "dg16_groth16_assemble"]
 
 
 def _ptr(x):
@@ -210,17 +216,54 @@ class Context:
 
     # ---- Groth16 prover ---------------------------------------------------------------------------------
     def pk_create(self, curve, num_vars, num_inputs, domain_size, a_query, b_g1_query, b_g2_query, h_query,
-                  l_query, fixed_points, device_ptrs=False):
+                  l_query, fixed_points, device_ptrs=False, shard=0, n_shards=1):
         """Makes an arkworks-shaped ProvingKey resident (see include/dg16.h).  Arguments are numpy
-        arrays (host) or raw device pointers (device_ptrs=True)."""
+        arrays (host) or raw device pointers (device_ptrs=True).  With n_shards > 1 only slice
+        `shard` of every MSM range is kept (one process per GPU)."""
         h = ctypes.c_void_p()
         args = [a_query, b_g1_query, b_g2_query, h_query, l_query, fixed_points]
         if not device_ptrs:
             args = [np.ascontiguousarray(x, dtype=np.uint64) for x in args]
-        self._chk(self.L.dg16_pk_create(self.h, CURVES[curve], num_vars, num_inputs, domain_size,
-                                        *[_ptr(x) for x in args], F_DEVICE_PTRS if device_ptrs else 0,
-                                        ctypes.byref(h)))
+        self._chk(self.L.dg16_pk_create_shard(self.h, CURVES[curve], num_vars, num_inputs, domain_size,
+                                              *[_ptr(x) for x in args], shard, n_shards,
+                                              F_DEVICE_PTRS if device_ptrs else 0, ctypes.byref(h)))
         return ProvingKey(self, h, curve, num_vars, num_inputs, domain_size)
+
+    def results_bytes(self, curve):
+        return self.L.dg16_groth16_results_bytes(CURVES[curve])
+
+    def groth16_msms_dev(self, pk, a_ptr, b_ptr, c_ptr, w_ptr, rs_host, results_ptr, scalars_mont=True):
+        rs_host = np.ascontiguousarray(rs_host, dtype=np.uint64)
+        self._chk(self.L.dg16_groth16_msms(self.h, pk.h, _ptr(a_ptr), _ptr(b_ptr), _ptr(c_ptr), _ptr(w_ptr),
+                                           _ptr(rs_host), F_DEVICE_PTRS | (F_SCALARS_MONT if scalars_mont else 0),
+                                           _ptr(results_ptr)))
+
+    def groth16_assemble_dev(self, pk, gathered_ptr, n_shards, rs_host, proof_ptr, scalars_mont=True):
+        rs_host = np.ascontiguousarray(rs_host, dtype=np.uint64)
+        self._chk(self.L.dg16_groth16_assemble(self.h, pk.h, _ptr(gathered_ptr), n_shards, _ptr(rs_host),
+                                               F_DEVICE_PTRS | (F_SCALARS_MONT if scalars_mont else 0),
+                                               _ptr(proof_ptr)))
+
+    def groth16_msms(self, pk, a, b, c, full_assignment, r, s, scalars_mont=True):
+        """Host arrays in, this shard's results record (uint8 array) out."""
+        a, b, c, w = (np.ascontiguousarray(v, dtype=np.uint64) for v in (a, b, c, full_assignment))
+        rs = np.ascontiguousarray(np.concatenate([np.asarray(r, dtype=np.uint64).reshape(1, 4),
+                                                  np.asarray(s, dtype=np.uint64).reshape(1, 4)]))
+        out = np.zeros(self.results_bytes(pk.curve), dtype=np.uint8)
+        self._chk(self.L.dg16_groth16_msms(self.h, pk.h, _ptr(a), _ptr(b), _ptr(c), _ptr(w), _ptr(rs),
+                                           F_SCALARS_MONT if scalars_mont else 0, _ptr(out)))
+        return out
+
+    def groth16_assemble(self, pk, gathered, r, s, scalars_mont=True):
+        gathered = np.ascontiguousarray(gathered, dtype=np.uint8)
+        n_shards = gathered.size // self.results_bytes(pk.curve)
+        rs = np.ascontiguousarray(np.concatenate([np.asarray(r, dtype=np.uint64).reshape(1, 4),
+                                                  np.asarray(s, dtype=np.uint64).reshape(1, 4)]))
+        nl = FQ_LIMBS64[pk.curve]
+        out = np.zeros(12 * nl, dtype=np.uint64)
+        self._chk(self.L.dg16_groth16_assemble(self.h, pk.h, _ptr(gathered), n_shards, _ptr(rs),
+                                               F_SCALARS_MONT if scalars_mont else 0, _ptr(out)))
+        return out[:3 * nl].reshape(1, -1), out[3 * nl:9 * nl].reshape(1, -1), out[9 * nl:].reshape(1, -1)
 
     def prove(self, pk, a, b, c, full_assignment, r, s, scalars_mont=True):
         """Host arrays in, (A, B, C) Jacobian arrays out."""

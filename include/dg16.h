@@ -135,12 +135,34 @@ int dg16_pk_create(dg16_ctx *ctx, int curve, size_t num_vars, size_t num_inputs,
                    dg16_pk **out);
 void dg16_pk_destroy(dg16_pk *pk);
 
+/* Multi-GPU form: the key holds slice `shard` of `n_shards` of every MSM range (contiguous slices of
+ * a_query[1..], b_g1_query[1..], b_g2_query[1..], l_query, h_query); the delta pairs ride on the last
+ * shard.  Pass the FULL queries; only the slice is copied to the device. */
+int dg16_pk_create_shard(dg16_ctx *ctx, int curve, size_t num_vars, size_t num_inputs,
+                         size_t domain_size, const void *a_query, const void *b_g1_query,
+                         const void *b_g2_query, const void *h_query, const void *l_query,
+                         const void *fixed_points, unsigned shard, unsigned n_shards, unsigned flags,
+                         dg16_pk **out);
+
 /* a, b, c: QAP evaluation vectors (domain_size Montgomery Fr elements each); full_assignment:
  * num_vars Fr elements [1, public.., witness..] (Montgomery iff DG16_F_SCALARS_MONT); r_s: HOST
  * pointer to r || s (2 x 32 bytes, same form as the assignment).  proof_out: A (G1 Jacobian) |
  * B (G2 Jacobian) | C (G1 Jacobian).  Uses all three channels. */
 int dg16_groth16_prove(dg16_ctx *ctx, const dg16_pk *pk, const void *a, const void *b, const void *c,
                        const void *full_assignment, const void *r_s, unsigned flags, void *proof_out);
+
+/* The two halves of dg16_groth16_prove, for one-process-per-GPU runs:
+ *   dg16_groth16_msms      h-polynomial + this shard's five MSMs -> results record
+ *                          (A, B1, L, H as G1 Jacobian, then B as G2 Jacobian; dg16_groth16_results_bytes)
+ *   <all-gather of the records over RCCL, done by the caller>
+ *   dg16_groth16_assemble  per-MSM sum of the n_shards records + the A/B/C assembly of prove.rs:21-136
+ * This is d_msm's "gather to king, sum, broadcast" (dist-primitives/src/dmsm/mod.rs:88-97) with the
+ * sum done on every rank. */
+size_t dg16_groth16_results_bytes(int curve);
+int dg16_groth16_msms(dg16_ctx *ctx, const dg16_pk *pk, const void *a, const void *b, const void *c,
+                      const void *full_assignment, const void *r_s, unsigned flags, void *results_out);
+int dg16_groth16_assemble(dg16_ctx *ctx, const dg16_pk *pk, const void *gathered_results,
+                          size_t n_shards, const void *r_s, unsigned flags, void *proof_out);
 
 /* Duration in milliseconds of the dominant kernel(s) of the most recent call on `channel`
  * (HIP events recorded on the channel's stream); 0 if none.  which: 0 = whole call,

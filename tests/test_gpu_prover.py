@@ -78,3 +78,35 @@ def test_prove_matches_bigint_prover(curve, nc, nw):
         assert gA == g1.mul(g1.gen, sa) and gB == g2.mul(g2.gen, sb) and gC == g1.mul(g1.gen, scc)
         assert G.verify_in_exponent(r1cs, F, td, sc, (sa, sb, scc), w)
     dpk.close()
+
+
+def test_sharded_prove_equals_unsharded():
+    """The multi-GPU split run as N shards on one GPU: per-shard MSM records, concatenated as the
+    all-gather would, assembled -> the same proof as the unsharded key."""
+    curve = "bn254"
+    F, Fq = FR[curve], FQ[curve]
+    ni, nc, nw = 2, 45, 50
+    r1cs, w = G.synthetic_r1cs(F, num_constraints=nc, num_instance=ni, num_witness=nw, seed=11)
+    rng = random.Random(8)
+    td = tuple(rng.randrange(1, F.p) for _ in range(5))
+    pk, _ = G.setup(curve, r1cs, td)
+    a, b, c, dom = G.qap(r1cs, w, F)
+    c_ = ctx()
+    fixed = np.concatenate([enc_g1(Fq, [pk["alpha_g1"], pk["beta_g1"], pk["delta_g1"]]).reshape(-1),
+                            enc_g2(Fq, [pk["beta_g2"], pk["delta_g2"]]).reshape(-1)])
+    args = (curve, ni + nw, ni, dom.size, enc_g1(Fq, pk["a_query"]), enc_g1(Fq, pk["b_g1_query"]),
+            enc_g2(Fq, pk["b_g2_query"]), enc_g1(Fq, pk["h_query"]), enc_g1(Fq, pk["l_query"]), fixed)
+    r, s = rng.randrange(1, F.p), rng.randrange(1, F.p)
+    exp = G.create_proof(curve, pk, r, s, r1cs, w)
+    for world in (1, 2, 3, 8):
+        recs = []
+        keys = [c_.pk_create(*args, shard=k, n_shards=world) for k in range(world)]
+        for k in range(world):
+            recs.append(c_.groth16_msms(keys[k], enc_fr(F, a), enc_fr(F, b), enc_fr(F, c), enc_fr(F, w),
+                                        enc_fr(F, [r]), enc_fr(F, [s])))
+        A, B, C = c_.groth16_assemble(keys[0], np.concatenate(recs), enc_fr(F, [r]), enc_fr(F, [s]))
+        got = (dec_g1(Fq, corc.jac_to_affine(curve, 1, A)), dec_g2(Fq, corc.jac_to_affine(curve, 2, B)),
+               dec_g1(Fq, corc.jac_to_affine(curve, 1, C)))
+        assert got == exp, world
+        for k in keys:
+            k.close()

@@ -1,0 +1,153 @@
+"""N > 1 path on CPU: world_size-2 gloo run of DistributedProver with an oracle-backed engine standing
+in for the GPU (test infrastructure only).  Checks the shard bounds, the single all-gather and the
+assembly: the distributed proof must equal the single-prover proof of the big-int restatement."""
+
+import os
+import random
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+class OracleEngine:
+    """Stands in for GpuEngine: same record layout (A, B1, L, H as G1 Jacobian then B as G2 Jacobian,
+    Montgomery limbs), computed with the CPU oracle on this rank's slices."""
+
+    def __init__(self, curve, pk, r1cs_dims, shard, n_shards):
+        from oracle import corc
+        from dg16_amd.parallel import shard_bounds
+        self.corc, self.curve, self.pk = corc, curve, pk
+        self.nv, self.ni, self.m = r1cs_dims
+        self.ab = shard_bounds(self.nv - 1, shard, n_shards)
+        self.lb = shard_bounds(self.nv - self.ni, shard, n_shards)
+        self.hb = shard_bounds(self.m, shard, n_shards)
+        self.last = shard + 1 == n_shards
+        self.rec = (4 * 3 * 4 + 3 * 8) * 8
+
+    def _jac(self, group, aff):
+        nl = 4 * (2 if group == 2 else 1)
+        out = np.zeros(3 * nl, dtype=np.uint64)
+        if aff.any():
+            out[:2 * nl] = aff.reshape(-1)
+            one = self.corc.field_op(self.curve, "fq", "to_mont", self.corc.ints_to_arr([1], 4)).reshape(-1)
+            out[2 * nl:2 * nl + 4] = one
+        return out
+
+    def partial(self, a, b, c, w, rs_host, scalars_mont):
+        corc, cv = self.corc, self.curve
+        R = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+        r = int(sum(int(x) << (64 * i) for i, x in enumerate(rs_host[0])))
+        s = int(sum(int(x) << (64 * i) for i, x in enumerate(rs_host[1])))
+        if not self.last:
+            r = s = 0
+        w = w.numpy()
+        h = corc.field_op(cv, "fr", "from_mont", corc.h_poly(cv, a.numpy(), b.numpy(), c.numpy()))
+        pk = self.pk
+        sc = lambda v: corc.ints_to_arr([v], 4)
+        lo, hi = self.ab
+        A = corc.msm(cv, 1, np.concatenate([pk["a_query"][1:][lo:hi], pk["delta_g1"]]), np.concatenate([w[1:][lo:hi], sc(r)]))
+        B1 = corc.msm(cv, 1, np.concatenate([pk["b_g1_query"][1:][lo:hi], pk["delta_g1"]]), np.concatenate([w[1:][lo:hi], sc(s)]))
+        B2 = corc.msm(cv, 2, np.concatenate([pk["b_g2_query"][1:][lo:hi], pk["delta_g2"]]), np.concatenate([w[1:][lo:hi], sc(s)]))
+        lo, hi = self.lb
+        L = corc.msm(cv, 1, np.concatenate([pk["l_query"][lo:hi], pk["delta_g1"]]),
+                     np.concatenate([w[self.ni:][lo:hi], sc((R - r * s % R) % R)]))
+        lo, hi = self.hb
+        H = corc.msm(cv, 1, pk["h_query"][lo:hi], h[lo:hi])
+        rec = np.concatenate([self._jac(1, A), self._jac(1, B1), self._jac(1, L), self._jac(1, H), self._jac(2, B2)])
+        return torch.from_numpy(rec.view(np.uint8).copy())
+
+    def empty_gather(self, n):
+        return torch.empty(n * self.rec, dtype=torch.uint8)
+
+    def assemble(self, gathered, n_shards, rs_host, scalars_mont):
+        corc, cv, pk = self.corc, self.curve, self.pk
+        g = gathered.numpy().view(np.uint64).reshape(n_shards, -1)
+        r = int(sum(int(x) << (64 * i) for i, x in enumerate(rs_host[0])))
+        s = int(sum(int(x) << (64 * i) for i, x in enumerate(rs_host[1])))
+
+        def total(group, off, nl):
+            acc = np.zeros((1, 2 * nl), dtype=np.uint64)
+            for k in range(n_shards):
+                acc = corc.point_add(cv, group, acc, corc.jac_to_affine(cv, group, g[k, off:off + 3 * nl]))
+            return acc
+        A, B1, L, H = (total(1, 12 * i, 4) for i in range(4))
+        B2 = total(2, 48, 8)
+        add = lambda grp, p, q: corc.point_add(cv, grp, p, q)
+        gA = add(1, add(1, A, pk["alpha_g1"]), pk["a_query"][0:1])
+        gB1 = add(1, add(1, B1, pk["beta_g1"]), pk["b_g1_query"][0:1]) if r else np.zeros_like(gA)
+        gB = add(2, add(2, B2, pk["beta_g2"]), pk["b_g2_query"][0:1])
+        gC = add(1, add(1, L, H), add(1, corc.point_mul(cv, 1, gA, s), corc.point_mul(cv, 1, gB1, r)))
+        return gA, gB, gC
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import dg16_amd  # noqa: F401
+    from dg16_amd.parallel import DistributedProver
+    from oracle.pyref.fields import FQ, FR
+    from oracle.pyref import groth16 as G
+    from oracle import corc
+    from test_gpu_prover import enc_fr, enc_g1, enc_g2, dec_g1, dec_g2
+    curve = "bn254"
+    F, Fq = FR[curve], FQ[curve]
+    r1cs, w = G.synthetic_r1cs(F, num_constraints=13, num_instance=2, num_witness=17, seed=3)
+    rng = random.Random(5)
+    td = tuple(rng.randrange(1, F.p) for _ in range(5))
+    pk, _ = G.setup(curve, r1cs, td)
+    a, b, c, dom = G.qap(r1cs, w, F)
+    hpk = {k: enc_g1(Fq, v if isinstance(v, list) else [v]) for k, v in pk.items()
+           if k in ("a_query", "b_g1_query", "h_query", "l_query", "alpha_g1", "beta_g1", "delta_g1")}
+    hpk.update({k: enc_g2(Fq, v if isinstance(v, list) else [v]) for k, v in pk.items()
+                if k in ("b_g2_query", "beta_g2", "delta_g2")})
+    eng = OracleEngine(curve, hpk, (len(w), 2, dom.size), rank, world)
+    prover = DistributedProver(eng, dist, rank, world)
+    r, s = rng.randrange(1, F.p), rng.randrange(1, F.p)
+    rs = corc.ints_to_arr([r, s], 4)
+    t = lambda v: torch.from_numpy(enc_fr(F, v).view(np.int64))
+    wc = torch.from_numpy(corc.ints_to_arr([x % F.p for x in w], 4))
+    gA, gB, gC = prover.prove(t(a), t(b), t(c), wc, rs, scalars_mont=False)
+    exp = G.create_proof(curve, pk, r, s, r1cs, w)
+    ok = (dec_g1(Fq, gA), dec_g2(Fq, gB), dec_g1(Fq, gC)) == exp
+    q.put((rank, ok))
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_proof_equals_single_prover():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, True), (1, True)]
+
+
+def test_shard_bounds_cover_range():
+    from dg16_amd.parallel import shard_bounds
+    for n in (0, 1, 7, 1048575):
+        for world in (1, 2, 3, 8):
+            pieces = [shard_bounds(n, k, world) for k in range(world)]
+            assert pieces[0][0] == 0 and pieces[-1][1] == n
+            assert all(pieces[i][1] == pieces[i + 1][0] for i in range(world - 1))
