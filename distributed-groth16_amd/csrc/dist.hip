@@ -1,0 +1,530 @@
+// Host side of the dist-primitives mirror (see dist_impl.h): PackedSharingParams, the MpcNet-shaped
+// transport with an in-process LocalNet, and d_fft / d_ifft / d_msm / d_pp / deg_red / ext_wit::h with
+// the reference's names, argument meaning and error behaviour.
+#include <chrono>
+
+#include "dist_impl.h"
+
+using namespace dg16;
+
+// ---- transport -----------------------------------------------------------------------------------
+// In-process n-party net (LocalTestNet, mpc-net/src/multi.rs:227-329): parties are host threads of one
+// process, payloads are device buffers, the king reads the other parties' buffers directly.
+struct dg16_localnet {
+  unsigned n;
+  std::mutex mu;
+  std::condition_variable cv;
+  struct Slot {
+    unsigned arrived = 0, generation = 0;
+    const void* send[kMaxParties] = {};
+    void* king_recv = nullptr;
+    const void* king_send = nullptr;
+    size_t bytes = 0;
+    bool failed = false;
+  } slot[kChannels][2];   // [channel][0 = gather, 1 = scatter]
+  dg16_net party[kMaxParties];
+  struct PartyRef { dg16_localnet* net; unsigned id; } ref[kMaxParties];
+  bool aborted = false;       // a party died: every pending and future collective fails ("Stream died")
+  unsigned timeout_s = 120;
+};
+
+namespace dg16 {
+
+// Rendezvous of all n parties on one slot; `king_work` runs on the king once everybody has arrived,
+// everybody leaves after it is done.  Returns false if any party reported mismatching sizes.
+template <class Fn>
+static bool rendezvous(dg16_localnet* ln, dg16_localnet::Slot& s, unsigned id, Fn&& king_work) {
+  std::unique_lock<std::mutex> lk(ln->mu);
+  if (ln->aborted) return false;
+  unsigned gen = s.generation;
+  s.arrived++;
+  const auto limit = std::chrono::seconds(ln->timeout_s);
+  if (id == 0) {
+    if (!ln->cv.wait_for(lk, limit, [&] { return s.arrived == ln->n || ln->aborted; }) || ln->aborted) {
+      ln->aborted = true;     // a peer never arrived: fail everybody instead of hanging
+      ln->cv.notify_all();
+      return false;
+    }
+    bool ok = !s.failed;
+    if (ok) {
+      lk.unlock();
+      ok = king_work();
+      lk.lock();
+    }
+    s.failed = !ok;
+    bool result = ok;
+    s.arrived = 0;
+    s.generation++;
+    ln->cv.notify_all();
+    s.failed = false;
+    return result;
+  }
+  ln->cv.notify_all();
+  if (!ln->cv.wait_for(lk, limit, [&] { return s.generation != gen || ln->aborted; }) || ln->aborted) {
+    ln->aborted = true;
+    ln->cv.notify_all();
+    return false;
+  }
+  return true;
+}
+
+static int localnet_gather(void* self, int channel, const void* send_dev, size_t bytes, void* recv_dev, void* stream) {
+  auto* ref = (dg16_localnet::PartyRef*)self;
+  dg16_localnet* ln = ref->net;
+  auto& s = ln->slot[channel][0];
+  if (stream && hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return DG16_ERR_HIP;  // payload complete
+  {
+    std::lock_guard<std::mutex> g(ln->mu);
+    s.send[ref->id] = send_dev;
+    if (ref->id == 0) { s.king_recv = recv_dev; s.bytes = bytes; }
+  }
+  bool ok = rendezvous(ln, s, ref->id, [&] {
+    for (unsigned p = 0; p < ln->n; p++)
+      if (hipMemcpy((uint8_t*)s.king_recv + p * s.bytes, s.send[p], s.bytes, hipMemcpyDeviceToDevice) != hipSuccess)
+        return false;
+    return hipDeviceSynchronize() == hipSuccess;   // device-to-device hipMemcpy may return early
+  });
+  return ok ? DG16_OK : DG16_ERR_NET;
+}
+
+static int localnet_scatter(void* self, int channel, const void* send_dev, size_t bytes, void* recv_dev, void* stream) {
+  auto* ref = (dg16_localnet::PartyRef*)self;
+  dg16_localnet* ln = ref->net;
+  auto& s = ln->slot[channel][1];
+  if (stream && hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return DG16_ERR_HIP;
+  {
+    std::lock_guard<std::mutex> g(ln->mu);
+    s.send[ref->id] = recv_dev;   // reuse the pointer table for the receive buffers
+    if (ref->id == 0) { s.king_send = send_dev; s.bytes = bytes; }
+  }
+  bool ok = rendezvous(ln, s, ref->id, [&] {
+    // the king checks that all outgoing buffers have the same length by construction (one `bytes`),
+    // mpc-net/src/lib.rs:116-124
+    for (unsigned p = 0; p < ln->n; p++)
+      if (hipMemcpy((void*)s.send[p], (const uint8_t*)s.king_send + p * s.bytes, s.bytes, hipMemcpyDeviceToDevice) !=
+          hipSuccess)
+        return false;
+    return hipDeviceSynchronize() == hipSuccess;
+  });
+  return ok ? DG16_OK : DG16_ERR_NET;
+}
+static unsigned localnet_n(void* self) { return ((dg16_localnet::PartyRef*)self)->net->n; }
+static unsigned localnet_id(void* self) { return ((dg16_localnet::PartyRef*)self)->id; }
+
+static void net_check(int rc) {
+  if (rc != DG16_OK) throw StatusError{DG16_ERR_NET, "MpcNet collective failed (Stream died / NotConnected)"};
+}
+
+// ---- typed implementation -----------------------------------------------------------------------------
+template <class Fr>
+struct Dist {
+  static Fr* mat(const dg16_pss* pp, int which) {  // 0 pack [n][l], 1 unpack [l][n], 2 unpack2 [l][n]
+    Fr* m = (Fr*)pp->mats;
+    return which == 0 ? m : which == 1 ? m + pp->n * pp->l : m + 2 * pp->n * pp->l;
+  }
+  static Fr* mat_canon(const dg16_pss* pp, int which) { return mat(pp, which) + 3 * pp->n * pp->l; }
+  static Fr* v2sum(const dg16_pss* pp) { return (Fr*)pp->mats + 6 * pp->n * pp->l; }
+
+  // fft2_with_rearrange_pad (dfft/mod.rs:185-256).  px: this party's m/l elements (device).
+  static void fft2_with_rearrange_pad(Call& k, const dg16_pss* pp, const dg16_net* net, int curve, Fr* px,
+                                      size_t mbyl, bool rearrange, unsigned pad, bool degree2, unsigned log_m,
+                                      int inverse, Fr* out, int sid) {
+    const unsigned n = pp->n, l = pp->l;
+    const size_t m = mbyl * l, total = (size_t)pad * m, out_per_party = total / l;
+    const bool king = net->party_id(net->self) == 0;
+    Fr* gathered = king ? (Fr*)ws(k.c, 18, (size_t)n * mbyl * sizeof(Fr)) : nullptr;
+    net_check(net->gather_to_king(net->self, sid, px, mbyl * sizeof(Fr), gathered, k.s()));
+    Fr* send = nullptr;
+    if (king) {
+      Fr* s1 = (Fr*)ws(k.c, 19, total * sizeof(Fr));
+      Fr* s2 = (Fr*)ws(k.c, 20, total * sizeof(Fr));
+      send = (Fr*)ws(k.c, 21, (size_t)n * out_per_party * sizeof(Fr));
+      // transpose + unpack (dfft/mod.rs:207-220): s1[e*l + j] = sum_p U[j][p] * gathered[p][e]
+      hipLaunchKernelGGL(matvec_kernel<Fr>, dim3(nblk(mbyl)), dim3(256), 0, k.s(), mat(pp, degree2 ? 2 : 1), l, n,
+                         gathered, (size_t)1, mbyl, s1, (size_t)l, (size_t)1, mbyl, -1);
+      // fft2_in_place (dfft/mod.rs:161-177)
+      const TwiddleSet& ts = twiddles(k, curve, log_m, inverse);
+      unsigned log_l = 0;
+      while ((1u << log_l) < l) log_l++;
+      Fr *a = s1, *b = s2;
+      for (unsigned i = log_l; i >= 1; i--) {
+        hipLaunchKernelGGL(fft2_level_kernel<Fr>, dim3(nblk(m / 2)), dim3(256), 0, k.s(), a, b, m, i, log_m,
+                           (const Fr*)ts.lo, (const Fr*)ts.hi, ts.lb);
+        std::swap(a, b);
+      }
+      hipLaunchKernelGGL(rotate_pad_kernel<Fr>, dim3(nblk(total)), dim3(256), 0, k.s(), a, b, m, total);
+      // b now holds the padded natural-order vector
+      if (rearrange) {
+        // bit-reverse, then pack s1r[i], s1r[i + len/l], .. (dfft/mod.rs:230-245): in index = bitrev(i + j*len/l)
+        unsigned bits = 0;
+        while (((size_t)1 << bits) < total) bits++;
+        hipLaunchKernelGGL(matvec_kernel<Fr>, dim3(nblk(out_per_party)), dim3(256), 0, k.s(), mat(pp, 0), n, l, b,
+                           (size_t)1, out_per_party, send, (size_t)1, out_per_party, out_per_party, (int)bits);
+      } else {
+        // pack_vec over consecutive l-chunks (utils/pack.rs:4-16), transposed to [party][chunk]
+        hipLaunchKernelGGL(matvec_kernel<Fr>, dim3(nblk(out_per_party)), dim3(256), 0, k.s(), mat(pp, 0), n, l, b,
+                           (size_t)l, (size_t)1, send, (size_t)1, out_per_party, out_per_party, -1);
+      }
+      DG_HIP(hipGetLastError());
+    }
+    net_check(net->scatter_from_king(net->self, sid, send, out_per_party * sizeof(Fr), out, k.s()));
+  }
+
+  static const TwiddleSet& twiddles(Call& k, int curve, unsigned log_n, int inverse);
+
+  // deg_red (utils/deg_red.rs:10-28) on device buffers
+  static void deg_red(Call& k, const dg16_pss* pp, const dg16_net* net, const Fr* din, size_t count, Fr* dout, int sid) {
+    const unsigned n = pp->n, l = pp->l;
+    const bool king = net->party_id(net->self) == 0;
+    Fr* gathered = king ? (Fr*)ws(k.c, 18, (size_t)n * count * sizeof(Fr)) : nullptr;
+    net_check(net->gather_to_king(net->self, sid, din, count * sizeof(Fr), gathered, k.s()));
+    Fr* send = nullptr;
+    if (king) {
+      Fr* sec = (Fr*)ws(k.c, 19, count * l * sizeof(Fr));
+      send = (Fr*)ws(k.c, 21, (size_t)n * count * sizeof(Fr));
+      // unpack2_in_place then pack_from_public_in_place per packed element
+      hipLaunchKernelGGL(matvec_kernel<Fr>, dim3(nblk(count)), dim3(256), 0, k.s(), mat(pp, 2), l, n, gathered,
+                         (size_t)1, count, sec, (size_t)l, (size_t)1, count, -1);
+      hipLaunchKernelGGL(matvec_kernel<Fr>, dim3(nblk(count)), dim3(256), 0, k.s(), mat(pp, 0), n, l, sec, (size_t)l,
+                         (size_t)1, send, (size_t)1, count, count, -1);
+      DG_HIP(hipGetLastError());
+    }
+    net_check(net->scatter_from_king(net->self, sid, send, count * sizeof(Fr), dout, k.s()));
+  }
+
+  // d_fft / d_ifft (dfft/mod.rs:17-95)
+  static void d_fft(Call& k, const dg16_pss* pp, const dg16_net* net, int curve, Fr* share, size_t mbyl, bool rearrange,
+                    unsigned pad, bool degree2, unsigned log_m, int inverse, Fr* out, int sid) {
+    const unsigned l = pp->l;
+    DG_REQUIRE(mbyl * l == ((size_t)1 << log_m), DG16_ERR_BAD_ARG, "Mismatch of size in FFT (share.len() * l != dom.size())");
+    const TwiddleSet& ts = twiddles(k, curve, log_m, inverse);
+    if (inverse)   // peval_share *= dom.size_inv() (dfft/mod.rs:78)
+      hipLaunchKernelGGL(scale_kernel<Fr>, dim3(nblk(mbyl)), dim3(256), 0, k.s(), share, (const Fr*)ts.n_inv, mbyl);
+    unsigned log_l = 0;
+    while ((1u << log_l) < l) log_l++;
+    // fft1_in_place: levels i = log2 m down to log2 l + 1 (dfft/mod.rs:122-135)
+    for (unsigned i = log_m; i > log_l; i--) {
+      unsigned log_ps = log_m - i;
+      hipLaunchKernelGGL(fft1_level_kernel<Fr>, dim3(nblk(mbyl / 2)), dim3(256), 0, k.s(), share, mbyl / 2, log_ps, i,
+                         log_m, (const Fr*)ts.lo, (const Fr*)ts.hi, ts.lb);
+    }
+    DG_HIP(hipGetLastError());
+    fft2_with_rearrange_pad(k, pp, net, curve, share, mbyl, rearrange, pad, degree2, log_m, inverse, out, sid);
+  }
+};
+
+// twiddle sets are built by ntt.hip; re-declared here
+const TwiddleSet& get_twiddles_any(Call& k, int curve, unsigned log_n, int inverse);
+template <class Fr>
+const TwiddleSet& Dist<Fr>::twiddles(Call& k, int curve, unsigned log_n, int inverse) {
+  return get_twiddles_any(k, curve, log_n, inverse);
+}
+
+template <class Fr>
+static void pss_build(dg16_pss* pp) {
+  const unsigned n = pp->n, l = pp->l;
+  DG_HIP(hipMalloc(&pp->mats, (6 * n * l + n) * sizeof(Fr)));
+  hipLaunchKernelGGL(pss_setup_kernel<Fr>, dim3(1), dim3(256), 0, 0, l, (Fr*)pp->mats);
+  DG_HIP(hipGetLastError());
+  DG_HIP(hipDeviceSynchronize());
+}
+
+#define FR_SWITCH(curve, ...)                                   \
+  switch (curve) {                                              \
+    case 0: { using Fr = bn254_fr; __VA_ARGS__ } break;         \
+    case 1: { using Fr = bls12_381_fr; __VA_ARGS__ } break;     \
+    default: { using Fr = bls12_377_fr; __VA_ARGS__ } break;    \
+  }
+
+}  // namespace dg16
+
+// per-(curve, group) entry points defined in msm_<curve>_g<k>.hip
+namespace dg16 {
+#define DECL_G(name)                                                                                         \
+  void d_msm_##name(Call&, const dg16_pss*, const dg16_net*, int, const void*, const void*, size_t, bool, void*); \
+  void packexp_##name(Call&, const dg16_pss*, int, const void*, size_t, void*);
+DECL_G(bn254_g1) DECL_G(bn254_g2) DECL_G(bls12_381_g1) DECL_G(bls12_381_g2) DECL_G(bls12_377_g1)
+#define DISPATCH_G(fn, curve, group, ...)                                                        \
+  switch ((curve) * 2 + (group) - 1) {                                                           \
+    case 0: fn##_bn254_g1(__VA_ARGS__); break;                                                   \
+    case 1: fn##_bn254_g2(__VA_ARGS__); break;                                                   \
+    case 2: fn##_bls12_381_g1(__VA_ARGS__); break;                                               \
+    case 3: fn##_bls12_381_g2(__VA_ARGS__); break;                                               \
+    case 4: fn##_bls12_377_g1(__VA_ARGS__); break;                                               \
+    default: throw StatusError{DG16_ERR_UNSUPPORTED, "BLS12-377 G2 is not on the reference's path"}; \
+  }
+}  // namespace dg16
+
+extern "C" {
+
+// ---- PackedSharingParams ------------------------------------------------------------------------------
+int dg16_pss_create(dg16_ctx* ctx, int curve, unsigned l, dg16_pss** out) {
+  if (!ctx || !out) return DG16_ERR_BAD_ARG;
+  *out = nullptr;
+  dg16_pss* pp = new dg16_pss{ctx, curve, l, l - 1, 4 * l, nullptr};
+  int rc = guarded(ctx, [&] {
+    DG_REQUIRE(curve >= 0 && curve <= 2, DG16_ERR_BAD_CURVE, "unknown curve id");
+    DG_REQUIRE(l >= 1 && l <= 8 && !(l & (l - 1)), DG16_ERR_BAD_ARG, "packing factor must be a power of two <= 8");
+    DG_HIP(hipSetDevice(ctx->device));
+    FR_SWITCH(curve, pss_build<Fr>(pp);)
+  });
+  if (rc != DG16_OK) { delete pp; return rc; }
+  *out = pp;
+  return DG16_OK;
+}
+void dg16_pss_destroy(dg16_pss* pp) {
+  if (!pp) return;
+  hipSetDevice(pp->ctx->device);
+  if (pp->mats) hipFree(pp->mats);
+  delete pp;
+}
+
+// batched pack_from_public / unpack / unpack2 (pss.rs:86-148): `count` independent packings.
+// which: 0 pack ([count][l] -> [count][n]), 1 unpack ([count][n] -> [count][l]), 2 unpack2.
+int dg16_pss_apply(dg16_ctx* ctx, const dg16_pss* pp, int which, const void* in, size_t count, void* out,
+                   unsigned flags, int channel) {
+  int rc = guard_channel(ctx, channel);
+  if (rc) return rc;
+  return guarded(ctx, [&] {
+    DG_REQUIRE(pp && in && out && which >= 0 && which <= 2, DG16_ERR_BAD_ARG, "bad argument");
+    const unsigned n = pp->n, l = pp->l;
+    const unsigned cols = which == 0 ? l : n, rows = which == 0 ? n : l;
+    bool dev = flags & DG16_F_DEVICE_PTRS;
+    Call k(ctx, channel);
+    FR_SWITCH(pp->curve, {
+      const Fr* din = (const Fr*)stage_in(k, 0, in, count * cols * sizeof(Fr), dev);
+      Fr* dout = dev ? (Fr*)out : (Fr*)ws(k.c, 1, count * rows * sizeof(Fr));
+      if (count)
+        hipLaunchKernelGGL(matvec_kernel<Fr>, dim3(nblk(count)), dim3(256), 0, k.s(), Dist<Fr>::mat(pp, which), rows,
+                           cols, din, (size_t)cols, (size_t)1, dout, (size_t)rows, (size_t)1, count, -1);
+      DG_HIP(hipGetLastError());
+      if (!dev) stage_out(k, out, dout, count * rows * sizeof(Fr), false);
+    })
+    k.finish();
+    if (!dev) DG_HIP(hipStreamSynchronize(k.s()));
+  });
+}
+
+// ---- LocalNet -------------------------------------------------------------------------------------------
+int dg16_localnet_create(unsigned n_parties, dg16_localnet** out) {
+  if (!out || n_parties < 1 || n_parties > kMaxParties) return DG16_ERR_BAD_ARG;
+  dg16_localnet* ln = new dg16_localnet();
+  ln->n = n_parties;
+  for (unsigned i = 0; i < n_parties; i++) {
+    ln->ref[i] = {ln, i};
+    ln->party[i] = dg16_net{&ln->ref[i], localnet_n, localnet_id, localnet_gather, localnet_scatter};
+  }
+  *out = ln;
+  return DG16_OK;
+}
+const dg16_net* dg16_localnet_party(dg16_localnet* ln, unsigned id) {
+  return (ln && id < ln->n) ? &ln->party[id] : nullptr;
+}
+void dg16_localnet_destroy(dg16_localnet* ln) { delete ln; }
+// A party that fails outside a collective calls this so that its peers error out instead of waiting
+// (the reference surfaces a dead peer as MpcNetError::Generic("Stream died"), mpc-net/src/multi.rs:393).
+void dg16_localnet_abort(dg16_localnet* ln) {
+  if (!ln) return;
+  std::lock_guard<std::mutex> g(ln->mu);
+  ln->aborted = true;
+  ln->cv.notify_all();
+}
+void dg16_localnet_reset(dg16_localnet* ln, unsigned timeout_s) {
+  if (!ln) return;
+  std::lock_guard<std::mutex> g(ln->mu);
+  ln->aborted = false;
+  if (timeout_s) ln->timeout_s = timeout_s;
+  for (auto& ch : ln->slot)
+    for (auto& sl : ch) { sl.arrived = 0; sl.failed = false; }
+}
+
+// ---- d_fft / d_ifft -----------------------------------------------------------------------------------------
+int dg16_d_fft(dg16_ctx* ctx, const dg16_pss* pp, const dg16_net* net, const void* share, size_t share_len,
+               unsigned log_m, int rearrange, unsigned pad, int degree2, int inverse, void* out, unsigned flags,
+               int channel) {
+  int rc = guard_channel(ctx, channel);
+  if (rc) return rc;
+  return guarded(ctx, [&] {
+    DG_REQUIRE(pp && net && share && out && pad >= 1, DG16_ERR_BAD_ARG, "bad argument");
+    DG_REQUIRE(net->n_parties(net->self) == pp->n, DG16_ERR_BAD_ARG, "net.n_parties() != pp.n");
+    // debug_assert_eq!(pcoeff_share.len() * pp.l, dom.size()) (dfft/mod.rs:31-37)
+    DG_REQUIRE(share_len * pp->l == ((size_t)1 << log_m), DG16_ERR_BAD_ARG,
+               "Mismatch of size in FFT (share.len() * l != dom.size())");
+    const size_t mbyl = share_len, out_n = (size_t)pad * mbyl;
+    bool dev = flags & DG16_F_DEVICE_PTRS;
+    Call k(ctx, channel);
+    FR_SWITCH(pp->curve, {
+      Fr* work = (Fr*)ws(k.c, 0, mbyl * sizeof(Fr));   // the reference consumes its input Vec
+      DG_HIP(hipMemcpyAsync(work, share, mbyl * sizeof(Fr), dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, k.s()));
+      Fr* dout = dev ? (Fr*)out : (Fr*)ws(k.c, 1, out_n * sizeof(Fr));
+      Dist<Fr>::d_fft(k, pp, net, pp->curve, work, mbyl, rearrange != 0, pad, degree2 != 0, log_m, inverse, dout, channel);
+      if (!dev) stage_out(k, out, dout, out_n * sizeof(Fr), false);
+    })
+    k.finish();
+    if (!dev) DG_HIP(hipStreamSynchronize(k.s()));
+  });
+}
+
+// ---- d_msm (dmsm/mod.rs:70-98) and pack/unpack in the exponent (dmsm/mod.rs:7-68) -------------------------
+int dg16_d_msm(dg16_ctx* ctx, const dg16_pss* pp, const dg16_net* net, int group, const void* bases,
+               const void* scalars, size_t n_bases, size_t n_scalars, unsigned flags, int channel, void* out) {
+  int rc = guard_channel(ctx, channel);
+  if (rc) return rc;
+  return guarded(ctx, [&] {
+    DG_REQUIRE(pp && net && out && (group == 1 || group == 2), DG16_ERR_BAD_ARG, "bad argument");
+    DG_REQUIRE(n_bases == n_scalars, DG16_ERR_LENGTH_MISMATCH,
+               "bases and scalars differ in length (VariableBaseMSM::msm returns Err(min_len))");
+    DG_REQUIRE(net->n_parties(net->self) == pp->n, DG16_ERR_BAD_ARG, "net.n_parties() != pp.n");
+    bool dev = flags & DG16_F_DEVICE_PTRS;
+    size_t pb = affine_bytes(pp->curve, group);
+    Call k(ctx, channel);
+    const void* dbases = stage_in(k, 0, bases, n_bases * pb, dev);
+    const void* dscal = stage_in(k, 1, scalars, n_bases * 32, dev);
+    void* dout = dev ? out : ws(k.c, 2, pb / 2 * 3);
+    DISPATCH_G(d_msm, pp->curve, group, k, pp, net, channel, dbases, dscal, n_bases, flags & DG16_F_SCALARS_MONT, dout)
+    if (!dev) stage_out(k, out, dout, pb / 2 * 3, false);
+    k.finish();
+    if (!dev) DG_HIP(hipStreamSynchronize(k.s()));
+  });
+}
+
+// which: 0 packexp_from_public ([count][l] -> [count][n]), 1 unpackexp degree t+l, 2 unpackexp degree2
+int dg16_pss_apply_exp(dg16_ctx* ctx, const dg16_pss* pp, int group, int which, const void* in, size_t count,
+                       void* out, unsigned flags, int channel) {
+  int rc = guard_channel(ctx, channel);
+  if (rc) return rc;
+  return guarded(ctx, [&] {
+    DG_REQUIRE(pp && in && out && which >= 0 && which <= 2 && (group == 1 || group == 2), DG16_ERR_BAD_ARG, "bad argument");
+    const unsigned cols = which == 0 ? pp->l : pp->n, rows = which == 0 ? pp->n : pp->l;
+    bool dev = flags & DG16_F_DEVICE_PTRS;
+    size_t pb = affine_bytes(pp->curve, group);
+    Call k(ctx, channel);
+    const void* din = stage_in(k, 0, in, count * cols * pb, dev);
+    void* dout = dev ? out : ws(k.c, 1, count * rows * pb);
+    if (count) { DISPATCH_G(packexp, pp->curve, group, k, pp, which, din, count, dout) }
+    if (!dev) stage_out(k, out, dout, count * rows * pb, false);
+    k.finish();
+    if (!dev) DG_HIP(hipStreamSynchronize(k.s()));
+  });
+}
+
+// ---- deg_red (utils/deg_red.rs:10-28) ---------------------------------------------------------------------------
+int dg16_deg_red(dg16_ctx* ctx, const dg16_pss* pp, const dg16_net* net, const void* px, size_t count, void* out,
+                 unsigned flags, int channel) {
+  int rc = guard_channel(ctx, channel);
+  if (rc) return rc;
+  return guarded(ctx, [&] {
+    DG_REQUIRE(pp && net && px && out, DG16_ERR_BAD_ARG, "bad argument");
+    bool dev = flags & DG16_F_DEVICE_PTRS;
+    Call k(ctx, channel);
+    FR_SWITCH(pp->curve, {
+      const Fr* din = (const Fr*)stage_in(k, 0, px, count * sizeof(Fr), dev);
+      Fr* dout = dev ? (Fr*)out : (Fr*)ws(k.c, 1, count * sizeof(Fr));
+      Dist<Fr>::deg_red(k, pp, net, din, count, dout, channel);
+      if (!dev) stage_out(k, out, dout, count * sizeof(Fr), false);
+    })
+    k.finish();
+    if (!dev) DG_HIP(hipStreamSynchronize(k.s()));
+  });
+}
+
+// ---- d_pp (dpp/mod.rs:17-88): packed shares of the prefix products of num[i]/den[i] ---------------------------------
+int dg16_d_pp(dg16_ctx* ctx, const dg16_pss* pp, const dg16_net* net, const void* num, const void* den, size_t count,
+              void* out, unsigned flags, int channel) {
+  int rc = guard_channel(ctx, channel);
+  if (rc) return rc;
+  return guarded(ctx, [&] {
+    DG_REQUIRE(pp && net && num && den && out, DG16_ERR_BAD_ARG, "bad argument");
+    const unsigned n = pp->n, l = pp->l;
+    bool dev = flags & DG16_F_DEVICE_PTRS;
+    Call k(ctx, channel);
+    FR_SWITCH(pp->curve, {
+      // numden_rand = num*s ++ den*s with the dummy mask s = 1 (dpp/mod.rs:24-34)
+      Fr* nd = (Fr*)ws(k.c, 0, 2 * count * sizeof(Fr));
+      hipMemcpyKind kind = dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+      DG_HIP(hipMemcpyAsync(nd, num, count * sizeof(Fr), kind, k.s()));
+      DG_HIP(hipMemcpyAsync(nd + count, den, count * sizeof(Fr), kind, k.s()));
+      Fr* mid = (Fr*)ws(k.c, 2, count * sizeof(Fr));
+      const bool king = net->party_id(net->self) == 0;
+      Fr* gathered = king ? (Fr*)ws(k.c, 18, (size_t)n * 2 * count * sizeof(Fr)) : nullptr;
+      net_check(net->gather_to_king(net->self, channel, nd, 2 * count * sizeof(Fr), gathered, k.s()));
+      Fr* send = nullptr;
+      if (king) {
+        const size_t tot = 2 * count * l, half = count * l;
+        Fr* numden = (Fr*)ws(k.c, 19, tot * sizeof(Fr));
+        Fr* ratio = (Fr*)ws(k.c, 20, half * sizeof(Fr));
+        send = (Fr*)ws(k.c, 21, (size_t)n * count * sizeof(Fr));
+        // unpack2 of every packed element: numden = [num secrets (count*l) | den secrets (count*l)]
+        hipLaunchKernelGGL(matvec_kernel<Fr>, dim3(nblk(2 * count)), dim3(256), 0, k.s(), Dist<Fr>::mat(pp, 2), l, n,
+                           gathered, (size_t)1, 2 * count, numden, (size_t)l, (size_t)1, 2 * count, -1);
+        hipLaunchKernelGGL(ratio_kernel<Fr>, dim3(nblk(half)), dim3(256), 0, k.s(), numden, ratio, half);   // :58-63
+        size_t ntiles = (half + kScanTile - 1) / kScanTile;
+        Fr* tops = (Fr*)ws(k.c, 22, ntiles * sizeof(Fr));
+        hipLaunchKernelGGL(prefix_prod_tile_kernel<Fr>, dim3((unsigned)ntiles), dim3(256), 0, k.s(), ratio, half, tops);
+        hipLaunchKernelGGL(prefix_prod_tops_kernel<Fr>, dim3(1), dim3(1), 0, k.s(), tops, ntiles);
+        hipLaunchKernelGGL(prefix_prod_fix_kernel<Fr>, dim3(nblk(half)), dim3(256), 0, k.s(), ratio, half, tops);  // :66-69
+        hipLaunchKernelGGL(matvec_kernel<Fr>, dim3(nblk(count)), dim3(256), 0, k.s(), Dist<Fr>::mat(pp, 0), n, l, ratio,
+                           (size_t)l, (size_t)1, send, (size_t)1, count, count, -1);                                  // :74-79
+        DG_HIP(hipGetLastError());
+      }
+      net_check(net->scatter_from_king(net->self, channel, send, count * sizeof(Fr), mid, k.s()));
+      // sinv = 1: nothing to remove (dpp/mod.rs:86); then the degree reduction (dpp/mod.rs:87)
+      Fr* dout = dev ? (Fr*)out : (Fr*)ws(k.c, 1, count * sizeof(Fr));
+      Dist<Fr>::deg_red(k, pp, net, mid, count, dout, channel);
+      if (!dev) stage_out(k, out, dout, count * sizeof(Fr), false);
+    })
+    k.finish();
+    if (!dev) DG_HIP(hipStreamSynchronize(k.s()));
+  });
+}
+
+// ---- ext_wit::h (groth16/src/ext_wit.rs:16-101) -------------------------------------------------------------------------
+int dg16_ext_wit_h(dg16_ctx* ctx, const dg16_pss* pp, const dg16_net* net, const void* a_share, const void* b_share,
+                   const void* c_share, unsigned log_m, void* out, unsigned flags) {
+  if (!ctx) return DG16_ERR_BAD_ARG;
+  return guarded(ctx, [&] {
+    DG_REQUIRE(pp && net && a_share && b_share && c_share && out, DG16_ERR_BAD_ARG, "bad argument");
+    const unsigned n = pp->n, l = pp->l;
+    const size_t m = (size_t)1 << log_m, mbyl = m / l;
+    bool dev = flags & DG16_F_DEVICE_PTRS;
+    Call k(ctx, 0);
+    FR_SWITCH(pp->curve, {
+      const void* in[3] = {a_share, b_share, c_share};
+      Fr* ev = (Fr*)ws(k.c, 2, 3 * 2 * mbyl * sizeof(Fr));      // three vectors of 2m/l evaluations
+      Fr* work = (Fr*)ws(k.c, 0, 2 * mbyl * sizeof(Fr));
+      Fr* coeff = (Fr*)ws(k.c, 1, 2 * mbyl * sizeof(Fr));
+      for (int v = 0; v < 3; v++) {
+        DG_HIP(hipMemcpyAsync(work, in[v], mbyl * sizeof(Fr), dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, k.s()));
+        // d_ifft(.., rearrange = true, pad = 2) on the m domain, then d_fft on the 2m domain (ext_wit.rs:34-49)
+        Dist<Fr>::d_fft(k, pp, net, pp->curve, work, mbyl, true, 2, false, log_m, 1, coeff, 0);
+        DG_HIP(hipMemcpyAsync(work, coeff, 2 * mbyl * sizeof(Fr), hipMemcpyDeviceToDevice, k.s()));
+        Dist<Fr>::d_fft(k, pp, net, pp->curve, work, 2 * mbyl, false, 1, false, log_m + 1, 0, ev + (size_t)v * 2 * mbyl, 0);
+      }
+      // king: unpack p, q, w, keep the odd positions, h = p*q - w, pack_vec, scatter (ext_wit.rs:54-96)
+      const bool king = net->party_id(net->self) == 0;
+      Fr* gathered = king ? (Fr*)ws(k.c, 18, (size_t)n * 3 * 2 * mbyl * sizeof(Fr)) : nullptr;
+      net_check(net->gather_to_king(net->self, 0, ev, 3 * 2 * mbyl * sizeof(Fr), gathered, k.s()));
+      Fr* send = nullptr;
+      Fr* dout = dev ? (Fr*)out : (Fr*)ws(k.c, 3, mbyl * sizeof(Fr));
+      if (king) {
+        Fr* un = (Fr*)ws(k.c, 19, 3 * 2 * m * sizeof(Fr));
+        Fr* h = (Fr*)ws(k.c, 20, m * sizeof(Fr));
+        send = (Fr*)ws(k.c, 21, (size_t)n * mbyl * sizeof(Fr));
+        for (int v = 0; v < 3; v++)   // party p's record holds its three vectors back to back
+          hipLaunchKernelGGL(matvec_kernel<Fr>, dim3(nblk(2 * mbyl)), dim3(256), 0, k.s(), Dist<Fr>::mat(pp, 1), l, n,
+                             gathered + (size_t)v * 2 * mbyl, (size_t)1, (size_t)3 * 2 * mbyl, un + (size_t)v * 2 * m,
+                             (size_t)l, (size_t)1, 2 * mbyl, -1);
+        hipLaunchKernelGGL(h_odd_kernel<Fr>, dim3(nblk(m)), dim3(256), 0, k.s(), un, un + 2 * m, un + 4 * m, h, m, l, pp->t);
+        hipLaunchKernelGGL(matvec_kernel<Fr>, dim3(nblk(mbyl)), dim3(256), 0, k.s(), Dist<Fr>::mat(pp, 0), n, l, h,
+                           (size_t)l, (size_t)1, send, (size_t)1, mbyl, mbyl, -1);
+        DG_HIP(hipGetLastError());
+      }
+      net_check(net->scatter_from_king(net->self, 0, send, mbyl * sizeof(Fr), dout, k.s()));
+      if (!dev) stage_out(k, out, dout, mbyl * sizeof(Fr), false);
+    })
+    k.finish();
+    if (!dev) DG_HIP(hipStreamSynchronize(k.s()));
+  });
+}
+
+}  // extern "C"

@@ -336,6 +336,14 @@ static void ntt_typed(Call& k, int curve, void* data, unsigned log_n, int invers
   k.end_dominant();
 }
 
+const TwiddleSet& get_twiddles_any(Call& k, int curve, unsigned log_n, int inverse) {
+  switch (curve) {
+    case 0: return get_twiddles<bn254_fr>(k, curve, log_n, inverse);
+    case 1: return get_twiddles<bls12_381_fr>(k, curve, log_n, inverse);
+    default: return get_twiddles<bls12_377_fr>(k, curve, log_n, inverse);
+  }
+}
+
 void ntt_launch(Call& k, int curve, void* data, unsigned log_n, int inverse, const void* coset_host) {
   switch (curve) {
     case 0: ntt_typed<bn254_fr>(k, curve, data, log_n, inverse, coset_host); break;

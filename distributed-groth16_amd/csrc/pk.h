@@ -1,0 +1,34 @@
+// Resident proving key record shared by the prover translation units.
+#pragma once
+#include "ctx.h"
+
+namespace dg16 {
+
+struct PkDev {
+  int curve = 0;
+  size_t num_vars = 0, num_inputs = 0, m = 0;
+  unsigned shard = 0, nshards = 1;   // this key holds slice `shard` of every MSM range (multi-GPU)
+  size_t ab_lo = 0, ab_hi = 0, l_lo = 0, l_hi = 0, h_lo = 0, h_hi = 0;
+  // all device pointers
+  void* a_q = nullptr;    // a_query[1..][ab_lo..ab_hi) ++ delta_g1        (G1)
+  void* b1_q = nullptr;   // b_g1_query[1..][ab_lo..ab_hi) ++ delta_g1     (G1)
+  void* b2_q = nullptr;   // b_g2_query[1..][ab_lo..ab_hi) ++ delta_g2     (G2)
+  void* l_q = nullptr;    // l_query[l_lo..l_hi) ++ delta_g1               (G1)
+  void* h_q = nullptr;    // h_query[h_lo..h_hi)                           (G1)
+  void* fixed = nullptr;  // alpha_g1, a_query[0], beta_g1, b_g1_query[0] (G1 affine) | beta_g2, b_g2_query[0] (G2 affine)
+};
+
+}  // namespace dg16
+
+struct dg16_pk {
+  dg16_ctx* ctx;
+  dg16::PkDev d;
+};
+
+namespace dg16 {
+inline void pk_free(PkDev& d) {
+  for (void* p : {d.a_q, d.b1_q, d.b2_q, d.l_q, d.h_q, d.fixed})
+    if (p) hipFree(p);
+  d = PkDev{};
+}
+}  // namespace dg16

@@ -1,0 +1,23 @@
+// Groth16 prover instantiated for curve id 1 (bls12_381).
+#include "prover_impl.h"
+
+namespace dg16 {
+void pk_build_bls12_381(dg16_ctx* ctx, PkDev& d, const void* a, const void* b1, const void* b2, const void* h, const void* l,
+                 const void* fx, bool dev) { pk_build<1>(ctx, d, a, b1, b2, h, l, fx, dev); }
+void prove_bls12_381(dg16_ctx* ctx, const PkDev& pk, const void* a, const void* b, const void* c, const void* w,
+              const void* rs, bool mont, bool dev, void* out) { prove_typed<1>(ctx, pk, a, b, c, w, rs, mont, dev, out); }
+void msms_bls12_381(dg16_ctx* ctx, Call& k0, Call& k1, Call& k2, const PkDev& pk, const void* a, const void* b, const void* c,
+             const void* w, const void* rs, bool mont, bool dev, uint8_t* res) {
+  msms_typed<1>(ctx, k0, k1, k2, pk, a, b, c, w, rs, mont, dev, res);
+}
+void assemble_bls12_381(Call& k0, const PkDev& pk, const uint8_t* gathered, size_t n_shards, uint8_t* summed, const void* rs,
+                 bool mont, uint8_t* proof) {
+  reduce_results_typed<1>(k0, gathered, n_shards, summed);
+  assemble_typed<1>(k0, pk, summed, rs, mont, proof);
+}
+size_t results_bytes_bls12_381() { return msm_results_bytes<1>(); }
+size_t proof_bytes_bls12_381() {
+  using CT = CurveTypes<1>;
+  return 2 * sizeof(Jacobian<CT::Fq>) + sizeof(Jacobian<CT::Fq2>);
+}
+}  // namespace dg16

@@ -72,6 +72,25 @@ def load():
     L.dg16_groth16_results_bytes.restype = sz
     L.dg16_groth16_msms.argtypes = [vp, vp, vp, vp, vp, vp, vp, u, vp]
     L.dg16_groth16_assemble.argtypes = [vp, vp, vp, sz, vp, u, vp]
+    L.dg16_localnet_create.argtypes = [u, ctypes.POINTER(vp)]
+    L.dg16_localnet_party.argtypes = [vp, u]
+    L.dg16_localnet_party.restype = vp
+    L.dg16_localnet_destroy.argtypes = [vp]
+    L.dg16_localnet_destroy.restype = None
+    L.dg16_pss_create.argtypes = [vp, i, u, ctypes.POINTER(vp)]
+    L.dg16_pss_destroy.argtypes = [vp]
+    L.dg16_pss_destroy.restype = None
+    L.dg16_pss_apply.argtypes = [vp, vp, i, vp, sz, vp, u, i]
+    L.dg16_pss_apply_exp.argtypes = [vp, vp, i, i, vp, sz, vp, u, i]
+    L.dg16_d_fft.argtypes = [vp, vp, vp, vp, sz, u, i, u, i, i, vp, u, i]
+    L.dg16_localnet_abort.argtypes = [vp]
+    L.dg16_localnet_abort.restype = None
+    L.dg16_localnet_reset.argtypes = [vp, u]
+    L.dg16_localnet_reset.restype = None
+    L.dg16_d_msm.argtypes = [vp, vp, vp, i, vp, vp, sz, sz, u, i, vp]
+    L.dg16_deg_red.argtypes = [vp, vp, vp, vp, sz, vp, u, i]
+    L.dg16_d_pp.argtypes = [vp, vp, vp, vp, vp, sz, vp, u, i]
+    L.dg16_ext_wit_h.argtypes = [vp, vp, vp, vp, vp, vp, u, vp, u]
     _lib = L
     return L
 
@@ -80,7 +99,10 @@ EXPORTED = ["dg16_ctx_create", "dg16_ctx_destroy", "dg16_last_error", "dg16_set_
             "dg16_device_info", "dg16_field_op", "dg16_ntt", "dg16_h_poly", "dg16_msm",
             "dg16_gen_bases", "dg16_to_affine", "dg16_last_kernel_ms", "dg16_pk_create", "dg16_pk_destroy",
             "dg16_groth16_prove", "dg16_pk_create_shard", "dg16_groth16_results_bytes", "dg16_groth16_msms",
-            "dg16_groth16_assemble"]
+            "dg16_groth16_assemble", "dg16_localnet_create", "dg16_localnet_party", "dg16_localnet_destroy", "dg16_localnet_abort",
+            "dg16_localnet_reset",
+            "dg16_pss_create", "dg16_pss_destroy", "dg16_pss_apply", "dg16_pss_apply_exp", "dg16_d_fft",
+            "dg16_d_msm", "dg16_deg_red", "dg16_d_pp", "dg16_ext_wit_h"]
 
 
 def _ptr(x):

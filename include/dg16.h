@@ -164,6 +164,80 @@ int dg16_groth16_msms(dg16_ctx *ctx, const dg16_pk *pk, const void *a, const voi
 int dg16_groth16_assemble(dg16_ctx *ctx, const dg16_pk *pk, const void *gathered_results,
                           size_t n_shards, const void *r_s, unsigned flags, void *proof_out);
 
+/* ---- dist-primitives, literally (packed secret sharing over an MpcNet) -----------------------------
+ * These mirror the reference's functions one to one; "party" = one caller (a host thread with its own
+ * dg16_ctx for the in-process LocalNet, or one process per GPU with RCCL-backed callbacks).  All
+ * payloads are device buffers.
+ *
+ *   dg16_pss_create        PackedSharingParams::new(l)                 secret-sharing/src/pss.rs:34-62
+ *   dg16_pss_apply         pack_from_public / unpack / unpack2 (batched) pss.rs:86-148
+ *   dg16_pss_apply_exp     packexp_from_public / unpackexp             dist-primitives/src/dmsm/mod.rs:7-68
+ *   dg16_d_fft             d_fft (inverse = 0) / d_ifft (inverse = 1)  dist-primitives/src/dfft/mod.rs:17-95
+ *                          incl. fft1_in_place :98-140, fft2_in_place :142-182,
+ *                          fft2_with_rearrange_pad :185-256, fft_in_place_rearrange :258-271,
+ *                          pack_vec / transpose utils/pack.rs:4-33
+ *   dg16_d_msm             d_msm                                        dist-primitives/src/dmsm/mod.rs:70-98
+ *   dg16_deg_red           deg_red                                      dist-primitives/src/utils/deg_red.rs:10-28
+ *   dg16_d_pp              d_pp                                         dist-primitives/src/dpp/mod.rs:17-88
+ *   dg16_ext_wit_h         ext_wit::h                                   groth16/src/ext_wit.rs:16-101
+ *   dg16_net               MpcNet's provided gather / scatter           mpc-net/src/lib.rs:61-140
+ *   dg16_localnet_*        LocalTestNet                                 mpc-net/src/multi.rs:227-329
+ */
+typedef struct dg16_pss dg16_pss;
+typedef struct dg16_localnet dg16_localnet;
+
+/* Transport vtable (MpcNet): both collectives are blocking and ordered per channel.  send/recv are
+ * device pointers; `hip_stream` is the stream the payload was produced on (the callee synchronises or
+ * orders on it).  gather: every party contributes `bytes`; on the king (party 0) `recv_dev` receives
+ * n_parties * bytes ordered by party id (client_send_or_king_receive, lib.rs:61-99).  scatter: the king
+ * provides n_parties * bytes in `send_dev`, every party receives its `bytes` (lib.rs:102-140; equal
+ * lengths are enforced by the single `bytes`, as lib.rs:116-124 checks). */
+typedef struct dg16_net {
+  void *self;
+  unsigned (*n_parties)(void *self);
+  unsigned (*party_id)(void *self);
+  int (*gather_to_king)(void *self, int channel, const void *send_dev, size_t bytes, void *recv_dev,
+                        void *hip_stream);
+  int (*scatter_from_king)(void *self, int channel, const void *send_dev, size_t bytes, void *recv_dev,
+                           void *hip_stream);
+} dg16_net;
+
+int dg16_localnet_create(unsigned n_parties, dg16_localnet **out);
+const dg16_net *dg16_localnet_party(dg16_localnet *net, unsigned id);
+void dg16_localnet_destroy(dg16_localnet *net);
+/* A party that fails outside a collective aborts the net: pending and future collectives return
+ * DG16_ERR_NET on every party ("Stream died", mpc-net/src/multi.rs:393) instead of waiting; a
+ * collective that is not joined by all parties within the timeout aborts by itself. */
+void dg16_localnet_abort(dg16_localnet *net);
+void dg16_localnet_reset(dg16_localnet *net, unsigned timeout_s);
+
+int dg16_pss_create(dg16_ctx *ctx, int curve, unsigned l, dg16_pss **out);
+void dg16_pss_destroy(dg16_pss *pp);
+/* which: 0 pack ([count][l] -> [count][n]), 1 unpack ([count][n] -> [count][l]), 2 unpack2 */
+int dg16_pss_apply(dg16_ctx *ctx, const dg16_pss *pp, int which, const void *in, size_t count,
+                   void *out, unsigned flags, int channel);
+/* same on affine group elements ("in the exponent"); group 1 or 2 */
+int dg16_pss_apply_exp(dg16_ctx *ctx, const dg16_pss *pp, int group, int which, const void *in,
+                       size_t count, void *out, unsigned flags, int channel);
+
+/* share: this party's share_len packed shares; share_len * l must equal 2^log_m (the reference's
+ * debug assertion, dfft/mod.rs:31-37) else DG16_ERR_BAD_ARG; out: pad * share_len elements. */
+int dg16_d_fft(dg16_ctx *ctx, const dg16_pss *pp, const dg16_net *net, const void *share,
+               size_t share_len, unsigned log_m, int rearrange, unsigned pad, int degree2, int inverse,
+               void *out, unsigned flags, int channel);
+/* bases / scalars: this party's share vectors; out: Jacobian point, identical on all parties. */
+int dg16_d_msm(dg16_ctx *ctx, const dg16_pss *pp, const dg16_net *net, int group, const void *bases,
+               const void *scalars, size_t n_bases, size_t n_scalars, unsigned flags, int channel,
+               void *out);
+int dg16_deg_red(dg16_ctx *ctx, const dg16_pss *pp, const dg16_net *net, const void *px, size_t count,
+                 void *out, unsigned flags, int channel);
+int dg16_d_pp(dg16_ctx *ctx, const dg16_pss *pp, const dg16_net *net, const void *num, const void *den,
+              size_t count, void *out, unsigned flags, int channel);
+/* a/b/c_share: this party's PackedQAPShare vectors (m/l each); out: m/l packed shares of h.
+ * Uses channel 0 (the reference multiplexes channels 0..2 for the three transforms). */
+int dg16_ext_wit_h(dg16_ctx *ctx, const dg16_pss *pp, const dg16_net *net, const void *a_share,
+                   const void *b_share, const void *c_share, unsigned log_m, void *out, unsigned flags);
+
 /* Duration in milliseconds of the dominant kernel(s) of the most recent call on `channel`
  * (HIP events recorded on the channel's stream); 0 if none.  which: 0 = whole call,
  * 1 = bucket accumulation (MSM) / butterfly passes (NTT). */

@@ -1,0 +1,173 @@
+"""GPU parity of the dist-primitives mirror (PSS, d_fft/d_ifft, d_msm, d_pp, deg_red, ext_wit::h) against
+the line-by-line restatement in oracle/pyref (which itself reproduces the reference's relational tests).
+The protocol is deterministic, so every party's output SHARES must be bit-identical, not only the
+unpacked values.  8 parties (l = 2) as host threads over the in-process LocalTestNet."""
+
+import random
+
+import numpy as np
+import pytest
+
+from oracle import corc
+from oracle.pyref.fields import FQ, FR
+from oracle.pyref.curves import CURVES
+from oracle.pyref.poly import Domain
+from oracle.pyref.pss import PackedSharingParams as RefPSS
+from oracle.pyref import dist as R, groth16 as G
+
+pytestmark = pytest.mark.gpu
+
+_state = {}
+
+
+def parties(curve, l=2):
+    """n contexts + params + net, cached per (curve, l)."""
+    key = (curve, l)
+    if key not in _state:
+        import dg16_amd
+        from dg16_amd import dist as D
+        n = 4 * l
+        ctxs = [dg16_amd.Context(0) for _ in range(n)]
+        pps = [D.PackedSharingParams(c, curve, l) for c in ctxs]
+        _state[key] = (ctxs, pps, D.LocalTestNet(n), D)
+    return _state[key]
+
+
+def enc(F, vals):
+    return corc.ints_to_arr([F.to_mont(v) for v in vals], 4)
+
+
+def dec(F, arr):
+    return [F.from_mont(v) for v in corc.arr_to_ints(np.asarray(arr).reshape(-1, 4))]
+
+
+@pytest.mark.parametrize("curve,l", [("bls12_377", 2), ("bn254", 2), ("bls12_377", 4)])
+def test_pss_pack_unpack(curve, l):
+    F = FR[curve]
+    ctxs, pps, net, D = parties(curve, l)
+    ref = RefPSS(F, l)
+    rng = random.Random(l)
+    cnt = 50
+    secrets = [[rng.randrange(F.p) for _ in range(l)] for _ in range(cnt)]
+    got = pps[0].pack_from_public(np.concatenate([enc(F, s) for s in secrets]))
+    exp = [ref.pack_from_public(s) for s in secrets]
+    assert [dec(F, got[i]) for i in range(cnt)] == exp
+    assert [dec(F, x) for x in pps[0].unpack(got)] == secrets
+    # share-wise product then unpack2 (pss.rs:200-241)
+    other = [[rng.randrange(F.p) for _ in range(l)] for _ in range(cnt)]
+    prod = [[a * b % F.p for a, b in zip(ref.pack_from_public(s), ref.pack_from_public(o))]
+            for s, o in zip(secrets, other)]
+    got2 = pps[0].unpack2(np.concatenate([enc(F, p_) for p_ in prod]))
+    assert [dec(F, x) for x in got2] == [[a * b % F.p for a, b in zip(s, o)] for s, o in zip(secrets, other)]
+
+
+@pytest.mark.parametrize("log_m", [3, 6, 10])
+@pytest.mark.parametrize("inverse", [False, True])
+def test_d_fft_shares_bit_exact(log_m, inverse):
+    curve = "bls12_377"                      # dfft/mod.rs:277
+    F = FR[curve]
+    ctxs, pps, net, D = parties(curve)
+    ref = RefPSS(F, 2)
+    m = 1 << log_m
+    dom = Domain(F, m)
+    rng = random.Random(log_m)
+    x = [rng.randrange(F.p) for _ in range(m)]
+    shares = R.share_for_dfft(x, ref)
+    for rearrange, pad, degree2 in ((False, 1, False), (True, 2, False), (True, 1, False)):
+        fn = R.d_ifft if inverse else R.d_fft
+        exp = fn(shares, rearrange, pad, degree2, dom, ref)
+        got = net.simulate_network_round(
+            lambda i, h: D.d_fft(ctxs[i], pps[i], h, enc(F, shares[i]), log_m, rearrange, pad, degree2, inverse=inverse))
+        assert [dec(F, g) for g in got] == exp, (rearrange, pad)
+    # and the relation the reference asserts: unpacked result == domain.fft / ifft (dfft/mod.rs:373,458)
+    plain = net.simulate_network_round(
+        lambda i, h: D.d_fft(ctxs[i], pps[i], h, enc(F, shares[i]), log_m, False, 1, False, inverse=inverse))
+    per_elem = np.stack(plain, axis=1)       # [m/l][n][4]
+    vals = [v for row in pps[0].unpack(per_elem) for v in dec(F, row)]
+    assert vals == (dom.ifft(x) if inverse else dom.fft(x))
+
+
+def test_d_fft_degree2_and_size_mismatch():
+    import dg16_amd
+    curve = "bn254"
+    F = FR[curve]
+    ctxs, pps, net, D = parties(curve)
+    ref = RefPSS(F, 2)
+    m = 16
+    dom = Domain(F, m)
+    rng = random.Random(1)
+    x = [rng.randrange(F.p) for _ in range(m)]
+    y = [rng.randrange(F.p) for _ in range(m)]
+    sx, sy = R.share_for_dfft(x, ref), R.share_for_dfft(y, ref)
+    prod = [[a * b % F.p for a, b in zip(px, py)] for px, py in zip(sx, sy)]     # degree-2(t+l) shares
+    exp = R.d_fft(prod, False, 1, True, dom, ref)
+    got = net.simulate_network_round(
+        lambda i, h: D.d_fft(ctxs[i], pps[i], h, enc(F, prod[i]), 4, False, 1, True))
+    assert [dec(F, g) for g in got] == exp
+    with pytest.raises(dg16_amd.Dg16Error):     # share.len() * l != dom.size()
+        D.d_fft(ctxs[0], pps[0], net.party(0), enc(F, prod[0]), 5, False, 1, False)
+
+
+@pytest.mark.parametrize("curve,group", [("bls12_377", 1), ("bn254", 1), ("bn254", 2)])
+def test_d_msm_equals_clear_msm(curve, group):
+    # dist-primitives/examples/dmsm_test.rs:62-64 and dmsm/mod.rs:147-193
+    F, Fq = FR[curve], FQ[curve]
+    C = CURVES[curve, "g%d" % group]
+    ctxs, pps, net, D = parties(curve)
+    ref = RefPSS(F, 2)
+    rng = random.Random(9)
+    M = 32
+    pts_arr = corc.gen_points(curve, group, 3, M)
+    sc = [rng.randrange(F.p) for _ in range(M)]
+    clear = corc.msm(curve, group, pts_arr, corc.ints_to_arr(sc, 4))
+    # pack bases in the exponent on the GPU (packexp_from_public) and scalars with pack_from_public
+    packed_bases = pps[0].packexp_from_public(group, pts_arr.reshape(M // 2, 2, -1))    # [M/l][n][..]
+    packed_sc = pps[0].pack_from_public(enc(F, sc).reshape(M // 2, 2, 4))               # [M/l][n][4]
+    got = net.simulate_network_round(
+        lambda i, h: D.d_msm(ctxs[i], pps[i], h, group, packed_bases[:, i], packed_sc[:, i]))
+    aff = [corc.jac_to_affine(curve, group, g) for g in got]
+    assert all(np.array_equal(a, clear) for a in aff)
+    # unpackexp(packexp(x)) == x (dmsm/mod.rs:127-145)
+    back = pps[0].unpackexp(group, packed_bases[:4], False)
+    assert np.array_equal(back.reshape(8, -1), pts_arr[:8])
+
+
+def test_d_pp_and_deg_red():
+    curve = "bls12_377"
+    F = FR[curve]
+    ctxs, pps, net, D = parties(curve)
+    ref = RefPSS(F, 2)
+    rng = random.Random(4)
+    m = 64
+    num = [rng.randrange(1, F.p) for _ in range(m)]
+    den = [rng.randrange(1, F.p) for _ in range(m)]
+    ns = R.transpose(R.pack_vec(num, ref))
+    ds = R.transpose(R.pack_vec(den, ref))
+    exp = R.d_pp(ns, ds, ref)
+    got = net.simulate_network_round(lambda i, h: D.d_pp(ctxs[i], pps[i], h, enc(F, ns[i]), enc(F, ds[i])))
+    assert [dec(F, g) for g in got] == exp
+    prod = [[a * b % F.p for a, b in zip(p_, q_)] for p_, q_ in zip(ns, ds)]
+    exp = R.deg_red(prod, ref)
+    got = net.simulate_network_round(lambda i, h: D.deg_red(ctxs[i], pps[i], h, enc(F, prod[i])))
+    assert [dec(F, g) for g in got] == exp
+
+
+@pytest.mark.parametrize("log_m", [3, 7])
+def test_ext_wit_h_equals_witness_map(log_m):
+    # groth16/src/ext_wit.rs:118-190: distributed h == CircomReduction::witness_map_from_matrices
+    curve = "bn254"
+    F = FR[curve]
+    ctxs, pps, net, D = parties(curve)
+    ref = RefPSS(F, 2)
+    m = 1 << log_m
+    rng = random.Random(log_m)
+    a, b, c = ([rng.randrange(F.p) for _ in range(m)] for _ in range(3))
+    dom = Domain(F, m)
+    qs = G.qap_pss(a, b, c, ref)
+    exp_shares = G.ext_wit_h(qs, dom, ref)
+    got = net.simulate_network_round(
+        lambda i, h: D.ext_wit_h(ctxs[i], pps[i], h, enc(F, qs[i][0]), enc(F, qs[i][1]), enc(F, qs[i][2]), log_m))
+    assert [dec(F, g) for g in got] == exp_shares
+    per_elem = np.stack(got, axis=1)
+    vals = [v for row in pps[0].unpack(per_elem) for v in dec(F, row)]
+    assert vals == G.witness_map_from_abc(a, b, c, dom)
