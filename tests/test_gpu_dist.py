@@ -171,3 +171,35 @@ def test_ext_wit_h_equals_witness_map(log_m):
     per_elem = np.stack(got, axis=1)
     vals = [v for row in pps[0].unpack(per_elem) for v in dec(F, row)]
     assert vals == G.witness_map_from_abc(a, b, c, dom)
+
+
+def test_mpc_prove_equals_single_prover():
+    """groth16/examples/sha256.rs: the 8-party proof (after adding a_query[0] + alpha etc. on the
+    client, :208-212) equals the single-prover proof with r = s = 0; all on the GPU, checked against
+    the big-int prover."""
+    from dg16_amd import groth16_mpc as M
+    from test_gpu_prover import enc_g1, enc_g2, dec_g1, dec_g2
+    curve = "bn254"
+    F, Fq = FR[curve], FQ[curve]
+    ctxs, pps, net, D = parties(curve)
+    r1cs, w = G.synthetic_r1cs(F, num_constraints=13, num_instance=2, num_witness=17, seed=3)
+    rng = random.Random(5)
+    td = tuple(rng.randrange(1, F.p) for _ in range(5))
+    pk, _ = G.setup(curve, r1cs, td)
+    a, b, c, dom = G.qap(r1cs, w, F)
+    hpk = {k: enc_g1(Fq, pk[k]) for k in ("a_query", "b_g1_query", "h_query", "l_query")}
+    hpk["b_g2_query"] = enc_g2(Fq, pk["b_g2_query"])
+    crs = M.pack_from_arkworks_proving_key(pps[0], hpk)
+    qs = M.qap_pss(pps[0], enc(F, a), enc(F, b), enc(F, c))
+    a_sh = M.pack_from_witness(pps[0], enc(F, w[1:]))
+    ax_sh = M.pack_from_witness(pps[0], enc(F, w[2:]))
+    log_m = dom.size.bit_length() - 1
+    res = net.simulate_network_round(
+        lambda i, h: M.party_prove(ctxs[i], pps[i], h, crs[i], qs[i], a_sh[i], ax_sh[i], log_m))
+    pi_a, pi_b, (wv, uv) = res[0]
+    g1, g2 = CURVES[curve, "g1"], CURVES[curve, "g2"]
+    A = g1.add(dec_g1(Fq, corc.jac_to_affine(curve, 1, pi_a)), g1.add(pk["a_query"][0], pk["alpha_g1"]))
+    B = g2.add(dec_g2(Fq, corc.jac_to_affine(curve, 2, pi_b)), g2.add(pk["b_g2_query"][0], pk["beta_g2"]))
+    C = g1.add(dec_g1(Fq, corc.jac_to_affine(curve, 1, wv)), dec_g1(Fq, corc.jac_to_affine(curve, 1, uv)))
+    assert (A, B, C) == G.create_proof(curve, pk, 0, 0, r1cs, w)
+    assert all(np.array_equal(r[0], res[0][0]) for r in res)      # same point on every party
