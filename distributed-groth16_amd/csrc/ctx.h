@@ -84,7 +84,7 @@ inline void* ws(Channel& c, int slot, size_t bytes) {
   if (bytes == 0) bytes = 16;
   if (c.slot_bytes[slot] < bytes) {
     if (c.slot[slot]) {
-      DG_HIP(hipStreamSynchronize(c.cur));
+      DG_HIP(hipDeviceSynchronize());   // other streams may still read the old buffer (prover pipelines)
       DG_HIP(hipFree(c.slot[slot]));
       c.slot[slot] = nullptr;
       c.slot_bytes[slot] = 0;

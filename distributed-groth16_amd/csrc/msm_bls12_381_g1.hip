@@ -18,22 +18,22 @@ void d_msm_bls12_381_g1(Call& k, const dg16_pss* pp, const dg16_net* net, int si
   using F = CT::Fq;
   using Fr = CT::Fr;
   const unsigned np = pp->n;
-  Affine<F>* c_share = (Affine<F>*)ws(k.c, 9, sizeof(Affine<F>));
+  Affine<F>* c_share = (Affine<F>*)ws(k.c, 18, sizeof(Affine<F>));
   msm_run<F, Fr, CT::SCALAR_BITS>(k, bases, scalars, n, mont, true, c_share);          // dmsm/mod.rs:82
   const bool king = net->party_id(net->self) == 0;
-  Affine<F>* shares = king ? (Affine<F>*)ws(k.c, 10, np * sizeof(Affine<F>)) : nullptr;
+  Affine<F>* shares = king ? (Affine<F>*)ws(k.c, 19, np * sizeof(Affine<F>)) : nullptr;
   if (net->gather_to_king(net->self, sid, c_share, sizeof(Affine<F>), shares, k.s()) != DG16_OK)
     throw StatusError{DG16_ERR_NET, "send_to_king failed"};
   Affine<F>* send = nullptr;
   if (king) {
-    send = (Affine<F>*)ws(k.c, 11, np * sizeof(Affine<F>));
+    send = (Affine<F>*)ws(k.c, 20, np * sizeof(Affine<F>));
     const Fr* v2 = (const Fr*)pp->mats + 6 * pp->n * pp->l;
     hipLaunchKernelGGL((matvec_points_kernel<F, Fr>), dim3(1), dim3(64), 0, k.s(), v2, 1u, np, shares, send, (size_t)1);
     for (unsigned p = 1; p < np; p++)   // vec![output; n_parties] (dmsm/mod.rs:94)
       DG_HIP(hipMemcpyAsync(send + p, send, sizeof(Affine<F>), hipMemcpyDeviceToDevice, k.s()));
     DG_HIP(hipGetLastError());
   }
-  Affine<F>* got = (Affine<F>*)ws(k.c, 12, sizeof(Affine<F>));
+  Affine<F>* got = (Affine<F>*)ws(k.c, 21, sizeof(Affine<F>));
   if (net->scatter_from_king(net->self, sid, send, sizeof(Affine<F>), got, k.s()) != DG16_OK)
     throw StatusError{DG16_ERR_NET, "recv_from_king failed"};
   hipLaunchKernelGGL(affine_to_jacobian_kernel<F>, dim3(1), dim3(1), 0, k.s(), got, (Jacobian<F>*)out_jac);

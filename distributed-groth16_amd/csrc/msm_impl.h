@@ -28,29 +28,56 @@
 
 namespace dg16 {
 
-constexpr unsigned kSegLog = 4;          // entries per accumulation segment = 16
-constexpr unsigned kSeg = 1u << kSegLog;
-constexpr unsigned kGiantSegs = 32;      // buckets with more segments are reduced by a whole workgroup
+// Accumulation segments: a lane sums <= 2^seg_log consecutive entries of one bucket.  seg_log follows the
+// mean bucket occupancy (mean/4, clamped to 16..128): 16 when buckets hold ~32 points (32 measured 20 %
+// slower there: lanes idle behind the longest segment of their wave), larger when buckets are large
+// (table mode), which keeps the number of partials per bucket -- the finalize work -- small.
+constexpr unsigned kMinSegLog = 4, kMaxSegLog = 7;
+constexpr unsigned kGiantSegs = 64;      // buckets with more segments are reduced by a whole workgroup
 
 struct MsmGeom {
   unsigned c;        // window bits
-  unsigned nwin;     // W
-  unsigned log_nb;   // log2 buckets per window = c - 1
-  unsigned seg_cap;  // segment slots per window = 2^log_nb + ceil(n / kSeg)
+  unsigned nwin;     // W: signed digits per scalar
+  unsigned log_nb;   // log2 buckets per bucket-window = c - 1
+  unsigned seg_log;  // log2 entries per accumulation segment
+  unsigned seg_cap;  // segment slots per bucket-window
+  unsigned bw;       // bucket-windows: W, or 1 in table mode (all digits share one bucket set)
+  unsigned table;    // 1: bases are a table T[w*n + i] = 2^(c*w) * P_i (resident keys)
+  size_t region;     // entries per bucket-window: n, or W*n in table mode
 };
 
-inline MsmGeom msm_geometry(size_t n, unsigned scalar_bits) {
+// window size: plain mode keeps ~32 points per bucket; table mode has a single bucket set of W*n entries:
+// c = log2(n) - 3 keeps the bucket reduction at a few percent of the MSM (measured at 2^20: c = 17 beats
+// both 16 and 20)
+inline unsigned msm_window_bits(size_t n, bool table) {
   unsigned lg = 0;
   while (((size_t)1 << (lg + 1)) <= n) lg++;
-  int c = (int)lg - 4;
-  if (const char* e = getenv("DG16_MSM_C")) c = atoi(e);
+  if (n > ((size_t)3 << lg) / 2) lg++;     // nearest power of two (2^20 - 5 points are "2^20")
+  int c = table ? (int)lg - 3 : (int)lg - 4;
+  if (const char* e = getenv(table ? "DG16_MSM_TABLE_C" : "DG16_MSM_C")) c = atoi(e);
+  int hi = table ? 20 : 16;
   if (c < 4) c = 4;
-  if (c > 16) c = 16;
+  if (c > hi) c = hi;
+  return (unsigned)c;
+}
+
+inline MsmGeom msm_geometry(size_t n, unsigned scalar_bits, bool table = false, unsigned c_fixed = 0) {
   MsmGeom g;
-  g.c = (unsigned)c;
+  g.c = c_fixed ? c_fixed : msm_window_bits(n, table);
   g.nwin = (scalar_bits + 1 + g.c - 1) / g.c;   // one spare bit absorbs the last carry
   g.log_nb = g.c - 1;
-  g.seg_cap = (1u << g.log_nb) + (unsigned)((n + kSeg - 1) >> kSegLog);
+  g.table = table ? 1u : 0u;
+  g.bw = table ? 1u : g.nwin;
+  g.region = table ? (size_t)g.nwin * n : n;
+  {
+    size_t mean = g.region >> g.log_nb;   // entries per bucket
+    unsigned lm = 0;
+    while (((size_t)2 << lm) <= mean) lm++;
+    int sl = (int)lm - 2;
+    if (const char* e = getenv("DG16_MSM_SEG_LOG")) sl = atoi(e);
+    g.seg_log = (unsigned)(sl < (int)kMinSegLog ? (int)kMinSegLog : sl > (int)kMaxSegLog ? (int)kMaxSegLog : sl);
+  }
+  g.seg_cap = (1u << g.log_nb) + (unsigned)((g.region + (1u << g.seg_log) - 1) >> g.seg_log);
   return g;
 }
 
@@ -80,32 +107,33 @@ __global__ void __launch_bounds__(256) msm_digits_kernel(const Fr* __restrict__ 
     digits[(size_t)w * n + i] = d;
     if (d != 0) {
       unsigned b = (unsigned)(d < 0 ? -d : d) - 1;
-      atomicAdd(&counts[((size_t)w << g.log_nb) + b], 1u);
+      atomicAdd(&counts[(g.table ? (size_t)0 : ((size_t)w << g.log_nb)) + b], 1u);
     }
   }
 }
 
-// ---- 2: per-window exclusive scan (one 1024-thread workgroup per window) ------------------------
-// (templated only so that every translation unit carries its own copy of the kernel)
+// ---- 2: per-bucket-window exclusive scans (entry offsets and segment offsets), three small launches ---
+// (kernels are templated on a dummy so that every translation unit carries its own copy)
+constexpr unsigned kScanBlock = 4096;   // buckets per workgroup (1024 threads x 4)
 template <int TU>
-__global__ void __launch_bounds__(1024) msm_scan_kernel(const unsigned* __restrict__ counts,
-                                                         unsigned* __restrict__ offsets,
-                                                         unsigned* __restrict__ seg_off,
-                                                         unsigned* __restrict__ seg_total,
-                                                         unsigned* __restrict__ cursor, unsigned log_nb) {
+__global__ void __launch_bounds__(1024) msm_scan_local_kernel(const unsigned* __restrict__ counts,
+                                                               unsigned* __restrict__ offsets,
+                                                               unsigned* __restrict__ seg_off,
+                                                               unsigned* __restrict__ block_tot, unsigned log_nb,
+                                                               unsigned seg_log) {
   __shared__ unsigned sh[1024];
   __shared__ unsigned sh2[1024];
   const unsigned nb = 1u << log_nb;
-  const unsigned ipt = (nb + 1023) / 1024;
-  const size_t base = (size_t)blockIdx.x << log_nb;
-  const unsigned lo = threadIdx.x * ipt;
-  unsigned sum = 0, ssum = 0;
-  for (unsigned j = 0; j < ipt; j++)
-    if (lo + j < nb) {
-      unsigned cn = counts[base + lo + j];
-      sum += cn;
-      ssum += (cn + kSeg - 1) >> kSegLog;
-    }
+  const unsigned seg_round = (1u << seg_log) - 1;
+  const size_t base = (size_t)blockIdx.y << log_nb;
+  const unsigned lo = blockIdx.x * kScanBlock + threadIdx.x * 4;
+  unsigned cn[4], sum = 0, ssum = 0;
+#pragma unroll
+  for (unsigned j = 0; j < 4; j++) {
+    cn[j] = (lo + j < nb) ? counts[base + lo + j] : 0;
+    sum += cn[j];
+    ssum += (cn[j] + seg_round) >> seg_log;
+  }
   sh[threadIdx.x] = sum;
   sh2[threadIdx.x] = ssum;
   __syncthreads();
@@ -117,18 +145,64 @@ __global__ void __launch_bounds__(1024) msm_scan_kernel(const unsigned* __restri
     sh2[threadIdx.x] += v2;
     __syncthreads();
   }
-  unsigned run = sh[threadIdx.x] - sum;   // exclusive prefix of this thread's segment
-  unsigned srun = sh2[threadIdx.x] - ssum;
-  for (unsigned j = 0; j < ipt; j++)
+  unsigned run = sh[threadIdx.x] - sum, srun = sh2[threadIdx.x] - ssum;
+#pragma unroll
+  for (unsigned j = 0; j < 4; j++)
     if (lo + j < nb) {
-      unsigned cn = counts[base + lo + j];
       offsets[base + lo + j] = run;
       seg_off[base + lo + j] = srun;
-      cursor[base + lo + j] = 0;
-      run += cn;
-      srun += (cn + kSeg - 1) >> kSegLog;
+      run += cn[j];
+      srun += (cn[j] + seg_round) >> seg_log;
     }
+  if (threadIdx.x == 1023) {
+    size_t t = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 2;
+    block_tot[t] = sh[1023];
+    block_tot[t + 1] = sh2[1023];
+  }
+}
+// one workgroup per bucket-window: exclusive scan of the (<= 1024) block totals
+template <int TU>
+__global__ void __launch_bounds__(1024) msm_scan_tops_kernel(unsigned* __restrict__ block_tot, unsigned nblocks,
+                                                              unsigned* __restrict__ seg_total) {
+  __shared__ unsigned sh[1024];
+  __shared__ unsigned sh2[1024];
+  unsigned* t = block_tot + (size_t)blockIdx.x * nblocks * 2;
+  unsigned a = threadIdx.x < nblocks ? t[threadIdx.x * 2] : 0;
+  unsigned b = threadIdx.x < nblocks ? t[threadIdx.x * 2 + 1] : 0;
+  sh[threadIdx.x] = a;
+  sh2[threadIdx.x] = b;
+  __syncthreads();
+  for (unsigned d = 1; d < 1024; d <<= 1) {
+    unsigned v = threadIdx.x >= d ? sh[threadIdx.x - d] : 0;
+    unsigned v2 = threadIdx.x >= d ? sh2[threadIdx.x - d] : 0;
+    __syncthreads();
+    sh[threadIdx.x] += v;
+    sh2[threadIdx.x] += v2;
+    __syncthreads();
+  }
+  if (threadIdx.x < nblocks) {
+    t[threadIdx.x * 2] = sh[threadIdx.x] - a;
+    t[threadIdx.x * 2 + 1] = sh2[threadIdx.x] - b;
+  }
   if (threadIdx.x == 1023) seg_total[blockIdx.x] = sh2[1023];
+}
+template <int TU>
+__global__ void __launch_bounds__(1024) msm_scan_fix_kernel(unsigned* __restrict__ offsets,
+                                                             unsigned* __restrict__ seg_off,
+                                                             unsigned* __restrict__ cursor,
+                                                             const unsigned* __restrict__ block_tot, unsigned log_nb) {
+  const unsigned nb = 1u << log_nb;
+  const size_t base = (size_t)blockIdx.y << log_nb;
+  const size_t t = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 2;
+  const unsigned add = block_tot[t], sadd = block_tot[t + 1];
+  const unsigned lo = blockIdx.x * kScanBlock + threadIdx.x * 4;
+#pragma unroll
+  for (unsigned j = 0; j < 4; j++)
+    if (lo + j < nb) {
+      offsets[base + lo + j] += add;
+      seg_off[base + lo + j] += sadd;
+      cursor[base + lo + j] = 0;
+    }
 }
 
 // ---- 3: scatter ---------------------------------------------------------------------------------
@@ -145,10 +219,13 @@ __global__ void __launch_bounds__(256) msm_scatter_kernel(const int* __restrict_
     int d = digits[(size_t)w * n + i];
     if (d == 0) continue;
     unsigned b = (unsigned)(d < 0 ? -d : d) - 1;
-    size_t slot = ((size_t)w << g.log_nb) + b;
+    const unsigned bwin = g.table ? 0u : w;
+    size_t slot = ((size_t)bwin << g.log_nb) + b;
     unsigned rank = atomicAdd(&cursor[slot], 1u);
-    entries[(size_t)w * n + offsets[slot] + rank] = (unsigned)i | (d < 0 ? 0x80000000u : 0u);
-    if ((rank & (kSeg - 1)) == 0) seg_bucket[(size_t)w * g.seg_cap + seg_off[slot] + (rank >> kSegLog)] = b;
+    unsigned ref = g.table ? (unsigned)((size_t)w * n + i) : (unsigned)i;   // table row 2^(c*w) * P_i
+    entries[(size_t)bwin * g.region + offsets[slot] + rank] = ref | (d < 0 ? 0x80000000u : 0u);
+    if ((rank & ((1u << g.seg_log) - 1)) == 0)
+      seg_bucket[(size_t)bwin * g.seg_cap + seg_off[slot] + (rank >> g.seg_log)] = b;
   }
 }
 
@@ -168,10 +245,10 @@ __global__ void __launch_bounds__(256) msm_accumulate_kernel(const Affine<F>* __
   const size_t sslot = (size_t)w * g.seg_cap + t;
   const unsigned b = seg_bucket[sslot];
   const size_t bslot = ((size_t)w << g.log_nb) + b;
-  const unsigned first = (t - seg_off[bslot]) << kSegLog;   // rank of this segment's first entry
+  const unsigned first = (t - seg_off[bslot]) << g.seg_log;   // rank of this segment's first entry
   unsigned cnt = counts[bslot] - first;
-  if (cnt > kSeg) cnt = kSeg;
-  const unsigned* e = entries + (size_t)w * n + offsets[bslot] + first;
+  if (cnt > (1u << g.seg_log)) cnt = 1u << g.seg_log;
+  const unsigned* e = entries + (size_t)w * g.region + offsets[bslot] + first;
   // No software prefetch of the point: holding a second Affine<F> costs 16..64 VGPRs (occupancy for
   // G1; for G2 hipcc parked both copies in scratch and serialised every 16-byte piece behind
   // vmcnt(0)).  Only the 4-byte entry index is fetched one iteration ahead.
@@ -195,10 +272,10 @@ __global__ void __launch_bounds__(256) msm_finalize_kernel(MsmGeom g, const unsi
                                                             unsigned* __restrict__ giant_count,
                                                             unsigned* __restrict__ giant_list, unsigned giant_cap) {
   size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  size_t total = (size_t)g.nwin << g.log_nb;
+  size_t total = (size_t)g.bw << g.log_nb;
   if (gid >= total) return;
   const unsigned w = (unsigned)(gid >> g.log_nb);
-  const unsigned nseg = (counts[gid] + kSeg - 1) >> kSegLog;
+  const unsigned nseg = (counts[gid] + (1u << g.seg_log) - 1) >> g.seg_log;
   if (nseg == 0) { buckets[gid] = XYZZ<F>::inf(); return; }
   const XYZZ<F>* sp = seg_sum + (size_t)w * g.seg_cap + seg_off[gid];
   if (nseg == 1) { buckets[gid] = sp[0]; return; }
@@ -225,7 +302,7 @@ __global__ void __launch_bounds__(256) msm_giant_kernel(MsmGeom g, const unsigne
   for (unsigned gi = blockIdx.x; gi < ng; gi += gridDim.x) {
     const unsigned gid = giant_list[gi];
     const unsigned w = gid >> g.log_nb;
-    const unsigned nseg = (counts[gid] + kSeg - 1) >> kSegLog;
+    const unsigned nseg = (counts[gid] + (1u << g.seg_log) - 1) >> g.seg_log;
     const XYZZ<F>* sp = seg_sum + (size_t)w * g.seg_cap + seg_off[gid];
     XYZZ<F> acc = XYZZ<F>::inf();
     for (unsigned s = threadIdx.x; s < nseg; s += 256) acc = acc.add(sp[s]);
@@ -254,6 +331,9 @@ __device__ XYZZ<F> mul_small(const XYZZ<F>& p, unsigned k) {
 }
 
 // ---- 5a: chunks of 2^kChunkLog buckets -> one weighted partial each -----------------------------
+// (A recursive running-sum scheme without the per-chunk scalar multiple does 2.4x fewer group operations
+// but chains ~200 dependent ones through a dozen small launches; measured 4x slower per MSM.  Keeping the
+// bucket count moderate -- c <= 17 in table mode -- makes this phase ~3 % of an MSM instead.)
 constexpr unsigned kChunkLog = 3;
 template <class F>
 __global__ void __launch_bounds__(256) msm_chunk_kernel(const XYZZ<F>* __restrict__ buckets, MsmGeom g,
@@ -261,7 +341,7 @@ __global__ void __launch_bounds__(256) msm_chunk_kernel(const XYZZ<F>* __restric
   const unsigned log_chunks = g.log_nb > kChunkLog ? g.log_nb - kChunkLog : 0;
   const unsigned L = 1u << (g.log_nb - log_chunks);
   size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  size_t total = (size_t)g.nwin << log_chunks;
+  size_t total = (size_t)g.bw << log_chunks;
   if (gid >= total) return;
   size_t w = gid >> log_chunks;
   unsigned ch = (unsigned)(gid & (((size_t)1 << log_chunks) - 1));
@@ -277,28 +357,32 @@ __global__ void __launch_bounds__(256) msm_chunk_kernel(const XYZZ<F>* __restric
   partial[gid] = acc;
 }
 
-// ---- 5b: per-window sum of the partials (one workgroup per window) --------------------------------
+// plain sums: grid (slices, windows); one workgroup reduces `per_block` consecutive elements
 template <class F>
-__global__ void __launch_bounds__(256) msm_window_sum_kernel(const XYZZ<F>* __restrict__ partial, unsigned count,
-                                                              XYZZ<F>* __restrict__ window_sums) {
+__global__ void __launch_bounds__(256) msm_sum_kernel(const XYZZ<F>* __restrict__ in, unsigned in_stride,
+                                                       unsigned count, unsigned per_block,
+                                                       XYZZ<F>* __restrict__ out, unsigned out_stride,
+                                                       unsigned out_offset) {
   __shared__ XYZZ<F> sh[256];
-  const XYZZ<F>* p = partial + (size_t)blockIdx.x * count;
+  const XYZZ<F>* p = in + (size_t)blockIdx.y * in_stride;
+  unsigned lo = blockIdx.x * per_block;
+  unsigned hi = lo + per_block < count ? lo + per_block : count;
   XYZZ<F> acc = XYZZ<F>::inf();
-  for (unsigned i = threadIdx.x; i < count; i += 256) acc = acc.add(p[i]);
+  for (unsigned i = lo + threadIdx.x; i < hi; i += 256) acc = acc.add(p[i]);
   sh[threadIdx.x] = acc;
   __syncthreads();
   for (unsigned stride = 128; stride > 0; stride >>= 1) {
     if (threadIdx.x < stride) sh[threadIdx.x] = sh[threadIdx.x].add(sh[threadIdx.x + stride]);
     __syncthreads();
   }
-  if (threadIdx.x == 0) window_sums[blockIdx.x] = sh[0];
+  if (threadIdx.x == 0) out[(size_t)blockIdx.y * out_stride + out_offset + blockIdx.x] = sh[0];
 }
 
 // ---- 6: Horner tail ---------------------------------------------------------------------------------
 template <class F>
 __global__ void msm_tail_kernel(const XYZZ<F>* __restrict__ window_sums, MsmGeom g, int affine, F* __restrict__ out) {
   XYZZ<F> total = XYZZ<F>::inf();
-  for (int w = (int)g.nwin - 1; w >= 0; w--) {
+  for (int w = (int)g.bw - 1; w >= 0; w--) {
     for (unsigned k = 0; k < g.c; k++) total = total.dbl();
     total = total.add(window_sums[w]);
   }
@@ -314,63 +398,202 @@ __global__ void msm_tail_kernel(const XYZZ<F>* __restrict__ window_sums, MsmGeom
   }
 }
 
+// Result of the scalar-side passes (digits, scan, scatter): shared by every MSM over the same scalars.
+struct MsmSort {
+  MsmGeom g;
+  size_t n = 0;
+  int* digits = nullptr;
+  unsigned *entries = nullptr, *counts = nullptr, *offsets = nullptr, *seg_off = nullptr, *cursor = nullptr;
+  unsigned *seg_total = nullptr, *seg_bucket = nullptr;
+};
+
+template <class Fr, int SCALAR_BITS>
+MsmSort msm_sort_on(hipStream_t s, Channel& wsch, const void* scalars, size_t n, bool scalars_mont, bool table,
+                    unsigned c_fixed);
+template <class Fr, int SCALAR_BITS>
+MsmSort msm_sort(Call& k, const void* scalars, size_t n, bool scalars_mont, bool table, unsigned c_fixed = 0) {
+  return msm_sort_on<Fr, SCALAR_BITS>(k.s(), k.c, scalars, n, scalars_mont, table, c_fixed);
+}
+// sort on stream `s` with the buffers of channel `wsch`
+template <class Fr, int SCALAR_BITS>
+MsmSort msm_sort_on(hipStream_t s, Channel& wsch, const void* scalars, size_t n, bool scalars_mont, bool table,
+                    unsigned c_fixed) {
+  MsmSort r;
+  r.n = n;
+  r.g = msm_geometry(n ? n : 1, SCALAR_BITS, table, c_fixed);
+  const MsmGeom& g = r.g;
+  const size_t nbw = (size_t)g.bw << g.log_nb;
+  const size_t nseg_slots = (size_t)g.bw * g.seg_cap;
+  DG_REQUIRE((size_t)g.nwin * n < ((size_t)1 << 31), DG16_ERR_BAD_ARG, "W * n must be < 2^31");
+  r.digits = (int*)ws(wsch, 4, (size_t)g.nwin * n * 4);
+  r.entries = (unsigned*)ws(wsch, 5, (size_t)g.nwin * n * 4);
+  unsigned* tabs = (unsigned*)ws(wsch, 6, (nbw * 4 + g.bw + nseg_slots) * 4);
+  r.counts = tabs;
+  r.offsets = r.counts + nbw;
+  r.seg_off = r.offsets + nbw;
+  r.cursor = r.seg_off + nbw;
+  r.seg_total = r.cursor + nbw;
+  r.seg_bucket = r.seg_total + g.bw;
+  DG_HIP(hipMemsetAsync(r.counts, 0, nbw * 4, s));
+  if (n)
+    hipLaunchKernelGGL(msm_digits_kernel<Fr>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const Fr*)scalars,
+                       n, (int)scalars_mont, g, r.digits, r.counts);
+  {
+    const unsigned nblocks = ((1u << g.log_nb) + kScanBlock - 1) / kScanBlock;   // <= 512 for c <= 22
+    unsigned* block_tot = (unsigned*)ws(wsch, 9, (size_t)g.bw * nblocks * 2 * 4);
+    hipLaunchKernelGGL(msm_scan_local_kernel<0>, dim3(nblocks, g.bw), dim3(1024), 0, s, r.counts, r.offsets,
+                       r.seg_off, block_tot, g.log_nb, g.seg_log);
+    hipLaunchKernelGGL(msm_scan_tops_kernel<0>, dim3(g.bw), dim3(1024), 0, s, block_tot, nblocks, r.seg_total);
+    hipLaunchKernelGGL(msm_scan_fix_kernel<0>, dim3(nblocks, g.bw), dim3(1024), 0, s, r.offsets, r.seg_off, r.cursor,
+                       block_tot, g.log_nb);
+  }
+  if (n)
+    hipLaunchKernelGGL(msm_scatter_kernel<0>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, r.digits, n, g,
+                       r.offsets, r.seg_off, r.cursor, r.entries, r.seg_bucket);
+  DG_HIP(hipGetLastError());
+  return r;
+}
+
+// Workspace of one MSM's bucket phases (lives in `wsch`'s slots 7, 17, 15, 10 until the reduction is done).
+template <class F>
+struct MsmBuffers {
+  XYZZ<F>* buckets;
+  XYZZ<F>* seg_sum;
+  XYZZ<F>* partial;
+  XYZZ<F>* slice_buf;
+  XYZZ<F>* window_sums;
+  unsigned* giant;
+  unsigned giant_cap, chunks, log_chunks;
+  size_t nbw, nchunks;
+};
+constexpr unsigned kSumSlices = 64;
+
+template <class F>
+MsmBuffers<F> msm_buffers(Channel& wsch, const MsmGeom& g) {
+  MsmBuffers<F> b;
+  b.nbw = (size_t)g.bw << g.log_nb;
+  const size_t nseg_slots = (size_t)g.bw * g.seg_cap;
+  b.giant_cap = (unsigned)(nseg_slots / kGiantSegs + 1);
+  b.buckets = (XYZZ<F>*)ws(wsch, 7, b.nbw * sizeof(XYZZ<F>));
+  b.seg_sum = (XYZZ<F>*)ws(wsch, 17, nseg_slots * sizeof(XYZZ<F>));
+  b.log_chunks = g.log_nb > kChunkLog ? g.log_nb - kChunkLog : 0;
+  b.chunks = 1u << b.log_chunks;
+  b.nchunks = (size_t)g.bw << b.log_chunks;
+  b.partial = (XYZZ<F>*)ws(wsch, 15, (b.nchunks + (size_t)g.bw * kSumSlices + g.bw) * sizeof(XYZZ<F>));
+  b.slice_buf = b.partial + b.nchunks;
+  b.window_sums = b.slice_buf + (size_t)g.bw * kSumSlices;
+  b.giant = (unsigned*)ws(wsch, 10, (b.giant_cap + 1) * 4);   // [0] = count, [1..] = bucket ids
+  return b;
+}
+
+// Phase A (saturates the GPU): segment accumulation.  `bases` is the plain array (n points) or, in table
+// mode, the table of W*n points.
+template <class F>
+void msm_accumulate_phase(hipStream_t s, const MsmSort& st, const MsmBuffers<F>& b, const void* bases) {
+  const MsmGeom& g = st.g;
+  hipLaunchKernelGGL(msm_accumulate_kernel<F>, dim3((g.seg_cap + 255) / 256, g.bw), dim3(256), 0, s,
+                     (const Affine<F>*)bases, st.n, g, st.offsets, st.counts, st.seg_off, st.seg_total, st.seg_bucket,
+                     st.entries, b.seg_sum);
+  DG_HIP(hipGetLastError());
+}
+
+// Phase B (latency-bound, few waves): finalize -> chunk sums -> window sums -> tail.  May run on another
+// stream than phase A so that it hides behind the next MSM's accumulation.
+template <class F>
+void msm_bucket_phase(hipStream_t s, const MsmSort& st, const MsmBuffers<F>& b, bool out_affine, void* out_dev) {
+  const MsmGeom& g = st.g;
+  DG_HIP(hipMemsetAsync(b.giant, 0, 4, s));
+  hipLaunchKernelGGL(msm_finalize_kernel<F>, dim3((unsigned)((b.nbw + 255) / 256)), dim3(256), 0, s, g, st.counts,
+                     st.seg_off, b.seg_sum, b.buckets, b.giant, b.giant + 1, b.giant_cap);
+  {
+    unsigned gblocks = b.giant_cap < 64 ? b.giant_cap : 64;
+    hipLaunchKernelGGL(msm_giant_kernel<F>, dim3(gblocks), dim3(256), 0, s, g, st.counts, st.seg_off, b.seg_sum,
+                       b.buckets, b.giant, b.giant + 1, b.giant_cap);
+  }
+  hipLaunchKernelGGL(msm_chunk_kernel<F>, dim3((unsigned)((b.nchunks + 255) / 256)), dim3(256), 0, s, b.buckets, g,
+                     b.partial);
+  {
+    // two-stage plain sum of the chunk partials of every window
+    unsigned per_block = (b.chunks + kSumSlices - 1) / kSumSlices;
+    if (per_block < 256) per_block = 256;
+    unsigned slices = (b.chunks + per_block - 1) / per_block;
+    if (slices > 1) {
+      hipLaunchKernelGGL(msm_sum_kernel<F>, dim3(slices, g.bw), dim3(256), 0, s, b.partial, b.chunks, b.chunks,
+                         per_block, b.slice_buf, kSumSlices, 0u);
+      hipLaunchKernelGGL(msm_sum_kernel<F>, dim3(1, g.bw), dim3(256), 0, s, b.slice_buf, kSumSlices, slices, slices,
+                         b.window_sums, 1u, 0u);
+    } else {
+      hipLaunchKernelGGL(msm_sum_kernel<F>, dim3(1, g.bw), dim3(256), 0, s, b.partial, b.chunks, b.chunks, b.chunks,
+                         b.window_sums, 1u, 0u);
+    }
+  }
+  hipLaunchKernelGGL(msm_tail_kernel<F>, dim3(1), dim3(1), 0, s, b.window_sums, g, (int)out_affine, (F*)out_dev);
+  DG_HIP(hipGetLastError());
+}
+
+// both phases on the call's own stream and workspace
+template <class F>
+void msm_reduce(Call& k, const MsmSort& st, const void* bases, bool out_affine, void* out_dev) {
+  MsmBuffers<F> b = msm_buffers<F>(k.c, st.g);
+  k.begin_dominant();
+  msm_accumulate_phase<F>(k.s(), st, b, bases);
+  k.end_dominant();
+  msm_bucket_phase<F>(k.s(), st, b, out_affine, out_dev);
+}
+
 template <class F, class Fr, int SCALAR_BITS>
 void msm_run(Call& k, const void* bases, const void* scalars, size_t n, bool scalars_mont, bool out_affine,
              void* out_dev) {
-  hipStream_t s = k.s();
-  MsmGeom g = msm_geometry(n ? n : 1, SCALAR_BITS);
-  const size_t nbw = (size_t)g.nwin << g.log_nb;   // buckets over all windows
-  const size_t nseg_slots = (size_t)g.nwin * g.seg_cap;
-  const unsigned giant_cap = (unsigned)(nseg_slots / kGiantSegs + 1);
-  int* digits = (int*)ws(k.c, 4, (size_t)g.nwin * n * 4);
-  unsigned* entries = (unsigned*)ws(k.c, 5, (size_t)g.nwin * n * 4);
-  // u32 tables: counts | offsets | seg_off | cursor | seg_total[W] | giant_count | giant_list | seg_bucket
-  unsigned* tabs = (unsigned*)ws(k.c, 6, (nbw * 4 + g.nwin + 1 + giant_cap + nseg_slots) * 4);
-  unsigned* counts = tabs;
-  unsigned* offsets = counts + nbw;
-  unsigned* seg_off = offsets + nbw;
-  unsigned* cursor = seg_off + nbw;
-  unsigned* seg_total = cursor + nbw;
-  unsigned* giant_count = seg_total + g.nwin;
-  unsigned* giant_list = giant_count + 1;
-  unsigned* seg_bucket = giant_list + giant_cap;
-  XYZZ<F>* buckets = (XYZZ<F>*)ws(k.c, 7, nbw * sizeof(XYZZ<F>));
-  XYZZ<F>* seg_sum = (XYZZ<F>*)ws(k.c, 17, nseg_slots * sizeof(XYZZ<F>));
-  const unsigned log_chunks = g.log_nb > kChunkLog ? g.log_nb - kChunkLog : 0;
-  const size_t nchunks = (size_t)g.nwin << log_chunks;
-  XYZZ<F>* partial = (XYZZ<F>*)ws(k.c, 15, (nchunks + g.nwin) * sizeof(XYZZ<F>));
-  XYZZ<F>* window_sums = partial + nchunks;
+  MsmSort st = msm_sort<Fr, SCALAR_BITS>(k, scalars, n, scalars_mont, false);
+  msm_reduce<F>(k, st, bases, out_affine, out_dev);
+}
 
-  DG_HIP(hipMemsetAsync(counts, 0, nbw * 4, s));
-  DG_HIP(hipMemsetAsync(giant_count, 0, 4, s));
-  if (n) {
-    hipLaunchKernelGGL(msm_digits_kernel<Fr>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s,
-                       (const Fr*)scalars, n, (int)scalars_mont, g, digits, counts);
+// ---- table of window multiples for resident bases: T[w*n + i] = 2^(c*w) * P_i (affine) -----------------
+constexpr unsigned kMaxTableWin = 64;
+template <class F>
+__global__ void __launch_bounds__(64) msm_table_kernel(const Affine<F>* __restrict__ bases, size_t n, unsigned c,
+                                                        unsigned nwin, Affine<F>* __restrict__ table) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Affine<F> p = bases[i];
+  table[i] = p;
+  if (p.is_inf()) {
+    for (unsigned w = 1; w < nwin; w++) table[(size_t)w * n + i] = p;
+    return;
   }
-  hipLaunchKernelGGL(msm_scan_kernel<0>, dim3(g.nwin), dim3(1024), 0, s, counts, offsets, seg_off, seg_total,
-                     cursor, g.log_nb);
-  if (n) {
-    hipLaunchKernelGGL(msm_scatter_kernel<0>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, digits, n, g,
-                       offsets, seg_off, cursor, entries, seg_bucket);
+  // rows 1..nwin-1 by repeated doubling; one shared inversion (Montgomery's trick over the rows)
+  XYZZ<F> pts[kMaxTableWin];
+  F pref[kMaxTableWin];
+  XYZZ<F> cur = XYZZ<F>::from_affine(p);
+  F run = F::one();
+  for (unsigned w = 1; w < nwin; w++) {
+    for (unsigned j = 0; j < c; j++) cur = cur.dbl();
+    pts[w] = cur;
+    pref[w] = run;
+    // a point of odd prime order never doubles to the identity; tolerate small-order inputs anyway
+    run = run * (cur.is_inf() ? F::one() : cur.zzz);
   }
-  k.begin_dominant();
-  hipLaunchKernelGGL(msm_accumulate_kernel<F>, dim3((g.seg_cap + 255) / 256, g.nwin), dim3(256), 0, s,
-                     (const Affine<F>*)bases, n, g, offsets, counts, seg_off, seg_total, seg_bucket, entries,
-                     seg_sum);
-  k.end_dominant();
-  hipLaunchKernelGGL(msm_finalize_kernel<F>, dim3((unsigned)((nbw + 255) / 256)), dim3(256), 0, s, g, counts,
-                     seg_off, seg_sum, buckets, giant_count, giant_list, giant_cap);
-  {
-    unsigned gblocks = giant_cap < 1024 ? giant_cap : 1024;
-    hipLaunchKernelGGL(msm_giant_kernel<F>, dim3(gblocks), dim3(256), 0, s, g, counts, seg_off, seg_sum, buckets,
-                       giant_count, giant_list, giant_cap);
+  F inv = run.inv();
+  for (unsigned w = nwin - 1; w >= 1; w--) {
+    if (pts[w].is_inf()) { table[(size_t)w * n + i] = Affine<F>::inf(); continue; }
+    F zi3 = inv * pref[w];
+    inv = inv * pts[w].zzz;
+    F zi2 = (zi3 * pts[w].zz).sqr();
+    table[(size_t)w * n + i] = {pts[w].x * zi2, pts[w].y * zi3};
   }
-  hipLaunchKernelGGL(msm_chunk_kernel<F>, dim3((unsigned)((nchunks + 255) / 256)), dim3(256), 0, s, buckets, g,
-                     partial);
-  hipLaunchKernelGGL(msm_window_sum_kernel<F>, dim3(g.nwin), dim3(256), 0, s, partial, 1u << log_chunks,
-                     window_sums);
-  hipLaunchKernelGGL(msm_tail_kernel<F>, dim3(1), dim3(1), 0, s, window_sums, g, (int)out_affine, (F*)out_dev);
+}
+
+// returns a device table of nwin*n affine points (caller owns it) for window size c
+template <class F>
+void* msm_build_table(hipStream_t s, const void* bases, size_t n, unsigned c, unsigned nwin) {
+  DG_REQUIRE(nwin <= kMaxTableWin, DG16_ERR_BAD_ARG, "too many table windows");
+  void* t = nullptr;
+  DG_HIP(hipMalloc(&t, (size_t)nwin * (n ? n : 1) * sizeof(Affine<F>)));
+  if (n)
+    hipLaunchKernelGGL(msm_table_kernel<F>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, (const Affine<F>*)bases, n,
+                       c, nwin, (Affine<F>*)t);
   DG_HIP(hipGetLastError());
+  return t;
 }
 
 // ---- synthetic bases: P_i = (k0 + i*k1) * G -----------------------------------------------------------

@@ -16,6 +16,12 @@ struct PkDev {
   void* l_q = nullptr;    // l_query[l_lo..l_hi) ++ delta_g1               (G1)
   void* h_q = nullptr;    // h_query[h_lo..h_hi)                           (G1)
   void* fixed = nullptr;  // alpha_g1, a_query[0], beta_g1, b_g1_query[0] (G1 affine) | beta_g2, b_g2_query[0] (G2 affine)
+  // The five base arrays above are TABLES of window multiples, T[w*n + i] = 2^(c*w) * P_i (HBM is 288 GB:
+  // 13 rows x 64 B x 2^20 = 0.8 GB per G1 query), so a proof's MSMs have one bucket set and no Horner tail.
+  // Row layouts: a_q / b1_q / b2_q = slice ++ two delta slots (A: [delta_g1, 0]; B1: [0, delta_g1];
+  // B: [0, delta_g2]) so the three MSMs share ONE scalar vector w[1..] ++ [r, s] and one digit sort;
+  // l_q = slice ++ [delta_g1] (scalar -r*s).
+  unsigned c_ab = 0, c_l = 0, c_h = 0;   // window bits the tables were built for
 };
 
 }  // namespace dg16

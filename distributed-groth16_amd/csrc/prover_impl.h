@@ -21,23 +21,23 @@
 #include "ctx.h"
 #include "types.h"
 
+#include "msm_impl.h"
 #include "pk.h"
 
 namespace dg16 {
 
-// scalars[n_w] = extra (the r / s / -rs slot that pairs with the appended delta base)
+// Extra scalar slots that pair with the delta bases: ab[n_ab] = r, ab[n_ab + 1] = s, l[n_l] = -r*s.
 template <class Fr>
-__global__ void prover_scalar_prep_kernel(const Fr* r_s, Fr* sc_a, Fr* sc_b1, Fr* sc_b2, Fr* sc_l, size_t n_ab,
-                                          size_t n_l, int mont, int carries_delta) {
+__global__ void prover_scalar_prep_kernel(const Fr* r_s, Fr* sc_ab, Fr* sc_l, size_t n_ab, size_t n_l, int mont,
+                                          int carries_delta) {
   // r_s[0] = r, r_s[1] = s in the same form as the witness (Montgomery iff mont).  Only the last
-  // shard carries the delta pairs; the others multiply their delta slot by zero.
+  // shard carries the delta pairs; the others multiply their delta slots by zero.
   Fr r = r_s[0], s = r_s[1];
   if (!carries_delta) { r = Fr::zero(); s = Fr::zero(); }
   Fr rm = mont ? r : r.to_mont(), sm = mont ? s : s.to_mont();
   Fr nrs = (rm * sm).neg();                 // Montgomery form of -(r*s)
-  sc_a[n_ab] = r;
-  sc_b1[n_ab] = s;
-  sc_b2[n_ab] = s;
+  sc_ab[n_ab] = r;
+  sc_ab[n_ab + 1] = s;
   sc_l[n_l] = mont ? nrs : nrs.from_mont();
 }
 
@@ -47,13 +47,12 @@ __device__ XYZZ<F> mul_by_fr(const XYZZ<F>& p, const Fr& k_canon) {
   return scalar_mul<F, Fr::NL>(p, k_canon.l);
 }
 
-// stage 1 (after the A, B1, B2 MSMs): A, B and the two scalar multiples needed by C
-template <class Fq, class Fq2, class Fr>
-__global__ void __launch_bounds__(192) prover_stage1_kernel(const Jacobian<Fq>* msm_a, const Jacobian<Fq>* msm_b1,
-                                                             const Jacobian<Fq2>* msm_b2, const Affine<Fq>* fixed_g1,
-                                                             const Affine<Fq2>* fixed_g2, const Fr* r_s, int mont,
-                                                             Jacobian<Fq>* out_a, Jacobian<Fq2>* out_b,
-                                                             XYZZ<Fq>* s_a, XYZZ<Fq>* r_b1) {
+// stage 1a (after the A and B1 MSMs): A and the two scalar multiples needed by C.  Serial double-and-add,
+// one lane each in two waves (~3 ms): launched as early as possible so that it hides behind other MSMs.
+template <class Fq, class Fr>
+__global__ void __launch_bounds__(128) prover_stage1_g1_kernel(const Jacobian<Fq>* msm_a, const Jacobian<Fq>* msm_b1,
+                                                                const Affine<Fq>* fixed_g1, const Fr* r_s, int mont,
+                                                                Jacobian<Fq>* out_a, XYZZ<Fq>* s_a, XYZZ<Fq>* r_b1) {
   const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   if (lane != 0) return;
   Fr r = r_s[0], s = r_s[1];
@@ -62,14 +61,17 @@ __global__ void __launch_bounds__(192) prover_stage1_kernel(const Jacobian<Fq>* 
     XYZZ<Fq> a = XYZZ<Fq>::from_jacobian(*msm_a).madd(fixed_g1[0], false).madd(fixed_g1[1], false);
     *out_a = a.to_jacobian();
     *s_a = mul_by_fr<Fq, Fr>(a, s);
-  } else if (wave == 1) {
+  } else {
     XYZZ<Fq> b1 = XYZZ<Fq>::inf();
     if (!r.is_zero()) b1 = XYZZ<Fq>::from_jacobian(*msm_b1).madd(fixed_g1[2], false).madd(fixed_g1[3], false);
     *r_b1 = mul_by_fr<Fq, Fr>(b1, r);
-  } else {
-    XYZZ<Fq2> b = XYZZ<Fq2>::from_jacobian(*msm_b2).madd(fixed_g2[0], false).madd(fixed_g2[1], false);
-    *out_b = b.to_jacobian();
   }
+}
+// stage 1b (after the G2 MSM): B = msm + beta_g2 + b_g2_query[0]
+template <class Fq2>
+__global__ void prover_stage1_g2_kernel(const Jacobian<Fq2>* msm_b2, const Affine<Fq2>* fixed_g2, Jacobian<Fq2>* out_b) {
+  XYZZ<Fq2> b = XYZZ<Fq2>::from_jacobian(*msm_b2).madd(fixed_g2[0], false).madd(fixed_g2[1], false);
+  *out_b = b.to_jacobian();
 }
 
 // stage 2 (after the L and H MSMs): C = L + H + s*A + r*B1   (-rs*delta is inside L)
@@ -93,7 +95,7 @@ static size_t msm_results_bytes() {
 template <int CURVE>
 static void msms_typed(dg16_ctx* ctx, Call& k0, Call& k1, Call& k2, const PkDev& pk, const void* a, const void* b,
                        const void* c, const void* witness, const void* r_s_host, bool mont, bool dev_ptrs,
-                       uint8_t* res_dev) {
+                       uint8_t* res_dev, uint8_t* proof_dev = nullptr) {
   using CT = CurveTypes<CURVE>;
   using Fq = typename CT::Fq;
   using Fq2 = typename CT::Fq2;
@@ -117,48 +119,84 @@ static void msms_typed(dg16_ctx* ctx, Call& k0, Call& k1, Call& k2, const PkDev&
   Jacobian<Fq>* res_h = res_a + 3;
   Jacobian<Fq2>* res_b2 = (Jacobian<Fq2>*)(res_dev + 4 * g1j);
   DG_HIP(hipMemcpyAsync(r_s, r_s_host, 2 * sizeof(Fr), hipMemcpyHostToDevice, k0.s()));
-  // scalar vectors with the extra slot (one per MSM that carries a delta pair)
-  Fr* sc_a = (Fr*)ws(k0.c, 23, ((n_ab + 1) * 3 + (n_l + 1)) * sizeof(Fr));
-  Fr* sc_b1 = sc_a + (n_ab + 1);
-  Fr* sc_b2 = sc_b1 + (n_ab + 1);
-  Fr* sc_l = sc_b2 + (n_ab + 1);
-  DG_HIP(hipMemcpyAsync(sc_a, w_dev + 1 + pk.ab_lo, n_ab * sizeof(Fr), hipMemcpyDeviceToDevice, k0.s()));
-  DG_HIP(hipMemcpyAsync(sc_b1, w_dev + 1 + pk.ab_lo, n_ab * sizeof(Fr), hipMemcpyDeviceToDevice, k0.s()));
-  DG_HIP(hipMemcpyAsync(sc_b2, w_dev + 1 + pk.ab_lo, n_ab * sizeof(Fr), hipMemcpyDeviceToDevice, k0.s()));
+  // one scalar vector for A, B1 and B (w[1..] slice ++ [r, s]) and one for L (w[ni..] slice ++ [-rs])
+  Fr* sc_ab = (Fr*)ws(k0.c, 23, ((n_ab + 2) + (n_l + 1)) * sizeof(Fr));
+  Fr* sc_l = sc_ab + (n_ab + 2);
+  DG_HIP(hipMemcpyAsync(sc_ab, w_dev + 1 + pk.ab_lo, n_ab * sizeof(Fr), hipMemcpyDeviceToDevice, k0.s()));
   DG_HIP(hipMemcpyAsync(sc_l, w_dev + ni + pk.l_lo, n_l * sizeof(Fr), hipMemcpyDeviceToDevice, k0.s()));
-  hipLaunchKernelGGL(prover_scalar_prep_kernel<Fr>, dim3(1), dim3(1), 0, k0.s(), r_s, sc_a, sc_b1, sc_b2, sc_l,
-                     n_ab, n_l, (int)mont, (int)(pk.shard + 1 == pk.nshards));
+  hipLaunchKernelGGL(prover_scalar_prep_kernel<Fr>, dim3(1), dim3(1), 0, k0.s(), r_s, sc_ab, sc_l, n_ab, n_l,
+                     (int)mont, (int)(pk.shard + 1 == pk.nshards));
   DG_HIP(hipGetLastError());
-  hipEvent_t ready, e1, e2;
-  DG_HIP(hipEventCreateWithFlags(&ready, hipEventDisableTiming));
-  DG_HIP(hipEventCreateWithFlags(&e1, hipEventDisableTiming));
-  DG_HIP(hipEventCreateWithFlags(&e2, hipEventDisableTiming));
-  DG_HIP(hipEventRecord(ready, k0.s()));
-  DG_HIP(hipStreamWaitEvent(k1.s(), ready, 0));
-  DG_HIP(hipStreamWaitEvent(k2.s(), ready, 0));
+  // Scheduling.  Every saturating kernel of a proof (digit sorts, bucket accumulations, NTTs) goes down ONE
+  // stream (channel 0): they are all VALU-bound, and co-scheduling them was measured equal at best and up to
+  // 1.7x worse from run to run.  The latency-bound bucket reductions (finalize -> chunk -> sums -> tail: a few
+  // hundred dependent group operations on < 10 % of the SIMDs) and the serial s*A, r*B1 run on channels 1 / 2
+  // behind the next accumulation; only the last reduction is exposed.
+  hipStream_t main = k0.s(), side = k1.s(), side2 = k2.s();
+  hipEvent_t ev[8];
+  for (auto& e : ev) DG_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  const Affine<Fq>* fixed_g1 = (const Affine<Fq>*)pk.fixed;
+  const Affine<Fq2>* fixed_g2 = (const Affine<Fq2>*)((const uint8_t*)pk.fixed + 4 * sizeof(Affine<Fq>));
+  XYZZ<Fq>* s_a = (XYZZ<Fq>*)((uint8_t*)r_s + 64);     // scratch shared with assemble_typed
+  XYZZ<Fq>* r_b1 = s_a + 1;
 
-  // channel 2: B (G2) alone -- the longest chain (its serial Horner tail is ~10 ms);
-  // channel 1: A, B1, L | channel 0: h-poly, H
+  // ONE digit sort for A, B1 and B (same scalars w[1..] ++ [r, s]); its buffers live in channel 1
+  MsmSort st_ab = msm_sort_on<Fr, CT::SCALAR_BITS>(main, k1.c, sc_ab, n_ab + 2, mont, true, pk.c_ab);
+  MsmBuffers<Fq> buf_a = msm_buffers<Fq>(k0.c, st_ab.g);
+  MsmBuffers<Fq> buf_b1 = msm_buffers<Fq>(k1.c, st_ab.g);
+  MsmBuffers<Fq2> buf_b2 = msm_buffers<Fq2>(k2.c, st_ab.g);
+  msm_accumulate_phase<Fq>(main, st_ab, buf_a, pk.a_q);
+  DG_HIP(hipEventRecord(ev[0], main));
+  msm_accumulate_phase<Fq>(main, st_ab, buf_b1, pk.b1_q);
+  DG_HIP(hipEventRecord(ev[1], main));
+  msm_accumulate_phase<Fq2>(main, st_ab, buf_b2, pk.b2_q);
+  DG_HIP(hipEventRecord(ev[2], main));
+  // side: reductions of A and B1, then (unsharded proof) the serial scalar multiples
+  DG_HIP(hipStreamWaitEvent(side, ev[0], 0));
+  msm_bucket_phase<Fq>(side, st_ab, buf_a, false, res_a);
+  DG_HIP(hipEventRecord(ev[3], side));                 // A's buffers (channel 0) are free again
+  DG_HIP(hipStreamWaitEvent(side, ev[1], 0));
+  msm_bucket_phase<Fq>(side, st_ab, buf_b1, false, res_b1);
+  DG_HIP(hipEventRecord(ev[4], side));                 // B1's buffers (channel 1) are free again
+  if (proof_dev)
+    hipLaunchKernelGGL((prover_stage1_g1_kernel<Fq, Fr>), dim3(1), dim3(128), 0, side, res_a, res_b1, fixed_g1, r_s,
+                       (int)mont, (Jacobian<Fq>*)proof_dev, s_a, r_b1);
+  // side2: reduction of B
+  DG_HIP(hipStreamWaitEvent(side2, ev[2], 0));
+  msm_bucket_phase<Fq2>(side2, st_ab, buf_b2, false, res_b2);
+  if (proof_dev)
+    hipLaunchKernelGGL(prover_stage1_g2_kernel<Fq2>, dim3(1), dim3(1), 0, side2, res_b2, fixed_g2,
+                       (Jacobian<Fq2>*)(proof_dev + g1j));
+  DG_HIP(hipEventRecord(ev[5], side2));                // sort_ab (channel 1's sort buffers) no longer needed by B
+
+  // main: h-polynomial, then H (sort buffers: channel 0; bucket buffers: channel 0 after A's reduction)
+  DG_HIP(hipStreamWaitEvent(main, ev[3], 0));
   Fr* h_dev = (Fr*)ws(k0.c, 3, m * sizeof(Fr));
-  msm_launch(k2, CURVE, 2, pk.b2_q, sc_b2, n_ab + 1, mont, false, res_b2);
   h_poly_launch(k0, CURVE, a_dev, b_dev, c_dev, log_m, h_dev);
-  msm_launch(k1, CURVE, 1, pk.a_q, sc_a, n_ab + 1, mont, false, res_a);
-  msm_launch(k0, CURVE, 1, pk.h_q, h_dev + pk.h_lo, n_h, true, false, res_h);
-  msm_launch(k1, CURVE, 1, pk.b1_q, sc_b1, n_ab + 1, mont, false, res_b1);
-  msm_launch(k1, CURVE, 1, pk.l_q, sc_l, n_l + 1, mont, false, res_l);
-  DG_HIP(hipEventRecord(e1, k1.s()));
-  DG_HIP(hipEventRecord(e2, k2.s()));
-  DG_HIP(hipStreamWaitEvent(k0.s(), e1, 0));
-  DG_HIP(hipStreamWaitEvent(k0.s(), e2, 0));
-  DG_HIP(hipEventDestroy(ready));
-  DG_HIP(hipEventDestroy(e1));
-  DG_HIP(hipEventDestroy(e2));
+  MsmSort st_h = msm_sort_on<Fr, CT::SCALAR_BITS>(main, k0.c, h_dev + pk.h_lo, n_h, true, true, pk.c_h);
+  MsmBuffers<Fq> buf_h = msm_buffers<Fq>(k0.c, st_h.g);
+  msm_accumulate_phase<Fq>(main, st_h, buf_h, pk.h_q);
+  DG_HIP(hipEventRecord(ev[6], main));
+  // L: sort buffers of channel 2 (unused so far), bucket buffers of channel 1 after B1's reduction
+  MsmSort st_l = msm_sort_on<Fr, CT::SCALAR_BITS>(main, k2.c, sc_l, n_l + 1, mont, true, pk.c_l);
+  DG_HIP(hipStreamWaitEvent(main, ev[4], 0));
+  MsmBuffers<Fq> buf_l = msm_buffers<Fq>(k1.c, st_l.g);
+  msm_accumulate_phase<Fq>(main, st_l, buf_l, pk.l_q);
+  // side: H's reduction hides behind L's sort + accumulation; L's reduction is the exposed tail
+  DG_HIP(hipStreamWaitEvent(side, ev[6], 0));
+  msm_bucket_phase<Fq>(side, st_h, buf_h, false, res_h);
+  msm_bucket_phase<Fq>(main, st_l, buf_l, false, res_l);
+  DG_HIP(hipEventRecord(ev[7], side));
+  DG_HIP(hipStreamWaitEvent(main, ev[7], 0));           // A, B1, H results + s*A, r*B1
+  DG_HIP(hipStreamWaitEvent(main, ev[5], 0));           // B result
+  DG_HIP(hipGetLastError());
+  for (auto& e : ev) DG_HIP(hipEventDestroy(e));
 }
 
 // proof = assemble(sum of the shards' MSM results).  res_dev: msm_results_bytes() on the device.
 template <int CURVE>
 static void assemble_typed(Call& k0, const PkDev& pk, const uint8_t* res_dev, const void* r_s_host, bool mont,
-                           uint8_t* proof_dev) {
+                           uint8_t* proof_dev, bool stage1_done = false) {
   using CT = CurveTypes<CURVE>;
   using Fq = typename CT::Fq;
   using Fq2 = typename CT::Fq2;
@@ -168,13 +206,16 @@ static void assemble_typed(Call& k0, const PkDev& pk, const uint8_t* res_dev, co
   Fr* r_s = (Fr*)small;
   XYZZ<Fq>* s_a = (XYZZ<Fq>*)(small + 64);
   XYZZ<Fq>* r_b1 = s_a + 1;
-  DG_HIP(hipMemcpyAsync(r_s, r_s_host, 2 * sizeof(Fr), hipMemcpyHostToDevice, k0.s()));
   const Jacobian<Fq>* res = (const Jacobian<Fq>*)res_dev;
-  const Affine<Fq>* fixed_g1 = (const Affine<Fq>*)pk.fixed;
-  const Affine<Fq2>* fixed_g2 = (const Affine<Fq2>*)((const uint8_t*)pk.fixed + 4 * sizeof(Affine<Fq>));
-  hipLaunchKernelGGL((prover_stage1_kernel<Fq, Fq2, Fr>), dim3(1), dim3(192), 0, k0.s(), res, res + 1,
-                     (const Jacobian<Fq2>*)(res_dev + 4 * g1j), fixed_g1, fixed_g2, r_s, (int)mont,
-                     (Jacobian<Fq>*)proof_dev, (Jacobian<Fq2>*)(proof_dev + g1j), s_a, r_b1);
+  if (!stage1_done) {
+    DG_HIP(hipMemcpyAsync(r_s, r_s_host, 2 * sizeof(Fr), hipMemcpyHostToDevice, k0.s()));
+    const Affine<Fq>* fixed_g1 = (const Affine<Fq>*)pk.fixed;
+    const Affine<Fq2>* fixed_g2 = (const Affine<Fq2>*)((const uint8_t*)pk.fixed + 4 * sizeof(Affine<Fq>));
+    hipLaunchKernelGGL((prover_stage1_g1_kernel<Fq, Fr>), dim3(1), dim3(128), 0, k0.s(), res, res + 1, fixed_g1, r_s,
+                       (int)mont, (Jacobian<Fq>*)proof_dev, s_a, r_b1);
+    hipLaunchKernelGGL(prover_stage1_g2_kernel<Fq2>, dim3(1), dim3(1), 0, k0.s(),
+                       (const Jacobian<Fq2>*)(res_dev + 4 * g1j), fixed_g2, (Jacobian<Fq2>*)(proof_dev + g1j));
+  }
   hipLaunchKernelGGL(prover_stage2_kernel<Fq>, dim3(1), dim3(1), 0, k0.s(), res + 2, res + 3, s_a, r_b1,
                      (Jacobian<Fq>*)(proof_dev + g1j + g2j));
   DG_HIP(hipGetLastError());
@@ -191,8 +232,8 @@ static void prove_typed(dg16_ctx* ctx, const PkDev& pk, const void* a, const voi
   uint8_t* res_dev = buf;
   uint8_t* proof_dev = buf + 4096;
   k0.begin_dominant();
-  msms_typed<CURVE>(ctx, k0, k1, k2, pk, a, b, c, witness, r_s_host, mont, dev_ptrs, res_dev);
-  assemble_typed<CURVE>(k0, pk, res_dev, r_s_host, mont, proof_dev);
+  msms_typed<CURVE>(ctx, k0, k1, k2, pk, a, b, c, witness, r_s_host, mont, dev_ptrs, res_dev, proof_dev);
+  assemble_typed<CURVE>(k0, pk, res_dev, r_s_host, mont, proof_dev, /*stage1_done=*/true);
   k0.end_dominant();
   stage_out(k0, proof_out, proof_dev, 2 * g1j + g2j, dev_ptrs);
   k0.finish();
@@ -246,11 +287,13 @@ static void pk_build(dg16_ctx* ctx, PkDev& d, const void* a_query, const void* b
   slice(m, d.h_lo, d.h_hi);
   const size_t n_ab = d.ab_hi - d.ab_lo, n_l = d.l_hi - d.l_lo, n_h = d.h_hi - d.h_lo;
   DG_HIP(hipSetDevice(ctx->device));
-  DG_HIP(hipMalloc(&d.a_q, (n_ab + 1) * p1));
-  DG_HIP(hipMalloc(&d.b1_q, (n_ab + 1) * p1));
-  DG_HIP(hipMalloc(&d.b2_q, (n_ab + 1) * p2));
-  DG_HIP(hipMalloc(&d.l_q, (n_l + 1) * p1));
-  DG_HIP(hipMalloc(&d.h_q, (n_h ? n_h : 1) * p1));
+  // plain arrays first (slice ++ delta slots), then the window tables that replace them
+  void *a_plain, *b1_plain, *b2_plain, *l_plain, *h_plain;
+  DG_HIP(hipMalloc(&a_plain, (n_ab + 2) * p1));
+  DG_HIP(hipMalloc(&b1_plain, (n_ab + 2) * p1));
+  DG_HIP(hipMalloc(&b2_plain, (n_ab + 2) * p2));
+  DG_HIP(hipMalloc(&l_plain, (n_l + 1) * p1));
+  DG_HIP(hipMalloc(&h_plain, (n_h ? n_h : 1) * p1));
   DG_HIP(hipMalloc(&d.fixed, 4 * p1 + 2 * p2));
   // fixed_host layout: alpha_g1, beta_g1, delta_g1 (G1 affine) | beta_g2, delta_g2 (G2 affine)
   const uint8_t* fx = (const uint8_t*)fixed_host;
@@ -258,15 +301,32 @@ static void pk_build(dg16_ctx* ctx, PkDev& d, const void* a_query, const void* b
   const uint8_t* b1 = (const uint8_t*)b_g1_query;
   const uint8_t* b2 = (const uint8_t*)b_g2_query;
   uint8_t* fixed = (uint8_t*)d.fixed;
-  DG_HIP(hipMemcpy(d.a_q, aq + (1 + d.ab_lo) * p1, n_ab * p1, kind));
-  DG_HIP(hipMemcpy((uint8_t*)d.a_q + n_ab * p1, fx + 2 * p1, p1, kind));            // delta_g1
-  DG_HIP(hipMemcpy(d.b1_q, b1 + (1 + d.ab_lo) * p1, n_ab * p1, kind));
-  DG_HIP(hipMemcpy((uint8_t*)d.b1_q + n_ab * p1, fx + 2 * p1, p1, kind));
-  DG_HIP(hipMemcpy(d.b2_q, b2 + (1 + d.ab_lo) * p2, n_ab * p2, kind));
-  DG_HIP(hipMemcpy((uint8_t*)d.b2_q + n_ab * p2, fx + 3 * p1 + p2, p2, kind));      // delta_g2
-  DG_HIP(hipMemcpy(d.l_q, (const uint8_t*)l_query + d.l_lo * p1, n_l * p1, kind));
-  DG_HIP(hipMemcpy((uint8_t*)d.l_q + n_l * p1, fx + 2 * p1, p1, kind));
-  if (n_h) DG_HIP(hipMemcpy(d.h_q, (const uint8_t*)h_query + d.h_lo * p1, n_h * p1, kind));
+  DG_HIP(hipMemset((uint8_t*)a_plain + n_ab * p1, 0, 2 * p1));
+  DG_HIP(hipMemset((uint8_t*)b1_plain + n_ab * p1, 0, 2 * p1));
+  DG_HIP(hipMemset((uint8_t*)b2_plain + n_ab * p2, 0, 2 * p2));
+  DG_HIP(hipMemcpy(a_plain, aq + (1 + d.ab_lo) * p1, n_ab * p1, kind));
+  DG_HIP(hipMemcpy((uint8_t*)a_plain + n_ab * p1, fx + 2 * p1, p1, kind));                 // [delta_g1, 0]
+  DG_HIP(hipMemcpy(b1_plain, b1 + (1 + d.ab_lo) * p1, n_ab * p1, kind));
+  DG_HIP(hipMemcpy((uint8_t*)b1_plain + (n_ab + 1) * p1, fx + 2 * p1, p1, kind));          // [0, delta_g1]
+  DG_HIP(hipMemcpy(b2_plain, b2 + (1 + d.ab_lo) * p2, n_ab * p2, kind));
+  DG_HIP(hipMemcpy((uint8_t*)b2_plain + (n_ab + 1) * p2, fx + 3 * p1 + p2, p2, kind));     // [0, delta_g2]
+  DG_HIP(hipMemcpy(l_plain, (const uint8_t*)l_query + d.l_lo * p1, n_l * p1, kind));
+  DG_HIP(hipMemcpy((uint8_t*)l_plain + n_l * p1, fx + 2 * p1, p1, kind));
+  if (n_h) DG_HIP(hipMemcpy(h_plain, (const uint8_t*)h_query + d.h_lo * p1, n_h * p1, kind));
+  {
+    using CTc = CurveTypes<CURVE>;
+    auto nwin_of = [](unsigned c) { return (unsigned)((CTc::SCALAR_BITS + 1 + c - 1) / c); };
+    d.c_ab = msm_window_bits(n_ab + 2, true);
+    d.c_l = msm_window_bits(n_l + 1, true);
+    d.c_h = msm_window_bits(n_h ? n_h : 1, true);
+    d.a_q = msm_build_table<Fq>(nullptr, a_plain, n_ab + 2, d.c_ab, nwin_of(d.c_ab));
+    d.b1_q = msm_build_table<Fq>(nullptr, b1_plain, n_ab + 2, d.c_ab, nwin_of(d.c_ab));
+    d.b2_q = msm_build_table<Fq2>(nullptr, b2_plain, n_ab + 2, d.c_ab, nwin_of(d.c_ab));
+    d.l_q = msm_build_table<Fq>(nullptr, l_plain, n_l + 1, d.c_l, nwin_of(d.c_l));
+    d.h_q = msm_build_table<Fq>(nullptr, h_plain, n_h, d.c_h, nwin_of(d.c_h));
+    DG_HIP(hipDeviceSynchronize());
+    for (void* p : {a_plain, b1_plain, b2_plain, l_plain, h_plain}) DG_HIP(hipFree(p));
+  }
   DG_HIP(hipMemcpy(fixed, fx, p1, kind));                     // alpha_g1
   DG_HIP(hipMemcpy(fixed + p1, aq, p1, kind));                // a_query[0]
   DG_HIP(hipMemcpy(fixed + 2 * p1, fx + p1, p1, kind));       // beta_g1

@@ -15,7 +15,12 @@ reps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
 n = 1 << log_n
 dev = torch.device("cuda:0")
 ctx = dg16_amd.Context(0)
-ctx.set_stream(0, torch.cuda.current_stream().cuda_stream)
+import os
+if os.environ.get("DG16_ONE_STREAM"):
+    for ch in range(3):
+        ctx.set_stream(ch, torch.cuda.current_stream().cuda_stream)
+elif what != "prove":
+    ctx.set_stream(0, torch.cuda.current_stream().cuda_stream)
 curve = "bn254"
 
 
