@@ -68,8 +68,10 @@ class Workload:
 
         self.aq, self.b1q, self.b2q = bases(1, nv, 1), bases(1, nv, 2), bases(2, nv, 3)
         self.hq, self.lq = bases(1, m, 4), bases(1, nv - ni, 5)
-        self.fixed = torch.cat([bases(1, 3, 6), bases(2, 2, 7)])
-        ctx.sync(0)
+        f1, f2 = bases(1, 3, 6), bases(2, 2, 7)
+        ctx.sync(0)          # the generators ran on the library's stream: finish before torch touches them
+        self.fixed = torch.cat([f1, f2])
+        torch.cuda.synchronize()
         self.pk = ctx.pk_create(CURVE, nv, ni, m, self.aq.data_ptr(), self.b1q.data_ptr(), self.b2q.data_ptr(),
                                 self.hq.data_ptr(), self.lq.data_ptr(), self.fixed.data_ptr(), device_ptrs=True,
                                 shard=rank, n_shards=world)
@@ -82,6 +84,7 @@ class Workload:
         self.a[self.nc + ni:] = 0
         self.b[self.nc:] = 0
         self.c = torch.zeros_like(self.a)
+        torch.cuda.synchronize()   # torch's stream -> the library's stream
         ctx.field_op_dev(CURVE, "fr", 2, self.a.data_ptr(), self.b.data_ptr(), self.c.data_ptr(), m)
         ctx.sync(0)
         self.c[self.nc:] = 0

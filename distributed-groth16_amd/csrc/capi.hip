@@ -39,6 +39,7 @@ int dg16_ctx_create(int device, dg16_ctx** out) {
       ctx->ch[i].cur = ctx->ch[i].own;
       for (int e = 0; e < 4; e++) DG_HIP(hipEventCreate(&ctx->ch[i].ev[e]));
     }
+    for (auto& e : ctx->pipe_ev) DG_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   });
   if (rc != DG16_OK) {
     // keep the message reachable for the caller that failed to get a context
@@ -62,6 +63,8 @@ void dg16_ctx_destroy(dg16_ctx* ctx) {
       if (ctx->ch[i].ev[e]) hipEventDestroy(ctx->ch[i].ev[e]);
     if (ctx->ch[i].own) hipStreamDestroy(ctx->ch[i].own);
   }
+  for (auto& e : ctx->pipe_ev)
+    if (e) hipEventDestroy(e);
   for (auto& kv : ctx->twiddles) {
     hipFree(kv.second.lo);
     hipFree(kv.second.hi);

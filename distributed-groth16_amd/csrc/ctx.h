@@ -56,6 +56,11 @@ struct dg16_ctx {
   dg16::Channel ch[dg16::kChannels];
   std::mutex mu;  // guards err + twiddle cache
   std::string err;
+  // Long-lived events for cross-stream dependencies inside one call (prover pipeline).  They are never
+  // destroyed while the context lives: destroying an event right after hipStreamWaitEvent() let later
+  // launches overtake the wait once all buffers were warm (second proof on a context differed from the
+  // oracle; the first one was masked by the implicit synchronisation of hipMalloc).
+  hipEvent_t pipe_ev[16] = {};
   std::map<dg16::TwiddleKey, dg16::TwiddleSet> twiddles;
 };
 

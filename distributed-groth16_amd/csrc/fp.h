@@ -196,6 +196,13 @@ struct alignas(16) Fp {
 #endif
   }
   DG_HD Fp sqr() const { return *this * *this; }
+  // Out-of-line product for code that is register-bound rather than call-bound (the G2 bucket kernel:
+  // with every base-field multiplication inlined hipcc needs 449 registers = ONE wave per SIMD).
+#if defined(__HIPCC__)
+  static __host__ __device__ __attribute__((noinline)) Fp mul_call(Fp a, Fp b) { return a * b; }
+#else
+  static __attribute__((noinline)) Fp mul_call(Fp a, Fp b) { return a * b; }
+#endif
 
   DG_HD Fp to_mont() const { return *this * r2(); }  // canonical integer (< p) -> Montgomery
   DG_HD Fp from_mont() const {                        // Montgomery -> canonical integer

@@ -23,15 +23,15 @@ struct Fp2 {
   DG_HD Fp2 dbl() const { return {c0.dbl(), c1.dbl()}; }
   // Karatsuba: 3 base multiplications
   DG_HD friend Fp2 operator*(const Fp2& a, const Fp2& b) {
-    F v0 = a.c0 * b.c0;
-    F v1 = a.c1 * b.c1;
-    F s = (a.c0 + a.c1) * (b.c0 + b.c1);
+    F v0 = F::mul_call(a.c0, b.c0);
+    F v1 = F::mul_call(a.c1, b.c1);
+    F s = F::mul_call(a.c0 + a.c1, b.c0 + b.c1);
     return {v0 - v1, s - v0 - v1};
   }
   // complex squaring: 2 base multiplications
   DG_HD Fp2 sqr() const {
-    F t = c0 * c1;
-    return {(c0 + c1) * (c0 - c1), t.dbl()};
+    F t = F::mul_call(c0, c1);
+    return {F::mul_call(c0 + c1, c0 - c1), t.dbl()};
   }
   DG_HD Fp2 inv() const {
     F n = (c0.sqr() + c1.sqr()).inv();

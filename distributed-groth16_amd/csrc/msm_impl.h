@@ -231,7 +231,8 @@ __global__ void __launch_bounds__(256) msm_scatter_kernel(const int* __restrict_
 
 // ---- 4: segment accumulation -------------------------------------------------------------------
 template <class F>
-__global__ void __launch_bounds__(256) msm_accumulate_kernel(const Affine<F>* __restrict__ bases, size_t n,
+__global__ void __launch_bounds__(256, (sizeof(F) > 48 ? 2 : 1))
+msm_accumulate_kernel(const Affine<F>* __restrict__ bases, size_t n,
                                                               MsmGeom g, const unsigned* __restrict__ offsets,
                                                               const unsigned* __restrict__ counts,
                                                               const unsigned* __restrict__ seg_off,
@@ -249,16 +250,31 @@ __global__ void __launch_bounds__(256) msm_accumulate_kernel(const Affine<F>* __
   unsigned cnt = counts[bslot] - first;
   if (cnt > (1u << g.seg_log)) cnt = 1u << g.seg_log;
   const unsigned* e = entries + (size_t)w * g.region + offsets[bslot] + first;
-  // No software prefetch of the point: holding a second Affine<F> costs 16..64 VGPRs (occupancy for
-  // G1; for G2 hipcc parked both copies in scratch and serialised every 16-byte piece behind
-  // vmcnt(0)).  Only the 4-byte entry index is fetched one iteration ahead.
+  // Latency hiding.  G1 runs 4 waves/SIMD, which covers the dependent (entry -> 64-B point) gathers, and a
+  // second Affine would cost occupancy; only the 4-byte entry index is fetched one iteration ahead.  G2 has
+  // ONE wave per SIMD (449 registers), so nothing else hides a gather: its time was bimodal from box to box
+  // (10.3 vs 20.5 ms at 2^20, identical binary -- consistent with TLB-miss latency on fragmented page
+  // tables); there the NEXT point is loaded before the current mixed add (register-to-register now that the
+  // add path has no calls).
+  constexpr bool kPrefetchPoint = sizeof(F) > 48;
   unsigned cur = e[0];
   XYZZ<F> acc = XYZZ<F>::inf();
-  for (unsigned j = 0; j < cnt; j++) {
-    unsigned nxt = (j + 1 < cnt) ? e[j + 1] : 0u;
+  if constexpr (kPrefetchPoint) {
     Affine<F> p = bases[cur & 0x7fffffffu];
-    acc = acc.madd(p, cur >> 31);
-    cur = nxt;
+    for (unsigned j = 0; j < cnt; j++) {
+      unsigned nxt = (j + 1 < cnt) ? e[j + 1] : cur;
+      Affine<F> pn = bases[nxt & 0x7fffffffu];
+      acc = acc.madd(p, cur >> 31);
+      cur = nxt;
+      p = pn;
+    }
+  } else {
+    for (unsigned j = 0; j < cnt; j++) {
+      unsigned nxt = (j + 1 < cnt) ? e[j + 1] : 0u;
+      Affine<F> p = bases[cur & 0x7fffffffu];
+      acc = acc.madd(p, cur >> 31);
+      cur = nxt;
+    }
   }
   seg_sum[sslot] = acc;
 }

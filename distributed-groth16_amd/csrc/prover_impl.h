@@ -133,8 +133,7 @@ static void msms_typed(dg16_ctx* ctx, Call& k0, Call& k1, Call& k2, const PkDev&
   // hundred dependent group operations on < 10 % of the SIMDs) and the serial s*A, r*B1 run on channels 1 / 2
   // behind the next accumulation; only the last reduction is exposed.
   hipStream_t main = k0.s(), side = k1.s(), side2 = k2.s();
-  hipEvent_t ev[8];
-  for (auto& e : ev) DG_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  hipEvent_t* ev = ctx->pipe_ev;   // persistent (see ctx.h)
   const Affine<Fq>* fixed_g1 = (const Affine<Fq>*)pk.fixed;
   const Affine<Fq2>* fixed_g2 = (const Affine<Fq2>*)((const uint8_t*)pk.fixed + 4 * sizeof(Affine<Fq>));
   XYZZ<Fq>* s_a = (XYZZ<Fq>*)((uint8_t*)r_s + 64);     // scratch shared with assemble_typed
@@ -190,7 +189,6 @@ static void msms_typed(dg16_ctx* ctx, Call& k0, Call& k1, Call& k2, const PkDev&
   DG_HIP(hipStreamWaitEvent(main, ev[7], 0));           // A, B1, H results + s*A, r*B1
   DG_HIP(hipStreamWaitEvent(main, ev[5], 0));           // B result
   DG_HIP(hipGetLastError());
-  for (auto& e : ev) DG_HIP(hipEventDestroy(e));
 }
 
 // proof = assemble(sum of the shards' MSM results).  res_dev: msm_results_bytes() on the device.

@@ -41,6 +41,14 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # One HIP runtime per process: torch ships its own libamdhip64; if libdg16 (linked against /opt/rocm)
+    # initialises first, torch.cuda later reports "No HIP GPUs are available".  Let torch load first when
+    # it is importable (it is only plumbing for device memory / streams / torch.distributed).
+    try:
+        import torch
+        torch.cuda.is_available()
+    except ImportError:
+        pass
     path = lib_path()
     if not os.path.exists(path):
         raise ImportError(

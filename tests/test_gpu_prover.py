@@ -110,3 +110,13 @@ def test_sharded_prove_equals_unsharded():
         assert got == exp, world
         for k in keys:
             k.close()
+
+
+@pytest.mark.parametrize("log_m", [6, 9, 12, 14, 16])
+def test_prove_medium_sizes_vs_oracle(log_m):
+    """Resident-table prover at sizes where every phase is multi-block (scan, segments, two-stage sums):
+    the proof of a synthetic 2^log_m instance must equal the C oracle's proof of the same inputs."""
+    import torch
+    import bench
+    cb, ok = bench.cpu_baseline_and_parity(ctx(), torch.device("cuda", 0), log_m)
+    assert ok

@@ -48,7 +48,7 @@ if what in ("msm", "msm2"):
     group = 1 if what == "msm" else 2
     pb = 64 * group
     bases = torch.empty(n * pb, dtype=torch.uint8, device=dev)
-    ctx.gen_bases_dev(curve, group, 2, n, bases.data_ptr())
+    ctx.gen_bases_dev(curve, group, int(os.environ.get('SEED', '2')), n, bases.data_ptr())
     scal = rand_fr(n)
     out = torch.empty(96 * group, dtype=torch.uint8, device=dev)
     best, avg = timed(lambda: ctx.msm_dev(curve, group, bases.data_ptr(), scal.data_ptr(), n, out.data_ptr()))
@@ -68,7 +68,9 @@ elif what == "prove":
         return t
     aq, b1q, b2q, hq, lq = bases(1, nv, 11), bases(1, nv, 12), bases(2, nv, 13), bases(1, m, 14), bases(1, nv - ni, 15)
     f1, f2 = bases(1, 3, 16), bases(2, 2, 17)
+    ctx.sync(0)
     fixed = torch.cat([f1, f2])
+    torch.cuda.synchronize()
     pk = ctx.pk_create(curve, nv, ni, m, aq.data_ptr(), b1q.data_ptr(), b2q.data_ptr(), hq.data_ptr(), lq.data_ptr(),
                        fixed.data_ptr(), device_ptrs=True)
     a, b, c, w = rand_fr(m), rand_fr(m), rand_fr(m), rand_fr(nv)
