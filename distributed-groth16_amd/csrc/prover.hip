@@ -7,7 +7,7 @@ namespace dg16 {
   void prove_##name(dg16_ctx*, const PkDev&, const void*, const void*, const void*, const void*, const void*, bool, bool, void*); \
   void msms_##name(dg16_ctx*, Call&, Call&, Call&, const PkDev&, const void*, const void*, const void*, const void*,    \
                    const void*, bool, bool, uint8_t*);                                                                  \
-  void assemble_##name(Call&, const PkDev&, const uint8_t*, size_t, uint8_t*, const void*, bool, uint8_t*);             \
+  void assemble_##name(Call&, const uint8_t*, size_t, uint8_t*);                                                        \
   size_t results_bytes_##name();                                                                                        \
   size_t proof_bytes_##name();
 DECL_P(bn254) DECL_P(bls12_381)
@@ -121,15 +121,13 @@ int dg16_groth16_assemble(dg16_ctx* ctx, const dg16_pk* pk, const void* gathered
     Call k0(ctx, 0);
     size_t rec = dg16_groth16_results_bytes(pk->d.curve);
     const uint8_t* g = (const uint8_t*)stage_in(k0, 19, gathered_results, n_shards * rec, dev);
-    uint8_t* buf = (uint8_t*)ws(k0.c, 16, 8192);
-    uint8_t* summed = buf;
-    uint8_t* proof_dev = buf + 4096;
+    uint8_t* proof_dev = (uint8_t*)ws(k0.c, 16, 8192) + 4096;
     size_t proof_bytes;
     if (pk->d.curve == DG16_BN254) {
-      assemble_bn254(k0, pk->d, g, n_shards, summed, r_s, mont, proof_dev);
+      assemble_bn254(k0, g, n_shards, proof_dev);
       proof_bytes = proof_bytes_bn254();
     } else {
-      assemble_bls12_381(k0, pk->d, g, n_shards, summed, r_s, mont, proof_dev);
+      assemble_bls12_381(k0, g, n_shards, proof_dev);
       proof_bytes = proof_bytes_bls12_381();
     }
     stage_out(k0, proof_out, proof_dev, proof_bytes, dev);

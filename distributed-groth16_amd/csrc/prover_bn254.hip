@@ -10,10 +10,8 @@ void msms_bn254(dg16_ctx* ctx, Call& k0, Call& k1, Call& k2, const PkDev& pk, co
              const void* w, const void* rs, bool mont, bool dev, uint8_t* res) {
   msms_typed<0>(ctx, k0, k1, k2, pk, a, b, c, w, rs, mont, dev, res);
 }
-void assemble_bn254(Call& k0, const PkDev& pk, const uint8_t* gathered, size_t n_shards, uint8_t* summed, const void* rs,
-                 bool mont, uint8_t* proof) {
-  reduce_results_typed<0>(k0, gathered, n_shards, summed);
-  assemble_typed<0>(k0, pk, summed, rs, mont, proof);
+void assemble_bn254(Call& k0, const uint8_t* gathered, size_t n_shards, uint8_t* proof) {
+  assemble_typed<0>(k0, gathered, n_shards, proof);
 }
 size_t results_bytes_bn254() { return msm_results_bytes<0>(); }
 size_t proof_bytes_bn254() {

@@ -47,46 +47,73 @@ __device__ XYZZ<F> mul_by_fr(const XYZZ<F>& p, const Fr& k_canon) {
   return scalar_mul<F, Fr::NL>(p, k_canon.l);
 }
 
-// stage 1a (after the A and B1 MSMs): A and the two scalar multiples needed by C.  Serial double-and-add,
-// one lane each in two waves (~3 ms): launched as early as possible so that it hides behind other MSMs.
+// Per-shard record (what the ranks all-gather): A', B1', L, H, s*A', r*B1' (G1 Jacobian) then B' (G2 Jacobian),
+// where the primed values of shard 0 already contain the fixed points (alpha + a_query[0] etc.).  Everything
+// after the gather is then a plain per-slot sum: C = sum L + sum H + sum s*A' + sum r*B1' (linearity), so the
+// two serial scalar multiplications (~2.5 ms, one lane each) run BEFORE the exchange, hidden behind the other
+// MSMs on a side stream, on every rank.
+constexpr int kRecA = 0, kRecB1 = 1, kRecL = 2, kRecH = 3, kRecSA = 4, kRecRB1 = 5, kRecG1 = 6;
+
 template <class Fq, class Fr>
-__global__ void __launch_bounds__(128) prover_stage1_g1_kernel(const Jacobian<Fq>* msm_a, const Jacobian<Fq>* msm_b1,
-                                                                const Affine<Fq>* fixed_g1, const Fr* r_s, int mont,
-                                                                Jacobian<Fq>* out_a, XYZZ<Fq>* s_a, XYZZ<Fq>* r_b1) {
+__global__ void __launch_bounds__(128) prover_stage1_g1_kernel(Jacobian<Fq>* rec, const Affine<Fq>* fixed_g1,
+                                                                const Fr* r_s, int mont, int first_shard) {
   const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   if (lane != 0) return;
   Fr r = r_s[0], s = r_s[1];
   if (mont) { r = r.from_mont(); s = s.from_mont(); }
   if (wave == 0) {
-    XYZZ<Fq> a = XYZZ<Fq>::from_jacobian(*msm_a).madd(fixed_g1[0], false).madd(fixed_g1[1], false);
-    *out_a = a.to_jacobian();
-    *s_a = mul_by_fr<Fq, Fr>(a, s);
+    XYZZ<Fq> a = XYZZ<Fq>::from_jacobian(rec[kRecA]);
+    if (first_shard) a = a.madd(fixed_g1[0], false).madd(fixed_g1[1], false);   // + alpha_g1 + a_query[0]
+    rec[kRecA] = a.to_jacobian();
+    rec[kRecSA] = mul_by_fr<Fq, Fr>(a, s).to_jacobian();
   } else {
     XYZZ<Fq> b1 = XYZZ<Fq>::inf();
-    if (!r.is_zero()) b1 = XYZZ<Fq>::from_jacobian(*msm_b1).madd(fixed_g1[2], false).madd(fixed_g1[3], false);
-    *r_b1 = mul_by_fr<Fq, Fr>(b1, r);
+    if (!r.is_zero()) {      // B1 only matters when r != 0 (prove.rs:106-136)
+      b1 = XYZZ<Fq>::from_jacobian(rec[kRecB1]);
+      if (first_shard) b1 = b1.madd(fixed_g1[2], false).madd(fixed_g1[3], false);   // + beta_g1 + b_g1_query[0]
+    }
+    rec[kRecB1] = b1.to_jacobian();
+    rec[kRecRB1] = mul_by_fr<Fq, Fr>(b1, r).to_jacobian();
   }
 }
-// stage 1b (after the G2 MSM): B = msm + beta_g2 + b_g2_query[0]
+// B' = msm (+ beta_g2 + b_g2_query[0] on shard 0)
 template <class Fq2>
-__global__ void prover_stage1_g2_kernel(const Jacobian<Fq2>* msm_b2, const Affine<Fq2>* fixed_g2, Jacobian<Fq2>* out_b) {
+__global__ void prover_stage1_g2_kernel(Jacobian<Fq2>* msm_b2, const Affine<Fq2>* fixed_g2, int first_shard) {
+  if (!first_shard) return;
   XYZZ<Fq2> b = XYZZ<Fq2>::from_jacobian(*msm_b2).madd(fixed_g2[0], false).madd(fixed_g2[1], false);
-  *out_b = b.to_jacobian();
+  *msm_b2 = b.to_jacobian();
 }
 
-// stage 2 (after the L and H MSMs): C = L + H + s*A + r*B1   (-rs*delta is inside L)
-template <class Fq>
-__global__ void prover_stage2_kernel(const Jacobian<Fq>* msm_l, const Jacobian<Fq>* msm_h, const XYZZ<Fq>* s_a,
-                                     const XYZZ<Fq>* r_b1, Jacobian<Fq>* out_c) {
-  XYZZ<Fq> c = XYZZ<Fq>::from_jacobian(*msm_l).add(XYZZ<Fq>::from_jacobian(*msm_h)).add(*s_a).add(*r_b1);
-  *out_c = c.to_jacobian();
+// after the gather: per-slot sums over the shards, C = L + H + s*A + r*B1 (-rs*delta is inside L)
+template <class Fq, class Fq2>
+__global__ void __launch_bounds__(192) prover_assemble_kernel(const uint8_t* gathered, size_t n_shards, size_t rec_bytes,
+                                                               Jacobian<Fq>* out_a, Jacobian<Fq2>* out_b,
+                                                               Jacobian<Fq>* out_c) {
+  const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane != 0) return;
+  auto g1 = [&](size_t k, int slot) { return XYZZ<Fq>::from_jacobian(((const Jacobian<Fq>*)(gathered + k * rec_bytes))[slot]); };
+  if (wave == 0) {
+    XYZZ<Fq> a = XYZZ<Fq>::inf();
+    for (size_t k = 0; k < n_shards; k++) a = a.add(g1(k, kRecA));
+    *out_a = a.to_jacobian();
+  } else if (wave == 1) {
+    XYZZ<Fq2> b = XYZZ<Fq2>::inf();
+    for (size_t k = 0; k < n_shards; k++)
+      b = b.add(XYZZ<Fq2>::from_jacobian(*(const Jacobian<Fq2>*)(gathered + k * rec_bytes + kRecG1 * sizeof(Jacobian<Fq>))));
+    *out_b = b.to_jacobian();
+  } else {
+    XYZZ<Fq> c = XYZZ<Fq>::inf();
+    for (size_t k = 0; k < n_shards; k++)
+      c = c.add(g1(k, kRecL)).add(g1(k, kRecH)).add(g1(k, kRecSA)).add(g1(k, kRecRB1));
+    *out_c = c.to_jacobian();
+  }
 }
 
-// partial results of one shard: A, B1, L, H (G1 Jacobian) then B (G2 Jacobian)
+// bytes of one shard's record (layout above)
 template <int CURVE>
 static size_t msm_results_bytes() {
   using CT = CurveTypes<CURVE>;
-  return 4 * sizeof(Jacobian<typename CT::Fq>) + sizeof(Jacobian<typename CT::Fq2>);
+  return kRecG1 * sizeof(Jacobian<typename CT::Fq>) + sizeof(Jacobian<typename CT::Fq2>);
 }
 
 // h-polynomial + the five MSMs of this key's shard.  res_out (device or host per dev_ptrs) receives
@@ -95,7 +122,7 @@ static size_t msm_results_bytes() {
 template <int CURVE>
 static void msms_typed(dg16_ctx* ctx, Call& k0, Call& k1, Call& k2, const PkDev& pk, const void* a, const void* b,
                        const void* c, const void* witness, const void* r_s_host, bool mont, bool dev_ptrs,
-                       uint8_t* res_dev, uint8_t* proof_dev = nullptr) {
+                       uint8_t* res_dev) {
   using CT = CurveTypes<CURVE>;
   using Fq = typename CT::Fq;
   using Fq2 = typename CT::Fq2;
@@ -113,11 +140,13 @@ static void msms_typed(dg16_ctx* ctx, Call& k0, Call& k1, Call& k2, const PkDev&
   const void* b_dev = stage_in(k0, 20, b, m * sizeof(Fr), dev_ptrs);
   const void* c_dev = stage_in(k0, 21, c, m * sizeof(Fr), dev_ptrs);
   Fr* r_s = (Fr*)ws(k0.c, 22, 4096);
-  Jacobian<Fq>* res_a = (Jacobian<Fq>*)res_dev;
-  Jacobian<Fq>* res_b1 = res_a + 1;
-  Jacobian<Fq>* res_l = res_a + 2;
-  Jacobian<Fq>* res_h = res_a + 3;
-  Jacobian<Fq2>* res_b2 = (Jacobian<Fq2>*)(res_dev + 4 * g1j);
+  Jacobian<Fq>* rec = (Jacobian<Fq>*)res_dev;
+  Jacobian<Fq>* res_a = rec + kRecA;
+  Jacobian<Fq>* res_b1 = rec + kRecB1;
+  Jacobian<Fq>* res_l = rec + kRecL;
+  Jacobian<Fq>* res_h = rec + kRecH;
+  Jacobian<Fq2>* res_b2 = (Jacobian<Fq2>*)(res_dev + kRecG1 * g1j);
+  const int first_shard = pk.shard == 0;
   DG_HIP(hipMemcpyAsync(r_s, r_s_host, 2 * sizeof(Fr), hipMemcpyHostToDevice, k0.s()));
   // one scalar vector for A, B1 and B (w[1..] slice ++ [r, s]) and one for L (w[ni..] slice ++ [-rs])
   Fr* sc_ab = (Fr*)ws(k0.c, 23, ((n_ab + 2) + (n_l + 1)) * sizeof(Fr));
@@ -136,8 +165,6 @@ static void msms_typed(dg16_ctx* ctx, Call& k0, Call& k1, Call& k2, const PkDev&
   hipEvent_t* ev = ctx->pipe_ev;   // persistent (see ctx.h)
   const Affine<Fq>* fixed_g1 = (const Affine<Fq>*)pk.fixed;
   const Affine<Fq2>* fixed_g2 = (const Affine<Fq2>*)((const uint8_t*)pk.fixed + 4 * sizeof(Affine<Fq>));
-  XYZZ<Fq>* s_a = (XYZZ<Fq>*)((uint8_t*)r_s + 64);     // scratch shared with assemble_typed
-  XYZZ<Fq>* r_b1 = s_a + 1;
 
   // ONE digit sort for A, B1 and B (same scalars w[1..] ++ [r, s]); its buffers live in channel 1
   MsmSort st_ab = msm_sort_on<Fr, CT::SCALAR_BITS>(main, k1.c, sc_ab, n_ab + 2, mont, true, pk.c_ab);
@@ -150,22 +177,19 @@ static void msms_typed(dg16_ctx* ctx, Call& k0, Call& k1, Call& k2, const PkDev&
   DG_HIP(hipEventRecord(ev[1], main));
   msm_accumulate_phase<Fq2>(main, st_ab, buf_b2, pk.b2_q);
   DG_HIP(hipEventRecord(ev[2], main));
-  // side: reductions of A and B1, then (unsharded proof) the serial scalar multiples
+  // side: reductions of A and B1, then the serial scalar multiples s*A', r*B1' of this shard
   DG_HIP(hipStreamWaitEvent(side, ev[0], 0));
   msm_bucket_phase<Fq>(side, st_ab, buf_a, false, res_a);
   DG_HIP(hipEventRecord(ev[3], side));                 // A's buffers (channel 0) are free again
   DG_HIP(hipStreamWaitEvent(side, ev[1], 0));
   msm_bucket_phase<Fq>(side, st_ab, buf_b1, false, res_b1);
   DG_HIP(hipEventRecord(ev[4], side));                 // B1's buffers (channel 1) are free again
-  if (proof_dev)
-    hipLaunchKernelGGL((prover_stage1_g1_kernel<Fq, Fr>), dim3(1), dim3(128), 0, side, res_a, res_b1, fixed_g1, r_s,
-                       (int)mont, (Jacobian<Fq>*)proof_dev, s_a, r_b1);
+  hipLaunchKernelGGL((prover_stage1_g1_kernel<Fq, Fr>), dim3(1), dim3(128), 0, side, rec, fixed_g1, r_s, (int)mont,
+                     first_shard);
   // side2: reduction of B
   DG_HIP(hipStreamWaitEvent(side2, ev[2], 0));
   msm_bucket_phase<Fq2>(side2, st_ab, buf_b2, false, res_b2);
-  if (proof_dev)
-    hipLaunchKernelGGL(prover_stage1_g2_kernel<Fq2>, dim3(1), dim3(1), 0, side2, res_b2, fixed_g2,
-                       (Jacobian<Fq2>*)(proof_dev + g1j));
+  hipLaunchKernelGGL(prover_stage1_g2_kernel<Fq2>, dim3(1), dim3(1), 0, side2, res_b2, fixed_g2, first_shard);
   DG_HIP(hipEventRecord(ev[5], side2));                // sort_ab (channel 1's sort buffers) no longer needed by B
 
   // main: h-polynomial, then H (sort buffers: channel 0; bucket buffers: channel 0 after A's reduction)
@@ -193,28 +217,13 @@ static void msms_typed(dg16_ctx* ctx, Call& k0, Call& k1, Call& k2, const PkDev&
 
 // proof = assemble(sum of the shards' MSM results).  res_dev: msm_results_bytes() on the device.
 template <int CURVE>
-static void assemble_typed(Call& k0, const PkDev& pk, const uint8_t* res_dev, const void* r_s_host, bool mont,
-                           uint8_t* proof_dev, bool stage1_done = false) {
+static void assemble_typed(Call& k0, const uint8_t* gathered_dev, size_t n_shards, uint8_t* proof_dev) {
   using CT = CurveTypes<CURVE>;
   using Fq = typename CT::Fq;
   using Fq2 = typename CT::Fq2;
-  using Fr = typename CT::Fr;
   const size_t g1j = sizeof(Jacobian<Fq>), g2j = sizeof(Jacobian<Fq2>);
-  uint8_t* small = (uint8_t*)ws(k0.c, 22, 4096);
-  Fr* r_s = (Fr*)small;
-  XYZZ<Fq>* s_a = (XYZZ<Fq>*)(small + 64);
-  XYZZ<Fq>* r_b1 = s_a + 1;
-  const Jacobian<Fq>* res = (const Jacobian<Fq>*)res_dev;
-  if (!stage1_done) {
-    DG_HIP(hipMemcpyAsync(r_s, r_s_host, 2 * sizeof(Fr), hipMemcpyHostToDevice, k0.s()));
-    const Affine<Fq>* fixed_g1 = (const Affine<Fq>*)pk.fixed;
-    const Affine<Fq2>* fixed_g2 = (const Affine<Fq2>*)((const uint8_t*)pk.fixed + 4 * sizeof(Affine<Fq>));
-    hipLaunchKernelGGL((prover_stage1_g1_kernel<Fq, Fr>), dim3(1), dim3(128), 0, k0.s(), res, res + 1, fixed_g1, r_s,
-                       (int)mont, (Jacobian<Fq>*)proof_dev, s_a, r_b1);
-    hipLaunchKernelGGL(prover_stage1_g2_kernel<Fq2>, dim3(1), dim3(1), 0, k0.s(),
-                       (const Jacobian<Fq2>*)(res_dev + 4 * g1j), fixed_g2, (Jacobian<Fq2>*)(proof_dev + g1j));
-  }
-  hipLaunchKernelGGL(prover_stage2_kernel<Fq>, dim3(1), dim3(1), 0, k0.s(), res + 2, res + 3, s_a, r_b1,
+  hipLaunchKernelGGL((prover_assemble_kernel<Fq, Fq2>), dim3(1), dim3(192), 0, k0.s(), gathered_dev, n_shards,
+                     msm_results_bytes<CURVE>(), (Jacobian<Fq>*)proof_dev, (Jacobian<Fq2>*)(proof_dev + g1j),
                      (Jacobian<Fq>*)(proof_dev + g1j + g2j));
   DG_HIP(hipGetLastError());
 }
@@ -230,39 +239,14 @@ static void prove_typed(dg16_ctx* ctx, const PkDev& pk, const void* a, const voi
   uint8_t* res_dev = buf;
   uint8_t* proof_dev = buf + 4096;
   k0.begin_dominant();
-  msms_typed<CURVE>(ctx, k0, k1, k2, pk, a, b, c, witness, r_s_host, mont, dev_ptrs, res_dev, proof_dev);
-  assemble_typed<CURVE>(k0, pk, res_dev, r_s_host, mont, proof_dev, /*stage1_done=*/true);
+  msms_typed<CURVE>(ctx, k0, k1, k2, pk, a, b, c, witness, r_s_host, mont, dev_ptrs, res_dev);
+  assemble_typed<CURVE>(k0, res_dev, 1, proof_dev);
   k0.end_dominant();
   stage_out(k0, proof_out, proof_dev, 2 * g1j + g2j, dev_ptrs);
   k0.finish();
   k1.finish();
   k2.finish();
   if (!dev_ptrs) DG_HIP(hipStreamSynchronize(k0.s()));
-}
-
-// out = sum of n Jacobian points (one lane; n is the number of GPUs)
-template <class F>
-__global__ void point_sum_kernel(const Jacobian<F>* in, size_t n, size_t stride_bytes, Jacobian<F>* out) {
-  XYZZ<F> acc = XYZZ<F>::inf();
-  for (size_t i = 0; i < n; i++)
-    acc = acc.add(XYZZ<F>::from_jacobian(*(const Jacobian<F>*)((const uint8_t*)in + i * stride_bytes)));
-  *out = acc.to_jacobian();
-}
-
-// gathered: n_shards records of msm_results_bytes(); out: one record with the per-MSM sums
-template <int CURVE>
-static void reduce_results_typed(Call& k, const uint8_t* gathered, size_t n_shards, uint8_t* out) {
-  using CT = CurveTypes<CURVE>;
-  using Fq = typename CT::Fq;
-  using Fq2 = typename CT::Fq2;
-  const size_t rec = msm_results_bytes<CURVE>(), g1j = sizeof(Jacobian<Fq>);
-  // the 1-lane adds of the five results are independent: one block each
-  for (int i = 0; i < 4; i++)
-    hipLaunchKernelGGL(point_sum_kernel<Fq>, dim3(1), dim3(1), 0, k.s(), (const Jacobian<Fq>*)(gathered + i * g1j),
-                       n_shards, rec, (Jacobian<Fq>*)(out + i * g1j));
-  hipLaunchKernelGGL(point_sum_kernel<Fq2>, dim3(1), dim3(1), 0, k.s(), (const Jacobian<Fq2>*)(gathered + 4 * g1j),
-                     n_shards, rec, (Jacobian<Fq2>*)(out + 4 * g1j));
-  DG_HIP(hipGetLastError());
 }
 
 // a_query etc. are given as full arkworks vectors (element 0 included); delta is appended here

@@ -4,7 +4,8 @@ re-mapped to the GPUs of one MI355X node.
 
 Every rank holds a contiguous 1/N slice of each MSM's bases (`Context.pk_create(..., shard, n_shards)`),
 computes the h-polynomial (replicated: 6 NTTs, ~5 % of a proof) and its five partial MSMs, then ONE
-collective moves N x 480 bytes: an all-gather of the partial results (RCCL has no user-defined
+collective moves N x 768 bytes: an all-gather of the per-rank records (A, B1, L, H, s*A, r*B1 in G1 and B in G2;
+the serial scalar multiples s*A, r*B1 are taken BEFORE the exchange, by linearity) (RCCL has no user-defined
 reduction, so an elliptic-curve "all-reduce" is all-gather + local add), after which every rank adds
 the N partial points per MSM and assembles (A, B, C).  The exchange is latency-bound (microseconds over
 xGMI); link bandwidth is irrelevant at this size, so there is exactly one collective per proof.
@@ -63,6 +64,6 @@ class DistributedProver:
             gathered = part
         else:
             gathered = self.engine.empty_gather(self.world)
-            # the only data-path collective of a proof: N records of 480 B (BN254) over RCCL / xGMI
+            # the only data-path collective of a proof: N records of 768 B (BN254) over RCCL / xGMI
             self.dist.all_gather_into_tensor(gathered, part)
         return self.engine.assemble(gathered, self.world, rs_host, scalars_mont)

@@ -26,8 +26,9 @@ def _free_port():
 
 
 class OracleEngine:
-    """Stands in for GpuEngine: same record layout (A, B1, L, H as G1 Jacobian then B as G2 Jacobian,
-    Montgomery limbs), computed with the CPU oracle on this rank's slices."""
+    """Stands in for GpuEngine: same record layout as csrc/prover_impl.h (A', B1', L, H, s*A', r*B1' as G1
+    Jacobian, then B' as G2 Jacobian, Montgomery limbs; shard 0 folds the fixed points in), computed with the
+    CPU oracle on this rank's slices."""
 
     def __init__(self, curve, pk, r1cs_dims, shard, n_shards):
         from oracle import corc
@@ -37,8 +38,9 @@ class OracleEngine:
         self.ab = shard_bounds(self.nv - 1, shard, n_shards)
         self.lb = shard_bounds(self.nv - self.ni, shard, n_shards)
         self.hb = shard_bounds(self.m, shard, n_shards)
+        self.first = shard == 0
         self.last = shard + 1 == n_shards
-        self.rec = (4 * 3 * 4 + 3 * 8) * 8
+        self.rec = (6 * 3 * 4 + 3 * 8) * 8
 
     def _jac(self, group, aff):
         nl = 4 * (2 if group == 2 else 1)
@@ -52,48 +54,51 @@ class OracleEngine:
     def partial(self, a, b, c, w, rs_host, scalars_mont):
         corc, cv = self.corc, self.curve
         R = 21888242871839275222246405745257275088548364400416034343698204186575808495617
-        r = int(sum(int(x) << (64 * i) for i, x in enumerate(rs_host[0])))
-        s = int(sum(int(x) << (64 * i) for i, x in enumerate(rs_host[1])))
-        if not self.last:
-            r = s = 0
+        r_full = int(sum(int(x) << (64 * i) for i, x in enumerate(rs_host[0])))
+        s_full = int(sum(int(x) << (64 * i) for i, x in enumerate(rs_host[1])))
+        r, s = (r_full, s_full) if self.last else (0, 0)     # the delta pairs ride on the last shard
         w = w.numpy()
         h = corc.field_op(cv, "fr", "from_mont", corc.h_poly(cv, a.numpy(), b.numpy(), c.numpy()))
         pk = self.pk
         sc = lambda v: corc.ints_to_arr([v], 4)
+        add = lambda grp, p, q: corc.point_add(cv, grp, p, q)
         lo, hi = self.ab
         A = corc.msm(cv, 1, np.concatenate([pk["a_query"][1:][lo:hi], pk["delta_g1"]]), np.concatenate([w[1:][lo:hi], sc(r)]))
         B1 = corc.msm(cv, 1, np.concatenate([pk["b_g1_query"][1:][lo:hi], pk["delta_g1"]]), np.concatenate([w[1:][lo:hi], sc(s)]))
         B2 = corc.msm(cv, 2, np.concatenate([pk["b_g2_query"][1:][lo:hi], pk["delta_g2"]]), np.concatenate([w[1:][lo:hi], sc(s)]))
+        if self.first:                                        # shard 0 folds the fixed points in
+            A = add(1, add(1, A, pk["alpha_g1"]), pk["a_query"][0:1])
+            B1 = add(1, add(1, B1, pk["beta_g1"]), pk["b_g1_query"][0:1])
+            B2 = add(2, add(2, B2, pk["beta_g2"]), pk["b_g2_query"][0:1])
+        if r_full == 0:
+            B1 = np.zeros_like(B1)
         lo, hi = self.lb
         L = corc.msm(cv, 1, np.concatenate([pk["l_query"][lo:hi], pk["delta_g1"]]),
                      np.concatenate([w[self.ni:][lo:hi], sc((R - r * s % R) % R)]))
         lo, hi = self.hb
         H = corc.msm(cv, 1, pk["h_query"][lo:hi], h[lo:hi])
-        rec = np.concatenate([self._jac(1, A), self._jac(1, B1), self._jac(1, L), self._jac(1, H), self._jac(2, B2)])
+        sA = corc.point_mul(cv, 1, A, s_full)
+        rB1 = corc.point_mul(cv, 1, B1, r_full)
+        rec = np.concatenate([self._jac(1, A), self._jac(1, B1), self._jac(1, L), self._jac(1, H), self._jac(1, sA),
+                              self._jac(1, rB1), self._jac(2, B2)])
         return torch.from_numpy(rec.view(np.uint8).copy())
 
     def empty_gather(self, n):
         return torch.empty(n * self.rec, dtype=torch.uint8)
 
     def assemble(self, gathered, n_shards, rs_host, scalars_mont):
-        corc, cv, pk = self.corc, self.curve, self.pk
+        corc, cv = self.corc, self.curve
         g = gathered.numpy().view(np.uint64).reshape(n_shards, -1)
-        r = int(sum(int(x) << (64 * i) for i, x in enumerate(rs_host[0])))
-        s = int(sum(int(x) << (64 * i) for i, x in enumerate(rs_host[1])))
 
         def total(group, off, nl):
             acc = np.zeros((1, 2 * nl), dtype=np.uint64)
             for k in range(n_shards):
                 acc = corc.point_add(cv, group, acc, corc.jac_to_affine(cv, group, g[k, off:off + 3 * nl]))
             return acc
-        A, B1, L, H = (total(1, 12 * i, 4) for i in range(4))
-        B2 = total(2, 48, 8)
+        A, B1, L, H, sA, rB1 = (total(1, 12 * i, 4) for i in range(6))
+        B2 = total(2, 72, 8)
         add = lambda grp, p, q: corc.point_add(cv, grp, p, q)
-        gA = add(1, add(1, A, pk["alpha_g1"]), pk["a_query"][0:1])
-        gB1 = add(1, add(1, B1, pk["beta_g1"]), pk["b_g1_query"][0:1]) if r else np.zeros_like(gA)
-        gB = add(2, add(2, B2, pk["beta_g2"]), pk["b_g2_query"][0:1])
-        gC = add(1, add(1, L, H), add(1, corc.point_mul(cv, 1, gA, s), corc.point_mul(cv, 1, gB1, r)))
-        return gA, gB, gC
+        return A, B2, add(1, add(1, L, H), add(1, sA, rB1))
 
 
 def _worker(rank, world, port, q):
