@@ -279,6 +279,94 @@ msm_accumulate_kernel(const Affine<F>* __restrict__ bases, size_t n,
   seg_sum[sslot] = acc;
 }
 
+// ---- 4 (G2): the same segment accumulation with the accumulator staged through LDS -------------------------
+// An Fq2 mixed addition keeps ~200 registers live when the four accumulator coordinates stay in LDS between
+// uses; with them in registers hipcc needs 449 (one wave per SIMD, AGPR spills, box-dependent 2x slowdowns)
+// or, bounded to 256, spills ~200 dwords/lane to scratch (30 GB of HBM traffic per 2^20 launch, PMC).  LDS
+// layout: [coordinate word][lane] (consecutive lanes -> consecutive banks: conflict-free ds_read/write_b32),
+// 4 coordinates x sizeof(F)/4 words x BLOCK lanes = 64 KiB for BN254 Fq2 at BLOCK = 256 (2 workgroups per CU).
+template <class F, int BLOCK>
+__global__ void __launch_bounds__(BLOCK, (BLOCK == 256 ? 2 : 1))
+msm_accumulate_lds_kernel(const Affine<F>* __restrict__ bases, size_t n, MsmGeom g,
+                          const unsigned* __restrict__ offsets, const unsigned* __restrict__ counts,
+                          const unsigned* __restrict__ seg_off, const unsigned* __restrict__ seg_total,
+                          const unsigned* __restrict__ seg_bucket, const unsigned* __restrict__ entries,
+                          XYZZ<F>* __restrict__ seg_sum) {
+  constexpr int WORDS = sizeof(F) / 4;
+  __shared__ uint32_t sh[4 * WORDS][BLOCK];
+  const unsigned lane = threadIdx.x;
+  auto ld = [&](int coord) {
+    F v;
+    uint32_t* w = reinterpret_cast<uint32_t*>(&v);
+#pragma unroll
+    for (int i = 0; i < WORDS; i++) w[i] = sh[coord * WORDS + i][lane];
+    return v;
+  };
+  auto st = [&](int coord, const F& v) {
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(&v);
+#pragma unroll
+    for (int i = 0; i < WORDS; i++) sh[coord * WORDS + i][lane] = w[i];
+  };
+#define DG_STAGE() asm volatile("" ::: "memory")   /* keep LDS reloads where they are written */
+  const unsigned w = blockIdx.y;
+  const unsigned t = blockIdx.x * BLOCK + threadIdx.x;
+  if (t >= seg_total[w]) return;
+  const size_t sslot = (size_t)w * g.seg_cap + t;
+  const unsigned b = seg_bucket[sslot];
+  const size_t bslot = ((size_t)w << g.log_nb) + b;
+  const unsigned first = (t - seg_off[bslot]) << g.seg_log;
+  unsigned cnt = counts[bslot] - first;
+  if (cnt > (1u << g.seg_log)) cnt = 1u << g.seg_log;
+  const unsigned* e = entries + (size_t)w * g.region + offsets[bslot] + first;
+  bool inf = true;
+  unsigned cur = e[0];
+  for (unsigned j = 0; j < cnt; j++) {
+    unsigned nxt = (j + 1 < cnt) ? e[j + 1] : 0u;
+    Affine<F> q = bases[cur & 0x7fffffffu];
+    const bool negate = cur >> 31;
+    cur = nxt;
+    if (q.is_inf()) continue;
+    F qy = negate ? q.y.neg() : q.y;
+    if (inf) {
+      st(0, q.x); st(1, qy); st(2, F::one()); st(3, F::one());
+      inf = false;
+      continue;
+    }
+    F p = q.x * ld(2) - ld(0);          // U2 - X1
+    DG_STAGE();
+    F r = qy * ld(3) - ld(1);           // S2 - Y1
+    DG_STAGE();
+    if (p.is_zero()) {
+      if (r.is_zero()) {
+        XYZZ<F> d = XYZZ<F>::dbl_affine(q.x, qy);
+        st(0, d.x); st(1, d.y); st(2, d.zz); st(3, d.zzz);
+      } else {
+        inf = true;
+      }
+      continue;
+    }
+    F pp = p.sqr();
+    F ppp = p * pp;
+    DG_STAGE();
+    st(2, ld(2) * pp);
+    DG_STAGE();
+    st(3, ld(3) * ppp);
+    DG_STAGE();
+    F q_ = ld(0) * pp;
+    DG_STAGE();
+    F x3 = r.sqr() - ppp - q_.dbl();
+    st(0, x3);
+    DG_STAGE();
+    F y3 = r * (q_ - x3) - ld(1) * ppp;
+    st(1, y3);
+    DG_STAGE();
+  }
+  XYZZ<F> out = XYZZ<F>::inf();
+  if (!inf) out = {ld(0), ld(1), ld(2), ld(3)};
+  seg_sum[sslot] = out;
+#undef DG_STAGE
+}
+
 // ---- 4b: bucket = sum of its segment partials -----------------------------------------------------
 template <class F>
 __global__ void __launch_bounds__(256) msm_finalize_kernel(MsmGeom g, const unsigned* __restrict__ counts,
@@ -507,9 +595,17 @@ MsmBuffers<F> msm_buffers(Channel& wsch, const MsmGeom& g) {
 template <class F>
 void msm_accumulate_phase(hipStream_t s, const MsmSort& st, const MsmBuffers<F>& b, const void* bases) {
   const MsmGeom& g = st.g;
-  hipLaunchKernelGGL(msm_accumulate_kernel<F>, dim3((g.seg_cap + 255) / 256, g.bw), dim3(256), 0, s,
-                     (const Affine<F>*)bases, st.n, g, st.offsets, st.counts, st.seg_off, st.seg_total, st.seg_bucket,
-                     st.entries, b.seg_sum);
+  if constexpr (sizeof(F) > 48) {
+    // G2 (Fq2 coordinates): LDS-staged accumulator; 64 KiB of LDS per workgroup at most
+    constexpr int BLOCK = sizeof(XYZZ<F>) * 256 <= 65536 ? 256 : 128;
+    hipLaunchKernelGGL((msm_accumulate_lds_kernel<F, BLOCK>), dim3((g.seg_cap + BLOCK - 1) / BLOCK, g.bw), dim3(BLOCK),
+                       0, s, (const Affine<F>*)bases, st.n, g, st.offsets, st.counts, st.seg_off, st.seg_total,
+                       st.seg_bucket, st.entries, b.seg_sum);
+  } else {
+    hipLaunchKernelGGL(msm_accumulate_kernel<F>, dim3((g.seg_cap + 255) / 256, g.bw), dim3(256), 0, s,
+                       (const Affine<F>*)bases, st.n, g, st.offsets, st.counts, st.seg_off, st.seg_total,
+                       st.seg_bucket, st.entries, b.seg_sum);
+  }
   DG_HIP(hipGetLastError());
 }
 
