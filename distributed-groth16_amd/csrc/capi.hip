@@ -257,4 +257,51 @@ int dg16_to_affine(dg16_ctx* ctx, int curve, int group, const void* jac, void* o
   });
 }
 
+// QAP evaluation vectors from the R1CS matrices and the full assignment.
+int dg16_qap(dg16_ctx* ctx, int curve, size_t num_constraints, size_t num_inputs, size_t num_vars, unsigned log_m,
+             const uint32_t* a_row_ptr, const uint32_t* a_col, const void* a_coeff, const uint32_t* b_row_ptr,
+             const uint32_t* b_col, const void* b_coeff, const void* full_assignment, void* a_out, void* b_out,
+             void* c_out, unsigned flags, int channel) {
+  int rc = guard_channel(ctx, channel);
+  if (rc) return rc;
+  return guarded(ctx, [&] {
+    DG_REQUIRE(curve >= 0 && curve <= 2, DG16_ERR_BAD_CURVE, "unknown curve id");
+    DG_REQUIRE(a_row_ptr && b_row_ptr && full_assignment && a_out && b_out && c_out, DG16_ERR_BAD_ARG, "null operand");
+    const size_t m = (size_t)1 << log_m;
+    // D::new(num_constraints + num_inputs) (qap.rs:53): the domain must hold both
+    DG_REQUIRE(num_constraints + num_inputs <= m && num_inputs <= num_vars, DG16_ERR_BAD_ARG,
+               "domain smaller than num_constraints + num_inputs");
+    bool dev = flags & DG16_F_DEVICE_PTRS;
+    Call k(ctx, channel);
+    size_t a_nnz = 0, b_nnz = 0;
+    if (dev) {
+      DG_HIP(hipMemcpy(&a_nnz, a_row_ptr + num_constraints, 4, hipMemcpyDeviceToHost));
+      DG_HIP(hipMemcpy(&b_nnz, b_row_ptr + num_constraints, 4, hipMemcpyDeviceToHost));
+    } else {
+      a_nnz = a_row_ptr[num_constraints];
+      b_nnz = b_row_ptr[num_constraints];
+    }
+    const unsigned* ap = (const unsigned*)stage_in(k, 0, a_row_ptr, (num_constraints + 1) * 4, dev);
+    const unsigned* ac = (const unsigned*)stage_in(k, 1, a_col, a_nnz * 4, dev);
+    const void* av = stage_in(k, 2, a_coeff, a_nnz * 32, dev);
+    const unsigned* bp = (const unsigned*)stage_in(k, 3, b_row_ptr, (num_constraints + 1) * 4, dev);
+    const unsigned* bc = (const unsigned*)stage_in(k, 18, b_col, b_nnz * 4, dev);
+    const void* bv = stage_in(k, 19, b_coeff, b_nnz * 32, dev);
+    const void* w = stage_in(k, 20, full_assignment, num_vars * 32, dev);
+    uint8_t* out = dev ? nullptr : (uint8_t*)ws(k.c, 21, 3 * m * 32);
+    void* da = dev ? a_out : out;
+    void* db = dev ? b_out : out + m * 32;
+    void* dc = dev ? c_out : out + 2 * m * 32;
+    qap_launch(k, curve, ap, ac, av, bp, bc, bv, w, flags & DG16_F_SCALARS_MONT, num_constraints, num_inputs, m, da, db,
+               dc);
+    if (!dev) {
+      stage_out(k, a_out, da, m * 32, false);
+      stage_out(k, b_out, db, m * 32, false);
+      stage_out(k, c_out, dc, m * 32, false);
+    }
+    k.finish();
+    if (!dev) DG_HIP(hipStreamSynchronize(k.s()));
+  });
+}
+
 }  // extern "C"

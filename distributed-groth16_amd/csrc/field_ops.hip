@@ -37,6 +37,56 @@ static void launch(Call& k, int op, const void* a, const void* b, void* out, siz
   DG_HIP(hipGetLastError());
 }
 
+// ---- QAP evaluation vectors (groth16/src/qap.rs:44-91 == ark-circom/src/circom/qap.rs:34-62) --------------
+// a[i] = <A_i, w>, b[i] = <B_i, w> over the CSR rows (evaluate_constraint), a[nc + j] = w[j] for the
+// num_inputs instance variables, c = a o b on the constraint rows, zero above.  One lane per domain slot;
+// HBM-bound gather: ~3 nonzeros x (32 B coefficient + 32 B witness element) per row.
+template <class Fr>
+__global__ void __launch_bounds__(256) qap_kernel(const unsigned* __restrict__ a_ptr, const unsigned* __restrict__ a_col,
+                                                   const Fr* __restrict__ a_val, const unsigned* __restrict__ b_ptr,
+                                                   const unsigned* __restrict__ b_col, const Fr* __restrict__ b_val,
+                                                   const Fr* __restrict__ w, int w_mont, size_t nc, size_t ni, size_t m,
+                                                   Fr* __restrict__ a, Fr* __restrict__ b, Fr* __restrict__ c) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  Fr av = Fr::zero(), bv = Fr::zero(), cv = Fr::zero();
+  if (i < nc) {
+    for (unsigned j = a_ptr[i]; j < a_ptr[i + 1]; j++) {
+      Fr x = w[a_col[j]];
+      if (!w_mont) x = x.to_mont();
+      av = av + a_val[j] * x;
+    }
+    for (unsigned j = b_ptr[i]; j < b_ptr[i + 1]; j++) {
+      Fr x = w[b_col[j]];
+      if (!w_mont) x = x.to_mont();
+      bv = bv + b_val[j] * x;
+    }
+    cv = av * bv;
+  } else if (i < nc + ni) {
+    av = w[i - nc];
+    if (!w_mont) av = av.to_mont();
+  }
+  a[i] = av;
+  b[i] = bv;
+  c[i] = cv;
+}
+
+void qap_launch(Call& k, int curve, const unsigned* a_ptr, const unsigned* a_col, const void* a_val,
+                const unsigned* b_ptr, const unsigned* b_col, const void* b_val, const void* w, bool w_mont, size_t nc,
+                size_t ni, size_t m, void* a, void* b, void* c) {
+  unsigned blocks = (unsigned)((m + 255) / 256);
+#define QAP(F)                                                                                              \
+  hipLaunchKernelGGL(qap_kernel<F>, dim3(blocks), dim3(256), 0, k.s(), a_ptr, a_col, (const F*)a_val, b_ptr, \
+                     b_col, (const F*)b_val, (const F*)w, (int)w_mont, nc, ni, m, (F*)a, (F*)b, (F*)c)
+  switch (curve) {
+    case 0: QAP(bn254_fr); break;
+    case 1: QAP(bls12_381_fr); break;
+    default: QAP(bls12_377_fr); break;
+  }
+#undef QAP
+  DG_HIP(hipGetLastError());
+}
+
 void field_op_launch(Call& k, int field_id, int op, const void* a, const void* b, void* out, size_t n) {
   switch (field_id) {
     case 0: launch<bn254_fq>(k, op, a, b, out, n); break;

@@ -80,6 +80,7 @@ def load():
     L.dg16_groth16_results_bytes.restype = sz
     L.dg16_groth16_msms.argtypes = [vp, vp, vp, vp, vp, vp, vp, u, vp]
     L.dg16_groth16_assemble.argtypes = [vp, vp, vp, sz, vp, u, vp]
+    L.dg16_qap.argtypes = [vp, i, sz, sz, sz, u, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, u, i]
     L.dg16_localnet_create.argtypes = [u, ctypes.POINTER(vp)]
     L.dg16_localnet_party.argtypes = [vp, u]
     L.dg16_localnet_party.restype = vp
@@ -110,7 +111,7 @@ EXPORTED = ["dg16_ctx_create", "dg16_ctx_destroy", "dg16_last_error", "dg16_set_
             "dg16_groth16_assemble", "dg16_localnet_create", "dg16_localnet_party", "dg16_localnet_destroy", "dg16_localnet_abort",
             "dg16_localnet_reset",
             "dg16_pss_create", "dg16_pss_destroy", "dg16_pss_apply", "dg16_pss_apply_exp", "dg16_d_fft",
-            "dg16_d_msm", "dg16_deg_red", "dg16_d_pp", "dg16_ext_wit_h"]
+            "dg16_d_msm", "dg16_deg_red", "dg16_d_pp", "dg16_ext_wit_h", "dg16_qap"]
 
 
 def _ptr(x):
@@ -242,6 +243,21 @@ class Context:
         out = np.zeros((jac.shape[0], 2 * nl), dtype=np.uint64)
         self._chk(self.L.dg16_to_affine(self.h, CURVES[curve], group, _ptr(jac), _ptr(out), jac.shape[0], 0,
                                         channel))
+        return out
+
+    # ---- QAP (R1CS x witness) ---------------------------------------------------------------------------
+    def qap(self, curve, num_constraints, num_inputs, csr_a, csr_b, full_assignment, scalars_mont=True, channel=0):
+        """csr_* = (row_ptr uint32, col uint32, coeff uint64[nnz][4] in Montgomery form).  Returns a, b, c."""
+        w = np.ascontiguousarray(full_assignment, dtype=np.uint64).reshape(-1, 4)
+        need = num_constraints + num_inputs
+        log_m = max(need - 1, 0).bit_length()
+        m = 1 << log_m
+        out = [np.zeros((m, 4), dtype=np.uint64) for _ in range(3)]
+        ap, ac, av = (np.ascontiguousarray(x) for x in csr_a)
+        bp, bc, bv = (np.ascontiguousarray(x) for x in csr_b)
+        self._chk(self.L.dg16_qap(self.h, CURVES[curve], num_constraints, num_inputs, w.shape[0], log_m, _ptr(ap),
+                                  _ptr(ac), _ptr(av), _ptr(bp), _ptr(bc), _ptr(bv), _ptr(w), _ptr(out[0]),
+                                  _ptr(out[1]), _ptr(out[2]), F_SCALARS_MONT if scalars_mont else 0, channel))
         return out
 
     # ---- Groth16 prover ---------------------------------------------------------------------------------

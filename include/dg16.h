@@ -10,6 +10,7 @@
  *                          and the butterfly loops fft1/fft2_in_place  dist-primitives/src/dfft/mod.rs:98-182
  *   dg16_h_poly         <- `CircomReduction::witness_map_from_matrices` (NTT part)
  *                                                              ark-circom/src/circom/qap.rs:64-91
+ *   dg16_qap            <- `qap::qap` (R1CS x witness)          groth16/src/qap.rs:44-91
  *   dg16_field_op       <- element-wise ark-ff ops (parity probe for the Montgomery kernels)
  *   dg16_gen_bases      <- `PackedProvingKeyShare::rand`       groth16/src/proving_key.rs:112-155
  *   dg16_groth16_prove  <- `create_proof_with_reduction_and_matrices`  groth16/examples/sha256.rs:159
@@ -100,6 +101,18 @@ int dg16_ntt(dg16_ctx *ctx, int curve, void *data, unsigned log_n, int inverse,
  * shift = multiply coefficient i by w_{2m}^i.  a, b, c are not modified; out may alias a. */
 int dg16_h_poly(dg16_ctx *ctx, int curve, const void *a, const void *b, const void *c,
                 unsigned log_m, void *out, unsigned flags, int channel);
+
+/* ---- QAP evaluation vectors (sparse R1CS x witness) ------------------------------------------------
+ * Replaces `qap::qap` (groth16/src/qap.rs:44-91; the same loops open ark-circom/src/circom/qap.rs:34-62):
+ * a[i] = <A_i, w>, b[i] = <B_i, w> for the num_constraints CSR rows (coefficients in Montgomery form),
+ * a[num_constraints + j] = w[j] for j < num_inputs, c = a o b on the constraint rows, zero padding up to
+ * 2^log_m = D::new(num_constraints + num_inputs).size().  full_assignment: num_vars Fr elements
+ * (Montgomery iff DG16_F_SCALARS_MONT); outputs: 2^log_m Montgomery elements each. */
+int dg16_qap(dg16_ctx *ctx, int curve, size_t num_constraints, size_t num_inputs, size_t num_vars,
+             unsigned log_m, const uint32_t *a_row_ptr, const uint32_t *a_col, const void *a_coeff,
+             const uint32_t *b_row_ptr, const uint32_t *b_col, const void *b_coeff,
+             const void *full_assignment, void *a_out, void *b_out, void *c_out, unsigned flags,
+             int channel);
 
 /* ---- MSM ----------------------------------------------------------------------------------------
  * out = sum_i scalars[i] * bases[i] in G1 (group = 1) or G2 (group = 2).
