@@ -81,15 +81,47 @@ inline MsmGeom msm_geometry(size_t n, unsigned scalar_bits, bool table = false, 
   return g;
 }
 
+// atomicAdd(&ctr[idx], 1) for every active lane, returning the old value -- robust to heavy hitters.  Random
+// digits almost never collide inside a wave, but the top window of any c (2 bits at c = 18: ALL scalars land
+// in 3 buckets) and real witnesses (bits: half of all entries hit bucket 0 of window 0) serialise a million
+// atomics on one address (measured: 23 -> 57 ms per proof at c = 18).  Cheap test first (does my neighbour
+// lane hit the same counter?); only skewed waves pay the leader loop: one atomic per distinct counter.
+__device__ __forceinline__ unsigned wave_atomic_inc(unsigned* __restrict__ ctr, unsigned idx, bool active) {
+  const unsigned lane = __lane_id();
+  const unsigned nb = __shfl_down(idx, 1);
+  const bool nb_active = __shfl_down((int)active, 1);
+  const unsigned long long like = __ballot(active && nb_active && nb == idx && lane < 63);
+  unsigned old = 0;
+  if (__popcll(like) < 8) {
+    if (active) old = atomicAdd(&ctr[idx], 1u);
+    return old;
+  }
+  unsigned long long todo = __ballot(active);
+  while (todo) {
+    const int leader = __ffsll((long long)todo) - 1;
+    const unsigned lidx = __shfl(idx, leader);
+    const unsigned long long grp = __ballot(active && idx == lidx) & todo;
+    unsigned base = 0;
+    if ((int)lane == leader) base = atomicAdd(&ctr[lidx], (unsigned)__popcll(grp));
+    base = __shfl(base, leader);
+    if ((grp >> lane) & 1) old = base + (unsigned)__popcll(grp & ((1ull << lane) - 1));
+    todo &= ~grp;
+  }
+  return old;
+}
+
 // ---- 1: digits + histogram -------------------------------------------------------------------
 template <class Fr>
 __global__ void __launch_bounds__(256) msm_digits_kernel(const Fr* __restrict__ scalars, size_t n, int mont,
                                                           MsmGeom g, int* __restrict__ digits,
                                                           unsigned* __restrict__ counts) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  Fr s = scalars[i];
-  if (mont) s = s.from_mont();
+  const bool live = i < n;          // no early exit: the wave-aggregated histogram needs every lane
+  Fr s = Fr::zero();
+  if (live) {
+    s = scalars[i];
+    if (mont) s = s.from_mont();
+  }
   const unsigned c = g.c;
   const unsigned half = 1u << (c - 1);
   unsigned carry = 0;
@@ -104,11 +136,10 @@ __global__ void __launch_bounds__(256) msm_digits_kernel(const Fr* __restrict__ 
     }
     int d = (int)((unsigned)v & ((1u << c) - 1)) + (int)carry;
     if ((unsigned)d > half) { d -= (int)(1u << c); carry = 1; } else { carry = 0; }
-    digits[(size_t)w * n + i] = d;
-    if (d != 0) {
-      unsigned b = (unsigned)(d < 0 ? -d : d) - 1;
-      atomicAdd(&counts[(g.table ? (size_t)0 : ((size_t)w << g.log_nb)) + b], 1u);
-    }
+    if (live) digits[(size_t)w * n + i] = d;
+    unsigned b = d ? (unsigned)(d < 0 ? -d : d) - 1 : 0u;
+    unsigned slot = (g.table ? 0u : (w << g.log_nb)) + b;
+    wave_atomic_inc(counts, slot, live && d != 0);
   }
 }
 
@@ -214,14 +245,15 @@ __global__ void __launch_bounds__(256) msm_scatter_kernel(const int* __restrict_
                                                            unsigned* __restrict__ entries,
                                                            unsigned* __restrict__ seg_bucket) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+  const bool live = i < n;
   for (unsigned w = 0; w < g.nwin; w++) {
-    int d = digits[(size_t)w * n + i];
-    if (d == 0) continue;
-    unsigned b = (unsigned)(d < 0 ? -d : d) - 1;
+    int d = live ? digits[(size_t)w * n + i] : 0;
+    const bool act = d != 0;
+    unsigned b = act ? (unsigned)(d < 0 ? -d : d) - 1 : 0u;
     const unsigned bwin = g.table ? 0u : w;
-    size_t slot = ((size_t)bwin << g.log_nb) + b;
-    unsigned rank = atomicAdd(&cursor[slot], 1u);
+    unsigned slot = (bwin << g.log_nb) + b;
+    unsigned rank = wave_atomic_inc(cursor, slot, act);
+    if (!act) continue;
     unsigned ref = g.table ? (unsigned)((size_t)w * n + i) : (unsigned)i;   // table row 2^(c*w) * P_i
     entries[(size_t)bwin * g.region + offsets[slot] + rank] = ref | (d < 0 ? 0x80000000u : 0u);
     if ((rank & ((1u << g.seg_log) - 1)) == 0)

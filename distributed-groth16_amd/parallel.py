@@ -41,6 +41,15 @@ class GpuEngine:
                                   out.data_ptr(), scalars_mont=scalars_mont)
         return out
 
+    def before_collective(self):
+        """The record is produced on libdg16's stream; RCCL (torch.distributed) orders only against torch's
+        current stream -- finish the record before handing it over (one host sync, ~10 us)."""
+        self.ctx.sync(0)
+
+    def after_collective(self):
+        """...and the gathered records must have landed before libdg16's stream reads them."""
+        self.torch.cuda.current_stream(self.device).synchronize()
+
     def assemble(self, gathered, n_shards, rs_host, scalars_mont):
         nl = 4 if self.curve == "bn254" else 6
         proof = self.torch.empty(12 * nl * 8, dtype=self.torch.uint8, device=self.device)
@@ -64,6 +73,10 @@ class DistributedProver:
             gathered = part
         else:
             gathered = self.engine.empty_gather(self.world)
+            if hasattr(self.engine, "before_collective"):
+                self.engine.before_collective()
             # the only data-path collective of a proof: N records of 768 B (BN254) over RCCL / xGMI
             self.dist.all_gather_into_tensor(gathered, part)
+            if hasattr(self.engine, "after_collective"):
+                self.engine.after_collective()
         return self.engine.assemble(gathered, self.world, rs_host, scalars_mont)
