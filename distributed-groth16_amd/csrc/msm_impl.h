@@ -425,26 +425,73 @@ __global__ void __launch_bounds__(256) msm_finalize_kernel(MsmGeom g, const unsi
   buckets[gid] = acc;
 }
 
+// Giant buckets (a boolean witness puts half of ALL entries into bucket 0; the short top window of a c that does
+// not divide the scalar width does the same): two launches.  Stage 1 cuts the bucket's segment partials into
+// <= kGiantSlices slices, one workgroup each, and leaves every slice's sum IN PLACE in the slice's first
+// segment slot; stage 2 adds the slice sums.  (One workgroup per bucket chained 128 dependent additions per
+// lane for a 2^20-bit witness: 2.5 ms for G1, far more for G2.)
+constexpr unsigned kGiantSlices = 64;
+constexpr unsigned kGiantSliceSegs = 512;
+__device__ __forceinline__ void giant_geometry(unsigned nseg, unsigned& slices, unsigned& per) {
+  slices = (nseg + kGiantSliceSegs - 1) / kGiantSliceSegs;
+  if (slices > kGiantSlices) slices = kGiantSlices;
+  per = (nseg + slices - 1) / slices;
+  slices = (nseg + per - 1) / per;
+}
+
 template <class F>
 __global__ void __launch_bounds__(256) msm_giant_kernel(MsmGeom g, const unsigned* __restrict__ counts,
                                                          const unsigned* __restrict__ seg_off,
-                                                         const XYZZ<F>* __restrict__ seg_sum,
-                                                         XYZZ<F>* __restrict__ buckets,
+                                                         XYZZ<F>* __restrict__ seg_sum,
                                                          const unsigned* __restrict__ giant_count,
                                                          const unsigned* __restrict__ giant_list, unsigned giant_cap) {
   __shared__ XYZZ<F> sh[256];
+  unsigned ng = *giant_count;
+  if (ng > giant_cap) ng = giant_cap;
+  for (unsigned gi = blockIdx.y; gi < ng; gi += gridDim.y) {
+    const unsigned gid = giant_list[gi];
+    const unsigned w = gid >> g.log_nb;
+    const unsigned nseg = (counts[gid] + (1u << g.seg_log) - 1) >> g.seg_log;
+    unsigned slices, per;
+    giant_geometry(nseg, slices, per);
+    if (blockIdx.x >= slices) continue;          // block-uniform
+    XYZZ<F>* sp = seg_sum + (size_t)w * g.seg_cap + seg_off[gid];
+    const unsigned lo = blockIdx.x * per;
+    const unsigned hi = lo + per < nseg ? lo + per : nseg;
+    XYZZ<F> acc = XYZZ<F>::inf();
+    for (unsigned s = lo + threadIdx.x; s < hi; s += 256) acc = acc.add(sp[s]);
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (unsigned stride = 128; stride > 0; stride >>= 1) {
+      if (threadIdx.x < stride) sh[threadIdx.x] = sh[threadIdx.x].add(sh[threadIdx.x + stride]);
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) sp[lo] = sh[0];
+    __syncthreads();
+  }
+}
+
+template <class F>
+__global__ void __launch_bounds__(64) msm_giant_fold_kernel(MsmGeom g, const unsigned* __restrict__ counts,
+                                                             const unsigned* __restrict__ seg_off,
+                                                             const XYZZ<F>* __restrict__ seg_sum,
+                                                             XYZZ<F>* __restrict__ buckets,
+                                                             const unsigned* __restrict__ giant_count,
+                                                             const unsigned* __restrict__ giant_list,
+                                                             unsigned giant_cap) {
+  __shared__ XYZZ<F> sh[kGiantSlices];
   unsigned ng = *giant_count;
   if (ng > giant_cap) ng = giant_cap;
   for (unsigned gi = blockIdx.x; gi < ng; gi += gridDim.x) {
     const unsigned gid = giant_list[gi];
     const unsigned w = gid >> g.log_nb;
     const unsigned nseg = (counts[gid] + (1u << g.seg_log) - 1) >> g.seg_log;
+    unsigned slices, per;
+    giant_geometry(nseg, slices, per);
     const XYZZ<F>* sp = seg_sum + (size_t)w * g.seg_cap + seg_off[gid];
-    XYZZ<F> acc = XYZZ<F>::inf();
-    for (unsigned s = threadIdx.x; s < nseg; s += 256) acc = acc.add(sp[s]);
-    sh[threadIdx.x] = acc;
+    sh[threadIdx.x] = threadIdx.x < slices ? sp[(size_t)threadIdx.x * per] : XYZZ<F>::inf();
     __syncthreads();
-    for (unsigned stride = 128; stride > 0; stride >>= 1) {
+    for (unsigned stride = kGiantSlices / 2; stride > 0; stride >>= 1) {
       if (threadIdx.x < stride) sh[threadIdx.x] = sh[threadIdx.x].add(sh[threadIdx.x + stride]);
       __syncthreads();
     }
@@ -650,8 +697,10 @@ void msm_bucket_phase(hipStream_t s, const MsmSort& st, const MsmBuffers<F>& b, 
   hipLaunchKernelGGL(msm_finalize_kernel<F>, dim3((unsigned)((b.nbw + 255) / 256)), dim3(256), 0, s, g, st.counts,
                      st.seg_off, b.seg_sum, b.buckets, b.giant, b.giant + 1, b.giant_cap);
   {
-    unsigned gblocks = b.giant_cap < 64 ? b.giant_cap : 64;
-    hipLaunchKernelGGL(msm_giant_kernel<F>, dim3(gblocks), dim3(256), 0, s, g, st.counts, st.seg_off, b.seg_sum,
+    unsigned grows = b.giant_cap < 64 ? b.giant_cap : 64;
+    hipLaunchKernelGGL(msm_giant_kernel<F>, dim3(kGiantSlices, grows), dim3(256), 0, s, g, st.counts, st.seg_off,
+                       b.seg_sum, b.giant, b.giant + 1, b.giant_cap);
+    hipLaunchKernelGGL(msm_giant_fold_kernel<F>, dim3(grows), dim3(64), 0, s, g, st.counts, st.seg_off, b.seg_sum,
                        b.buckets, b.giant, b.giant + 1, b.giant_cap);
   }
   hipLaunchKernelGGL(msm_chunk_kernel<F>, dim3((unsigned)((b.nchunks + 255) / 256)), dim3(256), 0, s, b.buckets, g,

@@ -1,6 +1,7 @@
 """Device-resident timing probe (run on the GPU box, optionally under rocprofv3 --kernel-trace --stats).
 usage: python tools/perf_probe.py [msm|msm2|ntt|hpoly] [log_n] [reps]"""
 
+import os
 import sys
 import time
 
@@ -32,6 +33,17 @@ def rand_fr(n):
     return torch.cat([lo, hi], dim=1).contiguous()
 
 
+def witness_fr(n):
+    """SKEW=bits|bytes: scalars like a real circom witness (mostly booleans / small integers)."""
+    skew = os.environ.get("SKEW")
+    if not skew:
+        return rand_fr(n)
+    hi = 2 if skew == "bits" else 256
+    z = torch.zeros((n, 4), dtype=torch.int64, device=dev)
+    z[:, 0] = torch.randint(0, hi, (n,), dtype=torch.int64, device=dev)
+    return z.contiguous()
+
+
 def timed(fn):
     fn()
     torch.cuda.synchronize()
@@ -49,7 +61,7 @@ if what in ("msm", "msm2"):
     pb = 64 * group
     bases = torch.empty(n * pb, dtype=torch.uint8, device=dev)
     ctx.gen_bases_dev(curve, group, int(os.environ.get('SEED', '2')), n, bases.data_ptr())
-    scal = rand_fr(n)
+    scal = witness_fr(n)
     out = torch.empty(96 * group, dtype=torch.uint8, device=dev)
     best, avg = timed(lambda: ctx.msm_dev(curve, group, bases.data_ptr(), scal.data_ptr(), n, out.data_ptr()))
     print("msm G%d 2^%d: best %.3f ms avg %.3f ms  -> %.1f Mpts/s ; accumulate kernel %.3f ms" %
@@ -73,7 +85,7 @@ elif what == "prove":
     torch.cuda.synchronize()
     pk = ctx.pk_create(curve, nv, ni, m, aq.data_ptr(), b1q.data_ptr(), b2q.data_ptr(), hq.data_ptr(), lq.data_ptr(),
                        fixed.data_ptr(), device_ptrs=True)
-    a, b, c, w = rand_fr(m), rand_fr(m), rand_fr(m), rand_fr(nv)
+    a, b, c, w = rand_fr(m), rand_fr(m), rand_fr(m), witness_fr(nv)
     import numpy as np
     rs = np.array([[1, 2, 3, 4], [5, 6, 7, 8]], dtype=np.uint64)
     out = torch.empty(96 * 2 + 192, dtype=torch.uint8, device=dev)
