@@ -697,7 +697,7 @@ void msm_bucket_phase(hipStream_t s, const MsmSort& st, const MsmBuffers<F>& b, 
   hipLaunchKernelGGL(msm_finalize_kernel<F>, dim3((unsigned)((b.nbw + 255) / 256)), dim3(256), 0, s, g, st.counts,
                      st.seg_off, b.seg_sum, b.buckets, b.giant, b.giant + 1, b.giant_cap);
   {
-    unsigned grows = b.giant_cap < 64 ? b.giant_cap : 64;
+    unsigned grows = b.giant_cap < 512 ? b.giant_cap : 512;   // idle rows exit at once
     hipLaunchKernelGGL(msm_giant_kernel<F>, dim3(kGiantSlices, grows), dim3(256), 0, s, g, st.counts, st.seg_off,
                        b.seg_sum, b.giant, b.giant + 1, b.giant_cap);
     hipLaunchKernelGGL(msm_giant_fold_kernel<F>, dim3(grows), dim3(64), 0, s, g, st.counts, st.seg_off, b.seg_sum,

@@ -156,6 +156,7 @@ static void msms_typed(dg16_ctx* ctx, Call& k0, Call& k1, Call& k2, const PkDev&
   hipLaunchKernelGGL(prover_scalar_prep_kernel<Fr>, dim3(1), dim3(1), 0, k0.s(), r_s, sc_ab, sc_l, n_ab, n_l,
                      (int)mont, (int)(pk.shard + 1 == pk.nshards));
   DG_HIP(hipGetLastError());
+  DG_HIP(hipEventRecord(ctx->pipe_ev[8], k0.s()));
   // Scheduling.  Every saturating kernel of a proof (digit sorts, bucket accumulations, NTTs) goes down ONE
   // stream (channel 0): they are all VALU-bound, and co-scheduling them was measured equal at best and up to
   // 1.7x worse from run to run.  The latency-bound bucket reductions (finalize -> chunk -> sums -> tail: a few
@@ -186,22 +187,37 @@ static void msms_typed(dg16_ctx* ctx, Call& k0, Call& k1, Call& k2, const PkDev&
   DG_HIP(hipEventRecord(ev[4], side));                 // B1's buffers (channel 1) are free again
   hipLaunchKernelGGL((prover_stage1_g1_kernel<Fq, Fr>), dim3(1), dim3(128), 0, side, rec, fixed_g1, r_s, (int)mont,
                      first_shard);
-  // side2: reduction of B
+  // h-polynomial + the digit sorts of H and L do not depend on the witness MSMs.  DG16_PREP_OVERLAP=1 sends them
+  // down side2 underneath the A / B1 / B accumulations; measured 23.3 ms (off) vs 24.4 ms (on) per 2^20 proof:
+  // the chip is saturated either way and the co-scheduled accumulations slow down by more than is hidden.
+  static const bool overlap = [] { const char* e = getenv("DG16_PREP_OVERLAP"); return e && atoi(e) != 0; }();
+  hipStream_t prep = overlap ? side2 : main;
+  if (overlap) DG_HIP(hipStreamWaitEvent(prep, ev[8], 0));   // staged a, b, c and the scalar vectors
+  else DG_HIP(hipStreamWaitEvent(main, ev[3], 0));
+  Fr* h_dev = (Fr*)ws(k0.c, 3, m * sizeof(Fr));
+  {
+    hipStream_t saved = k0.c.cur;     // h_poly_launch() issues on the Call's stream, with channel 0's buffers
+    k0.c.cur = prep;
+    h_poly_launch(k0, CURVE, a_dev, b_dev, c_dev, log_m, h_dev);
+    k0.c.cur = saved;
+  }
+  MsmSort st_h = msm_sort_on<Fr, CT::SCALAR_BITS>(prep, k0.c, h_dev + pk.h_lo, n_h, true, true, pk.c_h);
+  MsmSort st_l = msm_sort_on<Fr, CT::SCALAR_BITS>(prep, k2.c, sc_l, n_l + 1, mont, true, pk.c_l);
+  if (overlap) {
+    DG_HIP(hipEventRecord(ev[9], prep));
+    DG_HIP(hipStreamWaitEvent(main, ev[9], 0));
+    DG_HIP(hipStreamWaitEvent(main, ev[3], 0));
+  }
+  // side2: reduction of B (queued behind the prep work there)
   DG_HIP(hipStreamWaitEvent(side2, ev[2], 0));
   msm_bucket_phase<Fq2>(side2, st_ab, buf_b2, false, res_b2);
   hipLaunchKernelGGL(prover_stage1_g2_kernel<Fq2>, dim3(1), dim3(1), 0, side2, res_b2, fixed_g2, first_shard);
   DG_HIP(hipEventRecord(ev[5], side2));                // sort_ab (channel 1's sort buffers) no longer needed by B
 
-  // main: h-polynomial, then H (sort buffers: channel 0; bucket buffers: channel 0 after A's reduction)
-  DG_HIP(hipStreamWaitEvent(main, ev[3], 0));
-  Fr* h_dev = (Fr*)ws(k0.c, 3, m * sizeof(Fr));
-  h_poly_launch(k0, CURVE, a_dev, b_dev, c_dev, log_m, h_dev);
-  MsmSort st_h = msm_sort_on<Fr, CT::SCALAR_BITS>(main, k0.c, h_dev + pk.h_lo, n_h, true, true, pk.c_h);
   MsmBuffers<Fq> buf_h = msm_buffers<Fq>(k0.c, st_h.g);
   msm_accumulate_phase<Fq>(main, st_h, buf_h, pk.h_q);
   DG_HIP(hipEventRecord(ev[6], main));
-  // L: sort buffers of channel 2 (unused so far), bucket buffers of channel 1 after B1's reduction
-  MsmSort st_l = msm_sort_on<Fr, CT::SCALAR_BITS>(main, k2.c, sc_l, n_l + 1, mont, true, pk.c_l);
+  // L: sort buffers of channel 2, bucket buffers of channel 1 after B1's reduction
   DG_HIP(hipStreamWaitEvent(main, ev[4], 0));
   MsmBuffers<Fq> buf_l = msm_buffers<Fq>(k1.c, st_l.g);
   msm_accumulate_phase<Fq>(main, st_l, buf_l, pk.l_q);

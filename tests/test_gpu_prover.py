@@ -11,6 +11,7 @@ from oracle import corc
 from oracle.pyref.fields import FQ, FR
 from oracle.pyref.curves import CURVES
 from oracle.pyref import groth16 as G
+from oracle.pyref import pairing as PR
 from gpu_util import ctx
 
 pytestmark = pytest.mark.gpu
@@ -77,6 +78,12 @@ def test_prove_matches_bigint_prover(curve, nc, nw):
         sa, sb, scc = G.proof_scalars_from_trapdoor(r1cs, F, td, sc, r, s, w)
         assert gA == g1.mul(g1.gen, sa) and gB == g2.mul(g2.gen, sb) and gC == g1.mul(g1.gen, scc)
         assert G.verify_in_exponent(r1cs, F, td, sc, (sa, sb, scc), w)
+    # ... and the GPU's last (blinded) proof is accepted by the pairing verifier that accepts the reference's
+    # snarkjs proof (tests/test_oracle_pairing.py): e(A, B) = e(alpha, beta) e(IC(x), gamma) e(C, delta)
+    vk = {"alpha_g1": pk["alpha_g1"], "beta_g2": pk["beta_g2"], "gamma_g2": pk["gamma_g2"],
+          "delta_g2": pk["delta_g2"], "ic": pk["gamma_abc_g1"]}
+    assert PR.groth16_verify(curve, vk, w[1:ni], (gA, gB, gC))
+    assert not PR.groth16_verify(curve, vk, [(w[1] + 1) % F.p], (gA, gB, gC))
     dpk.close()
 
 
