@@ -16,7 +16,7 @@
 namespace dg16 {
 
 constexpr int kChannels = 3;
-constexpr int kSlots = 24;
+constexpr int kSlots = 32;
 
 struct Channel {
   hipStream_t own = nullptr;

@@ -261,6 +261,228 @@ __global__ void __launch_bounds__(256) msm_scatter_kernel(const int* __restrict_
   }
 }
 
+// ---- 1'-3': partitioned digit sort (large MSMs) ------------------------------------------------------
+// The atomic path above issues one device-scope atomic per entry twice (histogram, rank) and scatters 4-byte
+// entries at random: ~31 G atomics/s and a 64-byte memory transaction per entry, 1.5 ms per 2^20-scalar sort.
+// Here the slot index (bucket-window, bucket) is split into a partition (high bits, <= 256 of them) and a bin
+// (low bits, <= 4096).  Pass 1 recomputes the digits twice instead of storing them: (a) per-workgroup LDS
+// histogram over partitions, (b) after a scan, (ref, slot) pairs go to their partition at LDS-ranked
+// positions.  Pass 2 walks each partition in tiles: (a) LDS histogram over bins -> bucket counts (one global
+// atomic per non-empty bin and workgroup instead of one per entry), (b) after the usual bucket scans, LDS ranks
+// inside the tile + one returning atomic per bin and tile give every entry its final position.
+constexpr unsigned kPartScalars = 1024;   // scalars per workgroup in pass 1
+constexpr unsigned kPartMax = 256;        // partitions
+constexpr unsigned kPartMaxLowBits = 12;  // bins per partition <= 4096
+constexpr unsigned kPartTileLog = 11;     // entries per tile in pass 2 (8 per lane)
+constexpr unsigned kPartBlocks = 32;      // workgroups striding over one partition's tiles
+
+struct PartGeom {
+  unsigned low_bits, nparts, nblk1;
+};
+
+template <class Fr>
+__device__ __forceinline__ int msm_digit(const Fr& s, unsigned w, unsigned c, unsigned& carry) {
+  const unsigned half = 1u << (c - 1);
+  unsigned bit = w * c;
+  unsigned limb = bit >> 5, off = bit & 31;
+  uint64_t v = 0;
+  if (limb < (unsigned)Fr::NL) {
+    v = s.l[limb];
+    if (limb + 1 < (unsigned)Fr::NL) v |= (uint64_t)s.l[limb + 1] << 32;
+    v >>= off;
+  }
+  int d = (int)((unsigned)v & ((1u << c) - 1)) + (int)carry;
+  if ((unsigned)d > half) { d -= (int)(1u << c); carry = 1; } else { carry = 0; }
+  return d;
+}
+
+template <class Fr>
+__global__ void __launch_bounds__(256) msm_part_hist_kernel(const Fr* __restrict__ scalars, size_t n, int mont,
+                                                             MsmGeom g, PartGeom pg,
+                                                             unsigned* __restrict__ blockhist) {
+  __shared__ unsigned hist[kPartMax];
+  hist[threadIdx.x] = 0;
+  __syncthreads();
+  for (unsigned k = 0; k < kPartScalars / 256; k++) {
+    size_t i = (size_t)blockIdx.x * kPartScalars + k * 256 + threadIdx.x;
+    if (i >= n) continue;
+    Fr s = scalars[i];
+    if (mont) s = s.from_mont();
+    unsigned carry = 0;
+    for (unsigned w = 0; w < g.nwin; w++) {
+      int d = msm_digit(s, w, g.c, carry);
+      if (d == 0) continue;
+      unsigned slot = (g.table ? 0u : (w << g.log_nb)) + (unsigned)(d < 0 ? -d : d) - 1;
+      atomicAdd(&hist[slot >> pg.low_bits], 1u);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < pg.nparts) blockhist[(size_t)threadIdx.x * pg.nblk1 + blockIdx.x] = hist[threadIdx.x];
+}
+
+template <class Fr>
+__global__ void __launch_bounds__(256) msm_part_scatter_kernel(const Fr* __restrict__ scalars, size_t n, int mont,
+                                                                MsmGeom g, PartGeom pg,
+                                                                const unsigned* __restrict__ blockoff,
+                                                                uint2* __restrict__ part) {
+  __shared__ unsigned cur[kPartMax];
+  if (threadIdx.x < pg.nparts) cur[threadIdx.x] = blockoff[(size_t)threadIdx.x * pg.nblk1 + blockIdx.x];
+  __syncthreads();
+  for (unsigned k = 0; k < kPartScalars / 256; k++) {
+    size_t i = (size_t)blockIdx.x * kPartScalars + k * 256 + threadIdx.x;
+    if (i >= n) continue;
+    Fr s = scalars[i];
+    if (mont) s = s.from_mont();
+    unsigned carry = 0;
+    for (unsigned w = 0; w < g.nwin; w++) {
+      int d = msm_digit(s, w, g.c, carry);
+      if (d == 0) continue;
+      unsigned slot = (g.table ? 0u : (w << g.log_nb)) + (unsigned)(d < 0 ? -d : d) - 1;
+      unsigned ref = g.table ? (unsigned)((size_t)w * n + i) : (unsigned)i;   // table row 2^(c*w) * P_i
+      unsigned pos = atomicAdd(&cur[slot >> pg.low_bits], 1u);
+      part[pos] = make_uint2(ref | (d < 0 ? 0x80000000u : 0u), slot);
+    }
+  }
+}
+
+// generic in-place exclusive scan of a[0..len): chunk scan -> scan of chunk totals -> add back
+template <int TU>
+__global__ void __launch_bounds__(1024) scan_chunk_kernel(unsigned* __restrict__ a, size_t len,
+                                                           unsigned* __restrict__ tot) {
+  __shared__ unsigned sh[1024];
+  const size_t lo = (size_t)blockIdx.x * 4096 + threadIdx.x * 4;
+  unsigned v[4], sum = 0;
+#pragma unroll
+  for (unsigned j = 0; j < 4; j++) {
+    v[j] = lo + j < len ? a[lo + j] : 0;
+    sum += v[j];
+  }
+  sh[threadIdx.x] = sum;
+  __syncthreads();
+  for (unsigned d = 1; d < 1024; d <<= 1) {
+    unsigned t = threadIdx.x >= d ? sh[threadIdx.x - d] : 0;
+    __syncthreads();
+    sh[threadIdx.x] += t;
+    __syncthreads();
+  }
+  unsigned run = sh[threadIdx.x] - sum;
+#pragma unroll
+  for (unsigned j = 0; j < 4; j++)
+    if (lo + j < len) {
+      a[lo + j] = run;
+      run += v[j];
+    }
+  if (threadIdx.x == 1023) tot[blockIdx.x] = sh[1023];
+}
+template <int TU>
+__global__ void __launch_bounds__(1024) scan_tops_kernel(unsigned* __restrict__ tot, unsigned nchunks) {
+  __shared__ unsigned sh[1024];
+  const unsigned per = (nchunks + 1023) / 1024;
+  const unsigned lo = threadIdx.x * per;
+  unsigned sum = 0;
+  for (unsigned j = 0; j < per; j++)
+    if (lo + j < nchunks) sum += tot[lo + j];
+  sh[threadIdx.x] = sum;
+  __syncthreads();
+  for (unsigned d = 1; d < 1024; d <<= 1) {
+    unsigned t = threadIdx.x >= d ? sh[threadIdx.x - d] : 0;
+    __syncthreads();
+    sh[threadIdx.x] += t;
+    __syncthreads();
+  }
+  unsigned run = sh[threadIdx.x] - sum;
+  for (unsigned j = 0; j < per; j++)
+    if (lo + j < nchunks) {
+      unsigned t = tot[lo + j];
+      tot[lo + j] = run;
+      run += t;
+    }
+}
+template <int TU>
+__global__ void __launch_bounds__(1024) scan_add_kernel(unsigned* __restrict__ a, size_t len,
+                                                         const unsigned* __restrict__ tot) {
+  const size_t lo = (size_t)blockIdx.x * 4096 + threadIdx.x * 4;
+  const unsigned add = tot[blockIdx.x];
+#pragma unroll
+  for (unsigned j = 0; j < 4; j++)
+    if (lo + j < len) a[lo + j] += add;
+}
+
+template <int TU>
+__global__ void __launch_bounds__(256) msm_part_count_kernel(const uint2* __restrict__ part,
+                                                              const unsigned* __restrict__ blockoff, PartGeom pg,
+                                                              unsigned* __restrict__ counts) {
+  __shared__ unsigned hist[1u << kPartMaxLowBits];
+  const unsigned p = blockIdx.y;
+  const unsigned lo = blockoff[(size_t)p * pg.nblk1];
+  const unsigned size = blockoff[(size_t)(p + 1) * pg.nblk1] - lo;
+  if (((size_t)blockIdx.x << kPartTileLog) >= size) return;
+  const unsigned nlow = 1u << pg.low_bits;
+  for (unsigned b = threadIdx.x; b < nlow; b += 256) hist[b] = 0;
+  __syncthreads();
+  for (size_t t = (size_t)blockIdx.x << kPartTileLog; t < size; t += (size_t)gridDim.x << kPartTileLog)
+    for (unsigned j = 0; j < (1u << kPartTileLog) / 256; j++) {
+      size_t idx = t + j * 256 + threadIdx.x;
+      if (idx < size) atomicAdd(&hist[part[lo + idx].y & (nlow - 1)], 1u);
+    }
+  __syncthreads();
+  for (unsigned b = threadIdx.x; b < nlow; b += 256)
+    if (hist[b]) atomicAdd(&counts[((size_t)p << pg.low_bits) + b], hist[b]);
+}
+
+template <int TU>
+__global__ void __launch_bounds__(256) msm_part_place_kernel(const uint2* __restrict__ part,
+                                                              const unsigned* __restrict__ blockoff, PartGeom pg,
+                                                              MsmGeom g, const unsigned* __restrict__ offsets,
+                                                              const unsigned* __restrict__ seg_off,
+                                                              unsigned* __restrict__ cursor,
+                                                              unsigned* __restrict__ entries,
+                                                              unsigned* __restrict__ seg_bucket) {
+  __shared__ unsigned cnt[1u << kPartMaxLowBits];    // entries of this tile per bin
+  __shared__ unsigned rank0[1u << kPartMaxLowBits];  // rank of the tile's first entry inside its bucket
+  __shared__ unsigned dst0[1u << kPartMaxLowBits];   // position of the bucket's first entry
+  const unsigned p = blockIdx.y;
+  const unsigned lo = blockoff[(size_t)p * pg.nblk1];
+  const unsigned size = blockoff[(size_t)(p + 1) * pg.nblk1] - lo;
+  if (((size_t)blockIdx.x << kPartTileLog) >= size) return;
+  const unsigned nlow = 1u << pg.low_bits;
+  constexpr unsigned PER = (1u << kPartTileLog) / 256;
+  for (size_t t = (size_t)blockIdx.x << kPartTileLog; t < size; t += (size_t)gridDim.x << kPartTileLog) {
+    for (unsigned b = threadIdx.x; b < nlow; b += 256) cnt[b] = 0;
+    __syncthreads();
+    uint2 e[PER];
+    unsigned lr[PER];
+#pragma unroll
+    for (unsigned j = 0; j < PER; j++) {
+      size_t idx = t + j * 256 + threadIdx.x;
+      e[j] = make_uint2(0u, 0xFFFFFFFFu);
+      if (idx < size) {
+        e[j] = part[lo + idx];
+        lr[j] = atomicAdd(&cnt[e[j].y & (nlow - 1)], 1u);
+      }
+    }
+    __syncthreads();
+    for (unsigned b = threadIdx.x; b < nlow; b += 256)
+      if (cnt[b]) {
+        const size_t slot = ((size_t)p << pg.low_bits) + b;
+        rank0[b] = atomicAdd(&cursor[slot], cnt[b]);
+        dst0[b] = (unsigned)((slot >> g.log_nb) * g.region) + offsets[slot];
+      }
+    __syncthreads();
+#pragma unroll
+    for (unsigned j = 0; j < PER; j++) {
+      if (e[j].y == 0xFFFFFFFFu) continue;
+      const unsigned slot = e[j].y, b = slot & (nlow - 1);
+      const unsigned rank = rank0[b] + lr[j];
+      entries[dst0[b] + rank] = e[j].x;
+      if ((rank & ((1u << g.seg_log) - 1)) == 0)
+        seg_bucket[(size_t)(slot >> g.log_nb) * g.seg_cap + seg_off[slot] + (rank >> g.seg_log)] =
+            slot & ((1u << g.log_nb) - 1);
+    }
+    __syncthreads();
+  }
+}
+
 // ---- 4: segment accumulation -------------------------------------------------------------------
 template <class F>
 __global__ void __launch_bounds__(256, (sizeof(F) > 48 ? 2 : 1))
@@ -608,7 +830,17 @@ MsmSort msm_sort_on(hipStream_t s, Channel& wsch, const void* scalars, size_t n,
   const size_t nbw = (size_t)g.bw << g.log_nb;
   const size_t nseg_slots = (size_t)g.bw * g.seg_cap;
   DG_REQUIRE((size_t)g.nwin * n < ((size_t)1 << 31), DG16_ERR_BAD_ARG, "W * n must be < 2^31");
-  r.digits = (int*)ws(wsch, 4, (size_t)g.nwin * n * 4);
+  // large sorts: LDS-partitioned passes; small ones: the direct atomic path (fewer launches)
+  unsigned lg_nbw = 0;
+  while (((size_t)1 << lg_nbw) < nbw) lg_nbw++;
+  static const int force_path = [] { const char* e = getenv("DG16_MSM_SORT"); return e ? atoi(e) : 0; }();  // 1 atomic, 2 partitioned
+  PartGeom pg;
+  pg.low_bits = lg_nbw > 8 ? lg_nbw - 8 : 0;
+  const bool partitioned = pg.low_bits <= kPartMaxLowBits &&
+                           (force_path == 2 || (force_path != 1 && (size_t)g.nwin * n >= ((size_t)1 << 18)));
+  pg.nparts = (unsigned)((nbw + ((size_t)1 << pg.low_bits) - 1) >> pg.low_bits);
+  pg.nblk1 = (unsigned)((n + kPartScalars - 1) / kPartScalars);
+  r.digits = (int*)ws(wsch, 4, (size_t)g.nwin * n * (partitioned ? 8 : 4));
   r.entries = (unsigned*)ws(wsch, 5, (size_t)g.nwin * n * 4);
   unsigned* tabs = (unsigned*)ws(wsch, 6, (nbw * 4 + g.bw + nseg_slots) * 4);
   r.counts = tabs;
@@ -618,9 +850,27 @@ MsmSort msm_sort_on(hipStream_t s, Channel& wsch, const void* scalars, size_t n,
   r.seg_total = r.cursor + nbw;
   r.seg_bucket = r.seg_total + g.bw;
   DG_HIP(hipMemsetAsync(r.counts, 0, nbw * 4, s));
-  if (n)
+  uint2* part = (uint2*)r.digits;
+  unsigned* blockoff = nullptr;
+  if (n && partitioned) {
+    const size_t len = (size_t)pg.nparts * pg.nblk1 + 1;      // + sentinel = total entries
+    const unsigned nchunks = (unsigned)((len + 4095) / 4096);
+    blockoff = (unsigned*)ws(wsch, 25, (len + nchunks) * 4);
+    unsigned* tot = blockoff + len;
+    DG_HIP(hipMemsetAsync(blockoff + len - 1, 0, 4, s));
+    hipLaunchKernelGGL(msm_part_hist_kernel<Fr>, dim3(pg.nblk1), dim3(256), 0, s, (const Fr*)scalars, n,
+                       (int)scalars_mont, g, pg, blockoff);
+    hipLaunchKernelGGL(scan_chunk_kernel<0>, dim3(nchunks), dim3(1024), 0, s, blockoff, len, tot);
+    hipLaunchKernelGGL(scan_tops_kernel<0>, dim3(1), dim3(1024), 0, s, tot, nchunks);
+    hipLaunchKernelGGL(scan_add_kernel<0>, dim3(nchunks), dim3(1024), 0, s, blockoff, len, tot);
+    hipLaunchKernelGGL(msm_part_scatter_kernel<Fr>, dim3(pg.nblk1), dim3(256), 0, s, (const Fr*)scalars, n,
+                       (int)scalars_mont, g, pg, blockoff, part);
+    hipLaunchKernelGGL(msm_part_count_kernel<0>, dim3(kPartBlocks, pg.nparts), dim3(256), 0, s, part, blockoff, pg,
+                       r.counts);
+  } else if (n) {
     hipLaunchKernelGGL(msm_digits_kernel<Fr>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const Fr*)scalars,
                        n, (int)scalars_mont, g, r.digits, r.counts);
+  }
   {
     const unsigned nblocks = ((1u << g.log_nb) + kScanBlock - 1) / kScanBlock;   // <= 512 for c <= 22
     unsigned* block_tot = (unsigned*)ws(wsch, 9, (size_t)g.bw * nblocks * 2 * 4);
@@ -630,7 +880,10 @@ MsmSort msm_sort_on(hipStream_t s, Channel& wsch, const void* scalars, size_t n,
     hipLaunchKernelGGL(msm_scan_fix_kernel<0>, dim3(nblocks, g.bw), dim3(1024), 0, s, r.offsets, r.seg_off, r.cursor,
                        block_tot, g.log_nb);
   }
-  if (n)
+  if (n && partitioned)
+    hipLaunchKernelGGL(msm_part_place_kernel<0>, dim3(kPartBlocks, pg.nparts), dim3(256), 0, s, part, blockoff, pg, g,
+                       r.offsets, r.seg_off, r.cursor, r.entries, r.seg_bucket);
+  else if (n)
     hipLaunchKernelGGL(msm_scatter_kernel<0>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, r.digits, n, g,
                        r.offsets, r.seg_off, r.cursor, r.entries, r.seg_bucket);
   DG_HIP(hipGetLastError());
