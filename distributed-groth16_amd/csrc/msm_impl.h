@@ -621,6 +621,20 @@ msm_accumulate_lds_kernel(const Affine<F>* __restrict__ bases, size_t n, MsmGeom
 #undef DG_STAGE
 }
 
+// Giant buckets (a boolean witness puts half of ALL entries into bucket 0; the short top window of a c that does
+// not divide the scalar width does the same): two launches.  Stage 1 cuts the bucket's segment partials into
+// <= kGiantSlices slices, one workgroup each, and leaves every slice's sum IN PLACE in the slice's first
+// segment slot; stage 2 adds the slice sums.  (One workgroup per bucket chained 128 dependent additions per
+// lane for a 2^20-bit witness: 2.5 ms for G1, far more for G2.)
+constexpr unsigned kGiantSlices = 64;
+constexpr unsigned kGiantSliceSegs = 512;
+__device__ __forceinline__ void giant_geometry(unsigned nseg, unsigned& slices, unsigned& per) {
+  slices = (nseg + kGiantSliceSegs - 1) / kGiantSliceSegs;
+  if (slices > kGiantSlices) slices = kGiantSlices;
+  per = (nseg + slices - 1) / slices;
+  slices = (nseg + per - 1) / per;
+}
+
 // ---- 4b: bucket = sum of its segment partials -----------------------------------------------------
 template <class F>
 __global__ void __launch_bounds__(256) msm_finalize_kernel(MsmGeom g, const unsigned* __restrict__ counts,
@@ -639,26 +653,20 @@ __global__ void __launch_bounds__(256) msm_finalize_kernel(MsmGeom g, const unsi
   if (nseg == 1) { buckets[gid] = sp[0]; return; }
   if (nseg > kGiantSegs) {
     unsigned slot = atomicAdd(giant_count, 1u);
-    if (slot < giant_cap) { giant_list[slot] = (unsigned)gid; return; }
+    if (slot < giant_cap) {
+      giant_list[slot] = (unsigned)gid;
+      unsigned slices, per;
+      giant_geometry(nseg, slices, per);
+      unsigned wb = atomicAdd(giant_count + 1, slices);   // work items: (giant, slice)
+      unsigned* work = giant_list + giant_cap;
+      for (unsigned k = 0; k < slices; k++) work[wb + k] = (slot << 6) | k;
+      return;
+    }
     // list full (cannot happen: giant_cap >= total segments / kGiantSegs): fall through, serial
   }
   XYZZ<F> acc = sp[0];
   for (unsigned s = 1; s < nseg; s++) acc = acc.add(sp[s]);
   buckets[gid] = acc;
-}
-
-// Giant buckets (a boolean witness puts half of ALL entries into bucket 0; the short top window of a c that does
-// not divide the scalar width does the same): two launches.  Stage 1 cuts the bucket's segment partials into
-// <= kGiantSlices slices, one workgroup each, and leaves every slice's sum IN PLACE in the slice's first
-// segment slot; stage 2 adds the slice sums.  (One workgroup per bucket chained 128 dependent additions per
-// lane for a 2^20-bit witness: 2.5 ms for G1, far more for G2.)
-constexpr unsigned kGiantSlices = 64;
-constexpr unsigned kGiantSliceSegs = 512;
-__device__ __forceinline__ void giant_geometry(unsigned nseg, unsigned& slices, unsigned& per) {
-  slices = (nseg + kGiantSliceSegs - 1) / kGiantSliceSegs;
-  if (slices > kGiantSlices) slices = kGiantSlices;
-  per = (nseg + slices - 1) / slices;
-  slices = (nseg + per - 1) / per;
 }
 
 template <class F>
@@ -668,17 +676,17 @@ __global__ void __launch_bounds__(256) msm_giant_kernel(MsmGeom g, const unsigne
                                                          const unsigned* __restrict__ giant_count,
                                                          const unsigned* __restrict__ giant_list, unsigned giant_cap) {
   __shared__ XYZZ<F> sh[256];
-  unsigned ng = *giant_count;
-  if (ng > giant_cap) ng = giant_cap;
-  for (unsigned gi = blockIdx.y; gi < ng; gi += gridDim.y) {
-    const unsigned gid = giant_list[gi];
+  const unsigned nwork = giant_count[1];
+  const unsigned* work = giant_list + giant_cap;
+  for (unsigned wi = blockIdx.x; wi < nwork; wi += gridDim.x) {
+    const unsigned item = work[wi];
+    const unsigned gid = giant_list[item >> 6], slice = item & 63;
     const unsigned w = gid >> g.log_nb;
     const unsigned nseg = (counts[gid] + (1u << g.seg_log) - 1) >> g.seg_log;
     unsigned slices, per;
     giant_geometry(nseg, slices, per);
-    if (blockIdx.x >= slices) continue;          // block-uniform
     XYZZ<F>* sp = seg_sum + (size_t)w * g.seg_cap + seg_off[gid];
-    const unsigned lo = blockIdx.x * per;
+    const unsigned lo = slice * per;
     const unsigned hi = lo + per < nseg ? lo + per : nseg;
     XYZZ<F> acc = XYZZ<F>::inf();
     for (unsigned s = lo + threadIdx.x; s < hi; s += 256) acc = acc.add(sp[s]);
@@ -918,7 +926,8 @@ MsmBuffers<F> msm_buffers(Channel& wsch, const MsmGeom& g) {
   b.partial = (XYZZ<F>*)ws(wsch, 15, (b.nchunks + (size_t)g.bw * kSumSlices + g.bw) * sizeof(XYZZ<F>));
   b.slice_buf = b.partial + b.nchunks;
   b.window_sums = b.slice_buf + (size_t)g.bw * kSumSlices;
-  b.giant = (unsigned*)ws(wsch, 10, (b.giant_cap + 1) * 4);   // [0] = count, [1..] = bucket ids
+  // [0] giants, [1] work items, then giant_cap bucket ids, then <= 2 * giant_cap (giant, slice) work items
+  b.giant = (unsigned*)ws(wsch, 10, ((size_t)b.giant_cap * 3 + 2) * 4);
   return b;
 }
 
@@ -946,15 +955,15 @@ void msm_accumulate_phase(hipStream_t s, const MsmSort& st, const MsmBuffers<F>&
 template <class F>
 void msm_bucket_phase(hipStream_t s, const MsmSort& st, const MsmBuffers<F>& b, bool out_affine, void* out_dev) {
   const MsmGeom& g = st.g;
-  DG_HIP(hipMemsetAsync(b.giant, 0, 4, s));
+  DG_HIP(hipMemsetAsync(b.giant, 0, 8, s));
   hipLaunchKernelGGL(msm_finalize_kernel<F>, dim3((unsigned)((b.nbw + 255) / 256)), dim3(256), 0, s, g, st.counts,
-                     st.seg_off, b.seg_sum, b.buckets, b.giant, b.giant + 1, b.giant_cap);
+                     st.seg_off, b.seg_sum, b.buckets, b.giant, b.giant + 2, b.giant_cap);
   {
-    unsigned grows = b.giant_cap < 512 ? b.giant_cap : 512;   // idle rows exit at once
-    hipLaunchKernelGGL(msm_giant_kernel<F>, dim3(kGiantSlices, grows), dim3(256), 0, s, g, st.counts, st.seg_off,
-                       b.seg_sum, b.giant, b.giant + 1, b.giant_cap);
-    hipLaunchKernelGGL(msm_giant_fold_kernel<F>, dim3(grows), dim3(64), 0, s, g, st.counts, st.seg_off, b.seg_sum,
-                       b.buckets, b.giant, b.giant + 1, b.giant_cap);
+    // few workgroups striding over the device-side work list: nothing to do (the common case) costs ~10 us
+    hipLaunchKernelGGL(msm_giant_kernel<F>, dim3(256), dim3(256), 0, s, g, st.counts, st.seg_off, b.seg_sum, b.giant,
+                       b.giant + 2, b.giant_cap);
+    hipLaunchKernelGGL(msm_giant_fold_kernel<F>, dim3(64), dim3(64), 0, s, g, st.counts, st.seg_off, b.seg_sum,
+                       b.buckets, b.giant, b.giant + 2, b.giant_cap);
   }
   hipLaunchKernelGGL(msm_chunk_kernel<F>, dim3((unsigned)((b.nchunks + 255) / 256)), dim3(256), 0, s, b.buckets, g,
                      b.partial);

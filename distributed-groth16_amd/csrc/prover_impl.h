@@ -193,7 +193,6 @@ static void msms_typed(dg16_ctx* ctx, Call& k0, Call& k1, Call& k2, const PkDev&
   static const bool overlap = [] { const char* e = getenv("DG16_PREP_OVERLAP"); return e && atoi(e) != 0; }();
   hipStream_t prep = overlap ? side2 : main;
   if (overlap) DG_HIP(hipStreamWaitEvent(prep, ev[8], 0));   // staged a, b, c and the scalar vectors
-  else DG_HIP(hipStreamWaitEvent(main, ev[3], 0));
   Fr* h_dev = (Fr*)ws(k0.c, 3, m * sizeof(Fr));
   {
     hipStream_t saved = k0.c.cur;     // h_poly_launch() issues on the Call's stream, with channel 0's buffers
@@ -206,8 +205,8 @@ static void msms_typed(dg16_ctx* ctx, Call& k0, Call& k1, Call& k2, const PkDev&
   if (overlap) {
     DG_HIP(hipEventRecord(ev[9], prep));
     DG_HIP(hipStreamWaitEvent(main, ev[9], 0));
-    DG_HIP(hipStreamWaitEvent(main, ev[3], 0));
   }
+  DG_HIP(hipStreamWaitEvent(main, ev[3], 0));          // H's bucket buffers = A's (channel 0)
   // side2: reduction of B (queued behind the prep work there)
   DG_HIP(hipStreamWaitEvent(side2, ev[2], 0));
   msm_bucket_phase<Fq2>(side2, st_ab, buf_b2, false, res_b2);
