@@ -155,7 +155,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--log-m", type=int, default=20)
-    ap.add_argument("--cpu-sample-log", type=int, default=16)
+    ap.add_argument("--cpu-sample-log", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -230,7 +230,9 @@ def main():
     alg_bytes = 160.0 * n_g2
     achieved = alg_bytes / (g2_acc_ms * 1e-3) / 1e9
     # bucket additions of that launch: one mixed add (8M + 2S in Fq2 = 28 Fq multiplications) per nonzero digit
-    lg = n_g2.bit_length() - 1                      # msm_geometry() of csrc/msm_impl.h
+    lg = n_g2.bit_length() - 1                      # msm_window_bits() of csrc/msm_impl.h: nearest power of two
+    if n_g2 > (3 << lg) // 2:
+        lg += 1
     cbits = min(max(lg - 4, 4), 16)
     nwin = (254 + 1 + cbits - 1) // cbits
     montmuls = 28.0 * n_g2 * nwin
@@ -276,7 +278,7 @@ def main():
                           "g1_accumulate_ms": g1_ms[-1][0], "g1_call_ms": g1_ms[-1][1]},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cb, ok = cpu_baseline_and_parity(ctx, dev, args.cpu_sample_log)
+        cb, ok = cpu_baseline_and_parity(ctx, dev, min(args.cpu_sample_log, args.log_m))
         res["cpu_baseline"] = cb
         res["parity_check"] = "pass" if ok else "FAIL"
         if not ok:

@@ -1,7 +1,17 @@
-"""Summarise a rocprofv3 results .db (rocpd sqlite): per-kernel count / total / avg / min / max.
-usage: python tools/rocprof_stats.py gpurun_out/prof_x/name_results.db [out.md]"""
+"""Summarise a rocprofv3 run: per-kernel count / total / avg / min / max, as a markdown table.
+Input: the rocpd sqlite .db (default output format) or the *_kernel_stats.csv of `--output-format csv`.
+usage: python tools/rocprof_stats.py gpurun_out/prof_x/name_results.db|name_kernel_stats.csv [out.md]"""
+import csv
 import sqlite3
 import sys
+
+
+def stats_csv(path):
+    rows = []
+    for r in csv.DictReader(open(path)):
+        rows.append((r["Name"], int(r["Calls"]), float(r["TotalDurationNs"]) / 1e6, float(r["AverageNs"]) / 1e3,
+                     float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3))
+    return sorted(rows, key=lambda t: -t[2])
 
 
 def stats(path):
@@ -17,7 +27,7 @@ def stats(path):
 
 
 def main():
-    rows = stats(sys.argv[1])
+    rows = stats_csv(sys.argv[1]) if sys.argv[1].endswith(".csv") else stats(sys.argv[1])
     lines = ["| kernel | calls | total ms | avg us | min us | max us |", "|---|---|---|---|---|---|"]
     for r in rows:
         name = r[0].replace("|", "/")
