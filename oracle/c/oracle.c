@@ -10,7 +10,10 @@
  *   - an independent pure-Python big-int restatement (oracle/pyref) that reproduces the
  *     reference's own relational tests (d_fft == domain.fft, d_msm == msm, mpc proof == proof),
  *   - definitional checks (naive double-and-add MSM, O(n^2) DFT, known-trapdoor Groth16).
- * For numeric MSM/NTT outputs: "parity unpinned by golden vectors" (none exist upstream).
+ *   - the reference's one complete numeric vector: the snarkjs proof triple of fixtures/million is
+ *     accepted by the pairing verifier of oracle/pyref (whose field / curve arithmetic this file is
+ *     cross-checked against point by point), and so are the proofs this oracle's prover produces.
+ * For numeric MSM/NTT outputs taken alone: "parity unpinned by golden vectors" (none exist upstream).
  *
  * Build: make -C oracle/c   ->  oracle/c/liboracle.so   (gcc -O3 -march=native -fopenmp)
  */

@@ -4,8 +4,10 @@ reference obtains from arkworks (ark-ff / ark-ec / ark-poly 0.4, NOT vendored un
 
 Parity status: the reference holds no golden MSM/NTT vectors; the
 arithmetic here is pinned by (i) the curve-family parametrisations q(u), r(u), (ii) the
-in-tree known answers listed in SURVEY.md section 0 (tests/test_oracle_kats.py) and
-(iii) definitional identities (generator order, on-curve, DFT by definition).
+in-tree known answers listed in SURVEY.md section 0 (tests/test_oracle_kats.py),
+(iii) definitional identities (generator order, on-curve, DFT by definition) and (iv) the
+reference's snarkjs-generated Groth16 proof triple (fixtures/million), which the pairing
+verifier built on this arithmetic accepts (oracle/pyref/pairing.py, tests/test_oracle_pairing.py).
 
 Field elements are plain Python ints in [0, p).  Montgomery form (the arkworks in-memory
 representation, R = 2^(64*limbs), pinned by /root/reference/ark-circom/src/zkey.rs:417-427)

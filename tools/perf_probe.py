@@ -22,14 +22,16 @@ if os.environ.get("DG16_ONE_STREAM"):
         ctx.set_stream(ch, torch.cuda.current_stream().cuda_stream)
 elif what != "prove":
     ctx.set_stream(0, torch.cuda.current_stream().cuda_stream)
-curve = "bn254"
+curve = os.environ.get("CURVE", "bn254")
+FQB = 32 if curve == "bn254" else 48            # bytes per base-field element
+FR_TOP = 0x30644E72E131A029 if curve == "bn254" else 0x73EDA753299D7D48
 
 
 def rand_fr(n):
     # uniform over [0, r_top * 2^192) with r_top = top limb of the BN254 scalar modulus: canonical,
     # and statistically indistinguishable from uniform mod r for the bucket histogram
     lo = torch.randint(-2**63, 2**63 - 1, (n, 3), dtype=torch.int64, device=dev)
-    hi = torch.randint(0, 0x30644E72E131A029, (n, 1), dtype=torch.int64, device=dev)
+    hi = torch.randint(0, FR_TOP, (n, 1), dtype=torch.int64, device=dev)
     return torch.cat([lo, hi], dim=1).contiguous()
 
 
@@ -58,11 +60,11 @@ def timed(fn):
 
 if what in ("msm", "msm2"):
     group = 1 if what == "msm" else 2
-    pb = 64 * group
+    pb = 2 * FQB * group
     bases = torch.empty(n * pb, dtype=torch.uint8, device=dev)
     ctx.gen_bases_dev(curve, group, int(os.environ.get('SEED', '2')), n, bases.data_ptr())
     scal = witness_fr(n)
-    out = torch.empty(96 * group, dtype=torch.uint8, device=dev)
+    out = torch.empty(3 * FQB * group, dtype=torch.uint8, device=dev)
     best, avg = timed(lambda: ctx.msm_dev(curve, group, bases.data_ptr(), scal.data_ptr(), n, out.data_ptr()))
     print("msm G%d 2^%d: best %.3f ms avg %.3f ms  -> %.1f Mpts/s ; accumulate kernel %.3f ms" %
           (group, log_n, best * 1e3, avg * 1e3, n / best / 1e6, ctx.last_kernel_ms(0, 1)))
@@ -75,7 +77,7 @@ elif what == "prove":
     # synthetic proving key like PackedProvingKeyShare::rand (groth16/src/proving_key.rs:112-155)
     nv, ni, m = n - 7, 2, n
     def bases(group, cnt, seed):
-        t = torch.empty(cnt * 64 * group, dtype=torch.uint8, device=dev)
+        t = torch.empty(cnt * 2 * FQB * group, dtype=torch.uint8, device=dev)
         ctx.gen_bases_dev(curve, group, seed, cnt, t.data_ptr())
         return t
     aq, b1q, b2q, hq, lq = bases(1, nv, 11), bases(1, nv, 12), bases(2, nv, 13), bases(1, m, 14), bases(1, nv - ni, 15)
@@ -88,12 +90,12 @@ elif what == "prove":
     a, b, c, w = rand_fr(m), rand_fr(m), rand_fr(m), witness_fr(nv)
     import numpy as np
     rs = np.array([[1, 2, 3, 4], [5, 6, 7, 8]], dtype=np.uint64)
-    out = torch.empty(96 * 2 + 192, dtype=torch.uint8, device=dev)
+    out = torch.empty(12 * FQB, dtype=torch.uint8, device=dev)
     def run():
         ctx.prove_dev(pk, a.data_ptr(), b.data_ptr(), c.data_ptr(), w.data_ptr(), rs, out.data_ptr(), scalars_mont=False)
         ctx.sync(0); ctx.sync(1); ctx.sync(2)
     best, avg = timed(run)
-    print("groth16 prove m=2^%d: best %.3f ms avg %.3f ms -> %.2f M constraints/s" % (log_n, best * 1e3, avg * 1e3, (m - ni) / best / 1e6))
+    print(curve, "groth16 prove m=2^%d: best %.3f ms avg %.3f ms -> %.2f M constraints/s" % (log_n, best * 1e3, avg * 1e3, (m - ni) / best / 1e6))
 else:
     a, b, c = rand_fr(n), rand_fr(n), rand_fr(n)
     o = torch.empty_like(a)
