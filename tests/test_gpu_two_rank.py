@@ -1,0 +1,33 @@
+"""GPU: the N > 1 path with the real engine.  Two processes share the one GPU of the test box, each owns a
+shard key, computes its records with libdg16, exchanges them through torch.distributed (gloo: RCCL refuses
+two ranks on one device) and assembles; every rank's proof must equal the unsharded proof.  Everything of
+bench.py's multi-GPU path except the RCCL transport itself is exercised."""
+
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("world,log_m", [(2, 12), (3, 14)])
+def test_sharded_proof_across_processes(world, log_m):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "tools", "two_rank_check.py"), str(log_m)]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=280)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert "TWO_RANK_CHECK PASS" in out.stdout

@@ -86,7 +86,9 @@ elif what == "prove":
     fixed = torch.cat([f1, f2])
     torch.cuda.synchronize()
     pk = ctx.pk_create(curve, nv, ni, m, aq.data_ptr(), b1q.data_ptr(), b2q.data_ptr(), hq.data_ptr(), lq.data_ptr(),
-                       fixed.data_ptr(), device_ptrs=True)
+                       fixed.data_ptr(), device_ptrs=True, shard=0, n_shards=int(os.environ.get("SHARDS", "1")))
+    # SHARDS=N: time what ONE rank of an N-GPU job does (shard 0's key; the record is assembled alone, so the
+    # output is not a proof -- timing only; the all-gather of N x 768 B is not included)
     a, b, c, w = rand_fr(m), rand_fr(m), rand_fr(m), witness_fr(nv)
     import numpy as np
     rs = np.array([[1, 2, 3, 4], [5, 6, 7, 8]], dtype=np.uint64)
