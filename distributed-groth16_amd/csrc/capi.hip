@@ -40,6 +40,7 @@ int dg16_ctx_create(int device, dg16_ctx** out) {
       for (int e = 0; e < 4; e++) DG_HIP(hipEventCreate(&ctx->ch[i].ev[e]));
     }
     for (auto& e : ctx->pipe_ev) DG_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (auto& st : ctx->aux) DG_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
   });
   if (rc != DG16_OK) {
     // keep the message reachable for the caller that failed to get a context
@@ -65,6 +66,8 @@ void dg16_ctx_destroy(dg16_ctx* ctx) {
   }
   for (auto& e : ctx->pipe_ev)
     if (e) hipEventDestroy(e);
+  for (auto& st : ctx->aux)
+    if (st) hipStreamDestroy(st);
   for (auto& kv : ctx->twiddles) {
     hipFree(kv.second.lo);
     hipFree(kv.second.hi);

@@ -61,6 +61,7 @@ struct dg16_ctx {
   // launches overtake the wait once all buffers were warm (second proof on a context differed from the
   // oracle; the first one was masked by the implicit synchronisation of hipMalloc).
   hipEvent_t pipe_ev[16] = {};
+  hipStream_t aux[2] = {};   // extra internal streams of the prover pipeline (never handed out)
   std::map<dg16::TwiddleKey, dg16::TwiddleSet> twiddles;
 };
 

@@ -32,7 +32,8 @@ namespace dg16 {
 // mean bucket occupancy (mean/4, clamped to 16..128): 16 when buckets hold ~32 points (32 measured 20 %
 // slower there: lanes idle behind the longest segment of their wave), larger when buckets are large
 // (table mode), which keeps the number of partials per bucket -- the finalize work -- small.
-constexpr unsigned kMinSegLog = 4, kMaxSegLog = 7;
+constexpr unsigned kMinSegLog = 3, kMaxSegLog = 7;
+constexpr unsigned kMinLanesLog = 18;    // want >= 2^18 segments (4 waves per SIMD) in an accumulation launch
 constexpr unsigned kGiantSegs = 64;      // buckets with more segments are reduced by a whole workgroup
 
 struct MsmGeom {
@@ -54,6 +55,10 @@ inline unsigned msm_window_bits(size_t n, bool table) {
   while (((size_t)1 << (lg + 1)) <= n) lg++;
   if (n > ((size_t)3 << lg) / 2) lg++;     // nearest power of two (2^20 - 5 points are "2^20")
   int c = table ? (int)lg - 3 : (int)lg - 4;
+  // short tables (the shards of a multi-GPU key): the bucket reduction's latency does not shrink with the bucket
+  // count, the number of bucket entries W*n does shrink with c -- measured on a 2^17-point shard: c = 14: 8.2 ms
+  // per proof, 15: 6.2, 16: 6.2, 17: 6.3
+  if (table && c < 16) c = (int)lg + 1 < 16 ? (int)lg + 1 : 16;
   if (const char* e = getenv(table ? "DG16_MSM_TABLE_C" : "DG16_MSM_C")) c = atoi(e);
   int hi = table ? 20 : 16;
   if (c < 4) c = 4;
@@ -74,6 +79,13 @@ inline MsmGeom msm_geometry(size_t n, unsigned scalar_bits, bool table = false, 
     unsigned lm = 0;
     while (((size_t)2 << lm) <= mean) lm++;
     int sl = (int)lm - 2;
+    if (sl < 4) sl = 4;
+    // ... but never so long that the launch runs out of lanes (a 2^17-point shard with 32-entry segments has
+    // 1.2 waves per SIMD: measured 0.62 ms per G1 accumulation instead of 0.25)
+    unsigned le = 0;
+    while (((size_t)2 << le) <= (size_t)g.nwin * n) le++;
+    const int cap = (int)le - (int)kMinLanesLog;
+    if (sl > cap) sl = cap;
     if (const char* e = getenv("DG16_MSM_SEG_LOG")) sl = atoi(e);
     g.seg_log = (unsigned)(sl < (int)kMinSegLog ? (int)kMinSegLog : sl > (int)kMaxSegLog ? (int)kMaxSegLog : sl);
   }
@@ -853,6 +865,49 @@ __device__ __forceinline__ XYZZ<F> dbl_wave(const XYZZ<F>& p) {
   return {x3, y3, zz3, lane_bcast(r3, 8)};
 }
 
+// p + o, both (and the result) uniform across the wave: 14 products in 4 levels       (add-2008-s)
+template <class F>
+__device__ __forceinline__ XYZZ<F> add_wave(const XYZZ<F>& p, const XYZZ<F>& o) {
+  if (o.is_inf()) return p;
+  if (p.is_inf()) return o;
+  const unsigned slot = __lane_id() >> 2;
+  // level 1: u1 = x1 zz2 | u2 = x2 zz1 | s1 = y1 zzz2 | s2 = y2 zzz1
+  const F a1 = F::select(slot == 0, p.x, F::select(slot == 1, o.x, F::select(slot == 2, p.y, o.y)));
+  const F b1 = F::select(slot == 0, o.zz, F::select(slot == 1, p.zz, F::select(slot == 2, o.zzz, p.zzz)));
+  const F r1 = slot_mul(a1, b1);
+  const F u1 = lane_bcast(r1, 0), u2 = lane_bcast(r1, 4), s1 = lane_bcast(r1, 8), s2 = lane_bcast(r1, 12);
+  const F pd = u2 - u1, rd = s2 - s1;
+  if (pd.is_zero()) {
+    if (rd.is_zero()) return dbl_wave(p);
+    return XYZZ<F>::inf();
+  }
+  // level 2: pp = p^2 | rr = r^2 | zz1 zz2 | zzz1 zzz2
+  const F a2 = F::select(slot == 0, pd, F::select(slot == 1, rd, F::select(slot == 2, p.zz, p.zzz)));
+  const F b2 = F::select(slot == 0, pd, F::select(slot == 1, rd, F::select(slot == 2, o.zz, o.zzz)));
+  const F r2 = slot_mul(a2, b2);
+  const F pp = lane_bcast(r2, 0), rr = lane_bcast(r2, 4), zzp = lane_bcast(r2, 8), zzzp = lane_bcast(r2, 12);
+  // level 3: ppp = p pp | q = u1 pp | zz3 = (zz1 zz2) pp
+  const F a3 = F::select(slot == 0, pd, F::select(slot == 1, u1, zzp));
+  const F r3 = slot_mul(a3, pp);
+  const F ppp = lane_bcast(r3, 0), q = lane_bcast(r3, 4), zz3 = lane_bcast(r3, 8);
+  const F x3 = rr - ppp - q.dbl();
+  // level 4: r (q - x3) | s1 ppp | zzz3 = (zzz1 zzz2) ppp
+  const F a4 = F::select(slot == 0, rd, F::select(slot == 1, s1, zzzp));
+  const F b4 = F::select(slot == 0, q - x3, ppp);
+  const F r4 = slot_mul(a4, b4);
+  return {x3, lane_bcast(r4, 0) - lane_bcast(r4, 4), zz3, lane_bcast(r4, 8)};
+}
+// k * p by double-and-add on one wave; k = NW little-endian 32-bit words (plain integer), uniform
+template <class F, int NW>
+__device__ __forceinline__ XYZZ<F> scalar_mul_wave(const XYZZ<F>& p, const uint32_t* k) {
+  XYZZ<F> acc = XYZZ<F>::inf();
+  for (int i = NW * 32 - 1; i >= 0; i--) {
+    acc = dbl_wave(acc);
+    if ((k[i / 32] >> (i % 32)) & 1) acc = add_wave(acc, p);
+  }
+  return acc;
+}
+
 template <class F>
 __global__ void __launch_bounds__(64) msm_tail_kernel(const XYZZ<F>* __restrict__ window_sums, MsmGeom g,
                                                        int affine, F* __restrict__ out) {
@@ -860,7 +915,7 @@ __global__ void __launch_bounds__(64) msm_tail_kernel(const XYZZ<F>* __restrict_
   XYZZ<F> total = XYZZ<F>::inf();
   for (int w = (int)g.bw - 1; w >= 0; w--) {
     for (unsigned k = 0; k < g.c; k++) total = dbl_wave(total);
-    total = total.add(window_sums[w]);
+    total = add_wave(total, window_sums[w]);
   }
   if (threadIdx.x != 0) return;
   if (affine) {

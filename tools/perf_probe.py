@@ -93,8 +93,13 @@ elif what == "prove":
     import numpy as np
     rs = np.array([[1, 2, 3, 4], [5, 6, 7, 8]], dtype=np.uint64)
     out = torch.empty(12 * FQB, dtype=torch.uint8, device=dev)
+    rec = torch.empty(ctx.results_bytes(curve), dtype=torch.uint8, device=dev)
     def run():
-        ctx.prove_dev(pk, a.data_ptr(), b.data_ptr(), c.data_ptr(), w.data_ptr(), rs, out.data_ptr(), scalars_mont=False)
+        if os.environ.get("SHARDS", "1") == "1":
+            ctx.prove_dev(pk, a.data_ptr(), b.data_ptr(), c.data_ptr(), w.data_ptr(), rs, out.data_ptr(), scalars_mont=False)
+        else:
+            ctx.groth16_msms_dev(pk, a.data_ptr(), b.data_ptr(), c.data_ptr(), w.data_ptr(), rs, rec.data_ptr(), scalars_mont=False)
+            ctx.groth16_assemble_dev(pk, rec.data_ptr(), 1, rs, out.data_ptr(), scalars_mont=False)
         ctx.sync(0); ctx.sync(1); ctx.sync(2)
     best, avg = timed(run)
     print(curve, "groth16 prove m=2^%d: best %.3f ms avg %.3f ms -> %.2f M constraints/s" % (log_n, best * 1e3, avg * 1e3, (m - ni) / best / 1e6))
