@@ -29,7 +29,7 @@
 namespace dg16 {
 
 // Accumulation segments: a lane sums <= 2^seg_log consecutive entries of one bucket.  seg_log follows the
-// mean bucket occupancy (mean/4, clamped to 16..128): 16 when buckets hold ~32 points (32 measured 20 %
+// mean bucket occupancy (mean/8, clamped to 8..128 and by the lane count): 16 when buckets hold ~32 points (32 measured 20 %
 // slower there: lanes idle behind the longest segment of their wave), larger when buckets are large
 // (table mode), which keeps the number of partials per bucket -- the finalize work -- small.
 constexpr unsigned kMinSegLog = 3, kMaxSegLog = 7;
@@ -78,7 +78,7 @@ inline MsmGeom msm_geometry(size_t n, unsigned scalar_bits, bool table = false, 
     size_t mean = g.region >> g.log_nb;   // entries per bucket
     unsigned lm = 0;
     while (((size_t)2 << lm) <= mean) lm++;
-    int sl = (int)lm - 2;
+    int sl = (int)lm - 3;      // mean/8: 2^20-point table, mean 240 -> 16 (measured 18.8 ms per proof; 32: 19.5; 8: 19.6)
     if (sl < 4) sl = 4;
     // ... but never so long that the launch runs out of lanes (a 2^17-point shard with 32-entry segments has
     // 1.2 waves per SIMD: measured 0.62 ms per G1 accumulation instead of 0.25)
