@@ -136,6 +136,14 @@ def d_msm(ctx, pp, net, group, bases, scalars, scalars_mont=True, sid=0):
     return out
 
 
+def dpoly_commit(ctx, pp, net, srs_shares, coeff_shares, scalars_mont=True, sid=0):
+    """KZG-style commitment to a polynomial held as packed coefficient shares: one `d_msm` of the coefficient
+    shares against the packed-in-the-exponent SRS powers [tau^i]_1.  The north star names `dpoly_commit`, but the
+    reference has no such module (only the launcher scripts/dpoly_commit_test.zsh:5-7; dist-primitives/src/lib.rs:2-6
+    lists dfft, dmsm, dpp, utils, channel) -- there is no behaviour to match beyond d_msm's (dmsm/mod.rs:70-98)."""
+    return d_msm(ctx, pp, net, 1, srs_shares, coeff_shares, scalars_mont=scalars_mont, sid=sid)
+
+
 def deg_red(ctx, pp, net, px, sid=0):
     px = _fr(px)
     out = np.zeros_like(px)

@@ -132,6 +132,27 @@ def test_d_msm_equals_clear_msm(curve, group):
     assert np.array_equal(back.reshape(8, -1), pts_arr[:8])
 
 
+def test_dpoly_commit_is_the_kzg_commitment():
+    """dpoly_commit (no reference module exists; thin wrapper over d_msm): commit(p) with an SRS of known tau must be
+    p(tau) * G."""
+    curve = "bn254"
+    F = FR[curve]
+    C = CURVES[curve, "g1"]
+    ctxs, pps, net, D = parties(curve)
+    rng = random.Random(21)
+    M, tau = 16, 0xC0FFEE
+    coeffs = [rng.randrange(F.p) for _ in range(M)]
+    g = corc.generator(curve, 1)
+    srs = np.concatenate([corc.point_mul(curve, 1, g, pow(tau, i, F.p)) for i in range(M)])
+    packed_srs = pps[0].packexp_from_public(1, srs.reshape(M // 2, 2, -1))
+    packed_c = pps[0].pack_from_public(enc(F, coeffs).reshape(M // 2, 2, 4))
+    got = net.simulate_network_round(
+        lambda i, h: D.dpoly_commit(ctxs[i], pps[i], h, packed_srs[:, i], packed_c[:, i]))
+    p_tau = sum(c * pow(tau, i, F.p) for i, c in enumerate(coeffs)) % F.p
+    exp = corc.point_mul(curve, 1, g, p_tau)
+    assert all(np.array_equal(corc.jac_to_affine(curve, 1, x), exp) for x in got)
+
+
 def test_d_pp_and_deg_red():
     curve = "bls12_377"
     F = FR[curve]
