@@ -24,8 +24,8 @@ constexpr unsigned kLoBits = 11;          // twiddle table split
 
 template <class F>
 struct StepArgs {
-  const F* src;
-  F* dst;
+  const F* src[3];           // up to three independent transforms per launch (blockIdx.y): the a, b, c of a proof
+  F* dst[3];
   unsigned log_n, s, log_a, log_b;
   unsigned last;             // 1: B == 1, transposed store to natural order
   unsigned log_n1, log_n2;   // last step: a = k1*N2 + k2, out = k1 + N1*k2 + N1N2*k
@@ -83,7 +83,7 @@ __global__ void __launch_bounds__(256) ntt_step_kernel(StepArgs<F> p) {
       t = idx >> s;
       g = ((((k1_0 + t) << p.log_n2) + k2) << s) + n;
     }
-    F v = p.src[g];
+    F v = p.src[blockIdx.y][g];
     if (p.pre_lo) {
       F w = p.pre_lo[g & ((1u << p.plb) - 1)] * p.pre_hi[g >> p.plb];
       v = v * w;
@@ -137,7 +137,7 @@ __global__ void __launch_bounds__(256) ntt_step_kernel(StepArgs<F> p) {
         v = v * w;
       }
     }
-    p.dst[g] = v;
+    p.dst[blockIdx.y][g] = v;
   }
 }
 
@@ -250,15 +250,17 @@ static Plan make_plan(unsigned log_n) {
   return pl;
 }
 
-// data <- transform(data); tmp is a scratch buffer of the same size (multi-step plans ping-pong).
-// pre_g / post_g: device pointers to one element each (or null); see StepArgs.
+// data[i] <- transform(in[i]) for i < nb (in may equal data); tmp[i] are scratch buffers of the same size
+// (multi-step plans ping-pong).  The nb transforms share every launch (grid.y = nb): a 2^20 transform alone is
+// only 1024 workgroups = 4 per CU.  pre_* / post_*: power tables or null; see StepArgs.
 template <class F>
-static void ntt_run(Call& k, int curve, F* data, F* tmp, unsigned log_n, int inverse,
-                    const F* pre_lo, const F* pre_hi, const F* post_lo, const F* post_hi, unsigned plb) {
+static void ntt_run_batch(Call& k, int curve, unsigned nb, const F* const* in, F* const* data, F* const* tmp,
+                          unsigned log_n, int inverse, const F* pre_lo, const F* pre_hi, const F* post_lo,
+                          const F* post_hi, unsigned plb) {
   DG_REQUIRE(log_n <= 3 * kMaxStepLog, DG16_ERR_UNSUPPORTED, "log_n > 27 not supported yet");
+  DG_REQUIRE(nb >= 1 && nb <= 3, DG16_ERR_BAD_ARG, "1..3 transforms per batch");
   const TwiddleSet& ts = get_twiddles<F>(k, curve, log_n, inverse);
   Plan pl = make_plan(log_n);
-  F* src = data;
   unsigned consumed = 0;
   for (unsigned j = 0; j < pl.nsteps; j++) {
     StepArgs<F> a{};
@@ -282,19 +284,12 @@ static void ntt_run(Call& k, int curve, F* data, F* tmp, unsigned log_n, int inv
     if (j == 0) { a.pre_lo = pre_lo; a.pre_hi = pre_hi; }
     if (a.last) { a.post_lo = post_lo; a.post_hi = post_hi; }
     a.plb = plb;
-    // ping-pong: first step data -> tmp (same layout), middle step in place, last step tmp -> data
-    F* dst;
-    if (pl.nsteps == 1) {
-      dst = data;  // a single workgroup holds the whole vector in LDS before storing
-    } else if (j == 0) {
-      dst = tmp;
-    } else if (a.last) {
-      dst = data;
-    } else {
-      dst = src;
+    // ping-pong: first step in -> tmp (same layout), middle step in place on tmp, last step tmp -> data;
+    // a single step goes in -> data (one workgroup holds the whole vector in LDS before storing)
+    for (unsigned i = 0; i < nb; i++) {
+      a.src[i] = j == 0 ? in[i] : tmp[i];
+      a.dst[i] = (pl.nsteps == 1 || a.last) ? data[i] : tmp[i];
     }
-    a.src = src;
-    a.dst = dst;
     unsigned log_tile = log_n < kTileLog ? log_n : kTileLog;
     size_t blocks = (size_t)1 << (log_n - log_tile);
     if (a.last && pl.nsteps > 1) {
@@ -304,11 +299,18 @@ static void ntt_run(Call& k, int curve, F* data, F* tmp, unsigned log_n, int inv
       unsigned log_t = log_tile - a.s;
       DG_REQUIRE(a.log_b >= log_t, DG16_ERR_UNSUPPORTED, "plan violates B >= T");
     }
-    hipLaunchKernelGGL(ntt_step_kernel<F>, dim3((unsigned)blocks), dim3(256), 0, k.s(), a);
+    hipLaunchKernelGGL(ntt_step_kernel<F>, dim3((unsigned)blocks, nb), dim3(256), 0, k.s(), a);
     DG_HIP(hipGetLastError());
-    src = dst;
     consumed += pl.s[j];
   }
+}
+template <class F>
+static void ntt_run(Call& k, int curve, F* data, F* tmp, unsigned log_n, int inverse,
+                    const F* pre_lo, const F* pre_hi, const F* post_lo, const F* post_hi, unsigned plb) {
+  const F* in[1] = {data};
+  F* d[1] = {data};
+  F* t[1] = {tmp};
+  ntt_run_batch<F>(k, curve, 1, in, d, t, log_n, inverse, pre_lo, pre_hi, post_lo, post_hi, plb);
 }
 
 template <class F>
@@ -366,17 +368,16 @@ static void h_poly_typed(Call& k, int curve, const void* a, const void* b, const
                          void* out) {
   size_t bytes = sizeof(F) << log_m;
   F* v[3] = {(F*)ws(k.c, 12, bytes), (F*)ws(k.c, 13, bytes), (F*)ws(k.c, 14, bytes)};
-  F* tmp = (F*)ws(k.c, 8, bytes);
-  const void* in[3] = {a, b, c};
+  F* t0 = (F*)ws(k.c, 8, 3 * bytes);
+  F* tmp[3] = {t0, t0 + ((size_t)1 << log_m), t0 + ((size_t)2 << log_m)};
+  const F* in[3] = {(const F*)a, (const F*)b, (const F*)c};
   // shift tables: powers of w_{2m} (the forward 2m-domain root), applied on the iNTT's store
   const TwiddleSet& t2 = get_twiddles<F>(k, curve, log_m + 1, 0);
   // lo/hi of the 2m domain cover exponents < 2m; we only need o < m
   k.begin_dominant();
-  for (int i = 0; i < 3; i++) {
-    DG_HIP(hipMemcpyAsync(v[i], in[i], bytes, hipMemcpyDeviceToDevice, k.s()));
-    ntt_run<F>(k, curve, v[i], tmp, log_m, 1, nullptr, nullptr, (const F*)t2.lo, (const F*)t2.hi, t2.lb);
-    ntt_run<F>(k, curve, v[i], tmp, log_m, 0, nullptr, nullptr, nullptr, nullptr, 0);
-  }
+  // a, b, c go through every step together; the first iNTT step reads the caller's vectors in place
+  ntt_run_batch<F>(k, curve, 3, in, v, tmp, log_m, 1, nullptr, nullptr, (const F*)t2.lo, (const F*)t2.hi, t2.lb);
+  ntt_run_batch<F>(k, curve, 3, v, v, tmp, log_m, 0, nullptr, nullptr, nullptr, nullptr, 0);
   size_t n = (size_t)1 << log_m;
   size_t blocks = (n + 255) / 256;
   size_t cap = (size_t)k.ctx->compute_units * 8;
