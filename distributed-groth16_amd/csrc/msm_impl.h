@@ -633,6 +633,110 @@ msm_accumulate_lds_kernel(const Affine<F>* __restrict__ bases, size_t n, MsmGeom
 #undef DG_STAGE
 }
 
+// ---- wave-cooperative group operations (single-chain phases: Horner tail, s*A / r*B1) ------------------------
+// A lone lane takes ~10 us (G1) / ~40 us (G2) per dependent group operation; these phases are chains of such
+// operations with little parallelism, so one WAVE runs each chain and spreads the independent products of an
+// operation over its lanes: the operands are uniform across the wave, slot = lane / 4 picks the product, an Fq2
+// product is itself split over three lanes of the quad (Karatsuba), results are shared with readlane.
+template <class P>
+__device__ __forceinline__ Fp<P> lane_bcast(const Fp<P>& v, int src) {   // src: wave-uniform lane index
+  Fp<P> r;
+#pragma unroll
+  for (int i = 0; i < Fp<P>::NL; i++) r.l[i] = (uint32_t)__builtin_amdgcn_readlane((int)v.l[i], src);
+  return r;
+}
+template <class F>
+__device__ __forceinline__ Fp2<F> lane_bcast(const Fp2<F>& v, int src) {
+  return {lane_bcast(v.c0, src), lane_bcast(v.c1, src)};
+}
+template <class P>
+__device__ __forceinline__ Fp<P> lane_get(const Fp<P>& v, int src) {     // src: per-lane index
+  Fp<P> r;
+#pragma unroll
+  for (int i = 0; i < Fp<P>::NL; i++) r.l[i] = (uint32_t)__shfl((int)v.l[i], src);
+  return r;
+}
+// product per slot (slot = lane / 4; the operands must be equal across the quad)
+template <class P>
+__device__ __forceinline__ Fp<P> slot_mul(const Fp<P>& a, const Fp<P>& b) { return a * b; }
+template <class F>
+__device__ __forceinline__ Fp2<F> slot_mul(const Fp2<F>& a, const Fp2<F>& b) {
+  const unsigned q = __lane_id() & 3;
+  const F x = F::select(q == 0, a.c0, F::select(q == 1, a.c1, a.c0 + a.c1));
+  const F y = F::select(q == 0, b.c0, F::select(q == 1, b.c1, b.c0 + b.c1));
+  const F t = x * y;
+  const int base = (int)(__lane_id() & ~3u);
+  const F t0 = lane_get(t, base), t1 = lane_get(t, base + 1), t2 = lane_get(t, base + 2);
+  return {t0 - t1, t2 - t0 - t1};
+}
+// 2 * p with p (and the result) uniform across the wave                 (dbl-2008-s-1, a = 0)
+template <class F>
+__device__ __forceinline__ XYZZ<F> dbl_wave(const XYZZ<F>& p) {
+  if (p.is_inf()) return p;
+  const unsigned slot = __lane_id() >> 2;
+  const F u = p.y.dbl();
+  // level 1: v = u^2 | xx = x^2
+  const F a1 = F::select(slot == 0, u, p.x);
+  const F r1 = slot_mul(a1, a1);
+  const F v = lane_bcast(r1, 0), xx = lane_bcast(r1, 4);
+  const F m = xx.dbl() + xx;
+  // level 2: w = u v | s = x v | m^2 | zz' = v zz
+  const F a2 = F::select(slot == 0, u, F::select(slot == 1, p.x, F::select(slot == 2, m, v)));
+  const F b2 = F::select(slot <= 1, v, F::select(slot == 2, m, p.zz));
+  const F r2 = slot_mul(a2, b2);
+  const F w = lane_bcast(r2, 0), sv = lane_bcast(r2, 4), mm = lane_bcast(r2, 8), zz3 = lane_bcast(r2, 12);
+  const F x3 = mm - sv.dbl();
+  // level 3: m (s - x3) | w y | zzz' = w zzz
+  const F a3 = F::select(slot == 0, m, w);
+  const F b3 = F::select(slot == 0, sv - x3, F::select(slot == 1, p.y, p.zzz));
+  const F r3 = slot_mul(a3, b3);
+  const F y3 = lane_bcast(r3, 0) - lane_bcast(r3, 4);
+  return {x3, y3, zz3, lane_bcast(r3, 8)};
+}
+
+// p + o, both (and the result) uniform across the wave: 14 products in 4 levels       (add-2008-s)
+template <class F>
+__device__ __forceinline__ XYZZ<F> add_wave(const XYZZ<F>& p, const XYZZ<F>& o) {
+  if (o.is_inf()) return p;
+  if (p.is_inf()) return o;
+  const unsigned slot = __lane_id() >> 2;
+  // level 1: u1 = x1 zz2 | u2 = x2 zz1 | s1 = y1 zzz2 | s2 = y2 zzz1
+  const F a1 = F::select(slot == 0, p.x, F::select(slot == 1, o.x, F::select(slot == 2, p.y, o.y)));
+  const F b1 = F::select(slot == 0, o.zz, F::select(slot == 1, p.zz, F::select(slot == 2, o.zzz, p.zzz)));
+  const F r1 = slot_mul(a1, b1);
+  const F u1 = lane_bcast(r1, 0), u2 = lane_bcast(r1, 4), s1 = lane_bcast(r1, 8), s2 = lane_bcast(r1, 12);
+  const F pd = u2 - u1, rd = s2 - s1;
+  if (pd.is_zero()) {
+    if (rd.is_zero()) return dbl_wave(p);
+    return XYZZ<F>::inf();
+  }
+  // level 2: pp = p^2 | rr = r^2 | zz1 zz2 | zzz1 zzz2
+  const F a2 = F::select(slot == 0, pd, F::select(slot == 1, rd, F::select(slot == 2, p.zz, p.zzz)));
+  const F b2 = F::select(slot == 0, pd, F::select(slot == 1, rd, F::select(slot == 2, o.zz, o.zzz)));
+  const F r2 = slot_mul(a2, b2);
+  const F pp = lane_bcast(r2, 0), rr = lane_bcast(r2, 4), zzp = lane_bcast(r2, 8), zzzp = lane_bcast(r2, 12);
+  // level 3: ppp = p pp | q = u1 pp | zz3 = (zz1 zz2) pp
+  const F a3 = F::select(slot == 0, pd, F::select(slot == 1, u1, zzp));
+  const F r3 = slot_mul(a3, pp);
+  const F ppp = lane_bcast(r3, 0), q = lane_bcast(r3, 4), zz3 = lane_bcast(r3, 8);
+  const F x3 = rr - ppp - q.dbl();
+  // level 4: r (q - x3) | s1 ppp | zzz3 = (zzz1 zzz2) ppp
+  const F a4 = F::select(slot == 0, rd, F::select(slot == 1, s1, zzzp));
+  const F b4 = F::select(slot == 0, q - x3, ppp);
+  const F r4 = slot_mul(a4, b4);
+  return {x3, lane_bcast(r4, 0) - lane_bcast(r4, 4), zz3, lane_bcast(r4, 8)};
+}
+// k * p by double-and-add on one wave; k = NW little-endian 32-bit words (plain integer), uniform
+template <class F, int NW>
+__device__ __forceinline__ XYZZ<F> scalar_mul_wave(const XYZZ<F>& p, const uint32_t* k) {
+  XYZZ<F> acc = XYZZ<F>::inf();
+  for (int i = NW * 32 - 1; i >= 0; i--) {
+    acc = dbl_wave(acc);
+    if ((k[i / 32] >> (i % 32)) & 1) acc = add_wave(acc, p);
+  }
+  return acc;
+}
+
 // Giant buckets (a boolean witness puts half of ALL entries into bucket 0; the short top window of a c that does
 // not divide the scalar width does the same): two launches.  Stage 1 cuts the bucket's segment partials into
 // <= kGiantSlices slices, one workgroup each, and leaves every slice's sum IN PLACE in the slice's first
@@ -782,6 +886,7 @@ __global__ void __launch_bounds__(256) msm_chunk_kernel(const XYZZ<F>* __restric
   partial[gid] = acc;
 }
 
+
 // plain sums: grid (slices, windows); one workgroup reduces `per_block` consecutive elements
 template <class F>
 __global__ void __launch_bounds__(256) msm_sum_kernel(const XYZZ<F>* __restrict__ in, unsigned in_stride,
@@ -809,105 +914,6 @@ __global__ void __launch_bounds__(256) msm_sum_kernel(const XYZZ<F>* __restrict_
 // is evaluated by different lanes at once and shared with readlane.  An Fq2 product is itself spread over three
 // lanes of a quad (Karatsuba).  One thread per MSM took 2.5 ms (G1) / 10.2 ms (G2) for the 256 doublings of a
 // 2^20-point MSM, as long as the bucket accumulation itself.
-template <class P>
-__device__ __forceinline__ Fp<P> lane_bcast(const Fp<P>& v, int src) {   // src: wave-uniform lane index
-  Fp<P> r;
-#pragma unroll
-  for (int i = 0; i < Fp<P>::NL; i++) r.l[i] = (uint32_t)__builtin_amdgcn_readlane((int)v.l[i], src);
-  return r;
-}
-template <class F>
-__device__ __forceinline__ Fp2<F> lane_bcast(const Fp2<F>& v, int src) {
-  return {lane_bcast(v.c0, src), lane_bcast(v.c1, src)};
-}
-template <class P>
-__device__ __forceinline__ Fp<P> lane_get(const Fp<P>& v, int src) {     // src: per-lane index
-  Fp<P> r;
-#pragma unroll
-  for (int i = 0; i < Fp<P>::NL; i++) r.l[i] = (uint32_t)__shfl((int)v.l[i], src);
-  return r;
-}
-// product per slot (slot = lane / 4; the operands must be equal across the quad)
-template <class P>
-__device__ __forceinline__ Fp<P> slot_mul(const Fp<P>& a, const Fp<P>& b) { return a * b; }
-template <class F>
-__device__ __forceinline__ Fp2<F> slot_mul(const Fp2<F>& a, const Fp2<F>& b) {
-  const unsigned q = __lane_id() & 3;
-  const F x = F::select(q == 0, a.c0, F::select(q == 1, a.c1, a.c0 + a.c1));
-  const F y = F::select(q == 0, b.c0, F::select(q == 1, b.c1, b.c0 + b.c1));
-  const F t = x * y;
-  const int base = (int)(__lane_id() & ~3u);
-  const F t0 = lane_get(t, base), t1 = lane_get(t, base + 1), t2 = lane_get(t, base + 2);
-  return {t0 - t1, t2 - t0 - t1};
-}
-// 2 * p with p (and the result) uniform across the wave                 (dbl-2008-s-1, a = 0)
-template <class F>
-__device__ __forceinline__ XYZZ<F> dbl_wave(const XYZZ<F>& p) {
-  if (p.is_inf()) return p;
-  const unsigned slot = __lane_id() >> 2;
-  const F u = p.y.dbl();
-  // level 1: v = u^2 | xx = x^2
-  const F a1 = F::select(slot == 0, u, p.x);
-  const F r1 = slot_mul(a1, a1);
-  const F v = lane_bcast(r1, 0), xx = lane_bcast(r1, 4);
-  const F m = xx.dbl() + xx;
-  // level 2: w = u v | s = x v | m^2 | zz' = v zz
-  const F a2 = F::select(slot == 0, u, F::select(slot == 1, p.x, F::select(slot == 2, m, v)));
-  const F b2 = F::select(slot <= 1, v, F::select(slot == 2, m, p.zz));
-  const F r2 = slot_mul(a2, b2);
-  const F w = lane_bcast(r2, 0), sv = lane_bcast(r2, 4), mm = lane_bcast(r2, 8), zz3 = lane_bcast(r2, 12);
-  const F x3 = mm - sv.dbl();
-  // level 3: m (s - x3) | w y | zzz' = w zzz
-  const F a3 = F::select(slot == 0, m, w);
-  const F b3 = F::select(slot == 0, sv - x3, F::select(slot == 1, p.y, p.zzz));
-  const F r3 = slot_mul(a3, b3);
-  const F y3 = lane_bcast(r3, 0) - lane_bcast(r3, 4);
-  return {x3, y3, zz3, lane_bcast(r3, 8)};
-}
-
-// p + o, both (and the result) uniform across the wave: 14 products in 4 levels       (add-2008-s)
-template <class F>
-__device__ __forceinline__ XYZZ<F> add_wave(const XYZZ<F>& p, const XYZZ<F>& o) {
-  if (o.is_inf()) return p;
-  if (p.is_inf()) return o;
-  const unsigned slot = __lane_id() >> 2;
-  // level 1: u1 = x1 zz2 | u2 = x2 zz1 | s1 = y1 zzz2 | s2 = y2 zzz1
-  const F a1 = F::select(slot == 0, p.x, F::select(slot == 1, o.x, F::select(slot == 2, p.y, o.y)));
-  const F b1 = F::select(slot == 0, o.zz, F::select(slot == 1, p.zz, F::select(slot == 2, o.zzz, p.zzz)));
-  const F r1 = slot_mul(a1, b1);
-  const F u1 = lane_bcast(r1, 0), u2 = lane_bcast(r1, 4), s1 = lane_bcast(r1, 8), s2 = lane_bcast(r1, 12);
-  const F pd = u2 - u1, rd = s2 - s1;
-  if (pd.is_zero()) {
-    if (rd.is_zero()) return dbl_wave(p);
-    return XYZZ<F>::inf();
-  }
-  // level 2: pp = p^2 | rr = r^2 | zz1 zz2 | zzz1 zzz2
-  const F a2 = F::select(slot == 0, pd, F::select(slot == 1, rd, F::select(slot == 2, p.zz, p.zzz)));
-  const F b2 = F::select(slot == 0, pd, F::select(slot == 1, rd, F::select(slot == 2, o.zz, o.zzz)));
-  const F r2 = slot_mul(a2, b2);
-  const F pp = lane_bcast(r2, 0), rr = lane_bcast(r2, 4), zzp = lane_bcast(r2, 8), zzzp = lane_bcast(r2, 12);
-  // level 3: ppp = p pp | q = u1 pp | zz3 = (zz1 zz2) pp
-  const F a3 = F::select(slot == 0, pd, F::select(slot == 1, u1, zzp));
-  const F r3 = slot_mul(a3, pp);
-  const F ppp = lane_bcast(r3, 0), q = lane_bcast(r3, 4), zz3 = lane_bcast(r3, 8);
-  const F x3 = rr - ppp - q.dbl();
-  // level 4: r (q - x3) | s1 ppp | zzz3 = (zzz1 zzz2) ppp
-  const F a4 = F::select(slot == 0, rd, F::select(slot == 1, s1, zzzp));
-  const F b4 = F::select(slot == 0, q - x3, ppp);
-  const F r4 = slot_mul(a4, b4);
-  return {x3, lane_bcast(r4, 0) - lane_bcast(r4, 4), zz3, lane_bcast(r4, 8)};
-}
-// k * p by double-and-add on one wave; k = NW little-endian 32-bit words (plain integer), uniform
-template <class F, int NW>
-__device__ __forceinline__ XYZZ<F> scalar_mul_wave(const XYZZ<F>& p, const uint32_t* k) {
-  XYZZ<F> acc = XYZZ<F>::inf();
-  for (int i = NW * 32 - 1; i >= 0; i--) {
-    acc = dbl_wave(acc);
-    if ((k[i / 32] >> (i % 32)) & 1) acc = add_wave(acc, p);
-  }
-  return acc;
-}
-
 template <class F>
 __global__ void __launch_bounds__(64) msm_tail_kernel(const XYZZ<F>* __restrict__ window_sums, MsmGeom g,
                                                        int affine, F* __restrict__ out) {
@@ -1084,6 +1090,9 @@ void msm_bucket_phase(hipStream_t s, const MsmSort& st, const MsmBuffers<F>& b, 
     hipLaunchKernelGGL(msm_giant_fold_kernel<F>, dim3(64), dim3(64), 0, s, g, st.counts, st.seg_off, b.seg_sum,
                        b.buckets, b.giant, b.giant + 2, b.giant_cap);
   }
+  // (one WAVE per chunk with the cooperative operations above was tried for the exposed last reduction and for
+  // short shards: 16 of 64 lanes useful and 4 levels per operation cost ~18x the multiplications; measured slower
+  // everywhere -- 2^20 proof 18.7 -> 18.9 ms, one rank of 8: 7.1 -> 8.6 ms -- so chunks stay one lane each)
   hipLaunchKernelGGL(msm_chunk_kernel<F>, dim3((unsigned)((b.nchunks + 255) / 256)), dim3(256), 0, s, b.buckets, g,
                      b.partial);
   {
