@@ -169,12 +169,14 @@ static void msms_typed(dg16_ctx* ctx, Call& k0, Call& k1, Call& k2, const PkDev&
   MsmBuffers<Fq> buf_a = msm_buffers<Fq>(k0.c, st_ab.g);
   MsmBuffers<Fq> buf_b1 = msm_buffers<Fq>(k1.c, st_ab.g);
   MsmBuffers<Fq2> buf_b2 = msm_buffers<Fq2>(k2.c, st_ab.g);
+  // B (G2) first: its bucket reduction is the longest latency chain of a proof (on a short multi-GPU shard it
+  // outlasts everything else), so it gets the whole rest of the pipeline to hide behind
+  msm_accumulate_phase<Fq2>(main, st_ab, buf_b2, pk.b2_q);
+  DG_HIP(hipEventRecord(ev[2], main));
   msm_accumulate_phase<Fq>(main, st_ab, buf_a, pk.a_q);
   DG_HIP(hipEventRecord(ev[0], main));
   msm_accumulate_phase<Fq>(main, st_ab, buf_b1, pk.b1_q);
   DG_HIP(hipEventRecord(ev[1], main));
-  msm_accumulate_phase<Fq2>(main, st_ab, buf_b2, pk.b2_q);
-  DG_HIP(hipEventRecord(ev[2], main));
   // side: reductions of A and B1, then the serial scalar multiples s*A', r*B1' of this shard
   DG_HIP(hipStreamWaitEvent(side, ev[0], 0));
   msm_bucket_phase<Fq>(side, st_ab, buf_a, false, res_a);
