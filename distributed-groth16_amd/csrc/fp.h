@@ -31,6 +31,10 @@ namespace dg16 {
 #define DG_MADC_S(acc, c2, x, y)                                                          \
   asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32_e64 %1, vcc, 0, %1, vcc"        \
       : "+v"(acc), "+v"(c2) : "v"(x), "s"(y) : "vcc")
+// first product of a column: c2 is SET to the carry (no zeroing move at every column hand-over)
+#define DG_MADC0(acc, c2, x, y)                                                           \
+  asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32_e64 %1, vcc, 0, 0, vcc"         \
+      : "+v"(acc), "=v"(c2) : "v"(x), "v"(y) : "vcc")
 #endif
 
 template <class P>
@@ -138,33 +142,33 @@ struct alignas(16) Fp {
 #if defined(__HIP_DEVICE_COMPILE__)
     // product scanning; (c2:acc) is a 96-bit column accumulator
     uint64_t acc = 0;
-    uint32_t c2 = 0;
+    uint32_t c2;
     uint32_t m[NL];
     uint32_t t[NL];
 #pragma unroll
     for (int k = 0; k < NL; k++) {
+      // column k: a_0 b_k first (sets the carry word), then the remaining a_i b_(k-i) and m_i p_(k-i)
+      DG_MADC0(acc, c2, a.l[0], b.l[k]);
 #pragma unroll
-      for (int i = 0; i < k; i++) {
-        DG_MADC(acc, c2, a.l[i], b.l[k - i]);
-        DG_MADC_S(acc, c2, m[i], P::P[k - i]);
-      }
-      DG_MADC(acc, c2, a.l[k], b.l[0]);
+      for (int i = 1; i <= k; i++) DG_MADC(acc, c2, a.l[i], b.l[k - i]);
+#pragma unroll
+      for (int i = 0; i < k; i++) DG_MADC_S(acc, c2, m[i], P::P[k - i]);
       m[k] = (uint32_t)acc * P::INV;
       DG_MADC_S(acc, c2, m[k], P::P[0]);
       acc = (acc >> 32) | ((uint64_t)c2 << 32);
-      c2 = 0;
     }
 #pragma unroll
-    for (int k = NL; k < 2 * NL; k++) {
+    for (int k = NL; k < 2 * NL - 1; k++) {
+      DG_MADC0(acc, c2, a.l[k - NL + 1], b.l[NL - 1]);
 #pragma unroll
-      for (int i = k - NL + 1; i < NL; i++) {
-        DG_MADC(acc, c2, a.l[i], b.l[k - i]);
-        DG_MADC_S(acc, c2, m[i], P::P[k - i]);
-      }
+      for (int i = k - NL + 2; i < NL; i++) DG_MADC(acc, c2, a.l[i], b.l[k - i]);
+#pragma unroll
+      for (int i = k - NL + 1; i < NL; i++) DG_MADC_S(acc, c2, m[i], P::P[k - i]);
       t[k - NL] = (uint32_t)acc;
       acc = (acc >> 32) | ((uint64_t)c2 << 32);
-      c2 = 0;
     }
+    t[NL - 1] = (uint32_t)acc;          // column 2NL-1 holds no products
+    acc >>= 32;
     return reduce_once(t, (uint32_t)acc);
 #else
     // portable CIOS (host-side unit tests only)
