@@ -30,7 +30,8 @@ class Dg16Error(RuntimeError):
 
 
 def lib_path():
-    return os.path.join(_HERE, "libdg16.so")
+    # DG16_LIB: an explicitly named build of the same library (A/B timing of two builds on one box)
+    return os.environ.get("DG16_LIB") or os.path.join(_HERE, "libdg16.so")
 
 
 _lib = None
