@@ -8,8 +8,8 @@
 A step = one complete Groth16 proof (h-polynomial: 3 iNTT + 3 NTT of size 2^20 + pointwise; five
 MSMs: A, B1, L, H in G1 and B in G2; A/B/C assembly) with every input already resident in HBM.
 N > 1 is STRONG scaling of one proof: each rank owns a contiguous 1/N slice of every MSM's bases and
-scalars, the h-polynomial is replicated, and one RCCL all-gather of N x 480 B partial results precedes
-the assembly (distributed-groth16_amd/parallel.py).
+scalars, the h-polynomial is replicated, and one RCCL all-gather of N x 768 B records (A, B1, L, H, s*A, r*B1
+in G1 and B in G2, Jacobian) precedes the assembly (distributed-groth16_amd/parallel.py).
 
 One JSON line is printed by rank 0.  `roofline` describes the dominant kernel (the G2 bucket
 accumulation): achieved = algorithmic bytes (160 B/point) / its HIP-event duration
@@ -17,8 +17,9 @@ measured here on the stream it runs on -- against the 8 TB/s HBM roof this is sm
 the kernel does ~28 x 10 Montgomery multiplications per 160 bytes and is integer-VALU-bound, so the
 honest second roof (`valu_roofline`: Montgomery multiplications per second against the measured
 chip rate of tools/ubench/montmul_rate) is printed next to it.  `cpu_baseline` times the oracle
-("port": arkworks-structured CPU restatement, NOT arkworks) on a bounded sample of the same workload
-on this box's host cores and doubles as a live parity check of the GPU proof.
+("port": arkworks-structured CPU restatement, NOT arkworks) on a second instance of the same 2^20 workload
+(~3 s on 32 threads; --cpu-sample-log shrinks it) on this box's host cores and doubles as a live parity check
+of the GPU proof.  `roofline.traffic` is the HBM traffic of the same launch from the committed --pmc passes.
 """
 
 import argparse
@@ -35,7 +36,7 @@ sys.path.insert(0, ROOT)
 
 CURVE = "bn254"
 BN254_R_TOP = 0x30644E72E131A029   # top 64-bit limb of the BN254 scalar modulus
-MONTMUL_PEAK_G = 105.0             # G montmul/s, BN254 Fq, measured chip rate (gpurun_out/montmul_rate_r1b.txt)
+MONTMUL_PEAK_G = 105.0             # G montmul/s, BN254 Fq, measured chip rate (profiles/r1_ubench_montmul_rate.txt)
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md
 
 
