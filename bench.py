@@ -36,7 +36,8 @@ sys.path.insert(0, ROOT)
 
 CURVE = "bn254"
 BN254_R_TOP = 0x30644E72E131A029   # top 64-bit limb of the BN254 scalar modulus
-MONTMUL_PEAK_G = 105.0             # G montmul/s, BN254 Fq, measured chip rate (profiles/r1_ubench_montmul_rate.txt)
+MONTMUL_PEAK_G = 114.0             # G montmul/s, BN254 Fq, measured chip rate of the shipped multiply
+                                   # (variant D of tools/ubench/montmul_rate: profiles/r1_ubench_montmul_rate_v2.txt)
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md
 
 

@@ -67,6 +67,36 @@ __device__ __forceinline__ void mont_mul_B(uint32_t* r, const uint32_t* a, const
 }
 
 
+// Variant D = variant B as shipped at the end of round 1 (csrc/fp.h): the first product of a column SETS the carry
+// word, so no zeroing move at the column hand-over and hipcc coalesces the carry word into the next accumulator pair.
+#define MADC0(acc, c2, x, y) asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32_e64 %1, vcc, 0, 0, vcc" : "+v"(acc), "=v"(c2) : "v"(x), "v"(y) : "vcc")
+__device__ __forceinline__ void mont_mul_D(uint32_t* r, const uint32_t* a, const uint32_t* b) {
+  uint64_t acc = 0; uint32_t c2; uint32_t m[NL]; uint32_t t[NL];
+#pragma unroll
+  for (int k = 0; k < NL; k++) {
+    MADC0(acc, c2, a[0], b[k]);
+#pragma unroll
+    for (int i = 1; i <= k; i++) MADC(acc, c2, a[i], b[k - i]);
+#pragma unroll
+    for (int i = 0; i < k; i++) MADC_S(acc, c2, m[i], Pk[k - i]);
+    m[k] = (uint32_t)acc * INV;
+    MADC_S(acc, c2, m[k], Pk[0]);
+    acc = (acc >> 32) | ((uint64_t)c2 << 32);
+  }
+#pragma unroll
+  for (int k = NL; k < 2 * NL - 1; k++) {
+    MADC0(acc, c2, a[k - NL + 1], b[NL - 1]);
+#pragma unroll
+    for (int i = k - NL + 2; i < NL; i++) MADC(acc, c2, a[i], b[k - i]);
+#pragma unroll
+    for (int i = k - NL + 1; i < NL; i++) MADC_S(acc, c2, m[i], Pk[k - i]);
+    t[k - NL] = (uint32_t)acc;
+    acc = (acc >> 32) | ((uint64_t)c2 << 32);
+  }
+  t[NL - 1] = (uint32_t)acc;
+  final_sub(r, t, (uint32_t)(acc >> 32));
+}
+
 // Variant C: column-parallel CIOS with lazy carries.  NL+1 live columns, each a 64-bit accumulator
 // plus a 32-bit overflow counter; the 8 MADCs of a row hit 8 different columns (ILP 8), so a single
 // wave is not bound by the mad->addc->mad dependency chain of variant B.
@@ -107,7 +137,7 @@ template <int V> __global__ void chain(uint32_t* out, const uint32_t* in, int it
   int tid = blockIdx.x * blockDim.x + threadIdx.x;
   uint32_t a[NL], b[NL];
   for (int i = 0; i < NL; i++) { a[i] = in[tid * 16 + i]; b[i] = in[tid * 16 + 8 + i]; }
-  for (int it = 0; it < iters; it++) { if (V == 0) mont_mul_A(a, a, b); else if (V == 1) mont_mul_B(a, a, b); else mont_mul_C(a, a, b); }
+  for (int it = 0; it < iters; it++) { if (V == 0) mont_mul_A(a, a, b); else if (V == 1) mont_mul_B(a, a, b); else if (V == 3) mont_mul_D(a, a, b); else mont_mul_C(a, a, b); }
   for (int i = 0; i < NL; i++) out[tid * 8 + i] = a[i];
 }
 // 4 independent chains per lane (ILP)
@@ -117,7 +147,7 @@ template <int V> __global__ void chain4(uint32_t* out, const uint32_t* in, int i
   for (int i = 0; i < NL; i++) { b[i] = in[tid * 16 + 8 + i]; for (int c = 0; c < 4; c++) a[c][i] = in[tid * 16 + i] ^ (c * 77); a[0][7] &= 0x0fffffff; a[1][7] &= 0x0fffffff; a[2][7] &= 0x0fffffff; a[3][7] &= 0x0fffffff; }
   for (int it = 0; it < iters; it++) {
 #pragma unroll
-    for (int c = 0; c < 4; c++) { if (V == 0) mont_mul_A(a[c], a[c], b); else if (V == 1) mont_mul_B(a[c], a[c], b); else mont_mul_C(a[c], a[c], b); }
+    for (int c = 0; c < 4; c++) { if (V == 0) mont_mul_A(a[c], a[c], b); else if (V == 1) mont_mul_B(a[c], a[c], b); else if (V == 3) mont_mul_D(a[c], a[c], b); else mont_mul_C(a[c], a[c], b); }
   }
   for (int i = 0; i < NL; i++) out[tid * 8 + i] = a[0][i] ^ a[1][i] ^ a[2][i] ^ a[3][i];
 }
@@ -143,6 +173,10 @@ int main() {
   CHECK(hipMemcpy(h_c.data(), d_out, (size_t)n * 32, hipMemcpyDeviceToHost));
   size_t badC = 0; for (size_t i = 0; i < h_c.size(); i++) if (h_c[i] != h_a[i]) badC++;
   printf("correctness: C_dev vs A_dev mismatches %zu\n", badC);
+  hipLaunchKernelGGL(chain<3>, dim3(blocks), dim3(threads), 0, 0, d_out, d_in, 5);
+  CHECK(hipMemcpy(h_c.data(), d_out, (size_t)n * 32, hipMemcpyDeviceToHost));
+  size_t badD = 0; for (size_t i = 0; i < h_c.size(); i++) if (h_c[i] != h_a[i]) badD++;
+  printf("correctness: D_dev vs A_dev mismatches %zu\n", badD);
   size_t badAB = 0, badH = 0;
   for (int t = 0; t < n; t++) {
     uint32_t a[8], b[8];
@@ -168,8 +202,10 @@ int main() {
   timeit("B (asm product-scan) chain", chain<1>, 1);
   timeit("A x4 ILP", chain4<0>, 4);
   timeit("B x4 ILP", chain4<1>, 4);
+  timeit("D (B + carry-set) chain", chain<3>, 1);
+  timeit("D x4 ILP", chain4<3>, 4);
   timeit("C (column-parallel) chain", chain<2>, 1);
   timeit("C x4 ILP", chain4<2>, 4);
-  for (int w : {1, 2, 3, 4}) { timeit("B chain", chain<1>, 1, w); timeit("C chain", chain<2>, 1, w); timeit("A chain", chain<0>, 1, w); }
+  for (int w : {1, 2, 3, 4}) { timeit("D chain", chain<3>, 1, w); timeit("B chain", chain<1>, 1, w); timeit("C chain", chain<2>, 1, w); timeit("A chain", chain<0>, 1, w); }
   return 0;
 }
