@@ -1,0 +1,45 @@
+"""CPU: compile-time resource figures of the hot kernels, from the reports hipcc writes during `make`
+(csrc/*.usage.txt, -Rpass-analysis=kernel-resource-usage).  A regression here is a performance bug that no parity
+test sees: the G2 bucket kernel once spilled ~200 dwords per lane (31.7 GB of HBM traffic per launch instead of
+2.7 GB), and an out-of-line call in the hot loop once kept the loaded point in scratch memory."""
+
+import os
+import sys
+
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+import resource_report  # noqa: E402
+
+REP = {resource_report.short(k): v for k, v in resource_report.load().items()}
+pytestmark = pytest.mark.skipif(not REP, reason="no csrc/*.usage.txt: run `make -C distributed-groth16_amd/csrc` first")
+
+
+def find(prefix):
+    hits = {k: v for k, v in REP.items() if k.replace(" ", "").startswith(prefix.replace(" ", ""))}
+    assert hits, "kernel %s not in the build" % prefix
+    return hits
+
+
+def test_g1_bucket_accumulation_has_no_scratch_and_four_waves():
+    (r,) = find("msm_accumulate_kernel<bn254_fq>").values()
+    assert r["scratch"] == 0 and r["agprs"] == 0 and r["occupancy"] >= 4
+    for k, r in find("msm_accumulate_kernel<bls12_").items():
+        assert r["scratch"] == 0, k
+
+
+def test_g2_bucket_accumulation_stages_through_lds_without_spilling():
+    (r,) = find("msm_accumulate_lds_kernel<Fp2<bn254_fq>,256>").values()
+    assert r["lds"] == 65536 and r["occupancy"] == 2
+    assert r["scratch"] <= 64 and r["agprs"] == 0          # 16 B: the by-value multiply arguments
+
+
+def test_ntt_and_sort_kernels_are_register_and_lds_only():
+    for k, r in find("ntt_step_kernel<").items():
+        assert r["scratch"] == 0 and r["lds"] == 32768 and r["occupancy"] >= 4, k
+    for name in ("msm_part_hist_kernel<", "msm_part_scatter_kernel<", "msm_part_count_kernel<", "msm_part_place_kernel<",
+                 "msm_digits_kernel<", "msm_scatter_kernel<"):
+        for k, r in find(name).items():
+            assert r["scratch"] == 0 and r["vgprs"] <= 64, k
+    (r,) = find("msm_part_place_kernel<").values()
+    assert r["lds"] == 3 * 4096 * 4                          # bin counts, bucket ranks, bucket destinations
