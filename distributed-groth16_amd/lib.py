@@ -29,6 +29,30 @@ class Dg16Error(RuntimeError):
         self.code = code
 
 
+class R1csHeader(ctypes.Structure):       # dg16_r1cs_header
+    _fields_ = [(n, ctypes.c_uint32) for n in ("n_wires", "n_pub_out", "n_pub_in", "n_prv_in", "n_constraints",
+                                                "has_wire_map")] + [("n_labels", ctypes.c_uint64)]
+
+
+class ZkeyHeader(ctypes.Structure):       # dg16_zkey_header
+    _fields_ = [(n, ctypes.c_uint32) for n in ("n_vars", "n_public", "domain_size", "num_constraints")]
+
+
+class Csr(ctypes.Structure):              # dg16_csr
+    _fields_ = [("n_rows", ctypes.c_uint64), ("nnz", ctypes.c_uint64), ("row_ptr", ctypes.POINTER(ctypes.c_uint32)),
+                ("col", ctypes.POINTER(ctypes.c_uint32)), ("coeff", ctypes.c_void_p)]
+
+    def arrays(self):
+        """Copies out (row_ptr uint32[n_rows + 1], col uint32[nnz], coeff uint64[nnz][4])."""
+        n, nnz = int(self.n_rows), int(self.nnz)
+        ptr = np.ctypeslib.as_array(self.row_ptr, shape=(n + 1,)).copy() if n or nnz else np.zeros(1, dtype=np.uint32)
+        if nnz == 0:
+            return ptr, np.zeros(0, dtype=np.uint32), np.zeros((0, 4), dtype=np.uint64)
+        col = np.ctypeslib.as_array(self.col, shape=(nnz,)).copy()
+        raw = (ctypes.c_uint64 * (4 * nnz)).from_address(self.coeff)
+        return ptr, col, np.frombuffer(raw, dtype=np.uint64).reshape(nnz, 4).copy()
+
+
 def lib_path():
     # DG16_LIB: an explicitly named build of the same library (A/B timing of two builds on one box)
     return os.environ.get("DG16_LIB") or os.path.join(_HERE, "libdg16.so")
@@ -101,6 +125,21 @@ def load():
     L.dg16_deg_red.argtypes = [vp, vp, vp, vp, sz, vp, u, i]
     L.dg16_d_pp.argtypes = [vp, vp, vp, vp, vp, sz, vp, u, i]
     L.dg16_ext_wit_h.argtypes = [vp, vp, vp, vp, vp, vp, u, vp, u]
+    # file-format readers (host side of the library)
+    L.dg16_io_error.argtypes = []
+    L.dg16_io_error.restype = ctypes.c_char_p
+    L.dg16_r1cs_parse.argtypes = [vp, sz, ctypes.POINTER(vp)]
+    L.dg16_r1cs_header_get.argtypes = [vp, ctypes.POINTER(R1csHeader)]
+    L.dg16_r1cs_matrix.argtypes = [vp, i, ctypes.POINTER(Csr)]
+    L.dg16_r1cs_wire_map.argtypes = [vp, ctypes.POINTER(ctypes.POINTER(u64))]
+    L.dg16_r1cs_free.argtypes = [vp]
+    L.dg16_r1cs_free.restype = None
+    L.dg16_zkey_parse.argtypes = [vp, sz, ctypes.POINTER(vp)]
+    L.dg16_zkey_header_get.argtypes = [vp, ctypes.POINTER(ZkeyHeader)]
+    L.dg16_zkey_points.argtypes = [vp, i, ctypes.POINTER(vp), ctypes.POINTER(sz)]
+    L.dg16_zkey_matrix.argtypes = [vp, i, ctypes.POINTER(Csr)]
+    L.dg16_zkey_free.argtypes = [vp]
+    L.dg16_zkey_free.restype = None
     _lib = L
     return L
 
@@ -112,7 +151,10 @@ EXPORTED = ["dg16_ctx_create", "dg16_ctx_destroy", "dg16_last_error", "dg16_set_
             "dg16_groth16_assemble", "dg16_localnet_create", "dg16_localnet_party", "dg16_localnet_destroy", "dg16_localnet_abort",
             "dg16_localnet_reset",
             "dg16_pss_create", "dg16_pss_destroy", "dg16_pss_apply", "dg16_pss_apply_exp", "dg16_d_fft",
-            "dg16_d_msm", "dg16_deg_red", "dg16_d_pp", "dg16_ext_wit_h", "dg16_qap"]
+            "dg16_d_msm", "dg16_deg_red", "dg16_d_pp", "dg16_ext_wit_h", "dg16_qap",
+            "dg16_io_error", "dg16_r1cs_parse", "dg16_r1cs_header_get", "dg16_r1cs_matrix", "dg16_r1cs_wire_map",
+            "dg16_r1cs_free", "dg16_zkey_parse", "dg16_zkey_header_get", "dg16_zkey_points", "dg16_zkey_matrix",
+            "dg16_zkey_free"]
 
 
 def _ptr(x):

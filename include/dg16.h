@@ -251,6 +251,48 @@ int dg16_d_pp(dg16_ctx *ctx, const dg16_pss *pp, const dg16_net *net, const void
 int dg16_ext_wit_h(dg16_ctx *ctx, const dg16_pss *pp, const dg16_net *net, const void *a_share,
                    const void *b_share, const void *c_share, unsigned log_m, void *out, unsigned flags);
 
+/* ---- circom `.r1cs` / snarkjs `.zkey` readers (host side of the library; no GPU involved) ----------------
+ *   dg16_r1cs_parse   <- R1CSFile::new              ark-circom/src/circom/r1cs_reader.rs:54-249
+ *   dg16_zkey_parse   <- read_zkey / BinFile         ark-circom/src/zkey.rs:53-388
+ * Same acceptance rules as the reference (magic, version 1, 32-byte fields, BN254 moduli, section sizes, wire 0).
+ * On failure the status is non-zero and dg16_io_error() (thread-local) gives the reference's error text.
+ * dg16_r1cs copies what it keeps.  dg16_zkey is ZERO-COPY for points -- a zkey stores x || y Montgomery limbs with
+ * the identity as (0, 0), i.e. this library's base layout -- so `data` must outlive the handle and the pointers
+ * of dg16_zkey_points go straight into dg16_pk_create.  Matrix coefficients of a zkey are value * R^2 as stored
+ * (zkey.rs:332-337): one dg16_field_op(from_mont) gives the Montgomery values dg16_qap takes; the rows snarkjs
+ * appends for the public inputs are dropped and num_constraints = max row - n_public (zkey.rs:176-198). */
+typedef struct dg16_r1cs dg16_r1cs;
+typedef struct dg16_zkey dg16_zkey;
+typedef struct dg16_r1cs_header {
+  uint32_t n_wires, n_pub_out, n_pub_in, n_prv_in, n_constraints, has_wire_map;
+  uint64_t n_labels;
+} dg16_r1cs_header;
+typedef struct dg16_zkey_header {
+  uint32_t n_vars, n_public, domain_size, num_constraints;
+} dg16_zkey_header;
+typedef struct dg16_csr {   /* owned by the handle; coeff: nnz x 32-byte little-endian field elements */
+  uint64_t n_rows, nnz;
+  const uint32_t *row_ptr, *col;
+  const void *coeff;
+} dg16_csr;
+enum {
+  DG16_ZKEY_ALPHA_G1 = 0, DG16_ZKEY_BETA_G1 = 1, DG16_ZKEY_BETA_G2 = 2, DG16_ZKEY_GAMMA_G2 = 3,
+  DG16_ZKEY_DELTA_G1 = 4, DG16_ZKEY_DELTA_G2 = 5, DG16_ZKEY_IC = 6, DG16_ZKEY_A = 7, DG16_ZKEY_B1 = 8,
+  DG16_ZKEY_B2 = 9, DG16_ZKEY_L = 10, DG16_ZKEY_H = 11
+};
+const char *dg16_io_error(void);
+int dg16_r1cs_parse(const void *data, size_t bytes, dg16_r1cs **out);
+int dg16_r1cs_header_get(const dg16_r1cs *f, dg16_r1cs_header *out);
+int dg16_r1cs_matrix(const dg16_r1cs *f, int which /* 0 A, 1 B, 2 C; canonical coefficients */, dg16_csr *out);
+int dg16_r1cs_wire_map(const dg16_r1cs *f, const uint64_t **map /* NULL when the file has none */);
+void dg16_r1cs_free(dg16_r1cs *f);
+int dg16_zkey_parse(const void *data, size_t bytes, dg16_zkey **out);
+int dg16_zkey_header_get(const dg16_zkey *z, dg16_zkey_header *out);
+int dg16_zkey_points(const dg16_zkey *z, int which /* DG16_ZKEY_* */, const void **ptr, size_t *count);
+int dg16_zkey_matrix(const dg16_zkey *z, int which /* 0 A, 1 B; value * R^2 */, dg16_csr *out);
+void dg16_zkey_free(dg16_zkey *z);
+
+
 /* Duration in milliseconds of the dominant kernel(s) of the most recent call on `channel`
  * (HIP events recorded on the channel's stream); 0 if none.  which: 0 = whole call,
  * 1 = bucket accumulation (MSM) / butterfly passes (NTT). */
