@@ -7,7 +7,10 @@ bit 7 = "y is the negative root" (y > -y; for Fq2 the comparison is lexicographi
 infinity (x = 0).  G2's x is c0 || c1.  Decoding validates like `Validate::Yes`: x < q, on the curve, in the
 prime-order subgroup.
 
-Host-side format code on three points per proof (plain Python integers); nothing here is on the proving path."""
+Two implementations: the native one of libdg16 (`dg16_proof_compress` / `dg16_proof_decompress`, csrc/serialize.hip,
+on the Montgomery limbs the GPU prover writes -- `compress_gpu_proof` / `decompress_to_limbs` below) and this
+module's plain-Python one on integers; the tests hold them against each other and against the reference's real
+proof.bin.  Host-side format code on three points per proof; nothing here is on the proving path."""
 
 Q = 21888242871839275222246405745257275088696311157297823662689037894645226208583
 R = 21888242871839275222246405745257275088548364400416034343698204186575808495617
@@ -194,3 +197,33 @@ def g1_from_bytes(raw):
 
 def g2_from_bytes(raw):
     return _decode(_G2, raw)
+
+
+# ---- native path (libdg16): straight from / to the limbs the GPU prover uses ----------------------------------
+def compress_gpu_proof(proof_jacobian_u64):
+    """12 x 4 uint64 limbs as written by `dg16_groth16_prove` (A, B, C Jacobian, Montgomery) -> 128 bytes."""
+    import ctypes
+    import numpy as np
+    from . import lib as _lib
+    L = _lib.load()
+    src = np.ascontiguousarray(proof_jacobian_u64, dtype=np.uint64).reshape(-1)
+    if src.size != 48:
+        raise SerializationError("a BN254 proof is 12 field elements")
+    out = ctypes.create_string_buffer(128)
+    if L.dg16_proof_compress(0, src.ctypes.data_as(ctypes.c_void_p), out) != 0:
+        raise SerializationError(L.dg16_serialize_error().decode())
+    return out.raw
+
+
+def decompress_to_limbs(raw, validate=True):
+    """128 bytes -> 8 x 4 uint64 Montgomery limbs: A.x A.y | B.x0 B.x1 B.y0 B.y1 | C.x C.y (identity = zeros)."""
+    import ctypes
+    import numpy as np
+    from . import lib as _lib
+    L = _lib.load()
+    if len(raw) != 128:
+        raise SerializationError("a compressed BN254 proof is 128 bytes")
+    out = np.zeros((8, 4), dtype=np.uint64)
+    if L.dg16_proof_decompress(0, bytes(raw), 1 if validate else 0, out.ctypes.data_as(ctypes.c_void_p)) != 0:
+        raise SerializationError(L.dg16_serialize_error().decode())
+    return out

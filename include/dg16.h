@@ -293,6 +293,18 @@ int dg16_zkey_matrix(const dg16_zkey *z, int which /* 0 A, 1 B; value * R^2 */, 
 void dg16_zkey_free(dg16_zkey *z);
 
 
+/* ---- arkworks compressed Proof<Bn254> (host side; no GPU involved) ---------------------------------------
+ *   dg16_proof_compress    <- proof.serialize_compressed       mpc-api/src/main.rs:154-171 (proof.bin)
+ *   dg16_proof_decompress  <- Proof::deserialize_compressed     zk-cli verify path, test-circuits/sha256/proof.bin
+ * 128 bytes: A (G1, 32) || B (G2, 64) || C (G1, 32); little-endian x, flags in the two top bits of the last byte
+ * (bit 7: y > -y, Fq2 compared on (c1, c0); bit 6: infinity).  compress takes the 12 field elements that
+ * dg16_groth16_prove writes (A, B, C Jacobian, Montgomery limbs); decompress writes A.x A.y | B.x B.y | C.x C.y
+ * (8 field elements, Montgomery limbs, identity = zeros) and, with validate != 0, checks like Validate::Yes:
+ * reduced coordinates, on the curve, B in the order-r subgroup.  BN254 only (the reference's proof curve). */
+const char *dg16_serialize_error(void);
+int dg16_proof_compress(int curve, const void *proof_jacobian, void *out128);
+int dg16_proof_decompress(int curve, const void *in128, int validate, void *proof_affine);
+
 /* Duration in milliseconds of the dominant kernel(s) of the most recent call on `channel`
  * (HIP events recorded on the channel's stream); 0 if none.  which: 0 = whole call,
  * 1 = bucket accumulation (MSM) / butterfly passes (NTT). */

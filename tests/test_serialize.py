@@ -74,3 +74,67 @@ def test_malformed_encodings_are_rejected():
         x = (x[0] + 1, 0)
     with pytest.raises(S.SerializationError):
         S.g2_from_bytes(S.g2_to_bytes((x, y)))
+
+
+# ---- the native implementation of libdg16 (host code, runs without a GPU) ---------------------------------
+RMONT = (1 << 256) % S.Q
+
+
+def limbs(v):
+    import numpy as np
+    return np.frombuffer((v * RMONT % S.Q).to_bytes(32, "little"), dtype=np.uint64)
+
+
+def unlimbs(row):
+    return int.from_bytes(row.tobytes(), "little") * pow(RMONT, -1, S.Q) % S.Q
+
+
+def test_native_decompress_gives_the_printed_points():
+    out = S.decompress_to_limbs(raw())
+    got = [unlimbs(r) for r in out]
+    assert got == [A[0], A[1], B[0][0], B[0][1], B[1][0], B[1][1], C[0], C[1]]
+
+
+def test_native_compress_of_jacobian_limbs_gives_the_reference_proof_bin():
+    import numpy as np
+    z1, z2, z3 = 0x1234567, (5, 7), 0xABCDEF987            # arbitrary non-trivial Jacobian denominators
+    f2 = S._f2_mul
+    za = [A[0] * z1 ** 2 % S.Q, A[1] * z1 ** 3 % S.Q, z1]
+    zz2 = f2(z2, z2)
+    zb = [f2(B[0], zz2), f2(B[1], f2(zz2, z2)), z2]
+    zc = [C[0] * z3 ** 2 % S.Q, C[1] * z3 ** 3 % S.Q, z3]
+    flat = za + [c for e in zb for c in e] + zc
+    jac = np.stack([limbs(v) for v in flat])
+    assert S.compress_gpu_proof(jac) == raw()
+    # identity (z = 0) encodes as the infinity flag, and decodes back to zeros
+    jac0 = jac.copy()
+    jac0[2] = 0
+    enc = S.compress_gpu_proof(jac0)
+    assert enc[:32] == bytes(31) + b"\x40" and enc[32:] == raw()[32:]
+    assert not S.decompress_to_limbs(enc)[:2].any()
+
+
+def test_native_and_python_decoders_agree_on_malformed_input():
+    r = bytearray(raw())
+    bad_cases = []
+    b = bytearray(r); b[31] |= 0xC0; bad_cases.append(bytes(b))
+    b = bytearray(r); b[0:31] = b"\xff" * 31; b[31] = 0x3F; bad_cases.append(bytes(b))
+    x = 1
+    while S._sqrt_fq((x ** 3 + 3) % S.Q) is not None:
+        x += 1
+    bad_cases.append(x.to_bytes(32, "little") + bytes(r[32:]))
+    x = (1, 0)
+    while True:
+        y = S._sqrt_fq2(S._G2.add(S._f2_mul(S._f2_mul(x, x), x), S._B2))
+        if y is not None and not S._in_subgroup(S._G2, (x, y)):
+            break
+        x = (x[0] + 1, 0)
+    off_subgroup = bytes(r[:32]) + S.g2_to_bytes((x, y)) + bytes(r[96:])
+    bad_cases.append(off_subgroup)
+    for case in bad_cases:
+        with pytest.raises(S.SerializationError):
+            S.proof_from_bytes(case)
+        with pytest.raises(S.SerializationError):
+            S.decompress_to_limbs(case)
+    # without validation the off-subgroup point decodes (Validate::No)
+    assert S.decompress_to_limbs(off_subgroup, validate=False).any()
