@@ -144,6 +144,9 @@ def load():
     L.dg16_serialize_error.restype = ctypes.c_char_p
     L.dg16_proof_compress.argtypes = [i, vp, vp]
     L.dg16_proof_decompress.argtypes = [i, vp, i, vp]
+    L.dg16_verify_error.argtypes = []
+    L.dg16_verify_error.restype = ctypes.c_char_p
+    L.dg16_groth16_verify.argtypes = [i, vp, vp, vp, vp, vp, sz, vp, sz, vp, u, ctypes.POINTER(i)]
     _lib = L
     return L
 
@@ -158,7 +161,8 @@ EXPORTED = ["dg16_ctx_create", "dg16_ctx_destroy", "dg16_last_error", "dg16_set_
             "dg16_d_msm", "dg16_deg_red", "dg16_d_pp", "dg16_ext_wit_h", "dg16_qap",
             "dg16_io_error", "dg16_r1cs_parse", "dg16_r1cs_header_get", "dg16_r1cs_matrix", "dg16_r1cs_wire_map",
             "dg16_r1cs_free", "dg16_zkey_parse", "dg16_zkey_header_get", "dg16_zkey_points", "dg16_zkey_matrix",
-            "dg16_zkey_free", "dg16_serialize_error", "dg16_proof_compress", "dg16_proof_decompress"]
+            "dg16_zkey_free", "dg16_serialize_error", "dg16_proof_compress", "dg16_proof_decompress",
+            "dg16_verify_error", "dg16_groth16_verify"]
 
 
 def _ptr(x):

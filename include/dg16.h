@@ -305,6 +305,18 @@ const char *dg16_serialize_error(void);
 int dg16_proof_compress(int curve, const void *proof_jacobian, void *out128);
 int dg16_proof_decompress(int curve, const void *in128, int validate, void *proof_affine);
 
+/* ---- Groth16 verification, BN254 (host side; no GPU involved: four pairings) --------------------------------
+ *   dg16_groth16_verify  <- Groth16::<Bn254>::verify_proof   groth16/examples/sha256.rs:228-254, mpc-api verify
+ * e(A, B) = e(alpha, beta) e(IC_0 + sum x_i IC_i, gamma) e(C, delta).  Points are affine x || y Montgomery limbs
+ * with the identity as zeros -- the layout of a zkey's header / IC section (dg16_zkey_points) and of
+ * dg16_proof_decompress.  public_inputs: n_public scalars of 32 bytes, canonical or (DG16_F_SCALARS_MONT)
+ * Montgomery.  n_ic != n_public + 1 returns DG16_ERR_LENGTH_MISMATCH (ark-groth16's MalformedVerifyingKey).
+ * *accepted = 1 iff the equation holds (a proof point off its curve is a rejection, not an error). */
+const char *dg16_verify_error(void);
+int dg16_groth16_verify(int curve, const void *alpha_g1, const void *beta_g2, const void *gamma_g2,
+                        const void *delta_g2, const void *ic, size_t n_ic, const void *public_inputs,
+                        size_t n_public, const void *proof_affine, unsigned flags, int *accepted);
+
 /* Duration in milliseconds of the dominant kernel(s) of the most recent call on `channel`
  * (HIP events recorded on the channel's stream); 0 if none.  which: 0 = whole call,
  * 1 = bucket accumulation (MSM) / butterfly passes (NTT). */
