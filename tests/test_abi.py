@@ -45,3 +45,45 @@ def test_product_does_not_import_oracle():
                 txt = open(os.path.join(dirpath, f)).read()
                 for needle in ("import oracle", "from oracle", "liboracle", "oracle/c", "corc"):
                     assert needle not in txt, "%s references the oracle (%s)" % (f, needle)
+
+
+def test_header_is_valid_c_and_cpp():
+    import subprocess
+    hdr = os.path.join(ROOT, "include", "dg16.h")
+    subprocess.check_call(["gcc", "-fsyntax-only", "-x", "c", "-std=c99", "-Wall", "-Wextra", "-Werror", hdr])
+    subprocess.check_call(["g++", "-fsyntax-only", "-x", "c++", "-std=c++11", "-Wall", "-Werror", hdr])
+
+
+def test_plain_c_consumer_parses_a_zkey_and_verifies_a_proof(tmp_path):
+    """tests/abi_c/consumer.c, built with gcc against include/dg16.h and libdg16.so: zkey -> vk, proof.bin bytes ->
+    proof, dg16_groth16_verify -- the reference's `zk-cli verify` path from C."""
+    import random
+    import subprocess
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import dg16_amd  # noqa: F401
+    from dg16_amd import serialize as S
+    from oracle.pyref import groth16 as G
+    from oracle.pyref.fields import FR
+    from test_zkey_reader import small_key
+    from zkey_writer import write_zkey
+    lib_dir = os.path.join(ROOT, "distributed-groth16_amd")
+    exe = str(tmp_path / "consumer")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "abi_c", "consumer.c"), "-o", exe, "-L", lib_dir, "-ldg16",
+                           "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib"])
+    F = FR["bn254"]
+    r1cs, w, pk, m = small_key(seed=4, nc=17, ni=2, nw=9)
+    rng = random.Random(2)
+    proof = G.create_proof("bn254", pk, rng.randrange(1, F.p), rng.randrange(1, F.p), r1cs, w)
+    (tmp_path / "k.zkey").write_bytes(write_zkey(pk, r1cs, m))
+    (tmp_path / "proof.bin").write_bytes(S.proof_to_bytes(*proof))
+    for name, vals, expect in (("good", w[1:2], "accepted=1"), ("bad", [(w[1] + 1) % F.p], "accepted=0")):
+        (tmp_path / (name + ".bin")).write_bytes(b"".join(v.to_bytes(32, "little") for v in vals))
+        out = subprocess.run([exe, str(tmp_path / "k.zkey"), str(tmp_path / "proof.bin"), str(tmp_path / (name + ".bin"))],
+                             capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0, out.stdout + out.stderr
+        assert expect in out.stdout and "n_public=1" in out.stdout
+        import torch
+        if not torch.cuda.is_available():
+            assert "ctx_create=0" not in out.stdout          # no GPU: a status, not a context
