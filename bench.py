@@ -2,29 +2,34 @@
 """bench.py -- Groth16 proving throughput on MI355X (BASELINE.json metric: constraints/sec, BN254,
 2^20-constraint synthetic R1CS, at 1/2/4/8 GPUs).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--curve bn254|bls12_381] [--log-m 20]
     (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-A step = one complete Groth16 proof (h-polynomial: 3 iNTT + 3 NTT of size 2^20 + pointwise; five
-MSMs: A, B1, L, H in G1 and B in G2; A/B/C assembly) with every input already resident in HBM.
-N > 1 is STRONG scaling of one proof: each rank owns a contiguous 1/N slice of every MSM's bases and
-scalars, the h-polynomial is replicated, and one RCCL all-gather of N x 768 B records (A, B1, L, H, s*A, r*B1
-in G1 and B in G2, Jacobian) precedes the assembly (distributed-groth16_amd/parallel.py).
+A step = one complete Groth16 proof FROM THE MATRICES, the scope of the reference's
+`create_proof_with_reduction_and_matrices` (groth16/examples/sha256.rs:159): R1CS x witness (dg16_qap:
+a = A w, b = B w, c = a o b), h-polynomial (3 iNTT + 3 NTT of size m + pointwise), five MSMs (A, B1, L, H in G1,
+B in G2; r, s != 0), A/B/C assembly -- with every input (CSR matrices, assignment, RESIDENT proving key =
+window tables built once per key, outside the timed region, like any fixed CRS) already in HBM.
+N > 1 is STRONG scaling of one proof (distributed-groth16_amd/parallel.py): each rank owns a 1/N slice of every
+MSM and of the h-polynomial's transforms; the exchanges run inside libdg16 over RCCL.
 
-One JSON line is printed by rank 0.  `roofline` describes the dominant kernel (the G2 bucket
-accumulation): achieved = algorithmic bytes (160 B/point) / its HIP-event duration
-measured here on the stream it runs on -- against the 8 TB/s HBM roof this is small BY CONSTRUCTION:
-the kernel does ~28 x 10 Montgomery multiplications per 160 bytes and is integer-VALU-bound, so the
-honest second roof (`valu_roofline`: Montgomery multiplications per second against the measured
-chip rate of tools/ubench/montmul_rate) is printed next to it.  `cpu_baseline` times the oracle
-("port": arkworks-structured CPU restatement, NOT arkworks) on a second instance of the same 2^20 workload
-(~3 s on 32 threads; --cpu-sample-log shrinks it) on this box's host cores and doubles as a live parity check
-of the GPU proof.  `roofline.traffic` is the HBM traffic of the same launch from the committed --pmc passes.
+One JSON line is printed by rank 0:
+  roofline       the dominant kernel of the timed loop (G2 bucket accumulation, table mode), timed with HIP events
+                 on the stream it runs on INSIDE the timed proofs: achieved = 160 B/point x points
+                 per launch / duration, against the 8 TB/s HBM roof.  Small BY CONSTRUCTION (Pippenger does ~28 x W
+                 field multiplications per 160 bytes): the binding roof is integer VALU, `valu_roofline`, priced
+                 against BOTH the measured rate of this library's multiply and the v_mad_u64_u32 issue bound.
+  cpu_baseline   the oracle ("port": arkworks-structured CPU restatement, NOT arkworks) proving THE TIMED INSTANCE on
+                 this box's host cores (all cores, bounded to 32 OpenMP threads; plus a 1-thread run on a smaller
+                 sample) -- its proof is compared with the GPU's proof of the timed loop (live parity gate).
+  extras         ntt_2^22 (BASELINE config 3), plain / resident MSM points/s for G1 and G2 (config 2), the
+                 sha256-shaped prove (config 4), key table bytes and build time.
 """
 
 import argparse
 import json
 import os
+import platform
 import sys
 import time
 
@@ -34,38 +39,44 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-CURVE = "bn254"
-BN254_R_TOP = 0x30644E72E131A029   # top 64-bit limb of the BN254 scalar modulus
-MONTMUL_PEAK_G = 114.0             # G montmul/s, BN254 Fq, measured chip rate of the shipped multiply
-                                   # (variant D of tools/ubench/montmul_rate: profiles/r1_ubench_montmul_rate_v2.txt)
+CURVE = "bn254"                    # default curve (kept as a module constant for tools/ that import bench)
+FR_TOP = {"bn254": 0x30644E72E131A029, "bls12_381": 0x73EDA753299D7D48}   # top 64-bit limb of the scalar modulus
+FR_MOD = {"bn254": 21888242871839275222246405745257275088548364400416034343698204186575808495617,
+          "bls12_381": 52435875175126190479447740508185965837690552500527637822603658699938581184513}
+FQ_BYTES = {"bn254": 32, "bls12_381": 48}
+SCALAR_BITS = {"bn254": 254, "bls12_381": 255}
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md
+MAD_ISSUE_T = 34.4                 # T lane-op/s of v_mad_u64_u32, chip-wide (profiles/r1_ubench_instr_rate.txt)
 
 
-def rand_fr(n, dev, gen):
+def rand_fr(n, dev, gen, curve=CURVE):
     """Uniform canonical scalars in [0, r_top * 2^192) (statistically uniform mod r for histograms)."""
     lo = torch.randint(-2**63, 2**63 - 1, (n, 3), dtype=torch.int64, device=dev, generator=gen)
-    hi = torch.randint(0, BN254_R_TOP, (n, 1), dtype=torch.int64, device=dev, generator=gen)
+    hi = torch.randint(0, FR_TOP[curve], (n, 1), dtype=torch.int64, device=dev, generator=gen)
     return torch.cat([lo, hi], dim=1).contiguous()
 
 
 class Workload:
-    """Synthetic proving key (like PackedProvingKeyShare::rand, groth16/src/proving_key.rs:112-155) and
-    a synthetic satisfied-shape QAP instance of `log_m`: num_constraints = 2^log_m - 2, 2 instance
-    variables, 2^log_m wires."""
+    """Synthetic proving key (like PackedProvingKeyShare::rand, groth16/src/proving_key.rs:112-155) and a synthetic
+    R1CS instance: `nc` constraints with `nnz` nonzeros per row of A and of B, `nv` wires of which `ni` are instance
+    variables, domain m = 2^log_m >= nc + ni.  Defaults: nc = m - 2, nv = m (the headline shape).  The prover's work
+    does not depend on the R1CS being satisfied (qap.rs:44-91 sets c = a o b), so A, B are uniform sparse rows."""
 
-    def __init__(self, ctx, dev, log_m, rank, world, seed=20):
+    def __init__(self, ctx, dev, log_m, rank=0, world=1, seed=20, curve=CURVE, nv=None, nc=None, ni=2, nnz=3):
         import dg16_amd  # noqa: F401
-        self.ctx, self.dev = ctx, dev
+        self.ctx, self.dev, self.curve = ctx, dev, curve
         self.m = 1 << log_m
         self.log_m = log_m
-        self.ni = 2
-        self.nv = self.m
-        self.nc = self.m - self.ni
-        m, nv, ni = self.m, self.nv, self.ni
+        self.ni = ni
+        self.nv = self.m if nv is None else nv
+        self.nc = self.m - ni if nc is None else nc
+        assert self.nc + ni <= self.m and ni <= self.nv
+        m, nv, nc = self.m, self.nv, self.nc
+        fqb = FQ_BYTES[curve]
 
         def bases(group, cnt, s):
-            t = torch.empty(cnt * 64 * group, dtype=torch.uint8, device=dev)
-            ctx.gen_bases_dev(CURVE, group, seed * 100 + s, cnt, t.data_ptr())
+            t = torch.empty(cnt * 2 * fqb * group, dtype=torch.uint8, device=dev)
+            ctx.gen_bases_dev(curve, group, seed * 100 + s, cnt, t.data_ptr())
             return t
 
         self.aq, self.b1q, self.b2q = bases(1, nv, 1), bases(1, nv, 2), bases(2, nv, 3)
@@ -74,81 +85,213 @@ class Workload:
         ctx.sync(0)          # the generators ran on the library's stream: finish before torch touches them
         self.fixed = torch.cat([f1, f2])
         torch.cuda.synchronize()
-        self.pk = ctx.pk_create(CURVE, nv, ni, m, self.aq.data_ptr(), self.b1q.data_ptr(), self.b2q.data_ptr(),
+        t0 = time.perf_counter()
+        self.pk = ctx.pk_create(curve, nv, ni, m, self.aq.data_ptr(), self.b1q.data_ptr(), self.b2q.data_ptr(),
                                 self.hq.data_ptr(), self.lq.data_ptr(), self.fixed.data_ptr(), device_ptrs=True,
                                 shard=rank, n_shards=world)
+        self.pk_build_s = time.perf_counter() - t0
         gen = torch.Generator(device=dev)
         gen.manual_seed(seed)
-        # QAP evaluation vectors in Montgomery form: a, b random on the constraint rows, c = a o b
-        # (what a satisfied R1CS gives, groth16/src/qap.rs:60-80), zero padding above.
-        self.a = rand_fr(m, dev, gen)
-        self.b = rand_fr(m, dev, gen)
-        self.a[self.nc + ni:] = 0
-        self.b[self.nc:] = 0
-        self.c = torch.zeros_like(self.a)
-        torch.cuda.synchronize()   # torch's stream -> the library's stream
-        ctx.field_op_dev(CURVE, "fr", 2, self.a.data_ptr(), self.b.data_ptr(), self.c.data_ptr(), m)
-        ctx.sync(0)
-        self.c[self.nc:] = 0
-        self.w = rand_fr(nv, dev, gen)            # full assignment, canonical integers
+        # CSR matrices A, B (Montgomery coefficients) and the full assignment (canonical integers, w[0] = 1)
+        self.row_ptr = (torch.arange(nc + 1, dtype=torch.int64, device=dev) * nnz).to(torch.int32)
+        self.a_col = torch.randint(0, nv, (nc * nnz,), dtype=torch.int32, device=dev, generator=gen)
+        self.b_col = torch.randint(0, nv, (nc * nnz,), dtype=torch.int32, device=dev, generator=gen)
+        self.a_val = rand_fr(nc * nnz, dev, gen, curve)
+        self.b_val = rand_fr(nc * nnz, dev, gen, curve)
+        self.w = rand_fr(nv, dev, gen, curve)
+        self.w[0] = 0
+        self.w[0, 0] = 1
+        self.a = torch.empty((m, 4), dtype=torch.int64, device=dev)
+        self.b = torch.empty_like(self.a)
+        self.c = torch.empty_like(self.a)
         self.rs = np.array([[3, 1, 4, 1], [5, 9, 2, 6]], dtype=np.uint64)   # r, s (canonical, nonzero)
-        torch.cuda.synchronize()
+        torch.cuda.synchronize()   # torch's stream -> the library's stream
+        self.qap()
+        ctx.sync(0)
+
+    def qap(self):
+        """a, b, c <- R1CS x witness on the GPU (stream-ordered on channel 0, like the proof that follows)."""
+        self.ctx.qap_dev(self.curve, self.nc, self.ni, self.nv, self.log_m, self.row_ptr.data_ptr(),
+                         self.a_col.data_ptr(), self.a_val.data_ptr(), self.row_ptr.data_ptr(), self.b_col.data_ptr(),
+                         self.b_val.data_ptr(), self.w.data_ptr(), self.a.data_ptr(), self.b.data_ptr(),
+                         self.c.data_ptr(), scalars_mont=False)
+
+    def proof_bytes(self):
+        return 12 * FQ_BYTES[self.curve]
 
 
 def to_host_u64(t, cols):
     return t.view(torch.uint8).cpu().numpy().view(np.uint64).reshape(-1, cols)
 
 
-def cpu_baseline_and_parity(ctx, dev, log_s):
-    """Oracle ("port") prove on a 2^log_s sample + comparison with the GPU proof of the same sample."""
+def oracle_prove(wl, threads, r=None, s=None):
+    """The oracle ("port") proves the instance of `wl` from the matrices on the host cores.
+    Returns (A, B, C) affine arrays and the seconds spent in qap + h-polynomial + the five MSMs."""
     from oracle import corc
-    wl = Workload(ctx, dev, log_s, 0, 1, seed=7)
-    m, nv, ni = wl.m, wl.nv, wl.ni
-    proof = torch.empty(96 * 2 + 192, dtype=torch.uint8, device=dev)
-    ctx.prove_dev(wl.pk, wl.a.data_ptr(), wl.b.data_ptr(), wl.c.data_ptr(), wl.w.data_ptr(), wl.rs, proof.data_ptr(),
-                  scalars_mont=False)
-    for ch in range(3):
-        ctx.sync(ch)
-    gp = proof.cpu().numpy().view(np.uint64)
-    gA = corc.jac_to_affine(CURVE, 1, gp[:12])
-    gB = corc.jac_to_affine(CURVE, 2, gp[12:36])
-    gC = corc.jac_to_affine(CURVE, 1, gp[36:48])
-    # host copies of the same inputs
-    aq, b1q, b2q = to_host_u64(wl.aq, 8), to_host_u64(wl.b1q, 8), to_host_u64(wl.b2q, 16)
-    hq, lq = to_host_u64(wl.hq, 8), to_host_u64(wl.lq, 8)
-    f1 = to_host_u64(wl.fixed[:192], 8)
-    f2 = to_host_u64(wl.fixed[192:], 16)
+    curve, m, nv, ni, nc = wl.curve, wl.m, wl.nv, wl.ni, wl.nc
+    l1, l2 = FQ_BYTES[curve] // 4, FQ_BYTES[curve] // 2     # u64 limbs of a G1 / G2 affine point
+    aq, b1q, b2q = to_host_u64(wl.aq, l1), to_host_u64(wl.b1q, l1), to_host_u64(wl.b2q, l2)
+    hq, lq = to_host_u64(wl.hq, l1), to_host_u64(wl.lq, l1)
+    g1b = 3 * 2 * FQ_BYTES[curve]
+    f1 = to_host_u64(wl.fixed[:g1b], l1)
+    f2 = to_host_u64(wl.fixed[g1b:], l2)
     alpha, beta1, delta1 = f1[0:1], f1[1:2], f1[2:3]
     beta2, delta2 = f2[0:1], f2[1:2]
-    a, b, c, w = (to_host_u64(t, 4) for t in (wl.a, wl.b, wl.c, wl.w))
-    r = int(sum(int(x) << (64 * i) for i, x in enumerate(wl.rs[0])))
-    s = int(sum(int(x) << (64 * i) for i, x in enumerate(wl.rs[1])))
-    # >32 OpenMP threads only adds fork/join overhead here (measured on the EPYC 9575F GPU box:
-    # NTT 2^16 takes 5 ms at 32 threads and 2 s at 256)
-    threads = min(os.cpu_count() or 1, 32)
+    w = to_host_u64(wl.w, 4)
+    rp = wl.row_ptr.cpu().numpy().view(np.uint32)
+    csr_a = (rp, wl.a_col.cpu().numpy().view(np.uint32), to_host_u64(wl.a_val, 4))
+    csr_b = (rp, wl.b_col.cpu().numpy().view(np.uint32), to_host_u64(wl.b_val, 4))
+    w_mont = corc.field_op(curve, "fr", "to_mont", w)       # arkworks holds the assignment in Montgomery form
+    if r is None:
+        r = int(sum(int(x) << (64 * i) for i, x in enumerate(wl.rs[0])))
+        s = int(sum(int(x) << (64 * i) for i, x in enumerate(wl.rs[1])))
     t0 = time.perf_counter()
-    h = corc.h_poly(CURVE, a, b, c, threads=threads)
-    h_canon = corc.field_op(CURVE, "fr", "from_mont", h)
-    msm = lambda g, bases, sc: corc.msm(CURVE, g, bases, sc, threads=threads)
+    a, b, c = corc.qap(curve, nc, ni, m, csr_a, csr_b, w_mont, threads=threads)
+    h = corc.h_poly(curve, a, b, c, threads=threads)
+    h_canon = corc.field_op(curve, "fr", "from_mont", h)
+    msm = lambda g, bases, sc: corc.msm(curve, g, bases, sc, threads=threads)   # noqa: E731
     mA = msm(1, aq[1:], w[1:])
     mB1 = msm(1, b1q[1:], w[1:])
     mB2 = msm(2, b2q[1:], w[1:])
     mL = msm(1, lq, w[ni:])
     mH = msm(1, hq, h_canon)
     t_cpu = time.perf_counter() - t0
-    add = lambda g, p, q: corc.point_add(CURVE, g, p, q)
-    mul = lambda g, p, k: corc.point_mul(CURVE, g, p, k)
+    add = lambda g, p, q: corc.point_add(curve, g, p, q)    # noqa: E731
+    mul = lambda g, p, k: corc.point_mul(curve, g, p, k)    # noqa: E731
+    R = FR_MOD[curve]
     A = add(1, add(1, mA, aq[0:1]), add(1, alpha, mul(1, delta1, r)))
     B1 = add(1, add(1, mB1, b1q[0:1]), add(1, beta1, mul(1, delta1, s)))
     B = add(2, add(2, mB2, b2q[0:1]), add(2, beta2, mul(2, delta2, s)))
-    R = 21888242871839275222246405745257275088548364400416034343698204186575808495617
     C = add(1, add(1, mL, mH), add(1, add(1, mul(1, A, s), mul(1, B1, r)), mul(1, delta1, (R - r * s % R) % R)))
+    return (A, B, C), t_cpu
+
+
+def gpu_proof_affine(curve, proof_u8):
+    from oracle import corc
+    nl = FQ_BYTES[curve] // 8
+    gp = np.asarray(proof_u8).view(np.uint64)
+    return (corc.jac_to_affine(curve, 1, gp[:3 * nl]), corc.jac_to_affine(curve, 2, gp[3 * nl:9 * nl]),
+            corc.jac_to_affine(curve, 1, gp[9 * nl:]))
+
+
+def prove_once(ctx, wl, rs=None):
+    """qap + prove of `wl` on the GPU; returns the proof bytes (host)."""
+    proof = torch.empty(wl.proof_bytes(), dtype=torch.uint8, device=wl.dev)
+    wl.qap()
+    ctx.prove_dev(wl.pk, wl.a.data_ptr(), wl.b.data_ptr(), wl.c.data_ptr(), wl.w.data_ptr(),
+                  wl.rs if rs is None else rs, proof.data_ptr(), scalars_mont=False)
+    for ch in range(3):
+        ctx.sync(ch)
+    return proof.cpu().numpy()
+
+
+def cpu_threads():
+    # >32 OpenMP threads only adds fork/join overhead here (measured on the EPYC 9575F GPU box:
+    # NTT 2^16 takes 5 ms at 32 threads and 2 s at 256)
+    return min(os.cpu_count() or 1, 32)
+
+
+def cpu_baseline_and_parity(ctx, dev, log_s, curve=CURVE, wl=None, gpu_proof=None, **shape):
+    """Oracle ("port") prove + comparison with the GPU proof of the same instance.  With `wl` / `gpu_proof` given
+    the instance is the caller's (bench: the timed one); otherwise a fresh 2^log_s instance (seed 7) is proved
+    on both sides (smoke, tests)."""
+    own = wl is None
+    if own:
+        wl = Workload(ctx, dev, log_s, 0, 1, seed=7, curve=curve, **shape)
+    if gpu_proof is None:
+        gpu_proof = prove_once(ctx, wl)
+    threads = cpu_threads()
+    (A, B, C), t_cpu = oracle_prove(wl, threads)
+    gA, gB, gC = gpu_proof_affine(curve, gpu_proof)
     ok = bool(np.array_equal(A, gA) and np.array_equal(B, gB) and np.array_equal(C, gC))
-    wl.pk.close()
-    return {"value": (m - ni) / t_cpu, "unit": "constraints/s", "cores": threads, "kind": "port",
-            "sample": "one proof of a 2^%d-constraint instance of the same synthetic workload (h-poly + 5 MSMs; "
-                      "C oracle, OpenMP, Pippenger parallel over <=%d windows like arkworks): %.2f s"
-                      % (log_s, 19, t_cpu)}, ok
+    res = {"value": wl.nc / t_cpu, "unit": "constraints/s", "cores": threads, "kind": "port",
+           "sample": "one proof of %s (R1CS x witness + h-poly + 5 MSMs; C oracle, OpenMP, Pippenger parallel over "
+                     "<=19 windows like arkworks): %.2f s" % ("the timed instance" if not own else
+                                                              "a 2^%d instance of the same workload" % wl.log_m, t_cpu)}
+    if own:
+        wl.pk.close()
+    return res, ok
+
+
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return platform.processor() or "unknown"
+
+
+def time_call(ctx, fn, channel, reps=3):
+    """Median (whole call ms, dominant-kernel ms) by the library's HIP events on the channel's stream."""
+    out = []
+    for _ in range(reps + 1):
+        fn()
+        ctx.sync(channel)
+        out.append((ctx.last_kernel_ms(channel, 0), ctx.last_kernel_ms(channel, 1)))
+    out = sorted(out[1:])
+    return out[len(out) // 2]
+
+
+def extras(ctx, dev, wl, curve, res):
+    """Config 2 / 3 / 4 lines and key disclosure (N = 1, rank 0 only)."""
+    fqb = FQ_BYTES[curve]
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(3)
+    # BASELINE config 3: Fr radix-2 NTT, domain 2^22
+    x = rand_fr(1 << 22, dev, gen, curve)
+    torch.cuda.synchronize()
+    call_ms, k_ms = time_call(ctx, lambda: ctx.ntt_dev(curve, x.data_ptr(), 22), 0)
+    res["ntt_2^22"] = {"ms": k_ms, "algorithmic_GBps": 64.0 * (1 << 22) / (k_ms * 1e-3) / 1e9,
+                       "hbm_frac": 64.0 * (1 << 22) / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "field": curve + " Fr"}
+    del x
+    # BASELINE config 2: plain MSM over fresh bases (dg16_msm: sort + accumulate + reductions + Horner tail) and the
+    # resident form (dg16_bases_upload once, then dg16_msm_resident: window tables, no tail)
+    n = wl.nv - 1
+    msm = {}
+    for g, bases in ((1, wl.aq), (2, wl.b2q)):
+        pb = 2 * fqb * g
+        out = torch.empty(3 * fqb * g, dtype=torch.uint8, device=dev)
+        call_ms, acc_ms = time_call(ctx, lambda: ctx.msm_dev(curve, g, bases.data_ptr() + pb, wl.w.data_ptr() + 32, n,
+                                                              out.data_ptr(), channel=1), 1)
+        msm["g%d_plain_pts_per_s" % g] = n / (call_ms * 1e-3)
+        msm["g%d_plain_ms" % g] = call_ms
+        if hasattr(ctx, "bases_upload"):
+            hb = ctx.bases_upload(curve, g, bases.data_ptr() + pb, n, device_ptrs=True)
+            call_ms, acc_ms = time_call(ctx, lambda: ctx.msm_resident_dev(hb, wl.w.data_ptr() + 32, n, out.data_ptr(),
+                                                                          channel=1), 1)
+            msm["g%d_resident_pts_per_s" % g] = n / (call_ms * 1e-3)
+            msm["g%d_resident_ms" % g] = call_ms
+            hb.close()
+    msm["n"] = n
+    res["msm_pts_per_s"] = msm
+    # BASELINE config 4: sha256-shaped prove (29 823 wires, 2 instance variables, domain 2^15; the real r1cs is a
+    # missing blob of the reference tree: SURVEY.md section 0), parity against the oracle, r = s = 0 and random
+    if curve == "bn254":
+        sha = Workload(ctx, dev, 15, 0, 1, seed=4, curve=curve, nv=29823, nc=29400, ni=2)
+        ok = True
+        for rs in (np.zeros((2, 4), dtype=np.uint64), sha.rs):
+            gp = prove_once(ctx, sha, rs)
+            r = int(sum(int(v) << (64 * i) for i, v in enumerate(rs[0])))
+            s = int(sum(int(v) << (64 * i) for i, v in enumerate(rs[1])))
+            (A, B, C), t_cpu = oracle_prove(sha, cpu_threads(), r, s)
+            gA, gB, gC = gpu_proof_affine(curve, gp)
+            ok = ok and bool(np.array_equal(A, gA) and np.array_equal(B, gB) and np.array_equal(C, gC))
+        ts = []
+        for _ in range(6):
+            t0 = time.perf_counter()
+            prove_once(ctx, sha)
+            ts.append(time.perf_counter() - t0)
+        best = min(ts[1:])
+        res["config4_sha256_shaped"] = {"ms_per_proof": best * 1e3, "constraints_per_s": sha.nc / best,
+                                        "cpu_port_ms": t_cpu * 1e3, "parity_check": "pass" if ok else "FAIL",
+                                        "shape": "29823 wires, 29400 constraints, 2 instance variables, domain 2^15, "
+                                                 "3 nonzeros per row; r = s = 0 and r, s != 0 both checked"}
+        sha.pk.close()
+        if not ok:
+            raise SystemExit("sha256-shaped proof differs from the oracle's")
 
 
 def main():
@@ -156,10 +299,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--curve", default=CURVE, choices=sorted(FR_TOP))
     ap.add_argument("--log-m", type=int, default=20)
-    ap.add_argument("--cpu-sample-log", type=int, default=20)
+    ap.add_argument("--cpu-sample-log", type=int, default=20,
+                    help="log2 size of the CPU baseline / parity instance when the timed one is larger")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true")
     args = ap.parse_args()
+    curve = args.curve
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -178,13 +325,14 @@ def main():
         dist.init_process_group(backend="nccl", device_id=dev)
 
     import dg16_amd
-    from dg16_amd.parallel import DistributedProver, GpuEngine
+    from dg16_amd.parallel import make_prover
 
     ctx = dg16_amd.Context(local_rank)
-    wl = Workload(ctx, dev, args.log_m, rank, world)
-    prover = DistributedProver(GpuEngine(ctx, wl.pk, CURVE), dist, rank, world)
+    wl = Workload(ctx, dev, args.log_m, rank, world, curve=curve)
+    prover = make_prover(ctx, wl.pk, curve, dist, rank, world)
 
     def step():
+        wl.qap()
         return prover.prove(wl.a, wl.b, wl.c, wl.w, wl.rs, scalars_mont=False)
 
     def full_sync():
@@ -200,7 +348,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        proof = step()
     full_sync()
     if dist is not None:
         dist.barrier()
@@ -214,40 +362,32 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = wl.nc * args.steps / elapsed
 
-    # ---- dominant kernel, measured live with HIP events on its own stream ----
-    n_g2 = wl.nv - 1
-    out = torch.empty(192, dtype=torch.uint8, device=dev)
-    acc_ms = []
-    for _ in range(3):
-        ctx.msm_dev(CURVE, 2, wl.b2q.data_ptr() + 128, wl.w.data_ptr() + 32, n_g2, out.data_ptr(), channel=2)
-        ctx.sync(2)
-        acc_ms.append(ctx.last_kernel_ms(2, 1))
-    g2_acc_ms = sum(acc_ms[1:]) / len(acc_ms[1:])
-    g1_ms = []
-    out1 = torch.empty(96, dtype=torch.uint8, device=dev)
-    for _ in range(3):
-        ctx.msm_dev(CURVE, 1, wl.aq.data_ptr() + 64, wl.w.data_ptr() + 32, n_g2, out1.data_ptr(), channel=1)
-        ctx.sync(1)
-        g1_ms.append((ctx.last_kernel_ms(1, 1), ctx.last_kernel_ms(1, 0)))
-    alg_bytes = 160.0 * n_g2
-    achieved = alg_bytes / (g2_acc_ms * 1e-3) / 1e9
-    # bucket additions of that launch: one mixed add (8M + 2S in Fq2 = 28 Fq multiplications) per nonzero digit
-    lg = n_g2.bit_length() - 1                      # msm_window_bits() of csrc/msm_impl.h: nearest power of two
-    if n_g2 > (3 << lg) // 2:
-        lg += 1
-    cbits = min(max(lg - 4, 4), 16)
-    nwin = (254 + 1 + cbits - 1) // cbits
+    # ---- dominant kernel: the G2 bucket accumulation of the LAST TIMED PROOF (HIP events recorded around it on
+    # the stream it ran on: dg16_last_kernel_ms, channel 2 = G2 accumulation, channel 1 = A's G1 accumulation) ----
+    g2_acc_ms = ctx.last_kernel_ms(2, 1)
+    g1_acc_ms = ctx.last_kernel_ms(1, 1)
+    info = wl.pk.info()
+    n_g2 = info["n_ab"]                              # points of this rank's A / B1 / B launches (slice + 2 delta slots)
+    nwin = (SCALAR_BITS[curve] + 1 + info["c_ab"] - 1) // info["c_ab"]
+    g2_alg = {"bn254": 160.0, "bls12_381": 224.0}[curve]
+    alg_bytes = g2_alg * n_g2
+    achieved = alg_bytes / (g2_acc_ms * 1e-3) / 1e9 if g2_acc_ms else 0.0
+    # one XYZZ mixed addition (8M + 2S in Fq2 = 3 x 8 + 2 x 2 = 28 Fq multiplications) per nonzero digit
     montmuls = 28.0 * n_g2 * nwin
-    valu_g = montmuls / (g2_acc_ms * 1e-3) / 1e9
+    valu_g = montmuls / (g2_acc_ms * 1e-3) / 1e9 if g2_acc_ms else 0.0
+    mul_cost = info["fq_mul_mads"]                   # v_mad_u64_u32 per Fq product of the shipped multiply
+    mad_bound_g = MAD_ISSUE_T * 1e3 / mul_cost       # G products/s if only the multiplier issue slots counted
 
     # HBM traffic of that kernel: PMC counters cannot be read from inside the process; the committed summary of
     # the separate rocprofv3 --pmc passes over the same launch (same curve, group, size) supplies it.
     traffic, traffic_src = None, None
-    pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_pmc_g2_accumulate.json")
-    if args.log_m == 20 and os.path.exists(pmc_path):
-        with open(pmc_path) as f:
-            traffic = json.load(f)["traffic_bytes_per_launch"]
-        traffic_src = "profiles/r1_pmc_g2_accumulate.json (2 x FETCH_SIZE + WRITE_SIZE, separate --pmc passes)"
+    for name in ("r2_pmc_g2_accumulate.json", "r1_pmc_g2_accumulate.json"):
+        pmc_path = os.path.join(ROOT, "profiles", name)
+        if args.log_m == 20 and curve == "bn254" and world == 1 and os.path.exists(pmc_path):
+            with open(pmc_path) as f:
+                traffic = json.load(f)["traffic_bytes_per_launch"]
+            traffic_src = "profiles/%s (2 x FETCH_SIZE + WRITE_SIZE, separate --pmc passes)" % name
+            break
 
     res = {
         "metric": "groth16_constraints_per_sec",
@@ -262,32 +402,53 @@ def main():
         "vs_baseline": None,
         "dtype": "u32",
         "data": "synthetic",
-        "config": {"workload": "BN254 Groth16 prove, synthetic R1CS with 2^%d - 2 constraints, 2^%d wires, "
-                               "2 instance variables; r, s != 0 (4 G1 MSMs + 1 G2 MSM + 6 NTTs of 2^%d)"
-                               % (args.log_m, args.log_m, args.log_m),
-                   "curve": CURVE, "log_domain": args.log_m, "parallelism": "msm-shard x%d + all-gather" % world},
-        "roofline": {"bound": "hbm", "kernel": "msm_accumulate_lds_kernel<Fp2<bn254_fq>> (G2 bucket accumulation)",
-                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": traffic, "traffic_source": traffic_src, "kernel_ms": g2_acc_ms,
-                     "note": "160 B/point algorithmic (each point and scalar once); Pippenger gathers every point once "
-                             "per window (16 x 132 B/point + segment sums = 2.5 GB), which is what the PMC traffic "
-                             "shows -- no re-read waste; the kernel is integer-VALU-bound (see valu_roofline)"},
-        "valu_roofline": {"unit": "G montmul/s", "achieved": valu_g, "peak": MONTMUL_PEAK_G,
-                          "frac": valu_g / MONTMUL_PEAK_G,
-                          "note": "28 Fq multiplications per G2 mixed add x n x %d windows / kernel time; peak = " % nwin +
-                                  "measured chip rate of the same multiply (tools/ubench/montmul_rate)"},
-        "msm_pts_per_s": {"g1_2^%d" % args.log_m: n_g2 / (g1_ms[-1][1] * 1e-3),
-                          "g1_accumulate_ms": g1_ms[-1][0], "g1_call_ms": g1_ms[-1][1]},
+        "config": {"workload": "%s Groth16 prove from the matrices, synthetic R1CS with 2^%d - 2 constraints (3 nonzeros "
+                               "per row of A and B), 2^%d wires, 2 instance variables; r, s != 0 (R1CS x witness + "
+                               "6 NTTs of 2^%d + 4 G1 MSMs + 1 G2 MSM); proving key RESIDENT as window tables "
+                               "(built once per key outside the timed region)"
+                               % (curve.upper(), args.log_m, args.log_m, args.log_m),
+                   "curve": curve, "log_domain": args.log_m,
+                   "parallelism": prover.describe(),
+                   "key_table_bytes": info["table_bytes"], "key_table_build_s": wl.pk_build_s,
+                   "key_window_bits": {"ab": info["c_ab"], "l": info["c_l"], "h": info["c_h"]}},
+        "roofline": {"bound": "hbm", "kernel": info["g2_kernel"] + " (G2 bucket accumulation, table mode, inside the "
+                     "timed proofs)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                     "kernel_ms": g2_acc_ms, "points_per_launch": n_g2,
+                     "note": "%d B/point algorithmic (each point and scalar once); Pippenger gathers every point once "
+                             "per window, which is what the PMC traffic shows -- the kernel is integer-VALU-bound "
+                             "(see valu_roofline)" % int(g2_alg)},
+        "valu_roofline": {"unit": "G montmul/s", "achieved": valu_g, "peak": info["fq_mul_rate_g"],
+                          "frac": valu_g / info["fq_mul_rate_g"], "mad_issue_bound": mad_bound_g,
+                          "frac_of_mad_issue_bound": valu_g / mad_bound_g,
+                          "note": "28 Fq multiplications per G2 mixed add x %d points x %d windows / kernel time; peak = "
+                                  "measured chip rate of the shipped multiply (tools/ubench); mad_issue_bound = %.1f T "
+                                  "v_mad_u64_u32 lane-op/s / %d mads per product" % (n_g2, nwin, MAD_ISSUE_T, mul_cost)},
+        "g1_accumulate_ms": g1_acc_ms,
+        "host": {"cpu_model": cpu_model(), "nproc": os.cpu_count()},
     }
+    if rank == 0 and world == 1 and not args.no_extras:
+        extras(ctx, dev, wl, curve, res)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cb, ok = cpu_baseline_and_parity(ctx, dev, min(args.cpu_sample_log, args.log_m))
+        if args.log_m <= args.cpu_sample_log:
+            cb, ok = cpu_baseline_and_parity(ctx, dev, args.log_m, curve, wl=wl, gpu_proof=proof.cpu().numpy())
+        else:       # e.g. 2^24: prove a bounded 2^cpu_sample_log instance on both sides instead
+            cb, ok = cpu_baseline_and_parity(ctx, dev, args.cpu_sample_log, curve)
+        # 1-thread run on a smaller sample
+        small = Workload(ctx, dev, min(args.log_m, 16), 0, 1, seed=9, curve=curve)
+        _, t1 = oracle_prove(small, 1)
+        cb["one_thread"] = {"value": small.nc / t1, "unit": "constraints/s", "cores": 1,
+                            "sample": "one proof of a 2^%d instance: %.2f s" % (small.log_m, t1)}
+        small.pk.close()
+        cb["cpu_model"] = cpu_model()
         res["cpu_baseline"] = cb
         res["parity_check"] = "pass" if ok else "FAIL"
         if not ok:
             print(json.dumps(res))
-            raise SystemExit("GPU proof differs from the oracle proof on the sample")
+            raise SystemExit("GPU proof differs from the oracle proof")
     if rank == 0:
         print(json.dumps(res))
+    prover.close()
     if dist is not None:
         dist.destroy_process_group()
 

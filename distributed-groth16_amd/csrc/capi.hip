@@ -41,6 +41,9 @@ int dg16_ctx_create(int device, dg16_ctx** out) {
     }
     for (auto& e : ctx->pipe_ev) DG_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (auto& st : ctx->aux) DG_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    DG_HIP(hipHostMalloc((void**)&ctx->dev_flag_host, sizeof(unsigned), hipHostMallocMapped));
+    *ctx->dev_flag_host = 0;
+    DG_HIP(hipHostGetDevicePointer((void**)&ctx->dev_flag, ctx->dev_flag_host, 0));
   });
   if (rc != DG16_OK) {
     // keep the message reachable for the caller that failed to get a context
@@ -68,6 +71,7 @@ void dg16_ctx_destroy(dg16_ctx* ctx) {
     if (e) hipEventDestroy(e);
   for (auto& st : ctx->aux)
     if (st) hipStreamDestroy(st);
+  if (ctx->dev_flag_host) hipHostFree(ctx->dev_flag_host);
   for (auto& kv : ctx->twiddles) {
     hipFree(kv.second.lo);
     hipFree(kv.second.hi);
@@ -100,6 +104,13 @@ int dg16_sync(dg16_ctx* ctx, int channel) {
   return guarded(ctx, [&] {
     DG_HIP(hipSetDevice(ctx->device));
     DG_HIP(hipStreamSynchronize(ctx->ch[channel].cur));
+    // sticky device-side argument errors of stream-ordered (device-pointer) calls surface here
+    if (ctx->dev_flag_host && *ctx->dev_flag_host) {
+      const unsigned f = *ctx->dev_flag_host;
+      *ctx->dev_flag_host = 0;
+      throw StatusError{DG16_ERR_BAD_ARG, f & 1 ? "dg16_qap: coefficient out of range (column >= num_vars or bad row_ptr)"
+                                                : "device-side argument check failed"};
+    }
   });
 }
 
@@ -276,13 +287,24 @@ int dg16_qap(dg16_ctx* ctx, int curve, size_t num_constraints, size_t num_inputs
                "domain smaller than num_constraints + num_inputs");
     bool dev = flags & DG16_F_DEVICE_PTRS;
     Call k(ctx, channel);
+    // Matrix indices are checked before they index the assignment: a malformed key file must end in
+    // DG16_ERR_BAD_ARG, not in an out-of-bounds device read (the reference's Rust indexing panics).  Host
+    // pointers: checked here.  Device pointers: no read-back (the call stays stream-ordered); the kernel skips
+    // every out-of-range entry and raises the context's sticky device flag, which the next dg16_sync reports.
     size_t a_nnz = 0, b_nnz = 0;
-    if (dev) {
-      DG_HIP(hipMemcpy(&a_nnz, a_row_ptr + num_constraints, 4, hipMemcpyDeviceToHost));
-      DG_HIP(hipMemcpy(&b_nnz, b_row_ptr + num_constraints, 4, hipMemcpyDeviceToHost));
-    } else {
-      a_nnz = a_row_ptr[num_constraints];
-      b_nnz = b_row_ptr[num_constraints];
+    if (!dev) {
+      auto check = [&](const uint32_t* ptr, const uint32_t* col, size_t& nnz) {
+        DG_REQUIRE(ptr[0] == 0, DG16_ERR_BAD_ARG, "row_ptr[0] != 0");
+        for (size_t i = 0; i < num_constraints; i++)
+          DG_REQUIRE(ptr[i] <= ptr[i + 1], DG16_ERR_BAD_ARG, "row_ptr is not monotonic");
+        nnz = ptr[num_constraints];
+        DG_REQUIRE(nnz == 0 || col, DG16_ERR_BAD_ARG, "null column indices");
+        for (size_t j = 0; j < nnz; j++)
+          DG_REQUIRE(col[j] < num_vars, DG16_ERR_BAD_ARG, "coefficient out of range (column >= num_vars)");
+      };
+      check(a_row_ptr, a_col, a_nnz);
+      check(b_row_ptr, b_col, b_nnz);
+      DG_REQUIRE((a_nnz == 0 || a_coeff) && (b_nnz == 0 || b_coeff), DG16_ERR_BAD_ARG, "null coefficients");
     }
     const unsigned* ap = (const unsigned*)stage_in(k, 0, a_row_ptr, (num_constraints + 1) * 4, dev);
     const unsigned* ac = (const unsigned*)stage_in(k, 1, a_col, a_nnz * 4, dev);
@@ -295,8 +317,8 @@ int dg16_qap(dg16_ctx* ctx, int curve, size_t num_constraints, size_t num_inputs
     void* da = dev ? a_out : out;
     void* db = dev ? b_out : out + m * 32;
     void* dc = dev ? c_out : out + 2 * m * 32;
-    qap_launch(k, curve, ap, ac, av, bp, bc, bv, w, flags & DG16_F_SCALARS_MONT, num_constraints, num_inputs, m, da, db,
-               dc);
+    qap_launch(k, curve, ap, ac, av, bp, bc, bv, w, flags & DG16_F_SCALARS_MONT, num_constraints, num_inputs, num_vars,
+               m, da, db, dc);
     if (!dev) {
       stage_out(k, a_out, da, m * 32, false);
       stage_out(k, b_out, db, m * 32, false);

@@ -62,6 +62,10 @@ struct dg16_ctx {
   // oracle; the first one was masked by the implicit synchronisation of hipMalloc).
   hipEvent_t pipe_ev[16] = {};
   hipStream_t aux[2] = {};   // extra internal streams of the prover pipeline (never handed out)
+  // Sticky argument-error flag of stream-ordered calls (pinned host word mapped into the device: kernels OR
+  // bits into it, dg16_sync reads it after the stream has drained).  bit 0: dg16_qap index out of range.
+  unsigned* dev_flag_host = nullptr;
+  unsigned* dev_flag = nullptr;
   std::map<dg16::TwiddleKey, dg16::TwiddleSet> twiddles;
 };
 
@@ -176,7 +180,7 @@ inline void stage_out(Call& k, void* host_dst, const void* dev_src, size_t bytes
 void field_op_launch(Call& k, int field_id, int op, const void* a, const void* b, void* out, size_t n);
 void qap_launch(Call& k, int curve, const unsigned* a_ptr, const unsigned* a_col, const void* a_val,
                 const unsigned* b_ptr, const unsigned* b_col, const void* b_val, const void* w, bool w_mont, size_t nc,
-                size_t ni, size_t m, void* a, void* b, void* c);
+                size_t ni, size_t nv, size_t m, void* a, void* b, void* c);
 void ntt_launch(Call& k, int curve, void* data, unsigned log_n, int inverse, const void* coset_host);
 void h_poly_launch(Call& k, int curve, const void* a, const void* b, const void* c, unsigned log_m,
                    void* out);

@@ -19,8 +19,10 @@ struct dg16_localnet {
     const void* send[kMaxParties] = {};
     void* king_recv = nullptr;
     const void* king_send = nullptr;
-    size_t bytes = 0;
+    size_t bytes = 0;                   // the king's length
+    size_t party_bytes[kMaxParties] = {};   // what every party announced (mpc-net/src/lib.rs:116-124 checks them)
     bool failed = false;
+    bool result_ok = true;              // outcome of the last completed round, read by the clients
   } slot[kChannels][2];   // [channel][0 = gather, 1 = scatter]
   dg16_net party[kMaxParties];
   struct PartyRef { dg16_localnet* net; unsigned id; } ref[kMaxParties];
@@ -42,30 +44,33 @@ static bool rendezvous(dg16_localnet* ln, dg16_localnet::Slot& s, unsigned id, F
   if (id == 0) {
     if (!ln->cv.wait_for(lk, limit, [&] { return s.arrived == ln->n || ln->aborted; }) || ln->aborted) {
       ln->aborted = true;     // a peer never arrived: fail everybody instead of hanging
+      s.arrived = 0;          // ... and leave the slot clean for the next round after a reset
       ln->cv.notify_all();
       return false;
     }
-    bool ok = !s.failed;
+    // unequal lengths are an error on every party, like the reference's length check (a shorter buffer would be
+    // read or written past its end by the king's copies)
+    bool ok = true;
+    for (unsigned p = 0; p < ln->n; p++) ok = ok && s.party_bytes[p] == s.bytes;
     if (ok) {
       lk.unlock();
       ok = king_work();
       lk.lock();
     }
-    s.failed = !ok;
-    bool result = ok;
+    s.result_ok = ok;
     s.arrived = 0;
     s.generation++;
     ln->cv.notify_all();
-    s.failed = false;
-    return result;
+    return ok;
   }
   ln->cv.notify_all();
   if (!ln->cv.wait_for(lk, limit, [&] { return s.generation != gen || ln->aborted; }) || ln->aborted) {
     ln->aborted = true;
+    s.arrived = 0;
     ln->cv.notify_all();
     return false;
   }
-  return true;
+  return s.result_ok;
 }
 
 static int localnet_gather(void* self, int channel, const void* send_dev, size_t bytes, void* recv_dev, void* stream) {
@@ -76,6 +81,7 @@ static int localnet_gather(void* self, int channel, const void* send_dev, size_t
   {
     std::lock_guard<std::mutex> g(ln->mu);
     s.send[ref->id] = send_dev;
+    s.party_bytes[ref->id] = bytes;
     if (ref->id == 0) { s.king_recv = recv_dev; s.bytes = bytes; }
   }
   bool ok = rendezvous(ln, s, ref->id, [&] {
@@ -95,6 +101,7 @@ static int localnet_scatter(void* self, int channel, const void* send_dev, size_
   {
     std::lock_guard<std::mutex> g(ln->mu);
     s.send[ref->id] = recv_dev;   // reuse the pointer table for the receive buffers
+    s.party_bytes[ref->id] = bytes;
     if (ref->id == 0) { s.king_send = send_dev; s.bytes = bytes; }
   }
   bool ok = rendezvous(ln, s, ref->id, [&] {

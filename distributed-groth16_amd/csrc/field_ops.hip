@@ -45,21 +45,36 @@ template <class Fr>
 __global__ void __launch_bounds__(256) qap_kernel(const unsigned* __restrict__ a_ptr, const unsigned* __restrict__ a_col,
                                                    const Fr* __restrict__ a_val, const unsigned* __restrict__ b_ptr,
                                                    const unsigned* __restrict__ b_col, const Fr* __restrict__ b_val,
-                                                   const Fr* __restrict__ w, int w_mont, size_t nc, size_t ni, size_t m,
-                                                   Fr* __restrict__ a, Fr* __restrict__ b, Fr* __restrict__ c) {
+                                                   const Fr* __restrict__ w, int w_mont, size_t nc, size_t ni, size_t nv,
+                                                   size_t m, Fr* __restrict__ a, Fr* __restrict__ b, Fr* __restrict__ c,
+                                                   unsigned* __restrict__ err_flag) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= m) return;
   Fr av = Fr::zero(), bv = Fr::zero(), cv = Fr::zero();
   if (i < nc) {
-    for (unsigned j = a_ptr[i]; j < a_ptr[i + 1]; j++) {
-      Fr x = w[a_col[j]];
+    // indices from a key file are untrusted: an entry whose column is not a wire is skipped and reported
+    // through the context's sticky flag (dg16_sync -> DG16_ERR_BAD_ARG), never dereferenced
+    bool bad = false;
+    const unsigned a_lo = a_ptr[i], a_hi = a_ptr[i + 1], b_lo = b_ptr[i], b_hi = b_ptr[i + 1];
+    if (a_hi < a_lo || b_hi < b_lo || a_hi - a_lo > nv || b_hi - b_lo > nv) bad = true;
+    for (unsigned j = a_lo; !bad && j < a_hi; j++) {
+      const unsigned col = a_col[j];
+      if (col >= nv) { bad = true; break; }
+      Fr x = w[col];
       if (!w_mont) x = x.to_mont();
       av = av + a_val[j] * x;
     }
-    for (unsigned j = b_ptr[i]; j < b_ptr[i + 1]; j++) {
-      Fr x = w[b_col[j]];
+    for (unsigned j = b_lo; !bad && j < b_hi; j++) {
+      const unsigned col = b_col[j];
+      if (col >= nv) { bad = true; break; }
+      Fr x = w[col];
       if (!w_mont) x = x.to_mont();
       bv = bv + b_val[j] * x;
+    }
+    if (bad) {
+      *(volatile unsigned*)err_flag = 1u;   // plain store: the word lives in pinned host memory
+      av = Fr::zero();
+      bv = Fr::zero();
     }
     cv = av * bv;
   } else if (i < nc + ni) {
@@ -73,11 +88,12 @@ __global__ void __launch_bounds__(256) qap_kernel(const unsigned* __restrict__ a
 
 void qap_launch(Call& k, int curve, const unsigned* a_ptr, const unsigned* a_col, const void* a_val,
                 const unsigned* b_ptr, const unsigned* b_col, const void* b_val, const void* w, bool w_mont, size_t nc,
-                size_t ni, size_t m, void* a, void* b, void* c) {
+                size_t ni, size_t nv, size_t m, void* a, void* b, void* c) {
   unsigned blocks = (unsigned)((m + 255) / 256);
 #define QAP(F)                                                                                              \
   hipLaunchKernelGGL(qap_kernel<F>, dim3(blocks), dim3(256), 0, k.s(), a_ptr, a_col, (const F*)a_val, b_ptr, \
-                     b_col, (const F*)b_val, (const F*)w, (int)w_mont, nc, ni, m, (F*)a, (F*)b, (F*)c)
+                     b_col, (const F*)b_val, (const F*)w, (int)w_mont, nc, ni, nv, m, (F*)a, (F*)b, (F*)c,          \
+                     k.ctx->dev_flag)
   switch (curve) {
     case 0: QAP(bn254_fr); break;
     case 1: QAP(bls12_381_fr); break;

@@ -7,6 +7,8 @@
 #include <string.h>
 
 #include <map>
+#include <memory>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -87,9 +89,27 @@ extern "C" {
 
 const char* dg16_io_error(void) { return g_io_error.c_str(); }
 
-int dg16_r1cs_parse(const void* data, size_t bytes, dg16_r1cs** out) {
-  if (!data || !out) return fail(DG16_ERR_BAD_ARG, "null argument");
-  *out = nullptr;
+}  // extern "C"
+
+// Nothing may unwind through the C ABI: allocation failures of the containers below (sizes come from file
+// fields) are mapped to DG16_ERR_OOM / DG16_ERR_BAD_ARG, and the handle is owned by a unique_ptr until success.
+template <class Fn>
+static int no_throw(Fn&& fn) {
+  try {
+    return fn();
+  } catch (const std::bad_alloc&) {
+    return fail(DG16_ERR_OOM, "out of memory while parsing");
+  } catch (const std::length_error&) {
+    return fail(DG16_ERR_BAD_ARG, "section size exceeds what can be allocated");
+  } catch (const std::exception& e) {
+    g_io_error = e.what();
+    return DG16_ERR_BAD_ARG;
+  } catch (...) {
+    return fail(DG16_ERR_BAD_ARG, "unexpected failure while parsing");
+  }
+}
+
+static int r1cs_parse_impl(const void* data, size_t bytes, dg16_r1cs** out) {
   Reader r{(const uint8_t*)data, bytes};
   if (bytes < 4 || memcmp(r.p, "r1cs", 4) != 0) return fail(DG16_ERR_BAD_ARG, "Invalid magic number");
   std::map<uint32_t, Section> sec;
@@ -104,7 +124,7 @@ int dg16_r1cs_parse(const void* data, size_t bytes, dg16_r1cs** out) {
   if (field_size != 32) return fail(DG16_ERR_UNSUPPORTED, "This parser only supports 32-byte fields");
   if (hs->second.size != 32 + field_size) return fail(DG16_ERR_BAD_ARG, "Invalid header section size");
   if (memcmp(r.p + ho + 4, kBn254R, 32) != 0) return fail(DG16_ERR_UNSUPPORTED, "This parser only supports bn256");
-  dg16_r1cs* f = new dg16_r1cs();
+  std::unique_ptr<dg16_r1cs> f(new dg16_r1cs());
   f->h.n_wires = r.u32(ho + 36);
   f->h.n_pub_out = r.u32(ho + 40);
   f->h.n_pub_in = r.u32(ho + 44);
@@ -112,18 +132,21 @@ int dg16_r1cs_parse(const void* data, size_t bytes, dg16_r1cs** out) {
   f->h.n_labels = r.u64(ho + 52);
   f->h.n_constraints = r.u32(ho + 60);
   auto cs = sec.find(2);
-  if (cs == sec.end()) { delete f; return fail(DG16_ERR_BAD_ARG, "No section offset for constraint type found"); }
+  if (cs == sec.end()) return fail(DG16_ERR_BAD_ARG, "No section offset for constraint type found");
   size_t p = cs->second.off;
   const size_t end = cs->second.off + cs->second.size;
   for (int k = 0; k < 3; k++) f->m[k].row_ptr.assign(1, 0);
   for (uint32_t c = 0; c < f->h.n_constraints; c++)
     for (int k = 0; k < 3; k++) {
-      if (p + 4 > end) { delete f; return fail(DG16_ERR_BAD_ARG, "truncated constraint section"); }
+      if (p + 4 > end) return fail(DG16_ERR_BAD_ARG, "truncated constraint section");
       const uint32_t n_vec = r.u32(p);
       p += 4;
-      if ((size_t)n_vec * 36 > end - p) { delete f; return fail(DG16_ERR_BAD_ARG, "truncated constraint section"); }
+      if ((size_t)n_vec * 36 > end - p) return fail(DG16_ERR_BAD_ARG, "truncated constraint section");
       Csr& m = f->m[k];
       for (uint32_t j = 0; j < n_vec; j++) {
+        // a wire id indexes the assignment downstream (dg16_qap): the reference's Rust indexing would panic on
+        // an id >= n_wires, here the file is rejected
+        if (r.u32(p) >= f->h.n_wires) return fail(DG16_ERR_BAD_ARG, "coefficient out of range (wire >= n_wires)");
         m.col.push_back(r.u32(p));
         m.coeff.insert(m.coeff.end(), r.p + p + 4, r.p + p + 36);
         p += 36;
@@ -132,14 +155,22 @@ int dg16_r1cs_parse(const void* data, size_t bytes, dg16_r1cs** out) {
     }
   auto ms = sec.find(3);
   if (ms != sec.end()) {
-    if (ms->second.size != (size_t)f->h.n_wires * 8) { delete f; return fail(DG16_ERR_BAD_ARG, "Invalid map section size"); }
+    if (ms->second.size != (size_t)f->h.n_wires * 8) return fail(DG16_ERR_BAD_ARG, "Invalid map section size");
     f->wire_map.resize(f->h.n_wires);
     if (f->h.n_wires) memcpy(f->wire_map.data(), r.p + ms->second.off, (size_t)f->h.n_wires * 8);
-    if (f->h.n_wires && f->wire_map[0] != 0) { delete f; return fail(DG16_ERR_BAD_ARG, "Wire 0 should always be mapped to 0"); }
+    if (f->h.n_wires && f->wire_map[0] != 0) return fail(DG16_ERR_BAD_ARG, "Wire 0 should always be mapped to 0");
     f->h.has_wire_map = 1;
   }
-  *out = f;
+  *out = f.release();
   return DG16_OK;
+}
+
+extern "C" {
+
+int dg16_r1cs_parse(const void* data, size_t bytes, dg16_r1cs** out) {
+  if (!data || !out) return fail(DG16_ERR_BAD_ARG, "null argument");
+  *out = nullptr;
+  return no_throw([&] { return r1cs_parse_impl(data, bytes, out); });
 }
 
 int dg16_r1cs_header_get(const dg16_r1cs* f, dg16_r1cs_header* out) {
@@ -162,9 +193,9 @@ int dg16_r1cs_wire_map(const dg16_r1cs* f, const uint64_t** map) {
 
 void dg16_r1cs_free(dg16_r1cs* f) { delete f; }
 
-int dg16_zkey_parse(const void* data, size_t bytes, dg16_zkey** out) {
-  if (!data || !out) return fail(DG16_ERR_BAD_ARG, "null argument");
-  *out = nullptr;
+}  // extern "C"
+
+static int zkey_parse_impl(const void* data, size_t bytes, dg16_zkey** out) {
   Reader r{(const uint8_t*)data, bytes};
   if (bytes < 4 || memcmp(r.p, "zkey", 4) != 0) return fail(DG16_ERR_BAD_ARG, "Invalid magic number");
   std::map<uint32_t, Section> sec;
@@ -185,16 +216,14 @@ int dg16_zkey_parse(const void* data, size_t bytes, dg16_zkey** out) {
   p += 36;
   if (r.u32(p) != 32 || memcmp(r.p + p + 4, kBn254R, 32) != 0) return fail(DG16_ERR_UNSUPPORTED, "scalar field is not BN254's");
   p += 36;
-  dg16_zkey* z = new dg16_zkey();
+  std::unique_ptr<dg16_zkey> z(new dg16_zkey());
   z->h.n_vars = r.u32(p);
   z->h.n_public = r.u32(p + 4);
   z->h.domain_size = r.u32(p + 8);
   p += 12;
-  if (z->h.domain_size == 0 || (z->h.domain_size & (z->h.domain_size - 1))) {
-    delete z;
+  if (z->h.domain_size == 0 || (z->h.domain_size & (z->h.domain_size - 1)))
     return fail(DG16_ERR_BAD_ARG, "domain size is not a power of two");
-  }
-  if (z->h.n_vars < z->h.n_public + 1) { delete z; return fail(DG16_ERR_BAD_ARG, "n_vars < n_public + 1"); }
+  if (z->h.n_vars < z->h.n_public + 1) return fail(DG16_ERR_BAD_ARG, "n_vars < n_public + 1");
   // alpha_g1, beta_g1, beta_g2, gamma_g2, delta_g1, delta_g2 (zkey.rs:259-276)
   const size_t fixed_bytes[6] = {64, 64, 128, 128, 64, 128};
   for (int i = 0; i < 6; i++) {
@@ -210,7 +239,6 @@ int dg16_zkey_parse(const void* data, size_t bytes, dg16_zkey** out) {
   for (const auto& q : qs) {
     const Section s = sec[q.id];
     if (s.size < q.count * q.bytes) {
-      delete z;
       g_io_error = "section " + std::to_string(q.id) + " too short";
       return DG16_ERR_BAD_ARG;
     }
@@ -219,14 +247,16 @@ int dg16_zkey_parse(const void* data, size_t bytes, dg16_zkey** out) {
   }
   // ---- section 4: coefficients (zkey.rs:149-198) ----
   const Section cs = sec[4];
-  if (cs.size < 4) { delete z; return fail(DG16_ERR_BAD_ARG, "coefficient section too short"); }
+  if (cs.size < 4) return fail(DG16_ERR_BAD_ARG, "coefficient section too short");
   const uint32_t n_coeffs = r.u32(cs.off);
-  if (cs.size < 4 + (size_t)n_coeffs * 44) { delete z; return fail(DG16_ERR_BAD_ARG, "coefficient section too short"); }
+  if (cs.size < 4 + (size_t)n_coeffs * 44) return fail(DG16_ERR_BAD_ARG, "coefficient section too short");
   uint32_t max_row = 0;
   for (uint32_t i = 0; i < n_coeffs; i++) {
     const size_t o = cs.off + 4 + (size_t)i * 44;
     const uint32_t matrix = r.u32(o), row = r.u32(o + 4);
-    if (matrix > 1 || row >= z->h.domain_size) { delete z; return fail(DG16_ERR_BAD_ARG, "coefficient out of range"); }
+    // `signal` indexes the assignment downstream (dg16_qap): reject what the reference's indexing would panic on
+    if (matrix > 1 || row >= z->h.domain_size || r.u32(o + 8) >= z->h.n_vars)
+      return fail(DG16_ERR_BAD_ARG, "coefficient out of range");
     if (row > max_row) max_row = row;
   }
   // the rows above num_constraints (the public-input rows snarkjs appends) are dropped (zkey.rs:176-180)
@@ -254,8 +284,16 @@ int dg16_zkey_parse(const void* data, size_t bytes, dg16_zkey** out) {
     z->m[k].col[at] = r.u32(o + 8);
     memcpy(z->m[k].coeff.data() + (size_t)at * 32, r.p + o + 12, 32);
   }
-  *out = z;
+  *out = z.release();
   return DG16_OK;
+}
+
+extern "C" {
+
+int dg16_zkey_parse(const void* data, size_t bytes, dg16_zkey** out) {
+  if (!data || !out) return fail(DG16_ERR_BAD_ARG, "null argument");
+  *out = nullptr;
+  return no_throw([&] { return zkey_parse_impl(data, bytes, out); });
 }
 
 int dg16_zkey_header_get(const dg16_zkey* z, dg16_zkey_header* out) {

@@ -22,6 +22,7 @@ struct PkDev {
   // B: [0, delta_g2]) so the three MSMs share ONE scalar vector w[1..] ++ [r, s] and one digit sort;
   // l_q = slice ++ [delta_g1] (scalar -r*s).
   unsigned c_ab = 0, c_l = 0, c_h = 0;   // window bits the tables were built for
+  size_t table_bytes = 0;                // HBM held by the five tables
 };
 
 }  // namespace dg16

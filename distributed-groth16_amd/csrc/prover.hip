@@ -1,4 +1,7 @@
 // C ABI of the Groth16 prover (include/dg16.h); the per-curve instantiations live in prover_<curve>.hip.
+#include <stdio.h>
+#include <string.h>
+
 #include "pk.h"
 
 namespace dg16 {
@@ -58,6 +61,28 @@ int dg16_pk_create_shard(dg16_ctx* ctx, int curve, size_t num_vars, size_t num_i
     return rc;
   }
   *out = pk;
+  return DG16_OK;
+}
+
+int dg16_pk_info_get(const dg16_pk* pk, dg16_pk_info* out) {
+  if (!pk || !out) return DG16_ERR_BAD_ARG;
+  memset(out, 0, sizeof(*out));
+  const PkDev& d = pk->d;
+  out->n_ab = d.ab_hi - d.ab_lo + 2;
+  out->n_l = d.l_hi - d.l_lo + 1;
+  out->n_h = d.h_hi - d.h_lo;
+  out->c_ab = d.c_ab;
+  out->c_l = d.c_l;
+  out->c_h = d.c_h;
+  out->shard = d.shard;
+  out->n_shards = d.nshards;
+  out->table_bytes = d.table_bytes;
+  // the shipped base-field product: 8 (BN254) / 12 x 32-bit limbs, product scanning, one v_mad_u64_u32 per
+  // partial product (csrc/fp.h); measured chip rate: tools/ubench/montmul_rate (profiles/)
+  out->fq_mul_mads = d.curve == DG16_BN254 ? 128 : 288;
+  out->fq_mul_rate_g = d.curve == DG16_BN254 ? 114.0f : 50.0f;
+  snprintf(out->g2_kernel, sizeof(out->g2_kernel), "msm_accumulate_lds_kernel<Fp2<%s_fq>>",
+           d.curve == DG16_BN254 ? "bn254" : "bls12_381");
   return DG16_OK;
 }
 

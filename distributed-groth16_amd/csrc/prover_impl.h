@@ -171,9 +171,17 @@ static void msms_typed(dg16_ctx* ctx, Call& k0, Call& k1, Call& k2, const PkDev&
   MsmBuffers<Fq2> buf_b2 = msm_buffers<Fq2>(k2.c, st_ab.g);
   // B (G2) first: its bucket reduction is the longest latency chain of a proof (on a short multi-GPU shard it
   // outlasts everything else), so it gets the whole rest of the pipeline to hide behind
+  // (timing events of channels 2 / 1 bracket the G2 / first G1 accumulation ON THE STREAM THEY RUN ON, so that
+  // dg16_last_kernel_ms(ctx, 2 or 1, 1) reports the dominant kernels of the proof that was just made)
+  DG_HIP(hipEventRecord(k2.c.ev[2], main));
   msm_accumulate_phase<Fq2>(main, st_ab, buf_b2, pk.b2_q);
+  DG_HIP(hipEventRecord(k2.c.ev[3], main));
+  k2.c.ev_valid[1] = true;
   DG_HIP(hipEventRecord(ev[2], main));
+  DG_HIP(hipEventRecord(k1.c.ev[2], main));
   msm_accumulate_phase<Fq>(main, st_ab, buf_a, pk.a_q);
+  DG_HIP(hipEventRecord(k1.c.ev[3], main));
+  k1.c.ev_valid[1] = true;
   DG_HIP(hipEventRecord(ev[0], main));
   msm_accumulate_phase<Fq>(main, st_ab, buf_b1, pk.b1_q);
   DG_HIP(hipEventRecord(ev[1], main));
@@ -291,7 +299,16 @@ static void pk_build(dg16_ctx* ctx, PkDev& d, const void* a_query, const void* b
   const size_t n_ab = d.ab_hi - d.ab_lo, n_l = d.l_hi - d.l_lo, n_h = d.h_hi - d.h_lo;
   DG_HIP(hipSetDevice(ctx->device));
   // plain arrays first (slice ++ delta slots), then the window tables that replace them
-  void *a_plain, *b1_plain, *b2_plain, *l_plain, *h_plain;
+  // the plain arrays only live until the tables are built: freed on every path, including a DG_HIP throw mid-build
+  // (pk_free releases d.* -- the tables built so far and d.fixed -- when the caller sees the error)
+  void *a_plain = nullptr, *b1_plain = nullptr, *b2_plain = nullptr, *l_plain = nullptr, *h_plain = nullptr;
+  struct PlainGuard {
+    void **p[5];
+    ~PlainGuard() {
+      for (void** q : p)
+        if (*q) { hipFree(*q); *q = nullptr; }
+    }
+  } plain_guard{{&a_plain, &b1_plain, &b2_plain, &l_plain, &h_plain}};
   DG_HIP(hipMalloc(&a_plain, (n_ab + 2) * p1));
   DG_HIP(hipMalloc(&b1_plain, (n_ab + 2) * p1));
   DG_HIP(hipMalloc(&b2_plain, (n_ab + 2) * p2));
@@ -327,8 +344,9 @@ static void pk_build(dg16_ctx* ctx, PkDev& d, const void* a_query, const void* b
     d.b2_q = msm_build_table<Fq2>(nullptr, b2_plain, n_ab + 2, d.c_ab, nwin_of(d.c_ab));
     d.l_q = msm_build_table<Fq>(nullptr, l_plain, n_l + 1, d.c_l, nwin_of(d.c_l));
     d.h_q = msm_build_table<Fq>(nullptr, h_plain, n_h, d.c_h, nwin_of(d.c_h));
+    d.table_bytes = (size_t)nwin_of(d.c_ab) * (n_ab + 2) * (2 * p1 + p2) + (size_t)nwin_of(d.c_l) * (n_l + 1) * p1 +
+                    (size_t)nwin_of(d.c_h) * (n_h ? n_h : 1) * p1;
     DG_HIP(hipDeviceSynchronize());
-    for (void* p : {a_plain, b1_plain, b2_plain, l_plain, h_plain}) DG_HIP(hipFree(p));
   }
   DG_HIP(hipMemcpy(fixed, fx, p1, kind));                     // alpha_g1
   DG_HIP(hipMemcpy(fixed + p1, aq, p1, kind));                // a_query[0]

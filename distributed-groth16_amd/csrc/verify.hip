@@ -166,6 +166,23 @@ bool on_curve(const Affine<Fq2>& p) {
 }
 Affine<Fq> neg(const Affine<Fq>& p) { return p.is_inf() ? p : Affine<Fq>{p.x, p.y.neg()}; }
 
+// limb vector < modulus (arkworks rejects non-canonical field elements at deserialisation; without this check
+// x, x + r, x + 2r -- all below 2^256 -- would be the same public input: input aliasing)
+template <class P>
+bool canonical(const Fp<P>& v) {
+  for (int i = P::NL - 1; i >= 0; i--)
+    if (v.l[i] != P::P[i]) return v.l[i] < P::P[i];
+  return false;
+}
+bool canonical(const Fq2& v) { return canonical(v.c0) && canonical(v.c1); }
+template <class F>
+bool canonical(const Affine<F>& p) { return canonical(p.x) && canonical(p.y); }
+// r * Q == identity (G2 has cofactor > 1: on-curve is not enough; G1 of BN254 has cofactor 1)
+bool in_subgroup(const Affine<Fq2>& q) {
+  if (q.is_inf()) return true;
+  return scalar_mul<Fq2, Fr::NL>(XYZZ<Fq2>::from_affine(q), bn254_fr_params::P).is_inf();
+}
+
 thread_local const char* g_err = "";
 
 }  // namespace
@@ -197,10 +214,39 @@ int dg16_groth16_verify(int curve, const void* alpha_g1, const void* beta_g2, co
   memcpy(&a, pr, sizeof(a));
   memcpy(&b, pr + sizeof(a), sizeof(b));
   memcpy(&c, pr + sizeof(a) + sizeof(b), sizeof(c));
-  if (!on_curve(a) || !on_curve(c) || !on_curve(b)) { g_err = ""; return DG16_OK; }   // rejected
-  // prepared inputs: IC_0 + sum_i x_i IC_{i+1}
-  std::vector<Affine<Fq>> icv(n_ic);
+  // verification key: every coordinate reduced, every point on its curve, G2 points in the order-r subgroup
+  // (what `VerifyingKey::deserialize_compressed` with Validate::Yes guarantees on the reference's side)
+  std::vector<Affine<Fq>> icv;
+  try {
+    icv.resize(n_ic);
+  } catch (...) {
+    g_err = "out of memory";
+    return DG16_ERR_OOM;
+  }
   memcpy(icv.data(), ic, n_ic * sizeof(Affine<Fq>));
+  bool vk_ok = canonical(alpha) && on_curve(alpha) && canonical(beta) && on_curve(beta) && in_subgroup(beta) &&
+               canonical(gamma) && on_curve(gamma) && in_subgroup(gamma) && canonical(delta) && on_curve(delta) &&
+               in_subgroup(delta);
+  for (size_t i = 0; vk_ok && i < n_ic; i++) vk_ok = canonical(icv[i]) && on_curve(icv[i]);
+  if (!vk_ok) {
+    g_err = "malformed verifying key (non-reduced coordinate, point off its curve or outside the subgroup)";
+    return DG16_ERR_BAD_ARG;
+  }
+  for (size_t i = 0; i < n_public; i++) {
+    Fr x;
+    memcpy(&x, (const uint8_t*)public_inputs + i * sizeof(Fr), sizeof(Fr));
+    if (!canonical(x)) {
+      g_err = "public input is not a reduced field element (>= r)";
+      return DG16_ERR_BAD_ARG;
+    }
+  }
+  // proof: a non-reduced coordinate, a point off its curve or B outside the subgroup is a rejection
+  if (!canonical(a) || !canonical(b) || !canonical(c) || !on_curve(a) || !on_curve(c) || !on_curve(b) ||
+      !in_subgroup(b)) {
+    g_err = "";
+    return DG16_OK;
+  }
+  // prepared inputs: IC_0 + sum_i x_i IC_{i+1}
   XYZZ<Fq> acc = XYZZ<Fq>::from_affine(icv[0]);
   for (size_t i = 0; i < n_public; i++) {
     Fr x;

@@ -38,6 +38,13 @@ class ZkeyHeader(ctypes.Structure):       # dg16_zkey_header
     _fields_ = [(n, ctypes.c_uint32) for n in ("n_vars", "n_public", "domain_size", "num_constraints")]
 
 
+class PkInfo(ctypes.Structure):           # dg16_pk_info
+    _fields_ = [("n_ab", ctypes.c_uint64), ("n_l", ctypes.c_uint64), ("n_h", ctypes.c_uint64),
+                ("c_ab", ctypes.c_uint32), ("c_l", ctypes.c_uint32), ("c_h", ctypes.c_uint32),
+                ("shard", ctypes.c_uint32), ("n_shards", ctypes.c_uint32), ("table_bytes", ctypes.c_uint64),
+                ("fq_mul_mads", ctypes.c_uint32), ("fq_mul_rate_g", ctypes.c_float), ("g2_kernel", ctypes.c_char * 96)]
+
+
 class Csr(ctypes.Structure):              # dg16_csr
     _fields_ = [("n_rows", ctypes.c_uint64), ("nnz", ctypes.c_uint64), ("row_ptr", ctypes.POINTER(ctypes.c_uint32)),
                 ("col", ctypes.POINTER(ctypes.c_uint32)), ("coeff", ctypes.c_void_p)]
@@ -99,6 +106,7 @@ def load():
     L.dg16_pk_create.argtypes = [vp, i, sz, sz, sz, vp, vp, vp, vp, vp, vp, u, ctypes.POINTER(vp)]
     L.dg16_pk_destroy.argtypes = [vp]
     L.dg16_pk_destroy.restype = None
+    L.dg16_pk_info_get.argtypes = [vp, ctypes.POINTER(PkInfo)]
     L.dg16_groth16_prove.argtypes = [vp, vp, vp, vp, vp, vp, vp, u, vp]
     L.dg16_pk_create_shard.argtypes = [vp, i, sz, sz, sz, vp, vp, vp, vp, vp, vp, u, u, u, ctypes.POINTER(vp)]
     L.dg16_groth16_results_bytes.argtypes = [i]
@@ -152,7 +160,7 @@ def load():
 
 
 EXPORTED = ["dg16_ctx_create", "dg16_ctx_destroy", "dg16_last_error", "dg16_set_stream", "dg16_sync",
-            "dg16_device_info", "dg16_field_op", "dg16_ntt", "dg16_h_poly", "dg16_msm",
+            "dg16_device_info", "dg16_field_op", "dg16_ntt", "dg16_h_poly", "dg16_msm", "dg16_pk_info_get",
             "dg16_gen_bases", "dg16_to_affine", "dg16_last_kernel_ms", "dg16_pk_create", "dg16_pk_destroy",
             "dg16_groth16_prove", "dg16_pk_create_shard", "dg16_groth16_results_bytes", "dg16_groth16_msms",
             "dg16_groth16_assemble", "dg16_localnet_create", "dg16_localnet_party", "dg16_localnet_destroy", "dg16_localnet_abort",
@@ -180,6 +188,14 @@ class ProvingKey:
     def __init__(self, ctx, handle, curve, num_vars, num_inputs, domain_size):
         self.ctx, self.h, self.curve = ctx, handle, curve
         self.num_vars, self.num_inputs, self.domain_size = num_vars, num_inputs, domain_size
+
+    def info(self):
+        """dg16_pk_info as a dict (window bits, points per launch, table bytes, the multiply the kernels use)."""
+        i = PkInfo()
+        self.ctx._chk(self.ctx.L.dg16_pk_info_get(self.h, ctypes.byref(i)))
+        d = {n: getattr(i, n) for n, _ in PkInfo._fields_}
+        d["g2_kernel"] = i.g2_kernel.decode()
+        return d
 
     def close(self):
         if self.h and self.ctx.h:
@@ -310,6 +326,14 @@ class Context:
                                   _ptr(ac), _ptr(av), _ptr(bp), _ptr(bc), _ptr(bv), _ptr(w), _ptr(out[0]),
                                   _ptr(out[1]), _ptr(out[2]), F_SCALARS_MONT if scalars_mont else 0, channel))
         return out
+
+    def qap_dev(self, curve, num_constraints, num_inputs, num_vars, log_m, a_ptr_p, a_col_p, a_val_p, b_ptr_p,
+                b_col_p, b_val_p, w_p, a_out, b_out, c_out, scalars_mont=True, channel=0):
+        """Device pointers throughout; stream-ordered on the channel (index errors surface at the next sync)."""
+        self._chk(self.L.dg16_qap(self.h, CURVES[curve], num_constraints, num_inputs, num_vars, log_m, _ptr(a_ptr_p),
+                                  _ptr(a_col_p), _ptr(a_val_p), _ptr(b_ptr_p), _ptr(b_col_p), _ptr(b_val_p),
+                                  _ptr(w_p), _ptr(a_out), _ptr(b_out), _ptr(c_out),
+                                  F_DEVICE_PTRS | (F_SCALARS_MONT if scalars_mont else 0), channel))
 
     # ---- Groth16 prover ---------------------------------------------------------------------------------
     def pk_create(self, curve, num_vars, num_inputs, domain_size, a_query, b_g1_query, b_g2_query, h_query,

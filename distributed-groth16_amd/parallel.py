@@ -67,6 +67,12 @@ class DistributedProver:
     def __init__(self, engine, dist=None, rank=0, world=1):
         self.engine, self.dist, self.rank, self.world = engine, dist, rank, world
 
+    def describe(self):
+        return "msm-shard x%d + all-gather (torch.distributed)" % self.world
+
+    def close(self):
+        pass
+
     def prove(self, a, b, c, w, rs_host, scalars_mont=True):
         part = self.engine.partial(a, b, c, w, rs_host, scalars_mont)
         if self.world == 1:
@@ -80,3 +86,8 @@ class DistributedProver:
             if hasattr(self.engine, "after_collective"):
                 self.engine.after_collective()
         return self.engine.assemble(gathered, self.world, rs_host, scalars_mont)
+
+
+def make_prover(ctx, pk, curve, dist, rank, world):
+    """The prover bench.py and the tools drive: N = 1 is the plain resident-key prover behind the same interface."""
+    return DistributedProver(GpuEngine(ctx, pk, curve), dist, rank, world)

@@ -148,6 +148,22 @@ int dg16_pk_create(dg16_ctx *ctx, int curve, size_t num_vars, size_t num_inputs,
                    dg16_pk **out);
 void dg16_pk_destroy(dg16_pk *pk);
 
+/* What a resident key holds (for reports: bench.py prints it next to every timing, because the proof time depends
+ * on the window tables built here, once per key).  n_*: points per MSM launch of this shard (slice + delta slots);
+ * c_*: window bits of the tables; table_bytes: HBM held by the five tables; fq_mul_mads / fq_mul_rate_g: the
+ * v_mad_u64_u32 count of one base-field product in the bucket kernels and its measured chip-wide rate in G
+ * products/s (tools/ubench), i.e. the VALU roof those kernels are priced against. */
+typedef struct dg16_pk_info {
+  uint64_t n_ab, n_l, n_h;
+  uint32_t c_ab, c_l, c_h;
+  uint32_t shard, n_shards;
+  uint64_t table_bytes;
+  uint32_t fq_mul_mads;
+  float fq_mul_rate_g;
+  char g2_kernel[96];
+} dg16_pk_info;
+int dg16_pk_info_get(const dg16_pk *pk, dg16_pk_info *out);
+
 /* Multi-GPU form: the key holds slice `shard` of `n_shards` of every MSM range (contiguous slices of
  * a_query[1..], b_g1_query[1..], b_g2_query[1..], l_query, h_query); the delta pairs ride on the last
  * shard.  Pass the FULL queries; only the slice is copied to the device. */
@@ -311,7 +327,11 @@ int dg16_proof_decompress(int curve, const void *in128, int validate, void *proo
  * with the identity as zeros -- the layout of a zkey's header / IC section (dg16_zkey_points) and of
  * dg16_proof_decompress.  public_inputs: n_public scalars of 32 bytes, canonical or (DG16_F_SCALARS_MONT)
  * Montgomery.  n_ic != n_public + 1 returns DG16_ERR_LENGTH_MISMATCH (ark-groth16's MalformedVerifyingKey).
- * *accepted = 1 iff the equation holds (a proof point off its curve is a rejection, not an error). */
+ * Validation (what arkworks' Validate::Yes deserialisation guarantees before verify_proof runs): a verifying-key
+ * point with a non-reduced coordinate, off its curve or (G2) outside the order-r subgroup, or a public input >= r,
+ * returns DG16_ERR_BAD_ARG (no input aliasing: x and x + r are not the same input); a PROOF point with a
+ * non-reduced coordinate, off its curve, or B outside the subgroup is a rejection (*accepted = 0), not an error.
+ * *accepted = 1 iff all checks pass and the equation holds. */
 const char *dg16_verify_error(void);
 int dg16_groth16_verify(int curve, const void *alpha_g1, const void *beta_g2, const void *gamma_g2,
                         const void *delta_g2, const void *ic, size_t n_ic, const void *public_inputs,

@@ -368,6 +368,37 @@ int orc_h_poly(int curve, void *a, void *b, void *c, unsigned log_m, void *out, 
     return ORC_OK;
 }
 
+/* qap::qap (/root/reference/groth16/src/qap.rs:44-91; the same loops open
+ * /root/reference/ark-circom/src/circom/qap.rs:34-62): a[i] = <A_i, w>, b[i] = <B_i, w> over CSR rows
+ * (Montgomery coefficients, Montgomery assignment), a[nc + j] = w[j] for the instance variables,
+ * c = a o b on the constraint rows, zero padding up to m.  rayon-parallel in the reference: OpenMP here. */
+int orc_qap(int curve, size_t nc, size_t ni, size_t m, const uint32_t *a_ptr, const uint32_t *a_col,
+            const void *a_val, const uint32_t *b_ptr, const uint32_t *b_col, const void *b_val, const void *w,
+            void *a, void *b, void *c, int threads) {
+    if (threads <= 0) threads = omp_get_max_threads();
+    if (nc + ni > m) return ORC_BAD_ARG;
+#define DO_QAP(P)                                                                     \
+    const P##t *av = (const P##t *)a_val, *bv = (const P##t *)b_val, *wv = (const P##t *)w; \
+    P##t *ao = (P##t *)a, *bo = (P##t *)b, *co = (P##t *)c;                            \
+    _Pragma("omp parallel for schedule(static) num_threads(threads)")                 \
+    for (size_t i = 0; i < m; i++) {                                                  \
+        P##t x, y, t;                                                                 \
+        P##set_zero(&x); P##set_zero(&y);                                             \
+        if (i < nc) {                                                                 \
+            for (uint32_t j = a_ptr[i]; j < a_ptr[i + 1]; j++) { P##mul(&t, &av[j], &wv[a_col[j]]); P##add(&x, &x, &t); } \
+            for (uint32_t j = b_ptr[i]; j < b_ptr[i + 1]; j++) { P##mul(&t, &bv[j], &wv[b_col[j]]); P##add(&y, &y, &t); } \
+            P##mul(&co[i], &x, &y);                                                   \
+        } else {                                                                      \
+            if (i < nc + ni) x = wv[i - nc];                                          \
+            P##set_zero(&co[i]);                                                      \
+        }                                                                             \
+        ao[i] = x; bo[i] = y;                                                         \
+    }                                                                                 \
+    return ORC_OK;
+    FR_DISPATCH(curve, DO_QAP)
+    return ORC_OK;
+}
+
 /* root of unity of order 2^log_n (Montgomery) -- FftField::get_root_of_unity */
 int orc_root_of_unity(int curve, unsigned log_n, void *out) {
 #define DO_ROOT(P) return P##root_of_unity((P##t *)out, log_n);

@@ -51,6 +51,7 @@ def lib():
         L.orc_ntt.argtypes = [i, vp, ctypes.c_uint, i, vp, i]
         L.orc_h_poly.argtypes = [i, vp, vp, vp, ctypes.c_uint, vp, i]
         L.orc_root_of_unity.argtypes = [i, ctypes.c_uint, vp]
+        L.orc_qap.argtypes = [i, sz, sz, sz, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i]
         L.orc_affine_bytes.restype = sz
         L.orc_affine_bytes.argtypes = [i, i]
         _lib = L
@@ -179,6 +180,17 @@ def h_poly(curve, a, b, c, threads=0):
     log_m = m.bit_length() - 1
     out = np.empty_like(a)
     _chk(lib().orc_h_poly(CURVES[curve], _p(a), _p(b), _p(c), log_m, _p(out), threads))
+    return out
+
+
+def qap(curve, nc, ni, m, csr_a, csr_b, w, threads=0):
+    """qap::qap on CSR matrices (row_ptr uint32, col uint32, coeff Montgomery) and a Montgomery assignment."""
+    ap, ac, av = (np.ascontiguousarray(x) for x in csr_a)
+    bp, bc, bv = (np.ascontiguousarray(x) for x in csr_b)
+    w = np.ascontiguousarray(w, dtype=np.uint64)
+    out = [np.zeros((m, 4), dtype=np.uint64) for _ in range(3)]
+    _chk(lib().orc_qap(CURVES[curve], nc, ni, m, _p(ap), _p(ac), _p(av), _p(bp), _p(bc), _p(bv), _p(w),
+                       _p(out[0]), _p(out[1]), _p(out[2]), threads))
     return out
 
 

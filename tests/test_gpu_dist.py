@@ -224,3 +224,118 @@ def test_mpc_prove_equals_single_prover():
     C = g1.add(dec_g1(Fq, corc.jac_to_affine(curve, 1, wv)), dec_g1(Fq, corc.jac_to_affine(curve, 1, uv)))
     assert (A, B, C) == G.create_proof(curve, pk, 0, 0, r1cs, w)
     assert all(np.array_equal(r[0], res[0][0]) for r in res)      # same point on every party
+
+
+# ---- the reference's own sizes (dist-primitives/examples/*.rs run m = 2^15, 8 parties, l = 2) ---------------------
+@pytest.mark.parametrize("curve,log_M", [("bls12_377", 15), ("bn254", 16)])
+def test_d_msm_reference_size(curve, log_M):
+    """dist-primitives/examples/dmsm_test.rs:62-77 (scripts/dmsm_test.zsh): BLS12-377 G1, 2^15 points, 8 parties,
+    l = 2 -> a 2^14-point local MSM per party, d_msm == clear MSM.  BASELINE config 1 names the same path on
+    BN254 with 2^16 points."""
+    F = FR[curve]
+    ctxs, pps, net, D = parties(curve)
+    M = 1 << log_M
+    pts_arr = ctxs[0].gen_bases(curve, 1, 3, M)
+    sc = corc.rand_field(curve, "fr", 17, M, mont=True)
+    clear = corc.msm(curve, 1, pts_arr, sc, scalars_mont=True)
+    packed_bases = pps[0].packexp_from_public(1, pts_arr.reshape(M // 2, 2, -1))    # [M/l][n][..]
+    packed_sc = pps[0].pack_from_public(sc.reshape(M // 2, 2, 4))                   # [M/l][n][4]
+    got = net.simulate_network_round(
+        lambda i, h: D.d_msm(ctxs[i], pps[i], h, 1, np.ascontiguousarray(packed_bases[:, i]),
+                             np.ascontiguousarray(packed_sc[:, i])))
+    assert all(np.array_equal(corc.jac_to_affine(curve, 1, g), clear) for g in got)
+
+
+@pytest.mark.parametrize("inverse", [False, True])
+def test_d_fft_reference_size(inverse):
+    """m = 2^15 (the sha256 path's domain; dfft_test.rs runs 2^10): every party's shares equal the line-by-line
+    restatement, and the unpacked result equals the C oracle's plain transform (dfft/mod.rs:373,458)."""
+    curve = "bls12_377"
+    F = FR[curve]
+    ctxs, pps, net, D = parties(curve)
+    ref = RefPSS(F, 2)
+    log_m = 15
+    m = 1 << log_m
+    dom = Domain(F, m)
+    rng = random.Random(15)
+    x = [rng.randrange(F.p) for _ in range(m)]
+    shares = R.share_for_dfft(x, ref)
+    exp = (R.d_ifft if inverse else R.d_fft)(shares, False, 1, False, dom, ref)
+    got = net.simulate_network_round(
+        lambda i, h: D.d_fft(ctxs[i], pps[i], h, enc(F, shares[i]), log_m, False, 1, False, inverse=inverse))
+    assert [dec(F, g) for g in got] == exp
+    per_elem = np.stack(got, axis=1)
+    vals = pps[0].unpack(per_elem).reshape(m, 4)
+    assert np.array_equal(vals, corc.ntt(curve, enc(F, x), inverse=inverse))
+
+
+def test_d_pp_reference_size():
+    # dist-primitives/examples/dpp_test.rs:54-67: m = 2^15 (its debug_assert is a no-op in release: here it is checked)
+    curve = "bls12_377"
+    F = FR[curve]
+    ctxs, pps, net, D = parties(curve)
+    ref = RefPSS(F, 2)
+    rng = random.Random(44)
+    m = 1 << 15
+    num = [rng.randrange(1, F.p) for _ in range(m)]
+    den = [rng.randrange(1, F.p) for _ in range(m)]
+    ns = R.transpose(R.pack_vec(num, ref))
+    ds = R.transpose(R.pack_vec(den, ref))
+    exp = R.d_pp(ns, ds, ref)
+    got = net.simulate_network_round(lambda i, h: D.d_pp(ctxs[i], pps[i], h, enc(F, ns[i]), enc(F, ds[i])))
+    assert [dec(F, g) for g in got] == exp
+
+
+def test_ext_wit_h_reference_size():
+    """groth16/src/ext_wit.rs:118-190 at the sha256 circuit's domain m = 2^15: every party's h shares equal the
+    restatement's, and the unpacked h equals the single prover's witness map (C oracle)."""
+    curve = "bn254"
+    F = FR[curve]
+    ctxs, pps, net, D = parties(curve)
+    ref = RefPSS(F, 2)
+    log_m = 15
+    m = 1 << log_m
+    a, b, c = (corc.rand_field(curve, "fr", 60 + i, m) for i in range(3))
+    ai, bi, ci = (dec(F, v) for v in (a, b, c))
+    dom = Domain(F, m)
+    qs = G.qap_pss(ai, bi, ci, ref)
+    exp_shares = G.ext_wit_h(qs, dom, ref)
+    got = net.simulate_network_round(
+        lambda i, h: D.ext_wit_h(ctxs[i], pps[i], h, enc(F, qs[i][0]), enc(F, qs[i][1]), enc(F, qs[i][2]), log_m))
+    assert [dec(F, g) for g in got] == exp_shares
+    vals = pps[0].unpack(np.stack(got, axis=1)).reshape(m, 4)
+    assert np.array_equal(vals, corc.h_poly(curve, a, b, c))
+
+
+def test_mpc_prove_reference_size():
+    """groth16/examples/sha256.rs:26-95 (`dsha256`) at the sha256 circuit's shape: 29 823 wires, m = 2^15, 8 parties,
+    r = s = 0.  The 8-party proof, completed like :208-212, equals the single prover's -- the C oracle's proof of the
+    same statement (and therefore dg16_groth16_prove's, tests/test_gpu_prover.py)."""
+    import torch
+    import bench
+    from dg16_amd import groth16_mpc as M
+    curve = "bn254"
+    ctxs, pps, net, D = parties(curve)
+    dev = torch.device("cuda", 0)
+    wl = bench.Workload(ctxs[0], dev, 15, 0, 1, seed=4, curve=curve, nv=29823, nc=29400, ni=2)
+    host = lambda t, cols: bench.to_host_u64(t, cols)   # noqa: E731
+    hpk = {"a_query": host(wl.aq, 8), "b_g1_query": host(wl.b1q, 8), "b_g2_query": host(wl.b2q, 16),
+           "h_query": host(wl.hq, 8), "l_query": host(wl.lq, 8)}
+    crs = M.pack_from_arkworks_proving_key(pps[0], hpk)
+    a, b, c = (host(t, 4) for t in (wl.a, wl.b, wl.c))
+    w = corc.field_op(curve, "fr", "to_mont", host(wl.w, 4))
+    qs = M.qap_pss(pps[0], a, b, c)
+    a_sh = M.pack_from_witness(pps[0], w[1:])
+    ax_sh = M.pack_from_witness(pps[0], w[2:])
+    res = net.simulate_network_round(
+        lambda i, h: M.party_prove(ctxs[i], pps[i], h, crs[i], qs[i], a_sh[i], ax_sh[i], 15))
+    pi_a, pi_b, (wv, uv) = res[0]
+    f1 = host(wl.fixed[:192], 8)
+    f2 = host(wl.fixed[192:], 16)
+    add = lambda g, p, q: corc.point_add(curve, g, p, q)   # noqa: E731
+    A = add(1, corc.jac_to_affine(curve, 1, pi_a), add(1, hpk["a_query"][0:1], f1[0:1]))
+    B = add(2, corc.jac_to_affine(curve, 2, pi_b), add(2, hpk["b_g2_query"][0:1], f2[0:1]))
+    C = add(1, corc.jac_to_affine(curve, 1, wv), corc.jac_to_affine(curve, 1, uv))
+    (eA, eB, eC), _ = bench.oracle_prove(wl, bench.cpu_threads(), 0, 0)
+    assert np.array_equal(A, eA) and np.array_equal(B, eB) and np.array_equal(C, eC)
+    wl.pk.close()

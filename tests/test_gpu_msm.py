@@ -20,14 +20,41 @@ def check(curve, group, bases, scalars, **kw):
     return got
 
 
-@pytest.mark.parametrize("curve,group", GROUPS)
-@pytest.mark.parametrize("n", [1, 7, 100, 1 << 10, 1 << 13])
+# every (group, size) pair is a real case: no skips.  bn254 G1 gets the odd sizes too; every other group runs
+# n = 1, 100, 2^10 (direct atomic sort) and 2^14, 2^16 (W*n >= 2^18: LDS-partitioned sort, segment accumulation,
+# giant-bucket work list; for the G2 groups the LDS-staged accumulator incl. BLS12-381's BLOCK = 128 instantiation)
+SWEEP = [(c, g, n) for (c, g) in GROUPS for n in (1, 100, 1 << 10, 1 << 14, 1 << 16)] + \
+        [("bn254", 1, 7), ("bn254", 1, 1 << 13)]
+
+
+@pytest.mark.parametrize("curve,group,n", SWEEP)
 def test_msm_matches_oracle(curve, group, n):
-    if (curve, group) != ("bn254", 1) and n in (7, 1 << 13):
-        pytest.skip("full sweep on bn254 G1 only")
-    bases = corc.gen_points(curve, group, 2 + n, n)
+    if n >= 1 << 14:
+        bases = ctx().gen_bases(curve, group, 2 + n, n)     # same (k0, k1) walk as the oracle's generator
+    else:
+        bases = corc.gen_points(curve, group, 2 + n, n)
     scalars = corc.rand_field(curve, "fr", 9 + n, n, mont=False)
     check(curve, group, bases, scalars)
+
+
+def test_gen_bases_equals_oracle_generator():
+    # the large cases above take their bases from dg16_gen_bases: pin it to the oracle's walk bit for bit
+    for curve, group in GROUPS:
+        assert np.array_equal(ctx().gen_bases(curve, group, 77, 300), corc.gen_points(curve, group, 77, 300))
+
+
+@pytest.mark.parametrize("group", [1, 2])
+def test_msm_2_20_bls12_381(group):
+    """BASELINE config 5's curve at the size where every large-MSM path engages (partitioned sort, c = 16,
+    16 bucket windows, two-stage sums, Horner tail): bit-exact vs the C oracle + split linearity."""
+    curve, n = "bls12_381", 1 << 20
+    bases = ctx().gen_bases(curve, group, 5, n)
+    scalars = corc.rand_field(curve, "fr", 6, n, mont=False)
+    full = check(curve, group, bases, scalars)
+    h = n // 2 + 12345
+    a = corc.jac_to_affine(curve, group, ctx().msm(curve, group, bases[:h], scalars[:h]))
+    b = corc.jac_to_affine(curve, group, ctx().msm(curve, group, bases[h:], scalars[h:]))
+    assert np.array_equal(corc.point_add(curve, group, a, b), full)
 
 
 def test_msm_edge_cases():

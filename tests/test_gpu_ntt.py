@@ -12,11 +12,14 @@ pytestmark = pytest.mark.gpu
 ALL = ["bn254", "bls12_381", "bls12_377"]
 
 
-@pytest.mark.parametrize("curve", ALL)
-@pytest.mark.parametrize("log_n", [0, 1, 3, 9, 10, 11, 13, 18, 19, 20])
+# no skips: bn254 and bls12_381 (BASELINE configs 3 and 5) run every plan shape (1, 2 and 3 steps, odd and even
+# splits); bls12_377 (the reference's dfft tests, dfft/mod.rs:277) runs one size per plan shape
+SWEEP = [(c, k) for c in ("bn254", "bls12_381") for k in (0, 1, 3, 9, 10, 11, 13, 18, 19, 20)] + \
+        [("bls12_377", k) for k in (3, 10, 13, 19)]
+
+
+@pytest.mark.parametrize("curve,log_n", SWEEP)
 def test_ntt_matches_oracle(curve, log_n):
-    if curve != "bn254" and log_n not in (3, 10, 13, 19):
-        pytest.skip("full size sweep on bn254 only")
     n = 1 << log_n
     X = corc.rand_field(curve, "fr", 3 + log_n, n)
     c = ctx()
@@ -45,7 +48,8 @@ def test_ntt_x_equals_i():
     assert np.array_equal(ctx().ntt(curve, X), corc.ntt(curve, X))
 
 
-@pytest.mark.parametrize("curve,log_m", [("bn254", 3), ("bn254", 10), ("bn254", 15), ("bls12_381", 12)])
+@pytest.mark.parametrize("curve,log_m", [("bn254", 3), ("bn254", 10), ("bn254", 15), ("bn254", 20),
+                                         ("bls12_381", 12), ("bls12_381", 16), ("bls12_381", 20)])
 def test_h_poly_matches_oracle(curve, log_m):
     m = 1 << log_m
     a, b, c_ = (corc.rand_field(curve, "fr", 40 + i, m) for i in range(3))
@@ -53,12 +57,11 @@ def test_h_poly_matches_oracle(curve, log_m):
     assert np.array_equal(got, corc.h_poly(curve, a, b, c_))
 
 
-def test_ntt_2_22_properties():
-    # BASELINE config 3: domain 2^22.  Round trip + linearity + sampled entries against the
-    # O(n)-per-entry definition would be slow; the oracle NTT at 2^22 takes a few seconds, so we
-    # compare against it directly as well.
-    curve = "bn254"
-    n = 1 << 22
+@pytest.mark.parametrize("curve,log_n", [("bn254", 22), ("bls12_381", 22), ("bls12_381", 24)])
+def test_ntt_large_properties(curve, log_n):
+    # BASELINE config 3 (BN254, domain 2^22) and config 5's field at 2^22 / 2^24.  Round trip + linearity
+    # (size-independent properties) and the oracle NTT at full size (a few seconds on the host cores).
+    n = 1 << log_n
     c = ctx()
     X = corc.rand_field(curve, "fr", 3, n)
     Y = c.ntt(curve, X)

@@ -119,11 +119,63 @@ def test_sharded_prove_equals_unsharded():
             k.close()
 
 
-@pytest.mark.parametrize("log_m", [6, 9, 12, 14, 16])
-def test_prove_medium_sizes_vs_oracle(log_m):
-    """Resident-table prover at sizes where every phase is multi-block (scan, segments, two-stage sums):
-    the proof of a synthetic 2^log_m instance must equal the C oracle's proof of the same inputs."""
+@pytest.mark.parametrize("curve,log_m", [("bn254", 6), ("bn254", 9), ("bn254", 12), ("bn254", 14), ("bn254", 16),
+                                         ("bls12_381", 12), ("bls12_381", 14), ("bls12_381", 16)])
+def test_prove_medium_sizes_vs_oracle(curve, log_m):
+    """Resident-table prover at sizes where every phase is multi-block (scan, segments, two-stage sums): the
+    proof of a synthetic 2^log_m instance FROM THE MATRICES (dg16_qap + dg16_groth16_prove) must equal the C
+    oracle's proof of the same inputs.  BLS12-381 = BASELINE config 5's curve (384-bit base field: the 12-limb
+    multiply, the BLOCK = 128 G2 accumulation kernel)."""
     import torch
     import bench
-    cb, ok = bench.cpu_baseline_and_parity(ctx(), torch.device("cuda", 0), log_m)
+    cb, ok = bench.cpu_baseline_and_parity(ctx(), torch.device("cuda", 0), log_m, curve)
     assert ok
+
+
+@pytest.mark.parametrize("rs_zero", [True, False])
+def test_prove_sha256_shaped_config4(rs_zero):
+    """BASELINE config 4.  The reference's fixtures/sha256/sha256.r1cs is a missing blob, so
+    the instance is sha256-SHAPED: 29 823 wires, 2 instance variables, domain 2^15 (groth16/examples/sha256.rs runs
+    exactly this shape), r = s = 0 as at sha256.rs:152-153 and random r, s."""
+    import torch
+    import bench
+    dev = torch.device("cuda", 0)
+    wl = bench.Workload(ctx(), dev, 15, 0, 1, seed=4, curve="bn254", nv=29823, nc=29400, ni=2)
+    rs = np.zeros((2, 4), dtype=np.uint64) if rs_zero else wl.rs
+    gp = bench.prove_once(ctx(), wl, rs)
+    r = int(sum(int(v) << (64 * i) for i, v in enumerate(rs[0])))
+    s = int(sum(int(v) << (64 * i) for i, v in enumerate(rs[1])))
+    (A, B, C), _ = bench.oracle_prove(wl, bench.cpu_threads(), r, s)
+    gA, gB, gC = bench.gpu_proof_affine("bn254", gp)
+    assert np.array_equal(A, gA) and np.array_equal(B, gB) and np.array_equal(C, gC)
+    wl.pk.close()
+
+
+@pytest.mark.parametrize("curve,log_m,world", [("bls12_381", 12, 2), ("bls12_381", 14, 8), ("bn254", 16, 8),
+                                               ("bls12_381", 16, 1)])
+def test_sharded_prove_large_vs_oracle(curve, log_m, world):
+    """N shard keys on one GPU (what N ranks hold), records concatenated as the all-gather would, assembled: the
+    proof must equal the C oracle's, at sizes where the shards run the large-MSM paths."""
+    import torch
+    import bench
+    dev = torch.device("cuda", 0)
+    c_ = ctx()
+    shards = [bench.Workload(c_, dev, log_m, k, world, seed=31, curve=curve) for k in range(world)]
+    recs = []
+    for wl in shards:
+        rec = torch.empty(c_.results_bytes(curve), dtype=torch.uint8, device=dev)
+        wl.qap()
+        c_.groth16_msms_dev(wl.pk, wl.a.data_ptr(), wl.b.data_ptr(), wl.c.data_ptr(), wl.w.data_ptr(), wl.rs,
+                            rec.data_ptr(), scalars_mont=False)
+        for ch in range(3):
+            c_.sync(ch)
+        recs.append(rec)
+    gathered = torch.cat(recs)
+    proof = torch.empty(shards[0].proof_bytes(), dtype=torch.uint8, device=dev)
+    c_.groth16_assemble_dev(shards[0].pk, gathered.data_ptr(), world, shards[0].rs, proof.data_ptr(), scalars_mont=False)
+    c_.sync(0)
+    (A, B, C), _ = bench.oracle_prove(shards[0], bench.cpu_threads())
+    gA, gB, gC = bench.gpu_proof_affine(curve, proof.cpu().numpy())
+    assert np.array_equal(A, gA) and np.array_equal(B, gB) and np.array_equal(C, gC)
+    for wl in shards:
+        wl.pk.close()

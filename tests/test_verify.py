@@ -103,3 +103,45 @@ def test_verification_key_straight_from_a_zkey():
     assert V.verify_with_zkey(z, public, limbs)
     public[0, 0] ^= 1
     assert not V.verify_with_zkey(z, public, limbs)
+
+
+def test_non_canonical_inputs_do_not_alias():
+    """x, x + r and x + 2r all fit 256 bits: arkworks rejects a non-reduced field element at deserialisation, so
+    must the C ABI (public-input aliasing otherwise).  Non-reduced or off-subgroup verifying-key material is an
+    error; a proof coordinate + q is a rejection."""
+    vk, public, (A, B, C) = load("snarkjs_million")
+    raw = lambda v: np.frombuffer(int(v).to_bytes(32, "little"), dtype=np.uint64)   # noqa: E731  (no reduction)
+    args = [g1(vk["alpha_g1"]), g2(vk["beta_g2"]), g2(vk["gamma_g2"]), g2(vk["delta_g2"]),
+            np.stack([g1(P) for P in vk["ic"]])]
+    proof = np.concatenate([g1(A), g2(B), g1(C)])
+    assert V.verify_proof(*args, np.stack([raw(public[0])]), proof)
+    for k in (1, 2):
+        if public[0] + k * Fr.p < 1 << 256:
+            with pytest.raises(Dg16Error) as e:
+                V.verify_proof(*args, np.stack([raw(public[0] + k * Fr.p)]), proof)
+            assert e.value.code == 3                                  # BAD_ARG
+    # proof coordinate x + q (same residue, non-reduced Montgomery limbs): rejected, not accepted
+    bad = proof.copy()
+    ax = int.from_bytes(bad[:4].tobytes(), "little") + Fq.p
+    assert ax < 1 << 256
+    bad[:4] = raw(ax)
+    assert not V.verify_proof(*args, np.stack([raw(public[0])]), bad)
+    # verifying key: IC point with a non-reduced coordinate, and a G2 point on the twist but outside the subgroup
+    ic_bad = args[4].copy()
+    ic_bad[0, :4] = raw(int.from_bytes(ic_bad[0, :4].tobytes(), "little") + Fq.p)
+    with pytest.raises(Dg16Error):
+        V.verify_proof(args[0], args[1], args[2], args[3], ic_bad, np.stack([raw(public[0])]), proof)
+    from oracle.pyref.curves import CURVES
+    from dg16_amd import serialize as S
+    g2c = CURVES["bn254", "g2"]
+    rng = random.Random(1)
+    while True:                                                        # a point of E'(Fq2) that is not in G2
+        x = (rng.randrange(Fq.p), rng.randrange(Fq.p))
+        y = S._sqrt_fq2(g2c.F.add(g2c.F.mul(g2c.F.mul(x, x), x), g2c.b))
+        if y is not None:
+            break
+    Q = (x, y)
+    assert g2c.mul(Q, Fr.p) is not None                                # cofactor > 1: r * Q != identity
+    with pytest.raises(Dg16Error):
+        V.verify_proof(args[0], args[1], g2(Q), args[3], args[4], np.stack([raw(public[0])]), proof)
+    assert not V.verify_proof(*args, np.stack([raw(public[0])]), np.concatenate([g1(A), g2(Q), g1(C)]))
