@@ -1,0 +1,174 @@
+// Short-Weierstrass (a = 0) group arithmetic on the reduced-radix field types of fp29.h -- the bucket phases of the
+// MSM (segment accumulation, bucket reduction).  Same formulas and completeness rules as ec.h (XYZZ coordinates:
+// mixed add 8M + 2S, add 12M + 2S, doubling 6M + 3S; identity / doubling / inverse operands handled because the
+// reference's own tests feed them: dist-primitives/src/dmsm/mod.rs:155-159), but every temporary carries its bounds
+// in its type (`auto`), products normalise an operand only where a column could overflow, and coordinates are
+// stored normalised below a fixed storage bound BS p: nothing is compared or conditionally subtracted between
+// the products.  A formula that compiles cannot overflow (static_asserts of fp29.h).
+//
+// Coordinates are x R mod p with R = 2^(W N) (NOT the arkworks R = 2^(32 NL) of the C ABI): bases enter through
+// msm_to_internal_kernel / the table builder, results leave through to_xyzz32().
+// Identity: ZZ with all limbs zero (only ever created by inf(); never the result of arithmetic).
+#pragma once
+#include "ec.h"
+#include "fp29.h"
+
+namespace dg16 {
+
+// storage bound (in p / 64) of a coordinate.  7 p closes every formula below without a reduction when the field
+// has >= 7 spare bits and the coordinates are base-field elements; quadratic-extension coordinates over a field
+// with little slack (BN254: 7 bits) are reduced to ~p when stored (Fq2 products double the bounds twice).
+template <class P, bool EXT>
+struct StoreBound {
+  static constexpr int value = (EXT && RR<P>::SLACK < 9) ? 130 : 448;
+};
+
+template <class F> struct FieldOf;   // maps a 32-bit-limb field type (fp.h / fp2.h) to its reduced-radix storage type
+template <class P> struct FieldOf<Fp<P>> {
+  using Params = P;
+  static constexpr bool EXT = false;
+  static constexpr int BS = StoreBound<P, false>::value;
+  using Store = Fe<P, BS, 1>;
+  using Canon = Fe<P, 64, 1>;
+  static constexpr int WORDS = RR<P>::NL;           // packed words per element
+  DG_HD static Canon load_packed(const uint32_t* w) { return fe_from_words<P>(w); }
+  DG_HD static void store_packed(const Canon& a, uint32_t* w) { fe_to_words<P>(a, w); }
+  DG_HD static Canon canon_of(const Store& a) { return canon(a); }
+  DG_HD static Store one() { return fe_one<P>().template as<BS, 1>(); }
+  DG_HD static Store zero() { return Store::zero(); }
+  DG_HD static Fp<P> to32(const Store& a) { return fe_to_fp(a); }
+  DG_HD static Store from32(const Fp<P>& a) { return fit<BS>(fe_from_fp(a)); }
+};
+template <class P> struct FieldOf<Fp2<Fp<P>>> {
+  using Params = P;
+  static constexpr bool EXT = true;
+  static constexpr int BS = StoreBound<P, true>::value;
+  using Store = Fe2<P, BS, 1>;
+  using Canon = Fe2<P, 64, 1>;
+  static constexpr int WORDS = 2 * RR<P>::NL;
+  DG_HD static Canon load_packed(const uint32_t* w) { return {fe_from_words<P>(w), fe_from_words<P>(w + RR<P>::NL)}; }
+  DG_HD static void store_packed(const Canon& a, uint32_t* w) {
+    fe_to_words<P>(a.c0, w);
+    fe_to_words<P>(a.c1, w + RR<P>::NL);
+  }
+  DG_HD static Canon canon_of(const Store& a) { return {canon(a.c0), canon(a.c1)}; }
+  DG_HD static Store one() { return {fe_one<P>().template as<BS, 1>(), Fe<P, BS, 1>::zero()}; }
+  DG_HD static Store zero() { return {Fe<P, BS, 1>::zero(), Fe<P, BS, 1>::zero()}; }
+  DG_HD static Fp2<Fp<P>> to32(const Store& a) { return {fe_to_fp(a.c0), fe_to_fp(a.c1)}; }
+  DG_HD static Store from32(const Fp2<Fp<P>>& a) { return {fit<BS>(fe_from_fp(a.c0)), fit<BS>(fe_from_fp(a.c1))}; }
+};
+
+// affine point in internal form, canonical coordinates; identity = (0, 0)
+template <class F>
+struct Affine29 {
+  using FO = FieldOf<F>;
+  typename FO::Canon x, y;
+  DG_HD bool is_inf() const { return limbs_all_zero(x) && limbs_all_zero(y); }
+  // from / to the packed words the library's tables hold (x || y, FO::WORDS words each)
+  DG_HD static Affine29 load(const uint32_t* w) { return {FO::load_packed(w), FO::load_packed(w + FO::WORDS)}; }
+};
+
+template <class F>
+struct XYZZ29 {
+  using FO = FieldOf<F>;
+  using S = typename FO::Store;
+  static constexpr int BS = FO::BS;
+  S x, y, zz, zzz;
+
+  DG_HD bool is_inf() const { return limbs_all_zero(zz); }
+  DG_HD static XYZZ29 inf() { return {FO::one(), FO::one(), FO::zero(), FO::zero()}; }
+  DG_HD XYZZ29 neg_pt() const { return {x, fit<BS>(neg(y)), zz, zzz}; }
+
+  // 2 (qx, qy), the affine point not the identity                         (mdbl-2008-s-1, a = 0)
+  template <class FX, class FY>
+  DG_HD static XYZZ29 dbl_affine(const FX& qx, const FY& qy) {
+    const auto u = dbl(qy);
+    const auto v = sqr(u);
+    const auto w = u * v;
+    const auto s = qx * v;
+    const auto xx = sqr(qx);
+    const auto m = dbl(xx) + xx;
+    const auto x3 = fit<BS>(sqr(m) - dbl(s));
+    const auto y3 = m * (s - x3) - w * qy;
+    return {x3, fit<BS>(y3), fit<BS>(v), fit<BS>(w)};
+  }
+  // 2 this                                                                 (dbl-2008-s-1, a = 0)
+  DG_HD XYZZ29 dbl_pt() const {
+    if (is_inf()) return *this;
+    const auto u = dbl(y);
+    const auto v = sqr(u);
+    const auto w = u * v;
+    const auto s = x * v;
+    const auto xx = sqr(x);
+    const auto m = dbl(xx) + xx;
+    const auto x3 = fit<BS>(sqr(m) - dbl(s));
+    const auto y3 = m * (s - x3) - w * y;
+    return {x3, fit<BS>(y3), fit<BS>(v * zz), fit<BS>(w * zzz)};
+  }
+  // this + (negate ? -q : q), q affine                                      (madd-2008-s)
+  DG_HD XYZZ29 madd(const Affine29<F>& q, bool negate) const {
+    if (q.is_inf()) return *this;
+    const auto nqy = neg(q.y);
+    const auto qy = select(negate, nqy, q.y.template as<decltype(nqy)::Bound, decltype(nqy)::Limb>());
+    if (is_inf()) return {q.x.template as<BS, 1>(), fit<BS>(qy), FO::one(), FO::one()};
+    const auto u2 = q.x * zz;
+    const auto s2 = qy * zzz;
+    const auto p_ = norm(u2 - x);
+    const auto r_ = norm(s2 - y);
+    if (is_zero(p_)) {
+      if (is_zero(r_)) return dbl_affine(q.x, qy);
+      return inf();
+    }
+    const auto pp = sqr(p_);
+    const auto ppp = p_ * pp;
+    const auto q_ = x * pp;
+    const auto x3 = fit<BS>(sqr(r_) - (ppp + dbl(q_)));
+    const auto y3 = r_ * (q_ - x3) - y * ppp;
+    return {x3, fit<BS>(y3), fit<BS>(zz * pp), fit<BS>(zzz * ppp)};
+  }
+  // this + o                                                                 (add-2008-s)
+  DG_HD XYZZ29 add(const XYZZ29& o) const {
+    if (o.is_inf()) return *this;
+    if (is_inf()) return o;
+    const auto u1 = x * o.zz;
+    const auto u2 = o.x * zz;
+    const auto s1 = y * o.zzz;
+    const auto s2 = o.y * zzz;
+    const auto p_ = norm(u2 - u1);
+    const auto r_ = norm(s2 - s1);
+    if (is_zero(p_)) {
+      if (is_zero(r_)) return dbl_pt();
+      return inf();
+    }
+    const auto pp = sqr(p_);
+    const auto ppp = p_ * pp;
+    const auto q_ = u1 * pp;
+    const auto x3 = fit<BS>(sqr(r_) - (ppp + dbl(q_)));
+    const auto y3 = r_ * (q_ - x3) - s1 * ppp;
+    return {x3, fit<BS>(y3), fit<BS>((zz * o.zz) * pp), fit<BS>((zzz * o.zzz) * ppp)};
+  }
+  // -> the 32-bit-limb XYZZ of ec.h (arkworks Montgomery form, canonical): what the older kernels and the C ABI read
+  DG_HD XYZZ<F> to_xyzz32() const {
+    if (is_inf()) return XYZZ<F>::inf();
+    return {FO::to32(x), FO::to32(y), FO::to32(zz), FO::to32(zzz)};
+  }
+  DG_HD static XYZZ29 from_xyzz32(const XYZZ<F>& p) {
+    if (p.is_inf()) return inf();
+    return {FO::from32(p.x), FO::from32(p.y), FO::from32(p.zz), FO::from32(p.zzz)};
+  }
+};
+
+// arkworks-form affine point (C ABI layout) -> packed internal form, same byte size: x R32 -> x R, canonical
+template <class F>
+DG_HD void affine_to_internal(const Affine<F>& p, uint32_t* out_words) {
+  using FO = FieldOf<F>;
+  if (p.is_inf()) {
+#pragma unroll
+    for (int i = 0; i < 2 * FO::WORDS; i++) out_words[i] = 0;
+    return;
+  }
+  FO::store_packed(FO::canon_of(FO::from32(p.x)), out_words);
+  FO::store_packed(FO::canon_of(FO::from32(p.y)), out_words + FO::WORDS);
+}
+
+}  // namespace dg16

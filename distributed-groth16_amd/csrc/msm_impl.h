@@ -24,6 +24,7 @@
 // buckets XYZZ [W][2^(c-1)].
 #pragma once
 #include "ctx.h"
+#include "ec29.h"
 #include "types.h"
 
 namespace dg16 {
@@ -496,9 +497,27 @@ __global__ void __launch_bounds__(256) msm_part_place_kernel(const uint2* __rest
 }
 
 // ---- 4: segment accumulation -------------------------------------------------------------------
+// Bases arrive in the library's INTERNAL form (msm_to_internal_kernel / msm_table_kernel): x || y, each coordinate
+// x R mod p of the reduced-radix representation (fp29.h) packed into the arkworks word count, identity = zeros.
+// The mixed additions run on 29/28-bit limbs with lazy bounds (ec29.h: 162 v_mad_u64_u32 per Fq product and no
+// carry or compare instructions, against 128 mad + 128 addc + ~70 others for the 32-bit product); the segment sum
+// leaves in the 32-bit arkworks form the reduction kernels read (4 conversions per >= 8 additions).
+template <class F>
+__device__ __forceinline__ Affine29<F> load_internal(const uint32_t* __restrict__ bases, unsigned idx) {
+  constexpr int PW = 2 * FieldOf<F>::WORDS;               // words per point
+  uint32_t w[PW];
+  const uint4* src = reinterpret_cast<const uint4*>(bases + (size_t)idx * PW);
+#pragma unroll
+  for (int i = 0; i < PW / 4; i++) {
+    const uint4 v = src[i];
+    w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
+  }
+  return Affine29<F>::load(w);
+}
+
 template <class F>
 __global__ void __launch_bounds__(256, (sizeof(F) > 48 ? 2 : 1))
-msm_accumulate_kernel(const Affine<F>* __restrict__ bases, size_t n,
+msm_accumulate_kernel(const uint32_t* __restrict__ bases, size_t n,
                                                               MsmGeom g, const unsigned* __restrict__ offsets,
                                                               const unsigned* __restrict__ counts,
                                                               const unsigned* __restrict__ seg_off,
@@ -516,59 +535,45 @@ msm_accumulate_kernel(const Affine<F>* __restrict__ bases, size_t n,
   unsigned cnt = counts[bslot] - first;
   if (cnt > (1u << g.seg_log)) cnt = 1u << g.seg_log;
   const unsigned* e = entries + (size_t)w * g.region + offsets[bslot] + first;
-  // Latency hiding.  G1 runs 4 waves/SIMD, which covers the dependent (entry -> 64-B point) gathers, and a
-  // second Affine would cost occupancy; only the 4-byte entry index is fetched one iteration ahead.  G2 has
-  // ONE wave per SIMD (449 registers), so nothing else hides a gather: its time was bimodal from box to box
-  // (10.3 vs 20.5 ms at 2^20, identical binary -- consistent with TLB-miss latency on fragmented page
-  // tables); there the NEXT point is loaded before the current mixed add (register-to-register now that the
-  // add path has no calls).
-  constexpr bool kPrefetchPoint = sizeof(F) > 48;
+  // Latency hiding: several waves per SIMD cover the dependent (entry -> point) gathers; only the 4-byte entry
+  // index is fetched one iteration ahead (a second point in registers would cost occupancy).
   unsigned cur = e[0];
-  XYZZ<F> acc = XYZZ<F>::inf();
-  if constexpr (kPrefetchPoint) {
-    Affine<F> p = bases[cur & 0x7fffffffu];
-    for (unsigned j = 0; j < cnt; j++) {
-      unsigned nxt = (j + 1 < cnt) ? e[j + 1] : cur;
-      Affine<F> pn = bases[nxt & 0x7fffffffu];
-      acc = acc.madd(p, cur >> 31);
-      cur = nxt;
-      p = pn;
-    }
-  } else {
-    for (unsigned j = 0; j < cnt; j++) {
-      unsigned nxt = (j + 1 < cnt) ? e[j + 1] : 0u;
-      Affine<F> p = bases[cur & 0x7fffffffu];
-      acc = acc.madd(p, cur >> 31);
-      cur = nxt;
-    }
+  XYZZ29<F> acc = XYZZ29<F>::inf();
+  for (unsigned j = 0; j < cnt; j++) {
+    unsigned nxt = (j + 1 < cnt) ? e[j + 1] : 0u;
+    const Affine29<F> p = load_internal<F>(bases, cur & 0x7fffffffu);
+    acc = acc.madd(p, cur >> 31);
+    cur = nxt;
   }
-  seg_sum[sslot] = acc;
+  seg_sum[sslot] = acc.to_xyzz32();
 }
 
 // ---- 4 (G2): the same segment accumulation with the accumulator staged through LDS -------------------------
-// An Fq2 mixed addition keeps ~200 registers live when the four accumulator coordinates stay in LDS between
-// uses; with them in registers hipcc needs 449 (one wave per SIMD, AGPR spills, box-dependent 2x slowdowns)
-// or, bounded to 256, spills ~200 dwords/lane to scratch (30 GB of HBM traffic per 2^20 launch, PMC).  LDS
-// layout: [coordinate word][lane] (consecutive lanes -> consecutive banks: conflict-free ds_read/write_b32),
-// 4 coordinates x sizeof(F)/4 words x BLOCK lanes = 64 KiB for BN254 Fq2 at BLOCK = 256 (2 workgroups per CU).
+// An Fq2 mixed addition with its four accumulator coordinates in registers needs more than 256 VGPRs (one wave per
+// SIMD, AGPR spills); with the coordinates in LDS between uses (layout [coordinate word][lane]: consecutive lanes ->
+// consecutive banks, conflict-free ds_read/write_b32) the live set is the loaded point and ~6 temporaries.
+// 4 coordinates x 2 N words x BLOCK lanes = 72 KiB for BN254 Fq2 at BLOCK = 256 (two workgroups per CU, 160 KiB LDS).
 template <class F, int BLOCK>
 __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 ? 2 : 1))
-msm_accumulate_lds_kernel(const Affine<F>* __restrict__ bases, size_t n, MsmGeom g,
+msm_accumulate_lds_kernel(const uint32_t* __restrict__ bases, size_t n, MsmGeom g,
                           const unsigned* __restrict__ offsets, const unsigned* __restrict__ counts,
                           const unsigned* __restrict__ seg_off, const unsigned* __restrict__ seg_total,
                           const unsigned* __restrict__ seg_bucket, const unsigned* __restrict__ entries,
                           XYZZ<F>* __restrict__ seg_sum) {
-  constexpr int WORDS = sizeof(F) / 4;
+  using FO = FieldOf<F>;
+  using S = typename FO::Store;
+  constexpr int BS = FO::BS;
+  constexpr int WORDS = sizeof(S) / 4;
   __shared__ uint32_t sh[4 * WORDS][BLOCK];
   const unsigned lane = threadIdx.x;
   auto ld = [&](int coord) {
-    F v;
+    S v;
     uint32_t* w = reinterpret_cast<uint32_t*>(&v);
 #pragma unroll
     for (int i = 0; i < WORDS; i++) w[i] = sh[coord * WORDS + i][lane];
     return v;
   };
-  auto st = [&](int coord, const F& v) {
+  auto st = [&](int coord, const S& v) {
     const uint32_t* w = reinterpret_cast<const uint32_t*>(&v);
 #pragma unroll
     for (int i = 0; i < WORDS; i++) sh[coord * WORDS + i][lane] = w[i];
@@ -588,49 +593,65 @@ msm_accumulate_lds_kernel(const Affine<F>* __restrict__ bases, size_t n, MsmGeom
   unsigned cur = e[0];
   for (unsigned j = 0; j < cnt; j++) {
     unsigned nxt = (j + 1 < cnt) ? e[j + 1] : 0u;
-    Affine<F> q = bases[cur & 0x7fffffffu];
+    const Affine29<F> q = load_internal<F>(bases, cur & 0x7fffffffu);
     const bool negate = cur >> 31;
     cur = nxt;
     if (q.is_inf()) continue;
-    F qy = negate ? q.y.neg() : q.y;
+    const auto nqy = neg(q.y);
+    const auto qy = select(negate, nqy, q.y.template as<decltype(nqy)::Bound, decltype(nqy)::Limb>());
     if (inf) {
-      st(0, q.x); st(1, qy); st(2, F::one()); st(3, F::one());
+      st(0, q.x.template as<BS, 1>()); st(1, fit<BS>(qy)); st(2, FO::one()); st(3, FO::one());
       inf = false;
       continue;
     }
-    F p = q.x * ld(2) - ld(0);          // U2 - X1
+    const auto p_ = norm(q.x * ld(2) - ld(0));          // U2 - X1
     DG_STAGE();
-    F r = qy * ld(3) - ld(1);           // S2 - Y1
+    const auto r_ = norm(qy * ld(3) - ld(1));           // S2 - Y1
     DG_STAGE();
-    if (p.is_zero()) {
-      if (r.is_zero()) {
-        XYZZ<F> d = XYZZ<F>::dbl_affine(q.x, qy);
+    if (is_zero(p_)) {
+      if (is_zero(r_)) {
+        const XYZZ29<F> d = XYZZ29<F>::dbl_affine(q.x, qy);
         st(0, d.x); st(1, d.y); st(2, d.zz); st(3, d.zzz);
       } else {
         inf = true;
       }
       continue;
     }
-    F pp = p.sqr();
-    F ppp = p * pp;
+    const auto pp = sqr(p_);
+    const auto ppp = p_ * pp;
     DG_STAGE();
-    st(2, ld(2) * pp);
+    st(2, fit<BS>(ld(2) * pp));
     DG_STAGE();
-    st(3, ld(3) * ppp);
+    st(3, fit<BS>(ld(3) * ppp));
     DG_STAGE();
-    F q_ = ld(0) * pp;
+    const auto q_ = ld(0) * pp;
     DG_STAGE();
-    F x3 = r.sqr() - ppp - q_.dbl();
+    const auto x3 = fit<BS>(sqr(r_) - (ppp + dbl(q_)));
     st(0, x3);
     DG_STAGE();
-    F y3 = r * (q_ - x3) - ld(1) * ppp;
+    const auto y3 = fit<BS>(r_ * (q_ - x3) - ld(1) * ppp);
     st(1, y3);
     DG_STAGE();
   }
   XYZZ<F> out = XYZZ<F>::inf();
-  if (!inf) out = {ld(0), ld(1), ld(2), ld(3)};
+  if (!inf) out = XYZZ29<F>{ld(0), ld(1), ld(2), ld(3)}.to_xyzz32();
   seg_sum[sslot] = out;
 #undef DG_STAGE
+}
+
+// arkworks-form bases (C ABI) -> internal form for the accumulation kernels (plain dg16_msm: one pass per call,
+// 2 field products per point against ~10 W in the accumulation; resident keys convert once, in the table builder)
+template <class F>
+__global__ void __launch_bounds__(256) msm_to_internal_kernel(const Affine<F>* __restrict__ in, size_t n,
+                                                               uint32_t* __restrict__ out) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  constexpr int PW = 2 * FieldOf<F>::WORDS;
+  uint32_t w[PW];
+  affine_to_internal(in[i], w);
+  uint4* dst = reinterpret_cast<uint4*>(out + i * PW);
+#pragma unroll
+  for (int k = 0; k < PW / 4; k++) dst[k] = make_uint4(w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]);
 }
 
 // ---- wave-cooperative group operations (single-chain phases: Horner tail, s*A / r*B1) ------------------------
@@ -1056,20 +1077,20 @@ MsmBuffers<F> msm_buffers(Channel& wsch, const MsmGeom& g) {
   return b;
 }
 
-// Phase A (saturates the GPU): segment accumulation.  `bases` is the plain array (n points) or, in table
-// mode, the table of W*n points.
+// Phase A (saturates the GPU): segment accumulation.  `bases` is the array of n points or, in table mode, the
+// table of W*n points -- in INTERNAL form (msm_to_internal_kernel / msm_table_kernel).
 template <class F>
 void msm_accumulate_phase(hipStream_t s, const MsmSort& st, const MsmBuffers<F>& b, const void* bases) {
   const MsmGeom& g = st.g;
   if constexpr (sizeof(F) > 48) {
-    // G2 (Fq2 coordinates): LDS-staged accumulator; 64 KiB of LDS per workgroup at most
-    constexpr int BLOCK = sizeof(XYZZ<F>) * 256 <= 65536 ? 256 : 128;
+    // G2 (Fq2 coordinates): LDS-staged accumulator; two workgroups per CU must fit the 160 KiB of LDS
+    constexpr int BLOCK = sizeof(typename FieldOf<F>::Store) * 4 * 256 <= 80 * 1024 ? 256 : 128;
     hipLaunchKernelGGL((msm_accumulate_lds_kernel<F, BLOCK>), dim3((g.seg_cap + BLOCK - 1) / BLOCK, g.bw), dim3(BLOCK),
-                       0, s, (const Affine<F>*)bases, st.n, g, st.offsets, st.counts, st.seg_off, st.seg_total,
+                       0, s, (const uint32_t*)bases, st.n, g, st.offsets, st.counts, st.seg_off, st.seg_total,
                        st.seg_bucket, st.entries, b.seg_sum);
   } else {
     hipLaunchKernelGGL(msm_accumulate_kernel<F>, dim3((g.seg_cap + 255) / 256, g.bw), dim3(256), 0, s,
-                       (const Affine<F>*)bases, st.n, g, st.offsets, st.counts, st.seg_off, st.seg_total,
+                       (const uint32_t*)bases, st.n, g, st.offsets, st.counts, st.seg_off, st.seg_total,
                        st.seg_bucket, st.entries, b.seg_sum);
   }
   DG_HIP(hipGetLastError());
@@ -1128,7 +1149,11 @@ template <class F, class Fr, int SCALAR_BITS>
 void msm_run(Call& k, const void* bases, const void* scalars, size_t n, bool scalars_mont, bool out_affine,
              void* out_dev) {
   MsmSort st = msm_sort<Fr, SCALAR_BITS>(k, scalars, n, scalars_mont, false);
-  msm_reduce<F>(k, st, bases, out_affine, out_dev);
+  uint32_t* internal = (uint32_t*)ws(k.c, 24, (n ? n : 1) * sizeof(Affine<F>));
+  if (n)
+    hipLaunchKernelGGL(msm_to_internal_kernel<F>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, k.s(),
+                       (const Affine<F>*)bases, n, internal);
+  msm_reduce<F>(k, st, internal, out_affine, out_dev);
 }
 
 // ---- table of window multiples for resident bases: T[w*n + i] = 2^(c*w) * P_i (affine) -----------------
@@ -1139,9 +1164,11 @@ __global__ void __launch_bounds__(64) msm_table_kernel(const Affine<F>* __restri
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   Affine<F> p = bases[i];
-  table[i] = p;
+  // rows are stored in the accumulation kernels' internal form (same size; see msm_to_internal_kernel)
+  auto put = [&](size_t at, const Affine<F>& v) { affine_to_internal(v, reinterpret_cast<uint32_t*>(table + at)); };
+  put(i, p);
   if (p.is_inf()) {
-    for (unsigned w = 1; w < nwin; w++) table[(size_t)w * n + i] = p;
+    for (unsigned w = 1; w < nwin; w++) put((size_t)w * n + i, p);
     return;
   }
   // rows 1..nwin-1 by repeated doubling; one shared inversion (Montgomery's trick over the rows)
@@ -1158,11 +1185,11 @@ __global__ void __launch_bounds__(64) msm_table_kernel(const Affine<F>* __restri
   }
   F inv = run.inv();
   for (unsigned w = nwin - 1; w >= 1; w--) {
-    if (pts[w].is_inf()) { table[(size_t)w * n + i] = Affine<F>::inf(); continue; }
+    if (pts[w].is_inf()) { put((size_t)w * n + i, Affine<F>::inf()); continue; }
     F zi3 = inv * pref[w];
     inv = inv * pts[w].zzz;
     F zi2 = (zi3 * pts[w].zz).sqr();
-    table[(size_t)w * n + i] = {pts[w].x * zi2, pts[w].y * zi3};
+    put((size_t)w * n + i, Affine<F>{pts[w].x * zi2, pts[w].y * zi3});
   }
 }
 

@@ -6,6 +6,7 @@
 #include <string.h>
 #include "../../distributed-groth16_amd/csrc/consts_gen.h"
 #include "../../distributed-groth16_amd/csrc/ec.h"
+#include "../../distributed-groth16_amd/csrc/ec29.h"
 
 using namespace dg16;
 
@@ -72,6 +73,90 @@ extern "C" int ha_point_op(int curve, int group, int op, const void* a, const vo
     case 2: point_op<b381_fq>(op, (const Affine<b381_fq>*)a, (const Affine<b381_fq>*)b, (Affine<b381_fq>*)o, n); break;
     case 3: point_op<Fp2<b381_fq>>(op, (const Affine<Fp2<b381_fq>>*)a, (const Affine<Fp2<b381_fq>>*)b, (Affine<Fp2<b381_fq>>*)o, n); break;
     case 4: point_op<b377_fq>(op, (const Affine<b377_fq>*)a, (const Affine<b377_fq>*)b, (Affine<b377_fq>*)o, n); break;
+    default: return 1;
+  }
+  return 0;
+}
+
+
+// ---- reduced-radix types (fp29.h / ec29.h): same operations, through the 29/28-bit-limb representation ------------
+// field: op 0 add, 1 sub, 2 mul, 3 sqr, 7 neg, 8 = mul through a long lazy chain ((a + b)(a - b) + a b - b^2 == a^2 - 2b^2 + ab)
+template <class P> static void field_op29(int op, const Fp<P>* a, const Fp<P>* b, Fp<P>* o, size_t n) {
+  for (size_t i = 0; i < n; i++) {
+    const auto x = fe_from_fp(a[i]);
+    const auto y = fe_from_fp(b[i]);
+    switch (op) {
+      case 0: o[i] = fe_to_fp(x + y); break;
+      case 1: o[i] = fe_to_fp(x - y); break;
+      case 2: o[i] = fe_to_fp(x * y); break;
+      case 3: o[i] = fe_to_fp(sqr(x)); break;
+      case 7: o[i] = fe_to_fp(neg(x)); break;
+      default: {
+        const auto t = norm(norm((x + y) * (x - y) + x * y) - sqr(y));
+        const auto t4 = norm(dbl(dbl(t)));
+        const auto u = reduce(t4 + t);                   // 5 t through reduce()
+        o[i] = fe_to_fp(u - t4);                         // == t
+        // is_zero must see through every representation of zero
+        if (!is_zero(t - t) || !is_zero(norm(dbl(x) - x) - x) || is_zero(fe_one<P>() + (t - t))) o[i].l[0] ^= 0xdead;
+        break;
+      }
+    }
+  }
+}
+// points: the operations of point_op above on XYZZ29
+template <class F> static void point_op29(int op, const Affine<F>* a, const Affine<F>* b, Affine<F>* o, size_t n) {
+  using FO = FieldOf<F>;
+  for (size_t i = 0; i < n; i++) {
+    uint32_t wa[2 * FO::WORDS], wb[2 * FO::WORDS];
+    affine_to_internal(a[i], wa);
+    affine_to_internal(b[i], wb);
+    const Affine29<F> pa = Affine29<F>::load(wa), pb = Affine29<F>::load(wb);
+    XYZZ29<F> A = XYZZ29<F>::inf().madd(pa, false);
+    XYZZ29<F> r;
+    switch (op) {
+      case 0: {
+        XYZZ29<F> B = XYZZ29<F>::inf().madd(pb, false);
+        XYZZ29<F> A3 = A.dbl_pt().add(A), B3 = B.dbl_pt().add(B);
+        r = A3.add(B3).add(A.dbl_pt().neg_pt()).add(B.dbl_pt().neg_pt());
+        break;
+      }
+      case 1: r = A.dbl_pt().madd(pb, false).add(A.neg_pt()); break;
+      case 2: r = A.madd(pb, true); break;
+      case 3: r = A.dbl_pt(); break;
+      default: {   // k * a by double-and-add with k = b's first 8 words: long chains of dbl_pt / add
+        const uint32_t* k = (const uint32_t*)&b[i];
+        r = XYZZ29<F>::inf();
+        for (int bit = 255; bit >= 0; bit--) {
+          r = r.dbl_pt();
+          if ((k[bit / 32] >> (bit % 32)) & 1) r = (bit & 1) ? r.add(A) : r.madd(pa, false);
+        }
+        break;
+      }
+    }
+    XYZZ<F> r32 = r.to_xyzz32();
+    Jacobian<F> j = r32.to_jacobian();
+    o[i] = XYZZ<F>::from_jacobian(j).to_affine();
+  }
+}
+extern "C" int ha_field_op29(int fid, int op, const void* a, const void* b, void* o, size_t n) {
+  switch (fid) {
+    case 0: field_op29<bn254_fq_params>(op, (const bn_fq*)a, (const bn_fq*)b, (bn_fq*)o, n); break;
+    case 1: field_op29<bls12_381_fq_params>(op, (const b381_fq*)a, (const b381_fq*)b, (b381_fq*)o, n); break;
+    case 2: field_op29<bls12_377_fq_params>(op, (const b377_fq*)a, (const b377_fq*)b, (b377_fq*)o, n); break;
+    case 16: field_op29<bn254_fr_params>(op, (const bn_fr*)a, (const bn_fr*)b, (bn_fr*)o, n); break;
+    case 17: field_op29<bls12_381_fr_params>(op, (const b381_fr*)a, (const b381_fr*)b, (b381_fr*)o, n); break;
+    case 18: field_op29<bls12_377_fr_params>(op, (const b377_fr*)a, (const b377_fr*)b, (b377_fr*)o, n); break;
+    default: return 1;
+  }
+  return 0;
+}
+extern "C" int ha_point_op29(int curve, int group, int op, const void* a, const void* b, void* o, size_t n) {
+  switch (curve * 2 + group - 1) {
+    case 0: point_op29<bn_fq>(op, (const Affine<bn_fq>*)a, (const Affine<bn_fq>*)b, (Affine<bn_fq>*)o, n); break;
+    case 1: point_op29<Fp2<bn_fq>>(op, (const Affine<Fp2<bn_fq>>*)a, (const Affine<Fp2<bn_fq>>*)b, (Affine<Fp2<bn_fq>>*)o, n); break;
+    case 2: point_op29<b381_fq>(op, (const Affine<b381_fq>*)a, (const Affine<b381_fq>*)b, (Affine<b381_fq>*)o, n); break;
+    case 3: point_op29<Fp2<b381_fq>>(op, (const Affine<Fp2<b381_fq>>*)a, (const Affine<Fp2<b381_fq>>*)b, (Affine<Fp2<b381_fq>>*)o, n); break;
+    case 4: point_op29<b377_fq>(op, (const Affine<b377_fq>*)a, (const Affine<b377_fq>*)b, (Affine<b377_fq>*)o, n); break;
     default: return 1;
   }
   return 0;

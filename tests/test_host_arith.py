@@ -21,13 +21,15 @@ SO = os.path.join(HERE, "host_arith", "libhost_arith.so")
 @pytest.fixture(scope="module")
 def ha():
     hdrs = [os.path.join(HERE, "..", "distributed-groth16_amd", "csrc", f)
-            for f in ("fp.h", "fp2.h", "ec.h", "consts_gen.h")]
+            for f in ("fp.h", "fp2.h", "ec.h", "consts_gen.h", "fp29.h", "ec29.h")]
     if not os.path.exists(SO) or any(os.path.getmtime(SO) < os.path.getmtime(p) for p in [SRC] + hdrs):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", SO, SRC])
     L = ctypes.CDLL(SO)
     vp, sz, i = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int
     L.ha_field_op.argtypes = [i, i, vp, vp, vp, sz]
     L.ha_point_op.argtypes = [i, i, i, vp, vp, vp, sz]
+    L.ha_field_op29.argtypes = [i, i, vp, vp, vp, sz]
+    L.ha_point_op29.argtypes = [i, i, i, vp, vp, vp, sz]
     return L
 
 
@@ -61,8 +63,12 @@ def test_field_ops(ha, curve, kind):
 
 @pytest.mark.parametrize("curve,group", [("bn254", 1), ("bn254", 2), ("bls12_381", 1),
                                          ("bls12_381", 2), ("bls12_377", 1)])
-def test_point_ops(ha, curve, group):
+@pytest.mark.parametrize("rr", [False, True])
+def test_point_ops(ha, curve, group, rr):
+    """rr = True: the same operations through the reduced-radix types of fp29.h / ec29.h (the representation of the
+    bucket kernels: 29/28-bit limbs, lazy bounds, its own Montgomery radix), converted in and out."""
     cid = corc.CURVES[curve]
+    point_op = ha.ha_point_op29 if rr else ha.ha_point_op
     rng = random.Random(3)
     r = FR[curve].p
     n = 24
@@ -80,17 +86,17 @@ def test_point_ops(ha, curve, group):
     # general add and mixed add must both equal P + Q
     exp = oracle_pairwise(lambda a, b: corc.point_add(curve, group, a, b))
     for op in (0, 1):
-        assert ha.ha_point_op(cid, group, op, _p(P), _p(Q), _p(out), n) == 0
+        assert point_op(cid, group, op, _p(P), _p(Q), _p(out), n) == 0
         assert np.array_equal(out, exp), op
     # madd with negation: P - Q (index 0 gives the identity)
     negQ = np.concatenate([corc.point_mul(curve, group, Q[i:i + 1], r - 1) for i in range(n)])
     exp = np.concatenate([corc.point_add(curve, group, P[i:i + 1], negQ[i:i + 1]) for i in range(n)])
-    assert ha.ha_point_op(cid, group, 2, _p(P), _p(Q), _p(out), n) == 0
+    assert point_op(cid, group, 2, _p(P), _p(Q), _p(out), n) == 0
     assert np.array_equal(out, exp)
     assert not out[0].any()
     # doubling
     exp = np.concatenate([corc.point_add(curve, group, P[i:i + 1], P[i:i + 1]) for i in range(n)])
-    assert ha.ha_point_op(cid, group, 3, _p(P), _p(Q), _p(out), n) == 0
+    assert point_op(cid, group, 3, _p(P), _p(Q), _p(out), n) == 0
     assert np.array_equal(out, exp)
     # scalar multiplication by 256-bit integers (first 32 bytes of each Q slot hold k)
     K = Q.copy()
@@ -98,5 +104,29 @@ def test_point_ops(ha, curve, group):
     ks[4], ks[5] = 0, 1
     K[:, :4] = corc.ints_to_arr(ks, 4)
     exp = np.concatenate([corc.point_mul(curve, group, P[i:i + 1], ks[i]) for i in range(n)])
-    assert ha.ha_point_op(cid, group, 4, _p(P), _p(K), _p(out), n) == 0
+    assert point_op(cid, group, 4, _p(P), _p(K), _p(out), n) == 0
+    assert np.array_equal(out, exp)
+
+
+@pytest.mark.parametrize("curve", ["bn254", "bls12_381", "bls12_377"])
+@pytest.mark.parametrize("kind", ["fq", "fr"])
+def test_reduced_radix_field_ops(ha, curve, kind):
+    """fp29.h: conversion in (x R32 -> x R), the operation on 29/28-bit limbs with lazy bounds, conversion out
+    (canonical) must equal the oracle's result; op 8 runs a long lazy chain through reduce() and is_zero()."""
+    F = (FQ if kind == "fq" else FR)[curve]
+    nl = F.limbs64
+    n = 300
+    A = corc.rand_field(curve, kind, 11, n)
+    B = corc.rand_field(curve, kind, 12, n)
+    edge = corc.ints_to_arr([0, F.R, F.p - 1, 1, F.to_mont(F.p - 1), F.to_mont(1)], nl)
+    A[:6] = edge
+    B[:6] = edge[::-1]
+    for op in ("add", "sub", "mul", "sqr", "neg"):
+        out = np.empty_like(A)
+        assert ha.ha_field_op29(corc.fid(curve, kind), corc.OPS[op], _p(A), _p(B), _p(out), n) == 0
+        assert np.array_equal(out, corc.field_op(curve, kind, op, A, B)), op
+    out = np.empty_like(A)
+    assert ha.ha_field_op29(corc.fid(curve, kind), 8, _p(A), _p(B), _p(out), n) == 0
+    f = lambda op, x, y=None: corc.field_op(curve, kind, op, x, y)   # noqa: E731
+    exp = f("sub", f("add", f("mul", f("add", A, B), f("sub", A, B)), f("mul", A, B)), f("sqr", B))
     assert np.array_equal(out, exp)

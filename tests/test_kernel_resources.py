@@ -30,8 +30,10 @@ def test_g1_bucket_accumulation_has_no_scratch_and_four_waves():
 
 def test_g2_bucket_accumulation_stages_through_lds_without_spilling():
     (r,) = find("msm_accumulate_lds_kernel<Fp2<bn254_fq>,256>").values()
-    assert r["lds"] == 65536 and r["occupancy"] == 2
-    assert r["scratch"] <= 64 and r["agprs"] == 0          # 16 B: the by-value multiply arguments
+    assert r["lds"] == 4 * 18 * 256 * 4 and r["occupancy"] == 2   # 4 coordinates x 2 x 9 limbs x 256 lanes: 2 blocks / CU
+    assert r["scratch"] == 0 and r["agprs"] == 0
+    (r,) = find("msm_accumulate_lds_kernel<Fp2<bls12_381_fq>,128>").values()
+    assert r["scratch"] == 0 and r["agprs"] == 0 and r["lds"] == 4 * 28 * 128 * 4
 
 
 def test_ntt_and_sort_kernels_are_register_and_lds_only():
