@@ -1,5 +1,6 @@
 // C ABI of libdg16 (include/dg16.h): argument checking, host<->device staging, error mapping.
 // All compute is in the HIP translation units next to this file; there is no CPU path.
+#include <stdlib.h>
 #include <string.h>
 
 #include "ctx.h"
@@ -34,13 +35,20 @@ int dg16_ctx_create(int device, dg16_ctx** out) {
     ctx->device = device;
     ctx->compute_units = p.multiProcessorCount;
     ctx->name = p.gcnArchName;
+    // Channel 0 carries the saturating kernels of a proof; channels 1, 2 and the aux streams carry the latency-bound
+    // bucket reductions that hide behind them: those get the higher priority, so that their few waves are scheduled
+    // ahead of the thousands of queued accumulation waves (DG16_SIDE_PRIORITY=0 switches it off).
+    int prio_lo = 0, prio_hi = 0;
+    DG_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+    const char* pe = getenv("DG16_SIDE_PRIORITY");
+    const bool side_prio = !(pe && atoi(pe) == 0);
     for (int i = 0; i < kChannels; i++) {
-      DG_HIP(hipStreamCreateWithFlags(&ctx->ch[i].own, hipStreamNonBlocking));
+      DG_HIP(hipStreamCreateWithPriority(&ctx->ch[i].own, hipStreamNonBlocking, (i > 0 && side_prio) ? prio_hi : prio_lo));
       ctx->ch[i].cur = ctx->ch[i].own;
       for (int e = 0; e < 4; e++) DG_HIP(hipEventCreate(&ctx->ch[i].ev[e]));
     }
     for (auto& e : ctx->pipe_ev) DG_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    for (auto& st : ctx->aux) DG_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    for (auto& st : ctx->aux) DG_HIP(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, side_prio ? prio_hi : prio_lo));
     DG_HIP(hipHostMalloc((void**)&ctx->dev_flag_host, sizeof(unsigned), hipHostMallocMapped));
     *ctx->dev_flag_host = 0;
     DG_HIP(hipHostGetDevicePointer((void**)&ctx->dev_flag, ctx->dev_flag_host, 0));

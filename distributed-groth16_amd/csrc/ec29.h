@@ -147,6 +147,82 @@ struct XYZZ29 {
     const auto y3 = r_ * (q_ - x3) - s1 * ppp;
     return {x3, fit<BS>(y3), fit<BS>((zz * o.zz) * pp), fit<BS>((zzz * o.zzz) * ppp)};
   }
+  // ---- the same operations on operands that stay in memory (LDS / global / private) --------------------------
+  // Coordinates are loaded where a product consumes them and results are stored as soon as every input has been
+  // read, so the live set is ~6 field elements instead of both points + the temporaries (an Fq2 addition of
+  // BLS12-381 would otherwise need > 512 registers).  dst may alias a or b.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define DG29_STAGE() asm volatile("" ::: "memory")   /* keep the loads where they are written */
+#else
+#define DG29_STAGE()
+#endif
+  DG_HD static void add_mem(XYZZ29* dst, const XYZZ29* a, const XYZZ29* b) {
+    if (b->is_inf()) {
+      if (dst != a) *dst = *a;
+      return;
+    }
+    if (a->is_inf()) {
+      if (dst != b) *dst = *b;
+      return;
+    }
+    const auto u1 = a->x * b->zz;
+    DG29_STAGE();
+    const auto p_ = norm(b->x * a->zz - u1);
+    DG29_STAGE();
+    const auto s1 = a->y * b->zzz;
+    DG29_STAGE();
+    const auto r_ = norm(b->y * a->zzz - s1);
+    DG29_STAGE();
+    if (is_zero(p_)) {
+      if (is_zero(r_)) {
+        const XYZZ29 d = a->dbl_pt();
+        *dst = d;
+      } else {
+        *dst = inf();
+      }
+      return;
+    }
+    const auto pp = sqr(p_);
+    const auto ppp = p_ * pp;
+    const auto zz3 = fit<BS>((a->zz * b->zz) * pp);
+    DG29_STAGE();
+    const auto zzz3 = fit<BS>((a->zzz * b->zzz) * ppp);
+    DG29_STAGE();
+    dst->zz = zz3;          // every coordinate of a and b has been read by now
+    dst->zzz = zzz3;
+    DG29_STAGE();
+    const auto q_ = u1 * pp;
+    const auto x3 = fit<BS>(sqr(r_) - (ppp + dbl(q_)));
+    dst->x = x3;
+    DG29_STAGE();
+    dst->y = fit<BS>(r_ * (q_ - x3) - s1 * ppp);
+  }
+  DG_HD static void dbl_mem(XYZZ29* dst, const XYZZ29* a) {
+    if (a->is_inf()) {
+      if (dst != a) *dst = *a;
+      return;
+    }
+    const auto u = dbl(a->y);
+    const auto v = sqr(u);
+    const auto w = u * v;
+    DG29_STAGE();
+    const auto s = a->x * v;
+    const auto xx = sqr(a->x);
+    DG29_STAGE();
+    const auto m = dbl(xx) + xx;
+    const auto x3 = fit<BS>(sqr(m) - dbl(s));
+    const auto y3 = fit<BS>(m * (s - x3) - w * a->y);
+    DG29_STAGE();
+    const auto zz3 = fit<BS>(v * a->zz);
+    const auto zzz3 = fit<BS>(w * a->zzz);
+    DG29_STAGE();
+    dst->x = x3;
+    dst->y = y3;
+    dst->zz = zz3;
+    dst->zzz = zzz3;
+  }
+#undef DG29_STAGE
+
   // -> the 32-bit-limb XYZZ of ec.h (arkworks Montgomery form, canonical): what the older kernels and the C ABI read
   DG_HD XYZZ<F> to_xyzz32() const {
     if (is_inf()) return XYZZ<F>::inf();

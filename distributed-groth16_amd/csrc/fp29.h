@@ -296,7 +296,7 @@ constexpr bool rr_cols_fit(int lu_products) { return RR<P>::N * (lu_products + 1
 namespace rr {
 // (a b + c d) / R mod p on raw limbs (c, d may be null); the caller has checked the column bound
 template <class P, bool DUAL>
-DG_HD void mont(uint32_t* __restrict__ r, const uint32_t* a, const uint32_t* b, const uint32_t* c, const uint32_t* d) {
+DG_HD void mont_inl(uint32_t* __restrict__ r, const uint32_t* a, const uint32_t* b, const uint32_t* c, const uint32_t* d) {
   using T = RR<P>;
   constexpr int N = T::N;
   uint64_t acc = 0;
@@ -330,7 +330,7 @@ DG_HD void mont(uint32_t* __restrict__ r, const uint32_t* a, const uint32_t* b, 
 }
 // a^2 / R mod p with the doubled operand: N (N + 1) / 2 + N^2 products
 template <class P>
-DG_HD void mont_sqr(uint32_t* __restrict__ r, const uint32_t* a) {
+DG_HD void mont_sqr_inl(uint32_t* __restrict__ r, const uint32_t* a) {
   using T = RR<P>;
   constexpr int N = T::N;
   uint32_t a2[N];
@@ -361,6 +361,68 @@ DG_HD void mont_sqr(uint32_t* __restrict__ r, const uint32_t* a) {
   }
   r[N - 1] = (uint32_t)acc;
 }
+// Translation units of LATENCY-bound kernels (the bucket reduction: chains of a few dozen dependent group operations
+// at ~1 wave per SIMD) define DG29_OUTLINE_MUL: the products become calls (operands by value in VGPRs) so that a
+// group addition is ~4 KB of code instead of ~45 KB (G1) / ~120 KB (BN254 G2) / ~250 KB (BLS12-381 G2) -- the
+// instruction cache is 64 KB per two CUs, and the inlined kernels were instruction-fetch-bound (measured: 55 us per
+// dependent G1 addition against ~8 us of issue time).  Throughput kernels (bucket accumulation) keep them inline.
+#if defined(__HIP_DEVICE_COMPILE__) && defined(DG29_OUTLINE_MUL)
+template <class P>
+struct RawFe {
+  uint32_t l[RR<P>::N];
+};
+template <class P>
+__device__ __attribute__((noinline)) RawFe<P> mont_call(RawFe<P> a, RawFe<P> b) {
+  RawFe<P> r;
+  mont_inl<P, false>(r.l, a.l, b.l, nullptr, nullptr);
+  return r;
+}
+template <class P>
+__device__ __attribute__((noinline)) RawFe<P> mont_dual_call(RawFe<P> a, RawFe<P> b, RawFe<P> c, RawFe<P> d) {
+  RawFe<P> r;
+  mont_inl<P, true>(r.l, a.l, b.l, c.l, d.l);
+  return r;
+}
+template <class P>
+__device__ __attribute__((noinline)) RawFe<P> mont_sqr_call(RawFe<P> a) {
+  RawFe<P> r;
+  mont_sqr_inl<P>(r.l, a.l);
+  return r;
+}
+template <class P, bool DUAL>
+__device__ __forceinline__ void mont(uint32_t* __restrict__ r, const uint32_t* a, const uint32_t* b, const uint32_t* c,
+                                     const uint32_t* d) {
+  RawFe<P> x, y, o;
+#pragma unroll
+  for (int i = 0; i < RR<P>::N; i++) { x.l[i] = a[i]; y.l[i] = b[i]; }
+  if constexpr (DUAL) {
+    RawFe<P> z, w;
+#pragma unroll
+    for (int i = 0; i < RR<P>::N; i++) { z.l[i] = c[i]; w.l[i] = d[i]; }
+    o = mont_dual_call<P>(x, y, z, w);
+  } else {
+    o = mont_call<P>(x, y);
+  }
+#pragma unroll
+  for (int i = 0; i < RR<P>::N; i++) r[i] = o.l[i];
+}
+template <class P>
+__device__ __forceinline__ void mont_sqr(uint32_t* __restrict__ r, const uint32_t* a) {
+  RawFe<P> x;
+#pragma unroll
+  for (int i = 0; i < RR<P>::N; i++) x.l[i] = a[i];
+  const RawFe<P> o = mont_sqr_call<P>(x);
+#pragma unroll
+  for (int i = 0; i < RR<P>::N; i++) r[i] = o.l[i];
+}
+#else
+template <class P, bool DUAL>
+DG_HD void mont(uint32_t* __restrict__ r, const uint32_t* a, const uint32_t* b, const uint32_t* c, const uint32_t* d) {
+  mont_inl<P, DUAL>(r, a, b, c, d);
+}
+template <class P>
+DG_HD void mont_sqr(uint32_t* __restrict__ r, const uint32_t* a) { mont_sqr_inl<P>(r, a); }
+#endif
 }  // namespace rr
 
 // a b / R.  An operand is normalised first when a column could overflow otherwise.

@@ -1,21 +1,41 @@
-// MSM / base generation / affine conversion instantiated for curve id 0 (bn254), G2.
+// MSM / base generation / affine conversion / d_msm / packexp for ONE (curve, group), selected at compile time:
+//   hipcc -DDG_CURVE=<0|1|2> -DDG_GROUP=<1|2> -DDG_NAME=<curve>_g<k> -c msm_group.hip -o msm_<curve>_g<k>.o
+// (one object per pair so that the heavy template instantiations compile in parallel; msm.hip dispatches on the
+// names).  The bucket reduction of the same pair is msm_reduce.hip.
 #include "msm_impl.h"
 #include "dist_impl.h"
 
+#define DG_CAT2(a, b) a##b
+#define DG_CAT(a, b) DG_CAT2(a, b)
+#define DG_FN(stem) DG_CAT(stem, DG_NAME)
+
 namespace dg16 {
-using CT = CurveTypes<0>;
-void msm_bn254_g2(Call& k, const void* bases, const void* scalars, size_t n, bool mont, bool affine, void* out) {
-  msm_run<CT::Fq2, CT::Fr, CT::SCALAR_BITS>(k, bases, scalars, n, mont, affine, out);
+using CT = CurveTypes<DG_CURVE>;
+#if DG_GROUP == 1
+using GF = CT::Fq;
+using GC = CT::G1c;
+#else
+using GF = CT::Fq2;
+using GC = CT::G2c;
+#endif
+
+// the host-side phases other translation units (the prover) call for this pair: instantiated here, `extern` there
+template void msm_accumulate_phase<GF>(hipStream_t, const MsmSort&, const MsmBuffers<GF>&, const void*);
+template void* msm_build_table<GF>(hipStream_t, const void*, size_t, unsigned, unsigned);
+template MsmSort msm_sort_on<CT::Fr, CT::SCALAR_BITS>(hipStream_t, Channel&, const void*, size_t, bool, bool, unsigned);
+
+void DG_FN(msm_)(Call& k, const void* bases, const void* scalars, size_t n, bool mont, bool affine, void* out) {
+  msm_run<GF, CT::Fr, CT::SCALAR_BITS>(k, bases, scalars, n, mont, affine, out);
 }
-void gen_bases_bn254_g2(Call& k, uint64_t seed, size_t n, void* out) { gen_bases_run<CT::Fq2, CT::G2c>(k, seed, n, out); }
-void to_affine_bn254_g2(Call& k, const void* jac, void* out, size_t n) { to_affine_run<CT::Fq2>(k, jac, out, n); }
+void DG_FN(gen_bases_)(Call& k, uint64_t seed, size_t n, void* out) { gen_bases_run<GF, GC>(k, seed, n, out); }
+void DG_FN(to_affine_)(Call& k, const void* jac, void* out, size_t n) { to_affine_run<GF>(k, jac, out, n); }
 
 // d_msm (dist-primitives/src/dmsm/mod.rs:70-98): local MSM of the share vectors, gather to the king, who
 // interpolates in the exponent (unpackexp, degree2) and sums the l secrets -- one n-term combination with
 // the constant scalars v_j = sum_i unpack2[i][j] -- then sends the same point to every party.
-void d_msm_bn254_g2(Call& k, const dg16_pss* pp, const dg16_net* net, int sid, const void* bases,
-                          const void* scalars, size_t n, bool mont, void* out_jac) {
-  using F = CT::Fq2;
+void DG_FN(d_msm_)(Call& k, const dg16_pss* pp, const dg16_net* net, int sid, const void* bases, const void* scalars,
+                   size_t n, bool mont, void* out_jac) {
+  using F = GF;
   using Fr = CT::Fr;
   const unsigned np = pp->n;
   Affine<F>* c_share = (Affine<F>*)ws(k.c, 18, sizeof(Affine<F>));
@@ -39,8 +59,9 @@ void d_msm_bn254_g2(Call& k, const dg16_pss* pp, const dg16_net* net, int sid, c
   hipLaunchKernelGGL(affine_to_jacobian_kernel<F>, dim3(1), dim3(1), 0, k.s(), got, (Jacobian<F>*)out_jac);
   DG_HIP(hipGetLastError());
 }
-void packexp_bn254_g2(Call& k, const dg16_pss* pp, int which, const void* in, size_t count, void* out) {
-  using F = CT::Fq2;
+// packexp_from_public / unpackexp (dmsm/mod.rs:7-68): the constant n x l matrices applied to group elements
+void DG_FN(packexp_)(Call& k, const dg16_pss* pp, int which, const void* in, size_t count, void* out) {
+  using F = GF;
   using Fr = CT::Fr;
   const unsigned cols = which == 0 ? pp->l : pp->n, rows = which == 0 ? pp->n : pp->l;
   const Fr* Mc = (const Fr*)pp->mats + 3 * pp->n * pp->l + (size_t)which * pp->n * pp->l;

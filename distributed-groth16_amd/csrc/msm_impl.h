@@ -23,6 +23,10 @@
 // histogram/offsets uint32 [W][2^(c-1)]; segment map uint32 and segment sums XYZZ [W][2^(c-1)+n/16];
 // buckets XYZZ [W][2^(c-1)].
 #pragma once
+#include <stdio.h>
+
+#include <chrono>
+
 #include "ctx.h"
 #include "ec29.h"
 #include "types.h"
@@ -500,8 +504,8 @@ __global__ void __launch_bounds__(256) msm_part_place_kernel(const uint2* __rest
 // Bases arrive in the library's INTERNAL form (msm_to_internal_kernel / msm_table_kernel): x || y, each coordinate
 // x R mod p of the reduced-radix representation (fp29.h) packed into the arkworks word count, identity = zeros.
 // The mixed additions run on 29/28-bit limbs with lazy bounds (ec29.h: 162 v_mad_u64_u32 per Fq product and no
-// carry or compare instructions, against 128 mad + 128 addc + ~70 others for the 32-bit product); the segment sum
-// leaves in the 32-bit arkworks form the reduction kernels read (4 conversions per >= 8 additions).
+// carry or compare instructions, against 128 mad + 128 addc + ~70 others for the 32-bit product); segment sums stay
+// in that representation for the bucket reduction below.
 template <class F>
 __device__ __forceinline__ Affine29<F> load_internal(const uint32_t* __restrict__ bases, unsigned idx) {
   constexpr int PW = 2 * FieldOf<F>::WORDS;               // words per point
@@ -524,7 +528,7 @@ msm_accumulate_kernel(const uint32_t* __restrict__ bases, size_t n,
                                                               const unsigned* __restrict__ seg_total,
                                                               const unsigned* __restrict__ seg_bucket,
                                                               const unsigned* __restrict__ entries,
-                                                              XYZZ<F>* __restrict__ seg_sum) {
+                                                              XYZZ29<F>* __restrict__ seg_sum) {
   const unsigned w = blockIdx.y;
   const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= seg_total[w]) return;
@@ -545,7 +549,7 @@ msm_accumulate_kernel(const uint32_t* __restrict__ bases, size_t n,
     acc = acc.madd(p, cur >> 31);
     cur = nxt;
   }
-  seg_sum[sslot] = acc.to_xyzz32();
+  seg_sum[sslot] = acc;
 }
 
 // ---- 4 (G2): the same segment accumulation with the accumulator staged through LDS -------------------------
@@ -559,7 +563,7 @@ msm_accumulate_lds_kernel(const uint32_t* __restrict__ bases, size_t n, MsmGeom 
                           const unsigned* __restrict__ offsets, const unsigned* __restrict__ counts,
                           const unsigned* __restrict__ seg_off, const unsigned* __restrict__ seg_total,
                           const unsigned* __restrict__ seg_bucket, const unsigned* __restrict__ entries,
-                          XYZZ<F>* __restrict__ seg_sum) {
+                          XYZZ29<F>* __restrict__ seg_sum) {
   using FO = FieldOf<F>;
   using S = typename FO::Store;
   constexpr int BS = FO::BS;
@@ -633,8 +637,8 @@ msm_accumulate_lds_kernel(const uint32_t* __restrict__ bases, size_t n, MsmGeom 
     st(1, y3);
     DG_STAGE();
   }
-  XYZZ<F> out = XYZZ<F>::inf();
-  if (!inf) out = XYZZ29<F>{ld(0), ld(1), ld(2), ld(3)}.to_xyzz32();
+  XYZZ29<F> out = XYZZ29<F>::inf();
+  if (!inf) out = XYZZ29<F>{ld(0), ld(1), ld(2), ld(3)};
   seg_sum[sslot] = out;
 #undef DG_STAGE
 }
@@ -758,203 +762,17 @@ __device__ __forceinline__ XYZZ<F> scalar_mul_wave(const XYZZ<F>& p, const uint3
   return acc;
 }
 
-// Giant buckets (a boolean witness puts half of ALL entries into bucket 0; the short top window of a c that does
-// not divide the scalar width does the same): two launches.  Stage 1 cuts the bucket's segment partials into
-// <= kGiantSlices slices, one workgroup each, and leaves every slice's sum IN PLACE in the slice's first
-// segment slot; stage 2 adds the slice sums.  (One workgroup per bucket chained 128 dependent additions per
-// lane for a 2^20-bit witness: 2.5 ms for G1, far more for G2.)
-constexpr unsigned kGiantSlices = 64;
-constexpr unsigned kGiantSliceSegs = 512;
-__device__ __forceinline__ void giant_geometry(unsigned nseg, unsigned& slices, unsigned& per) {
-  slices = (nseg + kGiantSliceSegs - 1) / kGiantSliceSegs;
-  if (slices > kGiantSlices) slices = kGiantSlices;
-  per = (nseg + slices - 1) / slices;
-  slices = (nseg + per - 1) / per;
-}
-
-// ---- 4b: bucket = sum of its segment partials -----------------------------------------------------
-template <class F>
-__global__ void __launch_bounds__(256) msm_finalize_kernel(MsmGeom g, const unsigned* __restrict__ counts,
-                                                            const unsigned* __restrict__ seg_off,
-                                                            const XYZZ<F>* __restrict__ seg_sum,
-                                                            XYZZ<F>* __restrict__ buckets,
-                                                            unsigned* __restrict__ giant_count,
-                                                            unsigned* __restrict__ giant_list, unsigned giant_cap) {
-  size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  size_t total = (size_t)g.bw << g.log_nb;
-  if (gid >= total) return;
-  const unsigned w = (unsigned)(gid >> g.log_nb);
-  const unsigned nseg = (counts[gid] + (1u << g.seg_log) - 1) >> g.seg_log;
-  if (nseg == 0) { buckets[gid] = XYZZ<F>::inf(); return; }
-  const XYZZ<F>* sp = seg_sum + (size_t)w * g.seg_cap + seg_off[gid];
-  if (nseg == 1) { buckets[gid] = sp[0]; return; }
-  if (nseg > kGiantSegs) {
-    unsigned slot = atomicAdd(giant_count, 1u);
-    if (slot < giant_cap) {
-      giant_list[slot] = (unsigned)gid;
-      unsigned slices, per;
-      giant_geometry(nseg, slices, per);
-      unsigned wb = atomicAdd(giant_count + 1, slices);   // work items: (giant, slice)
-      unsigned* work = giant_list + giant_cap;
-      for (unsigned k = 0; k < slices; k++) work[wb + k] = (slot << 6) | k;
-      return;
-    }
-    // list full (cannot happen: giant_cap >= total segments / kGiantSegs): fall through, serial
-  }
-  XYZZ<F> acc = sp[0];
-  for (unsigned s = 1; s < nseg; s++) acc = acc.add(sp[s]);
-  buckets[gid] = acc;
-}
-
-template <class F>
-__global__ void __launch_bounds__(256) msm_giant_kernel(MsmGeom g, const unsigned* __restrict__ counts,
-                                                         const unsigned* __restrict__ seg_off,
-                                                         XYZZ<F>* __restrict__ seg_sum,
-                                                         const unsigned* __restrict__ giant_count,
-                                                         const unsigned* __restrict__ giant_list, unsigned giant_cap) {
-  __shared__ XYZZ<F> sh[256];
-  const unsigned nwork = giant_count[1];
-  const unsigned* work = giant_list + giant_cap;
-  for (unsigned wi = blockIdx.x; wi < nwork; wi += gridDim.x) {
-    const unsigned item = work[wi];
-    const unsigned gid = giant_list[item >> 6], slice = item & 63;
-    const unsigned w = gid >> g.log_nb;
-    const unsigned nseg = (counts[gid] + (1u << g.seg_log) - 1) >> g.seg_log;
-    unsigned slices, per;
-    giant_geometry(nseg, slices, per);
-    XYZZ<F>* sp = seg_sum + (size_t)w * g.seg_cap + seg_off[gid];
-    const unsigned lo = slice * per;
-    const unsigned hi = lo + per < nseg ? lo + per : nseg;
-    XYZZ<F> acc = XYZZ<F>::inf();
-    for (unsigned s = lo + threadIdx.x; s < hi; s += 256) acc = acc.add(sp[s]);
-    sh[threadIdx.x] = acc;
-    __syncthreads();
-    for (unsigned stride = 128; stride > 0; stride >>= 1) {
-      if (threadIdx.x < stride) sh[threadIdx.x] = sh[threadIdx.x].add(sh[threadIdx.x + stride]);
-      __syncthreads();
-    }
-    if (threadIdx.x == 0) sp[lo] = sh[0];
-    __syncthreads();
-  }
-}
-
-template <class F>
-__global__ void __launch_bounds__(64) msm_giant_fold_kernel(MsmGeom g, const unsigned* __restrict__ counts,
-                                                             const unsigned* __restrict__ seg_off,
-                                                             const XYZZ<F>* __restrict__ seg_sum,
-                                                             XYZZ<F>* __restrict__ buckets,
-                                                             const unsigned* __restrict__ giant_count,
-                                                             const unsigned* __restrict__ giant_list,
-                                                             unsigned giant_cap) {
-  __shared__ XYZZ<F> sh[kGiantSlices];
-  unsigned ng = *giant_count;
-  if (ng > giant_cap) ng = giant_cap;
-  for (unsigned gi = blockIdx.x; gi < ng; gi += gridDim.x) {
-    const unsigned gid = giant_list[gi];
-    const unsigned w = gid >> g.log_nb;
-    const unsigned nseg = (counts[gid] + (1u << g.seg_log) - 1) >> g.seg_log;
-    unsigned slices, per;
-    giant_geometry(nseg, slices, per);
-    const XYZZ<F>* sp = seg_sum + (size_t)w * g.seg_cap + seg_off[gid];
-    sh[threadIdx.x] = threadIdx.x < slices ? sp[(size_t)threadIdx.x * per] : XYZZ<F>::inf();
-    __syncthreads();
-    for (unsigned stride = kGiantSlices / 2; stride > 0; stride >>= 1) {
-      if (threadIdx.x < stride) sh[threadIdx.x] = sh[threadIdx.x].add(sh[threadIdx.x + stride]);
-      __syncthreads();
-    }
-    if (threadIdx.x == 0) buckets[gid] = sh[0];
-    __syncthreads();
-  }
-}
-
-// small * p, small < 2^32
-template <class F>
-__device__ XYZZ<F> mul_small(const XYZZ<F>& p, unsigned k) {
-  XYZZ<F> acc = XYZZ<F>::inf();
-  if (k == 0) return acc;
-  int top = 31 - __clz(k);
-  for (int i = top; i >= 0; i--) {
-    acc = acc.dbl();
-    if ((k >> i) & 1) acc = acc.add(p);
-  }
-  return acc;
-}
-
-// ---- 5a: chunks of 2^kChunkLog buckets -> one weighted partial each -----------------------------
-// (A recursive running-sum scheme without the per-chunk scalar multiple does 2.4x fewer group operations
-// but chains ~200 dependent ones through a dozen small launches; measured 4x slower per MSM.  Keeping the
-// bucket count moderate -- c <= 17 in table mode -- makes this phase ~3 % of an MSM instead.)
-constexpr unsigned kChunkLog = 3;
-template <class F>
-__global__ void __launch_bounds__(256) msm_chunk_kernel(const XYZZ<F>* __restrict__ buckets, MsmGeom g,
-                                                         XYZZ<F>* __restrict__ partial) {
-  const unsigned log_chunks = g.log_nb > kChunkLog ? g.log_nb - kChunkLog : 0;
-  const unsigned L = 1u << (g.log_nb - log_chunks);
-  size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  size_t total = (size_t)g.bw << log_chunks;
-  if (gid >= total) return;
-  size_t w = gid >> log_chunks;
-  unsigned ch = (unsigned)(gid & (((size_t)1 << log_chunks) - 1));
-  unsigned lo = ch * L;
-  const XYZZ<F>* b = buckets + (w << g.log_nb) + lo;
-  XYZZ<F> run = XYZZ<F>::inf(), acc = XYZZ<F>::inf();
-  for (int j = (int)L - 1; j >= 0; j--) {
-    run = run.add(b[j]);
-    acc = acc.add(run);
-  }
-  // sum_j (lo + j + 1) * B[lo + j] = acc + lo * run
-  if (lo) acc = acc.add(mul_small<F>(run, lo));
-  partial[gid] = acc;
-}
-
-
-// plain sums: grid (slices, windows); one workgroup reduces `per_block` consecutive elements
-template <class F>
-__global__ void __launch_bounds__(256) msm_sum_kernel(const XYZZ<F>* __restrict__ in, unsigned in_stride,
-                                                       unsigned count, unsigned per_block,
-                                                       XYZZ<F>* __restrict__ out, unsigned out_stride,
-                                                       unsigned out_offset) {
-  __shared__ XYZZ<F> sh[256];
-  const XYZZ<F>* p = in + (size_t)blockIdx.y * in_stride;
-  unsigned lo = blockIdx.x * per_block;
-  unsigned hi = lo + per_block < count ? lo + per_block : count;
-  XYZZ<F> acc = XYZZ<F>::inf();
-  for (unsigned i = lo + threadIdx.x; i < hi; i += 256) acc = acc.add(p[i]);
-  sh[threadIdx.x] = acc;
-  __syncthreads();
-  for (unsigned stride = 128; stride > 0; stride >>= 1) {
-    if (threadIdx.x < stride) sh[threadIdx.x] = sh[threadIdx.x].add(sh[threadIdx.x + stride]);
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) out[(size_t)blockIdx.y * out_stride + out_offset + blockIdx.x] = sh[0];
-}
-
-// ---- 6: Horner tail ---------------------------------------------------------------------------------
-// W*c dependent doublings: inherently serial in the group, but not inside one doubling.  One wave runs the
-// chain; the 9 multiplications of an XYZZ doubling form 3 dependency levels (2 | 4 | 3 products), each level
-// is evaluated by different lanes at once and shared with readlane.  An Fq2 product is itself spread over three
-// lanes of a quad (Karatsuba).  One thread per MSM took 2.5 ms (G1) / 10.2 ms (G2) for the 256 doublings of a
-// 2^20-point MSM, as long as the bucket accumulation itself.
-template <class F>
-__global__ void __launch_bounds__(64) msm_tail_kernel(const XYZZ<F>* __restrict__ window_sums, MsmGeom g,
-                                                       int affine, F* __restrict__ out) {
-  // one wave, every lane carries the same running total
-  XYZZ<F> total = XYZZ<F>::inf();
-  for (int w = (int)g.bw - 1; w >= 0; w--) {
-    for (unsigned k = 0; k < g.c; k++) total = dbl_wave(total);
-    total = add_wave(total, window_sums[w]);
-  }
-  if (threadIdx.x != 0) return;
-  if (affine) {
-    Affine<F> a = total.to_affine();
-    out[0] = a.x;
-    out[1] = a.y;
-  } else {
-    Jacobian<F> j = total.to_jacobian();
-    out[0] = j.x;
-    out[1] = j.y;
-    out[2] = j.z;
-  }
+// rows of 2^kRowLog buckets
+constexpr unsigned kRowLog = 8;
+struct RowGeom {
+  unsigned row_log;    // log2 buckets per row (<= kRowLog)
+  unsigned rows_log;   // log2 rows per bucket-window
+};
+inline RowGeom row_geometry(const MsmGeom& g) {
+  RowGeom r;
+  r.row_log = g.log_nb < kRowLog ? g.log_nb : kRowLog;
+  r.rows_log = g.log_nb - r.row_log;
+  return r;
 }
 
 // Result of the scalar-side passes (digits, scan, scatter): shared by every MSM over the same scalars.
@@ -1047,16 +865,17 @@ MsmSort msm_sort_on(hipStream_t s, Channel& wsch, const void* scalars, size_t n,
 // Workspace of one MSM's bucket phases (lives in `wsch`'s slots 7, 17, 15, 10 until the reduction is done).
 template <class F>
 struct MsmBuffers {
-  XYZZ<F>* buckets;
-  XYZZ<F>* seg_sum;
-  XYZZ<F>* partial;
-  XYZZ<F>* slice_buf;
+  XYZZ29<F>* buckets;
+  XYZZ29<F>* seg_sum;
+  XYZZ29<F>* row_w;
+  XYZZ29<F>* row_r;
+  XYZZ29<F>* fold;
   XYZZ<F>* window_sums;
   unsigned* giant;
-  unsigned giant_cap, chunks, log_chunks;
-  size_t nbw, nchunks;
+  unsigned giant_cap;
+  size_t nbw, nrows;
+  RowGeom rg;
 };
-constexpr unsigned kSumSlices = 64;
 
 template <class F>
 MsmBuffers<F> msm_buffers(Channel& wsch, const MsmGeom& g) {
@@ -1064,14 +883,16 @@ MsmBuffers<F> msm_buffers(Channel& wsch, const MsmGeom& g) {
   b.nbw = (size_t)g.bw << g.log_nb;
   const size_t nseg_slots = (size_t)g.bw * g.seg_cap;
   b.giant_cap = (unsigned)(nseg_slots / kGiantSegs + 1);
-  b.buckets = (XYZZ<F>*)ws(wsch, 7, b.nbw * sizeof(XYZZ<F>));
-  b.seg_sum = (XYZZ<F>*)ws(wsch, 17, nseg_slots * sizeof(XYZZ<F>));
-  b.log_chunks = g.log_nb > kChunkLog ? g.log_nb - kChunkLog : 0;
-  b.chunks = 1u << b.log_chunks;
-  b.nchunks = (size_t)g.bw << b.log_chunks;
-  b.partial = (XYZZ<F>*)ws(wsch, 15, (b.nchunks + (size_t)g.bw * kSumSlices + g.bw) * sizeof(XYZZ<F>));
-  b.slice_buf = b.partial + b.nchunks;
-  b.window_sums = b.slice_buf + (size_t)g.bw * kSumSlices;
+  b.buckets = (XYZZ29<F>*)ws(wsch, 7, b.nbw * sizeof(XYZZ29<F>));
+  b.seg_sum = (XYZZ29<F>*)ws(wsch, 17, nseg_slots * sizeof(XYZZ29<F>));
+  b.rg = row_geometry(g);
+  b.nrows = (size_t)g.bw << b.rg.rows_log;
+  const size_t nfold = (size_t)g.bw * 3 * 256;
+  uint8_t* p15 = (uint8_t*)ws(wsch, 15, (2 * b.nrows + nfold) * sizeof(XYZZ29<F>) + g.bw * sizeof(XYZZ<F>));
+  b.row_w = (XYZZ29<F>*)p15;
+  b.row_r = b.row_w + b.nrows;
+  b.fold = b.row_r + b.nrows;
+  b.window_sums = (XYZZ<F>*)(b.fold + nfold);
   // [0] giants, [1] work items, then giant_cap bucket ids, then <= 2 * giant_cap (giant, slice) work items
   b.giant = (unsigned*)ws(wsch, 10, ((size_t)b.giant_cap * 3 + 2) * 4);
   return b;
@@ -1096,44 +917,12 @@ void msm_accumulate_phase(hipStream_t s, const MsmSort& st, const MsmBuffers<F>&
   DG_HIP(hipGetLastError());
 }
 
-// Phase B (latency-bound, few waves): finalize -> chunk sums -> window sums -> tail.  May run on another
-// stream than phase A so that it hides behind the next MSM's accumulation.
+// Phase B (latency-bound, few waves): finalize -> giants -> rows -> top -> tail.  May run on another stream than
+// phase A so that it hides behind the next MSM's accumulation.  Defined in msm_reduce_impl.h and instantiated once per
+// (curve, group) in msm_reduce.hip -- a translation unit of its own because its kernels are compiled with out-of-line
+// field products (DG29_OUTLINE_MUL, fp29.h).
 template <class F>
-void msm_bucket_phase(hipStream_t s, const MsmSort& st, const MsmBuffers<F>& b, bool out_affine, void* out_dev) {
-  const MsmGeom& g = st.g;
-  DG_HIP(hipMemsetAsync(b.giant, 0, 8, s));
-  hipLaunchKernelGGL(msm_finalize_kernel<F>, dim3((unsigned)((b.nbw + 255) / 256)), dim3(256), 0, s, g, st.counts,
-                     st.seg_off, b.seg_sum, b.buckets, b.giant, b.giant + 2, b.giant_cap);
-  {
-    // few workgroups striding over the device-side work list: nothing to do (the common case) costs ~10 us
-    hipLaunchKernelGGL(msm_giant_kernel<F>, dim3(256), dim3(256), 0, s, g, st.counts, st.seg_off, b.seg_sum, b.giant,
-                       b.giant + 2, b.giant_cap);
-    hipLaunchKernelGGL(msm_giant_fold_kernel<F>, dim3(64), dim3(64), 0, s, g, st.counts, st.seg_off, b.seg_sum,
-                       b.buckets, b.giant, b.giant + 2, b.giant_cap);
-  }
-  // (one WAVE per chunk with the cooperative operations above was tried for the exposed last reduction and for
-  // short shards: 16 of 64 lanes useful and 4 levels per operation cost ~18x the multiplications; measured slower
-  // everywhere -- 2^20 proof 18.7 -> 18.9 ms, one rank of 8: 7.1 -> 8.6 ms -- so chunks stay one lane each)
-  hipLaunchKernelGGL(msm_chunk_kernel<F>, dim3((unsigned)((b.nchunks + 255) / 256)), dim3(256), 0, s, b.buckets, g,
-                     b.partial);
-  {
-    // two-stage plain sum of the chunk partials of every window
-    unsigned per_block = (b.chunks + kSumSlices - 1) / kSumSlices;
-    if (per_block < 256) per_block = 256;
-    unsigned slices = (b.chunks + per_block - 1) / per_block;
-    if (slices > 1) {
-      hipLaunchKernelGGL(msm_sum_kernel<F>, dim3(slices, g.bw), dim3(256), 0, s, b.partial, b.chunks, b.chunks,
-                         per_block, b.slice_buf, kSumSlices, 0u);
-      hipLaunchKernelGGL(msm_sum_kernel<F>, dim3(1, g.bw), dim3(256), 0, s, b.slice_buf, kSumSlices, slices, slices,
-                         b.window_sums, 1u, 0u);
-    } else {
-      hipLaunchKernelGGL(msm_sum_kernel<F>, dim3(1, g.bw), dim3(256), 0, s, b.partial, b.chunks, b.chunks, b.chunks,
-                         b.window_sums, 1u, 0u);
-    }
-  }
-  hipLaunchKernelGGL(msm_tail_kernel<F>, dim3(1), dim3(64), 0, s, b.window_sums, g, (int)out_affine, (F*)out_dev);
-  DG_HIP(hipGetLastError());
-}
+void msm_bucket_phase(hipStream_t s, const MsmSort& st, const MsmBuffers<F>& b, bool out_affine, void* out_dev);
 
 // both phases on the call's own stream and workspace
 template <class F>
@@ -1310,3 +1099,15 @@ void to_affine_run(Call& k, const void* jac, void* out, size_t n) {
 }
 
 }  // namespace dg16
+
+// Translation units that only CALL the MSM phases of a curve (the prover) declare them extern so that the kernels are
+// compiled once, in msm_group.hip / msm_reduce.hip:  namespace dg16 { DG16_MSM_EXTERN(CurveTypes<0>) }
+#define DG16_MSM_EXTERN_GROUP(F)                                                                                  \
+  extern template void msm_accumulate_phase<F>(hipStream_t, const MsmSort&, const MsmBuffers<F>&, const void*);   \
+  extern template void* msm_build_table<F>(hipStream_t, const void*, size_t, unsigned, unsigned);
+#define DG16_MSM_EXTERN(CT)                                                                                       \
+  DG16_MSM_EXTERN_GROUP(CT::Fq)                                                                                   \
+  DG16_MSM_EXTERN_GROUP(CT::Fq2)                                                                                  \
+  extern template MsmSort msm_sort_on<CT::Fr, CT::SCALAR_BITS>(hipStream_t, Channel&, const void*, size_t, bool, bool, \
+                                                              unsigned);
+

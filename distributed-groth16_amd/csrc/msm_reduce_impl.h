@@ -1,0 +1,433 @@
+// Bucket reduction of the MSM (phase B): sum_b (b + 1) B_b from the segment partials of phase A, and the Horner tail.
+// Included by msm_reduce.hip only, which is compiled once per (curve, group) with DG29_OUTLINE_MUL: these kernels are
+// chains of a few dozen dependent group operations at ~1 wave per SIMD, so they want SMALL code (the instruction cache
+// is 64 KB per two CUs; with every field product inlined a G1 addition was 45 KB and a BLS12-381 G2 addition 250 KB,
+// and the kernels were instruction-fetch-bound: 55 us per dependent G1 addition against ~8 us of issue time).
+#pragma once
+#include "msm_impl.h"
+
+namespace dg16 {
+
+// Giant buckets (a boolean witness puts half of ALL entries into bucket 0; the short top window of a c that does
+// not divide the scalar width does the same): two launches.  Stage 1 cuts the bucket's segment partials into
+// <= kGiantSlices slices, one workgroup each, and leaves every slice's sum IN PLACE in the slice's first
+// segment slot; stage 2 adds the slice sums.  (One workgroup per bucket chained 128 dependent additions per
+// lane for a 2^20-bit witness: 2.5 ms for G1, far more for G2.)
+constexpr unsigned kGiantSlices = 64;
+constexpr unsigned kGiantSliceSegs = 512;
+__device__ __forceinline__ void giant_geometry(unsigned nseg, unsigned& slices, unsigned& per) {
+  slices = (nseg + kGiantSliceSegs - 1) / kGiantSliceSegs;
+  if (slices > kGiantSlices) slices = kGiantSlices;
+  per = (nseg + slices - 1) / slices;
+  slices = (nseg + per - 1) / per;
+}
+
+// ---- 4b / 5: bucket reduction --------------------------------------------------------------------------------
+// sum_b (b + 1) B_b over the 2^(c-1) buckets of a bucket-window, B_b = sum of the bucket's segment partials.
+// Every phase is a short chain of dependent group operations (a lone lane needs ~5 us per G1 addition, ~15 us per
+// G2 addition), so the work is arranged for the shortest chains, not the fewest additions:
+//   finalize4   four lanes per bucket: strided partial sums + two shuffle steps (chain ~nseg/4 + 2 instead of nseg)
+//   giants      buckets with > kGiantSegs partials (boolean witnesses, short top windows): device-side work list,
+//               one workgroup per slice, then one fold per giant (unchanged idea, see giant_geometry)
+//   row         one workgroup per ROW of 256 buckets: suffix scan S_c = sum_{c' >= c} B_c' (8 steps) gives the row
+//               sum R = S_0, and the tree sum of the S_c (8 steps) gives W = sum_c (c + 1) B_c
+//   top         one workgroup per bucket-window: sum_r W_r (tree) and sum_r r R_r (serial running sums over the
+//               rows a lane owns, suffix scan + tree across lanes) on the two halves of the workgroup at once, then
+//               total = sum W + 256 * sum r R: 8 doublings and one addition
+// ~50 dependent operations per MSM instead of ~150 (finalize: ~16, 8-bucket chunks + 16-bit scalar multiple: ~40,
+// two 256-wide sums: ~70, each in its own launch at < 1 wave per SIMD).
+// The reduction kernels below are chains of a few dozen dependent group operations on operands that live in memory
+// (LDS / global).  Each kernel is written as ONE loop over a step schedule with exactly one addition site and one
+// doubling site (XYZZ29::add_mem / dbl_mem, inlined): an addition is ~4 000 (G1) to ~30 000 (BLS12-381 G2)
+// instructions, so a copy per call site made the library take 10 minutes to build, and an out-of-line copy behind
+// a call pays ~300 callee-saved register spills per call (and faulted for the largest type).
+template <class T>
+__device__ __forceinline__ T lane_xor_words(const T& v, int mask) {
+  static_assert(sizeof(T) % 4 == 0, "word-sized type");
+  T r;
+  const uint32_t* src = reinterpret_cast<const uint32_t*>(&v);
+  uint32_t* dst = reinterpret_cast<uint32_t*>(&r);
+#pragma unroll
+  for (unsigned i = 0; i < sizeof(T) / 4; i++) dst[i] = (uint32_t)__shfl_xor((int)src[i], mask);
+  return r;
+}
+
+template <class F>
+__global__ void __launch_bounds__(256) msm_finalize4_kernel(MsmGeom g, const unsigned* __restrict__ counts,
+                                                             const unsigned* __restrict__ seg_off,
+                                                             const XYZZ29<F>* __restrict__ seg_sum,
+                                                             XYZZ29<F>* __restrict__ buckets,
+                                                             unsigned* __restrict__ giant_count,
+                                                             unsigned* __restrict__ giant_list, unsigned giant_cap) {
+  const size_t gid4 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t gid = gid4 >> 2;
+  const unsigned q = (unsigned)gid4 & 3;
+  const size_t total = (size_t)g.bw << g.log_nb;
+  if (gid >= total) return;                 // whole quads leave together
+  const unsigned w = (unsigned)(gid >> g.log_nb);
+  const unsigned nseg = (counts[gid] + (1u << g.seg_log) - 1) >> g.seg_log;
+  if (nseg > kGiantSegs) {
+    if (q == 0) {
+      unsigned slot = atomicAdd(giant_count, 1u);
+      if (slot < giant_cap) {               // (always: giant_cap >= total segments / kGiantSegs)
+        giant_list[slot] = (unsigned)gid;
+        unsigned slices, per;
+        giant_geometry(nseg, slices, per);
+        unsigned wb = atomicAdd(giant_count + 1, slices);   // work items: (giant, slice)
+        unsigned* work = giant_list + giant_cap;
+        for (unsigned k = 0; k < slices; k++) work[wb + k] = (slot << 6) | k;
+      }
+    }
+    return;
+  }
+  const XYZZ29<F>* sp = seg_sum + (size_t)w * g.seg_cap + seg_off[gid];
+  // one (inlined) addition site: strided partials first, then the two quad-exchange steps
+  XYZZ29<F> acc = XYZZ29<F>::inf();
+  const unsigned iters = (nseg + 3) >> 2;
+#pragma unroll 1
+  for (unsigned it = 0; it < iters + 2; it++) {
+    XYZZ29<F> o;
+    if (it < iters) {
+      const unsigned s = q + 4 * it;
+      o = s < nseg ? sp[s] : XYZZ29<F>::inf();
+    } else {
+      o = lane_xor_words(acc, 1 << (it - iters));
+    }
+    acc = acc.add(o);
+  }
+  if (q == 0) buckets[gid] = acc;
+}
+
+// The same for quadratic-extension coordinates: with the accumulator in registers an Fq2 addition needs > 256 VGPRs
+// (one wave per SIMD); here every lane's accumulator lives in LDS (add_mem reads its operands where a product
+// consumes them), and the quad exchange reads the neighbour's accumulator straight from LDS.  Lanes of a quad run in
+// lockstep inside one wave, so a compiler + LDS-counter barrier between steps is all the ordering they need.
+template <class F, int BLOCK>
+__global__ void __launch_bounds__(BLOCK) msm_finalize4_lds_kernel(MsmGeom g, const unsigned* __restrict__ counts,
+                                                                  const unsigned* __restrict__ seg_off,
+                                                                  const XYZZ29<F>* __restrict__ seg_sum,
+                                                                  XYZZ29<F>* __restrict__ buckets,
+                                                                  unsigned* __restrict__ giant_count,
+                                                                  unsigned* __restrict__ giant_list, unsigned giant_cap) {
+  __shared__ XYZZ29<F> acc[BLOCK];
+  const size_t gid4 = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+  const size_t gid = gid4 >> 2;
+  const unsigned q = (unsigned)gid4 & 3;
+  const size_t total = (size_t)g.bw << g.log_nb;
+  if (gid >= total) return;                 // whole quads leave together
+  const unsigned w = (unsigned)(gid >> g.log_nb);
+  const unsigned nseg = (counts[gid] + (1u << g.seg_log) - 1) >> g.seg_log;
+  if (nseg > kGiantSegs) {
+    if (q == 0) {
+      unsigned slot = atomicAdd(giant_count, 1u);
+      if (slot < giant_cap) {
+        giant_list[slot] = (unsigned)gid;
+        unsigned slices, per;
+        giant_geometry(nseg, slices, per);
+        unsigned wb = atomicAdd(giant_count + 1, slices);
+        unsigned* work = giant_list + giant_cap;
+        for (unsigned k = 0; k < slices; k++) work[wb + k] = (slot << 6) | k;
+      }
+    }
+    return;
+  }
+  const XYZZ29<F>* sp = seg_sum + (size_t)w * g.seg_cap + seg_off[gid];
+  XYZZ29<F>* me = &acc[threadIdx.x];
+  *me = XYZZ29<F>::inf();
+  const unsigned iters = (nseg + 3) >> 2;
+#pragma unroll 1
+  for (unsigned it = 0; it < iters + 2; it++) {
+    const XYZZ29<F>* b;
+    bool on;
+    if (it < iters) {
+      const unsigned s = q + 4 * it;
+      on = s < nseg;
+      b = sp + (on ? s : 0);
+    } else {
+      const unsigned d = 1u << (it - iters);          // 1: lanes 0, 2 take their neighbour; 2: lane 0 takes lane 2
+      on = (q & (2 * d - 1)) == 0;
+      b = me + (on ? d : 0);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (on) XYZZ29<F>::add_mem(me, me, b);
+  }
+  if (q == 0) buckets[gid] = *me;
+}
+
+template <class F>
+__global__ void __launch_bounds__(256) msm_giant_kernel(MsmGeom g, const unsigned* __restrict__ counts,
+                                                         const unsigned* __restrict__ seg_off,
+                                                         XYZZ29<F>* __restrict__ seg_sum,
+                                                         const unsigned* __restrict__ giant_count,
+                                                         const unsigned* __restrict__ giant_list, unsigned giant_cap) {
+  __shared__ XYZZ29<F> sh[256];
+  const unsigned nwork = giant_count[1];
+  const unsigned* work = giant_list + giant_cap;
+  for (unsigned wi = blockIdx.x; wi < nwork; wi += gridDim.x) {
+    const unsigned item = work[wi];
+    const unsigned gid = giant_list[item >> 6], slice = item & 63;
+    const unsigned w = gid >> g.log_nb;
+    const unsigned nseg = (counts[gid] + (1u << g.seg_log) - 1) >> g.seg_log;
+    unsigned slices, per;
+    giant_geometry(nseg, slices, per);
+    XYZZ29<F>* sp = seg_sum + (size_t)w * g.seg_cap + seg_off[gid];
+    const unsigned lo = slice * per;
+    const unsigned hi = lo + per < nseg ? lo + per : nseg;
+    sh[threadIdx.x] = XYZZ29<F>::inf();
+    __syncthreads();
+    // steps 0 .. iters-1: strided partials of the slice; then 8 tree steps
+    const unsigned iters = (hi - lo + 255) >> 8;
+#pragma unroll 1
+    for (unsigned step = 0; step < iters + 8; step++) {
+      const XYZZ29<F>* b;
+      bool on;
+      if (step < iters) {
+        const unsigned s = lo + step * 256 + threadIdx.x;
+        on = s < hi;
+        b = &sp[on ? s : lo];
+      } else {
+        const unsigned stride = 128u >> (step - iters);
+        on = threadIdx.x < stride;
+        b = &sh[(threadIdx.x + stride) & 255];
+      }
+      if (on) XYZZ29<F>::add_mem(&sh[threadIdx.x], &sh[threadIdx.x], b);
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) sp[lo] = sh[0];
+    __syncthreads();
+  }
+}
+
+template <class F>
+__global__ void __launch_bounds__(64) msm_giant_fold_kernel(MsmGeom g, const unsigned* __restrict__ counts,
+                                                             const unsigned* __restrict__ seg_off,
+                                                             const XYZZ29<F>* __restrict__ seg_sum,
+                                                             XYZZ29<F>* __restrict__ buckets,
+                                                             const unsigned* __restrict__ giant_count,
+                                                             const unsigned* __restrict__ giant_list,
+                                                             unsigned giant_cap) {
+  __shared__ XYZZ29<F> sh[kGiantSlices];
+  unsigned ng = *giant_count;
+  if (ng > giant_cap) ng = giant_cap;
+  for (unsigned gi = blockIdx.x; gi < ng; gi += gridDim.x) {
+    const unsigned gid = giant_list[gi];
+    const unsigned w = gid >> g.log_nb;
+    const unsigned nseg = (counts[gid] + (1u << g.seg_log) - 1) >> g.seg_log;
+    unsigned slices, per;
+    giant_geometry(nseg, slices, per);
+    const XYZZ29<F>* sp = seg_sum + (size_t)w * g.seg_cap + seg_off[gid];
+    sh[threadIdx.x] = threadIdx.x < slices ? sp[(size_t)threadIdx.x * per] : XYZZ29<F>::inf();
+    __syncthreads();
+#pragma unroll 1
+    for (unsigned stride = kGiantSlices / 2; stride > 0; stride >>= 1) {
+      if (threadIdx.x < stride) XYZZ29<F>::add_mem(&sh[threadIdx.x], &sh[threadIdx.x], &sh[threadIdx.x + stride]);
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) buckets[gid] = sh[0];
+    __syncthreads();
+  }
+}
+
+template <class F>
+__global__ void __launch_bounds__(256) msm_row_kernel(MsmGeom g, RowGeom rg, const XYZZ29<F>* __restrict__ buckets,
+                                                       XYZZ29<F>* __restrict__ row_w, XYZZ29<F>* __restrict__ row_r) {
+  __shared__ XYZZ29<F> sh[256];
+  const unsigned c = threadIdx.x, row = 1u << rg.row_log;
+  const size_t rid = ((size_t)blockIdx.y << rg.rows_log) + blockIdx.x;      // (bucket-window, row)
+  sh[c] = c < row ? buckets[(rid << rg.row_log) + c] : XYZZ29<F>::inf();
+  __syncthreads();
+  // steps 0 .. row_log-1: inclusive suffix scan sh[c] <- sum_{c' >= c} B_c' (then sh[0] = R);
+  // steps row_log .. 2 row_log - 1: tree sum of the suffix sums = sum_c (c + 1) B_c
+#pragma unroll 1
+  for (unsigned step = 0; step < 2 * rg.row_log; step++) {
+    const bool scan = step < rg.row_log;
+    const unsigned d = scan ? 1u << step : row >> (step - rg.row_log + 1);
+    const bool on = scan ? c + d < row : c < d;
+    if (step == rg.row_log && c == 0) row_r[rid] = sh[0];
+    XYZZ29<F> v;
+    if (on) XYZZ29<F>::add_mem(&v, &sh[c], &sh[(c + d) & 255]);
+    __syncthreads();
+    if (on) sh[c] = v;
+    __syncthreads();
+  }
+  if (c == 0) {
+    if (rg.row_log == 0) row_r[rid] = sh[0];
+    row_w[rid] = sh[0];
+  }
+}
+
+// Bucket-windows with more than 256 rows (tables with c >= 18): every lane of the top kernel owns `per` consecutive
+// rows; their plain sums (W: half 0, R: half 1) and, for R, the lane-local weighted sum sum_j j R_j, are taken here
+// (serial running sums: 2 per operations) so that the top kernel always starts from <= 256 entries per half.
+template <class F>
+__global__ void __launch_bounds__(64) msm_rowfold_kernel(RowGeom rg, const XYZZ29<F>* __restrict__ row_w,
+                                                          const XYZZ29<F>* __restrict__ row_r,
+                                                          XYZZ29<F>* __restrict__ fold /* [bw][3][256]: W, R, local */) {
+  __shared__ XYZZ29<F> st[64][2];      // [lane][run, acc]
+  const unsigned gid = blockIdx.x * 64 + threadIdx.x;   // (half, t)
+  const unsigned half = gid >> 8, t = gid & 255;
+  const unsigned per_log = rg.rows_log - 8, per = 1u << per_log;
+  const size_t base = ((size_t)blockIdx.y << rg.rows_log) + (size_t)t * per;
+  XYZZ29<F>* run = &st[threadIdx.x][0];
+  XYZZ29<F>* acc = &st[threadIdx.x][1];
+  *run = XYZZ29<F>::inf();
+  *acc = XYZZ29<F>::inf();
+#pragma unroll 1
+  for (unsigned k = 0; k < 2 * per; k++) {
+    const unsigned j = per - 1 - (k >> 1);
+    // even k: acc += run (only the weighted half, and not before the first row); odd k: run += row j
+    const bool first = (k & 1) == 0;
+    const bool on = first ? (half == 1 && j + 1 < per) : true;
+    const XYZZ29<F>* b = first ? run : (half == 0 ? row_w : row_r) + base + j;
+    if (on) XYZZ29<F>::add_mem(first ? acc : run, first ? acc : run, b);
+  }
+  XYZZ29<F>* out = fold + (size_t)blockIdx.y * 3 * 256;
+  out[half * 256 + t] = *run;
+  if (half == 1) out[2 * 256 + t] = *acc;
+}
+
+// one workgroup per bucket-window; HALVES = 2: 512 lanes, lanes 0..255 sum_r W_r and lanes 256..511 sum_r r R_r at
+// the same time; HALVES = 1 (types whose 512 LDS slots exceed the 160 KiB: BLS12-381 G2): 256 lanes, one pass after
+// the other.  window sum = sum W + 2^row_log * sum r R, written in the 32-bit arkworks form the tail / the C ABI read.
+//   sum_r r R_r = sum_t local_t + per * sum_t t run_t,   sum_t t run_t = sum_{u >= 1} suffix_u(run)
+template <class F, int HALVES>
+__global__ void __launch_bounds__(256 * HALVES) msm_top_kernel(RowGeom rg, const XYZZ29<F>* __restrict__ row_w,
+                                                                const XYZZ29<F>* __restrict__ row_r,
+                                                                const XYZZ29<F>* __restrict__ fold,
+                                                                XYZZ<F>* __restrict__ window_sums) {
+  __shared__ XYZZ29<F> sh[256 * HALVES];
+  __shared__ XYZZ29<F> keep;                       // HALVES == 1: sum W while the second pass runs
+  const unsigned t = threadIdx.x & 255;
+  const bool folded = rg.rows_log > 8;
+  const unsigned per_log = folded ? rg.rows_log - 8 : 0;
+  const unsigned lanes = folded ? 256u : 1u << rg.rows_log;       // entries per half
+  const size_t base = (size_t)blockIdx.x << rg.rows_log;
+  const XYZZ29<F>* fb = fold + (size_t)blockIdx.x * 3 * 256;
+  XYZZ29<F>* me = &sh[threadIdx.x];
+#pragma unroll 1
+  for (int pass = 0; pass < 3 - HALVES; pass++) {
+    const unsigned half = HALVES == 2 ? threadIdx.x >> 8 : (unsigned)pass;
+    *me = t < lanes ? (folded ? fb[half * 256 + t] : (half == 0 ? row_w : row_r)[base + t]) : XYZZ29<F>::inf();
+    __syncthreads();
+    // schedule: 8 scan steps (weighted half) | drop suffix_0 | per_log doublings | + local (folded) | 8 tree steps |
+    // weighted half's lane 0 only: row_log doublings | + sum W  (total = sum W + 2^row_log * sum r R)
+    const unsigned s_tree = 9 + per_log, s_fin = s_tree + 8, n_steps = s_fin + rg.row_log + 1;
+    const XYZZ29<F>* wsum = HALVES == 2 ? &sh[0] : &keep;
+#pragma unroll 1
+    for (unsigned step = 0; step < n_steps; step++) {
+      XYZZ29<F> v;
+      bool on = false, is_dbl = false;
+      const XYZZ29<F>* b = me;
+      if (step < 8) {
+        const unsigned d = 1u << step;
+        on = half == 1 && t + d < 256;
+        b = me + (on ? d : 0);
+      } else if (step < 8 + per_log) {
+        on = half == 1;
+        is_dbl = true;
+      } else if (step == 8 + per_log) {
+        on = half == 1 && folded;
+        b = fb + 2 * 256 + t;
+      } else if (step < s_fin) {
+        const unsigned stride = 128u >> (step - s_tree);
+        on = t < stride;
+        b = me + (on ? stride : 0);
+      } else {
+        on = half == 1 && t == 0;
+        is_dbl = step < s_fin + rg.row_log;
+        b = wsum;
+      }
+      if (step == 8 && half == 1 && t == 0) *me = XYZZ29<F>::inf();   // weight t starts at 0: drop suffix_0
+      if (on) {
+        if (is_dbl) XYZZ29<F>::dbl_mem(&v, me);
+        else XYZZ29<F>::add_mem(&v, me, b);
+      }
+      __syncthreads();
+      if (on) *me = v;
+      __syncthreads();
+    }
+    if (HALVES == 1 && pass == 0) {
+      if (threadIdx.x == 0) keep = sh[0];
+      __syncthreads();
+    }
+  }
+  if (threadIdx.x == (HALVES == 2 ? 256u : 0u)) window_sums[blockIdx.x] = sh[threadIdx.x].to_xyzz32();
+}
+
+// ---- 6: Horner tail ---------------------------------------------------------------------------------
+// W*c dependent doublings: inherently serial in the group, but not inside one doubling.  One wave runs the
+// chain; the 9 multiplications of an XYZZ doubling form 3 dependency levels (2 | 4 | 3 products), each level
+// is evaluated by different lanes at once and shared with readlane.  An Fq2 product is itself spread over three
+// lanes of a quad (Karatsuba).  One thread per MSM took 2.5 ms (G1) / 10.2 ms (G2) for the 256 doublings of a
+// 2^20-point MSM, as long as the bucket accumulation itself.
+template <class F>
+__global__ void __launch_bounds__(64) msm_tail_kernel(const XYZZ<F>* __restrict__ window_sums, MsmGeom g,
+                                                       int affine, F* __restrict__ out) {
+  // one wave, every lane carries the same running total
+  XYZZ<F> total = XYZZ<F>::inf();
+  for (int w = (int)g.bw - 1; w >= 0; w--) {
+    for (unsigned k = 0; k < g.c; k++) total = dbl_wave(total);
+    total = add_wave(total, window_sums[w]);
+  }
+  if (threadIdx.x != 0) return;
+  if (affine) {
+    Affine<F> a = total.to_affine();
+    out[0] = a.x;
+    out[1] = a.y;
+  } else {
+    Jacobian<F> j = total.to_jacobian();
+    out[0] = j.x;
+    out[1] = j.y;
+    out[2] = j.z;
+  }
+}
+
+// Phase B (latency-bound, few waves): finalize -> giants -> rows -> top -> tail.  May run on another stream than
+// phase A so that it hides behind the next MSM's accumulation.
+// DG16_TRACE=1: synchronise after every launch of the bucket phase and print its wall time (debugging aid)
+inline void trace_point(hipStream_t s, const char* what) {
+  static const bool on = [] { const char* e = getenv("DG16_TRACE"); return e && atoi(e) != 0; }();
+  if (!on) return;
+  static thread_local std::chrono::steady_clock::time_point last = std::chrono::steady_clock::now();
+  hipError_t e = hipStreamSynchronize(s);
+  auto now = std::chrono::steady_clock::now();
+  fprintf(stderr, "[dg16 trace] %-24s %9.3f ms  %s\n", what, std::chrono::duration<double, std::milli>(now - last).count(),
+          e == hipSuccess ? "" : hipGetErrorString(e));
+  last = now;
+}
+
+template <class F>
+void msm_bucket_phase(hipStream_t s, const MsmSort& st, const MsmBuffers<F>& b, bool out_affine, void* out_dev) {
+  const MsmGeom& g = st.g;
+  trace_point(s, "(before bucket phase)");
+  DG_HIP(hipMemsetAsync(b.giant, 0, 8, s));
+  if constexpr (FieldOf<F>::EXT) {
+    constexpr int BLOCK = sizeof(XYZZ29<F>) * 256 <= 80 * 1024 ? 256 : 128;     // two workgroups per CU (160 KiB LDS)
+    hipLaunchKernelGGL((msm_finalize4_lds_kernel<F, BLOCK>), dim3((unsigned)((b.nbw * 4 + BLOCK - 1) / BLOCK)), dim3(BLOCK),
+                       0, s, g, st.counts, st.seg_off, b.seg_sum, b.buckets, b.giant, b.giant + 2, b.giant_cap);
+  } else {
+    hipLaunchKernelGGL(msm_finalize4_kernel<F>, dim3((unsigned)((b.nbw * 4 + 255) / 256)), dim3(256), 0, s, g,
+                       st.counts, st.seg_off, b.seg_sum, b.buckets, b.giant, b.giant + 2, b.giant_cap);
+  }
+  trace_point(s, "finalize4");
+  // few workgroups striding over the device-side work list: nothing to do (the common case) costs ~10 us
+  hipLaunchKernelGGL(msm_giant_kernel<F>, dim3(256), dim3(256), 0, s, g, st.counts, st.seg_off, b.seg_sum, b.giant,
+                     b.giant + 2, b.giant_cap);
+  hipLaunchKernelGGL(msm_giant_fold_kernel<F>, dim3(64), dim3(64), 0, s, g, st.counts, st.seg_off, b.seg_sum,
+                     b.buckets, b.giant, b.giant + 2, b.giant_cap);
+  trace_point(s, "giant + fold");
+  hipLaunchKernelGGL(msm_row_kernel<F>, dim3(1u << b.rg.rows_log, g.bw), dim3(256), 0, s, g, b.rg, b.buckets, b.row_w,
+                     b.row_r);
+  trace_point(s, "row");
+  if (b.rg.rows_log > 8)
+    hipLaunchKernelGGL(msm_rowfold_kernel<F>, dim3(8, g.bw), dim3(64), 0, s, b.rg, b.row_w, b.row_r, b.fold);
+  constexpr int HALVES = sizeof(XYZZ29<F>) * 513 <= 160 * 1024 ? 2 : 1;
+  hipLaunchKernelGGL((msm_top_kernel<F, HALVES>), dim3(g.bw), dim3(256 * HALVES), 0, s, b.rg, b.row_w, b.row_r,
+                     b.fold, b.window_sums);
+  trace_point(s, "top");
+  hipLaunchKernelGGL(msm_tail_kernel<F>, dim3(1), dim3(64), 0, s, b.window_sums, g, (int)out_affine, (F*)out_dev);
+  trace_point(s, "tail");
+  DG_HIP(hipGetLastError());
+}
+
+}  // namespace dg16

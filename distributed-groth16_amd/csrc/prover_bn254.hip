@@ -1,4 +1,10 @@
 // Groth16 prover instantiated for curve id 0 (bn254).
+#include "msm_impl.h"
+
+namespace dg16 {
+DG16_MSM_EXTERN(CurveTypes<0>)   // compiled in msm_group.hip / msm_reduce.hip
+}  // namespace dg16
+
 #include "prover_impl.h"
 
 namespace dg16 {

@@ -118,6 +118,25 @@ template <class F> static void point_op29(int op, const Affine<F>* a, const Affi
         XYZZ29<F> B = XYZZ29<F>::inf().madd(pb, false);
         XYZZ29<F> A3 = A.dbl_pt().add(A), B3 = B.dbl_pt().add(B);
         r = A3.add(B3).add(A.dbl_pt().neg_pt()).add(B.dbl_pt().neg_pt());
+        // the memory-operand forms (reduction kernels), incl. aliased destinations, must agree
+        XYZZ29<F> m3, t2 = A;
+        XYZZ29<F>::dbl_mem(&t2, &t2);                 // 2a (in place)
+        XYZZ29<F>::add_mem(&m3, &t2, &A);             // 3a
+        XYZZ29<F> n3 = B;
+        XYZZ29<F>::dbl_mem(&n3, &B);
+        XYZZ29<F>::add_mem(&n3, &n3, &B);             // 3b (dst aliases a)
+        XYZZ29<F>::add_mem(&n3, &m3, &n3);            // 3a + 3b (dst aliases b)
+        XYZZ29<F> na = A.dbl_pt().neg_pt(), nb = B.dbl_pt().neg_pt();
+        XYZZ29<F>::add_mem(&n3, &n3, &na);
+        XYZZ29<F>::add_mem(&n3, &n3, &nb);
+        XYZZ29<F> same = A, twice;                    // a + a through add_mem = the doubling branch
+        XYZZ29<F>::add_mem(&twice, &same, &A);
+        XYZZ29<F> chk = twice.add(A.dbl_pt().neg_pt());
+        {
+          XYZZ<F> x = r.to_xyzz32(), y = n3.to_xyzz32();
+          Affine<F> xa = x.to_affine(), ya = y.to_affine();
+          if (!(xa.x == ya.x) || !(xa.y == ya.y) || !(chk.is_inf() || A.is_inf())) r = XYZZ29<F>::inf().madd(pa, false);  // poison
+        }
         break;
       }
       case 1: r = A.dbl_pt().madd(pb, false).add(A.neg_pt()); break;
