@@ -86,6 +86,8 @@ void dg16_ctx_destroy(dg16_ctx* ctx) {
     if (kv.second.hi_scaled) hipFree(kv.second.hi_scaled);
     hipFree(kv.second.small);
     hipFree(kv.second.n_inv);
+    for (void* q : {kv.second.lo_i, kv.second.hi_i, kv.second.hi_scaled_i, kv.second.small_i, kv.second.n_inv_i})
+      if (q) hipFree(q);
   }
   delete ctx;
 }

@@ -45,6 +45,9 @@ struct TwiddleSet {   // all device pointers, 32-byte Fr elements
   void* small = nullptr;     // w_{2^sm}^t, t < 2^(sm-1)
   void* n_inv = nullptr;     // one element
   unsigned lb = 0, sm = 0;
+  // the same tables in the reduced-radix Montgomery form of fp29.h (x R, R = 2^261; packed, canonical): what the
+  // NTT kernels multiply by -- the arkworks-form tables above serve the dist-primitives mirror (dist_impl.h)
+  void *lo_i = nullptr, *hi_i = nullptr, *hi_scaled_i = nullptr, *small_i = nullptr, *n_inv_i = nullptr;
 };
 
 }  // namespace dg16

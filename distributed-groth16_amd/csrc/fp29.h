@@ -183,6 +183,15 @@ struct Fe {
     for (int i = 0; i < N; i++) r.l[i] = 0;
     return r;
   }
+  // same limbs under a TIGHTER static bound that the caller has proved by other means (a loop whose bound grows by
+  // a known amount per iteration cannot carry it in a loop-invariant type): unchecked
+  template <int B2, int LU2 = LU>
+  DG_HD Fe<P, B2, LU2> unsafe_assume() const {
+    Fe<P, B2, LU2> r;
+#pragma unroll
+    for (int i = 0; i < N; i++) r.l[i] = l[i];
+    return r;
+  }
   // same limbs under a looser static bound
   template <int B2, int LU2 = LU>
   DG_HD Fe<P, B2, LU2> as() const {

@@ -10,9 +10,16 @@
 // A workgroup owns a tile of 2^s points x T lines (T contiguous in memory => T*32-byte coalesced
 // segments), TILE = 1024 elements = 32 KiB of LDS, 256 threads, 2 butterflies/thread/level.
 //
-// Roofline: 64 B/element algorithmic traffic, but ~13 Montgomery multiplications per element at
-// 2^22 (~360 VALU instructions each) -- the kernel is VALU-bound, not HBM-bound.
+// Arithmetic: the reduced-radix representation of fp29.h (9 limbs of 29 bits, lazy bounds: a butterfly is one
+// 162-mad product + 18 plain additions, no carries or compares).  Data stays in the arkworks Montgomery form
+// (x R32) end to end: mont29(x R32, w R29) = x w R32, so only the TWIDDLE tables are held in the internal form.
+// The twiddles of the in-LDS butterflies are staged in LDS once per workgroup; two levels are taken per LDS round
+// trip (radix-4 steps: 4 products per 4 elements like radix-2, half the traffic and barriers).
+//
+// Roofline: 64 B/element algorithmic traffic, but ~10 Montgomery multiplications per element -- the kernel is
+// VALU-bound, not HBM-bound.
 #include "ctx.h"
+#include "fp29.h"
 #include "types.h"
 
 namespace dg16 {
@@ -46,16 +53,53 @@ __device__ __forceinline__ unsigned bitrev(unsigned v, unsigned bits) {
   return bits ? (__brev(v) >> (32 - bits)) : 0;
 }
 
+// bound (in p / 64) of a tile element between butterfly steps.  The first radix-4 step takes fresh loads (< 2 p)
+// to sums below 9 p; every later radix-4 step adds < 6 p to the bound of its inputs (x + t, then x - t + 3 p, twice,
+// with t a product < 2 p) and the odd last level < 3 p.  A step has at most (kMaxStepLog - 2) / 2 = 3 later radix-4
+// steps: true values stay below (9 + 18 + 3) p = 30 p < 40 p.  The static type cannot carry a bound that grows per
+// loop iteration, so the loop re-labels its results (Fe::unsafe_assume) -- this comment is the proof obligation.
+// 40 p + 6 p < 2^SLACK p for every scalar field (SLACK >= 6), which the types of the sums check at compile time.
+constexpr int kNttBound = 40 * 64;
+
 template <class F>
 __global__ void __launch_bounds__(256) ntt_step_kernel(StepArgs<F> p) {
-  __shared__ F tile[kTile];
+  using P = typename F::Params;
+  using T = RR<P>;
+  constexpr int N = T::N;
+  using El = Fe<P, kNttBound, 1>;
+  using Tw = Fe<P, 64, 1>;
+  __shared__ uint32_t tile_w[kTile * N];                               // [element][limb]: stride 9 words, conflict-free
+  __shared__ uint32_t tw_w[(1u << (kMaxStepLog - 1)) * N];            // w_{2^s}^t, t < 2^(s-1): this step's butterflies
   const unsigned tid = threadIdx.x;
   const unsigned s = p.s;
   const unsigned nj = 1u << s;
   const unsigned log_t = (p.log_n < kTileLog ? p.log_n : kTileLog) - s;  // lines per tile
-  const unsigned T = 1u << log_t;
+  const unsigned Tn = 1u << log_t;
   const unsigned elems = nj << log_t;
   const size_t tile_id = blockIdx.x;
+  // element e lives at slot e ^ ((e >> 2) & 31): with the odd word stride N every access pattern of the butterfly
+  // loops (32 lanes on 32 elements whose indices skip the two butterfly bits) and of the linear passes is free of
+  // bank conflicts (checked exhaustively for s = 4..9, tools/lds_swizzle_check.py)
+  auto slot = [](unsigned e) { return (e ^ ((e >> 2) & 31u)) * (unsigned)N; };
+  auto ld_tile = [&](unsigned i) {
+    El v;
+    const unsigned o = slot(i);
+#pragma unroll
+    for (int j = 0; j < N; j++) v.l[j] = tile_w[o + j];
+    return v;
+  };
+  auto st_tile = [&](unsigned i, const El& v) {
+    const unsigned o = slot(i);
+#pragma unroll
+    for (int j = 0; j < N; j++) tile_w[o + j] = v.l[j];
+  };
+  auto ld_tw = [&](unsigned i) {
+    Tw v;
+#pragma unroll
+    for (int j = 0; j < N; j++) v.l[j] = tw_w[i * N + j];
+    return v;
+  };
+  auto ld_packed = [&](const F* ptr) { return fe_from_words<P>(ptr->l); };   // a table entry (internal form) or data
 
   // tile origin
   size_t a = 0, b0 = 0, k1_0 = 0, k2 = 0;
@@ -70,12 +114,20 @@ __global__ void __launch_bounds__(256) ntt_step_kernel(StepArgs<F> p) {
     k1_0 = (tile_id & (((size_t)1 << k1_tiles_log) - 1)) << log_t;
   }
 
+  // ---- stage this step's butterfly twiddles: w_{2^s}^t = small[t << (sm - s)] ----
+  if (s >= 1)
+    for (unsigned t = tid; t < (nj >> 1); t += 256) {
+      const Tw w = ld_packed(p.small + ((size_t)t << (p.sm - s)));
+#pragma unroll
+      for (int j = 0; j < N; j++) tw_w[t * N + j] = w.l[j];
+    }
+
   // ---- load (bit-reversed rows so that in-place DIT yields natural order) ----
   for (unsigned idx = tid; idx < elems; idx += 256) {
     unsigned n, t;
     size_t g;
     if (!p.last) {
-      t = idx & (T - 1);
+      t = idx & (Tn - 1);
       n = idx >> log_t;
       g = ((((a << s) + n) << p.log_b) + b0 + t);
     } else {
@@ -83,62 +135,140 @@ __global__ void __launch_bounds__(256) ntt_step_kernel(StepArgs<F> p) {
       t = idx >> s;
       g = ((((k1_0 + t) << p.log_n2) + k2) << s) + n;
     }
-    F v = p.src[blockIdx.y][g];
+    const Tw x = ld_packed(p.src[blockIdx.y] + g);
+    El v = x.template as<kNttBound, 1>();
     if (p.pre_lo) {
-      F w = p.pre_lo[g & ((1u << p.plb) - 1)] * p.pre_hi[g >> p.plb];
-      v = v * w;
+      const auto w = ld_packed(p.pre_lo + (g & ((1u << p.plb) - 1))) * ld_packed(p.pre_hi + (g >> p.plb));
+      v = (x * w).template as<kNttBound, 1>();
     }
-    tile[(bitrev(n, s) << log_t) + t] = v;
-  }
-
-  // ---- s radix-2 DIT levels in LDS ----
-  const unsigned nbf = elems >> 1;
-  for (unsigned lv = 1; lv <= s; lv++) {
-    __syncthreads();
-    const unsigned half = 1u << (lv - 1);
-    for (unsigned q = tid; q < nbf; q += 256) {
-      unsigned t = q & (T - 1);
-      unsigned pi = q >> log_t;
-      unsigned k = pi & (half - 1);
-      unsigned blk = pi >> (lv - 1);
-      unsigned i0 = ((((blk << lv) + k)) << log_t) + t;
-      unsigned i1 = i0 + (half << log_t);
-      F x = tile[i0];
-      F y = tile[i1];
-      if (lv > 1) y = y * p.small[k << (p.sm - lv)];
-      tile[i0] = x + y;
-      tile[i1] = x - y;
-    }
+    st_tile((bitrev(n, s) << log_t) + t, v);
   }
   __syncthreads();
 
+  // ---- s radix-2 DIT levels in LDS, two per round trip (radix-4 steps), one plain level at the end when s is odd ----
+  // a radix-4 step on (xa, xb, xc, xd) at distance `half` lines: level lv pairs (a, b) and (c, d) with w_{2 half}^k,
+  // level lv + 1 pairs (a, c) with w_{4 half}^k and (b, d) with w_{4 half}^(k + half)
+  unsigned lv = 1;
+  if (s >= 2) {
+    // first step: half = 1, k = 0 -- three of the four twiddles are 1 and the inputs are fresh loads (< 2 p: canonical
+    // data, or the (1 + 3/64) p of a product with the coset table), so the sums are formed without products
+    using In = Fe<P, 128, 1>;
+    const Tw w3 = ld_tw(1u << (s - 2));        // w_4^1
+    for (unsigned q = tid; q < (elems >> 2); q += 256) {
+      const unsigned t = q & (Tn - 1), pi = q >> log_t;
+      const unsigned ia = (pi << (2 + log_t)) + t;
+      const In xa = ld_tile(ia).template unsafe_assume<128, 1>(), xb = ld_tile(ia + Tn).template unsafe_assume<128, 1>(),
+               xc = ld_tile(ia + 2 * Tn).template unsafe_assume<128, 1>(), xd = ld_tile(ia + 3 * Tn).template unsafe_assume<128, 1>();
+      const auto a1 = xa + xb;
+      const auto b1 = xa - xb;
+      const auto c1 = xc + xd;
+      const auto te = (xc - xd) * w3;
+      st_tile(ia, norm(a1 + c1).template as<kNttBound, 1>());
+      st_tile(ia + 2 * Tn, norm(a1 - c1).template as<kNttBound, 1>());
+      st_tile(ia + Tn, norm(b1 + te).template as<kNttBound, 1>());
+      st_tile(ia + 3 * Tn, norm(b1 - te).template as<kNttBound, 1>());
+    }
+    __syncthreads();
+    lv = 3;
+  }
+  for (; lv + 1 <= s; lv += 2) {
+    const unsigned half = 1u << (lv - 1);
+    const unsigned sh1 = s - lv, sh2 = s - lv - 1;
+    for (unsigned q = tid; q < (elems >> 2); q += 256) {
+      const unsigned t = q & (Tn - 1), pi = q >> log_t;
+      const unsigned k = pi & (half - 1), blk = pi >> (lv - 1);
+      const unsigned ia = ((((blk << (lv + 1)) + k)) << log_t) + t;
+      const unsigned st = half << log_t;
+      const El xa = ld_tile(ia), xb = ld_tile(ia + st), xc = ld_tile(ia + 2 * st), xd = ld_tile(ia + 3 * st);
+      const Tw w1 = ld_tw(k << sh1);
+      const auto tb = xb * w1;
+      const auto td = xd * w1;
+      const auto a1 = xa + tb;
+      const auto b1 = xa - tb;
+      const auto c1 = xc + td;
+      const auto d1 = xc - td;
+      const auto tc = c1 * ld_tw(k << sh2);
+      const auto te = d1 * ld_tw((k + half) << sh2);
+      // (see kNttBound: the static bound of each sum is within 6 p of El's; the true bound is tracked by the comment there)
+      st_tile(ia, norm(a1 + tc).template unsafe_assume<kNttBound, 1>());
+      st_tile(ia + 2 * st, norm(a1 - tc).template unsafe_assume<kNttBound, 1>());
+      st_tile(ia + st, norm(b1 + te).template unsafe_assume<kNttBound, 1>());
+      st_tile(ia + 3 * st, norm(b1 - te).template unsafe_assume<kNttBound, 1>());
+    }
+    __syncthreads();
+  }
+  if (lv == s) {
+    // the odd level: half = 2^(s - 1), twiddle w_{2^s}^k = tw[k]
+    const unsigned half = 1u << (s - 1);
+    for (unsigned q = tid; q < (elems >> 1); q += 256) {
+      const unsigned t = q & (Tn - 1), k = q >> log_t;
+      const unsigned i0 = (k << log_t) + t, i1 = i0 + (half << log_t);
+      const El x = ld_tile(i0);
+      const auto ty = ld_tile(i1) * ld_tw(k);
+      st_tile(i0, norm(x + ty).template unsafe_assume<kNttBound, 1>());
+      st_tile(i1, norm(x - ty).template unsafe_assume<kNttBound, 1>());
+    }
+    __syncthreads();
+  }
+
   // ---- twiddle + store ----
   for (unsigned idx = tid; idx < elems; idx += 256) {
-    unsigned t = idx & (T - 1);
+    unsigned t = idx & (Tn - 1);
     unsigned k = idx >> log_t;
-    F v = tile[(k << log_t) + t];
+    const El v = ld_tile((k << log_t) + t);
+    Fe<P, 64, 1> out;
     size_t g;
     if (!p.last) {
       size_t b = b0 + t;
       size_t e = (b * k) << p.log_a;   // < N
       if (e) {
-        F w = p.tw_lo[e & ((1u << p.lb) - 1)] * p.tw_hi[e >> p.lb];
-        v = v * w;
+        const auto w = ld_packed(p.tw_lo + (e & ((1u << p.lb) - 1))) * ld_packed(p.tw_hi + (e >> p.lb));
+        out = canon(v * w);
       } else if (p.scale) {
         // inverse transform with the n^-1 factor folded into tw_hi: e == 0 still needs it
-        v = v * p.tw_hi[0];
+        out = canon(v * ld_packed(p.tw_hi));
+      } else {
+        out = canon(v);
       }
       g = ((((a << s) + k) << p.log_b) + b);
     } else {
       g = (k1_0 + t) + (k2 << p.log_n1) + ((size_t)k << (p.log_n1 + p.log_n2));
-      if (p.scale) v = v * *p.scale;
-      if (p.post_lo) {
-        F w = p.post_lo[g & ((1u << p.plb) - 1)] * p.post_hi[g >> p.plb];
-        v = v * w;
+      if (p.scale && p.post_lo) {
+        const auto w = ld_packed(p.post_lo + (g & ((1u << p.plb) - 1))) * ld_packed(p.post_hi + (g >> p.plb));
+        out = canon((v * ld_packed(p.scale)) * w);
+      } else if (p.scale) {
+        out = canon(v * ld_packed(p.scale));
+      } else if (p.post_lo) {
+        const auto w = ld_packed(p.post_lo + (g & ((1u << p.plb) - 1))) * ld_packed(p.post_hi + (g >> p.plb));
+        out = canon(v * w);
+      } else {
+        out = canon(v);
       }
     }
-    p.dst[blockIdx.y][g] = v;
+    F o;
+    fe_to_words<P>(out, o.l);
+    p.dst[blockIdx.y][g] = o;
   }
+}
+
+// in place: arkworks-form table (x R32) -> internal form (x R of fp29.h), both packed and canonical
+template <class F>
+__global__ void to_internal_kernel(F* t, size_t count) {
+  size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= count) return;
+  using P = typename F::Params;
+  F c;
+#pragma unroll
+  for (int i = 0; i < F::NL; i++) c.l[i] = RR<P>::R_WORDS.v[i];
+  t[j] = t[j] * c;      // 32-bit Montgomery product: x R32 * (R mod p) / R32 = x R
+}
+template <class F>
+static void* internal_copy(hipStream_t s, const void* src, size_t count) {
+  void* d = nullptr;
+  DG_HIP(hipMalloc(&d, count * sizeof(F)));
+  DG_HIP(hipMemcpyAsync(d, src, count * sizeof(F), hipMemcpyDeviceToDevice, s));
+  hipLaunchKernelGGL(to_internal_kernel<F>, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, (F*)d, count);
+  return d;
 }
 
 // ---- twiddle tables -------------------------------------------------------------------------
@@ -209,6 +339,11 @@ static const TwiddleSet& get_twiddles(Call& k, int curve, unsigned log_n, int in
   hipLaunchKernelGGL(powers_kernel<F>, dim3((unsigned)((nsm + 255) / 256)), dim3(256), 0, s, (F*)ts.small,
                      nsm, log_n >= ts.sm ? log_n - ts.sm : 0, (const F*)nullptr, log_n ? log_n : 1, inverse,
                      (const F*)nullptr);
+  ts.lo_i = internal_copy<F>(s, ts.lo, nlo);
+  ts.hi_i = internal_copy<F>(s, ts.hi, nhi);
+  if (inverse) ts.hi_scaled_i = internal_copy<F>(s, ts.hi_scaled, nhi);
+  ts.small_i = internal_copy<F>(s, ts.small, nsm);
+  ts.n_inv_i = internal_copy<F>(s, ts.n_inv, 1);
   DG_HIP(hipGetLastError());
   DG_HIP(hipStreamSynchronize(s));   // tables are shared by all channels from here on
   return k.ctx->twiddles.emplace(key, ts).first->second;
@@ -222,6 +357,9 @@ static void build_power_tables(Call& k, const F* g_dev, unsigned log_n, F* lo, F
                      g_dev, 0u, 0, (const F*)nullptr);
   hipLaunchKernelGGL(powers_kernel<F>, dim3((unsigned)((nhi + 255) / 256)), dim3(256), 0, k.s(), hi, nhi, lb,
                      g_dev, 0u, 0, (const F*)nullptr);
+  // the NTT kernels multiply by tables in the internal form (see to_internal_kernel)
+  hipLaunchKernelGGL(to_internal_kernel<F>, dim3((unsigned)((nlo + 255) / 256)), dim3(256), 0, k.s(), lo, nlo);
+  hipLaunchKernelGGL(to_internal_kernel<F>, dim3((unsigned)((nhi + 255) / 256)), dim3(256), 0, k.s(), hi, nhi);
   DG_HIP(hipGetLastError());
 }
 
@@ -271,16 +409,16 @@ static void ntt_run_batch(Call& k, int curve, unsigned nb, const F* const* in, F
     a.last = (j == pl.nsteps - 1);
     a.log_n1 = pl.nsteps >= 2 ? pl.s[0] : 0;
     a.log_n2 = pl.nsteps == 3 ? pl.s[1] : 0;
-    a.small = (const F*)ts.small;
+    a.small = (const F*)ts.small_i;
     a.sm = ts.sm;
-    a.tw_lo = (const F*)ts.lo;
+    a.tw_lo = (const F*)ts.lo_i;
     // n^-1 rides on the first step's twiddles when there is more than one step
     bool fold_scale = inverse && pl.nsteps > 1 && j == 0;
-    a.tw_hi = (const F*)(fold_scale ? ts.hi_scaled : ts.hi);
+    a.tw_hi = (const F*)(fold_scale ? ts.hi_scaled_i : ts.hi_i);
     a.lb = ts.lb;
     a.scale = nullptr;
-    if (fold_scale) a.scale = (const F*)ts.n_inv;                  // marks "tw_hi carries n^-1"
-    if (inverse && pl.nsteps == 1) a.scale = (const F*)ts.n_inv;   // explicit multiply at the store
+    if (fold_scale) a.scale = (const F*)ts.n_inv_i;                  // marks "tw_hi carries n^-1"
+    if (inverse && pl.nsteps == 1) a.scale = (const F*)ts.n_inv_i;   // explicit multiply at the store
     if (j == 0) { a.pre_lo = pre_lo; a.pre_hi = pre_hi; }
     if (a.last) { a.post_lo = post_lo; a.post_hi = post_hi; }
     a.plb = plb;
@@ -376,7 +514,7 @@ static void h_poly_typed(Call& k, int curve, const void* a, const void* b, const
   // lo/hi of the 2m domain cover exponents < 2m; we only need o < m
   k.begin_dominant();
   // a, b, c go through every step together; the first iNTT step reads the caller's vectors in place
-  ntt_run_batch<F>(k, curve, 3, in, v, tmp, log_m, 1, nullptr, nullptr, (const F*)t2.lo, (const F*)t2.hi, t2.lb);
+  ntt_run_batch<F>(k, curve, 3, in, v, tmp, log_m, 1, nullptr, nullptr, (const F*)t2.lo_i, (const F*)t2.hi_i, t2.lb);
   ntt_run_batch<F>(k, curve, 3, v, v, tmp, log_m, 0, nullptr, nullptr, nullptr, nullptr, 0);
   size_t n = (size_t)1 << log_m;
   size_t blocks = (n + 255) / 256;

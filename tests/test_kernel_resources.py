@@ -38,7 +38,8 @@ def test_g2_bucket_accumulation_stages_through_lds_without_spilling():
 
 def test_ntt_and_sort_kernels_are_register_and_lds_only():
     for k, r in find("ntt_step_kernel<").items():
-        assert r["scratch"] == 0 and r["lds"] == 32768 and r["occupancy"] >= 4, k
+        # 1024 tile elements + 256 staged twiddles, 9 limbs each: three workgroups per CU
+        assert r["scratch"] == 0 and r["lds"] == (1024 + 256) * 9 * 4 and r["occupancy"] >= 3, k
     for name in ("msm_part_hist_kernel<", "msm_part_scatter_kernel<", "msm_part_count_kernel<", "msm_part_place_kernel<",
                  "msm_digits_kernel<", "msm_scatter_kernel<"):
         for k, r in find(name).items():
