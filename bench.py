@@ -86,9 +86,14 @@ class Workload:
         self.fixed = torch.cat([f1, f2])
         torch.cuda.synchronize()
         t0 = time.perf_counter()
+        # N > 1 (2 / 4 / 8 ranks): the h-polynomial is sharded -- this rank evaluates only its cyclic rows of a, b, c
+        # and owns the h bases h_query[rank + world * j] (parallel.py); otherwise whole vectors, contiguous slices
+        from dg16_amd.parallel import h_is_sharded
+        self.rank, self.world = rank, world
+        self.h_sharded = world > 1 and h_is_sharded(m, world)
         self.pk = ctx.pk_create(curve, nv, ni, m, self.aq.data_ptr(), self.b1q.data_ptr(), self.b2q.data_ptr(),
                                 self.hq.data_ptr(), self.lq.data_ptr(), self.fixed.data_ptr(), device_ptrs=True,
-                                shard=rank, n_shards=world)
+                                shard=rank, n_shards=world, h_cyclic=self.h_sharded)
         self.pk_build_s = time.perf_counter() - t0
         gen = torch.Generator(device=dev)
         gen.manual_seed(seed)
@@ -101,7 +106,7 @@ class Workload:
         self.w = rand_fr(nv, dev, gen, curve)
         self.w[0] = 0
         self.w[0, 0] = 1
-        self.a = torch.empty((m, 4), dtype=torch.int64, device=dev)
+        self.a = torch.empty((m // world if self.h_sharded else m, 4), dtype=torch.int64, device=dev)
         self.b = torch.empty_like(self.a)
         self.c = torch.empty_like(self.a)
         self.rs = np.array([[3, 1, 4, 1], [5, 9, 2, 6]], dtype=np.uint64)   # r, s (canonical, nonzero)
@@ -111,6 +116,13 @@ class Workload:
 
     def qap(self):
         """a, b, c <- R1CS x witness on the GPU (stream-ordered on channel 0, like the proof that follows)."""
+        if self.h_sharded:
+            self.ctx.qap_rows_dev(self.curve, self.nc, self.ni, self.nv, self.log_m, self.row_ptr.data_ptr(),
+                                  self.a_col.data_ptr(), self.a_val.data_ptr(), self.row_ptr.data_ptr(),
+                                  self.b_col.data_ptr(), self.b_val.data_ptr(), self.w.data_ptr(), self.rank,
+                                  self.world, self.a.data_ptr(), self.b.data_ptr(), self.c.data_ptr(),
+                                  scalars_mont=False)
+            return
         self.ctx.qap_dev(self.curve, self.nc, self.ni, self.nv, self.log_m, self.row_ptr.data_ptr(),
                          self.a_col.data_ptr(), self.a_val.data_ptr(), self.row_ptr.data_ptr(), self.b_col.data_ptr(),
                          self.b_val.data_ptr(), self.w.data_ptr(), self.a.data_ptr(), self.b.data_ptr(),
@@ -305,6 +317,9 @@ def main():
                     help="log2 size of the CPU baseline / parity instance when the timed one is larger")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--transport", default="rccl", choices=["rccl", "torch", "python"],
+                    help="N > 1: native RCCL communicator of libdg16 (default), torch.distributed under the native "
+                         "pipeline, or the Python-driven protocol")
     args = ap.parse_args()
     curve = args.curve
 
@@ -329,7 +344,15 @@ def main():
 
     ctx = dg16_amd.Context(local_rank)
     wl = Workload(ctx, dev, args.log_m, rank, world, curve=curve)
-    prover = make_prover(ctx, wl.pk, curve, dist, rank, world)
+    transport = args.transport
+    try:
+        prover = make_prover(ctx, wl.pk, curve, dist, rank, world, transport=transport)
+    except dg16_amd.Dg16Error as e:          # librccl could not be bound: say so and use torch.distributed
+        if world == 1 or transport != "rccl":
+            raise
+        print("bench: native RCCL transport unavailable (%s); using torch.distributed" % e, file=sys.stderr)
+        transport = "torch"
+        prover = make_prover(ctx, wl.pk, curve, dist, rank, world, transport=transport)
 
     def step():
         wl.qap()
@@ -446,6 +469,14 @@ def main():
         if not ok:
             print(json.dumps(res))
             raise SystemExit("GPU proof differs from the oracle proof")
+    if rank == 0 and world > 1 and not args.no_cpu_baseline and args.log_m <= args.cpu_sample_log:
+        # live parity gate of the distributed proof: the oracle proves the timed instance on rank 0's host cores
+        # (checker only: cpu_baseline is reported at N = 1)
+        _, ok = cpu_baseline_and_parity(ctx, dev, args.log_m, curve, wl=wl, gpu_proof=proof.cpu().numpy())
+        res["parity_check"] = "pass" if ok else "FAIL"
+        if not ok:
+            print(json.dumps(res))
+            raise SystemExit("distributed GPU proof differs from the oracle proof")
     if rank == 0:
         print(json.dumps(res))
     prover.close()

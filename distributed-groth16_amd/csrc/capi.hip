@@ -286,12 +286,23 @@ int dg16_qap(dg16_ctx* ctx, int curve, size_t num_constraints, size_t num_inputs
              const uint32_t* a_row_ptr, const uint32_t* a_col, const void* a_coeff, const uint32_t* b_row_ptr,
              const uint32_t* b_col, const void* b_coeff, const void* full_assignment, void* a_out, void* b_out,
              void* c_out, unsigned flags, int channel) {
+  return dg16_qap_rows(ctx, curve, num_constraints, num_inputs, num_vars, log_m, a_row_ptr, a_col, a_coeff, b_row_ptr,
+                       b_col, b_coeff, full_assignment, 0, 1, a_out, b_out, c_out, flags, channel);
+}
+
+int dg16_qap_rows(dg16_ctx* ctx, int curve, size_t num_constraints, size_t num_inputs, size_t num_vars, unsigned log_m,
+                  const uint32_t* a_row_ptr, const uint32_t* a_col, const void* a_coeff, const uint32_t* b_row_ptr,
+                  const uint32_t* b_col, const void* b_coeff, const void* full_assignment, size_t row_start,
+                  size_t row_stride, void* a_out, void* b_out, void* c_out, unsigned flags, int channel) {
   int rc = guard_channel(ctx, channel);
   if (rc) return rc;
   return guarded(ctx, [&] {
     DG_REQUIRE(curve >= 0 && curve <= 2, DG16_ERR_BAD_CURVE, "unknown curve id");
     DG_REQUIRE(a_row_ptr && b_row_ptr && full_assignment && a_out && b_out && c_out, DG16_ERR_BAD_ARG, "null operand");
     const size_t m = (size_t)1 << log_m;
+    DG_REQUIRE(row_stride >= 1 && !(row_stride & (row_stride - 1)) && row_stride <= m && row_start < row_stride,
+               DG16_ERR_BAD_ARG, "row_stride must be a power of two <= the domain, row_start < row_stride");
+    const size_t rows = m / row_stride;     // output elements per vector
     // D::new(num_constraints + num_inputs) (qap.rs:53): the domain must hold both
     DG_REQUIRE(num_constraints + num_inputs <= m && num_inputs <= num_vars, DG16_ERR_BAD_ARG,
                "domain smaller than num_constraints + num_inputs");
@@ -323,19 +334,56 @@ int dg16_qap(dg16_ctx* ctx, int curve, size_t num_constraints, size_t num_inputs
     const unsigned* bc = (const unsigned*)stage_in(k, 18, b_col, b_nnz * 4, dev);
     const void* bv = stage_in(k, 19, b_coeff, b_nnz * 32, dev);
     const void* w = stage_in(k, 20, full_assignment, num_vars * 32, dev);
-    uint8_t* out = dev ? nullptr : (uint8_t*)ws(k.c, 21, 3 * m * 32);
+    uint8_t* out = dev ? nullptr : (uint8_t*)ws(k.c, 21, 3 * rows * 32);
     void* da = dev ? a_out : out;
-    void* db = dev ? b_out : out + m * 32;
-    void* dc = dev ? c_out : out + 2 * m * 32;
+    void* db = dev ? b_out : out + rows * 32;
+    void* dc = dev ? c_out : out + 2 * rows * 32;
     qap_launch(k, curve, ap, ac, av, bp, bc, bv, w, flags & DG16_F_SCALARS_MONT, num_constraints, num_inputs, num_vars,
-               m, da, db, dc);
+               m, row_start, row_stride, da, db, dc);
     if (!dev) {
-      stage_out(k, a_out, da, m * 32, false);
-      stage_out(k, b_out, db, m * 32, false);
-      stage_out(k, c_out, dc, m * 32, false);
+      stage_out(k, a_out, da, rows * 32, false);
+      stage_out(k, b_out, db, rows * 32, false);
+      stage_out(k, c_out, dc, rows * 32, false);
     }
     k.finish();
     if (!dev) DG_HIP(hipStreamSynchronize(k.s()));
+  });
+}
+
+
+int dg16_h_poly_dist_stage(dg16_ctx* ctx, int curve, unsigned log_m, unsigned rank, unsigned n_ranks, int stage,
+                           const void* const* in, void* out, unsigned flags, int channel) {
+  int rc = guard_channel(ctx, channel);
+  if (rc) return rc;
+  return guarded(ctx, [&] {
+    DG_REQUIRE(curve >= 0 && curve <= 2, DG16_ERR_BAD_CURVE, "unknown curve id");
+    DG_REQUIRE(flags & DG16_F_DEVICE_PTRS, DG16_ERR_BAD_ARG, "the sharded h-polynomial works on device buffers");
+    DG_REQUIRE(in && in[0] && out && stage >= 0 && stage <= 2 && (stage != 0 || (in[1] && in[2])), DG16_ERR_BAD_ARG,
+               "null operand or unknown stage");
+    Call k(ctx, channel);
+    k.begin_dominant();
+    h_poly_dist_stage(k, curve, log_m, rank, n_ranks, stage, in, out);
+    k.end_dominant();
+    k.finish();
+  });
+}
+
+int dg16_h_poly_dist(dg16_ctx* ctx, int curve, const dg16_comm* comm, const void* a_rows, const void* b_rows,
+                     const void* c_rows, unsigned log_m, void* out, unsigned flags, int channel) {
+  int rc = guard_channel(ctx, channel);
+  if (rc) return rc;
+  return guarded(ctx, [&] {
+    DG_REQUIRE(curve >= 0 && curve <= 2, DG16_ERR_BAD_CURVE, "unknown curve id");
+    DG_REQUIRE(flags & DG16_F_DEVICE_PTRS, DG16_ERR_BAD_ARG, "the sharded h-polynomial works on device buffers");
+    DG_REQUIRE(a_rows && b_rows && c_rows && out, DG16_ERR_BAD_ARG, "null operand");
+    Call k(ctx, channel);
+    k.begin_dominant();
+    if (!comm || comm->n_ranks(comm->self) == 1)
+      h_poly_launch(k, curve, a_rows, b_rows, c_rows, log_m, out);
+    else
+      h_poly_dist_launch(k, curve, comm, a_rows, b_rows, c_rows, log_m, out);
+    k.end_dominant();
+    k.finish();
   });
 }
 

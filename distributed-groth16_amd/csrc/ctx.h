@@ -183,7 +183,11 @@ inline void stage_out(Call& k, void* host_dst, const void* dev_src, size_t bytes
 void field_op_launch(Call& k, int field_id, int op, const void* a, const void* b, void* out, size_t n);
 void qap_launch(Call& k, int curve, const unsigned* a_ptr, const unsigned* a_col, const void* a_val,
                 const unsigned* b_ptr, const unsigned* b_col, const void* b_val, const void* w, bool w_mont, size_t nc,
-                size_t ni, size_t nv, size_t m, void* a, void* b, void* c);
+                size_t ni, size_t nv, size_t m, size_t row_start, size_t row_stride, void* a, void* b, void* c);
+void h_poly_dist_stage(Call& k, int curve, unsigned log_m, unsigned rank, unsigned n_ranks, int stage,
+                       const void* const* in, void* out);
+void h_poly_dist_launch(Call& k, int curve, const dg16_comm* comm, const void* a, const void* b, const void* c,
+                        unsigned log_m, void* out);
 void ntt_launch(Call& k, int curve, void* data, unsigned log_n, int inverse, const void* coset_host);
 void h_poly_launch(Call& k, int curve, const void* a, const void* b, const void* c, unsigned log_m,
                    void* out);

@@ -24,6 +24,12 @@ struct dg16_localnet {
     bool failed = false;
     bool result_ok = true;              // outcome of the last completed round, read by the clients
   } slot[kChannels][2];   // [channel][0 = gather, 1 = scatter]
+  // point-to-point mailboxes (send_to / recv_from, mpc-net/src/lib.rs:48-58): [channel][from][to]
+  struct Box {
+    const void* src = nullptr;
+    size_t bytes = 0;
+    bool posted = false, done = false, ok = true;
+  } box[kChannels][kMaxParties][kMaxParties];
   dg16_net party[kMaxParties];
   struct PartyRef { dg16_localnet* net; unsigned id; } ref[kMaxParties];
   bool aborted = false;       // a party died: every pending and future collective fails ("Stream died")
@@ -115,6 +121,55 @@ static int localnet_scatter(void* self, int channel, const void* send_dev, size_
   });
   return ok ? DG16_OK : DG16_ERR_NET;
 }
+// send_to: post the device buffer, wait until the peer's recv_from has copied it (the reference's send completes
+// when the frame is written; here the buffer must stay valid until it is read, so the sender waits for the copy)
+static int localnet_send_to(void* self, unsigned peer, int channel, const void* send_dev, size_t bytes, void* stream) {
+  auto* ref = (dg16_localnet::PartyRef*)self;
+  dg16_localnet* ln = ref->net;
+  if (peer >= ln->n || peer == ref->id || channel < 0 || channel >= kChannels) return DG16_ERR_BAD_ARG;
+  if (stream && hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return DG16_ERR_HIP;
+  auto& b = ln->box[channel][ref->id][peer];
+  std::unique_lock<std::mutex> lk(ln->mu);
+  const auto limit = std::chrono::seconds(ln->timeout_s);
+  auto fail = [&] { ln->aborted = true; b = {}; ln->cv.notify_all(); return DG16_ERR_NET; };
+  if (!ln->cv.wait_for(lk, limit, [&] { return !b.posted || ln->aborted; }) || ln->aborted) return fail();
+  b.src = send_dev;
+  b.bytes = bytes;
+  b.posted = true;
+  b.done = false;
+  ln->cv.notify_all();
+  if (!ln->cv.wait_for(lk, limit, [&] { return b.done || ln->aborted; }) || ln->aborted) return fail();
+  const bool ok = b.ok;
+  b = {};
+  ln->cv.notify_all();
+  return ok ? DG16_OK : DG16_ERR_NET;
+}
+static int localnet_recv_from(void* self, unsigned peer, int channel, void* recv_dev, size_t bytes, void* stream) {
+  auto* ref = (dg16_localnet::PartyRef*)self;
+  dg16_localnet* ln = ref->net;
+  if (peer >= ln->n || peer == ref->id || channel < 0 || channel >= kChannels) return DG16_ERR_BAD_ARG;
+  if (stream && hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return DG16_ERR_HIP;
+  auto& b = ln->box[channel][peer][ref->id];
+  std::unique_lock<std::mutex> lk(ln->mu);
+  const auto limit = std::chrono::seconds(ln->timeout_s);
+  if (!ln->cv.wait_for(lk, limit, [&] { return (b.posted && !b.done) || ln->aborted; }) || ln->aborted) {
+    ln->aborted = true;
+    ln->cv.notify_all();
+    return DG16_ERR_NET;
+  }
+  bool ok = b.bytes == bytes;      // a frame of another length is a protocol error on both sides
+  const void* src = b.src;
+  if (ok) {
+    lk.unlock();
+    ok = hipMemcpy(recv_dev, src, bytes, hipMemcpyDeviceToDevice) == hipSuccess && hipDeviceSynchronize() == hipSuccess;
+    lk.lock();
+  }
+  b.ok = ok;
+  b.done = true;
+  ln->cv.notify_all();
+  return ok ? DG16_OK : DG16_ERR_NET;
+}
+static int localnet_is_init(void* self) { return !((dg16_localnet::PartyRef*)self)->net->aborted; }
 static unsigned localnet_n(void* self) { return ((dg16_localnet::PartyRef*)self)->net->n; }
 static unsigned localnet_id(void* self) { return ((dg16_localnet::PartyRef*)self)->id; }
 
@@ -319,7 +374,8 @@ int dg16_localnet_create(unsigned n_parties, dg16_localnet** out) {
   ln->n = n_parties;
   for (unsigned i = 0; i < n_parties; i++) {
     ln->ref[i] = {ln, i};
-    ln->party[i] = dg16_net{&ln->ref[i], localnet_n, localnet_id, localnet_gather, localnet_scatter};
+    ln->party[i] = dg16_net{&ln->ref[i], localnet_n, localnet_id, localnet_gather, localnet_scatter,
+                            localnet_is_init, localnet_send_to, localnet_recv_from};
   }
   *out = ln;
   return DG16_OK;
@@ -343,6 +399,9 @@ void dg16_localnet_reset(dg16_localnet* ln, unsigned timeout_s) {
   if (timeout_s) ln->timeout_s = timeout_s;
   for (auto& ch : ln->slot)
     for (auto& sl : ch) { sl.arrived = 0; sl.failed = false; }
+  for (auto& ch : ln->box)
+    for (auto& from : ch)
+      for (auto& b : from) b = {};
 }
 
 // ---- d_fft / d_ifft -----------------------------------------------------------------------------------------

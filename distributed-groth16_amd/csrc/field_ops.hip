@@ -46,9 +46,12 @@ __global__ void __launch_bounds__(256) qap_kernel(const unsigned* __restrict__ a
                                                    const Fr* __restrict__ a_val, const unsigned* __restrict__ b_ptr,
                                                    const unsigned* __restrict__ b_col, const Fr* __restrict__ b_val,
                                                    const Fr* __restrict__ w, int w_mont, size_t nc, size_t ni, size_t nv,
-                                                   size_t m, Fr* __restrict__ a, Fr* __restrict__ b, Fr* __restrict__ c,
+                                                   size_t m, size_t row_start, size_t row_stride, Fr* __restrict__ a,
+                                                   Fr* __restrict__ b, Fr* __restrict__ c,
                                                    unsigned* __restrict__ err_flag) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  // output slot `slot` holds domain row i = row_start + row_stride * slot (row_stride = 1: the whole vectors)
+  const size_t slot = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t i = row_start + row_stride * slot;
   if (i >= m) return;
   Fr av = Fr::zero(), bv = Fr::zero(), cv = Fr::zero();
   if (i < nc) {
@@ -81,18 +84,18 @@ __global__ void __launch_bounds__(256) qap_kernel(const unsigned* __restrict__ a
     av = w[i - nc];
     if (!w_mont) av = av.to_mont();
   }
-  a[i] = av;
-  b[i] = bv;
-  c[i] = cv;
+  a[slot] = av;
+  b[slot] = bv;
+  c[slot] = cv;
 }
 
 void qap_launch(Call& k, int curve, const unsigned* a_ptr, const unsigned* a_col, const void* a_val,
                 const unsigned* b_ptr, const unsigned* b_col, const void* b_val, const void* w, bool w_mont, size_t nc,
-                size_t ni, size_t nv, size_t m, void* a, void* b, void* c) {
-  unsigned blocks = (unsigned)((m + 255) / 256);
+                size_t ni, size_t nv, size_t m, size_t row_start, size_t row_stride, void* a, void* b, void* c) {
+  unsigned blocks = (unsigned)((m / row_stride + 255) / 256);
 #define QAP(F)                                                                                              \
   hipLaunchKernelGGL(qap_kernel<F>, dim3(blocks), dim3(256), 0, k.s(), a_ptr, a_col, (const F*)a_val, b_ptr, \
-                     b_col, (const F*)b_val, (const F*)w, (int)w_mont, nc, ni, nv, m, (F*)a, (F*)b, (F*)c,          \
+                     b_col, (const F*)b_val, (const F*)w, (int)w_mont, nc, ni, nv, m, row_start, row_stride, (F*)a, (F*)b, (F*)c, \
                      k.ctx->dev_flag)
   switch (curve) {
     case 0: QAP(bn254_fr); break;

@@ -47,6 +47,11 @@ struct StepArgs {
   const F* post_hi;
   unsigned plb;
   const F* scale;            // optional: out *= *scale on store (last step)
+  // sharded transforms: the vector is exchanged in 2^piece_log-element pieces that sit piece_stride elements apart in
+  // the exchange buffer (piece q of this vector at q * piece_stride); 0 = contiguous.  src_*: first-step loads,
+  // dst_*: last-step stores.
+  unsigned src_piece_log, dst_piece_log;
+  size_t src_piece_stride, dst_piece_stride;
 };
 
 __device__ __forceinline__ unsigned bitrev(unsigned v, unsigned bits) {
@@ -135,7 +140,8 @@ __global__ void __launch_bounds__(256) ntt_step_kernel(StepArgs<F> p) {
       t = idx >> s;
       g = ((((k1_0 + t) << p.log_n2) + k2) << s) + n;
     }
-    const Tw x = ld_packed(p.src[blockIdx.y] + g);
+    const size_t gs = p.src_piece_stride ? (g >> p.src_piece_log) * p.src_piece_stride + (g & (((size_t)1 << p.src_piece_log) - 1)) : g;
+    const Tw x = ld_packed(p.src[blockIdx.y] + gs);
     El v = x.template as<kNttBound, 1>();
     if (p.pre_lo) {
       const auto w = ld_packed(p.pre_lo + (g & ((1u << p.plb) - 1))) * ld_packed(p.pre_hi + (g >> p.plb));
@@ -247,6 +253,7 @@ __global__ void __launch_bounds__(256) ntt_step_kernel(StepArgs<F> p) {
     }
     F o;
     fe_to_words<P>(out, o.l);
+    if (p.dst_piece_stride) g = (g >> p.dst_piece_log) * p.dst_piece_stride + (g & (((size_t)1 << p.dst_piece_log) - 1));
     p.dst[blockIdx.y][g] = o;
   }
 }
@@ -394,7 +401,8 @@ static Plan make_plan(unsigned log_n) {
 template <class F>
 static void ntt_run_batch(Call& k, int curve, unsigned nb, const F* const* in, F* const* data, F* const* tmp,
                           unsigned log_n, int inverse, const F* pre_lo, const F* pre_hi, const F* post_lo,
-                          const F* post_hi, unsigned plb) {
+                          const F* post_hi, unsigned plb, unsigned src_piece_log = 0, size_t src_piece_stride = 0,
+                          unsigned dst_piece_log = 0, size_t dst_piece_stride = 0) {
   DG_REQUIRE(log_n <= 3 * kMaxStepLog, DG16_ERR_UNSUPPORTED, "log_n > 27 not supported yet");
   DG_REQUIRE(nb >= 1 && nb <= 3, DG16_ERR_BAD_ARG, "1..3 transforms per batch");
   const TwiddleSet& ts = get_twiddles<F>(k, curve, log_n, inverse);
@@ -419,8 +427,8 @@ static void ntt_run_batch(Call& k, int curve, unsigned nb, const F* const* in, F
     a.scale = nullptr;
     if (fold_scale) a.scale = (const F*)ts.n_inv_i;                  // marks "tw_hi carries n^-1"
     if (inverse && pl.nsteps == 1) a.scale = (const F*)ts.n_inv_i;   // explicit multiply at the store
-    if (j == 0) { a.pre_lo = pre_lo; a.pre_hi = pre_hi; }
-    if (a.last) { a.post_lo = post_lo; a.post_hi = post_hi; }
+    if (j == 0) { a.pre_lo = pre_lo; a.pre_hi = pre_hi; a.src_piece_log = src_piece_log; a.src_piece_stride = src_piece_stride; }
+    if (a.last) { a.post_lo = post_lo; a.post_hi = post_hi; a.dst_piece_log = dst_piece_log; a.dst_piece_stride = dst_piece_stride; }
     a.plb = plb;
     // ping-pong: first step in -> tmp (same layout), middle step in place on tmp, last step tmp -> data;
     // a single step goes in -> data (one workgroup holds the whole vector in LDS before storing)
@@ -523,6 +531,192 @@ static void h_poly_typed(Call& k, int curve, const void* a, const void* b, const
   hipLaunchKernelGGL(mul_sub_kernel<F>, dim3((unsigned)blocks), dim3(256), 0, k.s(), v[0], v[1], v[2], (F*)out, n);
   DG_HIP(hipGetLastError());
   k.end_dominant();
+}
+
+// ---- sharded h polynomial: one process per GPU, two all-to-alls -----------------------------
+// The m-point transforms of witness_map (qap.rs:64-91) split as m = N x M over N ranks.  Rank rho owns the cyclic
+// rows a[N j + rho] of the evaluation vectors and ends with h[rho + N j]; the N-point cross-rank parts of the inverse
+// and the forward transform meet in ONE kernel between the two exchanges (hdist_cross_kernel), the M-point parts are
+// the ordinary NTT above.  The reference's counterpart is d_ifft / d_fft (dist-primitives/src/dfft/mod.rs:17-95:
+// local levels, gather to the king, remaining levels, scatter); oracle/pyref/hdist.py restates this variant on
+// integers.  Exchange buffers are peer-major: [peer][vector a, b, c][S] with S = M / N, one message per peer.
+
+// w^e from a split power table (arkworks form)
+template <class F>
+__device__ __forceinline__ F tw_lookup(const F* lo, const F* hi, unsigned lb, size_t e) {
+  const size_t l = e & (((size_t)1 << lb) - 1), h = e >> lb;
+  if (l == 0) return hi[h];
+  if (h == 0) return lo[l];
+  return lo[l] * hi[h];
+}
+
+// x[q] <- sum_k x[k] root^(k q), N = 2^LOGN values in registers; roots[t] = root^t, t < N / 2
+template <int LOGN, class F>
+__device__ __forceinline__ void small_dft(F* x, const F* roots) {
+  constexpr int N = 1 << LOGN;
+#pragma unroll
+  for (int i = 0; i < N; i++) {
+    int j = 0;
+#pragma unroll
+    for (int b = 0; b < LOGN; b++) j |= ((i >> b) & 1) << (LOGN - 1 - b);
+    if (j > i) { const F t = x[i]; x[i] = x[j]; x[j] = t; }
+  }
+#pragma unroll
+  for (int lv = 1; lv <= LOGN; lv++) {
+    constexpr int dummy = 0; (void)dummy;
+    const int half = 1 << (lv - 1);
+#pragma unroll
+    for (int q = 0; q < N / 2; q++) {
+      const int kk = q & (half - 1), blk = q >> (lv - 1);
+      const int i0 = (blk << lv) + kk, i1 = i0 + half;
+      const F y = kk ? x[i1] * roots[kk << (LOGN - lv)] : x[i1];
+      const F u = x[i0];
+      x[i0] = u + y;
+      x[i1] = u - y;
+    }
+  }
+}
+
+struct CrossArgs {
+  const void *wi_lo, *wi_hi, *wf_lo, *wf_hi, *g_lo, *g_hi, *n_inv;   // w_m^-e, w_m^e, w_2m^e tables; 1 / N
+  unsigned wlb, glb;
+  unsigned log_m, rank;
+  size_t S;                 // elements per (peer, vector) piece
+};
+
+// in / out: [peer][vector][S].  One lane per (vector, j): the N values Z[.][v][j] of coefficient column k2 = rank S + j.
+template <class F, int LOGN>
+__global__ void __launch_bounds__(256) hdist_cross_kernel(const F* __restrict__ in, F* __restrict__ out, CrossArgs p) {
+  constexpr int N = 1 << LOGN;
+  const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= p.S) return;
+  const unsigned v = blockIdx.y;
+  const size_t M = p.S << LOGN;
+  const size_t k2 = (size_t)p.rank * p.S + j;
+  const F *wi_lo = (const F*)p.wi_lo, *wi_hi = (const F*)p.wi_hi, *wf_lo = (const F*)p.wf_lo, *wf_hi = (const F*)p.wf_hi;
+  const F *g_lo = (const F*)p.g_lo, *g_hi = (const F*)p.g_hi;
+  F x[N];
+#pragma unroll
+  for (int i = 0; i < N; i++) x[i] = in[((size_t)i * 3 + v) * p.S + j];
+  // t[i1] = Z[i1] w^(-i1 k2)
+  {
+    const F base = tw_lookup(wi_lo, wi_hi, p.wlb, k2);
+    F pw = base;
+#pragma unroll
+    for (int i = 1; i < N; i++) {
+      x[i] = x[i] * pw;
+      if (i + 1 < N) pw = pw * base;
+    }
+  }
+  F roots[N / 2 ? N / 2 : 1];
+#pragma unroll
+  for (int t = 0; t < N / 2; t++) roots[t] = tw_lookup(wi_lo, wi_hi, p.wlb, M * t);   // w_N^-t
+  small_dft<LOGN>(x, roots);
+  // coefficient M k1 + k2: scale by 1 / N and shift by g^(M k1 + k2)
+  {
+    const F gm = tw_lookup(g_lo, g_hi, p.glb, M);
+    F pw = tw_lookup(g_lo, g_hi, p.glb, k2) * *(const F*)p.n_inv;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      x[i] = x[i] * pw;
+      if (i + 1 < N) pw = pw * gm;
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < N / 2; t++) roots[t] = tw_lookup(wf_lo, wf_hi, p.wlb, M * t);   // w_N^t
+  small_dft<LOGN>(x, roots);
+  // U[q] = u[q] w^(q k2)
+  {
+    const F base = tw_lookup(wf_lo, wf_hi, p.wlb, k2);
+    F pw = base;
+#pragma unroll
+    for (int i = 1; i < N; i++) {
+      x[i] = x[i] * pw;
+      if (i + 1 < N) pw = pw * base;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < N; i++) out[((size_t)i * 3 + v) * p.S + j] = x[i];
+}
+
+static unsigned log2_exact(unsigned n) {
+  unsigned l = 0;
+  while ((1u << l) < n) l++;
+  DG_REQUIRE((1u << l) == n, DG16_ERR_BAD_ARG, "rank count must be a power of two");
+  return l;
+}
+
+// stage 0: rows (3 vectors of M) -> iNTT_M -> send buffer [peer][vector][S]
+// stage 1: receive buffer -> cross kernel -> send buffer
+// stage 2: receive buffer [peer][vector][S] (= W_v[k2], k2 = peer S + j) -> NTT_M -> a b - c -> out (M elements)
+template <class F>
+static void h_poly_dist_stage_typed(Call& k, int curve, unsigned log_m, unsigned rank, unsigned n_ranks, int stage,
+                                    const void* const* in, void* out) {
+  const unsigned log_n = log2_exact(n_ranks);
+  DG_REQUIRE(log_n >= 1 && log_n <= 3, DG16_ERR_UNSUPPORTED, "sharded h-polynomial: 2, 4 or 8 ranks");
+  DG_REQUIRE(log_m >= 2 * log_n, DG16_ERR_BAD_ARG, "sharded h-polynomial: domain smaller than ranks^2");
+  DG_REQUIRE(rank < n_ranks, DG16_ERR_BAD_ARG, "rank out of range");
+  const unsigned log_M = log_m - log_n, log_S = log_M - log_n;
+  const size_t M = (size_t)1 << log_M, S = (size_t)1 << log_S;
+  F* t0 = (F*)ws(k.c, 8, 3 * M * sizeof(F));
+  F* tmp[3] = {t0, t0 + M, t0 + 2 * M};
+  if (stage == 0) {
+    const F* src[3] = {(const F*)in[0], (const F*)in[1], (const F*)in[2]};
+    F* dst[3] = {(F*)out, (F*)out + S, (F*)out + 2 * S};
+    ntt_run_batch<F>(k, curve, 3, src, dst, tmp, log_M, 1, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, log_S, 3 * S);
+  } else if (stage == 1) {
+    const TwiddleSet& wi = get_twiddles<F>(k, curve, log_m, 1);
+    const TwiddleSet& wf = get_twiddles<F>(k, curve, log_m, 0);
+    const TwiddleSet& g = get_twiddles<F>(k, curve, log_m + 1, 0);
+    const TwiddleSet& nn = get_twiddles<F>(k, curve, log_n, 1);
+    CrossArgs a{wi.lo, wi.hi, wf.lo, wf.hi, g.lo, g.hi, nn.n_inv, wi.lb, g.lb, log_m, rank, S};
+    dim3 grid((unsigned)((S + 255) / 256), 3);
+    switch (log_n) {
+      case 1: hipLaunchKernelGGL((hdist_cross_kernel<F, 1>), grid, dim3(256), 0, k.s(), (const F*)in[0], (F*)out, a); break;
+      case 2: hipLaunchKernelGGL((hdist_cross_kernel<F, 2>), grid, dim3(256), 0, k.s(), (const F*)in[0], (F*)out, a); break;
+      default: hipLaunchKernelGGL((hdist_cross_kernel<F, 3>), grid, dim3(256), 0, k.s(), (const F*)in[0], (F*)out, a); break;
+    }
+    DG_HIP(hipGetLastError());
+  } else {
+    const F* base = (const F*)in[0];
+    const F* src[3] = {base, base + S, base + 2 * S};
+    F* v0 = (F*)ws(k.c, 12, 3 * M * sizeof(F));
+    F* v[3] = {v0, v0 + M, v0 + 2 * M};
+    ntt_run_batch<F>(k, curve, 3, src, v, tmp, log_M, 0, nullptr, nullptr, nullptr, nullptr, 0, log_S, 3 * S, 0, 0);
+    size_t blocks = (M + 255) / 256;
+    size_t cap = (size_t)k.ctx->compute_units * 8;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(mul_sub_kernel<F>, dim3((unsigned)blocks), dim3(256), 0, k.s(), v[0], v[1], v[2], (F*)out, M);
+    DG_HIP(hipGetLastError());
+  }
+}
+
+void h_poly_dist_stage(Call& k, int curve, unsigned log_m, unsigned rank, unsigned n_ranks, int stage,
+                       const void* const* in, void* out) {
+  switch (curve) {
+    case 0: h_poly_dist_stage_typed<bn254_fr>(k, curve, log_m, rank, n_ranks, stage, in, out); break;
+    case 1: h_poly_dist_stage_typed<bls12_381_fr>(k, curve, log_m, rank, n_ranks, stage, in, out); break;
+    default: h_poly_dist_stage_typed<bls12_377_fr>(k, curve, log_m, rank, n_ranks, stage, in, out); break;
+  }
+}
+
+// stage 0 -> all-to-all -> stage 1 -> all-to-all -> stage 2, stream-ordered on the Call's stream.
+// a, b, c: this rank's cyclic rows (M = 2^log_m / N elements each); out: h[rank + N j], j < M.
+void h_poly_dist_launch(Call& k, int curve, const dg16_comm* comm, const void* a, const void* b, const void* c,
+                        unsigned log_m, void* out) {
+  const unsigned n = comm->n_ranks(comm->self), rank = comm->rank(comm->self);
+  const size_t M = ((size_t)1 << log_m) / n, bytes = 3 * M * 32;
+  void* buf_a = ws(k.c, 26, bytes);
+  void* buf_b = ws(k.c, 27, bytes);
+  const void* rows[3] = {a, b, c};
+  h_poly_dist_stage(k, curve, log_m, rank, n, 0, rows, buf_a);
+  int rc = comm->all_to_all(comm->self, buf_a, buf_b, bytes / n, k.s());
+  DG_REQUIRE(rc == DG16_OK, DG16_ERR_NET, "all-to-all of the sharded h-polynomial failed");
+  const void* in1[1] = {buf_b};
+  h_poly_dist_stage(k, curve, log_m, rank, n, 1, in1, buf_a);
+  rc = comm->all_to_all(comm->self, buf_a, buf_b, bytes / n, k.s());
+  DG_REQUIRE(rc == DG16_OK, DG16_ERR_NET, "all-to-all of the sharded h-polynomial failed");
+  h_poly_dist_stage(k, curve, log_m, rank, n, 2, in1, out);
 }
 
 void h_poly_launch(Call& k, int curve, const void* a, const void* b, const void* c, unsigned log_m, void* out) {

@@ -8,6 +8,7 @@ struct PkDev {
   int curve = 0;
   size_t num_vars = 0, num_inputs = 0, m = 0;
   unsigned shard = 0, nshards = 1;   // this key holds slice `shard` of every MSM range (multi-GPU)
+  bool h_cyclic = false;             // h bases are h_query[shard + nshards * j] (DG16_F_H_CYCLIC): h_lo = 0, h_hi = m / nshards
   size_t ab_lo = 0, ab_hi = 0, l_lo = 0, l_hi = 0, h_lo = 0, h_hi = 0;
   // all device pointers
   void* a_q = nullptr;    // a_query[1..][ab_lo..ab_hi) ++ delta_g1        (G1)

@@ -9,7 +9,9 @@ namespace dg16 {
   void pk_build_##name(dg16_ctx*, PkDev&, const void*, const void*, const void*, const void*, const void*, const void*, bool); \
   void prove_##name(dg16_ctx*, const PkDev&, const void*, const void*, const void*, const void*, const void*, bool, bool, void*); \
   void msms_##name(dg16_ctx*, Call&, Call&, Call&, const PkDev&, const void*, const void*, const void*, const void*,    \
-                   const void*, bool, bool, uint8_t*);                                                                  \
+                   const void*, bool, bool, uint8_t*, const dg16_comm*, const void*);                                   \
+  void prove_dist_##name(dg16_ctx*, const PkDev&, const dg16_comm*, const void*, const void*, const void*, const void*, \
+                         const void*, bool, bool, void*);                                                               \
   void assemble_##name(Call&, const uint8_t*, size_t, uint8_t*);                                                        \
   size_t results_bytes_##name();                                                                                        \
   size_t proof_bytes_##name();
@@ -49,6 +51,7 @@ int dg16_pk_create_shard(dg16_ctx* ctx, int curve, size_t num_vars, size_t num_i
     DG_REQUIRE(n_shards >= 1 && shard < n_shards, DG16_ERR_BAD_ARG, "shard index out of range");
     pk->d.shard = shard;
     pk->d.nshards = n_shards;
+    pk->d.h_cyclic = (flags & DG16_F_H_CYCLIC) != 0;
     bool dev = flags & DG16_F_DEVICE_PTRS;
     if (curve == DG16_BN254)
       pk_build_bn254(ctx, pk->d, a_query, b_g1_query, b_g2_query, h_query, l_query, fixed_points, dev);
@@ -124,15 +127,55 @@ int dg16_groth16_msms(dg16_ctx* ctx, const dg16_pk* pk, const void* a, const voi
     uint8_t* res_dev = dev ? (uint8_t*)results_out : (uint8_t*)ws(k0.c, 16, 8192);
     k0.begin_dominant();
     if (pk->d.curve == DG16_BN254)
-      msms_bn254(ctx, k0, k1, k2, pk->d, a, b, c, full_assignment, r_s, mont, dev, res_dev);
+      msms_bn254(ctx, k0, k1, k2, pk->d, a, b, c, full_assignment, r_s, mont, dev, res_dev, nullptr, nullptr);
     else
-      msms_bls12_381(ctx, k0, k1, k2, pk->d, a, b, c, full_assignment, r_s, mont, dev, res_dev);
+      msms_bls12_381(ctx, k0, k1, k2, pk->d, a, b, c, full_assignment, r_s, mont, dev, res_dev, nullptr, nullptr);
     k0.end_dominant();
     if (!dev) stage_out(k0, results_out, res_dev, rec, false);
     k0.finish();
     k1.finish();
     k2.finish();
     if (!dev) DG_HIP(hipStreamSynchronize(k0.s()));
+  });
+}
+
+int dg16_groth16_msms_h(dg16_ctx* ctx, const dg16_pk* pk, const void* h_shard, const void* full_assignment,
+                        const void* r_s, unsigned flags, void* results_out) {
+  if (!ctx || !pk) return DG16_ERR_BAD_ARG;
+  return guarded(ctx, [&] {
+    DG_REQUIRE(pk->ctx == ctx, DG16_ERR_BAD_ARG, "proving key belongs to another context");
+    DG_REQUIRE(h_shard && full_assignment && r_s && results_out, DG16_ERR_BAD_ARG, "null operand");
+    bool mont = flags & DG16_F_SCALARS_MONT, dev = flags & DG16_F_DEVICE_PTRS;
+    Call k0(ctx, 0), k1(ctx, 1), k2(ctx, 2);
+    size_t rec = dg16_groth16_results_bytes(pk->d.curve);
+    uint8_t* res_dev = dev ? (uint8_t*)results_out : (uint8_t*)ws(k0.c, 16, 8192);
+    k0.begin_dominant();
+    if (pk->d.curve == DG16_BN254)
+      msms_bn254(ctx, k0, k1, k2, pk->d, nullptr, nullptr, nullptr, full_assignment, r_s, mont, dev, res_dev, nullptr, h_shard);
+    else
+      msms_bls12_381(ctx, k0, k1, k2, pk->d, nullptr, nullptr, nullptr, full_assignment, r_s, mont, dev, res_dev, nullptr,
+                     h_shard);
+    k0.end_dominant();
+    if (!dev) stage_out(k0, results_out, res_dev, rec, false);
+    k0.finish();
+    k1.finish();
+    k2.finish();
+    if (!dev) DG_HIP(hipStreamSynchronize(k0.s()));
+  });
+}
+
+int dg16_groth16_prove_dist(dg16_ctx* ctx, const dg16_pk* pk, const dg16_comm* comm, const void* a_rows,
+                            const void* b_rows, const void* c_rows, const void* full_assignment, const void* r_s,
+                            unsigned flags, void* proof_out) {
+  if (!ctx || !pk) return DG16_ERR_BAD_ARG;
+  return guarded(ctx, [&] {
+    DG_REQUIRE(pk->ctx == ctx, DG16_ERR_BAD_ARG, "proving key belongs to another context");
+    DG_REQUIRE(a_rows && b_rows && c_rows && full_assignment && r_s && proof_out, DG16_ERR_BAD_ARG, "null operand");
+    bool mont = flags & DG16_F_SCALARS_MONT, dev = flags & DG16_F_DEVICE_PTRS;
+    if (pk->d.curve == DG16_BN254)
+      prove_dist_bn254(ctx, pk->d, comm, a_rows, b_rows, c_rows, full_assignment, r_s, mont, dev, proof_out);
+    else
+      prove_dist_bls12_381(ctx, pk->d, comm, a_rows, b_rows, c_rows, full_assignment, r_s, mont, dev, proof_out);
   });
 }
 

@@ -13,8 +13,12 @@ void pk_build_bn254(dg16_ctx* ctx, PkDev& d, const void* a, const void* b1, cons
 void prove_bn254(dg16_ctx* ctx, const PkDev& pk, const void* a, const void* b, const void* c, const void* w,
               const void* rs, bool mont, bool dev, void* out) { prove_typed<0>(ctx, pk, a, b, c, w, rs, mont, dev, out); }
 void msms_bn254(dg16_ctx* ctx, Call& k0, Call& k1, Call& k2, const PkDev& pk, const void* a, const void* b, const void* c,
-             const void* w, const void* rs, bool mont, bool dev, uint8_t* res) {
-  msms_typed<0>(ctx, k0, k1, k2, pk, a, b, c, w, rs, mont, dev, res);
+             const void* w, const void* rs, bool mont, bool dev, uint8_t* res, const dg16_comm* comm, const void* h_given) {
+  msms_typed<0>(ctx, k0, k1, k2, pk, a, b, c, w, rs, mont, dev, res, comm, h_given);
+}
+void prove_dist_bn254(dg16_ctx* ctx, const PkDev& pk, const dg16_comm* comm, const void* a, const void* b, const void* c,
+              const void* w, const void* rs, bool mont, bool dev, void* out) {
+  prove_dist_typed<0>(ctx, pk, comm, a, b, c, w, rs, mont, dev, out);
 }
 void assemble_bn254(Call& k0, const uint8_t* gathered, size_t n_shards, uint8_t* proof) {
   assemble_typed<0>(k0, gathered, n_shards, proof);

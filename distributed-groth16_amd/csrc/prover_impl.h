@@ -115,11 +115,15 @@ static size_t msm_results_bytes() {
 
 // h-polynomial + the five MSMs of this key's shard.  res_out (device or host per dev_ptrs) receives
 // msm_results_bytes() bytes.  Uses all three channels; returns with the results stream-ordered on
-// channel 0.
+// channel 0.  Where h comes from:
+//   h_given            the caller made it (this key's n_h scalars; a, b, c unused)
+//   comm with > 1 rank  sharded h-polynomial (ntt.hip: h_poly_dist_launch): a, b, c are this rank's cyclic rows and
+//                      the key is a DG16_F_H_CYCLIC shard
+//   otherwise          the whole h-polynomial from the whole a, b, c; the key's slice of it is used
 template <int CURVE>
 static void msms_typed(dg16_ctx* ctx, Call& k0, Call& k1, Call& k2, const PkDev& pk, const void* a, const void* b,
                        const void* c, const void* witness, const void* r_s_host, bool mont, bool dev_ptrs,
-                       uint8_t* res_dev) {
+                       uint8_t* res_dev, const dg16_comm* comm = nullptr, const void* h_given = nullptr) {
   using CT = CurveTypes<CURVE>;
   using Fq = typename CT::Fq;
   using Fq2 = typename CT::Fq2;
@@ -132,10 +136,20 @@ static void msms_typed(dg16_ctx* ctx, Call& k0, Call& k1, Call& k2, const PkDev&
   while (((size_t)1 << log_m) < m) log_m++;
   const size_t g1j = sizeof(Jacobian<Fq>);
 
+  const bool dist = !h_given && comm && comm->n_ranks(comm->self) > 1;
+  if (dist) {
+    DG_REQUIRE(pk.h_cyclic && comm->n_ranks(comm->self) == pk.nshards && comm->rank(comm->self) == pk.shard,
+               DG16_ERR_BAD_ARG, "distributed prove: the key must be the DG16_F_H_CYCLIC shard `rank` of `n_ranks`");
+  } else if (!h_given) {
+    DG_REQUIRE(!(pk.h_cyclic && pk.nshards > 1), DG16_ERR_BAD_ARG,
+               "a DG16_F_H_CYCLIC shard needs the sharded h-polynomial (dg16_groth16_prove_dist / _msms_h)");
+  }
+  const size_t rows = dist ? m / pk.nshards : m;     // length of a, b, c
   const Fr* w_dev = (const Fr*)stage_in(k0, 18, witness, nv * sizeof(Fr), dev_ptrs);
-  const void* a_dev = stage_in(k0, 19, a, m * sizeof(Fr), dev_ptrs);
-  const void* b_dev = stage_in(k0, 20, b, m * sizeof(Fr), dev_ptrs);
-  const void* c_dev = stage_in(k0, 21, c, m * sizeof(Fr), dev_ptrs);
+  const void* a_dev = h_given ? nullptr : stage_in(k0, 19, a, rows * sizeof(Fr), dev_ptrs);
+  const void* b_dev = h_given ? nullptr : stage_in(k0, 20, b, rows * sizeof(Fr), dev_ptrs);
+  const void* c_dev = h_given ? nullptr : stage_in(k0, 21, c, rows * sizeof(Fr), dev_ptrs);
+  const Fr* h_in = h_given ? (const Fr*)stage_in(k0, 19, h_given, n_h * sizeof(Fr), dev_ptrs) : nullptr;
   Fr* r_s = (Fr*)ws(k0.c, 22, 4096);
   Jacobian<Fq>* rec = (Jacobian<Fq>*)res_dev;
   Jacobian<Fq>* res_a = rec + kRecA;
@@ -203,17 +217,25 @@ static void msms_typed(dg16_ctx* ctx, Call& k0, Call& k1, Call& k2, const PkDev&
   // h-polynomial + the digit sorts of H and L do not depend on the witness MSMs.  DG16_PREP_OVERLAP=1 sends them
   // down side2 underneath the A / B1 / B accumulations; measured 23.3 ms (off) vs 24.4 ms (on) per 2^20 proof:
   // the chip is saturated either way and the co-scheduled accumulations slow down by more than is hidden.
-  static const bool overlap = [] { const char* e = getenv("DG16_PREP_OVERLAP"); return e && atoi(e) != 0; }();
+  // (a distributed proof always overlaps: the two exchanges of the sharded h-polynomial are latency, and they hide
+  // behind the A / B1 / B accumulations only from a stream of their own)
+  static const bool overlap_env = [] { const char* e = getenv("DG16_PREP_OVERLAP"); return e && atoi(e) != 0; }();
+  const bool overlap = overlap_env || dist;
   hipStream_t prep = overlap ? side2 : main;
   if (overlap) DG_HIP(hipStreamWaitEvent(prep, ev[8], 0));   // staged a, b, c and the scalar vectors
-  Fr* h_dev = (Fr*)ws(k0.c, 3, m * sizeof(Fr));
-  {
+  const Fr* h_scalars = h_in;
+  if (!h_given) {
+    Fr* h_dev = (Fr*)ws(k0.c, 3, rows * sizeof(Fr));
     hipStream_t saved = k0.c.cur;     // h_poly_launch() issues on the Call's stream, with channel 0's buffers
     k0.c.cur = prep;
-    h_poly_launch(k0, CURVE, a_dev, b_dev, c_dev, log_m, h_dev);
+    if (dist)
+      h_poly_dist_launch(k0, CURVE, comm, a_dev, b_dev, c_dev, log_m, h_dev);
+    else
+      h_poly_launch(k0, CURVE, a_dev, b_dev, c_dev, log_m, h_dev);
     k0.c.cur = saved;
+    h_scalars = dist ? h_dev : h_dev + pk.h_lo;
   }
-  MsmSort st_h = msm_sort_on<Fr, CT::SCALAR_BITS>(prep, k0.c, h_dev + pk.h_lo, n_h, true, true, pk.c_h);
+  MsmSort st_h = msm_sort_on<Fr, CT::SCALAR_BITS>(prep, k0.c, h_scalars, n_h, true, true, pk.c_h);
   MsmSort st_l = msm_sort_on<Fr, CT::SCALAR_BITS>(prep, k2.c, sc_l, n_l + 1, mont, true, pk.c_l);
   if (overlap) {
     DG_HIP(hipEventRecord(ev[9], prep));
@@ -278,6 +300,39 @@ static void prove_typed(dg16_ctx* ctx, const PkDev& pk, const void* a, const voi
   if (!dev_ptrs) DG_HIP(hipStreamSynchronize(k0.s()));
 }
 
+// The whole distributed proof on this rank: msms (with the sharded h-polynomial) -> all-gather of the records on
+// channel 0's stream -> assembly.  No host synchronisation anywhere (device-pointer calls).
+template <int CURVE>
+static void prove_dist_typed(dg16_ctx* ctx, const PkDev& pk, const dg16_comm* comm, const void* a, const void* b,
+                             const void* c, const void* witness, const void* r_s_host, bool mont, bool dev_ptrs,
+                             void* proof_out) {
+  using CT = CurveTypes<CURVE>;
+  const size_t g1j = sizeof(Jacobian<typename CT::Fq>), g2j = sizeof(Jacobian<typename CT::Fq2>);
+  const unsigned n = comm ? comm->n_ranks(comm->self) : 1;
+  DG_REQUIRE(pk.nshards == n, DG16_ERR_BAD_ARG, "distributed prove: key shards != ranks");
+  Call k0(ctx, 0), k1(ctx, 1), k2(ctx, 2);
+  uint8_t* buf = (uint8_t*)ws(k0.c, 16, 8192);
+  uint8_t* res_dev = buf;
+  uint8_t* proof_dev = buf + 4096;
+  const size_t rec = msm_results_bytes<CURVE>();
+  uint8_t* gathered = n > 1 ? (uint8_t*)ws(k0.c, 28, n * rec) : res_dev;
+  k0.begin_dominant();
+  msms_typed<CURVE>(ctx, k0, k1, k2, pk, a, b, c, witness, r_s_host, mont, dev_ptrs, res_dev, comm, nullptr);
+  if (n > 1) {
+    // the "all-reduce of bucket sums": RCCL has no user-defined reduction, so the N records (768 B each for BN254)
+    // are gathered and every rank adds them (assemble)
+    int rc = comm->all_gather(comm->self, res_dev, rec, gathered, k0.s());
+    DG_REQUIRE(rc == DG16_OK, DG16_ERR_NET, "all-gather of the MSM records failed");
+  }
+  assemble_typed<CURVE>(k0, gathered, n, proof_dev);
+  k0.end_dominant();
+  stage_out(k0, proof_out, proof_dev, 2 * g1j + g2j, dev_ptrs);
+  k0.finish();
+  k1.finish();
+  k2.finish();
+  if (!dev_ptrs) DG_HIP(hipStreamSynchronize(k0.s()));
+}
+
 // a_query etc. are given as full arkworks vectors (element 0 included); delta is appended here
 template <int CURVE>
 static void pk_build(dg16_ctx* ctx, PkDev& d, const void* a_query, const void* b_g1_query,
@@ -296,6 +351,12 @@ static void pk_build(dg16_ctx* ctx, PkDev& d, const void* a_query, const void* b
   slice(nv - 1, d.ab_lo, d.ab_hi);
   slice(nv - ni, d.l_lo, d.l_hi);
   slice(m, d.h_lo, d.h_hi);
+  if (d.h_cyclic) {
+    DG_REQUIRE(!(d.nshards & (d.nshards - 1)) && (size_t)d.nshards * d.nshards <= m, DG16_ERR_BAD_ARG,
+               "DG16_F_H_CYCLIC: n_shards must be a power of two with n_shards^2 <= domain_size");
+    d.h_lo = 0;
+    d.h_hi = m / d.nshards;
+  }
   const size_t n_ab = d.ab_hi - d.ab_lo, n_l = d.l_hi - d.l_lo, n_h = d.h_hi - d.h_lo;
   DG_HIP(hipSetDevice(ctx->device));
   // plain arrays first (slice ++ delta slots), then the window tables that replace them
@@ -332,7 +393,9 @@ static void pk_build(dg16_ctx* ctx, PkDev& d, const void* a_query, const void* b
   DG_HIP(hipMemcpy((uint8_t*)b2_plain + (n_ab + 1) * p2, fx + 3 * p1 + p2, p2, kind));     // [0, delta_g2]
   DG_HIP(hipMemcpy(l_plain, (const uint8_t*)l_query + d.l_lo * p1, n_l * p1, kind));
   DG_HIP(hipMemcpy((uint8_t*)l_plain + n_l * p1, fx + 2 * p1, p1, kind));
-  if (n_h) DG_HIP(hipMemcpy(h_plain, (const uint8_t*)h_query + d.h_lo * p1, n_h * p1, kind));
+  if (d.h_cyclic)   // h_query[shard + nshards * j]: the layout the sharded h-polynomial leaves its output in
+    DG_HIP(hipMemcpy2D(h_plain, p1, (const uint8_t*)h_query + d.shard * p1, (size_t)d.nshards * p1, p1, n_h, kind));
+  else if (n_h) DG_HIP(hipMemcpy(h_plain, (const uint8_t*)h_query + d.h_lo * p1, n_h * p1, kind));
   {
     using CTc = CurveTypes<CURVE>;
     auto nwin_of = [](unsigned c) { return (unsigned)((CTc::SCALAR_BITS + 1 + c - 1) / c); };

@@ -1,0 +1,230 @@
+// Native RCCL transport of libdg16 (include/dg16.h: dg16_rccl_*).
+//
+// What it replaces: the reference's mpc-net -- ProdNet's TCP/TLS star around the king (mpc-net/src/prod.rs) under
+// the MpcNet trait (mpc-net/src/lib.rs:36-140) and the serialising MpcSerNet wrapper
+// (dist-primitives/src/channel/mod.rs:8-57).  On one MI355X node the parties are the GPUs: payloads stay in HBM
+// and move over xGMI as RCCL point-to-point transfers fused in one group per collective (xGMI is point to point --
+// a gather to the king is n - 1 concurrent link transfers, an all-to-all uses all seven links of every GPU), ordered
+// on the HIP stream the payload was produced on.  Nothing here synchronises the host.
+//
+// librccl is bound at run time: a process that has torch loaded already holds torch's copy (same soname) and gets
+// that one; a plain C consumer gets /opt/rocm's.  Linking it would make every libdg16 user load RCCL.
+#include <dlfcn.h>
+#include <string.h>
+
+#include <mutex>
+#include <string>
+
+#include "ctx.h"
+
+namespace {
+
+// the part of rccl.h this file needs (ABI of NCCL 2.x, unchanged across RCCL releases)
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef int ncclResult_t;        // ncclSuccess == 0
+constexpr int kNcclInt8 = 0;     // ncclInt8 / ncclChar
+
+struct Api {
+  void* lib = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  ncclResult_t (*Send)(const void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, int, ncclComm_t, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  std::string why;
+};
+
+thread_local std::string g_err;
+
+Api& api() {
+  static Api a;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    for (const char* n : names)
+      if ((a.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;        // the copy this process already uses
+    if (!a.lib)
+      for (const char* n : names)
+        if ((a.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+    if (!a.lib) {
+      a.why = std::string("librccl not found: ") + dlerror();
+      return;
+    }
+    auto sym = [&](const char* name) {
+      void* f = dlsym(a.lib, name);
+      if (!f && a.why.empty()) a.why = std::string("librccl lacks ") + name;
+      return f;
+    };
+    a.GetUniqueId = (decltype(a.GetUniqueId))sym("ncclGetUniqueId");
+    a.CommInitRank = (decltype(a.CommInitRank))sym("ncclCommInitRank");
+    a.CommDestroy = (decltype(a.CommDestroy))sym("ncclCommDestroy");
+    a.GroupStart = (decltype(a.GroupStart))sym("ncclGroupStart");
+    a.GroupEnd = (decltype(a.GroupEnd))sym("ncclGroupEnd");
+    a.Send = (decltype(a.Send))sym("ncclSend");
+    a.Recv = (decltype(a.Recv))sym("ncclRecv");
+    a.AllGather = (decltype(a.AllGather))sym("ncclAllGather");
+    a.GetErrorString = (decltype(a.GetErrorString))sym("ncclGetErrorString");
+  });
+  return a;
+}
+
+bool api_ok() {
+  Api& a = api();
+  if (!a.lib || !a.why.empty()) {
+    g_err = a.why;
+    return false;
+  }
+  return true;
+}
+
+}  // namespace
+
+struct dg16_rccl {
+  dg16_ctx* ctx = nullptr;
+  ncclComm_t comm = nullptr;
+  unsigned n = 0, me = 0;
+  dg16_comm comm_vt{};
+  dg16_net net_vt{};
+  bool check(ncclResult_t r, const char* what) {
+    if (r == 0) return true;
+    g_err = std::string(what) + ": " + (api().GetErrorString ? api().GetErrorString(r) : "rccl error");
+    return false;
+  }
+};
+
+namespace {
+
+unsigned rc_n(void* self) { return ((dg16_rccl*)self)->n; }
+unsigned rc_me(void* self) { return ((dg16_rccl*)self)->me; }
+int rc_is_init(void* self) { return ((dg16_rccl*)self)->comm != nullptr; }
+
+int rc_all_gather(void* self, const void* send, size_t bytes, void* recv, void* stream) {
+  auto* h = (dg16_rccl*)self;
+  if (hipSetDevice(h->ctx->device) != hipSuccess) return DG16_ERR_HIP;
+  return h->check(api().AllGather(send, recv, bytes, kNcclInt8, h->comm, (hipStream_t)stream), "ncclAllGather")
+             ? DG16_OK
+             : DG16_ERR_NET;
+}
+
+int rc_all_to_all(void* self, const void* send, void* recv, size_t bytes_per_peer, void* stream) {
+  auto* h = (dg16_rccl*)self;
+  Api& a = api();
+  if (hipSetDevice(h->ctx->device) != hipSuccess) return DG16_ERR_HIP;
+  bool ok = h->check(a.GroupStart(), "ncclGroupStart");
+  for (unsigned p = 0; ok && p < h->n; p++) {
+    ok = h->check(a.Send((const uint8_t*)send + p * bytes_per_peer, bytes_per_peer, kNcclInt8, (int)p, h->comm,
+                         (hipStream_t)stream), "ncclSend") &&
+         h->check(a.Recv((uint8_t*)recv + p * bytes_per_peer, bytes_per_peer, kNcclInt8, (int)p, h->comm,
+                         (hipStream_t)stream), "ncclRecv");
+  }
+  // the group is always closed, also after a failed call inside it (an open group would swallow later collectives)
+  const bool closed = h->check(a.GroupEnd(), "ncclGroupEnd");
+  return ok && closed ? DG16_OK : DG16_ERR_NET;
+}
+
+// client_send_or_king_receive (mpc-net/src/lib.rs:61-99): n - 1 sends meet n - 1 receives on the king; the king's
+// own block is a device copy on the same stream.  `channel` needs no tag: calls on one communicator are matched
+// in issue order, and every party issues the collectives of a protocol in the same order.
+int rc_gather(void* self, int, const void* send, size_t bytes, void* recv, void* stream) {
+  auto* h = (dg16_rccl*)self;
+  Api& a = api();
+  hipStream_t s = (hipStream_t)stream;
+  if (hipSetDevice(h->ctx->device) != hipSuccess) return DG16_ERR_HIP;
+  if (h->me != 0) return h->check(a.Send(send, bytes, kNcclInt8, 0, h->comm, s), "ncclSend") ? DG16_OK : DG16_ERR_NET;
+  if (hipMemcpyAsync(recv, send, bytes, hipMemcpyDeviceToDevice, s) != hipSuccess) return DG16_ERR_HIP;
+  bool ok = h->check(a.GroupStart(), "ncclGroupStart");
+  for (unsigned p = 1; ok && p < h->n; p++)
+    ok = h->check(a.Recv((uint8_t*)recv + p * bytes, bytes, kNcclInt8, (int)p, h->comm, s), "ncclRecv");
+  const bool closed = h->check(a.GroupEnd(), "ncclGroupEnd");
+  return ok && closed ? DG16_OK : DG16_ERR_NET;
+}
+
+// client_receive_or_king_send (mpc-net/src/lib.rs:102-140)
+int rc_scatter(void* self, int, const void* send, size_t bytes, void* recv, void* stream) {
+  auto* h = (dg16_rccl*)self;
+  Api& a = api();
+  hipStream_t s = (hipStream_t)stream;
+  if (hipSetDevice(h->ctx->device) != hipSuccess) return DG16_ERR_HIP;
+  if (h->me != 0) return h->check(a.Recv(recv, bytes, kNcclInt8, 0, h->comm, s), "ncclRecv") ? DG16_OK : DG16_ERR_NET;
+  if (hipMemcpyAsync(recv, send, bytes, hipMemcpyDeviceToDevice, s) != hipSuccess) return DG16_ERR_HIP;
+  bool ok = h->check(a.GroupStart(), "ncclGroupStart");
+  for (unsigned p = 1; ok && p < h->n; p++)
+    ok = h->check(a.Send((const uint8_t*)send + p * bytes, bytes, kNcclInt8, (int)p, h->comm, s), "ncclSend");
+  const bool closed = h->check(a.GroupEnd(), "ncclGroupEnd");
+  return ok && closed ? DG16_OK : DG16_ERR_NET;
+}
+
+int rc_send_to(void* self, unsigned peer, int, const void* send, size_t bytes, void* stream) {
+  auto* h = (dg16_rccl*)self;
+  if (peer >= h->n || peer == h->me) return DG16_ERR_BAD_ARG;
+  if (hipSetDevice(h->ctx->device) != hipSuccess) return DG16_ERR_HIP;
+  return h->check(api().Send(send, bytes, kNcclInt8, (int)peer, h->comm, (hipStream_t)stream), "ncclSend") ? DG16_OK
+                                                                                                            : DG16_ERR_NET;
+}
+int rc_recv_from(void* self, unsigned peer, int, void* recv, size_t bytes, void* stream) {
+  auto* h = (dg16_rccl*)self;
+  if (peer >= h->n || peer == h->me) return DG16_ERR_BAD_ARG;
+  if (hipSetDevice(h->ctx->device) != hipSuccess) return DG16_ERR_HIP;
+  return h->check(api().Recv(recv, bytes, kNcclInt8, (int)peer, h->comm, (hipStream_t)stream), "ncclRecv") ? DG16_OK
+                                                                                                            : DG16_ERR_NET;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* dg16_rccl_error(void) { return g_err.c_str(); }
+
+int dg16_rccl_unique_id(void* out128) {
+  if (!out128) return DG16_ERR_BAD_ARG;
+  if (!api_ok()) return DG16_ERR_UNSUPPORTED;
+  ncclUniqueId id;
+  ncclResult_t r = api().GetUniqueId(&id);
+  if (r != 0) {
+    g_err = std::string("ncclGetUniqueId: ") + api().GetErrorString(r);
+    return DG16_ERR_NET;
+  }
+  memcpy(out128, id.internal, sizeof(id.internal));
+  return DG16_OK;
+}
+
+int dg16_rccl_create(dg16_ctx* ctx, const void* unique_id128, unsigned n_ranks, unsigned rank, dg16_rccl** out) {
+  if (!ctx || !unique_id128 || !out || n_ranks == 0 || rank >= n_ranks) return DG16_ERR_BAD_ARG;
+  *out = nullptr;
+  if (!api_ok()) return DG16_ERR_UNSUPPORTED;
+  if (hipSetDevice(ctx->device) != hipSuccess) return DG16_ERR_HIP;
+  auto* h = new dg16_rccl();
+  h->ctx = ctx;
+  h->n = n_ranks;
+  h->me = rank;
+  ncclUniqueId id;
+  memcpy(id.internal, unique_id128, sizeof(id.internal));
+  if (!h->check(api().CommInitRank(&h->comm, (int)n_ranks, id, (int)rank), "ncclCommInitRank")) {
+    delete h;
+    return DG16_ERR_NET;
+  }
+  h->comm_vt = dg16_comm{h, rc_n, rc_me, rc_all_gather, rc_all_to_all};
+  h->net_vt = dg16_net{h, rc_n, rc_me, rc_gather, rc_scatter, rc_is_init, rc_send_to, rc_recv_from};
+  *out = h;
+  return DG16_OK;
+}
+
+const dg16_comm* dg16_rccl_comm(dg16_rccl* h) { return h ? &h->comm_vt : nullptr; }
+const dg16_net* dg16_rccl_net(dg16_rccl* h) { return h ? &h->net_vt : nullptr; }
+
+void dg16_rccl_destroy(dg16_rccl* h) {
+  if (!h) return;
+  if (h->comm) {
+    hipSetDevice(h->ctx->device);
+    hipDeviceSynchronize();
+    api().CommDestroy(h->comm);
+  }
+  delete h;
+}
+
+}  // extern "C"

@@ -18,6 +18,7 @@ FQ_LIMBS64 = {"bn254": 4, "bls12_381": 6, "bls12_377": 6}
 F_SCALARS_MONT = 1
 F_DEVICE_PTRS = 2
 F_OUT_AFFINE = 4
+F_H_CYCLIC = 8
 
 STATUS = {1: "LENGTH_MISMATCH", 2: "BAD_CURVE", 3: "BAD_ARG", 4: "OOM", 5: "HIP", 6: "NET",
           7: "UNSUPPORTED"}
@@ -58,6 +59,31 @@ class Csr(ctypes.Structure):              # dg16_csr
         col = np.ctypeslib.as_array(self.col, shape=(nnz,)).copy()
         raw = (ctypes.c_uint64 * (4 * nnz)).from_address(self.coeff)
         return ptr, col, np.frombuffer(raw, dtype=np.uint64).reshape(nnz, 4).copy()
+
+
+_COMM_N = ctypes.CFUNCTYPE(ctypes.c_uint, ctypes.c_void_p)
+_COMM_GATHER = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p,
+                                ctypes.c_void_p)
+_COMM_A2A = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t,
+                             ctypes.c_void_p)
+
+
+class CommStruct(ctypes.Structure):       # dg16_comm
+    _fields_ = [("self", ctypes.c_void_p), ("n_ranks", _COMM_N), ("rank", _COMM_N), ("all_gather", _COMM_GATHER),
+                ("all_to_all", _COMM_A2A)]
+
+
+_NET_COLL = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t,
+                             ctypes.c_void_p, ctypes.c_void_p)
+_NET_P2P = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_uint, ctypes.c_int, ctypes.c_void_p,
+                            ctypes.c_size_t, ctypes.c_void_p)
+
+
+class NetStruct(ctypes.Structure):        # dg16_net (MpcNet: mpc-net/src/lib.rs:36-140)
+    _fields_ = [("self", ctypes.c_void_p), ("n_parties", _COMM_N), ("party_id", _COMM_N),
+                ("gather_to_king", _NET_COLL), ("scatter_from_king", _NET_COLL),
+                ("is_init", ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p)), ("send_to", _NET_P2P),
+                ("recv_from", _NET_P2P)]
 
 
 def lib_path():
@@ -114,6 +140,21 @@ def load():
     L.dg16_groth16_msms.argtypes = [vp, vp, vp, vp, vp, vp, vp, u, vp]
     L.dg16_groth16_assemble.argtypes = [vp, vp, vp, sz, vp, u, vp]
     L.dg16_qap.argtypes = [vp, i, sz, sz, sz, u, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, u, i]
+    L.dg16_qap_rows.argtypes = [vp, i, sz, sz, sz, u, vp, vp, vp, vp, vp, vp, vp, sz, sz, vp, vp, vp, u, i]
+    L.dg16_h_poly_dist.argtypes = [vp, i, vp, vp, vp, vp, u, vp, u, i]
+    L.dg16_h_poly_dist_stage.argtypes = [vp, i, u, u, u, i, ctypes.POINTER(vp), vp, u, i]
+    L.dg16_groth16_msms_h.argtypes = [vp, vp, vp, vp, vp, u, vp]
+    L.dg16_groth16_prove_dist.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, u, vp]
+    L.dg16_rccl_unique_id.argtypes = [vp]
+    L.dg16_rccl_create.argtypes = [vp, vp, u, u, ctypes.POINTER(vp)]
+    L.dg16_rccl_comm.argtypes = [vp]
+    L.dg16_rccl_comm.restype = vp
+    L.dg16_rccl_net.argtypes = [vp]
+    L.dg16_rccl_net.restype = vp
+    L.dg16_rccl_destroy.argtypes = [vp]
+    L.dg16_rccl_destroy.restype = None
+    L.dg16_rccl_error.argtypes = []
+    L.dg16_rccl_error.restype = ctypes.c_char_p
     L.dg16_localnet_create.argtypes = [u, ctypes.POINTER(vp)]
     L.dg16_localnet_party.argtypes = [vp, u]
     L.dg16_localnet_party.restype = vp
@@ -166,7 +207,10 @@ EXPORTED = ["dg16_ctx_create", "dg16_ctx_destroy", "dg16_last_error", "dg16_set_
             "dg16_groth16_assemble", "dg16_localnet_create", "dg16_localnet_party", "dg16_localnet_destroy", "dg16_localnet_abort",
             "dg16_localnet_reset",
             "dg16_pss_create", "dg16_pss_destroy", "dg16_pss_apply", "dg16_pss_apply_exp", "dg16_d_fft",
-            "dg16_d_msm", "dg16_deg_red", "dg16_d_pp", "dg16_ext_wit_h", "dg16_qap",
+            "dg16_d_msm", "dg16_deg_red", "dg16_d_pp", "dg16_ext_wit_h", "dg16_qap", "dg16_qap_rows",
+            "dg16_h_poly_dist", "dg16_h_poly_dist_stage", "dg16_groth16_msms_h", "dg16_groth16_prove_dist",
+            "dg16_rccl_unique_id", "dg16_rccl_create", "dg16_rccl_comm", "dg16_rccl_net", "dg16_rccl_destroy",
+            "dg16_rccl_error",
             "dg16_io_error", "dg16_r1cs_parse", "dg16_r1cs_header_get", "dg16_r1cs_matrix", "dg16_r1cs_wire_map",
             "dg16_r1cs_free", "dg16_zkey_parse", "dg16_zkey_header_get", "dg16_zkey_points", "dg16_zkey_matrix",
             "dg16_zkey_free", "dg16_serialize_error", "dg16_proof_compress", "dg16_proof_decompress",
@@ -335,19 +379,53 @@ class Context:
                                   _ptr(w_p), _ptr(a_out), _ptr(b_out), _ptr(c_out),
                                   F_DEVICE_PTRS | (F_SCALARS_MONT if scalars_mont else 0), channel))
 
+    def qap_rows_dev(self, curve, num_constraints, num_inputs, num_vars, log_m, a_ptr_p, a_col_p, a_val_p, b_ptr_p,
+                     b_col_p, b_val_p, w_p, row_start, row_stride, a_out, b_out, c_out, scalars_mont=True, channel=0):
+        """qap_dev for the rows row_start + row_stride * j only (this rank's cyclic rows), written densely."""
+        self._chk(self.L.dg16_qap_rows(self.h, CURVES[curve], num_constraints, num_inputs, num_vars, log_m,
+                                       _ptr(a_ptr_p), _ptr(a_col_p), _ptr(a_val_p), _ptr(b_ptr_p), _ptr(b_col_p),
+                                       _ptr(b_val_p), _ptr(w_p), row_start, row_stride, _ptr(a_out), _ptr(b_out),
+                                       _ptr(c_out), F_DEVICE_PTRS | (F_SCALARS_MONT if scalars_mont else 0), channel))
+
+    # ---- one process per GPU: sharded h-polynomial, distributed prove -------------------------------------------
+    def h_poly_dist_dev(self, curve, comm, a_ptr, b_ptr, c_ptr, log_m, out_ptr, channel=0):
+        """comm: an object with `.comm_ptr` (RcclComm, TorchComm) or None."""
+        self._chk(self.L.dg16_h_poly_dist(self.h, CURVES[curve], comm.comm_ptr if comm is not None else None,
+                                          _ptr(a_ptr), _ptr(b_ptr), _ptr(c_ptr), log_m, _ptr(out_ptr), F_DEVICE_PTRS,
+                                          channel))
+
+    def h_poly_dist_stage_dev(self, curve, log_m, rank, n_ranks, stage, in_ptrs, out_ptr, channel=0):
+        arr = (ctypes.c_void_p * 3)(*[int(x) for x in list(in_ptrs) + [0] * (3 - len(in_ptrs))])
+        self._chk(self.L.dg16_h_poly_dist_stage(self.h, CURVES[curve], log_m, rank, n_ranks, stage, arr, _ptr(out_ptr),
+                                                F_DEVICE_PTRS, channel))
+
+    def groth16_msms_h_dev(self, pk, h_ptr, w_ptr, rs_host, results_ptr, scalars_mont=True):
+        rs_host = np.ascontiguousarray(rs_host, dtype=np.uint64)
+        self._chk(self.L.dg16_groth16_msms_h(self.h, pk.h, _ptr(h_ptr), _ptr(w_ptr), _ptr(rs_host),
+                                             F_DEVICE_PTRS | (F_SCALARS_MONT if scalars_mont else 0), _ptr(results_ptr)))
+
+    def prove_dist_dev(self, pk, comm, a_ptr, b_ptr, c_ptr, w_ptr, rs_host, out_ptr, scalars_mont=True):
+        rs_host = np.ascontiguousarray(rs_host, dtype=np.uint64)
+        self._chk(self.L.dg16_groth16_prove_dist(self.h, pk.h, comm.comm_ptr if comm is not None else None,
+                                                 _ptr(a_ptr), _ptr(b_ptr), _ptr(c_ptr), _ptr(w_ptr), _ptr(rs_host),
+                                                 F_DEVICE_PTRS | (F_SCALARS_MONT if scalars_mont else 0),
+                                                 _ptr(out_ptr)))
+
     # ---- Groth16 prover ---------------------------------------------------------------------------------
     def pk_create(self, curve, num_vars, num_inputs, domain_size, a_query, b_g1_query, b_g2_query, h_query,
-                  l_query, fixed_points, device_ptrs=False, shard=0, n_shards=1):
+                  l_query, fixed_points, device_ptrs=False, shard=0, n_shards=1, h_cyclic=False):
         """Makes an arkworks-shaped ProvingKey resident (see include/dg16.h).  Arguments are numpy
         arrays (host) or raw device pointers (device_ptrs=True).  With n_shards > 1 only slice
-        `shard` of every MSM range is kept (one process per GPU)."""
+        `shard` of every MSM range is kept (one process per GPU); h_cyclic: the h bases of the shard are
+        h_query[shard + n_shards * j], the output layout of the sharded h-polynomial."""
         h = ctypes.c_void_p()
         args = [a_query, b_g1_query, b_g2_query, h_query, l_query, fixed_points]
         if not device_ptrs:
             args = [np.ascontiguousarray(x, dtype=np.uint64) for x in args]
         self._chk(self.L.dg16_pk_create_shard(self.h, CURVES[curve], num_vars, num_inputs, domain_size,
                                               *[_ptr(x) for x in args], shard, n_shards,
-                                              F_DEVICE_PTRS if device_ptrs else 0, ctypes.byref(h)))
+                                              (F_DEVICE_PTRS if device_ptrs else 0) | (F_H_CYCLIC if h_cyclic else 0),
+                                              ctypes.byref(h)))
         return ProvingKey(self, h, curve, num_vars, num_inputs, domain_size)
 
     def results_bytes(self, curve):
@@ -427,3 +505,115 @@ class Context:
         fid = CURVES[curve] + (16 if kind == "fr" else 0)
         self._chk(self.L.dg16_field_op(self.h, fid, op, _ptr(a_ptr), _ptr(b_ptr), _ptr(out_ptr), n,
                                        F_DEVICE_PTRS, channel))
+
+
+# ---- transports of the one-process-per-GPU prover (dg16_comm) ---------------------------------------------------
+def rccl_unique_id():
+    """128 bytes made on rank 0 and handed to the other ranks out of band (e.g. torch.distributed's store)."""
+    L = load()
+    buf = ctypes.create_string_buffer(128)
+    rc = L.dg16_rccl_unique_id(buf)
+    if rc != 0:
+        raise Dg16Error(rc, L.dg16_rccl_error().decode())
+    return buf.raw
+
+
+class RcclComm:
+    """Native RCCL communicator of libdg16 (csrc/rccl_net.hip): `.comm_ptr` for prove_dist / h_poly_dist,
+    `.net_ptr` = the same communicator behind the MpcNet vtable (d_fft, d_msm, ... one party per GPU)."""
+
+    def __init__(self, ctx, unique_id, n_ranks, rank):
+        self.ctx, self.L = ctx, ctx.L
+        h = ctypes.c_void_p()
+        rc = self.L.dg16_rccl_create(ctx.h, unique_id, n_ranks, rank, ctypes.byref(h))
+        if rc != 0:
+            raise Dg16Error(rc, self.L.dg16_rccl_error().decode())
+        self.h = h
+        self.n_ranks, self.rank = n_ranks, rank
+        self.comm_ptr = ctypes.c_void_p(self.L.dg16_rccl_comm(h))
+        self.net_ptr = ctypes.c_void_p(self.L.dg16_rccl_net(h))
+
+    def describe(self):
+        return "native RCCL (grouped ncclSend/ncclRecv + ncclAllGather, stream-ordered)"
+
+    def close(self):
+        if getattr(self, "h", None) and self.ctx.h:
+            self.L.dg16_rccl_destroy(self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class TorchComm:
+    """dg16_comm implemented by the caller with torch.distributed: the `nccl` backend stays stream-ordered (the
+    collective is issued under the library's stream), `gloo` stages through host memory -- that one exists so that
+    the distributed entry points can be driven by several processes that share ONE GPU (tests), where RCCL refuses
+    to form a communicator."""
+
+    def __init__(self, dist, device, n_ranks, rank):
+        import torch
+        self.torch, self.dist, self.device = torch, dist, device
+        self.n_ranks, self.rank = n_ranks, rank
+        self.backend = dist.get_backend()
+        self.errors = []
+        self._cb = (_COMM_N(lambda _s: n_ranks), _COMM_N(lambda _s: rank), _COMM_GATHER(self._all_gather),
+                    _COMM_A2A(self._all_to_all))
+        self.struct = CommStruct(None, *self._cb)
+        self.comm_ptr = ctypes.cast(ctypes.pointer(self.struct), ctypes.c_void_p)
+
+    def describe(self):
+        return "torch.distributed (%s)" % self.backend
+
+    def close(self):
+        pass
+
+    def _tensor(self, ptr, nbytes):
+        class Buf:
+            pass
+        b = Buf()
+        b.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+        return self.torch.as_tensor(b, device=self.device)
+
+    def _run(self, stream, fn):
+        torch = self.torch
+        try:
+            ext = torch.cuda.ExternalStream(int(stream), device=self.device)
+            if self.backend == "nccl":
+                with torch.cuda.stream(ext):
+                    fn(False)
+            else:
+                ext.synchronize()
+                fn(True)
+                torch.cuda.synchronize(self.device)
+            return 0
+        except Exception as e:                       # never let an exception cross the C ABI
+            self.errors.append(repr(e))
+            return 6
+
+    def _all_gather(self, _s, send, nbytes, recv, stream):
+        def fn(host):
+            src, dst = self._tensor(send, nbytes), self._tensor(recv, nbytes * self.n_ranks)
+            if host:
+                out = self.torch.empty(nbytes * self.n_ranks, dtype=self.torch.uint8)
+                self.dist.all_gather_into_tensor(out, src.cpu())
+                dst.copy_(out)
+            else:
+                self.dist.all_gather_into_tensor(dst, src)
+        return self._run(stream, fn)
+
+    def _all_to_all(self, _s, send, recv, per_peer, stream):
+        def fn(host):
+            n = self.n_ranks
+            src, dst = self._tensor(send, per_peer * n), self._tensor(recv, per_peer * n)
+            if host:
+                # gloo has no all-to-all: gather everything, keep the column addressed to this rank
+                allbuf = self.torch.empty(per_peer * n * n, dtype=self.torch.uint8)
+                self.dist.all_gather_into_tensor(allbuf, src.cpu())
+                dst.copy_(allbuf.view(n, n, per_peer)[:, self.rank, :].reshape(-1))
+            else:
+                self.dist.all_to_all_single(dst, src)
+        return self._run(stream, fn)

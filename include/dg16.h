@@ -65,7 +65,9 @@ enum dg16_status {
 enum dg16_flags {
   DG16_F_SCALARS_MONT = 1u, /* scalars are in Montgomery form (arkworks memory) */
   DG16_F_DEVICE_PTRS = 2u,  /* all data pointers are device pointers */
-  DG16_F_OUT_AFFINE = 4u    /* group result as affine x || y (one inversion on the device) */
+  DG16_F_OUT_AFFINE = 4u,   /* group result as affine x || y (one inversion on the device) */
+  DG16_F_H_CYCLIC = 8u      /* dg16_pk_create_shard: this shard's h_query bases are h_query[shard + n_shards * j]
+                               (the output layout of the sharded h-polynomial) instead of a contiguous slice */
 };
 
 /* field ids for dg16_field_op: curve for the base field Fq, 16 + curve for the scalar field Fr */
@@ -113,6 +115,14 @@ int dg16_qap(dg16_ctx *ctx, int curve, size_t num_constraints, size_t num_inputs
              const uint32_t *b_row_ptr, const uint32_t *b_col, const void *b_coeff,
              const void *full_assignment, void *a_out, void *b_out, void *c_out, unsigned flags,
              int channel);
+
+/* The same for the rows i = row_start + row_stride * j, j < 2^log_m / row_stride, written densely (a_out[j] is row
+ * i): rank `row_start` of `row_stride` ranks computes exactly the cyclic rows the sharded h-polynomial consumes. */
+int dg16_qap_rows(dg16_ctx *ctx, int curve, size_t num_constraints, size_t num_inputs, size_t num_vars,
+                  unsigned log_m, const uint32_t *a_row_ptr, const uint32_t *a_col, const void *a_coeff,
+                  const uint32_t *b_row_ptr, const uint32_t *b_col, const void *b_coeff,
+                  const void *full_assignment, size_t row_start, size_t row_stride, void *a_out, void *b_out,
+                  void *c_out, unsigned flags, int channel);
 
 /* ---- MSM ----------------------------------------------------------------------------------------
  * out = sum_i scalars[i] * bases[i] in G1 (group = 1) or G2 (group = 2).
@@ -193,6 +203,69 @@ int dg16_groth16_msms(dg16_ctx *ctx, const dg16_pk *pk, const void *a, const voi
 int dg16_groth16_assemble(dg16_ctx *ctx, const dg16_pk *pk, const void *gathered_results,
                           size_t n_shards, const void *r_s, unsigned flags, void *proof_out);
 
+/* ---- one process per GPU: collectives, sharded h-polynomial, distributed prove ----------------------------------
+ * The king / client exchange of the reference (mpc-net/src/lib.rs:61-140 under dist-primitives/src/channel/mod.rs:8-57)
+ * re-mapped to the GPUs of one node: `dg16_comm` is what the prover needs from a transport, dg16_rccl_* is the
+ * native implementation (RCCL grouped send / recv on device buffers over xGMI, stream-ordered: no host
+ * synchronisation on the data path).  A comm may also be implemented by the caller (tests drive these entry points
+ * with a torch.distributed / gloo-backed comm).
+ *
+ *   all_gather   every rank contributes `bytes`; recv_dev gets n_ranks * bytes ordered by rank
+ *                (d_msm's "gather to king, sum, send back" with the sum on every rank, dmsm/mod.rs:88-97)
+ *   all_to_all   bytes_per_peer bytes at send_dev + p * bytes_per_peer go to rank p and land at
+ *                recv_dev + me * bytes_per_peer there (the butterfly exchange of the sharded NTT; the reference
+ *                does gather -> fft2_in_place -> scatter through the king, dfft/mod.rs:185-256)
+ * Both are ordered on `hip_stream`: the payload was produced on it, the result may be consumed on it. */
+typedef struct dg16_comm {
+  void *self;
+  unsigned (*n_ranks)(void *self);
+  unsigned (*rank)(void *self);
+  int (*all_gather)(void *self, const void *send_dev, size_t bytes, void *recv_dev, void *hip_stream);
+  int (*all_to_all)(void *self, const void *send_dev, void *recv_dev, size_t bytes_per_peer, void *hip_stream);
+} dg16_comm;
+
+/* h-polynomial over n_ranks GPUs (2, 4 or 8; 2^log_m >= n_ranks^2).  a, b, c: this rank's CYCLIC rows of the QAP
+ * evaluation vectors, a[n_ranks * j + rank], j < 2^log_m / n_ranks (dg16_qap_rows); out: h[rank + n_ranks * j] --
+ * the scalars of a DG16_F_H_CYCLIC key shard.  Two all-to-alls of 3 * 32 * 2^log_m / n_ranks bytes per rank.
+ * Device pointers only (DG16_F_DEVICE_PTRS must be set). */
+int dg16_h_poly_dist(dg16_ctx *ctx, int curve, const dg16_comm *comm, const void *a_rows, const void *b_rows,
+                     const void *c_rows, unsigned log_m, void *out, unsigned flags, int channel);
+/* The three local stages of dg16_h_poly_dist, for callers that run the exchanges themselves:
+ *   stage 0  in = {a_rows, b_rows, c_rows}         out = send buffer 1  [peer][vector][S], S = 2^log_m / n_ranks^2
+ *   stage 1  in = {receive buffer 1}               out = send buffer 2  [peer][vector][S]
+ *   stage 2  in = {receive buffer 2}               out = h[rank + n_ranks * j]
+ * Buffers hold 3 * 2^log_m / n_ranks elements. */
+int dg16_h_poly_dist_stage(dg16_ctx *ctx, int curve, unsigned log_m, unsigned rank, unsigned n_ranks, int stage,
+                           const void *const *in, void *out, unsigned flags, int channel);
+
+/* dg16_groth16_msms with the h-polynomial already made (h_shard: the n_h scalars of this key's h slice, Montgomery
+ * form, device pointer or host per flags) -- the half of a distributed proof after the sharded h-polynomial. */
+int dg16_groth16_msms_h(dg16_ctx *ctx, const dg16_pk *pk, const void *h_shard, const void *full_assignment,
+                        const void *r_s, unsigned flags, void *results_out);
+
+/* The whole distributed proof on this rank, stream-ordered: sharded h-polynomial (two all-to-alls), this shard's
+ * five MSMs, one all-gather of the results records, assembly.  pk: a DG16_F_H_CYCLIC shard (rank = shard,
+ * n_ranks = n_shards); a_rows, b_rows, c_rows as for dg16_h_poly_dist.  With comm == NULL (or one rank) and an
+ * unsharded key this is dg16_groth16_prove.  Every rank receives the same proof. */
+int dg16_groth16_prove_dist(dg16_ctx *ctx, const dg16_pk *pk, const dg16_comm *comm, const void *a_rows,
+                            const void *b_rows, const void *c_rows, const void *full_assignment, const void *r_s,
+                            unsigned flags, void *proof_out);
+
+/* Native RCCL transport.  Rank 0 makes the 128-byte id (dg16_rccl_unique_id) and hands it to the other ranks out
+ * of band (the launcher's rendezvous); every rank then calls dg16_rccl_create on its own context (blocking until all
+ * ranks have joined).  dg16_rccl_comm serves dg16_h_poly_dist / dg16_groth16_prove_dist; dg16_rccl_net is the same
+ * communicator behind the MpcNet vtable below (king = rank 0), so that d_fft / d_msm / d_pp / ext_wit::h run one
+ * party per GPU.  librccl is bound at run time (dlopen): without it these return DG16_ERR_UNSUPPORTED and the rest
+ * of the library is unaffected. */
+typedef struct dg16_rccl dg16_rccl;
+struct dg16_net;
+int dg16_rccl_unique_id(void *out128);
+int dg16_rccl_create(dg16_ctx *ctx, const void *unique_id128, unsigned n_ranks, unsigned rank, dg16_rccl **out);
+const dg16_comm *dg16_rccl_comm(dg16_rccl *h);
+const struct dg16_net *dg16_rccl_net(dg16_rccl *h);
+void dg16_rccl_destroy(dg16_rccl *h);
+const char *dg16_rccl_error(void);
+
 /* ---- dist-primitives, literally (packed secret sharing over an MpcNet) -----------------------------
  * These mirror the reference's functions one to one; "party" = one caller (a host thread with its own
  * dg16_ctx for the in-process LocalNet, or one process per GPU with RCCL-backed callbacks).  All
@@ -229,6 +302,13 @@ typedef struct dg16_net {
                         void *hip_stream);
   int (*scatter_from_king)(void *self, int channel, const void *send_dev, size_t bytes, void *recv_dev,
                            void *hip_stream);
+  /* MpcNet's required methods (mpc-net/src/lib.rs:46-58): is_init, and the point-to-point pair the two provided
+   * collectives above are written in terms of.  A send_to(peer) completes against the peer's recv_from(me) with
+   * the same channel and the same `bytes` (a length mismatch is DG16_ERR_NET on both sides, like the reference's
+   * framing error); both are ordered on `hip_stream`. */
+  int (*is_init)(void *self);
+  int (*send_to)(void *self, unsigned peer, int channel, const void *send_dev, size_t bytes, void *hip_stream);
+  int (*recv_from)(void *self, unsigned peer, int channel, void *recv_dev, size_t bytes, void *hip_stream);
 } dg16_net;
 
 int dg16_localnet_create(unsigned n_parties, dg16_localnet **out);

@@ -1,0 +1,225 @@
+"""GPU parity of the one-process-per-GPU path, on the one GPU of the test box:
+
+  * the sharded h-polynomial (csrc/ntt.hip: h_poly_dist_stage) -- all N ranks are played by this process, stage by
+    stage, with the two all-to-alls done as tensor transposes; every rank's slice must equal the C oracle's
+    h[rank + N j] (and, at 2^20, the unsharded GPU h-polynomial, itself oracle-checked in test_gpu_ntt.py);
+  * dg16_qap_rows against the oracle's QAP vectors, row subset by row subset;
+  * the native RCCL communicator at world size 1 (binding, communicator, grouped send / recv to self, all-gather) and
+    dg16_groth16_prove_dist through it;
+  * MpcNet's send_to / recv_from on the in-process LocalNet.
+The multi-process form (2 and 4 ranks sharing the GPU, gloo transport) is tests/test_gpu_two_rank.py."""
+
+import ctypes
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import corc
+from gpu_util import ctx
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def dev_t(arr):
+    return torch.from_numpy(np.ascontiguousarray(arr).view(np.int64)).to(DEV)
+
+
+def all_to_all(bufs):
+    """bufs[r]: rank r's send buffer as [peer][...]; returns the receive buffers [src][...]."""
+    n = len(bufs)
+    chunks = [b.view(n, -1) for b in bufs]
+    return [torch.stack([chunks[src][dst] for src in range(n)]).contiguous().view(-1) for dst in range(n)]
+
+
+def sharded_h(c, curve, a, b, cc, n_ranks):
+    """All ranks in this process.  a, b, cc: host arrays (m x 4, Montgomery).  Returns [rank] -> host array."""
+    m = a.shape[0]
+    log_m = m.bit_length() - 1
+    M = m // n_ranks
+    rows = [[dev_t(v[r::n_ranks]) for v in (a, b, cc)] for r in range(n_ranks)]
+    send = [torch.empty(3 * M * 4, dtype=torch.int64, device=DEV) for _ in range(n_ranks)]
+    for r in range(n_ranks):
+        c.h_poly_dist_stage_dev(curve, log_m, r, n_ranks, 0, [t.data_ptr() for t in rows[r]], send[r].data_ptr())
+    c.sync(0)
+    recv = all_to_all(send)
+    torch.cuda.synchronize()
+    send2 = [torch.empty_like(t) for t in recv]
+    for r in range(n_ranks):
+        c.h_poly_dist_stage_dev(curve, log_m, r, n_ranks, 1, [recv[r].data_ptr()], send2[r].data_ptr())
+    c.sync(0)
+    recv2 = all_to_all(send2)
+    torch.cuda.synchronize()
+    out = [torch.empty(M * 4, dtype=torch.int64, device=DEV) for _ in range(n_ranks)]
+    for r in range(n_ranks):
+        c.h_poly_dist_stage_dev(curve, log_m, r, n_ranks, 2, [recv2[r].data_ptr()], out[r].data_ptr())
+    c.sync(0)
+    return [t.cpu().numpy().view(np.uint64).reshape(M, 4) for t in out]
+
+
+@pytest.mark.parametrize("curve,log_m,n_ranks", [("bn254", 2, 2), ("bn254", 6, 2), ("bn254", 6, 4), ("bn254", 6, 8),
+                                                 ("bn254", 12, 4), ("bn254", 15, 8), ("bls12_381", 10, 2),
+                                                 ("bls12_381", 13, 8), ("bls12_377", 11, 4), ("bn254", 18, 2)])
+def test_sharded_h_poly_equals_oracle(curve, log_m, n_ranks):
+    m = 1 << log_m
+    a, b, cc = (corc.rand_field(curve, "fr", 11 * i + log_m, m) for i in (1, 2, 3))
+    ref = corc.h_poly(curve, a, b, cc)
+    got = sharded_h(ctx(), curve, a, b, cc, n_ranks)
+    for r in range(n_ranks):
+        assert np.array_equal(got[r], ref[r::n_ranks]), "rank %d" % r
+
+
+@pytest.mark.parametrize("curve", ["bn254", "bls12_381"])
+def test_sharded_h_poly_at_2e20_over_8_ranks_equals_unsharded(curve):
+    # BASELINE's headline domain: the per-rank transforms are 2^17-point (two-step plans), S = 2^14
+    m = 1 << 20
+    a, b, cc = (corc.rand_field(curve, "fr", 5 + i, m) for i in (1, 2, 3))
+    c = ctx()
+    ref = c.h_poly(curve, a, b, cc)
+    got = sharded_h(c, curve, a, b, cc, 8)
+    for r in range(8):
+        assert np.array_equal(got[r], ref[r::8]), "rank %d" % r
+
+
+def test_sharded_h_poly_argument_checks():
+    import dg16_amd
+    c = ctx()
+    t = torch.zeros(3 * 64 * 4, dtype=torch.int64, device=DEV)
+    for kw in (dict(log_m=6, rank=0, n_ranks=3), dict(log_m=3, rank=0, n_ranks=4), dict(log_m=6, rank=2, n_ranks=2),
+               dict(log_m=8, rank=0, n_ranks=16)):
+        with pytest.raises(dg16_amd.Dg16Error):
+            c.h_poly_dist_stage_dev("bn254", kw["log_m"], kw["rank"], kw["n_ranks"], 1, [t.data_ptr()], t.data_ptr())
+
+
+@pytest.mark.parametrize("stride", [1, 2, 8])
+def test_qap_rows_are_the_strided_rows_of_qap(stride):
+    from oracle.pyref.fields import FR
+    from oracle.pyref import groth16 as G
+    curve = "bn254"
+    F = FR[curve]
+    nc, ni = 200, 3
+    r1cs, w = G.synthetic_r1cs(F, num_constraints=nc, num_instance=ni, num_witness=90, seed=8)
+
+    def csr(rows):
+        ptr, col, val = [0], [], []
+        for row in rows:
+            for cf, idx in row:
+                col.append(idx)
+                val.append(cf)
+            ptr.append(len(col))
+        return (np.asarray(ptr, dtype=np.uint32), np.asarray(col, dtype=np.uint32),
+                corc.ints_to_arr([F.to_mont(v) for v in val], 4))
+
+    csr_a, csr_b = csr(r1cs["a"]), csr(r1cs["b"])
+    c = ctx()
+    wm = corc.ints_to_arr([F.to_mont(x % F.p) for x in w], 4)
+    full = c.qap(curve, nc, ni, csr_a, csr_b, wm)
+    log_m = full[0].shape[0].bit_length() - 1
+    d = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(DEV)      # noqa: E731
+    ap, ac, av = d(csr_a[0].view(np.int32)), d(csr_a[1].view(np.int32)), dev_t(csr_a[2])
+    bp, bc, bv = d(csr_b[0].view(np.int32)), d(csr_b[1].view(np.int32)), dev_t(csr_b[2])
+    wd = dev_t(wm)
+    rows = (1 << log_m) // stride
+    for start in range(stride):
+        outs = [torch.empty(rows * 4, dtype=torch.int64, device=DEV) for _ in range(3)]
+        c.qap_rows_dev(curve, nc, ni, len(w), log_m, ap.data_ptr(), ac.data_ptr(), av.data_ptr(), bp.data_ptr(),
+                       bc.data_ptr(), bv.data_ptr(), wd.data_ptr(), start, stride, *[o.data_ptr() for o in outs])
+        c.sync(0)
+        for o, f in zip(outs, full):
+            assert np.array_equal(o.cpu().numpy().view(np.uint64).reshape(rows, 4), f[start::stride])
+
+
+def test_native_rccl_comm_world_size_one():
+    """One rank: the library binds librccl, forms a communicator and runs its collectives against itself."""
+    from dg16_amd import lib
+    c = ctx()
+    comm = lib.RcclComm(c, lib.rccl_unique_id(), 1, 0)
+    vt = ctypes.cast(comm.comm_ptr, ctypes.POINTER(lib.CommStruct)).contents
+    assert vt.n_ranks(vt.self) == 1 and vt.rank(vt.self) == 0
+    src = torch.arange(4096, dtype=torch.int64, device=DEV)
+    dst = torch.zeros_like(src)
+    st = torch.cuda.current_stream().cuda_stream
+    assert vt.all_to_all(vt.self, src.data_ptr(), dst.data_ptr(), src.numel() * 8, st) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(src, dst)
+    dst.zero_()
+    assert vt.all_gather(vt.self, src.data_ptr(), src.numel() * 8, dst.data_ptr(), st) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(src, dst)
+    # the same communicator behind the MpcNet vtable: gather / scatter of the king with itself
+    net = ctypes.cast(comm.net_ptr, ctypes.POINTER(lib.NetStruct)).contents
+    assert net.n_parties(net.self) == 1 and net.party_id(net.self) == 0 and net.is_init(net.self) == 1
+    dst.zero_()
+    assert net.gather_to_king(net.self, 0, src.data_ptr(), src.numel() * 8, dst.data_ptr(), st) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(src, dst)
+    comm.close()
+
+
+def test_prove_dist_through_rccl_world_one_equals_prove():
+    import bench
+    from dg16_amd import lib
+    from dg16_amd.parallel import NativeProver
+    c = ctx()
+    wl = bench.Workload(c, torch.device(DEV), 10, 0, 1, seed=31)
+    ref = bench.prove_once(c, wl)
+    comm = lib.RcclComm(c, lib.rccl_unique_id(), 1, 0)
+    p = NativeProver(c, wl.pk, "bn254", comm, 0, 1)
+    wl.qap()
+    got = p.prove(wl.a, wl.b, wl.c, wl.w, wl.rs, scalars_mont=False)
+    for ch in range(3):
+        c.sync(ch)
+    # (Jacobian coordinates are not canonical: compare the points)
+    for x, y in zip(bench.gpu_proof_affine("bn254", got.cpu().numpy()), bench.gpu_proof_affine("bn254", ref)):
+        assert np.array_equal(x, y)
+    p.close()
+    wl.pk.close()
+
+
+def test_localnet_send_to_recv_from():
+    """MpcNet::send_to / recv_from (mpc-net/src/lib.rs:48-58) on the in-process net: a ring of three parties, and a
+    length mismatch that fails on both sides."""
+    from dg16_amd import lib
+    from dg16_amd.dist import LocalTestNet
+    net = LocalTestNet(3)
+    bufs = [torch.full((256,), 10 + i, dtype=torch.int64, device=DEV) for i in range(3)]
+    got = [torch.zeros(256, dtype=torch.int64, device=DEV) for _ in range(3)]
+    torch.cuda.synchronize()
+    res = [None] * 3
+
+    def party(i):
+        vt = ctypes.cast(net.party(i), ctypes.POINTER(lib.NetStruct)).contents
+        nxt, prv = (i + 1) % 3, (i + 2) % 3
+        if i == 0:      # break the ring's symmetry: party 0 sends first, the others receive first
+            a = vt.send_to(vt.self, nxt, 1, bufs[i].data_ptr(), 2048, None)
+            b = vt.recv_from(vt.self, prv, 1, got[i].data_ptr(), 2048, None)
+        else:
+            b = vt.recv_from(vt.self, prv, 1, got[i].data_ptr(), 2048, None)
+            a = vt.send_to(vt.self, nxt, 1, bufs[i].data_ptr(), 2048, None)
+        res[i] = (a, b)
+
+    ts = [threading.Thread(target=party, args=(i,)) for i in range(3)]
+    [t.start() for t in ts]
+    [t.join(60) for t in ts]
+    assert res == [(0, 0)] * 3
+    torch.cuda.synchronize()
+    for i in range(3):
+        assert torch.equal(got[i], bufs[(i + 2) % 3])
+    # unequal lengths: DG16_ERR_NET (6) on both sides
+    out = [None, None]
+
+    def snd():
+        vt = ctypes.cast(net.party(0), ctypes.POINTER(lib.NetStruct)).contents
+        out[0] = vt.send_to(vt.self, 1, 0, bufs[0].data_ptr(), 1024, None)
+
+    def rcv():
+        vt = ctypes.cast(net.party(1), ctypes.POINTER(lib.NetStruct)).contents
+        out[1] = vt.recv_from(vt.self, 0, 0, got[1].data_ptr(), 2048, None)
+
+    ts = [threading.Thread(target=snd), threading.Thread(target=rcv)]
+    [t.start() for t in ts]
+    [t.join(60) for t in ts]
+    assert out == [6, 6]
+    net.close()

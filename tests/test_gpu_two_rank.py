@@ -22,11 +22,14 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("world,log_m", [(2, 12), (3, 14)])
-def test_sharded_proof_across_processes(world, log_m):
+# (2, 4 ranks: sharded h-polynomial, native pipeline under a gloo-backed dg16_comm and the Python-driven protocol;
+#  3 ranks: replicated h-polynomial, contiguous slices)
+@pytest.mark.parametrize("world,log_m,transport", [(2, 12, "torch"), (4, 12, "torch"), (2, 10, "python"),
+                                                   (3, 14, "python")])
+def test_sharded_proof_across_processes(world, log_m, transport):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
-           os.path.join(ROOT, "tools", "two_rank_check.py"), str(log_m)]
+           os.path.join(ROOT, "tools", "two_rank_check.py"), str(log_m), transport]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=280)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]

@@ -1,6 +1,7 @@
-"""N > 1 path on CPU: world_size-2 gloo run of DistributedProver with an oracle-backed engine standing
-in for the GPU (test infrastructure only).  Checks the shard bounds, the single all-gather and the
-assembly: the distributed proof must equal the single-prover proof of the big-int restatement."""
+"""N > 1 path on CPU: world_size-2 gloo runs of DistributedProver with an oracle-backed engine standing
+in for the GPU (test infrastructure only).  Checks the shard bounds, the sharded h-polynomial's exchange layout
+(cyclic rows, two all-to-alls, cyclic h bases), the single all-gather and the assembly: the distributed proof must
+equal the single-prover proof of the big-int restatement -- with the replicated and with the sharded h-polynomial."""
 
 import os
 import random
@@ -30,11 +31,12 @@ class OracleEngine:
     Jacobian, then B' as G2 Jacobian, Montgomery limbs; shard 0 folds the fixed points in), computed with the
     CPU oracle on this rank's slices."""
 
-    def __init__(self, curve, pk, r1cs_dims, shard, n_shards):
+    def __init__(self, curve, pk, r1cs_dims, shard, n_shards, h_cyclic=False):
         from oracle import corc
         from dg16_amd.parallel import shard_bounds
         self.corc, self.curve, self.pk = corc, curve, pk
         self.nv, self.ni, self.m = r1cs_dims
+        self.shard, self.n_shards, self.h_cyclic = shard, n_shards, h_cyclic
         self.ab = shard_bounds(self.nv - 1, shard, n_shards)
         self.lb = shard_bounds(self.nv - self.ni, shard, n_shards)
         self.hb = shard_bounds(self.m, shard, n_shards)
@@ -51,14 +53,49 @@ class OracleEngine:
             out[2 * nl:2 * nl + 4] = one
         return out
 
-    def partial(self, a, b, c, w, rs_host, scalars_mont):
+    # ---- sharded h-polynomial: the stages of oracle/pyref/hdist.py behind GpuEngine's interface ----
+    def _ints(self, t):
+        arr = t.numpy().view(np.uint64).reshape(-1, 4)
+        return self.corc.arr_to_ints(self.corc.field_op(self.curve, "fr", "from_mont", arr))
+
+    def _tensor(self, vals):
+        from oracle.pyref.fields import FR
+        F = FR[self.curve]
+        return torch.from_numpy(self.corc.ints_to_arr([F.to_mont(v) for v in vals], 4).view(np.uint8).reshape(-1).copy())
+
+    def h_stage(self, stage, inputs, rank, world):
+        from oracle.pyref import hdist
+        from oracle.pyref.fields import FR
+        F, m = FR[self.curve], self.m
+        M, S = m // world, m // world // world
+        if stage == 0:      # rows -> [peer][vector][S]
+            Y = [hdist.stage0(self._ints(v), F, m, world) for v in inputs]
+            return self._tensor([Y[v][p * S + j] for p in range(world) for v in range(3) for j in range(S)])
+        buf = self._ints(inputs[0])
+        piece = lambda p, v: buf[(p * 3 + v) * S:(p * 3 + v + 1) * S]      # noqa: E731
+        if stage == 1:
+            U = [hdist.stage1([piece(p, v) for p in range(world)], F, m, world, rank) for v in range(3)]
+            return self._tensor([U[v][q][j] for q in range(world) for v in range(3) for j in range(S)])
+        W = [[x for p in range(world) for x in piece(p, v)] for v in range(3)]
+        return self._tensor(hdist.stage2(W[0], W[1], W[2], F, m, world))
+
+    def empty_like_bytes(self, t, times=1):
+        return torch.empty(t.numel() * times, dtype=torch.uint8)
+
+    def partial_h(self, h, w, rs_host, scalars_mont):
+        return self.partial(None, None, None, w, rs_host, scalars_mont, h_shard=h)
+
+    def partial(self, a, b, c, w, rs_host, scalars_mont, h_shard=None):
         corc, cv = self.corc, self.curve
         R = 21888242871839275222246405745257275088548364400416034343698204186575808495617
         r_full = int(sum(int(x) << (64 * i) for i, x in enumerate(rs_host[0])))
         s_full = int(sum(int(x) << (64 * i) for i, x in enumerate(rs_host[1])))
         r, s = (r_full, s_full) if self.last else (0, 0)     # the delta pairs ride on the last shard
         w = w.numpy()
-        h = corc.field_op(cv, "fr", "from_mont", corc.h_poly(cv, a.numpy(), b.numpy(), c.numpy()))
+        if h_shard is None:
+            h = corc.field_op(cv, "fr", "from_mont", corc.h_poly(cv, a.numpy(), b.numpy(), c.numpy()))
+        else:
+            h = corc.field_op(cv, "fr", "from_mont", h_shard.numpy().view(np.uint64).reshape(-1, 4))
         pk = self.pk
         sc = lambda v: corc.ints_to_arr([v], 4)
         add = lambda grp, p, q: corc.point_add(cv, grp, p, q)
@@ -76,7 +113,10 @@ class OracleEngine:
         L = corc.msm(cv, 1, np.concatenate([pk["l_query"][lo:hi], pk["delta_g1"]]),
                      np.concatenate([w[self.ni:][lo:hi], sc((R - r * s % R) % R)]))
         lo, hi = self.hb
-        H = corc.msm(cv, 1, pk["h_query"][lo:hi], h[lo:hi])
+        if h_shard is not None:      # cyclic bases h_query[shard + n_shards * j] against this rank's h
+            H = corc.msm(cv, 1, np.ascontiguousarray(pk["h_query"][self.shard::self.n_shards][:len(h)]), h)
+        else:
+            H = corc.msm(cv, 1, pk["h_query"][lo:hi], h[lo:hi])
         sA = corc.point_mul(cv, 1, A, s_full)
         rB1 = corc.point_mul(cv, 1, B1, r_full)
         rec = np.concatenate([self._jac(1, A), self._jac(1, B1), self._jac(1, L), self._jac(1, H), self._jac(1, sA),
@@ -101,7 +141,7 @@ class OracleEngine:
         return A, B2, add(1, add(1, L, H), add(1, sA, rB1))
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, sharded_h=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -123,8 +163,12 @@ def _worker(rank, world, port, q):
            if k in ("a_query", "b_g1_query", "h_query", "l_query", "alpha_g1", "beta_g1", "delta_g1")}
     hpk.update({k: enc_g2(Fq, v if isinstance(v, list) else [v]) for k, v in pk.items()
                 if k in ("b_g2_query", "beta_g2", "delta_g2")})
-    eng = OracleEngine(curve, hpk, (len(w), 2, dom.size), rank, world)
-    prover = DistributedProver(eng, dist, rank, world)
+    eng = OracleEngine(curve, hpk, (len(w), 2, dom.size), rank, world, h_cyclic=sharded_h)
+    prover = DistributedProver(eng, dist, rank, world, sharded_h=sharded_h)
+    if sharded_h:                    # every rank evaluates only its cyclic rows (dg16_qap_rows on the GPU)
+        from dg16_amd.parallel import h_is_sharded
+        assert h_is_sharded(dom.size, world)
+        a, b, c = a[rank::world], b[rank::world], c[rank::world]
     r, s = rng.randrange(1, F.p), rng.randrange(1, F.p)
     rs = corc.ints_to_arr([r, s], 4)
     t = lambda v: torch.from_numpy(enc_fr(F, v).view(np.int64))
@@ -136,11 +180,12 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_two_rank_gloo_proof_equals_single_prover():
+@pytest.mark.parametrize("sharded_h", [False, True])
+def test_two_rank_gloo_proof_equals_single_prover(sharded_h):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, sharded_h)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=240) for _ in procs]

@@ -1,8 +1,10 @@
-"""Two (or N) processes sharing ONE GPU prove one statement through DistributedProver + GpuEngine, exchanging
-their records with torch.distributed (gloo here: RCCL refuses two ranks on one device), and compare with the
-unsharded proof.  This is the multi-GPU path of bench.py with everything but the transport real.
+"""Two (or N) processes sharing ONE GPU prove one statement -- through the native pipeline
+(dg16_groth16_prove_dist under a torch.distributed-backed dg16_comm) or the Python-driven protocol
+(DistributedProver + GpuEngine) -- exchanging over gloo (RCCL refuses two ranks on one device), and compare with
+the unsharded proof.  This is the multi-GPU path of bench.py with everything but the RCCL transport real: sharded
+h-polynomial (cyclic rows, two all-to-alls), cyclic h bases, MSM slices, all-gather, assembly.
 Launch: python -m torch.distributed.run --nproc-per-node 2 --master-addr 127.0.0.1 --master-port P \
-            tools/two_rank_check.py [log_m]"""
+            tools/two_rank_check.py [log_m] [torch|python]"""
 import os
 import sys
 
@@ -12,19 +14,21 @@ import torch.distributed as dist
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import dg16_amd  # noqa: E402
-from dg16_amd.parallel import DistributedProver, GpuEngine  # noqa: E402
+from dg16_amd.parallel import make_prover  # noqa: E402
 import bench  # noqa: E402
 
 log_m = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+transport = sys.argv[2] if len(sys.argv) > 2 else "torch"
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group(backend=os.environ.get("DG16_DIST_BACKEND", "gloo"))
 torch.cuda.set_device(0)
 dev = torch.device("cuda", 0)
 ctx = dg16_amd.Context(0)
 wl = bench.Workload(ctx, dev, log_m, rank, world)          # same seed on every rank -> same statement
-prover = DistributedProver(GpuEngine(ctx, wl.pk, bench.CURVE), dist, rank, world)
+prover = make_prover(ctx, wl.pk, bench.CURVE, dist, rank, world, transport=transport)
 proofs = []
 for _ in range(3):                                          # repeated: buffers warm, events reused
+    wl.qap()
     proof = prover.prove(wl.a, wl.b, wl.c, wl.w, wl.rs, scalars_mont=False)
     for ch in range(3):
         ctx.sync(ch)
@@ -50,6 +54,7 @@ ok = all(np.array_equal(affine(p), affine(ref)) for p in proofs)
 flag = torch.tensor([1 if ok else 0])
 dist.all_reduce(flag, op=dist.ReduceOp.MIN)
 if rank == 0:
-    print("TWO_RANK_CHECK", "PASS" if int(flag.item()) == 1 else "FAIL", "world", world, "log_m", log_m)
+    print("TWO_RANK_CHECK", "PASS" if int(flag.item()) == 1 else "FAIL", "world", world, "log_m", log_m, "|",
+          prover.describe(), "| comm errors:", getattr(getattr(prover, "comm", None), "errors", []))
 dist.destroy_process_group()
 sys.exit(0 if int(flag.item()) == 1 else 1)
