@@ -62,7 +62,8 @@ class Workload:
     variables, domain m = 2^log_m >= nc + ni.  Defaults: nc = m - 2, nv = m (the headline shape).  The prover's work
     does not depend on the R1CS being satisfied (qap.rs:44-91 sets c = a o b), so A, B are uniform sparse rows."""
 
-    def __init__(self, ctx, dev, log_m, rank=0, world=1, seed=20, curve=CURVE, nv=None, nc=None, ni=2, nnz=3):
+    def __init__(self, ctx, dev, log_m, rank=0, world=1, seed=20, curve=CURVE, nv=None, nc=None, ni=2, nnz=3,
+                 h_sharded=None):
         import dg16_amd  # noqa: F401
         self.ctx, self.dev, self.curve = ctx, dev, curve
         self.m = 1 << log_m
@@ -90,7 +91,7 @@ class Workload:
         # and owns the h bases h_query[rank + world * j] (parallel.py); otherwise whole vectors, contiguous slices
         from dg16_amd.parallel import h_is_sharded
         self.rank, self.world = rank, world
-        self.h_sharded = world > 1 and h_is_sharded(m, world)
+        self.h_sharded = (world > 1 and h_is_sharded(m, world)) if h_sharded is None else bool(h_sharded)
         self.pk = ctx.pk_create(curve, nv, ni, m, self.aq.data_ptr(), self.b1q.data_ptr(), self.b2q.data_ptr(),
                                 self.hq.data_ptr(), self.lq.data_ptr(), self.fixed.data_ptr(), device_ptrs=True,
                                 shard=rank, n_shards=world, h_cyclic=self.h_sharded)

@@ -75,6 +75,9 @@ void dg16_ctx_destroy(dg16_ctx* ctx) {
       if (ctx->ch[i].ev[e]) hipEventDestroy(ctx->ch[i].ev[e]);
     if (ctx->ch[i].own) hipStreamDestroy(ctx->ch[i].own);
   }
+  for (auto& x : ctx->xws)
+    for (int s = 0; s < kSlots; s++)
+      if (x.slot[s]) hipFree(x.slot[s]);
   for (auto& e : ctx->pipe_ev)
     if (e) hipEventDestroy(e);
   for (auto& st : ctx->aux)

@@ -65,6 +65,7 @@ struct dg16_ctx {
   // oracle; the first one was masked by the implicit synchronisation of hipMalloc).
   hipEvent_t pipe_ev[16] = {};
   hipStream_t aux[2] = {};   // extra internal streams of the prover pipeline (never handed out)
+  dg16::Channel xws[2];      // workspace-only (no stream): the bucket buffers of the H and L MSMs of a proof
   // Sticky argument-error flag of stream-ordered calls (pinned host word mapped into the device: kernels OR
   // bits into it, dg16_sync reads it after the stream has drained).  bit 0: dg16_qap index out of range.
   unsigned* dev_flag_host = nullptr;

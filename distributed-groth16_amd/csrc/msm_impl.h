@@ -681,15 +681,18 @@ __device__ __forceinline__ Fp<P> lane_get(const Fp<P>& v, int src) {     // src:
   for (int i = 0; i < Fp<P>::NL; i++) r.l[i] = (uint32_t)__shfl((int)v.l[i], src);
   return r;
 }
-// product per slot (slot = lane / 4; the operands must be equal across the quad)
+// product per slot (slot = lane / 4; the operands must be equal across the quad).  The product is a CALL
+// (Fp::mul_call): these chains run once per proof on one wave, so their cost is dependent issue + instruction fetch
+// of cold code -- with every product inlined the s*A kernel was 180 KB and the proof assembly 210 KB of straight-line
+// code (0.46 ms for ~40 us of arithmetic); a call keeps an addition at ~4 KB.
 template <class P>
-__device__ __forceinline__ Fp<P> slot_mul(const Fp<P>& a, const Fp<P>& b) { return a * b; }
+__device__ __forceinline__ Fp<P> slot_mul(const Fp<P>& a, const Fp<P>& b) { return Fp<P>::mul_call(a, b); }
 template <class F>
 __device__ __forceinline__ Fp2<F> slot_mul(const Fp2<F>& a, const Fp2<F>& b) {
   const unsigned q = __lane_id() & 3;
   const F x = F::select(q == 0, a.c0, F::select(q == 1, a.c1, a.c0 + a.c1));
   const F y = F::select(q == 0, b.c0, F::select(q == 1, b.c1, b.c0 + b.c1));
-  const F t = x * y;
+  const F t = F::mul_call(x, y);
   const int base = (int)(__lane_id() & ~3u);
   const F t0 = lane_get(t, base), t1 = lane_get(t, base + 1), t2 = lane_get(t, base + 2);
   return {t0 - t1, t2 - t0 - t1};

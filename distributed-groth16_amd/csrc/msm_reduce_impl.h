@@ -59,6 +59,7 @@ __global__ void __launch_bounds__(256) msm_finalize4_kernel(MsmGeom g, const uns
                                                              XYZZ29<F>* __restrict__ buckets,
                                                              unsigned* __restrict__ giant_count,
                                                              unsigned* __restrict__ giant_list, unsigned giant_cap) {
+  __builtin_amdgcn_s_setprio(3);   // latency-bound chain: issue ahead of the accumulation waves sharing the SIMD
   const size_t gid4 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t gid = gid4 >> 2;
   const unsigned q = (unsigned)gid4 & 3;
@@ -109,6 +110,7 @@ __global__ void __launch_bounds__(BLOCK) msm_finalize4_lds_kernel(MsmGeom g, con
                                                                   XYZZ29<F>* __restrict__ buckets,
                                                                   unsigned* __restrict__ giant_count,
                                                                   unsigned* __restrict__ giant_list, unsigned giant_cap) {
+  __builtin_amdgcn_s_setprio(3);   // latency-bound chain: issue ahead of the accumulation waves sharing the SIMD
   __shared__ XYZZ29<F> acc[BLOCK];
   const size_t gid4 = (size_t)blockIdx.x * BLOCK + threadIdx.x;
   const size_t gid = gid4 >> 2;
@@ -160,6 +162,7 @@ __global__ void __launch_bounds__(256) msm_giant_kernel(MsmGeom g, const unsigne
                                                          XYZZ29<F>* __restrict__ seg_sum,
                                                          const unsigned* __restrict__ giant_count,
                                                          const unsigned* __restrict__ giant_list, unsigned giant_cap) {
+  __builtin_amdgcn_s_setprio(3);   // latency-bound chain: issue ahead of the accumulation waves sharing the SIMD
   __shared__ XYZZ29<F> sh[256];
   const unsigned nwork = giant_count[1];
   const unsigned* work = giant_list + giant_cap;
@@ -206,6 +209,7 @@ __global__ void __launch_bounds__(64) msm_giant_fold_kernel(MsmGeom g, const uns
                                                              const unsigned* __restrict__ giant_count,
                                                              const unsigned* __restrict__ giant_list,
                                                              unsigned giant_cap) {
+  __builtin_amdgcn_s_setprio(3);   // latency-bound chain: issue ahead of the accumulation waves sharing the SIMD
   __shared__ XYZZ29<F> sh[kGiantSlices];
   unsigned ng = *giant_count;
   if (ng > giant_cap) ng = giant_cap;
@@ -231,6 +235,7 @@ __global__ void __launch_bounds__(64) msm_giant_fold_kernel(MsmGeom g, const uns
 template <class F>
 __global__ void __launch_bounds__(256) msm_row_kernel(MsmGeom g, RowGeom rg, const XYZZ29<F>* __restrict__ buckets,
                                                        XYZZ29<F>* __restrict__ row_w, XYZZ29<F>* __restrict__ row_r) {
+  __builtin_amdgcn_s_setprio(3);   // latency-bound chain: issue ahead of the accumulation waves sharing the SIMD
   __shared__ XYZZ29<F> sh[256];
   const unsigned c = threadIdx.x, row = 1u << rg.row_log;
   const size_t rid = ((size_t)blockIdx.y << rg.rows_log) + blockIdx.x;      // (bucket-window, row)
@@ -263,6 +268,7 @@ template <class F>
 __global__ void __launch_bounds__(64) msm_rowfold_kernel(RowGeom rg, const XYZZ29<F>* __restrict__ row_w,
                                                           const XYZZ29<F>* __restrict__ row_r,
                                                           XYZZ29<F>* __restrict__ fold /* [bw][3][256]: W, R, local */) {
+  __builtin_amdgcn_s_setprio(3);   // latency-bound chain: issue ahead of the accumulation waves sharing the SIMD
   __shared__ XYZZ29<F> st[64][2];      // [lane][run, acc]
   const unsigned gid = blockIdx.x * 64 + threadIdx.x;   // (half, t)
   const unsigned half = gid >> 8, t = gid & 255;
@@ -295,6 +301,7 @@ __global__ void __launch_bounds__(256 * HALVES) msm_top_kernel(RowGeom rg, const
                                                                 const XYZZ29<F>* __restrict__ row_r,
                                                                 const XYZZ29<F>* __restrict__ fold,
                                                                 XYZZ<F>* __restrict__ window_sums) {
+  __builtin_amdgcn_s_setprio(3);   // latency-bound chain: issue ahead of the accumulation waves sharing the SIMD
   __shared__ XYZZ29<F> sh[256 * HALVES];
   __shared__ XYZZ29<F> keep;                       // HALVES == 1: sum W while the second pass runs
   const unsigned t = threadIdx.x & 255;
@@ -363,6 +370,7 @@ __global__ void __launch_bounds__(256 * HALVES) msm_top_kernel(RowGeom rg, const
 template <class F>
 __global__ void __launch_bounds__(64) msm_tail_kernel(const XYZZ<F>* __restrict__ window_sums, MsmGeom g,
                                                        int affine, F* __restrict__ out) {
+  __builtin_amdgcn_s_setprio(3);   // latency-bound chain: issue ahead of the accumulation waves sharing the SIMD
   // one wave, every lane carries the same running total
   XYZZ<F> total = XYZZ<F>::inf();
   for (int w = (int)g.bw - 1; w >= 0; w--) {

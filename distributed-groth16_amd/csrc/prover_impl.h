@@ -60,6 +60,7 @@ constexpr int kRecA = 0, kRecB1 = 1, kRecL = 2, kRecH = 3, kRecSA = 4, kRecRB1 =
 template <class Fq, class Fr>
 __global__ void __launch_bounds__(64) prover_stage1_g1_kernel(Jacobian<Fq>* rec, const Affine<Fq>* fixed_g1,
                                                                const Fr* r_s, int mont, int first_shard, int which) {
+  __builtin_amdgcn_s_setprio(3);     // a serial chain on one wave: ahead of the accumulation waves it shares a SIMD with
   Fr r = r_s[0], s = r_s[1];
   if (mont) { r = r.from_mont(); s = s.from_mont(); }
   XYZZ<Fq> v = XYZZ<Fq>::inf();
@@ -73,36 +74,55 @@ __global__ void __launch_bounds__(64) prover_stage1_g1_kernel(Jacobian<Fq>* rec,
   rec[which == 0 ? kRecA : kRecB1] = v.to_jacobian();
   rec[which == 0 ? kRecSA : kRecRB1] = kv.to_jacobian();
 }
-// B' = msm (+ beta_g2 + b_g2_query[0] on shard 0)
+// B' = msm (+ beta_g2 + b_g2_query[0] on shard 0); one wave, wave-cooperative additions (a lone lane took 0.13-0.3 ms
+// at the end of the longest chain of a proof)
 template <class Fq2>
-__global__ void prover_stage1_g2_kernel(Jacobian<Fq2>* msm_b2, const Affine<Fq2>* fixed_g2, int first_shard) {
+__global__ void __launch_bounds__(64) prover_stage1_g2_kernel(Jacobian<Fq2>* msm_b2, const Affine<Fq2>* fixed_g2,
+                                                               int first_shard) {
   if (!first_shard) return;
-  XYZZ<Fq2> b = XYZZ<Fq2>::from_jacobian(*msm_b2).madd(fixed_g2[0], false).madd(fixed_g2[1], false);
-  *msm_b2 = b.to_jacobian();
+  __builtin_amdgcn_s_setprio(3);
+  XYZZ<Fq2> b = XYZZ<Fq2>::from_jacobian(*msm_b2);
+#pragma unroll 1
+  for (int i = 0; i < 2; i++) b = add_wave(b, XYZZ<Fq2>::from_affine(fixed_g2[i]));
+  if (threadIdx.x == 0) *msm_b2 = b.to_jacobian();
 }
 
-// after the gather: per-slot sums over the shards, C = L + H + s*A + r*B1 (-rs*delta is inside L)
+// after the gather: per-slot sums over the shards, C = L + H + s*A + r*B1 (-rs*delta is inside L).
+// This kernel is the exposed tail of every proof, so each sum is a chain on its own WAVE with wave-cooperative
+// additions (msm_impl.h: add_wave, ~2.5 us per addition against ~15 us on a lone lane): waves 0 / 1 sum A / B,
+// waves 2..5 sum L, H, s*A, r*B1 into LDS and wave 2 adds those four -- n_shards + 3 dependent additions instead of
+// 4 n_shards (0.5 ms at 8 shards before).
 template <class Fq, class Fq2>
-__global__ void __launch_bounds__(192) prover_assemble_kernel(const uint8_t* gathered, size_t n_shards, size_t rec_bytes,
+__global__ void __launch_bounds__(384) prover_assemble_kernel(const uint8_t* gathered, size_t n_shards, size_t rec_bytes,
                                                                Jacobian<Fq>* out_a, Jacobian<Fq2>* out_b,
                                                                Jacobian<Fq>* out_c) {
+  __shared__ Jacobian<Fq> part[4];
+  __builtin_amdgcn_s_setprio(3);     // exposed tail: ahead of whatever else is resident on the SIMD
   const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  if (lane != 0) return;
-  auto g1 = [&](size_t k, int slot) { return XYZZ<Fq>::from_jacobian(((const Jacobian<Fq>*)(gathered + k * rec_bytes))[slot]); };
-  if (wave == 0) {
-    XYZZ<Fq> a = XYZZ<Fq>::inf();
-    for (size_t k = 0; k < n_shards; k++) a = a.add(g1(k, kRecA));
-    *out_a = a.to_jacobian();
-  } else if (wave == 1) {
+  if (wave == 1) {
     XYZZ<Fq2> b = XYZZ<Fq2>::inf();
+#pragma unroll 1
     for (size_t k = 0; k < n_shards; k++)
-      b = b.add(XYZZ<Fq2>::from_jacobian(*(const Jacobian<Fq2>*)(gathered + k * rec_bytes + kRecG1 * sizeof(Jacobian<Fq>))));
-    *out_b = b.to_jacobian();
-  } else {
-    XYZZ<Fq> c = XYZZ<Fq>::inf();
-    for (size_t k = 0; k < n_shards; k++)
-      c = c.add(g1(k, kRecL)).add(g1(k, kRecH)).add(g1(k, kRecSA)).add(g1(k, kRecRB1));
-    *out_c = c.to_jacobian();
+      b = add_wave(b, XYZZ<Fq2>::from_jacobian(*(const Jacobian<Fq2>*)(gathered + k * rec_bytes + kRecG1 * sizeof(Jacobian<Fq>))));
+    if (lane == 0) *out_b = b.to_jacobian();
+    __syncthreads();
+    return;
+  }
+  // one addition site for every G1 sum: n_shards records, then (wave 2 only, after the barrier) the other partials
+  const int slot = wave == 0 ? kRecA : wave == 2 ? kRecL : wave == 3 ? kRecH : wave == 4 ? kRecSA : kRecRB1;
+  XYZZ<Fq> a = XYZZ<Fq>::inf();
+  const size_t steps = n_shards + (wave == 2 ? 3 : 0);
+#pragma unroll 1
+  for (size_t k = 0; k < steps; k++) {
+    if (k == n_shards) __syncthreads();            // (wave 2 only: the other waves are past their loop, at the barrier below)
+    const Jacobian<Fq>* src = k < n_shards ? (const Jacobian<Fq>*)(gathered + k * rec_bytes) + slot : &part[k - n_shards + 1];
+    a = add_wave(a, XYZZ<Fq>::from_jacobian(*src));
+    if (k + 1 == n_shards && wave >= 3 && lane == 0) part[wave - 2] = a.to_jacobian();
+  }
+  if (wave != 2) __syncthreads();
+  if (lane == 0) {
+    if (wave == 0) *out_a = a.to_jacobian();
+    if (wave == 2) *out_c = a.to_jacobian();
   }
 }
 
@@ -192,37 +212,24 @@ static void msms_typed(dg16_ctx* ctx, Call& k0, Call& k1, Call& k2, const PkDev&
   DG_HIP(hipEventRecord(k2.c.ev[3], main));
   k2.c.ev_valid[1] = true;
   DG_HIP(hipEventRecord(ev[2], main));
-  DG_HIP(hipEventRecord(k1.c.ev[2], main));
-  msm_accumulate_phase<Fq>(main, st_ab, buf_a, pk.a_q);
-  DG_HIP(hipEventRecord(k1.c.ev[3], main));
-  k1.c.ev_valid[1] = true;
-  DG_HIP(hipEventRecord(ev[0], main));
-  msm_accumulate_phase<Fq>(main, st_ab, buf_b1, pk.b1_q);
-  DG_HIP(hipEventRecord(ev[1], main));
-  // side: reductions of A and B1, then the serial scalar multiples s*A', r*B1' of this shard
-  DG_HIP(hipStreamWaitEvent(side, ev[0], 0));
-  msm_bucket_phase<Fq>(side, st_ab, buf_a, false, res_a);
-  DG_HIP(hipEventRecord(ev[3], side));                 // A's buffers (channel 0) are free again
-  hipLaunchKernelGGL((prover_stage1_g1_kernel<Fq, Fr>), dim3(1), dim3(64), 0, side, rec, fixed_g1, r_s, (int)mont,
-                     first_shard, 0);
-  // aux: B1's reduction and r*B1' (own stream: with short shards -- many GPUs -- the latency-bound reductions
-  // would otherwise queue up behind one another on `side`)
-  hipStream_t aux = ctx->aux[0];
-  DG_HIP(hipStreamWaitEvent(aux, ev[1], 0));
-  msm_bucket_phase<Fq>(aux, st_ab, buf_b1, false, res_b1);
-  DG_HIP(hipEventRecord(ev[4], aux));                  // B1's buffers (channel 1) are free again
-  hipLaunchKernelGGL((prover_stage1_g1_kernel<Fq, Fr>), dim3(1), dim3(64), 0, aux, rec, fixed_g1, r_s, (int)mont,
-                     first_shard, 1);
-  DG_HIP(hipEventRecord(ev[10], aux));
-  // h-polynomial + the digit sorts of H and L do not depend on the witness MSMs.  DG16_PREP_OVERLAP=1 sends them
-  // down side2 underneath the A / B1 / B accumulations; measured 23.3 ms (off) vs 24.4 ms (on) per 2^20 proof:
-  // the chip is saturated either way and the co-scheduled accumulations slow down by more than is hidden.
-  // (a distributed proof always overlaps: the two exchanges of the sharded h-polynomial are latency, and they hide
-  // behind the A / B1 / B accumulations only from a stream of their own)
+  // h-polynomial + the digit sorts of H and L do not depend on the witness MSMs.  Single GPU: they go down `main`
+  // (DG16_PREP_OVERLAP=1 sends them down a stream of their own underneath the A / B1 / B accumulations; measured
+  // 23.3 ms (off) vs 24.4 ms (on) per 2^20 proof: the chip is saturated either way and the co-scheduled
+  // accumulations slow down by more than is hidden).  A distributed proof always overlaps: the two exchanges of
+  // the sharded h-polynomial are latency, and they hide behind the accumulations only from a stream of their own --
+  // L's sort goes first there (its scalars are ready), so that L's accumulation follows B1's without a gap.
+  // (host order matters: a proof is ~150 launches, so the work of the prep stream is enqueued HERE, while the sort
+  // and the G2 accumulation keep the GPU busy, not after the reductions' launches)
   static const bool overlap_env = [] { const char* e = getenv("DG16_PREP_OVERLAP"); return e && atoi(e) != 0; }();
   const bool overlap = overlap_env || dist;
-  hipStream_t prep = overlap ? side2 : main;
+  hipStream_t prep = overlap ? ctx->aux[1] : main;
   if (overlap) DG_HIP(hipStreamWaitEvent(prep, ev[8], 0));   // staged a, b, c and the scalar vectors
+  // H and L own their bucket buffers (288 GB of HBM: a few MB more beat waiting for A's / B1's reductions)
+  MsmSort st_l;
+  if (overlap) {
+    st_l = msm_sort_on<Fr, CT::SCALAR_BITS>(prep, k2.c, sc_l, n_l + 1, mont, true, pk.c_l);
+    DG_HIP(hipEventRecord(ev[11], prep));
+  }
   const Fr* h_scalars = h_in;
   if (!h_given) {
     Fr* h_dev = (Fr*)ws(k0.c, 3, rows * sizeof(Fr));
@@ -236,31 +243,58 @@ static void msms_typed(dg16_ctx* ctx, Call& k0, Call& k1, Call& k2, const PkDev&
     h_scalars = dist ? h_dev : h_dev + pk.h_lo;
   }
   MsmSort st_h = msm_sort_on<Fr, CT::SCALAR_BITS>(prep, k0.c, h_scalars, n_h, true, true, pk.c_h);
-  MsmSort st_l = msm_sort_on<Fr, CT::SCALAR_BITS>(prep, k2.c, sc_l, n_l + 1, mont, true, pk.c_l);
-  if (overlap) {
-    DG_HIP(hipEventRecord(ev[9], prep));
-    DG_HIP(hipStreamWaitEvent(main, ev[9], 0));
-  }
-  DG_HIP(hipStreamWaitEvent(main, ev[3], 0));          // H's bucket buffers = A's (channel 0)
-  // side2: reduction of B (queued behind the prep work there)
+  if (!overlap) st_l = msm_sort_on<Fr, CT::SCALAR_BITS>(prep, k2.c, sc_l, n_l + 1, mont, true, pk.c_l);
+  DG_HIP(hipEventRecord(k1.c.ev[2], main));
+  msm_accumulate_phase<Fq>(main, st_ab, buf_a, pk.a_q);
+  DG_HIP(hipEventRecord(k1.c.ev[3], main));
+  k1.c.ev_valid[1] = true;
+  DG_HIP(hipEventRecord(ev[0], main));
+  msm_accumulate_phase<Fq>(main, st_ab, buf_b1, pk.b1_q);
+  DG_HIP(hipEventRecord(ev[1], main));
+  // side2: reduction of B, straight behind its accumulation
   DG_HIP(hipStreamWaitEvent(side2, ev[2], 0));
   msm_bucket_phase<Fq2>(side2, st_ab, buf_b2, false, res_b2);
-  hipLaunchKernelGGL(prover_stage1_g2_kernel<Fq2>, dim3(1), dim3(1), 0, side2, res_b2, fixed_g2, first_shard);
-  DG_HIP(hipEventRecord(ev[5], side2));                // sort_ab (channel 1's sort buffers) no longer needed by B
-
-  MsmBuffers<Fq> buf_h = msm_buffers<Fq>(k0.c, st_h.g);
-  msm_accumulate_phase<Fq>(main, st_h, buf_h, pk.h_q);
-  DG_HIP(hipEventRecord(ev[6], main));
-  // L: sort buffers of channel 2, bucket buffers of channel 1 after B1's reduction
-  DG_HIP(hipStreamWaitEvent(main, ev[4], 0));
-  MsmBuffers<Fq> buf_l = msm_buffers<Fq>(k1.c, st_l.g);
-  msm_accumulate_phase<Fq>(main, st_l, buf_l, pk.l_q);
-  // side: H's reduction hides behind L's sort + accumulation; L's reduction is the exposed tail
-  DG_HIP(hipStreamWaitEvent(side, ev[6], 0));
-  msm_bucket_phase<Fq>(side, st_h, buf_h, false, res_h);
-  msm_bucket_phase<Fq>(main, st_l, buf_l, false, res_l);
+  hipLaunchKernelGGL(prover_stage1_g2_kernel<Fq2>, dim3(1), dim3(64), 0, side2, res_b2, fixed_g2, first_shard);
+  DG_HIP(hipEventRecord(ev[5], side2));
+  // side: reductions of A and B1, then the serial scalar multiples s*A', r*B1' of this shard
+  DG_HIP(hipStreamWaitEvent(side, ev[0], 0));
+  msm_bucket_phase<Fq>(side, st_ab, buf_a, false, res_a);
+  hipLaunchKernelGGL((prover_stage1_g1_kernel<Fq, Fr>), dim3(1), dim3(64), 0, side, rec, fixed_g1, r_s, (int)mont,
+                     first_shard, 0);
+  // aux: B1's reduction and r*B1' (own stream: with short shards -- many GPUs -- the latency-bound reductions
+  // would otherwise queue up behind one another on `side`)
+  hipStream_t aux = ctx->aux[0];
+  DG_HIP(hipStreamWaitEvent(aux, ev[1], 0));
+  msm_bucket_phase<Fq>(aux, st_ab, buf_b1, false, res_b1);
+  hipLaunchKernelGGL((prover_stage1_g1_kernel<Fq, Fr>), dim3(1), dim3(64), 0, aux, rec, fixed_g1, r_s, (int)mont,
+                     first_shard, 1);
+  DG_HIP(hipEventRecord(ev[10], aux));
+  MsmBuffers<Fq> buf_h = msm_buffers<Fq>(ctx->xws[0], st_h.g);
+  MsmBuffers<Fq> buf_l = msm_buffers<Fq>(ctx->xws[1], st_l.g);
+  if (overlap) {
+    // main: L (sorted early), then H; L's reduction on the prep stream (idle by then), H's is the exposed tail
+    DG_HIP(hipEventRecord(ev[9], prep));
+    DG_HIP(hipStreamWaitEvent(main, ev[11], 0));
+    msm_accumulate_phase<Fq>(main, st_l, buf_l, pk.l_q);
+    DG_HIP(hipEventRecord(ev[12], main));
+    DG_HIP(hipStreamWaitEvent(main, ev[9], 0));
+    msm_accumulate_phase<Fq>(main, st_h, buf_h, pk.h_q);
+    DG_HIP(hipStreamWaitEvent(prep, ev[12], 0));
+    msm_bucket_phase<Fq>(prep, st_l, buf_l, false, res_l);
+    DG_HIP(hipEventRecord(ev[13], prep));
+    msm_bucket_phase<Fq>(main, st_h, buf_h, false, res_h);
+    DG_HIP(hipStreamWaitEvent(main, ev[13], 0));          // L result
+  } else {
+    msm_accumulate_phase<Fq>(main, st_h, buf_h, pk.h_q);
+    DG_HIP(hipEventRecord(ev[6], main));
+    msm_accumulate_phase<Fq>(main, st_l, buf_l, pk.l_q);
+    // side: H's reduction hides behind L's accumulation; L's reduction is the exposed tail
+    DG_HIP(hipStreamWaitEvent(side, ev[6], 0));
+    msm_bucket_phase<Fq>(side, st_h, buf_h, false, res_h);
+    msm_bucket_phase<Fq>(main, st_l, buf_l, false, res_l);
+  }
   DG_HIP(hipEventRecord(ev[7], side));
-  DG_HIP(hipStreamWaitEvent(main, ev[7], 0));           // A, H results + s*A
+  DG_HIP(hipStreamWaitEvent(main, ev[7], 0));           // A result + s*A (and H's, single GPU)
   DG_HIP(hipStreamWaitEvent(main, ev[10], 0));          // B1 result + r*B1
   DG_HIP(hipStreamWaitEvent(main, ev[5], 0));           // B result
   DG_HIP(hipGetLastError());
@@ -273,7 +307,7 @@ static void assemble_typed(Call& k0, const uint8_t* gathered_dev, size_t n_shard
   using Fq = typename CT::Fq;
   using Fq2 = typename CT::Fq2;
   const size_t g1j = sizeof(Jacobian<Fq>), g2j = sizeof(Jacobian<Fq2>);
-  hipLaunchKernelGGL((prover_assemble_kernel<Fq, Fq2>), dim3(1), dim3(192), 0, k0.s(), gathered_dev, n_shards,
+  hipLaunchKernelGGL((prover_assemble_kernel<Fq, Fq2>), dim3(1), dim3(384), 0, k0.s(), gathered_dev, n_shards,
                      msm_results_bytes<CURVE>(), (Jacobian<Fq>*)proof_dev, (Jacobian<Fq2>*)(proof_dev + g1j),
                      (Jacobian<Fq>*)(proof_dev + g1j + g2j));
   DG_HIP(hipGetLastError());

@@ -83,6 +83,58 @@ def test_sharded_h_poly_at_2e20_over_8_ranks_equals_unsharded(curve):
         assert np.array_equal(got[r], ref[r::8]), "rank %d" % r
 
 
+@pytest.mark.parametrize("curve,log_m,world", [("bn254", 12, 2), ("bls12_381", 14, 8), ("bn254", 16, 4)])
+def test_sharded_h_prove_all_ranks_in_process_vs_oracle(curve, log_m, world):
+    """What N ranks do, on one GPU: DG16_F_H_CYCLIC key shards, cyclic QAP rows (dg16_qap_rows), the three stages of
+    the sharded h-polynomial with the exchanges as tensor transposes, dg16_groth16_msms_h, records concatenated as
+    the all-gather would, assembly -- the proof must equal the C oracle's."""
+    import bench
+    dev = torch.device(DEV)
+    c = ctx()
+    shards = [bench.Workload(c, dev, log_m, k, world, seed=33, curve=curve) for k in range(world)]
+    assert all(wl.h_sharded and wl.pk.info()["n_h"] == (1 << log_m) // world for wl in shards)
+    M = (1 << log_m) // world
+    for wl in shards:
+        wl.qap()
+    c.sync(0)
+    send = [torch.empty(3 * M * 4, dtype=torch.int64, device=DEV) for _ in range(world)]
+    for r, wl in enumerate(shards):
+        c.h_poly_dist_stage_dev(curve, log_m, r, world, 0, [wl.a.data_ptr(), wl.b.data_ptr(), wl.c.data_ptr()],
+                                send[r].data_ptr())
+    c.sync(0)
+    recv = all_to_all(send)
+    torch.cuda.synchronize()
+    for r in range(world):
+        c.h_poly_dist_stage_dev(curve, log_m, r, world, 1, [recv[r].data_ptr()], send[r].data_ptr())
+    c.sync(0)
+    recv = all_to_all(send)
+    torch.cuda.synchronize()
+    recs = []
+    for r, wl in enumerate(shards):
+        h = torch.empty(M * 4, dtype=torch.int64, device=DEV)
+        c.h_poly_dist_stage_dev(curve, log_m, r, world, 2, [recv[r].data_ptr()], h.data_ptr())
+        rec = torch.empty(c.results_bytes(curve), dtype=torch.uint8, device=DEV)
+        c.groth16_msms_h_dev(wl.pk, h.data_ptr(), wl.w.data_ptr(), wl.rs, rec.data_ptr(), scalars_mont=False)
+        for ch in range(3):
+            c.sync(ch)
+        recs.append(rec)
+    gathered = torch.cat(recs)
+    proof = torch.empty(shards[0].proof_bytes(), dtype=torch.uint8, device=DEV)
+    c.groth16_assemble_dev(shards[0].pk, gathered.data_ptr(), world, shards[0].rs, proof.data_ptr(), scalars_mont=False)
+    c.sync(0)
+    (A, B, C), _ = bench.oracle_prove(shards[0], bench.cpu_threads())
+    gA, gB, gC = bench.gpu_proof_affine(curve, proof.cpu().numpy())
+    assert np.array_equal(A, gA) and np.array_equal(B, gB) and np.array_equal(C, gC)
+    # a cyclic shard refuses the replicated entry point instead of using the wrong h slice
+    import dg16_amd
+    with pytest.raises(dg16_amd.Dg16Error):
+        wl = shards[0]
+        c.groth16_msms_dev(wl.pk, wl.a.data_ptr(), wl.b.data_ptr(), wl.c.data_ptr(), wl.w.data_ptr(), wl.rs,
+                           recs[0].data_ptr(), scalars_mont=False)
+    for wl in shards:
+        wl.pk.close()
+
+
 def test_sharded_h_poly_argument_checks():
     import dg16_amd
     c = ctx()

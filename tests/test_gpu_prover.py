@@ -155,12 +155,14 @@ def test_prove_sha256_shaped_config4(rs_zero):
                                                ("bls12_381", 16, 1)])
 def test_sharded_prove_large_vs_oracle(curve, log_m, world):
     """N shard keys on one GPU (what N ranks hold), records concatenated as the all-gather would, assembled: the
-    proof must equal the C oracle's, at sizes where the shards run the large-MSM paths."""
+    proof must equal the C oracle's, at sizes where the shards run the large-MSM paths.  Replicated h-polynomial,
+    contiguous h slices (the form for rank counts the sharded h-polynomial does not take); the sharded form is
+    tests/test_gpu_hdist.py::test_sharded_h_prove_all_ranks_in_process_vs_oracle."""
     import torch
     import bench
     dev = torch.device("cuda", 0)
     c_ = ctx()
-    shards = [bench.Workload(c_, dev, log_m, k, world, seed=31, curve=curve) for k in range(world)]
+    shards = [bench.Workload(c_, dev, log_m, k, world, seed=31, curve=curve, h_sharded=False) for k in range(world)]
     recs = []
     for wl in shards:
         rec = torch.empty(c_.results_bytes(curve), dtype=torch.uint8, device=dev)
