@@ -203,6 +203,31 @@ static void msms_typed(dg16_ctx* ctx, Call& k0, Call& k1, Call& k2, const PkDev&
   MsmBuffers<Fq> buf_a = msm_buffers<Fq>(k0.c, st_ab.g);
   MsmBuffers<Fq> buf_b1 = msm_buffers<Fq>(k1.c, st_ab.g);
   MsmBuffers<Fq2> buf_b2 = msm_buffers<Fq2>(k2.c, st_ab.g);
+  // FOUR streams, not more: the runtime multiplexes streams onto 4 hardware queues by default (GPU_MAX_HW_QUEUES);
+  // a fifth stream shares a queue with another one and its kernels serialise behind that one's (measured: +3 ms per
+  // 2^20 proof with H's reduction on a fifth stream).  The exchanges ride on `aux`, ahead of B1's reduction.
+  hipStream_t aux = ctx->aux[0], xch = aux;
+  // The sharded h-polynomial is three local stages around two exchanges.  The stages are saturating kernels and stay
+  // on `main` like every other one (co-scheduling them with the accumulations was measured slower: the G2
+  // accumulation holds 144 of a CU's 160 KB of LDS, an NTT workgroup next to it evicts half of it); the EXCHANGES go
+  // down a stream of their own (`xch`) and the stages are interleaved with the accumulations, so that each exchange's
+  // latency hides behind an accumulation:  stage 0 | a2a 1 || B2 | stage 1 | a2a 2 || A, B1 | stage 2, sorts, H, L.
+  const unsigned n_ranks = dist ? comm->n_ranks(comm->self) : 1, rank = dist ? comm->rank(comm->self) : 0;
+  const size_t xbytes = 3 * rows * sizeof(Fr);
+  void* xbuf_a = dist ? ws(k0.c, 26, xbytes) : nullptr;
+  void* xbuf_b = dist ? ws(k0.c, 27, xbytes) : nullptr;
+  auto exchange = [&](int ev_ready, int ev_done) {        // xbuf_a (made on main) -> all-to-all on xch -> xbuf_b
+    DG_HIP(hipEventRecord(ev[ev_ready], main));
+    DG_HIP(hipStreamWaitEvent(xch, ev[ev_ready], 0));
+    int rc = comm->all_to_all(comm->self, xbuf_a, xbuf_b, xbytes / n_ranks, xch);
+    DG_REQUIRE(rc == DG16_OK, DG16_ERR_NET, "all-to-all of the sharded h-polynomial failed");
+    DG_HIP(hipEventRecord(ev[ev_done], xch));
+  };
+  if (dist) {
+    const void* rows_in[3] = {a_dev, b_dev, c_dev};
+    h_poly_dist_stage(k0, CURVE, log_m, rank, n_ranks, 0, rows_in, xbuf_a);
+    exchange(3, 4);
+  }
   // B (G2) first: its bucket reduction is the longest latency chain of a proof (on a short multi-GPU shard it
   // outlasts everything else), so it gets the whole rest of the pipeline to hide behind
   // (timing events of channels 2 / 1 bracket the G2 / first G1 accumulation ON THE STREAM THEY RUN ON, so that
@@ -212,38 +237,17 @@ static void msms_typed(dg16_ctx* ctx, Call& k0, Call& k1, Call& k2, const PkDev&
   DG_HIP(hipEventRecord(k2.c.ev[3], main));
   k2.c.ev_valid[1] = true;
   DG_HIP(hipEventRecord(ev[2], main));
-  // h-polynomial + the digit sorts of H and L do not depend on the witness MSMs.  Single GPU: they go down `main`
-  // (DG16_PREP_OVERLAP=1 sends them down a stream of their own underneath the A / B1 / B accumulations; measured
-  // 23.3 ms (off) vs 24.4 ms (on) per 2^20 proof: the chip is saturated either way and the co-scheduled
-  // accumulations slow down by more than is hidden).  A distributed proof always overlaps: the two exchanges of
-  // the sharded h-polynomial are latency, and they hide behind the accumulations only from a stream of their own --
-  // L's sort goes first there (its scalars are ready), so that L's accumulation follows B1's without a gap.
-  // (host order matters: a proof is ~150 launches, so the work of the prep stream is enqueued HERE, while the sort
-  // and the G2 accumulation keep the GPU busy, not after the reductions' launches)
-  static const bool overlap_env = [] { const char* e = getenv("DG16_PREP_OVERLAP"); return e && atoi(e) != 0; }();
-  const bool overlap = overlap_env || dist;
-  hipStream_t prep = overlap ? ctx->aux[1] : main;
-  if (overlap) DG_HIP(hipStreamWaitEvent(prep, ev[8], 0));   // staged a, b, c and the scalar vectors
-  // H and L own their bucket buffers (288 GB of HBM: a few MB more beat waiting for A's / B1's reductions)
-  MsmSort st_l;
-  if (overlap) {
-    st_l = msm_sort_on<Fr, CT::SCALAR_BITS>(prep, k2.c, sc_l, n_l + 1, mont, true, pk.c_l);
-    DG_HIP(hipEventRecord(ev[11], prep));
+  // side2: reduction of B, straight behind its accumulation
+  DG_HIP(hipStreamWaitEvent(side2, ev[2], 0));
+  msm_bucket_phase<Fq2>(side2, st_ab, buf_b2, false, res_b2);
+  hipLaunchKernelGGL(prover_stage1_g2_kernel<Fq2>, dim3(1), dim3(64), 0, side2, res_b2, fixed_g2, first_shard);
+  DG_HIP(hipEventRecord(ev[5], side2));
+  if (dist) {
+    const void* in1[1] = {xbuf_b};
+    DG_HIP(hipStreamWaitEvent(main, ev[4], 0));
+    h_poly_dist_stage(k0, CURVE, log_m, rank, n_ranks, 1, in1, xbuf_a);
+    exchange(9, 11);
   }
-  const Fr* h_scalars = h_in;
-  if (!h_given) {
-    Fr* h_dev = (Fr*)ws(k0.c, 3, rows * sizeof(Fr));
-    hipStream_t saved = k0.c.cur;     // h_poly_launch() issues on the Call's stream, with channel 0's buffers
-    k0.c.cur = prep;
-    if (dist)
-      h_poly_dist_launch(k0, CURVE, comm, a_dev, b_dev, c_dev, log_m, h_dev);
-    else
-      h_poly_launch(k0, CURVE, a_dev, b_dev, c_dev, log_m, h_dev);
-    k0.c.cur = saved;
-    h_scalars = dist ? h_dev : h_dev + pk.h_lo;
-  }
-  MsmSort st_h = msm_sort_on<Fr, CT::SCALAR_BITS>(prep, k0.c, h_scalars, n_h, true, true, pk.c_h);
-  if (!overlap) st_l = msm_sort_on<Fr, CT::SCALAR_BITS>(prep, k2.c, sc_l, n_l + 1, mont, true, pk.c_l);
   DG_HIP(hipEventRecord(k1.c.ev[2], main));
   msm_accumulate_phase<Fq>(main, st_ab, buf_a, pk.a_q);
   DG_HIP(hipEventRecord(k1.c.ev[3], main));
@@ -251,50 +255,45 @@ static void msms_typed(dg16_ctx* ctx, Call& k0, Call& k1, Call& k2, const PkDev&
   DG_HIP(hipEventRecord(ev[0], main));
   msm_accumulate_phase<Fq>(main, st_ab, buf_b1, pk.b1_q);
   DG_HIP(hipEventRecord(ev[1], main));
-  // side2: reduction of B, straight behind its accumulation
-  DG_HIP(hipStreamWaitEvent(side2, ev[2], 0));
-  msm_bucket_phase<Fq2>(side2, st_ab, buf_b2, false, res_b2);
-  hipLaunchKernelGGL(prover_stage1_g2_kernel<Fq2>, dim3(1), dim3(64), 0, side2, res_b2, fixed_g2, first_shard);
-  DG_HIP(hipEventRecord(ev[5], side2));
-  // side: reductions of A and B1, then the serial scalar multiples s*A', r*B1' of this shard
+  // side: reduction of A, then the serial scalar multiple s*A' of this shard
   DG_HIP(hipStreamWaitEvent(side, ev[0], 0));
   msm_bucket_phase<Fq>(side, st_ab, buf_a, false, res_a);
   hipLaunchKernelGGL((prover_stage1_g1_kernel<Fq, Fr>), dim3(1), dim3(64), 0, side, rec, fixed_g1, r_s, (int)mont,
                      first_shard, 0);
   // aux: B1's reduction and r*B1' (own stream: with short shards -- many GPUs -- the latency-bound reductions
   // would otherwise queue up behind one another on `side`)
-  hipStream_t aux = ctx->aux[0];
   DG_HIP(hipStreamWaitEvent(aux, ev[1], 0));
   msm_bucket_phase<Fq>(aux, st_ab, buf_b1, false, res_b1);
   hipLaunchKernelGGL((prover_stage1_g1_kernel<Fq, Fr>), dim3(1), dim3(64), 0, aux, rec, fixed_g1, r_s, (int)mont,
                      first_shard, 1);
   DG_HIP(hipEventRecord(ev[10], aux));
+  // h (the rest of it), the digit sorts of H and L
+  const Fr* h_scalars = h_in;
+  if (!h_given) {
+    Fr* h_dev = (Fr*)ws(k0.c, 3, rows * sizeof(Fr));
+    if (dist) {
+      const void* in2[1] = {xbuf_b};
+      DG_HIP(hipStreamWaitEvent(main, ev[11], 0));
+      h_poly_dist_stage(k0, CURVE, log_m, rank, n_ranks, 2, in2, h_dev);
+    } else {
+      h_poly_launch(k0, CURVE, a_dev, b_dev, c_dev, log_m, h_dev);
+    }
+    h_scalars = dist ? h_dev : h_dev + pk.h_lo;
+  }
+  MsmSort st_h = msm_sort_on<Fr, CT::SCALAR_BITS>(main, k0.c, h_scalars, n_h, true, true, pk.c_h);
+  MsmSort st_l = msm_sort_on<Fr, CT::SCALAR_BITS>(main, k2.c, sc_l, n_l + 1, mont, true, pk.c_l);
+  // H and L own their bucket buffers (288 GB of HBM: a few MB more beat waiting for A's / B1's reductions)
   MsmBuffers<Fq> buf_h = msm_buffers<Fq>(ctx->xws[0], st_h.g);
   MsmBuffers<Fq> buf_l = msm_buffers<Fq>(ctx->xws[1], st_l.g);
-  if (overlap) {
-    // main: L (sorted early), then H; L's reduction on the prep stream (idle by then), H's is the exposed tail
-    DG_HIP(hipEventRecord(ev[9], prep));
-    DG_HIP(hipStreamWaitEvent(main, ev[11], 0));
-    msm_accumulate_phase<Fq>(main, st_l, buf_l, pk.l_q);
-    DG_HIP(hipEventRecord(ev[12], main));
-    DG_HIP(hipStreamWaitEvent(main, ev[9], 0));
-    msm_accumulate_phase<Fq>(main, st_h, buf_h, pk.h_q);
-    DG_HIP(hipStreamWaitEvent(prep, ev[12], 0));
-    msm_bucket_phase<Fq>(prep, st_l, buf_l, false, res_l);
-    DG_HIP(hipEventRecord(ev[13], prep));
-    msm_bucket_phase<Fq>(main, st_h, buf_h, false, res_h);
-    DG_HIP(hipStreamWaitEvent(main, ev[13], 0));          // L result
-  } else {
-    msm_accumulate_phase<Fq>(main, st_h, buf_h, pk.h_q);
-    DG_HIP(hipEventRecord(ev[6], main));
-    msm_accumulate_phase<Fq>(main, st_l, buf_l, pk.l_q);
-    // side: H's reduction hides behind L's accumulation; L's reduction is the exposed tail
-    DG_HIP(hipStreamWaitEvent(side, ev[6], 0));
-    msm_bucket_phase<Fq>(side, st_h, buf_h, false, res_h);
-    msm_bucket_phase<Fq>(main, st_l, buf_l, false, res_l);
-  }
+  msm_accumulate_phase<Fq>(main, st_h, buf_h, pk.h_q);
+  DG_HIP(hipEventRecord(ev[6], main));
+  msm_accumulate_phase<Fq>(main, st_l, buf_l, pk.l_q);
+  // side (behind A's reduction and s*A): H's reduction hides behind L's accumulation; L's is the exposed tail
+  DG_HIP(hipStreamWaitEvent(side, ev[6], 0));
+  msm_bucket_phase<Fq>(side, st_h, buf_h, false, res_h);
+  msm_bucket_phase<Fq>(main, st_l, buf_l, false, res_l);
   DG_HIP(hipEventRecord(ev[7], side));
-  DG_HIP(hipStreamWaitEvent(main, ev[7], 0));           // A result + s*A (and H's, single GPU)
+  DG_HIP(hipStreamWaitEvent(main, ev[7], 0));           // A, H results + s*A
   DG_HIP(hipStreamWaitEvent(main, ev[10], 0));          // B1 result + r*B1
   DG_HIP(hipStreamWaitEvent(main, ev[5], 0));           // B result
   DG_HIP(hipGetLastError());
