@@ -263,6 +263,73 @@ int dg16_msm(dg16_ctx* ctx, int curve, int group, const void* bases, const void*
   });
 }
 
+int dg16_bases_upload(dg16_ctx* ctx, int curve, int group, const void* bases, size_t n, unsigned flags,
+                      dg16_bases** out) {
+  if (!ctx || !out) return DG16_ERR_BAD_ARG;
+  *out = nullptr;
+  dg16_bases* h = new dg16_bases();
+  int rc = guarded(ctx, [&] {
+    check_curve_group(curve, group);
+    DG_REQUIRE(bases || n == 0, DG16_ERR_BAD_ARG, "null bases");
+    bool dev = flags & DG16_F_DEVICE_PTRS;
+    const size_t pb = affine_bytes(curve, group);
+    Call k(ctx, 0);
+    const void* d = stage_in(k, 0, bases, n * pb, dev);
+    h->ctx = ctx;
+    h->curve = curve;
+    h->group = group;
+    h->n = n;
+    h->table = bases_table_launch(k, curve, group, d, n, &h->c, &h->nwin);
+    h->bytes = (size_t)h->nwin * (n ? n : 1) * pb;
+    k.finish();
+    DG_HIP(hipStreamSynchronize(k.s()));     // the caller may free `bases` on return
+  });
+  if (rc != DG16_OK) {
+    if (h->table) hipFree(h->table);
+    delete h;
+    return rc;
+  }
+  *out = h;
+  return DG16_OK;
+}
+
+void dg16_bases_free(dg16_bases* h) {
+  if (!h) return;
+  hipSetDevice(h->ctx->device);
+  hipDeviceSynchronize();
+  if (h->table) hipFree(h->table);
+  delete h;
+}
+
+int dg16_bases_info(const dg16_bases* h, size_t* n, unsigned* window_bits, uint64_t* table_bytes) {
+  if (!h) return DG16_ERR_BAD_ARG;
+  if (n) *n = h->n;
+  if (window_bits) *window_bits = h->c;
+  if (table_bytes) *table_bytes = h->bytes;
+  return DG16_OK;
+}
+
+int dg16_msm_resident(dg16_ctx* ctx, const dg16_bases* h, const void* scalars, size_t n_scalars, unsigned flags,
+                      int channel, void* out) {
+  int rc = guard_channel(ctx, channel);
+  if (rc) return rc;
+  return guarded(ctx, [&] {
+    DG_REQUIRE(h && h->ctx == ctx, DG16_ERR_BAD_ARG, "bases handle belongs to another context");
+    DG_REQUIRE(h->n == n_scalars, DG16_ERR_LENGTH_MISMATCH,
+               "bases and scalars differ in length (VariableBaseMSM::msm returns Err(min_len))");
+    DG_REQUIRE(out && (scalars || n_scalars == 0), DG16_ERR_BAD_ARG, "null operand");
+    bool dev = flags & DG16_F_DEVICE_PTRS, aff = flags & DG16_F_OUT_AFFINE;
+    const size_t ob = affine_bytes(h->curve, h->group) / 2 * (aff ? 2 : 3);
+    Call k(ctx, channel);
+    const void* ds = stage_in(k, 1, scalars, n_scalars * 32, dev);
+    void* dout = dev ? out : ws(k.c, 2, ob);
+    msm_resident_launch(k, h->curve, h->group, h->table, h->n, h->c, ds, flags & DG16_F_SCALARS_MONT, aff, dout);
+    if (!dev) stage_out(k, out, dout, ob, false);
+    k.finish();
+    if (!dev) DG_HIP(hipStreamSynchronize(k.s()));
+  });
+}
+
 int dg16_gen_bases(dg16_ctx* ctx, int curve, int group, uint64_t seed, size_t n, void* out,
                    unsigned flags, int channel) {
   int rc = guard_channel(ctx, channel);

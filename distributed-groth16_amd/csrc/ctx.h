@@ -73,6 +73,15 @@ struct dg16_ctx {
   std::map<dg16::TwiddleKey, dg16::TwiddleSet> twiddles;
 };
 
+struct dg16_bases {          // resident bases: table of window multiples (dg16_bases_upload)
+  dg16_ctx* ctx = nullptr;
+  int curve = 0, group = 1;
+  size_t n = 0;
+  unsigned c = 0, nwin = 0;
+  void* table = nullptr;
+  size_t bytes = 0;
+};
+
 namespace dg16 {
 
 struct StatusError {
@@ -196,6 +205,9 @@ void msm_launch(Call& k, int curve, int group, const void* bases, const void* sc
                 bool scalars_mont, bool out_affine, void* out_dev);
 void gen_bases_launch(Call& k, int curve, int group, uint64_t seed, size_t n, void* out_dev);
 void to_affine_launch(Call& k, int curve, int group, const void* jac, void* out, size_t n);
+void* bases_table_launch(Call& k, int curve, int group, const void* bases, size_t n, unsigned* c, unsigned* nwin);
+void msm_resident_launch(Call& k, int curve, int group, const void* table, size_t n, unsigned c, const void* scalars,
+                         bool mont, bool affine, void* out);
 size_t fq_bytes(int curve);
 size_t affine_bytes(int curve, int group);
 

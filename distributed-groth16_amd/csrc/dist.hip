@@ -303,7 +303,8 @@ static void pss_build(dg16_pss* pp) {
 // per-(curve, group) entry points defined in msm_<curve>_g<k>.hip
 namespace dg16 {
 #define DECL_G(name)                                                                                         \
-  void d_msm_##name(Call&, const dg16_pss*, const dg16_net*, int, const void*, const void*, size_t, bool, void*); \
+  void d_msm_##name(Call&, const dg16_pss*, const dg16_net*, int, const void*, const void*, size_t, bool, void*,   \
+                    const void*, unsigned);                                                                       \
   void packexp_##name(Call&, const dg16_pss*, int, const void*, size_t, void*);
 DECL_G(bn254_g1) DECL_G(bn254_g2) DECL_G(bls12_381_g1) DECL_G(bls12_381_g2) DECL_G(bls12_377_g1)
 #define DISPATCH_G(fn, curve, group, ...)                                                        \
@@ -447,7 +448,31 @@ int dg16_d_msm(dg16_ctx* ctx, const dg16_pss* pp, const dg16_net* net, int group
     const void* dbases = stage_in(k, 0, bases, n_bases * pb, dev);
     const void* dscal = stage_in(k, 1, scalars, n_bases * 32, dev);
     void* dout = dev ? out : ws(k.c, 2, pb / 2 * 3);
-    DISPATCH_G(d_msm, pp->curve, group, k, pp, net, channel, dbases, dscal, n_bases, flags & DG16_F_SCALARS_MONT, dout)
+    DISPATCH_G(d_msm, pp->curve, group, k, pp, net, channel, dbases, dscal, n_bases, flags & DG16_F_SCALARS_MONT, dout,
+               nullptr, 0u)
+    if (!dev) stage_out(k, out, dout, pb / 2 * 3, false);
+    k.finish();
+    if (!dev) DG_HIP(hipStreamSynchronize(k.s()));
+  });
+}
+
+int dg16_d_msm_resident(dg16_ctx* ctx, const dg16_pss* pp, const dg16_net* net, const dg16_bases* bases,
+                        const void* scalars, size_t n_scalars, unsigned flags, int channel, void* out) {
+  int rc = guard_channel(ctx, channel);
+  if (rc) return rc;
+  return guarded(ctx, [&] {
+    DG_REQUIRE(pp && net && out && bases && bases->ctx == ctx && bases->curve == pp->curve, DG16_ERR_BAD_ARG,
+               "bad argument");
+    DG_REQUIRE(bases->n == n_scalars, DG16_ERR_LENGTH_MISMATCH,
+               "bases and scalars differ in length (VariableBaseMSM::msm returns Err(min_len))");
+    DG_REQUIRE(net->n_parties(net->self) == pp->n, DG16_ERR_BAD_ARG, "net.n_parties() != pp.n");
+    bool dev = flags & DG16_F_DEVICE_PTRS;
+    size_t pb = affine_bytes(pp->curve, bases->group);
+    Call k(ctx, channel);
+    const void* dscal = stage_in(k, 1, scalars, n_scalars * 32, dev);
+    void* dout = dev ? out : ws(k.c, 2, pb / 2 * 3);
+    DISPATCH_G(d_msm, pp->curve, bases->group, k, pp, net, channel, nullptr, dscal, n_scalars,
+               flags & DG16_F_SCALARS_MONT, dout, bases->table, bases->c)
     if (!dev) stage_out(k, out, dout, pb / 2 * 3, false);
     k.finish();
     if (!dev) DG_HIP(hipStreamSynchronize(k.s()));

@@ -6,7 +6,9 @@ namespace dg16 {
 #define DECL(name)                                                                              \
   void msm_##name(Call&, const void*, const void*, size_t, bool, bool, void*);                  \
   void gen_bases_##name(Call&, uint64_t, size_t, void*);                                        \
-  void to_affine_##name(Call&, const void*, void*, size_t);
+  void to_affine_##name(Call&, const void*, void*, size_t);                                     \
+  void* bases_table_##name(Call&, const void*, size_t, unsigned*, unsigned*);                   \
+  void msm_resident_##name(Call&, const void*, size_t, unsigned, const void*, bool, bool, void*);
 DECL(bn254_g1) DECL(bn254_g2) DECL(bls12_381_g1) DECL(bls12_381_g2) DECL(bls12_377_g1)
 
 #define DISPATCH(fn, ...)                                                                       \
@@ -28,5 +30,21 @@ void gen_bases_launch(Call& k, int curve, int group, uint64_t seed, size_t n, vo
 }
 void to_affine_launch(Call& k, int curve, int group, const void* jac, void* out, size_t n) {
   DISPATCH(to_affine, k, jac, out, n)
+}
+void* bases_table_launch(Call& k, int curve, int group, const void* bases, size_t n, unsigned* c, unsigned* nwin) {
+  void* t = nullptr;
+  switch (curve * 2 + group - 1) {
+    case 0: t = bases_table_bn254_g1(k, bases, n, c, nwin); break;
+    case 1: t = bases_table_bn254_g2(k, bases, n, c, nwin); break;
+    case 2: t = bases_table_bls12_381_g1(k, bases, n, c, nwin); break;
+    case 3: t = bases_table_bls12_381_g2(k, bases, n, c, nwin); break;
+    case 4: t = bases_table_bls12_377_g1(k, bases, n, c, nwin); break;
+    default: throw StatusError{DG16_ERR_UNSUPPORTED, "BLS12-377 G2 is not on the reference's path"};
+  }
+  return t;
+}
+void msm_resident_launch(Call& k, int curve, int group, const void* table, size_t n, unsigned c, const void* scalars,
+                         bool mont, bool affine, void* out) {
+  DISPATCH(msm_resident, k, table, n, c, scalars, mont, affine, out)
 }
 }  // namespace dg16

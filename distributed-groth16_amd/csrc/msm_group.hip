@@ -30,16 +30,35 @@ void DG_FN(msm_)(Call& k, const void* bases, const void* scalars, size_t n, bool
 void DG_FN(gen_bases_)(Call& k, uint64_t seed, size_t n, void* out) { gen_bases_run<GF, GC>(k, seed, n, out); }
 void DG_FN(to_affine_)(Call& k, const void* jac, void* out, size_t n) { to_affine_run<GF>(k, jac, out, n); }
 
+// resident bases: the table of window multiples (internal form) for n points; c and the window count come back
+void* DG_FN(bases_table_)(Call& k, const void* bases_dev, size_t n, unsigned* c_out, unsigned* nwin_out) {
+  const unsigned c = msm_window_bits(n ? n : 1, true);
+  const unsigned nwin = (CT::SCALAR_BITS + 1 + c - 1) / c;
+  *c_out = c;
+  *nwin_out = nwin;
+  return msm_build_table<GF>(k.s(), bases_dev, n, c, nwin);
+}
+// MSM over a resident table: one digit sort in table mode, one bucket set, no Horner tail
+void DG_FN(msm_resident_)(Call& k, const void* table, size_t n, unsigned c, const void* scalars, bool mont, bool affine,
+                          void* out) {
+  MsmSort st = msm_sort<CT::Fr, CT::SCALAR_BITS>(k, scalars, n, mont, true, c);
+  msm_reduce<GF>(k, st, table, affine, out);
+}
+
 // d_msm (dist-primitives/src/dmsm/mod.rs:70-98): local MSM of the share vectors, gather to the king, who
 // interpolates in the exponent (unpackexp, degree2) and sums the l secrets -- one n-term combination with
 // the constant scalars v_j = sum_i unpack2[i][j] -- then sends the same point to every party.
+// (table != nullptr: the base shares are resident, `bases` is unused)
 void DG_FN(d_msm_)(Call& k, const dg16_pss* pp, const dg16_net* net, int sid, const void* bases, const void* scalars,
-                   size_t n, bool mont, void* out_jac) {
+                   size_t n, bool mont, void* out_jac, const void* table, unsigned table_c) {
   using F = GF;
   using Fr = CT::Fr;
   const unsigned np = pp->n;
   Affine<F>* c_share = (Affine<F>*)ws(k.c, 18, sizeof(Affine<F>));
-  msm_run<F, Fr, CT::SCALAR_BITS>(k, bases, scalars, n, mont, true, c_share);          // dmsm/mod.rs:82
+  if (table)
+    DG_FN(msm_resident_)(k, table, n, table_c, scalars, mont, true, c_share);
+  else
+    msm_run<F, Fr, CT::SCALAR_BITS>(k, bases, scalars, n, mont, true, c_share);        // dmsm/mod.rs:82
   const bool king = net->party_id(net->self) == 0;
   Affine<F>* shares = king ? (Affine<F>*)ws(k.c, 19, np * sizeof(Affine<F>)) : nullptr;
   if (net->gather_to_king(net->self, sid, c_share, sizeof(Affine<F>), shares, k.s()) != DG16_OK)

@@ -136,6 +136,17 @@ def d_msm(ctx, pp, net, group, bases, scalars, scalars_mont=True, sid=0):
     return out
 
 
+def d_msm_resident(ctx, pp, net, resident_bases, scalars, scalars_mont=True, sid=0):
+    """d_msm over base shares uploaded once (`Context.bases_upload`): what a party does per proof with its
+    PackedProvingKeyShare (groth16/src/proving_key.rs:26-46)."""
+    scalars = _fr(scalars)
+    nl = FQ_LIMBS64[pp.curve] * (2 if resident_bases.group == 2 else 1)
+    out = np.zeros((1, 3 * nl), dtype=np.uint64)
+    ctx._chk(ctx.L.dg16_d_msm_resident(ctx.h, pp.h, net, resident_bases.h, _ptr(scalars), scalars.shape[0],
+                                       1 if scalars_mont else 0, sid, _ptr(out)))
+    return out
+
+
 def dpoly_commit(ctx, pp, net, srs_shares, coeff_shares, scalars_mont=True, sid=0):
     """KZG-style commitment to a polynomial held as packed coefficient shares: one `d_msm` of the coefficient
     shares against the packed-in-the-exponent SRS powers [tau^i]_1.  The north star names `dpoly_commit`, but the

@@ -127,6 +127,12 @@ def load():
     L.dg16_h_poly.argtypes = [vp, i, vp, vp, vp, u, vp, u, i]
     L.dg16_msm.argtypes = [vp, i, i, vp, vp, sz, sz, u, i, vp]
     L.dg16_gen_bases.argtypes = [vp, i, i, u64, sz, vp, u, i]
+    L.dg16_bases_upload.argtypes = [vp, i, i, vp, sz, u, ctypes.POINTER(vp)]
+    L.dg16_bases_free.argtypes = [vp]
+    L.dg16_bases_free.restype = None
+    L.dg16_bases_info.argtypes = [vp, ctypes.POINTER(sz), ctypes.POINTER(u), ctypes.POINTER(u64)]
+    L.dg16_msm_resident.argtypes = [vp, vp, vp, sz, u, i, vp]
+    L.dg16_d_msm_resident.argtypes = [vp, vp, vp, vp, vp, sz, u, i, vp]
     L.dg16_to_affine.argtypes = [vp, i, i, vp, vp, sz, u, i]
     L.dg16_last_kernel_ms.argtypes = [vp, i, i, ctypes.POINTER(ctypes.c_float)]
     L.dg16_pk_create.argtypes = [vp, i, sz, sz, sz, vp, vp, vp, vp, vp, vp, u, ctypes.POINTER(vp)]
@@ -210,7 +216,8 @@ EXPORTED = ["dg16_ctx_create", "dg16_ctx_destroy", "dg16_last_error", "dg16_set_
             "dg16_d_msm", "dg16_deg_red", "dg16_d_pp", "dg16_ext_wit_h", "dg16_qap", "dg16_qap_rows",
             "dg16_h_poly_dist", "dg16_h_poly_dist_stage", "dg16_groth16_msms_h", "dg16_groth16_prove_dist",
             "dg16_rccl_unique_id", "dg16_rccl_create", "dg16_rccl_comm", "dg16_rccl_net", "dg16_rccl_destroy",
-            "dg16_rccl_error",
+            "dg16_rccl_error", "dg16_bases_upload", "dg16_bases_free", "dg16_bases_info", "dg16_msm_resident",
+            "dg16_d_msm_resident",
             "dg16_io_error", "dg16_r1cs_parse", "dg16_r1cs_header_get", "dg16_r1cs_matrix", "dg16_r1cs_wire_map",
             "dg16_r1cs_free", "dg16_zkey_parse", "dg16_zkey_header_get", "dg16_zkey_points", "dg16_zkey_matrix",
             "dg16_zkey_free", "dg16_serialize_error", "dg16_proof_compress", "dg16_proof_decompress",
@@ -224,6 +231,29 @@ def _ptr(x):
     if isinstance(x, np.ndarray):
         return x.ctypes.data_as(ctypes.c_void_p)
     return ctypes.c_void_p(int(x))
+
+
+class ResidentBases:
+    """dg16_bases: a base vector resident in HBM as its table of window multiples."""
+
+    def __init__(self, ctx, handle, curve, group, n):
+        self.ctx, self.h, self.curve, self.group, self.n = ctx, handle, curve, group, n
+
+    def info(self):
+        n, c, b = ctypes.c_size_t(), ctypes.c_uint(), ctypes.c_uint64()
+        self.ctx._chk(self.ctx.L.dg16_bases_info(self.h, ctypes.byref(n), ctypes.byref(c), ctypes.byref(b)))
+        return {"n": n.value, "window_bits": c.value, "table_bytes": b.value}
+
+    def close(self):
+        if self.h and self.ctx.h:
+            self.ctx.L.dg16_bases_free(self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class ProvingKey:
@@ -340,6 +370,28 @@ class Context:
         self._chk(self.L.dg16_msm(self.h, CURVES[curve], group, _ptr(bases), _ptr(scalars), bases.shape[0],
                                   scalars.shape[0], flags, channel, _ptr(out)))
         return out
+
+    def bases_upload(self, curve, group, bases, n=None, device_ptrs=False):
+        """bases: numpy array of affine points (host) or a raw device pointer with n given."""
+        h = ctypes.c_void_p()
+        if not device_ptrs:
+            bases = np.ascontiguousarray(bases, dtype=np.uint64)
+            n = bases.shape[0]
+        self._chk(self.L.dg16_bases_upload(self.h, CURVES[curve], group, _ptr(bases), n,
+                                           F_DEVICE_PTRS if device_ptrs else 0, ctypes.byref(h)))
+        return ResidentBases(self, h, curve, group, n)
+
+    def msm_resident(self, hb, scalars, scalars_mont=False, affine=False, channel=0):
+        scalars = np.ascontiguousarray(scalars, dtype=np.uint64)
+        nl = FQ_LIMBS64[hb.curve] * (2 if hb.group == 2 else 1)
+        out = np.zeros((1, nl * (2 if affine else 3)), dtype=np.uint64)
+        flags = (F_SCALARS_MONT if scalars_mont else 0) | (F_OUT_AFFINE if affine else 0)
+        self._chk(self.L.dg16_msm_resident(self.h, hb.h, _ptr(scalars), scalars.shape[0], flags, channel, _ptr(out)))
+        return out
+
+    def msm_resident_dev(self, hb, scalars_ptr, n, out_ptr, scalars_mont=False, affine=False, channel=0):
+        flags = F_DEVICE_PTRS | (F_SCALARS_MONT if scalars_mont else 0) | (F_OUT_AFFINE if affine else 0)
+        self._chk(self.L.dg16_msm_resident(self.h, hb.h, _ptr(scalars_ptr), n, flags, channel, _ptr(out_ptr)))
 
     def gen_bases(self, curve, group, seed, n, channel=0):
         nl = FQ_LIMBS64[curve] * 2 * (2 if group == 2 else 1)

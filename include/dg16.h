@@ -131,6 +131,20 @@ int dg16_qap_rows(dg16_ctx *ctx, int curve, size_t num_constraints, size_t num_i
 int dg16_msm(dg16_ctx *ctx, int curve, int group, const void *bases, const void *scalars,
              size_t n_bases, size_t n_scalars, unsigned flags, int channel, void *out);
 
+/* Resident bases (bases_upload -> handle, msm_resident): a CRS is fixed, so its bases go to HBM once,
+ * as the table of window multiples T[w][i] = 2^(c w) P_i (288 GB of HBM: 15 rows x 64 B x 2^20 = 1 GB per G1
+ * vector) -- an MSM over them then has ONE bucket set and no Horner tail (2^20 points: ~2 ms G1 / ~6 ms G2 against
+ * ~4.7 / ~14 for dg16_msm).  This is what `PackedProvingKeyShare` (groth16/src/proving_key.rs:26-46) holds per party:
+ * dg16_d_msm_resident is d_msm (dist-primitives/src/dmsm/mod.rs:70-98) over such a handle.
+ * n_scalars != n returns DG16_ERR_LENGTH_MISMATCH like dg16_msm. */
+typedef struct dg16_bases dg16_bases;
+int dg16_bases_upload(dg16_ctx *ctx, int curve, int group, const void *bases, size_t n, unsigned flags,
+                      dg16_bases **out);
+void dg16_bases_free(dg16_bases *h);
+int dg16_bases_info(const dg16_bases *h, size_t *n, unsigned *window_bits, uint64_t *table_bytes);
+int dg16_msm_resident(dg16_ctx *ctx, const dg16_bases *h, const void *scalars, size_t n_scalars, unsigned flags,
+                      int channel, void *out);
+
 /* Synthetic bases P_i = (k0 + i*k1) * G (distinct, prime-order subgroup), written as affine points
  * to `out` (device or host per flags). */
 int dg16_gen_bases(dg16_ctx *ctx, int curve, int group, uint64_t seed, size_t n, void *out,
@@ -338,6 +352,9 @@ int dg16_d_fft(dg16_ctx *ctx, const dg16_pss *pp, const dg16_net *net, const voi
 int dg16_d_msm(dg16_ctx *ctx, const dg16_pss *pp, const dg16_net *net, int group, const void *bases,
                const void *scalars, size_t n_bases, size_t n_scalars, unsigned flags, int channel,
                void *out);
+/* d_msm with this party's base shares resident (dg16_bases_upload of the share vector). */
+int dg16_d_msm_resident(dg16_ctx *ctx, const dg16_pss *pp, const struct dg16_net *net, const dg16_bases *bases,
+                        const void *scalars, size_t n_scalars, unsigned flags, int channel, void *out);
 int dg16_deg_red(dg16_ctx *ctx, const dg16_pss *pp, const dg16_net *net, const void *px, size_t count,
                  void *out, unsigned flags, int channel);
 int dg16_d_pp(dg16_ctx *ctx, const dg16_pss *pp, const dg16_net *net, const void *num, const void *den,

@@ -132,6 +132,33 @@ def test_d_msm_equals_clear_msm(curve, group):
     assert np.array_equal(back.reshape(8, -1), pts_arr[:8])
 
 
+@pytest.mark.parametrize("curve,group", [("bls12_377", 1), ("bn254", 2)])
+def test_d_msm_resident_equals_d_msm(curve, group):
+    """dg16_d_msm_resident: every party uploads its base shares once (what PackedProvingKeyShare holds,
+    groth16/src/proving_key.rs:26-46) and runs d_msm over the table -- same point as d_msm and as the clear MSM,
+    repeatedly with fresh scalars."""
+    F = FR[curve]
+    ctxs, pps, net, D = parties(curve)
+    rng = random.Random(19)
+    M = 64
+    pts_arr = corc.gen_points(curve, group, 5, M)
+    packed_bases = pps[0].packexp_from_public(group, pts_arr.reshape(M // 2, 2, -1))
+    resident = [ctxs[i].bases_upload(curve, group, np.ascontiguousarray(packed_bases[:, i])) for i in range(len(ctxs))]
+    assert resident[0].info()["n"] == M // 2
+    for rep in range(2):
+        sc = [rng.randrange(F.p) for _ in range(M)]
+        clear = corc.msm(curve, group, pts_arr, corc.ints_to_arr(sc, 4))
+        packed_sc = pps[0].pack_from_public(enc(F, sc).reshape(M // 2, 2, 4))
+        got = net.simulate_network_round(
+            lambda i, h: D.d_msm_resident(ctxs[i], pps[i], h, resident[i], packed_sc[:, i]))
+        assert all(np.array_equal(corc.jac_to_affine(curve, group, g), clear) for g in got)
+    import dg16_amd
+    with pytest.raises(dg16_amd.Dg16Error):      # length mismatch, like VariableBaseMSM::msm's Err(min_len)
+        D.d_msm_resident(ctxs[0], pps[0], net.party(0), resident[0], packed_sc[:-1, 0])
+    for r in resident:
+        r.close()
+
+
 def test_dpoly_commit_is_the_kzg_commitment():
     """dpoly_commit (no reference module exists; thin wrapper over d_msm): commit(p) with an SRS of known tau must be
     p(tau) * G."""

@@ -147,3 +147,53 @@ def test_msm_skewed_witness(kind, group):
         sc = [r - 1 - int(v) for v in rng.integers(0, 4, n)]
     bases = corc.gen_points(curve, group, 6, n)
     check(curve, group, bases, corc.ints_to_arr(sc, 4))
+
+
+@pytest.mark.parametrize("curve,group,log_n", [("bn254", 1, 0), ("bn254", 1, 7), ("bn254", 1, 16), ("bn254", 2, 14),
+                                               ("bls12_381", 1, 15), ("bls12_381", 2, 12), ("bls12_377", 1, 13)])
+def test_resident_msm_matches_oracle(curve, group, log_n):
+    """dg16_bases_upload + dg16_msm_resident (window tables, one bucket set, no Horner tail) against the oracle and
+    against dg16_msm, with fresh scalars per call, canonical and Montgomery scalars, identity bases inside."""
+    import dg16_amd
+    n = 1 << log_n
+    c = ctx()
+    bases = corc.gen_points(curve, group, 21 + log_n, n)
+    if n >= 8:
+        bases[3] = 0          # the identity (0, 0) as a base
+    hb = c.bases_upload(curve, group, bases)
+    info = hb.info()
+    assert info["n"] == n and info["table_bytes"] >= bases.nbytes
+    for seed, mont in ((1, False), (2, True)):
+        sc = corc.rand_field(curve, "fr", seed, n, mont=mont)
+        want = corc.msm(curve, group, bases, sc, scalars_mont=mont)
+        got = c.msm_resident(hb, sc, scalars_mont=mont, affine=True)
+        assert np.array_equal(got.reshape(-1), np.asarray(want).reshape(-1))
+        plain = c.msm(curve, group, bases, sc, scalars_mont=mont, affine=True)
+        assert np.array_equal(plain, got)
+    if n > 1:
+        with pytest.raises(dg16_amd.Dg16Error) as e:
+            c.msm_resident(hb, sc[:-1])
+        assert e.value.code == 1          # DG16_ERR_LENGTH_MISMATCH
+    hb.close()
+
+
+def test_resident_msm_2e20_equals_plain_msm():
+    """BASELINE config 2's size through the resident path: same point as dg16_msm (itself oracle-checked above)."""
+    import torch
+    curve, n = "bn254", 1 << 20
+    c = ctx()
+    dev = torch.device("cuda:0")
+    for group in (1, 2):
+        pb = 64 * group
+        bases = torch.empty(n * pb, dtype=torch.uint8, device=dev)
+        c.gen_bases_dev(curve, group, 77, n, bases.data_ptr())
+        c.sync(0)
+        sc = torch.from_numpy(corc.rand_field(curve, "fr", 5, n, mont=False).view(np.int64)).to(dev)
+        out = torch.empty((2, pb), dtype=torch.uint8, device=dev)
+        hb = c.bases_upload(curve, group, bases.data_ptr(), n=n, device_ptrs=True)
+        c.msm_resident_dev(hb, sc.data_ptr(), n, out[0].data_ptr(), affine=True)
+        c.msm_dev(curve, group, bases.data_ptr(), sc.data_ptr(), n, out[1].data_ptr(), affine=True)
+        c.sync(0)
+        o = out.cpu().numpy()
+        assert np.array_equal(o[0], o[1]) and o[0].any()
+        hb.close()

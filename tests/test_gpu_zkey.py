@@ -43,3 +43,27 @@ def test_zkey_to_verified_proof():
           "delta_g2": dec_g2(Fq, z.delta_g2), "ic": [dec_g1(Fq, row) for row in z.ic]}
     assert PR.groth16_verify(curve, vk, w[1:z.num_instance_variables], proof)
     key.close()
+
+
+def test_reference_g2_bytes_are_the_generator_on_the_gpu():
+    """ark-circom/src/zkey.rs:443-456 (g2_buf): the 128 bytes snarkjs writes for G2.one, used AS THEY ARE as an MSM
+    base: 1 * P comes back as the same bytes, k * P equals the oracle's k * G2 -- the Fq2 component order and x || y
+    order of the G2 layout dg16_msm / dg16_pk_create consume is the reference's.  Same for g1_buf (:430-441)."""
+    import json
+    import os
+    kat = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_kats.json")))
+    curve = "bn254"
+    F, Fq = FR[curve], FQ[curve]
+    c_ = ctx()
+    for group, key, dec in ((1, "zkey_g1_buf", dec_g1), (2, "zkey_g2_buf", dec_g2)):
+        raw = np.frombuffer(bytes(kat[key]), dtype=np.uint64).reshape(1, -1).copy()
+        bases = np.repeat(raw, 3, axis=0)
+        one = c_.msm(curve, group, bases[:1], corc.ints_to_arr([1], 4), affine=True)
+        assert np.array_equal(one.reshape(-1), raw.reshape(-1))
+        ks = [5, 7, F.p - 3]
+        got = c_.msm(curve, group, bases, corc.ints_to_arr(ks, 4), affine=True)
+        gen = corc.generator(curve, group)
+        assert np.array_equal(np.asarray(gen).reshape(-1), raw.reshape(-1))
+        want = corc.point_mul(curve, group, gen, sum(ks) % F.p)
+        assert np.array_equal(got.reshape(-1), np.asarray(want).reshape(-1))
+        assert dec(Fq, got) is not None
