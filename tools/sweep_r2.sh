@@ -1,4 +1,4 @@
-for cfg in "DG16_PREP_OVERLAP=0" "DG16_PREP_OVERLAP=1"; do
-  echo "== $cfg"; env $cfg timeout 120 python bench.py --steps 10 --warmup 2 --no-extras --no-cpu-baseline 2>/dev/null | python -c "
-import json,sys; d=json.loads(sys.stdin.read()); print('ms/proof %.3f  g2acc %.3f g1acc %.3f'%(d['ms_per_step'], d['roofline']['kernel_ms'], d['g1_accumulate_ms']))"
+# geometry sweep of the resident-key prover on one box (same-call A/B: boxes differ by +-5 %)
+for cfg in "" "DG16_MSM_SEG_LOG=5" "DG16_MSM_SEG_LOG=6" "DG16_MSM_TABLE_C=16" "DG16_MSM_TABLE_C=18" "DG16_MSM_TABLE_C=18 DG16_MSM_SEG_LOG=5" ""; do
+  echo "== $cfg"; env $cfg timeout 120 python tools/shard_timing.py 20 10 bn254 1 2>/dev/null | grep world
 done
