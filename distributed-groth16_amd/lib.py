@@ -68,6 +68,12 @@ _COMM_A2A = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, cty
                              ctypes.c_void_p)
 
 
+class ArkKeyLayout(ctypes.Structure):     # dg16_arkkey_layout_t
+    _fields_ = [(n, ctypes.c_uint64) for n in
+                ("n_ic", "n_a", "n_b1", "n_b2", "n_h", "n_l", "off_alpha_g1", "off_beta_g2", "off_gamma_g2", "off_delta_g2",
+                 "off_ic", "off_beta_g1", "off_delta_g1", "off_a", "off_b1", "off_b2", "off_h", "off_l", "bytes")]
+
+
 class CommStruct(ctypes.Structure):       # dg16_comm
     _fields_ = [("self", ctypes.c_void_p), ("n_ranks", _COMM_N), ("rank", _COMM_N), ("all_gather", _COMM_GATHER),
                 ("all_to_all", _COMM_A2A)]
@@ -151,6 +157,11 @@ def load():
     L.dg16_h_poly_dist_stage.argtypes = [vp, i, u, u, u, i, ctypes.POINTER(vp), vp, u, i]
     L.dg16_groth16_msms_h.argtypes = [vp, vp, vp, vp, vp, u, vp]
     L.dg16_groth16_prove_dist.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, u, vp]
+    L.dg16_codec_error.argtypes = []
+    L.dg16_codec_error.restype = ctypes.c_char_p
+    L.dg16_arkkey_layout.argtypes = [vp, sz, i, ctypes.POINTER(ArkKeyLayout)]
+    L.dg16_points_compress.argtypes = [vp, i, i, vp, sz, vp, u, i]
+    L.dg16_points_decompress.argtypes = [vp, i, i, vp, sz, i, vp, u, i]
     L.dg16_rccl_unique_id.argtypes = [vp]
     L.dg16_rccl_create.argtypes = [vp, vp, u, u, ctypes.POINTER(vp)]
     L.dg16_rccl_comm.argtypes = [vp]
@@ -217,7 +228,8 @@ EXPORTED = ["dg16_ctx_create", "dg16_ctx_destroy", "dg16_last_error", "dg16_set_
             "dg16_h_poly_dist", "dg16_h_poly_dist_stage", "dg16_groth16_msms_h", "dg16_groth16_prove_dist",
             "dg16_rccl_unique_id", "dg16_rccl_create", "dg16_rccl_comm", "dg16_rccl_net", "dg16_rccl_destroy",
             "dg16_rccl_error", "dg16_bases_upload", "dg16_bases_free", "dg16_bases_info", "dg16_msm_resident",
-            "dg16_d_msm_resident",
+            "dg16_d_msm_resident", "dg16_codec_error", "dg16_arkkey_layout", "dg16_points_compress",
+            "dg16_points_decompress",
             "dg16_io_error", "dg16_r1cs_parse", "dg16_r1cs_header_get", "dg16_r1cs_matrix", "dg16_r1cs_wire_map",
             "dg16_r1cs_free", "dg16_zkey_parse", "dg16_zkey_header_get", "dg16_zkey_points", "dg16_zkey_matrix",
             "dg16_zkey_free", "dg16_serialize_error", "dg16_proof_compress", "dg16_proof_decompress",
@@ -392,6 +404,30 @@ class Context:
     def msm_resident_dev(self, hb, scalars_ptr, n, out_ptr, scalars_mont=False, affine=False, channel=0):
         flags = F_DEVICE_PTRS | (F_SCALARS_MONT if scalars_mont else 0) | (F_OUT_AFFINE if affine else 0)
         self._chk(self.L.dg16_msm_resident(self.h, hb.h, _ptr(scalars_ptr), n, flags, channel, _ptr(out_ptr)))
+
+    def points_compress(self, curve, group, affine, channel=0):
+        """affine: uint64 array [n][8 * group] (x || y Montgomery limbs) -> bytes, 32 * group per point (arkworks)."""
+        affine = np.ascontiguousarray(affine, dtype=np.uint64).reshape(-1, 8 * group)
+        out = np.zeros(affine.shape[0] * 32 * group, dtype=np.uint8)
+        self._chk(self.L.dg16_points_compress(self.h, CURVES[curve], group, _ptr(affine), affine.shape[0], _ptr(out), 0,
+                                              channel))
+        return out.tobytes()
+
+    def points_decompress(self, curve, group, raw, validate=False, channel=0):
+        raw = np.frombuffer(bytes(raw), dtype=np.uint8)
+        n = raw.size // (32 * group)
+        out = np.zeros((n, 8 * group), dtype=np.uint64)
+        self._chk(self.L.dg16_points_decompress(self.h, CURVES[curve], group, _ptr(raw), n, int(validate), _ptr(out), 0,
+                                                channel))
+        return out
+
+    def points_decompress_dev(self, curve, group, in_ptr, n, out_ptr, validate=False, channel=0):
+        self._chk(self.L.dg16_points_decompress(self.h, CURVES[curve], group, _ptr(in_ptr), n, int(validate),
+                                                _ptr(out_ptr), F_DEVICE_PTRS, channel))
+
+    def points_compress_dev(self, curve, group, in_ptr, n, out_ptr, channel=0):
+        self._chk(self.L.dg16_points_compress(self.h, CURVES[curve], group, _ptr(in_ptr), n, _ptr(out_ptr),
+                                              F_DEVICE_PTRS, channel))
 
     def gen_bases(self, curve, group, seed, n, channel=0):
         nl = FQ_LIMBS64[curve] * 2 * (2 if group == 2 else 1)

@@ -418,6 +418,30 @@ const char *dg16_serialize_error(void);
 int dg16_proof_compress(int curve, const void *proof_jacobian, void *out128);
 int dg16_proof_decompress(int curve, const void *in128, int validate, void *proof_affine);
 
+/* ---- arkworks compressed key files, BN254 -------------------------------------------------------------------------
+ *   <- pk.serialize_with_mode(.., Compress::Yes) / ProvingKey::deserialize_with_mode(.., Compress::Yes, Validate::No)
+ *      and the same for VerifyingKey                               mpc-api/src/main.rs:154-171, :459-512
+ * dg16_arkkey_layout (host code) walks the container: struct field order of ark-groth16's derive, a u64 little-endian
+ * length in front of every Vec; offsets are byte offsets into the file, counts are points.  The point sections are
+ * then (de)compressed in batches ON THE GPU by dg16_points_compress / _decompress -- one lane per point running the
+ * same routines as the proof.bin codec above (pinned by the reference's own proof.bin): affine x || y Montgomery limbs
+ * with the identity as zeros on one side (the layout dg16_pk_create and dg16_bases_upload take), 32 (G1) / 64 (G2)
+ * bytes per point on the other.  dg16_points_decompress is synchronous: a coordinate that is not reduced, bad flags
+ * or an x off the curve return DG16_ERR_BAD_ARG (dg16_codec_error names the first failing point), like the Err of
+ * deserialize_with_mode; validate != 0 adds the order-r subgroup check for G2 (Validate::Yes). */
+typedef struct dg16_arkkey_layout_t {
+  uint64_t n_ic, n_a, n_b1, n_b2, n_h, n_l;
+  uint64_t off_alpha_g1, off_beta_g2, off_gamma_g2, off_delta_g2, off_ic;              /* VerifyingKey */
+  uint64_t off_beta_g1, off_delta_g1, off_a, off_b1, off_b2, off_h, off_l;             /* rest of ProvingKey */
+  uint64_t bytes;
+} dg16_arkkey_layout_t;
+const char *dg16_codec_error(void);
+int dg16_arkkey_layout(const void *data, size_t bytes, int verifying_key_only, dg16_arkkey_layout_t *out);
+int dg16_points_compress(dg16_ctx *ctx, int curve, int group, const void *affine, size_t n, void *out,
+                         unsigned flags, int channel);
+int dg16_points_decompress(dg16_ctx *ctx, int curve, int group, const void *in, size_t n, int validate,
+                           void *affine_out, unsigned flags, int channel);
+
 /* ---- Groth16 verification, BN254 (host side; no GPU involved: four pairings) --------------------------------
  *   dg16_groth16_verify  <- Groth16::<Bn254>::verify_proof   groth16/examples/sha256.rs:228-254, mpc-api verify
  * e(A, B) = e(alpha, beta) e(IC_0 + sum x_i IC_i, gamma) e(C, delta).  Points are affine x || y Montgomery limbs
