@@ -920,6 +920,61 @@ void msm_accumulate_phase(hipStream_t s, const MsmSort& st, const MsmBuffers<F>&
   DG_HIP(hipGetLastError());
 }
 
+// ---- 4b: bucket = sum of its segment partials, as a throughput kernel -------------------------------------------
+// Giant buckets (a boolean witness puts half of ALL entries into bucket 0; the short top window of a c that does
+// not divide the scalar width does the same) go on a device-side work list: stage 1 cuts the bucket's segment
+// partials into <= kGiantSlices slices, one workgroup each; stage 2 adds the slice sums (msm_reduce_impl.h).
+constexpr unsigned kGiantSlices = 64;
+constexpr unsigned kGiantSliceSegs = 512;
+__device__ __forceinline__ void giant_geometry(unsigned nseg, unsigned& slices, unsigned& per) {
+  slices = (nseg + kGiantSliceSegs - 1) / kGiantSliceSegs;
+  if (slices > kGiantSlices) slices = kGiantSlices;
+  per = (nseg + slices - 1) / slices;
+  slices = (nseg + per - 1) / per;
+}
+
+
+// One lane per bucket, full XYZZ additions with inline products in registers.  2^16 buckets x ~15 partials per MSM of
+// a 2^20 proof = a million additions: the four-lanes-per-bucket, out-of-line-product finalize of the reduction unit
+// (built for short chains) spent 0.7 ms (G1) / 2.6 ms (G2) on them at low occupancy, next to an accumulation it
+// stretched by a millisecond; the 29-bit product runs at full rate at ONE wave per SIMD, so plain lanes do.
+template <class F>
+__global__ void __launch_bounds__(256) msm_finalize_thr_kernel(MsmGeom g, const unsigned* __restrict__ counts,
+                                                                const unsigned* __restrict__ seg_off,
+                                                                const XYZZ29<F>* __restrict__ seg_sum,
+                                                                XYZZ29<F>* __restrict__ buckets,
+                                                                unsigned* __restrict__ giant_count,
+                                                                unsigned* __restrict__ giant_list, unsigned giant_cap) {
+  const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)g.bw << g.log_nb;
+  if (gid >= total) return;
+  const unsigned w = (unsigned)(gid >> g.log_nb);
+  const unsigned nseg = (counts[gid] + (1u << g.seg_log) - 1) >> g.seg_log;
+  if (nseg > kGiantSegs) {
+    unsigned slot = atomicAdd(giant_count, 1u);
+    if (slot < giant_cap) {               // (always: giant_cap >= total segments / kGiantSegs)
+      giant_list[slot] = (unsigned)gid;
+      unsigned slices, per;
+      giant_geometry(nseg, slices, per);
+      unsigned wb = atomicAdd(giant_count + 1, slices);   // work items: (giant, slice)
+      unsigned* work = giant_list + giant_cap;
+      for (unsigned k = 0; k < slices; k++) work[wb + k] = (slot << 6) | k;
+    }
+    return;
+  }
+  const XYZZ29<F>* sp = seg_sum + (size_t)w * g.seg_cap + seg_off[gid];
+  XYZZ29<F> acc = nseg ? sp[0] : XYZZ29<F>::inf();
+#pragma unroll 1
+  for (unsigned s = 1; s < nseg; s++) acc = acc.add(sp[s]);
+  buckets[gid] = acc;
+}
+template <class F>
+void msm_finalize_phase(hipStream_t s, const MsmSort& st, const MsmBuffers<F>& b) {
+  hipLaunchKernelGGL(msm_finalize_thr_kernel<F>, dim3((unsigned)((b.nbw + 255) / 256)), dim3(256), 0, s, st.g, st.counts,
+                     st.seg_off, b.seg_sum, b.buckets, b.giant, b.giant + 2, b.giant_cap);
+  DG_HIP(hipGetLastError());
+}
+
 // Phase B (latency-bound, few waves): finalize -> giants -> rows -> top -> tail.  May run on another stream than
 // phase A so that it hides behind the next MSM's accumulation.  Defined in msm_reduce_impl.h and instantiated once per
 // (curve, group) in msm_reduce.hip -- a translation unit of its own because its kernels are compiled with out-of-line
@@ -1107,6 +1162,7 @@ void to_affine_run(Call& k, const void* jac, void* out, size_t n) {
 // compiled once, in msm_group.hip / msm_reduce.hip:  namespace dg16 { DG16_MSM_EXTERN(CurveTypes<0>) }
 #define DG16_MSM_EXTERN_GROUP(F)                                                                                  \
   extern template void msm_accumulate_phase<F>(hipStream_t, const MsmSort&, const MsmBuffers<F>&, const void*);   \
+  extern template void msm_finalize_phase<F>(hipStream_t, const MsmSort&, const MsmBuffers<F>&);                   \
   extern template void* msm_build_table<F>(hipStream_t, const void*, size_t, unsigned, unsigned);
 #define DG16_MSM_EXTERN(CT)                                                                                       \
   DG16_MSM_EXTERN_GROUP(CT::Fq)                                                                                   \

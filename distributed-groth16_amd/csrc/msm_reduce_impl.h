@@ -13,14 +13,7 @@ namespace dg16 {
 // <= kGiantSlices slices, one workgroup each, and leaves every slice's sum IN PLACE in the slice's first
 // segment slot; stage 2 adds the slice sums.  (One workgroup per bucket chained 128 dependent additions per
 // lane for a 2^20-bit witness: 2.5 ms for G1, far more for G2.)
-constexpr unsigned kGiantSlices = 64;
-constexpr unsigned kGiantSliceSegs = 512;
-__device__ __forceinline__ void giant_geometry(unsigned nseg, unsigned& slices, unsigned& per) {
-  slices = (nseg + kGiantSliceSegs - 1) / kGiantSliceSegs;
-  if (slices > kGiantSlices) slices = kGiantSlices;
-  per = (nseg + slices - 1) / slices;
-  slices = (nseg + per - 1) / per;
-}
+// (kGiantSlices, kGiantSliceSegs, giant_geometry: msm_impl.h -- the throughput finalize there registers giants too)
 
 // ---- 4b / 5: bucket reduction --------------------------------------------------------------------------------
 // sum_b (b + 1) B_b over the 2^(c-1) buckets of a bucket-window, B_b = sum of the bucket's segment partials.
@@ -409,7 +402,12 @@ void msm_bucket_phase(hipStream_t s, const MsmSort& st, const MsmBuffers<F>& b, 
   const MsmGeom& g = st.g;
   trace_point(s, "(before bucket phase)");
   DG_HIP(hipMemsetAsync(b.giant, 0, 8, s));
-  if constexpr (FieldOf<F>::EXT) {
+  static const bool finalize4 = [] { const char* e = getenv("DG16_FINALIZE"); return e && atoi(e) == 4; }();
+  if (!finalize4) {
+    // one lane per bucket, inline products (msm_impl.h: a THROUGHPUT kernel -- 2^16 buckets x ~15 partials is a
+    // million full additions, not a latency chain)
+    msm_finalize_phase<F>(s, st, b);
+  } else if constexpr (FieldOf<F>::EXT) {
     constexpr int BLOCK = sizeof(XYZZ29<F>) * 256 <= 80 * 1024 ? 256 : 128;     // two workgroups per CU (160 KiB LDS)
     hipLaunchKernelGGL((msm_finalize4_lds_kernel<F, BLOCK>), dim3((unsigned)((b.nbw * 4 + BLOCK - 1) / BLOCK)), dim3(BLOCK),
                        0, s, g, st.counts, st.seg_off, b.seg_sum, b.buckets, b.giant, b.giant + 2, b.giant_cap);
