@@ -71,8 +71,8 @@ int dg16_pk_info_get(const dg16_pk* pk, dg16_pk_info* out) {
   if (!pk || !out) return DG16_ERR_BAD_ARG;
   memset(out, 0, sizeof(*out));
   const PkDev& d = pk->d;
-  out->n_ab = d.ab_hi - d.ab_lo + 2;
-  out->n_l = d.l_hi - d.l_lo + 1;
+  out->n_ab = d.ab_hi - d.ab_lo + 3;
+  out->n_l = out->n_ab;
   out->n_h = d.h_hi - d.h_lo;
   out->c_ab = d.c_ab;
   out->c_l = d.c_l;

@@ -26,19 +26,20 @@
 
 namespace dg16 {
 
-// Extra scalar slots that pair with the delta bases: ab[n_ab] = r, ab[n_ab + 1] = s, l[n_l] = -r*s.
+// Extra scalar slots that pair with the delta bases: sc[n] = r, sc[n + 1] = s, sc[n + 2] = -r*s (n = the shard's slice of
+// w[1..]).  A, B1, B and L all take THIS scalar vector: the key stores their bases index-aligned (L's has the identity
+// at the public-input positions) with the delta slots [d1,0,0] / [0,d1,0] / [0,d2,0] / [0,0,d1].
 template <class Fr>
-__global__ void prover_scalar_prep_kernel(const Fr* r_s, Fr* sc_ab, Fr* sc_l, size_t n_ab, size_t n_l, int mont,
-                                          int carries_delta) {
+__global__ void prover_scalar_prep_kernel(const Fr* r_s, Fr* sc, size_t n, int mont, int carries_delta) {
   // r_s[0] = r, r_s[1] = s in the same form as the witness (Montgomery iff mont).  Only the last
   // shard carries the delta pairs; the others multiply their delta slots by zero.
   Fr r = r_s[0], s = r_s[1];
   if (!carries_delta) { r = Fr::zero(); s = Fr::zero(); }
   Fr rm = mont ? r : r.to_mont(), sm = mont ? s : s.to_mont();
   Fr nrs = (rm * sm).neg();                 // Montgomery form of -(r*s)
-  sc_ab[n_ab] = r;
-  sc_ab[n_ab + 1] = s;
-  sc_l[n_l] = mont ? nrs : nrs.from_mont();
+  sc[n] = r;
+  sc[n + 1] = s;
+  sc[n + 2] = mont ? nrs : nrs.from_mont();
 }
 
 // k * p, k canonical NL-limb integer, one lane
@@ -150,7 +151,6 @@ static void msms_typed(dg16_ctx* ctx, Call& k0, Call& k1, Call& k2, const PkDev&
   using Fr = typename CT::Fr;
   const size_t nv = pk.num_vars, ni = pk.num_inputs, m = pk.m;
   const size_t n_ab = pk.ab_hi - pk.ab_lo;   // this shard's slice of w[1..]
-  const size_t n_l = pk.l_hi - pk.l_lo;      // ... of w[ni..]
   const size_t n_h = pk.h_hi - pk.h_lo;      // ... of h
   unsigned log_m = 0;
   while (((size_t)1 << log_m) < m) log_m++;
@@ -179,13 +179,11 @@ static void msms_typed(dg16_ctx* ctx, Call& k0, Call& k1, Call& k2, const PkDev&
   Jacobian<Fq2>* res_b2 = (Jacobian<Fq2>*)(res_dev + kRecG1 * g1j);
   const int first_shard = pk.shard == 0;
   DG_HIP(hipMemcpyAsync(r_s, r_s_host, 2 * sizeof(Fr), hipMemcpyHostToDevice, k0.s()));
-  // one scalar vector for A, B1 and B (w[1..] slice ++ [r, s]) and one for L (w[ni..] slice ++ [-rs])
-  Fr* sc_ab = (Fr*)ws(k0.c, 23, ((n_ab + 2) + (n_l + 1)) * sizeof(Fr));
-  Fr* sc_l = sc_ab + (n_ab + 2);
+  // ONE scalar vector for A, B1, B and L: w[1..] slice ++ [r, s, -rs]
+  Fr* sc_ab = (Fr*)ws(k0.c, 23, (n_ab + 3) * sizeof(Fr));
   DG_HIP(hipMemcpyAsync(sc_ab, w_dev + 1 + pk.ab_lo, n_ab * sizeof(Fr), hipMemcpyDeviceToDevice, k0.s()));
-  DG_HIP(hipMemcpyAsync(sc_l, w_dev + ni + pk.l_lo, n_l * sizeof(Fr), hipMemcpyDeviceToDevice, k0.s()));
-  hipLaunchKernelGGL(prover_scalar_prep_kernel<Fr>, dim3(1), dim3(1), 0, k0.s(), r_s, sc_ab, sc_l, n_ab, n_l,
-                     (int)mont, (int)(pk.shard + 1 == pk.nshards));
+  hipLaunchKernelGGL(prover_scalar_prep_kernel<Fr>, dim3(1), dim3(1), 0, k0.s(), r_s, sc_ab, n_ab, (int)mont,
+                     (int)(pk.shard + 1 == pk.nshards));
   DG_HIP(hipGetLastError());
   DG_HIP(hipEventRecord(ctx->pipe_ev[8], k0.s()));
   // Scheduling.  Every saturating kernel of a proof (digit sorts, bucket accumulations, NTTs) goes down ONE
@@ -198,8 +196,8 @@ static void msms_typed(dg16_ctx* ctx, Call& k0, Call& k1, Call& k2, const PkDev&
   const Affine<Fq>* fixed_g1 = (const Affine<Fq>*)pk.fixed;
   const Affine<Fq2>* fixed_g2 = (const Affine<Fq2>*)((const uint8_t*)pk.fixed + 4 * sizeof(Affine<Fq>));
 
-  // ONE digit sort for A, B1 and B (same scalars w[1..] ++ [r, s]); its buffers live in channel 1
-  MsmSort st_ab = msm_sort_on<Fr, CT::SCALAR_BITS>(main, k1.c, sc_ab, n_ab + 2, mont, true, pk.c_ab);
+  // ONE digit sort for A, B1, B and L (same scalars w[1..] ++ [r, s, -rs]); its buffers live in channel 1
+  MsmSort st_ab = msm_sort_on<Fr, CT::SCALAR_BITS>(main, k1.c, sc_ab, n_ab + 3, mont, true, pk.c_ab);
   MsmBuffers<Fq> buf_a = msm_buffers<Fq>(k0.c, st_ab.g);
   MsmBuffers<Fq> buf_b1 = msm_buffers<Fq>(k1.c, st_ab.g);
   MsmBuffers<Fq2> buf_b2 = msm_buffers<Fq2>(k2.c, st_ab.g);
@@ -267,7 +265,7 @@ static void msms_typed(dg16_ctx* ctx, Call& k0, Call& k1, Call& k2, const PkDev&
   hipLaunchKernelGGL((prover_stage1_g1_kernel<Fq, Fr>), dim3(1), dim3(64), 0, aux, rec, fixed_g1, r_s, (int)mont,
                      first_shard, 1);
   DG_HIP(hipEventRecord(ev[10], aux));
-  // h (the rest of it), the digit sorts of H and L
+  // h (the rest of it) and the digit sort of H
   const Fr* h_scalars = h_in;
   if (!h_given) {
     Fr* h_dev = (Fr*)ws(k0.c, 3, rows * sizeof(Fr));
@@ -281,17 +279,16 @@ static void msms_typed(dg16_ctx* ctx, Call& k0, Call& k1, Call& k2, const PkDev&
     h_scalars = dist ? h_dev : h_dev + pk.h_lo;
   }
   MsmSort st_h = msm_sort_on<Fr, CT::SCALAR_BITS>(main, k0.c, h_scalars, n_h, true, true, pk.c_h);
-  MsmSort st_l = msm_sort_on<Fr, CT::SCALAR_BITS>(main, k2.c, sc_l, n_l + 1, mont, true, pk.c_l);
   // H and L own their bucket buffers (288 GB of HBM: a few MB more beat waiting for A's / B1's reductions)
   MsmBuffers<Fq> buf_h = msm_buffers<Fq>(ctx->xws[0], st_h.g);
-  MsmBuffers<Fq> buf_l = msm_buffers<Fq>(ctx->xws[1], st_l.g);
+  MsmBuffers<Fq> buf_l = msm_buffers<Fq>(ctx->xws[1], st_ab.g);
   msm_accumulate_phase<Fq>(main, st_h, buf_h, pk.h_q);
   DG_HIP(hipEventRecord(ev[6], main));
-  msm_accumulate_phase<Fq>(main, st_l, buf_l, pk.l_q);
+  msm_accumulate_phase<Fq>(main, st_ab, buf_l, pk.l_q);
   // side (behind A's reduction and s*A): H's reduction hides behind L's accumulation; L's is the exposed tail
   DG_HIP(hipStreamWaitEvent(side, ev[6], 0));
   msm_bucket_phase<Fq>(side, st_h, buf_h, false, res_h);
-  msm_bucket_phase<Fq>(main, st_l, buf_l, false, res_l);
+  msm_bucket_phase<Fq>(main, st_ab, buf_l, false, res_l);
   DG_HIP(hipEventRecord(ev[7], side));
   DG_HIP(hipStreamWaitEvent(main, ev[7], 0));           // A, H results + s*A
   DG_HIP(hipStreamWaitEvent(main, ev[10], 0));          // B1 result + r*B1
@@ -382,7 +379,10 @@ static void pk_build(dg16_ctx* ctx, PkDev& d, const void* a_query, const void* b
     hi = n * (d.shard + 1) / d.nshards;
   };
   slice(nv - 1, d.ab_lo, d.ab_hi);
-  slice(nv - ni, d.l_lo, d.l_hi);
+  // L rides on the digit sort of A / B1 / B: its bases are index-aligned with w[1..] -- position i of the slice holds
+  // l_query[ab_lo + i - (ni - 1)], the identity where w[1 + ab_lo + i] is a public input (l_query has no such element)
+  d.l_lo = (d.ab_lo > ni - 1 ? d.ab_lo : ni - 1) - (ni - 1);
+  d.l_hi = (d.ab_hi > ni - 1 ? d.ab_hi : ni - 1) - (ni - 1);
   slice(m, d.h_lo, d.h_hi);
   if (d.h_cyclic) {
     DG_REQUIRE(!(d.nshards & (d.nshards - 1)) && (size_t)d.nshards * d.nshards <= m, DG16_ERR_BAD_ARG,
@@ -403,10 +403,10 @@ static void pk_build(dg16_ctx* ctx, PkDev& d, const void* a_query, const void* b
         if (*q) { hipFree(*q); *q = nullptr; }
     }
   } plain_guard{{&a_plain, &b1_plain, &b2_plain, &l_plain, &h_plain}};
-  DG_HIP(hipMalloc(&a_plain, (n_ab + 2) * p1));
-  DG_HIP(hipMalloc(&b1_plain, (n_ab + 2) * p1));
-  DG_HIP(hipMalloc(&b2_plain, (n_ab + 2) * p2));
-  DG_HIP(hipMalloc(&l_plain, (n_l + 1) * p1));
+  DG_HIP(hipMalloc(&a_plain, (n_ab + 3) * p1));
+  DG_HIP(hipMalloc(&b1_plain, (n_ab + 3) * p1));
+  DG_HIP(hipMalloc(&b2_plain, (n_ab + 3) * p2));
+  DG_HIP(hipMalloc(&l_plain, (n_ab + 3) * p1));
   DG_HIP(hipMalloc(&h_plain, (n_h ? n_h : 1) * p1));
   DG_HIP(hipMalloc(&d.fixed, 4 * p1 + 2 * p2));
   // fixed_host layout: alpha_g1, beta_g1, delta_g1 (G1 affine) | beta_g2, delta_g2 (G2 affine)
@@ -415,32 +415,35 @@ static void pk_build(dg16_ctx* ctx, PkDev& d, const void* a_query, const void* b
   const uint8_t* b1 = (const uint8_t*)b_g1_query;
   const uint8_t* b2 = (const uint8_t*)b_g2_query;
   uint8_t* fixed = (uint8_t*)d.fixed;
-  DG_HIP(hipMemset((uint8_t*)a_plain + n_ab * p1, 0, 2 * p1));
-  DG_HIP(hipMemset((uint8_t*)b1_plain + n_ab * p1, 0, 2 * p1));
-  DG_HIP(hipMemset((uint8_t*)b2_plain + n_ab * p2, 0, 2 * p2));
+  DG_HIP(hipMemset((uint8_t*)a_plain + n_ab * p1, 0, 3 * p1));
+  DG_HIP(hipMemset((uint8_t*)b1_plain + n_ab * p1, 0, 3 * p1));
+  DG_HIP(hipMemset((uint8_t*)b2_plain + n_ab * p2, 0, 3 * p2));
+  DG_HIP(hipMemset(l_plain, 0, (n_ab + 3) * p1));
   DG_HIP(hipMemcpy(a_plain, aq + (1 + d.ab_lo) * p1, n_ab * p1, kind));
   DG_HIP(hipMemcpy((uint8_t*)a_plain + n_ab * p1, fx + 2 * p1, p1, kind));                 // [delta_g1, 0]
   DG_HIP(hipMemcpy(b1_plain, b1 + (1 + d.ab_lo) * p1, n_ab * p1, kind));
   DG_HIP(hipMemcpy((uint8_t*)b1_plain + (n_ab + 1) * p1, fx + 2 * p1, p1, kind));          // [0, delta_g1]
   DG_HIP(hipMemcpy(b2_plain, b2 + (1 + d.ab_lo) * p2, n_ab * p2, kind));
   DG_HIP(hipMemcpy((uint8_t*)b2_plain + (n_ab + 1) * p2, fx + 3 * p1 + p2, p2, kind));     // [0, delta_g2]
-  DG_HIP(hipMemcpy(l_plain, (const uint8_t*)l_query + d.l_lo * p1, n_l * p1, kind));
-  DG_HIP(hipMemcpy((uint8_t*)l_plain + n_l * p1, fx + 2 * p1, p1, kind));
+  if (n_l)      // slice position of l_query[l_lo]: (ni - 1 + l_lo) - ab_lo
+    DG_HIP(hipMemcpy((uint8_t*)l_plain + (ni - 1 + d.l_lo - d.ab_lo) * p1, (const uint8_t*)l_query + d.l_lo * p1, n_l * p1,
+                     kind));
+  DG_HIP(hipMemcpy((uint8_t*)l_plain + (n_ab + 2) * p1, fx + 2 * p1, p1, kind));          // [0, 0, delta_g1]
   if (d.h_cyclic)   // h_query[shard + nshards * j]: the layout the sharded h-polynomial leaves its output in
     DG_HIP(hipMemcpy2D(h_plain, p1, (const uint8_t*)h_query + d.shard * p1, (size_t)d.nshards * p1, p1, n_h, kind));
   else if (n_h) DG_HIP(hipMemcpy(h_plain, (const uint8_t*)h_query + d.h_lo * p1, n_h * p1, kind));
   {
     using CTc = CurveTypes<CURVE>;
     auto nwin_of = [](unsigned c) { return (unsigned)((CTc::SCALAR_BITS + 1 + c - 1) / c); };
-    d.c_ab = msm_window_bits(n_ab + 2, true);
-    d.c_l = msm_window_bits(n_l + 1, true);
+    d.c_ab = msm_window_bits(n_ab + 3, true);
+    d.c_l = d.c_ab;
     d.c_h = msm_window_bits(n_h ? n_h : 1, true);
-    d.a_q = msm_build_table<Fq>(nullptr, a_plain, n_ab + 2, d.c_ab, nwin_of(d.c_ab));
-    d.b1_q = msm_build_table<Fq>(nullptr, b1_plain, n_ab + 2, d.c_ab, nwin_of(d.c_ab));
-    d.b2_q = msm_build_table<Fq2>(nullptr, b2_plain, n_ab + 2, d.c_ab, nwin_of(d.c_ab));
-    d.l_q = msm_build_table<Fq>(nullptr, l_plain, n_l + 1, d.c_l, nwin_of(d.c_l));
+    d.a_q = msm_build_table<Fq>(nullptr, a_plain, n_ab + 3, d.c_ab, nwin_of(d.c_ab));
+    d.b1_q = msm_build_table<Fq>(nullptr, b1_plain, n_ab + 3, d.c_ab, nwin_of(d.c_ab));
+    d.b2_q = msm_build_table<Fq2>(nullptr, b2_plain, n_ab + 3, d.c_ab, nwin_of(d.c_ab));
+    d.l_q = msm_build_table<Fq>(nullptr, l_plain, n_ab + 3, d.c_ab, nwin_of(d.c_ab));
     d.h_q = msm_build_table<Fq>(nullptr, h_plain, n_h, d.c_h, nwin_of(d.c_h));
-    d.table_bytes = (size_t)nwin_of(d.c_ab) * (n_ab + 2) * (2 * p1 + p2) + (size_t)nwin_of(d.c_l) * (n_l + 1) * p1 +
+    d.table_bytes = (size_t)nwin_of(d.c_ab) * (n_ab + 3) * (3 * p1 + p2) +
                     (size_t)nwin_of(d.c_h) * (n_h ? n_h : 1) * p1;
     DG_HIP(hipDeviceSynchronize());
   }

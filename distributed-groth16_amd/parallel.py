@@ -35,6 +35,14 @@ def shard_bounds(n, shard, n_shards):
     return n * shard // n_shards, n * (shard + 1) // n_shards
 
 
+def l_bounds(num_vars, num_inputs, shard, n_shards):
+    """Range of l_query owned by `shard`: L rides on the digit sort of A / B1 / B, so its range is the shard's range of
+    w[1..] minus the public-input positions (PkDev::l_lo / l_hi in csrc/prover_impl.h)."""
+    lo, hi = shard_bounds(num_vars - 1, shard, n_shards)
+    k = num_inputs - 1
+    return max(lo, k) - k, max(hi, k) - k
+
+
 def h_is_sharded(m, world):
     """The sharded h-polynomial needs a power-of-two rank count (2, 4, 8) and m >= world^2 -- the condition
     csrc/ntt.hip (h_poly_dist_stage_typed) and DG16_F_H_CYCLIC enforce."""

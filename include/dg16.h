@@ -189,8 +189,9 @@ typedef struct dg16_pk_info {
 int dg16_pk_info_get(const dg16_pk *pk, dg16_pk_info *out);
 
 /* Multi-GPU form: the key holds slice `shard` of `n_shards` of every MSM range (contiguous slices of
- * a_query[1..], b_g1_query[1..], b_g2_query[1..], l_query, h_query); the delta pairs ride on the last
- * shard.  Pass the FULL queries; only the slice is copied to the device. */
+ * a_query[1..], b_g1_query[1..], b_g2_query[1..]; the l_query elements of the same wires -- L shares the digit sort
+ * of A / B1 / B; a contiguous slice of h_query, or with DG16_F_H_CYCLIC the elements shard + n_shards * j); the
+ * delta pairs ride on the last shard.  Pass the FULL queries; only the slice is copied to the device. */
 int dg16_pk_create_shard(dg16_ctx *ctx, int curve, size_t num_vars, size_t num_inputs,
                          size_t domain_size, const void *a_query, const void *b_g1_query,
                          const void *b_g2_query, const void *h_query, const void *l_query,

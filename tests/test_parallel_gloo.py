@@ -33,12 +33,12 @@ class OracleEngine:
 
     def __init__(self, curve, pk, r1cs_dims, shard, n_shards, h_cyclic=False):
         from oracle import corc
-        from dg16_amd.parallel import shard_bounds
+        from dg16_amd.parallel import shard_bounds, l_bounds
         self.corc, self.curve, self.pk = corc, curve, pk
         self.nv, self.ni, self.m = r1cs_dims
         self.shard, self.n_shards, self.h_cyclic = shard, n_shards, h_cyclic
         self.ab = shard_bounds(self.nv - 1, shard, n_shards)
-        self.lb = shard_bounds(self.nv - self.ni, shard, n_shards)
+        self.lb = l_bounds(self.nv, self.ni, shard, n_shards)
         self.hb = shard_bounds(self.m, shard, n_shards)
         self.first = shard == 0
         self.last = shard + 1 == n_shards
@@ -195,7 +195,12 @@ def test_two_rank_gloo_proof_equals_single_prover(sharded_h):
 
 
 def test_shard_bounds_cover_range():
-    from dg16_amd.parallel import shard_bounds
+    from dg16_amd.parallel import shard_bounds, l_bounds
+    for nv, ni in ((20, 3), (1 << 20, 2), (9, 9), (10, 1)):
+        for world in (1, 2, 3, 8):
+            pieces = [l_bounds(nv, ni, k, world) for k in range(world)]
+            assert pieces[0][0] == 0 and pieces[-1][1] == nv - ni
+            assert all(pieces[i][1] == pieces[i + 1][0] for i in range(world - 1))
     for n in (0, 1, 7, 1048575):
         for world in (1, 2, 3, 8):
             pieces = [shard_bounds(n, k, world) for k in range(world)]
