@@ -58,6 +58,30 @@ __global__ void __launch_bounds__(64) points_decode_g2_kernel(const uint8_t* __r
   out[i] = p;
 }
 
+// ---- Vec<F> on the wire: ark-serialize compressed form = u64 length || canonical little-endian elements ----------
+template <class Fr>
+__global__ void __launch_bounds__(256) wire_fr_encode_kernel(const Fr* __restrict__ in, size_t n, uint32_t* __restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const Fr c = in[i].from_mont();
+#pragma unroll
+  for (int k = 0; k < Fr::NL; k++) out[i * Fr::NL + k] = c.l[k];
+}
+template <class Fr>
+__global__ void __launch_bounds__(256) wire_fr_decode_kernel(const uint32_t* __restrict__ in, size_t n, Fr* __restrict__ out,
+                                                              unsigned* err) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Fr c;
+#pragma unroll
+  for (int k = 0; k < Fr::NL; k++) c.l[k] = in[i * Fr::NL + k];
+  bool lt = false;                       // canonical: c < r
+  for (int k = Fr::NL - 1; k >= 0; k--)
+    if (c.l[k] != Fr::Params::P[k]) { lt = c.l[k] < Fr::Params::P[k]; break; }
+  if (!lt) { report(err, i, 2); c = Fr::zero(); }
+  out[i] = c.to_mont();
+}
+
 }  // namespace dg16
 
 using namespace dg16;
@@ -141,6 +165,83 @@ int dg16_points_decompress(dg16_ctx* ctx, int curve, int group, const void* in, 
     if (tag != ~0ull) {
       const unsigned code = (unsigned)(tag & 0xFF);
       g_codec_err = std::string(kCodecErr[code < 5 ? code : 0]) + " (point " + std::to_string((tag >> 8) - 1) + ")";
+      throw StatusError{DG16_ERR_BAD_ARG, g_codec_err};
+    }
+  });
+}
+
+size_t dg16_wire_fr_bytes(size_t n) { return 8 + 32 * n; }
+
+int dg16_wire_fr_encode(dg16_ctx* ctx, int curve, const void* mont, size_t n, void* out, unsigned flags, int channel) {
+  int rc = guard_channel(ctx, channel);
+  if (rc) return rc;
+  return guarded(ctx, [&] {
+    DG_REQUIRE(curve >= 0 && curve <= 2, DG16_ERR_BAD_CURVE, "unknown curve id");
+    DG_REQUIRE(out && (mont || n == 0), DG16_ERR_BAD_ARG, "null operand");
+    const bool dev = flags & DG16_F_DEVICE_PTRS;
+    Call k(ctx, channel);
+    const void* din = stage_in(k, 0, mont, n * 32, dev);
+    uint8_t* dout = dev ? (uint8_t*)out : (uint8_t*)ws(k.c, 1, 8 + n * 32);
+    const uint64_t len = n;
+    DG_HIP(hipMemcpyAsync(dout, &len, 8, hipMemcpyHostToDevice, k.s()));
+    DG_HIP(hipStreamSynchronize(k.s()));                     // `len` lives on this stack frame
+    if (n) {
+      const unsigned blocks = (unsigned)((n + 255) / 256);
+      uint32_t* body = (uint32_t*)(dout + 8);
+      switch (curve) {
+        case 0: hipLaunchKernelGGL(wire_fr_encode_kernel<bn254_fr>, dim3(blocks), dim3(256), 0, k.s(), (const bn254_fr*)din, n, body); break;
+        case 1: hipLaunchKernelGGL(wire_fr_encode_kernel<bls12_381_fr>, dim3(blocks), dim3(256), 0, k.s(), (const bls12_381_fr*)din, n, body); break;
+        default: hipLaunchKernelGGL(wire_fr_encode_kernel<bls12_377_fr>, dim3(blocks), dim3(256), 0, k.s(), (const bls12_377_fr*)din, n, body); break;
+      }
+      DG_HIP(hipGetLastError());
+    }
+    if (!dev) stage_out(k, out, dout, 8 + n * 32, false);
+    k.finish();
+    if (!dev) DG_HIP(hipStreamSynchronize(k.s()));
+  });
+}
+
+// Synchronous (the length prefix and the "< r" check decide the return value, like deserialize_compressed's Err).
+int dg16_wire_fr_decode(dg16_ctx* ctx, int curve, const void* in, size_t bytes, void* out_mont, size_t* n_out,
+                        unsigned flags, int channel) {
+  int rc = guard_channel(ctx, channel);
+  if (rc) return rc;
+  return guarded(ctx, [&] {
+    DG_REQUIRE(curve >= 0 && curve <= 2, DG16_ERR_BAD_CURVE, "unknown curve id");
+    DG_REQUIRE(in && n_out && bytes >= 8, DG16_ERR_BAD_ARG, "null operand or missing length prefix");
+    const bool dev = flags & DG16_F_DEVICE_PTRS;
+    Call k(ctx, channel);
+    const uint8_t* din = (const uint8_t*)stage_in(k, 0, in, bytes, dev);
+    uint64_t len = 0;
+    DG_HIP(hipMemcpyAsync(&len, din, 8, hipMemcpyDeviceToHost, k.s()));
+    DG_HIP(hipStreamSynchronize(k.s()));
+    if (len != (bytes - 8) / 32 || (bytes - 8) % 32) {
+      g_codec_err = "Vec<F>: length prefix does not match the payload";
+      throw StatusError{DG16_ERR_BAD_ARG, g_codec_err};
+    }
+    const size_t n = (size_t)len;
+    *n_out = n;
+    DG_REQUIRE(out_mont || n == 0, DG16_ERR_BAD_ARG, "null output");
+    void* dout = dev ? out_mont : ws(k.c, 1, n * 32);
+    unsigned long long* err = (unsigned long long*)ws(k.c, 2, 16);
+    DG_HIP(hipMemsetAsync(err, 0xFF, 8, k.s()));
+    if (n) {
+      const unsigned blocks = (unsigned)((n + 255) / 256);
+      const uint32_t* body = (const uint32_t*)(din + 8);
+      switch (curve) {
+        case 0: hipLaunchKernelGGL(wire_fr_decode_kernel<bn254_fr>, dim3(blocks), dim3(256), 0, k.s(), body, n, (bn254_fr*)dout, (unsigned*)err); break;
+        case 1: hipLaunchKernelGGL(wire_fr_decode_kernel<bls12_381_fr>, dim3(blocks), dim3(256), 0, k.s(), body, n, (bls12_381_fr*)dout, (unsigned*)err); break;
+        default: hipLaunchKernelGGL(wire_fr_decode_kernel<bls12_377_fr>, dim3(blocks), dim3(256), 0, k.s(), body, n, (bls12_377_fr*)dout, (unsigned*)err); break;
+      }
+      DG_HIP(hipGetLastError());
+    }
+    if (!dev) stage_out(k, out_mont, dout, n * 32, false);
+    unsigned long long tag = ~0ull;
+    DG_HIP(hipMemcpyAsync(&tag, err, 8, hipMemcpyDeviceToHost, k.s()));
+    k.finish();
+    DG_HIP(hipStreamSynchronize(k.s()));
+    if (tag != ~0ull) {
+      g_codec_err = "Vec<F>: element " + std::to_string((tag >> 8) - 1) + " is not reduced";
       throw StatusError{DG16_ERR_BAD_ARG, g_codec_err};
     }
   });

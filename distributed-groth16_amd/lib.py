@@ -162,6 +162,10 @@ def load():
     L.dg16_arkkey_layout.argtypes = [vp, sz, i, ctypes.POINTER(ArkKeyLayout)]
     L.dg16_points_compress.argtypes = [vp, i, i, vp, sz, vp, u, i]
     L.dg16_points_decompress.argtypes = [vp, i, i, vp, sz, i, vp, u, i]
+    L.dg16_wire_fr_bytes.argtypes = [sz]
+    L.dg16_wire_fr_bytes.restype = sz
+    L.dg16_wire_fr_encode.argtypes = [vp, i, vp, sz, vp, u, i]
+    L.dg16_wire_fr_decode.argtypes = [vp, i, vp, sz, vp, ctypes.POINTER(sz), u, i]
     L.dg16_rccl_unique_id.argtypes = [vp]
     L.dg16_rccl_create.argtypes = [vp, vp, u, u, ctypes.POINTER(vp)]
     L.dg16_rccl_comm.argtypes = [vp]
@@ -229,7 +233,7 @@ EXPORTED = ["dg16_ctx_create", "dg16_ctx_destroy", "dg16_last_error", "dg16_set_
             "dg16_rccl_unique_id", "dg16_rccl_create", "dg16_rccl_comm", "dg16_rccl_net", "dg16_rccl_destroy",
             "dg16_rccl_error", "dg16_bases_upload", "dg16_bases_free", "dg16_bases_info", "dg16_msm_resident",
             "dg16_d_msm_resident", "dg16_codec_error", "dg16_arkkey_layout", "dg16_points_compress",
-            "dg16_points_decompress",
+            "dg16_points_decompress", "dg16_wire_fr_bytes", "dg16_wire_fr_encode", "dg16_wire_fr_decode",
             "dg16_io_error", "dg16_r1cs_parse", "dg16_r1cs_header_get", "dg16_r1cs_matrix", "dg16_r1cs_wire_map",
             "dg16_r1cs_free", "dg16_zkey_parse", "dg16_zkey_header_get", "dg16_zkey_points", "dg16_zkey_matrix",
             "dg16_zkey_free", "dg16_serialize_error", "dg16_proof_compress", "dg16_proof_decompress",
@@ -428,6 +432,21 @@ class Context:
     def points_compress_dev(self, curve, group, in_ptr, n, out_ptr, channel=0):
         self._chk(self.L.dg16_points_compress(self.h, CURVES[curve], group, _ptr(in_ptr), n, _ptr(out_ptr),
                                               F_DEVICE_PTRS, channel))
+
+    def wire_fr_encode(self, curve, mont, channel=0):
+        """Montgomery Fr elements -> ark-serialize compressed Vec<F> bytes (u64 length || canonical elements)."""
+        mont = np.ascontiguousarray(mont, dtype=np.uint64).reshape(-1, 4)
+        out = np.zeros(self.L.dg16_wire_fr_bytes(mont.shape[0]), dtype=np.uint8)
+        self._chk(self.L.dg16_wire_fr_encode(self.h, CURVES[curve], _ptr(mont), mont.shape[0], _ptr(out), 0, channel))
+        return out.tobytes()
+
+    def wire_fr_decode(self, curve, raw, channel=0):
+        raw = np.frombuffer(bytes(raw), dtype=np.uint8)
+        out = np.zeros((max(raw.size - 8, 0) // 32, 4), dtype=np.uint64)
+        n = ctypes.c_size_t()
+        self._chk(self.L.dg16_wire_fr_decode(self.h, CURVES[curve], _ptr(raw), raw.size, _ptr(out), ctypes.byref(n), 0,
+                                             channel))
+        return out[:n.value]
 
     def gen_bases(self, curve, group, seed, n, channel=0):
         nl = FQ_LIMBS64[curve] * 2 * (2 if group == 2 else 1)

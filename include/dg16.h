@@ -443,6 +443,15 @@ int dg16_points_compress(dg16_ctx *ctx, int curve, int group, const void *affine
 int dg16_points_decompress(dg16_ctx *ctx, int curve, int group, const void *in, size_t n, int validate,
                            void *affine_out, unsigned flags, int channel);
 
+/* Vec<F> as MpcSerNet puts it on the wire (`out.serialize_compressed`, dist-primitives/src/channel/mod.rs:14,49):
+ * u64 little-endian length || canonical little-endian 32-byte elements.  Between GPUs of one node the payloads of
+ * dg16_net stay in the HBM form; these two convert at the edge to a party that speaks ark-serialize (group elements:
+ * dg16_points_compress above).  Decode checks the prefix against `bytes` and every element < r. */
+size_t dg16_wire_fr_bytes(size_t n);
+int dg16_wire_fr_encode(dg16_ctx *ctx, int curve, const void *mont, size_t n, void *out, unsigned flags, int channel);
+int dg16_wire_fr_decode(dg16_ctx *ctx, int curve, const void *in, size_t bytes, void *out_mont, size_t *n_out,
+                        unsigned flags, int channel);
+
 /* ---- Groth16 verification, BN254 (host side; no GPU involved: four pairings) --------------------------------
  *   dg16_groth16_verify  <- Groth16::<Bn254>::verify_proof   groth16/examples/sha256.rs:228-254, mpc-api verify
  * e(A, B) = e(alpha, beta) e(IC_0 + sum x_i IC_i, gamma) e(C, delta).  Points are affine x || y Montgomery limbs

@@ -159,3 +159,24 @@ def test_point_codec_round_trip_2e16():
         c.points_decompress_dev("bn254", group, comp.data_ptr(), n, back.data_ptr(), validate=(group == 2))
         c.sync(0)
         assert torch.equal(pts, back)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("curve", ["bn254", "bls12_377", "bls12_381"])
+def test_vec_fr_wire_form(curve):
+    """`Vec<F>::serialize_compressed` as MpcSerNet sends it (dist-primitives/src/channel/mod.rs:14,49): u64 length ||
+    canonical little-endian elements -- against the integers, both directions, plus the error cases."""
+    from oracle import corc
+    c = _ctx()
+    F = FR[curve]
+    rng = random.Random(8)
+    vals = [0, 1, F.p - 1] + [rng.randrange(F.p) for _ in range(61)]
+    mont = corc.ints_to_arr([F.to_mont(v) for v in vals], 4)
+    want = struct.pack("<Q", len(vals)) + b"".join(v.to_bytes(32, "little") for v in vals)
+    raw = c.wire_fr_encode(curve, mont)
+    assert raw == want
+    assert np.array_equal(c.wire_fr_decode(curve, raw), mont)
+    assert c.wire_fr_encode(curve, mont[:0]) == struct.pack("<Q", 0) and c.wire_fr_decode(curve, struct.pack("<Q", 0)).shape[0] == 0
+    for bad in (want[:-1], struct.pack("<Q", len(vals) + 1) + want[8:], want[:8] + F.p.to_bytes(32, "little") + want[40:]):
+        with pytest.raises(dg16_amd.Dg16Error):
+            c.wire_fr_decode(curve, bad)
