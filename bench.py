@@ -332,13 +332,22 @@ def main():
             raise SystemExit("--gpus %d needs torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: libdg16 has no CPU path")
+    # DG16_BENCH_SINGLE_DEVICE=1: every rank on cuda:0 with a gloo process group -- the N > 1 flow of this file on a
+    # one-GPU box (RCCL refuses two ranks on one device; use --transport torch or python with it).  A test hook: such a
+    # run measures nothing.
+    single_dev = os.environ.get("DG16_BENCH_SINGLE_DEVICE") == "1"
+    if single_dev:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if single_dev:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)
 
     import dg16_amd
     from dg16_amd.parallel import make_prover
@@ -379,7 +388,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if single_dev else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
