@@ -60,7 +60,8 @@ constexpr int kRecA = 0, kRecB1 = 1, kRecL = 2, kRecH = 3, kRecSA = 4, kRecRB1 =
 // (msm_impl.h: dbl_wave / add_wave), 0.8 ms instead of 2.5 ms on one lane.
 template <class Fq, class Fr>
 __global__ void __launch_bounds__(64) prover_stage1_g1_kernel(Jacobian<Fq>* rec, const Affine<Fq>* fixed_g1,
-                                                               const Fr* r_s, int mont, int first_shard, int which) {
+                                                               const Fr* r_s, int mont, int first_shard) {
+  const int which = (int)blockIdx.x;     // two workgroups of one wave: s*A' and r*B1' side by side
   __builtin_amdgcn_s_setprio(3);     // a serial chain on one wave: ahead of the accumulation waves it shares a SIMD with
   Fr r = r_s[0], s = r_s[1];
   if (mont) { r = r.from_mont(); s = s.from_mont(); }
@@ -253,17 +254,17 @@ static void msms_typed(dg16_ctx* ctx, Call& k0, Call& k1, Call& k2, const PkDev&
   DG_HIP(hipEventRecord(ev[0], main));
   msm_accumulate_phase<Fq>(main, st_ab, buf_b1, pk.b1_q);
   DG_HIP(hipEventRecord(ev[1], main));
-  // side: reduction of A, then the serial scalar multiple s*A' of this shard
+  // side: reduction of A; aux: reduction of B1, then BOTH serial scalar multiples s*A', r*B1' in one launch of two
+  // waves (a millisecond each).  They used to follow their reductions on their own streams -- and H's reduction,
+  // queued on `side` behind s*A', became the end of the critical path on short shards.
   DG_HIP(hipStreamWaitEvent(side, ev[0], 0));
   msm_bucket_phase<Fq>(side, st_ab, buf_a, false, res_a);
-  hipLaunchKernelGGL((prover_stage1_g1_kernel<Fq, Fr>), dim3(1), dim3(64), 0, side, rec, fixed_g1, r_s, (int)mont,
-                     first_shard, 0);
-  // aux: B1's reduction and r*B1' (own stream: with short shards -- many GPUs -- the latency-bound reductions
-  // would otherwise queue up behind one another on `side`)
+  DG_HIP(hipEventRecord(ev[12], side));
   DG_HIP(hipStreamWaitEvent(aux, ev[1], 0));
   msm_bucket_phase<Fq>(aux, st_ab, buf_b1, false, res_b1);
-  hipLaunchKernelGGL((prover_stage1_g1_kernel<Fq, Fr>), dim3(1), dim3(64), 0, aux, rec, fixed_g1, r_s, (int)mont,
-                     first_shard, 1);
+  DG_HIP(hipStreamWaitEvent(aux, ev[12], 0));
+  hipLaunchKernelGGL((prover_stage1_g1_kernel<Fq, Fr>), dim3(2), dim3(64), 0, aux, rec, fixed_g1, r_s, (int)mont,
+                     first_shard);
   DG_HIP(hipEventRecord(ev[10], aux));
   // h (the rest of it) and the digit sort of H
   const Fr* h_scalars = h_in;
@@ -285,13 +286,13 @@ static void msms_typed(dg16_ctx* ctx, Call& k0, Call& k1, Call& k2, const PkDev&
   msm_accumulate_phase<Fq>(main, st_h, buf_h, pk.h_q);
   DG_HIP(hipEventRecord(ev[6], main));
   msm_accumulate_phase<Fq>(main, st_ab, buf_l, pk.l_q);
-  // side (behind A's reduction and s*A): H's reduction hides behind L's accumulation; L's is the exposed tail
+  // side (behind A's reduction): H's reduction hides behind L's accumulation; L's is the exposed tail
   DG_HIP(hipStreamWaitEvent(side, ev[6], 0));
   msm_bucket_phase<Fq>(side, st_h, buf_h, false, res_h);
   msm_bucket_phase<Fq>(main, st_ab, buf_l, false, res_l);
   DG_HIP(hipEventRecord(ev[7], side));
-  DG_HIP(hipStreamWaitEvent(main, ev[7], 0));           // A, H results + s*A
-  DG_HIP(hipStreamWaitEvent(main, ev[10], 0));          // B1 result + r*B1
+  DG_HIP(hipStreamWaitEvent(main, ev[7], 0));           // A, H results
+  DG_HIP(hipStreamWaitEvent(main, ev[10], 0));          // B1 result, s*A, r*B1
   DG_HIP(hipStreamWaitEvent(main, ev[5], 0));           // B result
   DG_HIP(hipGetLastError());
 }
