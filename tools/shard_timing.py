@@ -75,11 +75,12 @@ for world in worlds:
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
+    host_ms = (time.perf_counter() - t0) / steps * 1e3      # time the host spends enqueuing one proof
     sync()
     ms = (time.perf_counter() - t0) / steps * 1e3
     out["x%d" % world] = round(ms, 3)
-    print("world %d: %.3f ms per proof on rank 0 (n_ab %d, n_h %d)%s" % (
-        world, ms, wl.pk.info()["n_ab"], wl.pk.info()["n_h"], "  comm errors: %s" % comm.errors if comm and comm.errors else ""),
+    print("world %d: %.3f ms per proof on rank 0, host enqueue %.3f ms (n_ab %d, n_h %d)%s" % (
+        world, ms, host_ms, wl.pk.info()["n_ab"], wl.pk.info()["n_h"], "  comm errors: %s" % comm.errors if comm and comm.errors else ""),
         flush=True)
     wl.pk.close()
     del wl
