@@ -43,6 +43,13 @@ int main(int argc, char **argv) {
   if (rc != DG16_OK) { printf("verify: status %d %s\n", rc, dg16_verify_error()); return 1; }
   printf("accepted=%d\n", ok);
   dg16_zkey_free(z);
+  /* the container walk of an arkworks key file is host code too: a truncated file is a status, not a crash */
+  {
+    unsigned char tiny[40] = {0};
+    dg16_arkkey_layout_t lay;
+    rc = dg16_arkkey_layout(tiny, sizeof tiny, 1, &lay);
+    printf("arkkey_layout=%d (%s)\n", rc, rc ? dg16_codec_error() : "ok");
+  }
   /* compute entry points need a GPU: without one the library reports it */
   dg16_ctx *ctx = NULL;
   rc = dg16_ctx_create(0, &ctx);

@@ -84,6 +84,7 @@ def test_plain_c_consumer_parses_a_zkey_and_verifies_a_proof(tmp_path):
                              capture_output=True, text=True, timeout=120)
         assert out.returncode == 0, out.stdout + out.stderr
         assert expect in out.stdout and "n_public=1" in out.stdout
+        assert "arkkey_layout=3 (key file truncated)" in out.stdout
         import torch
         if not torch.cuda.is_available():
             assert "ctx_create=0" not in out.stdout          # no GPU: a status, not a context
