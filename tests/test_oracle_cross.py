@@ -222,3 +222,21 @@ def test_groth16_trapdoor_and_mpc_equal_single_prover():
         assert G.verify_in_exponent(r1cs, F, td, sc, (a, b, c), w)
     # groth16/examples/sha256.rs: the 8-party proof equals the arkworks proof (r = s = 0)
     assert G.mpc_prove("bn254", pk, r1cs, w) == G.create_proof("bn254", pk, 0, 0, r1cs, w)
+
+
+@pytest.mark.parametrize("curve,m,n_ranks", [("bn254", 16, 2), ("bn254", 16, 4), ("bn254", 64, 8), ("bls12_381", 64, 4),
+                                             ("bls12_377", 32, 2)])
+def test_sharded_h_polynomial_restatement_equals_witness_map(curve, m, n_ranks):
+    """oracle/pyref/hdist.py (what csrc/ntt.hip does on N ranks: cyclic rows, M-point transforms, two all-to-alls with
+    the N-point cross-rank parts in between) against the single prover's witness_map (ark-circom qap.rs:64-91):
+    rank rho must end with h[rho + N j]."""
+    import random
+    from oracle.pyref import groth16 as G, hdist
+    from oracle.pyref.fields import FR
+    from oracle.pyref.poly import Domain
+    F = FR[curve]
+    rng = random.Random(m + n_ranks)
+    a, b, c = ([rng.randrange(F.p) for _ in range(m)] for _ in range(3))
+    ref = G.witness_map_from_abc(a, b, c, Domain(F, m))
+    got = hdist.h_poly_sharded(a, b, c, F, n_ranks)
+    assert all(got[r] == ref[r::n_ranks] for r in range(n_ranks))
