@@ -437,6 +437,43 @@ int dg16_qap_rows(dg16_ctx* ctx, int curve, size_t num_constraints, size_t num_i
 }
 
 
+int dg16_ntt_dist_stage(dg16_ctx* ctx, int curve, unsigned log_n, unsigned rank, unsigned n_ranks, int inverse,
+                        int stage, const void* in, void* out, unsigned flags, int channel) {
+  int rc = guard_channel(ctx, channel);
+  if (rc) return rc;
+  return guarded(ctx, [&] {
+    DG_REQUIRE(curve >= 0 && curve <= 2, DG16_ERR_BAD_CURVE, "unknown curve id");
+    DG_REQUIRE(flags & DG16_F_DEVICE_PTRS, DG16_ERR_BAD_ARG, "the sharded NTT works on device buffers");
+    DG_REQUIRE(in && out && (stage == 0 || stage == 1), DG16_ERR_BAD_ARG, "null operand or unknown stage");
+    Call k(ctx, channel);
+    k.begin_dominant();
+    ntt_dist_stage(k, curve, log_n, rank, n_ranks, inverse, stage, in, out);
+    k.end_dominant();
+    k.finish();
+  });
+}
+
+int dg16_ntt_dist(dg16_ctx* ctx, int curve, const dg16_comm* comm, const void* in, void* out, unsigned log_n,
+                  int inverse, unsigned flags, int channel) {
+  int rc = guard_channel(ctx, channel);
+  if (rc) return rc;
+  return guarded(ctx, [&] {
+    DG_REQUIRE(curve >= 0 && curve <= 2, DG16_ERR_BAD_CURVE, "unknown curve id");
+    DG_REQUIRE(flags & DG16_F_DEVICE_PTRS, DG16_ERR_BAD_ARG, "the sharded NTT works on device buffers");
+    DG_REQUIRE(in && out, DG16_ERR_BAD_ARG, "null operand");
+    Call k(ctx, channel);
+    k.begin_dominant();
+    if (!comm || comm->n_ranks(comm->self) == 1) {
+      if (in != out) DG_HIP(hipMemcpyAsync(out, in, (size_t)32 << log_n, hipMemcpyDeviceToDevice, k.s()));
+      ntt_launch(k, curve, out, log_n, inverse, nullptr);
+    } else {
+      ntt_dist_launch(k, curve, comm, in, out, log_n, inverse);
+    }
+    k.end_dominant();
+    k.finish();
+  });
+}
+
 int dg16_h_poly_dist_stage(dg16_ctx* ctx, int curve, unsigned log_m, unsigned rank, unsigned n_ranks, int stage,
                            const void* const* in, void* out, unsigned flags, int channel) {
   int rc = guard_channel(ctx, channel);

@@ -198,6 +198,10 @@ void h_poly_dist_stage(Call& k, int curve, unsigned log_m, unsigned rank, unsign
                        const void* const* in, void* out);
 void h_poly_dist_launch(Call& k, int curve, const dg16_comm* comm, const void* a, const void* b, const void* c,
                         unsigned log_m, void* out);
+void ntt_dist_stage(Call& k, int curve, unsigned log_n_total, unsigned rank, unsigned n_ranks, int inverse, int stage,
+                    const void* in, void* out);
+void ntt_dist_launch(Call& k, int curve, const dg16_comm* comm, const void* in, void* out, unsigned log_n_total,
+                     int inverse);
 void ntt_launch(Call& k, int curve, void* data, unsigned log_n, int inverse, const void* coset_host);
 void h_poly_launch(Call& k, int curve, const void* a, const void* b, const void* c, unsigned log_m,
                    void* out);

@@ -639,6 +639,39 @@ __global__ void __launch_bounds__(256) hdist_cross_kernel(const F* __restrict__ 
   for (int i = 0; i < N; i++) out[((size_t)i * 3 + v) * p.S + j] = x[i];
 }
 
+// ---- one transform over N ranks with ONE all-to-all (dg16_ntt_dist) ------------------------------------------------
+// X[M k1 + k2] = sum_i1 w_N^(i1 k1) w^(i1 k2) Y_i1[k2],  Y_i1 = the M-point transform of rank i1's cyclic elements
+// x[N j + i1].  After the exchange rank sigma holds Z[i1][j] = Y_i1[sigma S + j]; this kernel applies the twiddle and the
+// N-point transform over i1 (in registers) and writes out[k1 S + j] = X[M k1 + sigma S + j] (times 1 / N if inverse --
+// the local inverse transform has already scaled by 1 / M).
+template <class F, int LOGN>
+__global__ void __launch_bounds__(256) ntt_dist_cross_kernel(const F* __restrict__ in, F* __restrict__ out, const F* w_lo,
+                                                              const F* w_hi, unsigned wlb, const F* n_inv, unsigned rank,
+                                                              size_t S) {
+  constexpr int N = 1 << LOGN;
+  const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= S) return;
+  const size_t M = S << LOGN, k2 = (size_t)rank * S + j;
+  F x[N];
+#pragma unroll
+  for (int i = 0; i < N; i++) x[i] = in[(size_t)i * S + j];
+  {
+    const F base = tw_lookup(w_lo, w_hi, wlb, k2);
+    F pw = base;
+#pragma unroll
+    for (int i = 1; i < N; i++) {
+      x[i] = x[i] * pw;
+      if (i + 1 < N) pw = pw * base;
+    }
+  }
+  F roots[N / 2 ? N / 2 : 1];
+#pragma unroll
+  for (int t = 0; t < N / 2; t++) roots[t] = tw_lookup(w_lo, w_hi, wlb, M * t);
+  small_dft<LOGN>(x, roots);
+#pragma unroll
+  for (int i = 0; i < N; i++) out[(size_t)i * S + j] = n_inv ? x[i] * *n_inv : x[i];
+}
+
 static unsigned log2_exact(unsigned n) {
   unsigned l = 0;
   while ((1u << l) < n) l++;
@@ -689,6 +722,59 @@ static void h_poly_dist_stage_typed(Call& k, int curve, unsigned log_m, unsigned
     hipLaunchKernelGGL(mul_sub_kernel<F>, dim3((unsigned)blocks), dim3(256), 0, k.s(), v[0], v[1], v[2], (F*)out, M);
     DG_HIP(hipGetLastError());
   }
+}
+
+// stage 0: in (M cyclic elements) -> M-point (i)NTT -> out (natural order = peer-major pieces of S)
+// stage 1: in (received [peer][S]) -> cross kernel -> out[k1 S + j] = X[M k1 + rank S + j]
+template <class F>
+static void ntt_dist_stage_typed(Call& k, int curve, unsigned log_n_total, unsigned rank, unsigned n_ranks, int inverse,
+                                 int stage, const void* in, void* out) {
+  const unsigned log_n = log2_exact(n_ranks);
+  DG_REQUIRE(log_n >= 1 && log_n <= 3, DG16_ERR_UNSUPPORTED, "sharded NTT: 2, 4 or 8 ranks");
+  DG_REQUIRE(log_n_total >= 2 * log_n, DG16_ERR_BAD_ARG, "sharded NTT: domain smaller than ranks^2");
+  DG_REQUIRE(rank < n_ranks, DG16_ERR_BAD_ARG, "rank out of range");
+  const unsigned log_M = log_n_total - log_n;
+  const size_t M = (size_t)1 << log_M, S = M >> log_n;
+  if (stage == 0) {
+    F* tmp = (F*)ws(k.c, 8, M * sizeof(F));
+    const F* src[1] = {(const F*)in};
+    F* dst[1] = {(F*)out};
+    F* t[1] = {tmp};
+    ntt_run_batch<F>(k, curve, 1, src, dst, t, log_M, inverse, nullptr, nullptr, nullptr, nullptr, 0);
+  } else {
+    const TwiddleSet& w = get_twiddles<F>(k, curve, log_n_total, inverse);
+    const F* n_inv = inverse ? (const F*)get_twiddles<F>(k, curve, log_n, 1).n_inv : nullptr;
+    dim3 grid((unsigned)((S + 255) / 256));
+#define DG_NDX(L)                                                                                                   \
+  hipLaunchKernelGGL((ntt_dist_cross_kernel<F, L>), grid, dim3(256), 0, k.s(), (const F*)in, (F*)out, (const F*)w.lo, \
+                     (const F*)w.hi, w.lb, n_inv, rank, S)
+    switch (log_n) {
+      case 1: DG_NDX(1); break;
+      case 2: DG_NDX(2); break;
+      default: DG_NDX(3); break;
+    }
+#undef DG_NDX
+    DG_HIP(hipGetLastError());
+  }
+}
+void ntt_dist_stage(Call& k, int curve, unsigned log_n_total, unsigned rank, unsigned n_ranks, int inverse, int stage,
+                    const void* in, void* out) {
+  switch (curve) {
+    case 0: ntt_dist_stage_typed<bn254_fr>(k, curve, log_n_total, rank, n_ranks, inverse, stage, in, out); break;
+    case 1: ntt_dist_stage_typed<bls12_381_fr>(k, curve, log_n_total, rank, n_ranks, inverse, stage, in, out); break;
+    default: ntt_dist_stage_typed<bls12_377_fr>(k, curve, log_n_total, rank, n_ranks, inverse, stage, in, out); break;
+  }
+}
+void ntt_dist_launch(Call& k, int curve, const dg16_comm* comm, const void* in, void* out, unsigned log_n_total,
+                     int inverse) {
+  const unsigned n = comm->n_ranks(comm->self), rank = comm->rank(comm->self);
+  const size_t bytes = (((size_t)1 << log_n_total) / n) * 32;
+  void* buf_a = ws(k.c, 26, bytes);
+  void* buf_b = ws(k.c, 27, bytes);
+  ntt_dist_stage(k, curve, log_n_total, rank, n, inverse, 0, in, buf_a);
+  int rc = comm->all_to_all(comm->self, buf_a, buf_b, bytes / n, k.s());
+  DG_REQUIRE(rc == DG16_OK, DG16_ERR_NET, "all-to-all of the sharded NTT failed");
+  ntt_dist_stage(k, curve, log_n_total, rank, n, inverse, 1, buf_b, out);
 }
 
 void h_poly_dist_stage(Call& k, int curve, unsigned log_m, unsigned rank, unsigned n_ranks, int stage,

@@ -154,6 +154,8 @@ def load():
     L.dg16_qap.argtypes = [vp, i, sz, sz, sz, u, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, u, i]
     L.dg16_qap_rows.argtypes = [vp, i, sz, sz, sz, u, vp, vp, vp, vp, vp, vp, vp, sz, sz, vp, vp, vp, u, i]
     L.dg16_h_poly_dist.argtypes = [vp, i, vp, vp, vp, vp, u, vp, u, i]
+    L.dg16_ntt_dist.argtypes = [vp, i, vp, vp, vp, u, i, u, i]
+    L.dg16_ntt_dist_stage.argtypes = [vp, i, u, u, u, i, i, vp, vp, u, i]
     L.dg16_h_poly_dist_stage.argtypes = [vp, i, u, u, u, i, ctypes.POINTER(vp), vp, u, i]
     L.dg16_groth16_msms_h.argtypes = [vp, vp, vp, vp, vp, u, vp]
     L.dg16_groth16_prove_dist.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, u, vp]
@@ -229,7 +231,7 @@ EXPORTED = ["dg16_ctx_create", "dg16_ctx_destroy", "dg16_last_error", "dg16_set_
             "dg16_localnet_reset",
             "dg16_pss_create", "dg16_pss_destroy", "dg16_pss_apply", "dg16_pss_apply_exp", "dg16_d_fft",
             "dg16_d_msm", "dg16_deg_red", "dg16_d_pp", "dg16_ext_wit_h", "dg16_qap", "dg16_qap_rows",
-            "dg16_h_poly_dist", "dg16_h_poly_dist_stage", "dg16_groth16_msms_h", "dg16_groth16_prove_dist",
+            "dg16_h_poly_dist", "dg16_h_poly_dist_stage", "dg16_ntt_dist", "dg16_ntt_dist_stage", "dg16_groth16_msms_h", "dg16_groth16_prove_dist",
             "dg16_rccl_unique_id", "dg16_rccl_create", "dg16_rccl_comm", "dg16_rccl_net", "dg16_rccl_destroy",
             "dg16_rccl_error", "dg16_bases_upload", "dg16_bases_free", "dg16_bases_info", "dg16_msm_resident",
             "dg16_d_msm_resident", "dg16_codec_error", "dg16_arkkey_layout", "dg16_points_compress",
@@ -500,6 +502,14 @@ class Context:
         self._chk(self.L.dg16_h_poly_dist(self.h, CURVES[curve], comm.comm_ptr if comm is not None else None,
                                           _ptr(a_ptr), _ptr(b_ptr), _ptr(c_ptr), log_m, _ptr(out_ptr), F_DEVICE_PTRS,
                                           channel))
+
+    def ntt_dist_dev(self, curve, comm, in_ptr, out_ptr, log_n, inverse=False, channel=0):
+        self._chk(self.L.dg16_ntt_dist(self.h, CURVES[curve], comm.comm_ptr if comm is not None else None, _ptr(in_ptr),
+                                       _ptr(out_ptr), log_n, int(inverse), F_DEVICE_PTRS, channel))
+
+    def ntt_dist_stage_dev(self, curve, log_n, rank, n_ranks, inverse, stage, in_ptr, out_ptr, channel=0):
+        self._chk(self.L.dg16_ntt_dist_stage(self.h, CURVES[curve], log_n, rank, n_ranks, int(inverse), stage, _ptr(in_ptr),
+                                             _ptr(out_ptr), F_DEVICE_PTRS, channel))
 
     def h_poly_dist_stage_dev(self, curve, log_m, rank, n_ranks, stage, in_ptrs, out_ptr, channel=0):
         arr = (ctypes.c_void_p * 3)(*[int(x) for x in list(in_ptrs) + [0] * (3 - len(in_ptrs))])

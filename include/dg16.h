@@ -239,6 +239,19 @@ typedef struct dg16_comm {
   int (*all_to_all)(void *self, const void *send_dev, void *recv_dev, size_t bytes_per_peer, void *hip_stream);
 } dg16_comm;
 
+/* ONE 2^log_n-point transform over n_ranks GPUs (2, 4 or 8; 2^log_n >= n_ranks^2) with ONE all-to-all -- the "all-to-all
+ * of NTT butterflies": what d_fft / d_ifft (dist-primitives/src/dfft/mod.rs:17-95) do through the king (local levels,
+ * gather, remaining levels, scatter), as a four-step transform without a king.  in: this rank's CYCLIC elements
+ * x[n_ranks * j + rank], j < M = 2^log_n / n_ranks.  out (M elements, may not alias in): the transposed layout of a
+ * four-step FFT, out[k1 * S + j] = X[M * k1 + rank * S + j], S = M / n_ranks, k1 < n_ranks (rank sigma ends with slice
+ * sigma of every length-M block of the natural-order output).  inverse != 0: inverse root and the 1 / 2^log_n scale.
+ * dg16_ntt_dist_stage: the two local stages for callers that run the exchange themselves (stage 0: in -> send buffer,
+ * natural order = n_ranks pieces of S; stage 1: receive buffer -> out). */
+int dg16_ntt_dist(dg16_ctx *ctx, int curve, const dg16_comm *comm, const void *in, void *out, unsigned log_n,
+                  int inverse, unsigned flags, int channel);
+int dg16_ntt_dist_stage(dg16_ctx *ctx, int curve, unsigned log_n, unsigned rank, unsigned n_ranks, int inverse,
+                        int stage, const void *in, void *out, unsigned flags, int channel);
+
 /* h-polynomial over n_ranks GPUs (2, 4 or 8; 2^log_m >= n_ranks^2).  a, b, c: this rank's CYCLIC rows of the QAP
  * evaluation vectors, a[n_ranks * j + rank], j < 2^log_m / n_ranks (dg16_qap_rows); out: h[rank + n_ranks * j] --
  * the scalars of a DG16_F_H_CYCLIC key shard.  Two all-to-alls of 3 * 32 * 2^log_m / n_ranks bytes per rank.

@@ -87,3 +87,27 @@ def h_poly_sharded(a, b, c, F, n_ranks):
         R = all_to_all(U)
         W.append([[x for piece in R[r] for x in piece] for r in range(N)])
     return [stage2(W[0][r], W[1][r], W[2][r], F, m, N) for r in range(N)]
+
+
+# ---- one transform with one all-to-all (dg16_ntt_dist) ---------------------------------------------------------------
+def ntt_sharded(x, F, n_ranks, inverse=False):
+    """All ranks in one process.  Rank rho starts with x[N j + rho]; returns out[rho][k1 S + j] = X[M k1 + rho S + j]
+    (X = the m-point transform of x; inverse: inverse root and 1 / m), the layout csrc/ntt.hip: ntt_dist_stage leaves."""
+    p, m, N = F.p, len(x), n_ranks
+    M, S = m // N, m // N // N
+    dom_m, dom_M = Domain(F, m), Domain(F, M)
+    w = dom_m.group_gen_inv if inverse else dom_m.group_gen
+    Y = [(dom_M.ifft(x[r::N]) if inverse else dom_M.fft(x[r::N])) for r in range(N)]
+    Z = all_to_all([[Y[r][s * S:(s + 1) * S] for s in range(N)] for r in range(N)])
+    n_inv = F.inv(N) if inverse else 1
+    wN = pow(w, M, p)
+    out = []
+    for rho in range(N):
+        o = [0] * M
+        for j in range(S):
+            k2 = rho * S + j
+            t = [Z[rho][i1][j] * pow(w, i1 * k2, p) % p for i1 in range(N)]
+            for k1 in range(N):
+                o[k1 * S + j] = sum(t[i1] * pow(wN, i1 * k1, p) for i1 in range(N)) * n_inv % p
+        out.append(o)
+    return out

@@ -135,6 +135,49 @@ def test_sharded_h_prove_all_ranks_in_process_vs_oracle(curve, log_m, world):
         wl.pk.close()
 
 
+@pytest.mark.parametrize("curve,log_n,n_ranks,inverse", [("bn254", 4, 2, False), ("bn254", 6, 8, True), ("bn254", 12, 4, False),
+                                                         ("bls12_381", 13, 8, True), ("bls12_377", 10, 2, False),
+                                                         ("bn254", 20, 8, False), ("bn254", 20, 8, True)])
+def test_sharded_ntt_one_all_to_all_equals_oracle(curve, log_n, n_ranks, inverse):
+    """dg16_ntt_dist_stage: all ranks in this process, the all-to-all as a tensor transpose; rank sigma must end with
+    out[k1 S + j] = X[M k1 + sigma S + j] of the oracle's (i)NTT -- the transposed layout of a four-step transform."""
+    m = 1 << log_n
+    M, S = m // n_ranks, m // n_ranks // n_ranks
+    x = corc.rand_field(curve, "fr", 17 + log_n, m)
+    X = corc.ntt(curve, x, inverse=inverse)
+    c = ctx()
+    send = []
+    for r in range(n_ranks):
+        src = dev_t(x[r::n_ranks])
+        dst = torch.empty(M * 4, dtype=torch.int64, device=DEV)
+        c.ntt_dist_stage_dev(curve, log_n, r, n_ranks, inverse, 0, src.data_ptr(), dst.data_ptr())
+        c.sync(0)
+        send.append(dst)
+    recv = all_to_all(send)
+    torch.cuda.synchronize()
+    for r in range(n_ranks):
+        out = torch.empty(M * 4, dtype=torch.int64, device=DEV)
+        c.ntt_dist_stage_dev(curve, log_n, r, n_ranks, inverse, 1, recv[r].data_ptr(), out.data_ptr())
+        c.sync(0)
+        got = out.cpu().numpy().view(np.uint64).reshape(n_ranks, S, 4)
+        want = X.reshape(n_ranks, n_ranks, S, 4)[:, r]          # [k1][sigma][j] -> sigma = r
+        assert np.array_equal(got, want), "rank %d" % r
+
+
+def test_ntt_dist_through_rccl_world_one_is_the_plain_transform():
+    from dg16_amd import lib
+    c = ctx()
+    comm = lib.RcclComm(c, lib.rccl_unique_id(), 1, 0)
+    x = corc.rand_field("bn254", "fr", 5, 1 << 12)
+    src = dev_t(x)
+    dst = torch.empty_like(src)
+    for inverse in (False, True):
+        c.ntt_dist_dev("bn254", comm, src.data_ptr(), dst.data_ptr(), 12, inverse=inverse)
+        c.sync(0)
+        assert np.array_equal(dst.cpu().numpy().view(np.uint64).reshape(-1, 4), corc.ntt("bn254", x, inverse=inverse))
+    comm.close()
+
+
 def test_sharded_h_poly_argument_checks():
     import dg16_amd
     c = ctx()

@@ -240,3 +240,20 @@ def test_sharded_h_polynomial_restatement_equals_witness_map(curve, m, n_ranks):
     ref = G.witness_map_from_abc(a, b, c, Domain(F, m))
     got = hdist.h_poly_sharded(a, b, c, F, n_ranks)
     assert all(got[r] == ref[r::n_ranks] for r in range(n_ranks))
+
+
+@pytest.mark.parametrize("m,n_ranks,inverse", [(16, 2, False), (16, 4, True), (64, 8, False), (64, 4, True)])
+def test_sharded_ntt_restatement_equals_the_domain_transform(m, n_ranks, inverse):
+    """oracle/pyref/hdist.py: ntt_sharded (one all-to-all, transposed output) against Radix2EvaluationDomain fft / ifft."""
+    import random
+    from oracle.pyref import hdist
+    from oracle.pyref.fields import FR
+    from oracle.pyref.poly import Domain
+    F = FR["bn254"]
+    rng = random.Random(m * n_ranks)
+    x = [rng.randrange(F.p) for _ in range(m)]
+    X = Domain(F, m).ifft(x) if inverse else Domain(F, m).fft(x)
+    M, S = m // n_ranks, m // n_ranks // n_ranks
+    got = hdist.ntt_sharded(x, F, n_ranks, inverse)
+    for rho in range(n_ranks):
+        assert got[rho] == [X[M * k1 + rho * S + j] for k1 in range(n_ranks) for j in range(S)]
