@@ -206,3 +206,37 @@ def test_shard_bounds_cover_range():
             pieces = [shard_bounds(n, k, world) for k in range(world)]
             assert pieces[0][0] == 0 and pieces[-1][1] == n
             assert all(pieces[i][1] == pieces[i + 1][0] for i in range(world - 1))
+
+
+def test_make_prover_picks_the_driver_by_rank_count():
+    """Host logic of parallel.make_prover (no GPU: dummy context / key): one rank -> the plain prover; 2 / 4 / 8 ranks
+    with m >= N^2 -> the native pipeline over the chosen transport; other rank counts (or a domain smaller than N^2) ->
+    the Python-driven protocol with the replicated h-polynomial."""
+    from dg16_amd import parallel as P
+
+    class Ctx:
+        device = 0
+
+        @staticmethod
+        def results_bytes(curve):
+            return 768
+
+    class Pk:
+        def __init__(self, m):
+            self.domain_size = m
+
+    class Dist:
+        @staticmethod
+        def get_backend():
+            return "gloo"
+
+    assert P.h_is_sharded(1 << 20, 8) and P.h_is_sharded(64, 8) and not P.h_is_sharded(32, 8)
+    assert not P.h_is_sharded(1 << 20, 3) and not P.h_is_sharded(1 << 20, 16) and not P.h_is_sharded(1 << 20, 1)
+    one = P.make_prover(Ctx(), Pk(1 << 10), "bn254", None, 0, 1)
+    assert isinstance(one, P.NativeProver) and one.describe() == "single GPU"
+    three = P.make_prover(Ctx(), Pk(1 << 10), "bn254", Dist(), 1, 3, transport="rccl")
+    assert isinstance(three, P.DistributedProver) and not three.sharded_h
+    tiny = P.make_prover(Ctx(), Pk(32), "bn254", Dist(), 0, 8, transport="rccl")
+    assert isinstance(tiny, P.DistributedProver) and not tiny.sharded_h
+    py = P.make_prover(Ctx(), Pk(1 << 10), "bn254", Dist(), 0, 4, transport="python")
+    assert isinstance(py, P.DistributedProver) and py.sharded_h and "sharded h-polynomial" in py.describe()
