@@ -13,8 +13,6 @@ size_t affine_bytes(int curve, int group) { return 2 * fq_bytes(curve) * (group 
 static void check_curve_group(int curve, int group) {
   DG_REQUIRE(curve >= 0 && curve <= 2, DG16_ERR_BAD_CURVE, "unknown curve id");
   DG_REQUIRE(group == 1 || group == 2, DG16_ERR_BAD_ARG, "group must be 1 (G1) or 2 (G2)");
-  DG_REQUIRE(!(curve == DG16_BLS12_377 && group == 2), DG16_ERR_UNSUPPORTED,
-             "BLS12-377 G2 is not on the reference's path (only G1/Fr are used there)");
 }
 }  // namespace dg16
 

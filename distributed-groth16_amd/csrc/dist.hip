@@ -306,7 +306,7 @@ namespace dg16 {
   void d_msm_##name(Call&, const dg16_pss*, const dg16_net*, int, const void*, const void*, size_t, bool, void*,   \
                     const void*, unsigned);                                                                       \
   void packexp_##name(Call&, const dg16_pss*, int, const void*, size_t, void*);
-DECL_G(bn254_g1) DECL_G(bn254_g2) DECL_G(bls12_381_g1) DECL_G(bls12_381_g2) DECL_G(bls12_377_g1)
+DECL_G(bn254_g1) DECL_G(bn254_g2) DECL_G(bls12_381_g1) DECL_G(bls12_381_g2) DECL_G(bls12_377_g1) DECL_G(bls12_377_g2)
 #define DISPATCH_G(fn, curve, group, ...)                                                        \
   switch ((curve) * 2 + (group) - 1) {                                                           \
     case 0: fn##_bn254_g1(__VA_ARGS__); break;                                                   \
@@ -314,7 +314,8 @@ DECL_G(bn254_g1) DECL_G(bn254_g2) DECL_G(bls12_381_g1) DECL_G(bls12_381_g2) DECL
     case 2: fn##_bls12_381_g1(__VA_ARGS__); break;                                               \
     case 3: fn##_bls12_381_g2(__VA_ARGS__); break;                                               \
     case 4: fn##_bls12_377_g1(__VA_ARGS__); break;                                               \
-    default: throw StatusError{DG16_ERR_UNSUPPORTED, "BLS12-377 G2 is not on the reference's path"}; \
+    case 5: fn##_bls12_377_g2(__VA_ARGS__); break;                                               \
+    default: throw StatusError{DG16_ERR_BAD_ARG, "unknown (curve, group)"};                      \
   }
 }  // namespace dg16
 

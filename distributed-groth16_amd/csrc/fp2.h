@@ -1,11 +1,25 @@
-// Quadratic extension Fq[u]/(u^2 + 1) (BN254 and BLS12-381 G2 coordinates; ark-bn254 /
-// ark-bls12-381 Fq2Config NONRESIDUE = -1).  Memory layout c0 || c1, each an Fp in Montgomery form,
+// Quadratic extension Fq[u]/(u^2 + BETA): BETA = 1 for BN254 and BLS12-381 (ark-bn254 / ark-bls12-381 Fq2Config
+// NONRESIDUE = -1), BETA = 5 for BLS12-377 (ark-bls12-377 Fq2Config NONRESIDUE = -5; the G2 of
+// groth16/examples/local_groth_bench.rs:141).  Memory layout c0 || c1, each an Fp in Montgomery form,
 // i.e. the arkworks `QuadExtField { c0, c1 }` the reference passes for E::G2Affine at
 // groth16/src/prove.rs:62-85.
 #pragma once
 #include "fp.h"
 
 namespace dg16 {
+
+// u^2 = -Fq2Beta<P>::value over the base field with parameters P (a small positive integer)
+struct bls12_377_fq_params;
+template <class P> struct Fq2Beta { static constexpr int value = 1; };
+template <> struct Fq2Beta<bls12_377_fq_params> { static constexpr int value = 5; };
+// BETA * a by additions (BETA is 1 or 5)
+template <class F>
+DG_HD F fq2_beta_mul(const F& a) {
+  constexpr int BETA = Fq2Beta<typename F::Params>::value;
+  static_assert(BETA == 1 || BETA == 5, "non-residue not wired");
+  if constexpr (BETA == 1) return a;
+  else return a.dbl().dbl() + a;
+}
 
 template <class F>
 struct Fp2 {
@@ -26,15 +40,17 @@ struct Fp2 {
     F v0 = F::mul_call(a.c0, b.c0);
     F v1 = F::mul_call(a.c1, b.c1);
     F s = F::mul_call(a.c0 + a.c1, b.c0 + b.c1);
-    return {v0 - v1, s - v0 - v1};
+    return {v0 - fq2_beta_mul(v1), s - v0 - v1};
   }
-  // complex squaring: 2 base multiplications
+  // complex squaring: 2 base multiplications.  (c0 + c1)(c0 - BETA c1) = c0^2 - BETA c1^2 - (BETA - 1) c0 c1
   DG_HD Fp2 sqr() const {
     F t = F::mul_call(c0, c1);
-    return {F::mul_call(c0 + c1, c0 - c1), t.dbl()};
+    F r0 = F::mul_call(c0 + c1, c0 - fq2_beta_mul(c1));
+    if constexpr (Fq2Beta<typename F::Params>::value != 1) r0 = r0 + fq2_beta_mul(t) - t;
+    return {r0, t.dbl()};
   }
   DG_HD Fp2 inv() const {
-    F n = (c0.sqr() + c1.sqr()).inv();
+    F n = (c0.sqr() + fq2_beta_mul(c1.sqr())).inv();
     return {c0 * n, (c1 * n).neg()};
   }
   DG_HD static Fp2 select(bool c, const Fp2& a, const Fp2& b) {

@@ -26,6 +26,7 @@
 // Plain C++ (no inline asm): the same header runs on the host in tests/host_arith.
 #pragma once
 #include "fp.h"
+#include "fp2.h"
 
 namespace dg16 {
 
@@ -265,6 +266,14 @@ DG_HD Fe<P, 2 * B, 2 * LU> dbl(const Fe<P, B, LU>& a) {
   Fe<P, 2 * B, 2 * LU> r;
 #pragma unroll
   for (int i = 0; i < RR<P>::N; i++) r.l[i] = a.l[i] << 1;
+  return r;
+}
+// K a for a small constant K (the non-residue of a quadratic extension): N independent multiplications by K
+template <int K, class P, int B, int LU>
+DG_HD Fe<P, K * B, K * LU> mul_small(const Fe<P, B, LU>& a) {
+  Fe<P, K * B, K * LU> r;
+#pragma unroll
+  for (int i = 0; i < RR<P>::N; i++) r.l[i] = a.l[i] * (uint32_t)K;
   return r;
 }
 // a - b + K with K = k p >= b whose limbs dominate b's: k = ceil(B2 / 64) + 1, s 2^W borrowed into every limb
@@ -613,7 +622,7 @@ DG_HD Fp<P> fe_to_fp(const Fe<P, B, LU>& a) {
 template <class P, int B, int LU>
 DG_HD void fe_store_packed(const Fe<P, B, LU>& a, uint32_t* w) { fe_to_words<P>(canon(a), w); }
 
-// ---- quadratic extension u^2 = -1 (BN254, BLS12-381 G2 coordinates) -------------------------------------------
+// ---- quadratic extension u^2 = -BETA (fp2.h: BETA = 1 for BN254 / BLS12-381, 5 for BLS12-377) -------------------
 template <class P, int B, int LU = 1>
 struct Fe2 {
   Fe<P, B, LU> c0, c1;
@@ -648,24 +657,40 @@ template <int BS, class P, int B, int LU>
 DG_HD Fe2<P, BS, 1> fit(const Fe2<P, B, LU>& a) { return {fit<BS>(a.c0), fit<BS>(a.c1)}; }
 template <class P, int B, int LU>
 DG_HD bool is_zero(const Fe2<P, B, LU>& a) { return is_zero(a.c0) && is_zero(a.c1); }
-// (a0 b0 - a1 b1) + (a0 b1 + a1 b0) u: two dual products, one reduction each; b.c1 is the component negated
-// (pass the tighter operand second)
+// (a0 b0 - BETA a1 b1) + (a0 b1 + a1 b0) u: two dual products, one reduction each; b.c1 is the component negated
+// (pass the tighter operand second), BETA rides on a.c1 (N small multiplications)
 template <class P, int B1, int L1, int B2, int L2>
 DG_HD auto operator*(const Fe2<P, B1, L1>& a, const Fe2<P, B2, L2>& b) {
+  constexpr int BETA = Fq2Beta<P>::value;
   const auto nb1 = neg(b.c1);
-  const auto c0 = mul_add(a.c0, b.c0, a.c1, nb1);
   const auto c1 = mul_add(a.c0, b.c1, a.c1, b.c0);
-  constexpr int BO = decltype(c0)::Bound > decltype(c1)::Bound ? decltype(c0)::Bound : decltype(c1)::Bound;
-  return Fe2<P, BO, 1>{c0.template as<BO, 1>(), c1.template as<BO, 1>()};
+  if constexpr (BETA == 1) {
+    const auto c0 = mul_add(a.c0, b.c0, a.c1, nb1);
+    constexpr int BO = decltype(c0)::Bound > decltype(c1)::Bound ? decltype(c0)::Bound : decltype(c1)::Bound;
+    return Fe2<P, BO, 1>{c0.template as<BO, 1>(), c1.template as<BO, 1>()};
+  } else {
+    const auto c0 = mul_add(a.c0, b.c0, mul_small<BETA>(norm(a.c1)), nb1);
+    constexpr int BO = decltype(c0)::Bound > decltype(c1)::Bound ? decltype(c0)::Bound : decltype(c1)::Bound;
+    return Fe2<P, BO, 1>{c0.template as<BO, 1>(), c1.template as<BO, 1>()};
+  }
 }
-// (a0 + a1)(a0 - a1) + 2 a0 a1 u
+// (a0 + a1)(a0 - BETA a1) + (BETA - 1) a0 a1  +  2 a0 a1 u   [= a0^2 - BETA a1^2 + 2 a0 a1 u]
 template <class P, int B, int LU>
 DG_HD auto sqr(const Fe2<P, B, LU>& a_) {
+  constexpr int BETA = Fq2Beta<P>::value;
   const auto a = norm(a_);
-  const auto c0 = (a.c0 + a.c1) * (a.c0 + neg(a.c1));
-  const auto c1 = dbl(a.c0) * a.c1;
-  constexpr int BO = decltype(c0)::Bound > decltype(c1)::Bound ? decltype(c0)::Bound : decltype(c1)::Bound;
-  return Fe2<P, BO, 1>{c0.template as<BO, 1>(), c1.template as<BO, 1>()};
+  if constexpr (BETA == 1) {
+    const auto c0 = (a.c0 + a.c1) * (a.c0 + neg(a.c1));
+    const auto c1 = dbl(a.c0) * a.c1;
+    constexpr int BO = decltype(c0)::Bound > decltype(c1)::Bound ? decltype(c0)::Bound : decltype(c1)::Bound;
+    return Fe2<P, BO, 1>{c0.template as<BO, 1>(), c1.template as<BO, 1>()};
+  } else {
+    const auto v = a.c0 * a.c1;
+    const auto c0 = norm((a.c0 + a.c1) * (a.c0 + neg(mul_small<BETA>(a.c1))) + mul_small<BETA - 1>(v));
+    const auto c1 = norm(dbl(v));
+    constexpr int BO = decltype(c0)::Bound > decltype(c1)::Bound ? decltype(c0)::Bound : decltype(c1)::Bound;
+    return Fe2<P, BO, 1>{c0.template as<BO, 1>(), c1.template as<BO, 1>()};
+  }
 }
 
 }  // namespace dg16

@@ -9,7 +9,7 @@ namespace dg16 {
   void to_affine_##name(Call&, const void*, void*, size_t);                                     \
   void* bases_table_##name(Call&, const void*, size_t, unsigned*, unsigned*);                   \
   void msm_resident_##name(Call&, const void*, size_t, unsigned, const void*, bool, bool, void*);
-DECL(bn254_g1) DECL(bn254_g2) DECL(bls12_381_g1) DECL(bls12_381_g2) DECL(bls12_377_g1)
+DECL(bn254_g1) DECL(bn254_g2) DECL(bls12_381_g1) DECL(bls12_381_g2) DECL(bls12_377_g1) DECL(bls12_377_g2)
 
 #define DISPATCH(fn, ...)                                                                       \
   switch (curve * 2 + group - 1) {                                                              \
@@ -18,7 +18,8 @@ DECL(bn254_g1) DECL(bn254_g2) DECL(bls12_381_g1) DECL(bls12_381_g2) DECL(bls12_3
     case 2: fn##_bls12_381_g1(__VA_ARGS__); break;                                              \
     case 3: fn##_bls12_381_g2(__VA_ARGS__); break;                                              \
     case 4: fn##_bls12_377_g1(__VA_ARGS__); break;                                              \
-    default: throw StatusError{DG16_ERR_UNSUPPORTED, "BLS12-377 G2 is not on the reference's path"}; \
+    case 5: fn##_bls12_377_g2(__VA_ARGS__); break;                                              \
+    default: throw StatusError{DG16_ERR_BAD_ARG, "unknown (curve, group)"};                     \
   }
 
 void msm_launch(Call& k, int curve, int group, const void* bases, const void* scalars, size_t n, bool mont,
@@ -39,7 +40,8 @@ void* bases_table_launch(Call& k, int curve, int group, const void* bases, size_
     case 2: t = bases_table_bls12_381_g1(k, bases, n, c, nwin); break;
     case 3: t = bases_table_bls12_381_g2(k, bases, n, c, nwin); break;
     case 4: t = bases_table_bls12_377_g1(k, bases, n, c, nwin); break;
-    default: throw StatusError{DG16_ERR_UNSUPPORTED, "BLS12-377 G2 is not on the reference's path"};
+    case 5: t = bases_table_bls12_377_g2(k, bases, n, c, nwin); break;
+    default: throw StatusError{DG16_ERR_BAD_ARG, "unknown (curve, group)"};
   }
   return t;
 }

@@ -695,7 +695,7 @@ __device__ __forceinline__ Fp2<F> slot_mul(const Fp2<F>& a, const Fp2<F>& b) {
   const F t = F::mul_call(x, y);
   const int base = (int)(__lane_id() & ~3u);
   const F t0 = lane_get(t, base), t1 = lane_get(t, base + 1), t2 = lane_get(t, base + 2);
-  return {t0 - t1, t2 - t0 - t1};
+  return {t0 - fq2_beta_mul(t1), t2 - t0 - t1};      // u^2 = -BETA (fp2.h)
 }
 // 2 * p with p (and the result) uniform across the wave                 (dbl-2008-s-1, a = 0)
 template <class F>

@@ -24,8 +24,8 @@ template <> struct CurveTypes<1> {
   static constexpr int SCALAR_BITS = 255;
 };
 template <> struct CurveTypes<2> {
-  using Fq = bls12_377_fq; using Fr = bls12_377_fr; using Fq2 = void;
-  using G1c = bls12_377_g1_consts; using G2c = void;
+  using Fq = bls12_377_fq; using Fr = bls12_377_fr; using Fq2 = Fp2<bls12_377_fq>;
+  using G1c = bls12_377_g1_consts; using G2c = bls12_377_g2_consts;
   static constexpr int SCALAR_BITS = 253;
 };
 

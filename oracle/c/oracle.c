@@ -58,14 +58,25 @@
 
 #define F2 bn254_fq2_
 #define FB bn254_fq_
+#define F2_BETA 1
 #include "fp2_tmpl.h"
 #undef F2
 #undef FB
+#undef F2_BETA
 #define F2 bls12_381_fq2_
 #define FB bls12_381_fq_
+#define F2_BETA 1
 #include "fp2_tmpl.h"
 #undef F2
 #undef FB
+#undef F2_BETA
+#define F2 bls12_377_fq2_
+#define FB bls12_377_fq_
+#define F2_BETA 5
+#include "fp2_tmpl.h"
+#undef F2
+#undef FB
+#undef F2_BETA
 
 /* ---- group instances ---------------------------------------------------------------------- */
 #define EC bn254_g1_
@@ -90,6 +101,11 @@
 #undef BF
 #define EC bls12_377_g1_
 #define BF bls12_377_fq_
+#include "ec_tmpl.h"
+#undef EC
+#undef BF
+#define EC bls12_377_g2_
+#define BF bls12_377_fq2_
 #include "ec_tmpl.h"
 #undef EC
 #undef BF
@@ -187,6 +203,7 @@ int orc_rand_field(int fid, uint64_t seed, size_t n, int mont, void *out) {
     case 2: { CALL(bls12_381_g1_, bls12_381_fq_, 0) } break;                        \
     case 3: { CALL(bls12_381_g2_, bls12_381_fq2_, 1) } break;                       \
     case 4: { CALL(bls12_377_g1_, bls12_377_fq_, 0) } break;                        \
+    case 5: { CALL(bls12_377_g2_, bls12_377_fq2_, 1) } break;                       \
     default: return ORC_BAD_ARG;                                                    \
     }
 
@@ -201,6 +218,11 @@ static void load_gen_bls12_381_g2(bls12_381_g2_aff_t *g) {
     memcpy(&g->x.c0, bls12_381_g2_GX_C0, 48); memcpy(&g->x.c1, bls12_381_g2_GX_C1, 48);
     memcpy(&g->y.c0, bls12_381_g2_GY_C0, 48); memcpy(&g->y.c1, bls12_381_g2_GY_C1, 48);
 }
+static void load_gen_bls12_377_g2(bls12_377_g2_aff_t *g) {
+    memcpy(&g->x.c0, bls12_377_g2_GX_C0, 48); memcpy(&g->x.c1, bls12_377_g2_GX_C1, 48);
+    memcpy(&g->y.c0, bls12_377_g2_GY_C0, 48); memcpy(&g->y.c1, bls12_377_g2_GY_C1, 48);
+}
+#define load_gen_bls12_377_g2_ load_gen_bls12_377_g2
 #define load_gen_bn254_g1_ load_gen_bn254_g1
 #define load_gen_bn254_g2_ load_gen_bn254_g2
 #define load_gen_bls12_381_g1_ load_gen_bls12_381_g1
@@ -257,6 +279,8 @@ int orc_on_curve(int curve, int group, const void *p) {
     case 3: { bls12_381_fq2_t b; memcpy(&b.c0, bls12_381_g2_B_C0, 48); memcpy(&b.c1, bls12_381_g2_B_C1, 48);
               return bls12_381_g2_aff_on_curve((const bls12_381_g2_aff_t *)p, &b); }
     case 4: return bls12_377_g1_aff_on_curve((const bls12_377_g1_aff_t *)p, (const bls12_377_fq_t *)bls12_377_g1_B);
+    case 5: { bls12_377_fq2_t b; memcpy(&b.c0, bls12_377_g2_B_C0, 48); memcpy(&b.c1, bls12_377_g2_B_C1, 48);
+              return bls12_377_g2_aff_on_curve((const bls12_377_g2_aff_t *)p, &b); }
     }
     return -1;
 }
@@ -335,6 +359,7 @@ int orc_msm(int curve, int group, const void *bases, const void *scalars, size_t
     case 2: { DO_MSM(bls12_381_g1_, bls12_381_fq_, 0) } break;
     case 3: { DO_MSM(bls12_381_g2_, bls12_381_fq2_, 1) } break;
     case 4: { DO_MSM(bls12_377_g1_, bls12_377_fq_, 0) } break;
+    case 5: { DO_MSM(bls12_377_g2_, bls12_377_fq2_, 1) } break;
     default: free(sc); return ORC_BAD_ARG;
     }
     free(sc);

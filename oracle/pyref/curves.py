@@ -210,11 +210,23 @@ def _mk():
          0x0606C4A02EA734CC32ACD2B02BC28B99CB3E287E85A763AF267492AB572E99AB3F370D275CEC1DA1AAA9075FF05F79BE),
     )
     out["bls12_381", "g2"] = Curve("bls12_381_g2", f2, (4, 4), g2, FR["bls12_381"].p)
-    # ---------------- BLS12-377 (G1 only: the reference uses it for dmsm/dfft tests) -------
+    # ---------------- BLS12-377 (the reference's curve for its dmsm / dfft tests and local_groth_bench) -------
     q = FQ["bls12_377"].p
     g1 = (0x008848DEFE740A67C8FC6225BF87FF5485951E2CAA9D41BB188282C8BD37CB5CD5481512FFCD394EEAB9B16EB21BE9EF,
           0x01914A69C5102EFF1F674F5D30AFEEC4BD7FB348CA3E52D96D182AD44FB82305C2FE3D3634A9591AFD82DE55559C8EA6)
     out["bls12_377", "g1"] = Curve("bls12_377_g1", FqOps(q), 1, g1, FR["bls12_377"].p)
+    # G2 over Fq2 = Fq[u]/(u^2 + 5) (ark-bls12-377 Fq2Config::NONRESIDUE = -5), D-type twist y^2 = x^3 + 1/u
+    # (groth16/examples/local_groth_bench.rs:141 runs E::G2::msm on this curve).  Generator = ark-bls12-377's
+    # G2_GENERATOR_{X,Y}; on-curve / order r checked in tests/test_oracle_kats.py.
+    f2 = Fq2Ops(q, -5)
+    b2 = f2.inv((0, 1))
+    g2 = (
+        (233578398248691099356572568220835526895379068987715365179118596935057653620464273615301663571204657964920925606294,
+         140913150380207355837477652521042157274541796891053068589147167627541651775299824604154852141315666357241556069118),
+        (63160294768292073209381361943935198908131692476676907196754037919244929611450776219210369229519898517858833747423,
+         149157405641012693445398062341192467754805999074082136895788947234480009303640899064710353187729182149407503257491),
+    )
+    out["bls12_377", "g2"] = Curve("bls12_377_g2", f2, b2, g2, FR["bls12_377"].p)
     return out
 
 

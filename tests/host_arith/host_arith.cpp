@@ -73,6 +73,7 @@ extern "C" int ha_point_op(int curve, int group, int op, const void* a, const vo
     case 2: point_op<b381_fq>(op, (const Affine<b381_fq>*)a, (const Affine<b381_fq>*)b, (Affine<b381_fq>*)o, n); break;
     case 3: point_op<Fp2<b381_fq>>(op, (const Affine<Fp2<b381_fq>>*)a, (const Affine<Fp2<b381_fq>>*)b, (Affine<Fp2<b381_fq>>*)o, n); break;
     case 4: point_op<b377_fq>(op, (const Affine<b377_fq>*)a, (const Affine<b377_fq>*)b, (Affine<b377_fq>*)o, n); break;
+    case 5: point_op<Fp2<b377_fq>>(op, (const Affine<Fp2<b377_fq>>*)a, (const Affine<Fp2<b377_fq>>*)b, (Affine<Fp2<b377_fq>>*)o, n); break;
     default: return 1;
   }
   return 0;
@@ -176,6 +177,7 @@ extern "C" int ha_point_op29(int curve, int group, int op, const void* a, const 
     case 2: point_op29<b381_fq>(op, (const Affine<b381_fq>*)a, (const Affine<b381_fq>*)b, (Affine<b381_fq>*)o, n); break;
     case 3: point_op29<Fp2<b381_fq>>(op, (const Affine<Fp2<b381_fq>>*)a, (const Affine<Fp2<b381_fq>>*)b, (Affine<Fp2<b381_fq>>*)o, n); break;
     case 4: point_op29<b377_fq>(op, (const Affine<b377_fq>*)a, (const Affine<b377_fq>*)b, (Affine<b377_fq>*)o, n); break;
+    case 5: point_op29<Fp2<b377_fq>>(op, (const Affine<Fp2<b377_fq>>*)a, (const Affine<Fp2<b377_fq>>*)b, (Affine<Fp2<b377_fq>>*)o, n); break;
     default: return 1;
   }
   return 0;

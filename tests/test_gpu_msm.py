@@ -9,7 +9,7 @@ from gpu_util import ctx
 
 pytestmark = pytest.mark.gpu
 
-GROUPS = [("bn254", 1), ("bn254", 2), ("bls12_381", 1), ("bls12_381", 2), ("bls12_377", 1)]
+GROUPS = [("bn254", 1), ("bn254", 2), ("bls12_381", 1), ("bls12_381", 2), ("bls12_377", 1), ("bls12_377", 2)]
 
 
 def check(curve, group, bases, scalars, **kw):
@@ -92,6 +92,50 @@ def test_msm_reference_degenerate_shape():
     assert np.array_equal(got, corc.point_mul(curve, group, g, M))
 
 
+def _doubling_chain(curve, group, seed, n):
+    """local_dummy_crs (groth16/examples/local_groth_bench.rs:21-52): s[0] random, s[i] = 2 s[i-1]."""
+    out = np.empty((n, corc.point_limbs(curve, group)), dtype=np.uint64)
+    out[0] = corc.gen_points(curve, group, seed, 1)[0]
+    for i in range(1, n):
+        out[i] = corc.point_add(curve, group, out[i - 1:i], out[i - 1:i])[0]
+    return out
+
+
+def test_local_groth_bench_shape_bls12_377():
+    """groth16/examples/local_groth_bench.rs:83-158 on its own curve (E = Bls12_377) at its own size m = 2^15
+    (:153): iFFT(m) x 3, FFT(2m) x 3 (the vectors grow to the size of `constraint2`), h = p q - w, iFFT(2m), then the
+    FIVE MSMs -- E::G1::msm(s, a),
+    E::G2::msm(v, a) (:141, the only BLS12-377 G2 use of the reference), E::G1::msm(h, a), E::G1::msm(w, a),
+    E::G1::msm(u, h_eval) -- with a_share = vec![rand; n] (ONE value repeated) and doubling-chain bases."""
+    curve = "bls12_377"
+    log_m = 15
+    m = 1 << log_m
+    c = ctx()
+    p_eval = corc.field_op(curve, "fr", "to_mont", corc.ints_to_arr(list(range(m)), 4))
+    want = corc.ntt(curve, p_eval.copy(), inverse=True)
+    got = c.ntt(curve, p_eval.copy(), inverse=True)
+    assert np.array_equal(got, want)
+    wide = np.concatenate([want, np.zeros_like(want)])            # fft_in_place with the 2m domain resizes
+    want2 = corc.ntt(curve, wide.copy())
+    got2 = c.ntt(curve, wide.copy())
+    assert np.array_equal(got2, want2)
+    h_want = corc.field_op(curve, "fr", "sub", corc.field_op(curve, "fr", "mul", want2, want2), want2)
+    h_got = c.field_op(curve, "fr", "sub", c.field_op(curve, "fr", "mul", got2, got2), got2)
+    assert np.array_equal(h_got, h_want)
+    h_want = corc.ntt(curve, h_want, inverse=True)
+    h_got = c.ntt(curve, h_got, inverse=True)
+    assert np.array_equal(h_got, h_want)
+    a_share = np.repeat(corc.rand_field(curve, "fr", 8, 1, mont=True), m, axis=0)
+    crs = {"s": (1, m), "v": (2, m), "h": (1, m), "w": (1, m), "u": (1, 2 * m)}
+    shares = {}
+    for i, (name, (group, n)) in enumerate(crs.items()):
+        bases = _doubling_chain(curve, group, 40 + i, n)
+        sc = h_got if name == "u" else a_share
+        shares[name] = check(curve, group, bases, sc, scalars_mont=True)
+    pi_c = corc.point_add(curve, 1, corc.point_add(curve, 1, shares["h"], shares["w"]), shares["u"])
+    assert pi_c.any() and shares["v"].any()
+
+
 def test_msm_length_mismatch_and_affine_out():
     import dg16_amd
     curve, group = "bn254", 1
@@ -150,7 +194,8 @@ def test_msm_skewed_witness(kind, group):
 
 
 @pytest.mark.parametrize("curve,group,log_n", [("bn254", 1, 0), ("bn254", 1, 7), ("bn254", 1, 16), ("bn254", 2, 14),
-                                               ("bls12_381", 1, 15), ("bls12_381", 2, 12), ("bls12_377", 1, 13)])
+                                               ("bls12_381", 1, 15), ("bls12_381", 2, 12), ("bls12_377", 1, 13),
+                                               ("bls12_377", 2, 12)])
 def test_resident_msm_matches_oracle(curve, group, log_n):
     """dg16_bases_upload + dg16_msm_resident (window tables, one bucket set, no Horner tail) against the oracle and
     against dg16_msm, with fresh scalars per call, canonical and Montgomery scalars, identity bases inside."""

@@ -62,7 +62,7 @@ def test_field_ops(ha, curve, kind):
 
 
 @pytest.mark.parametrize("curve,group", [("bn254", 1), ("bn254", 2), ("bls12_381", 1),
-                                         ("bls12_381", 2), ("bls12_377", 1)])
+                                         ("bls12_381", 2), ("bls12_377", 1), ("bls12_377", 2)])
 @pytest.mark.parametrize("rr", [False, True])
 def test_point_ops(ha, curve, group, rr):
     """rr = True: the same operations through the reduced-radix types of fp29.h / ec29.h (the representation of the

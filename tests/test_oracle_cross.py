@@ -62,7 +62,7 @@ def test_field_ops_c_vs_python(curve, kind):
 
 
 @pytest.mark.parametrize("curve,group", [("bn254", 1), ("bn254", 2), ("bls12_381", 1),
-                                         ("bls12_381", 2), ("bls12_377", 1)])
+                                         ("bls12_381", 2), ("bls12_377", 1), ("bls12_377", 2)])
 def test_group_and_msm_c_vs_python(curve, group):
     C = CURVES[curve, "g%d" % group]
     r = FR[curve].p
