@@ -2,6 +2,7 @@
 // transport with an in-process LocalNet, and d_fft / d_ifft / d_msm / d_pp / deg_red / ext_wit::h with
 // the reference's names, argument meaning and error behaviour.
 #include <chrono>
+#include <thread>
 
 #include "dist_impl.h"
 
@@ -305,7 +306,9 @@ namespace dg16 {
 #define DECL_G(name)                                                                                         \
   void d_msm_##name(Call&, const dg16_pss*, const dg16_net*, int, const void*, const void*, size_t, bool, void*,   \
                     const void*, unsigned);                                                                       \
-  void packexp_##name(Call&, const dg16_pss*, int, const void*, size_t, void*);
+  void packexp_##name(Call&, const dg16_pss*, int, const void*, size_t, void*);                                   \
+  void mpc_combine_##name(Call&, const void*, const void*, unsigned, unsigned, bool, void*);                      \
+  void affine_to_jac_##name(Call&, const void*, void*);
 DECL_G(bn254_g1) DECL_G(bn254_g2) DECL_G(bls12_381_g1) DECL_G(bls12_381_g2) DECL_G(bls12_377_g1) DECL_G(bls12_377_g2)
 #define DISPATCH_G(fn, curve, group, ...)                                                        \
   switch ((curve) * 2 + (group) - 1) {                                                           \
@@ -614,6 +617,137 @@ int dg16_ext_wit_h(dg16_ctx* ctx, const dg16_pss* pp, const dg16_net* net, const
       net_check(net->scatter_from_king(net->self, 0, send, mbyl * sizeof(Fr), dout, k.s()));
       if (!dev) stage_out(k, out, dout, mbyl * sizeof(Fr), false);
     })
+    k.finish();
+    if (!dev) DG_HIP(hipStreamSynchronize(k.s()));
+  });
+}
+
+}  // extern "C"
+
+// ---- prove::A / B / C::compute (groth16/src/prove.rs:21-46, 62-85, 106-136) ------------------------------------------
+namespace dg16 {
+// one d_msm on `channel` (its stream, its workspace), Jacobian result at the device address `out_dev`
+static void d_msm_on_channel(dg16_ctx* ctx, const dg16_pss* pp, const dg16_net* net, int group, const void* bases,
+                             const void* scalars, size_t n_bases, size_t n_scalars, unsigned flags, int channel,
+                             void* out_dev) {
+  DG_REQUIRE(n_bases == n_scalars, DG16_ERR_LENGTH_MISMATCH,
+             "bases and scalars differ in length (VariableBaseMSM::msm returns Err(min_len))");
+  const bool dev = flags & DG16_F_DEVICE_PTRS;
+  const size_t pb = affine_bytes(pp->curve, group);
+  Call k(ctx, channel);
+  const void* dbases = stage_in(k, 0, bases, n_bases * pb, dev);
+  const void* dscal = stage_in(k, 1, scalars, n_bases * 32, dev);
+  DISPATCH_G(d_msm, pp->curve, group, k, pp, net, channel, dbases, dscal, n_bases, flags & DG16_F_SCALARS_MONT, out_dev,
+             nullptr, 0u)
+  k.finish();
+  DG_HIP(hipStreamSynchronize(k.s()));     // the caller combines on another channel's stream
+}
+// Term buffer of one compute call (channel-0 workspace slot 29): 8 Jacobian slots, then 8 scalars, then the result.
+struct MpcTerms {
+  uint8_t* base;
+  size_t jb;
+  void* term(unsigned i) const { return base + i * jb; }
+  void* scalar(unsigned i) const { return base + 8 * jb + i * 32; }
+  void* result() const { return base + 8 * jb + 8 * 32; }
+};
+static MpcTerms mpc_terms(Channel& c, int curve, int group) {
+  const size_t jb = affine_bytes(curve, group) / 2 * 3;
+  return MpcTerms{(uint8_t*)ws(c, 29 + (group - 1), 9 * jb + 8 * 32), jb};
+}
+// affine point handed over by the caller (host or device) -> Jacobian term slot
+static void put_affine_term(Call& k, int curve, int group, const void* pt, bool dev, int stage_slot, void* term) {
+  const void* d = stage_in(k, stage_slot, pt, affine_bytes(curve, group), dev);
+  DISPATCH_G(affine_to_jac, curve, group, k, d, term)
+}
+static void put_scalar(Call& k, const void* sc, bool dev, void* dst) {
+  DG_HIP(hipMemcpyAsync(dst, sc, 32, dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, k.s()));
+}
+// A = L + N * r + d_msm(S, a) in G1 (prove.rs:36-44)  /  B = Z + K * s + d_msm(V, a) in G2 (prove.rs:76-83)
+static void prove_ab(dg16_ctx* ctx, const dg16_pss* pp, const dg16_net* net, int group, const void* fixed0,
+                     const void* fixed1, const void* k1, const void* bases, const void* scalars, size_t n_bases,
+                     size_t n_scalars, unsigned flags, int channel, void* out) {
+  DG_REQUIRE(pp && net && fixed0 && fixed1 && k1 && out, DG16_ERR_BAD_ARG, "bad argument");
+  DG_REQUIRE(net->n_parties(net->self) == pp->n, DG16_ERR_BAD_ARG, "net.n_parties() != pp.n");
+  const bool dev = flags & DG16_F_DEVICE_PTRS;
+  MpcTerms t;
+  {
+    Call k(ctx, channel);
+    t = mpc_terms(k.c, pp->curve, group);
+  }
+  d_msm_on_channel(ctx, pp, net, group, bases, scalars, n_bases, n_scalars, flags, channel, t.term(2));
+  Call k(ctx, channel);
+  put_affine_term(k, pp->curve, group, fixed0, dev, 2, t.term(0));      // L / Z
+  put_affine_term(k, pp->curve, group, fixed1, dev, 3, t.term(1));      // N / K
+  put_scalar(k, k1, dev, t.scalar(1));                                  // r / s
+  DISPATCH_G(mpc_combine, pp->curve, group, k, t.term(0), t.scalar(0), 3u, 0x2u, flags & DG16_F_SCALARS_MONT, t.result())
+  stage_out(k, out, t.result(), t.jb, dev);
+  k.finish();
+  if (!dev) DG_HIP(hipStreamSynchronize(k.s()));
+}
+}  // namespace dg16
+
+extern "C" {
+
+int dg16_prove_a(dg16_ctx* ctx, const dg16_pss* pp, const dg16_net* net, const void* L, const void* N, const void* r,
+                 const void* S, const void* a, size_t n_S, size_t n_a, unsigned flags, int channel, void* out) {
+  int rc = guard_channel(ctx, channel);
+  if (rc) return rc;
+  return guarded(ctx, [&] { prove_ab(ctx, pp, net, 1, L, N, r, S, a, n_S, n_a, flags, channel, out); });
+}
+
+int dg16_prove_b(dg16_ctx* ctx, const dg16_pss* pp, const dg16_net* net, const void* Z, const void* K, const void* s,
+                 const void* V, const void* a, size_t n_V, size_t n_a, unsigned flags, int channel, void* out) {
+  int rc = guard_channel(ctx, channel);
+  if (rc) return rc;
+  return guarded(ctx, [&] { prove_ab(ctx, pp, net, 2, Z, K, s, V, a, n_V, n_a, flags, channel, out); });
+}
+
+// C = w + u + A * s + M * r + h * r with w = d_msm(W, ax), u = d_msm(U, h), h = d_msm(H, a) JOINED on channels 0 / 1 / 2
+// (prove.rs:113-125: three futures under tokio::try_join!): three host threads drive the three channels of this one
+// context at the same time -- each channel has its own stream, workspace and lock (ctx.h), and the transport keeps one
+// rendezvous slot per channel -- then channel 0 combines (prove.rs:127-134).
+int dg16_prove_c(dg16_ctx* ctx, const dg16_pss* pp, const dg16_net* net, const void* A, const void* M, const void* s,
+                 const void* r, const void* W, const void* ax, size_t n_W, size_t n_ax, const void* U, const void* h,
+                 size_t n_U, size_t n_h, const void* H, const void* a, size_t n_H, size_t n_a, unsigned flags,
+                 void* out) {
+  if (!ctx) return DG16_ERR_BAD_ARG;
+  return guarded(ctx, [&] {
+    DG_REQUIRE(pp && net && A && M && s && r && out, DG16_ERR_BAD_ARG, "bad argument");
+    DG_REQUIRE(net->n_parties(net->self) == pp->n, DG16_ERR_BAD_ARG, "net.n_parties() != pp.n");
+    const bool dev = flags & DG16_F_DEVICE_PTRS;
+    MpcTerms t;
+    {
+      Call k(ctx, 0);
+      t = mpc_terms(k.c, pp->curve, 1);
+    }
+    // terms: 0 w, 1 u, 2 A (* s), 3 M (* r), 4 h (* r)
+    struct Job { const void *bases, *scalars; size_t nb, ns; unsigned slot; } jobs[3] = {
+        {W, ax, n_W, n_ax, 0}, {U, h, n_U, n_h, 1}, {H, a, n_H, n_a, 4}};
+    StatusError errs[3] = {{DG16_OK, ""}, {DG16_OK, ""}, {DG16_OK, ""}};
+    std::thread th[3];
+    for (int c = 0; c < 3; c++)
+      th[c] = std::thread([&, c] {
+        try {
+          d_msm_on_channel(ctx, pp, net, 1, jobs[c].bases, jobs[c].scalars, jobs[c].nb, jobs[c].ns, flags, c,
+                           t.term(jobs[c].slot));
+        } catch (const StatusError& e) {
+          errs[c] = e;
+        } catch (const std::exception& e) {
+          errs[c] = StatusError{DG16_ERR_HIP, e.what()};
+        }
+      });
+    for (auto& x : th) x.join();
+    for (const auto& e : errs)
+      if (e.code != DG16_OK) throw e;
+    Call k(ctx, 0);
+    const size_t jb = t.jb;
+    DG_HIP(hipMemcpyAsync(t.term(2), A, jb, dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, k.s()));   // A: E::G1
+    put_affine_term(k, pp->curve, 1, M, dev, 2, t.term(3));
+    put_scalar(k, s, dev, t.scalar(2));
+    put_scalar(k, r, dev, t.scalar(3));
+    put_scalar(k, r, dev, t.scalar(4));
+    DISPATCH_G(mpc_combine, pp->curve, 1, k, t.term(0), t.scalar(0), 5u, 0x1Cu, flags & DG16_F_SCALARS_MONT, t.result())
+    stage_out(k, out, t.result(), jb, dev);
     k.finish();
     if (!dev) DG_HIP(hipStreamSynchronize(k.s()));
   });

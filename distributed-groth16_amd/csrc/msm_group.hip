@@ -79,6 +79,42 @@ void DG_FN(d_msm_)(Call& k, const dg16_pss* pp, const dg16_net* net, int sid, co
   hipLaunchKernelGGL(affine_to_jacobian_kernel<F>, dim3(1), dim3(1), 0, k.s(), got, (Jacobian<F>*)out_jac);
   DG_HIP(hipGetLastError());
 }
+// The clear-text group arithmetic around the d_msm calls of prove::A / B / C::compute (groth16/src/prove.rs:36-44,
+// 76-83, 127-134): out = sum_i (mask bit i ? k_i * P_i : P_i) over <= 8 Jacobian terms.  One workgroup, one WAVE per
+// term: the scalar multiples (N * r, K * s, A * s, M * r, h * r) are wave-cooperative double-and-add chains side by
+// side, then wave 0 adds the terms in the order they were given.
+template <class F, class Fr>
+__global__ void __launch_bounds__(512) mpc_combine_kernel(const Jacobian<F>* __restrict__ terms,
+                                                           const Fr* __restrict__ scalars, unsigned n_terms,
+                                                           unsigned mask, int mont, Jacobian<F>* __restrict__ out) {
+  __shared__ XYZZ<F> part[8];
+  const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  XYZZ<F> v = XYZZ<F>::from_jacobian(terms[wave]);
+  if ((mask >> wave) & 1) {
+    Fr kk = scalars[wave];
+    if (mont) kk = kk.from_mont();
+    v = scalar_mul_wave<F, Fr::NL>(v, kk.l);
+  }
+  if (lane == 0) part[wave] = v;
+  __syncthreads();
+  if (wave != 0) return;
+  XYZZ<F> acc = XYZZ<F>::inf();
+#pragma unroll 1
+  for (unsigned i = 0; i < n_terms; i++) acc = add_wave(acc, part[i]);
+  if (lane == 0) *out = acc.to_jacobian();
+}
+// terms: n_terms Jacobian points; scalars: n_terms Fr (only those under `mask` are read); all device pointers
+void DG_FN(mpc_combine_)(Call& k, const void* terms, const void* scalars, unsigned n_terms, unsigned mask, bool mont,
+                         void* out_jac) {
+  DG_REQUIRE(n_terms >= 1 && n_terms <= 8, DG16_ERR_BAD_ARG, "mpc_combine: 1..8 terms");
+  hipLaunchKernelGGL((mpc_combine_kernel<GF, CT::Fr>), dim3(1), dim3(64 * n_terms), 0, k.s(), (const Jacobian<GF>*)terms,
+                     (const CT::Fr*)scalars, n_terms, mask, (int)mont, (Jacobian<GF>*)out_jac);
+  DG_HIP(hipGetLastError());
+}
+void DG_FN(affine_to_jac_)(Call& k, const void* aff, void* jac) {
+  hipLaunchKernelGGL(affine_to_jacobian_kernel<GF>, dim3(1), dim3(1), 0, k.s(), (const Affine<GF>*)aff, (Jacobian<GF>*)jac);
+  DG_HIP(hipGetLastError());
+}
 // packexp_from_public / unpackexp (dmsm/mod.rs:7-68): the constant n x l matrices applied to group elements
 void DG_FN(packexp_)(Call& k, const dg16_pss* pp, int which, const void* in, size_t count, void* out) {
   using F = GF;

@@ -197,6 +197,9 @@ def load():
     L.dg16_deg_red.argtypes = [vp, vp, vp, vp, sz, vp, u, i]
     L.dg16_d_pp.argtypes = [vp, vp, vp, vp, vp, sz, vp, u, i]
     L.dg16_ext_wit_h.argtypes = [vp, vp, vp, vp, vp, vp, u, vp, u]
+    L.dg16_prove_a.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, sz, sz, u, i, vp]
+    L.dg16_prove_b.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, sz, sz, u, i, vp]
+    L.dg16_prove_c.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, sz, vp, vp, sz, sz, vp, vp, sz, sz, u, vp]
     # file-format readers (host side of the library)
     L.dg16_io_error.argtypes = []
     L.dg16_io_error.restype = ctypes.c_char_p
@@ -239,7 +242,7 @@ EXPORTED = ["dg16_ctx_create", "dg16_ctx_destroy", "dg16_last_error", "dg16_set_
             "dg16_io_error", "dg16_r1cs_parse", "dg16_r1cs_header_get", "dg16_r1cs_matrix", "dg16_r1cs_wire_map",
             "dg16_r1cs_free", "dg16_zkey_parse", "dg16_zkey_header_get", "dg16_zkey_points", "dg16_zkey_matrix",
             "dg16_zkey_free", "dg16_serialize_error", "dg16_proof_compress", "dg16_proof_decompress",
-            "dg16_verify_error", "dg16_groth16_verify"]
+            "dg16_verify_error", "dg16_groth16_verify", "dg16_prove_a", "dg16_prove_b", "dg16_prove_c"]
 
 
 def _ptr(x):

@@ -310,6 +310,7 @@ const char *dg16_rccl_error(void);
  *   dg16_deg_red           deg_red                                      dist-primitives/src/utils/deg_red.rs:10-28
  *   dg16_d_pp              d_pp                                         dist-primitives/src/dpp/mod.rs:17-88
  *   dg16_ext_wit_h         ext_wit::h                                   groth16/src/ext_wit.rs:16-101
+ *   dg16_prove_a / _b / _c prove::A / B / C::compute                    groth16/src/prove.rs:21-46, 62-85, 106-136
  *   dg16_net               MpcNet's provided gather / scatter           mpc-net/src/lib.rs:61-140
  *   dg16_localnet_*        LocalTestNet                                 mpc-net/src/multi.rs:227-329
  */
@@ -377,6 +378,25 @@ int dg16_d_pp(dg16_ctx *ctx, const dg16_pss *pp, const dg16_net *net, const void
  * Uses channel 0 (the reference multiplexes channels 0..2 for the three transforms). */
 int dg16_ext_wit_h(dg16_ctx *ctx, const dg16_pss *pp, const dg16_net *net, const void *a_share,
                    const void *b_share, const void *c_share, unsigned log_m, void *out, unsigned flags);
+/* prove::A::compute (groth16/src/prove.rs:21-46): out = L + N * r + d_msm(S, a) on `channel` (the reference's `sid`).
+ * L, N: G1 affine, in the clear (the identity (0, 0) is arkworks' default, as groth16/examples/sha256.rs:46-48 passes
+ * it); r: one scalar (Montgomery iff DG16_F_SCALARS_MONT, like a); S, a: this party's packed shares; out: G1
+ * Jacobian (E::G1), identical on all parties.  n_S != n_a is DG16_ERR_LENGTH_MISMATCH (the Err of G::msm). */
+int dg16_prove_a(dg16_ctx *ctx, const dg16_pss *pp, const dg16_net *net, const void *L, const void *N,
+                 const void *r, const void *S, const void *a, size_t n_S, size_t n_a, unsigned flags, int channel,
+                 void *out);
+/* prove::B::compute (prove.rs:62-85): out = Z + K * s + d_msm(V, a) in G2 (Z, K: G2 affine; out: G2 Jacobian). */
+int dg16_prove_b(dg16_ctx *ctx, const dg16_pss *pp, const dg16_net *net, const void *Z, const void *K,
+                 const void *s, const void *V, const void *a, size_t n_V, size_t n_a, unsigned flags, int channel,
+                 void *out);
+/* prove::C::compute (prove.rs:106-136): out = w + u + A * s + M * r + h * r with w = d_msm(W, ax), u = d_msm(U, h),
+ * h = d_msm(H, a) JOINED on channels 0 / 1 / 2 like the reference's tokio::try_join! (:113-125): the call drives the
+ * three channels of `ctx` from three host threads at once (every party must do the same, so the three collectives
+ * of a channel meet their peers).  A: G1 Jacobian (E::G1, the value A::compute returned); M: G1 affine. */
+int dg16_prove_c(dg16_ctx *ctx, const dg16_pss *pp, const dg16_net *net, const void *A, const void *M,
+                 const void *s, const void *r, const void *W, const void *ax, size_t n_W, size_t n_ax,
+                 const void *U, const void *h, size_t n_U, size_t n_h, const void *H, const void *a, size_t n_H,
+                 size_t n_a, unsigned flags, void *out);
 
 /* ---- circom `.r1cs` / snarkjs `.zkey` readers (host side of the library; no GPU involved) ----------------
  *   dg16_r1cs_parse   <- R1CSFile::new              ark-circom/src/circom/r1cs_reader.rs:54-249

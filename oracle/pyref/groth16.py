@@ -263,8 +263,38 @@ def pack_proving_key(curve_name, pk, pp):
     return [dict(s=s[i], u=u[i], w=w[i], h=h[i], v=v[i]) for i in range(pp.n)]
 
 
-def mpc_prove(curve_name, pk, r1cs, full_assignment, l=2):
-    """groth16/examples/sha256.rs:26-95,173-212 with r = s = 0 (as in the example)."""
+def prove_A(g1, L, N, r, S, a, pp):
+    """prove::A::compute, groth16/src/prove.rs:21-46, line by line (S, a: lists of per-party share vectors)."""
+    v0 = g1.mul(N, r)                        # :36  Calculate (N)^r
+    v1 = g1.add(L, v0)                       # :38  L.(N)^r
+    prod = dist.d_msm(g1, S, a, pp)[0]       # :41
+    return g1.add(v1, prod)                  # :43
+
+
+def prove_B(g2, Z, K, s, V, a, pp):
+    """prove::B::compute, prove.rs:62-85."""
+    v0 = g2.mul(K, s)                        # :76
+    v1 = g2.add(Z, v0)                       # :78
+    prod = dist.d_msm(g2, V, a, pp)[0]       # :80
+    return g2.add(v1, prod)                  # :82
+
+
+def prove_C(g1, A, M, s, r, W, U, H, a, ax, h, pp):
+    """prove::C::compute, prove.rs:106-136 (the three d_msm are joined on channels 0 / 1 / 2 there)."""
+    w = dist.d_msm(g1, W, ax, pp)[0]         # :119
+    u = dist.d_msm(g1, U, h, pp)[0]          # :121
+    hh = dist.d_msm(g1, H, a, pp)[0]         # :123
+    v0 = g1.mul(A, s)                        # :128  A^s
+    v1 = g1.mul(M, r)                        # :130  M^r
+    v2 = g1.mul(hh, r)                       # :132
+    return g1.add(g1.add(g1.add(g1.add(w, u), v0), v1), v2)   # :134
+
+
+def mpc_prove(curve_name, pk, r1cs, full_assignment, l=2, r=0, s=0, L=None, N=None, Z=None, K=None, M=None):
+    """groth16/examples/sha256.rs:26-95,173-212.  The example runs r = s = 0 with Default (identity) L, N, Z, K, M
+    and completes the proof afterwards (:208-212); with L = alpha_g1 + a_query[0], N = delta_g1,
+    Z = beta_g2 + b_g2_query[0], K = delta_g2, M = beta_g1 + b_g1_query[0] the SAME three compute calls give the
+    blinded single-prover proof for any r, s (C's r (M + d_msm(H, a)) is r B1 - r s delta_g1)."""
     F = FR[curve_name]
     g1, g2 = CURVES[curve_name, "g1"], CURVES[curve_name, "g2"]
     pp = PackedSharingParams(F, l)
@@ -276,13 +306,13 @@ def mpc_prove(curve_name, pk, r1cs, full_assignment, l=2):
     ax_shares = pack_from_witness(pp, w[ni:])
     a_shares = pack_from_witness(pp, w[1:])
     h_shares = ext_wit_h(qap_shares, dom, pp)
-    pi_a = dist.d_msm(g1, [k["s"] for k in crs], a_shares, pp)[0]                # prove.rs:41
-    pi_b = dist.d_msm(g2, [k["v"] for k in crs], a_shares, pp)[0]                # prove.rs:80
-    wv = dist.d_msm(g1, [k["w"] for k in crs], ax_shares, pp)[0]                 # prove.rs:119
-    uv = dist.d_msm(g1, [k["u"] for k in crs], h_shares, pp)[0]                  # prove.rs:121
-    pi_c = g1.add(wv, uv)                                                        # prove.rs:134 (r = s = 0)
-    pi_a = g1.add(pi_a, g1.add(pk["a_query"][0], pk["alpha_g1"]))                # sha256.rs:211
-    pi_b = g2.add(pi_b, g2.add(pk["b_g2_query"][0], pk["beta_g2"]))              # sha256.rs:212
+    col = lambda k: [x[k] for x in crs]      # noqa: E731
+    pi_a = prove_A(g1, L, N, r, col("s"), a_shares, pp)                                   # sha256.rs:45-57
+    pi_b = prove_B(g2, Z, K, s, col("v"), a_shares, pp)                                   # sha256.rs:59-71
+    pi_c = prove_C(g1, pi_a, M, s, r, col("w"), col("u"), col("h"), a_shares, ax_shares, h_shares, pp)   # :73-92
+    if r == 0 and s == 0 and L is None and Z is None:
+        pi_a = g1.add(pi_a, g1.add(pk["a_query"][0], pk["alpha_g1"]))                # sha256.rs:211
+        pi_b = g2.add(pi_b, g2.add(pk["b_g2_query"][0], pk["beta_g2"]))              # sha256.rs:212
     return pi_a, pi_b, pi_c
 
 

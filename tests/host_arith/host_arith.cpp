@@ -182,3 +182,32 @@ extern "C" int ha_point_op29(int curve, int group, int op, const void* a, const 
   }
   return 0;
 }
+
+// ---- the constants fp29.h derives at compile time, dumped for tests/test_constants_independent.py ------------------------
+template <class P> static size_t rr_dump(uint32_t* o, size_t cap) {
+  using T = RR<P>;
+  const size_t need = 4 + 5 * T::N + 2 * (T::NL + 1) + 1;
+  if (cap < need) return 0;
+  size_t k = 0;
+  o[k++] = T::W; o[k++] = T::N; o[k++] = T::SLACK; o[k++] = T::INV;
+  for (int i = 0; i < T::N; i++) o[k++] = T::PL.v[i];
+  for (int i = 0; i < T::N; i++) o[k++] = T::ONE.v[i];
+  for (int i = 0; i < T::N; i++) o[k++] = T::R2.v[i];
+  for (int i = 0; i < T::N; i++) o[k++] = T::FROM32.v[i];
+  for (int i = 0; i < T::N; i++) o[k++] = T::TO32.v[i];
+  for (int i = 0; i <= T::NL; i++) o[k++] = T::R_WORDS.v[i];
+  for (int i = 0; i <= T::NL; i++) o[k++] = T::R32SQ_OVER_R_WORDS.v[i];
+  o[k++] = T::PTOP;
+  return k;
+}
+extern "C" int ha_rr_consts(int fid, uint32_t* out, size_t cap) {
+  switch (fid) {
+    case 0: return (int)rr_dump<bn254_fq_params>(out, cap);
+    case 1: return (int)rr_dump<bls12_381_fq_params>(out, cap);
+    case 2: return (int)rr_dump<bls12_377_fq_params>(out, cap);
+    case 16: return (int)rr_dump<bn254_fr_params>(out, cap);
+    case 17: return (int)rr_dump<bls12_381_fr_params>(out, cap);
+    case 18: return (int)rr_dump<bls12_377_fr_params>(out, cap);
+    default: return 0;
+  }
+}

@@ -108,7 +108,7 @@ def test_d_fft_degree2_and_size_mismatch():
         D.d_fft(ctxs[0], pps[0], net.party(0), enc(F, prod[0]), 5, False, 1, False)
 
 
-@pytest.mark.parametrize("curve,group", [("bls12_377", 1), ("bn254", 1), ("bn254", 2)])
+@pytest.mark.parametrize("curve,group", [("bls12_377", 1), ("bls12_377", 2), ("bn254", 1), ("bn254", 2)])
 def test_d_msm_equals_clear_msm(curve, group):
     # dist-primitives/examples/dmsm_test.rs:62-64 and dmsm/mod.rs:147-193
     F, Fq = FR[curve], FQ[curve]
@@ -244,13 +244,60 @@ def test_mpc_prove_equals_single_prover():
     log_m = dom.size.bit_length() - 1
     res = net.simulate_network_round(
         lambda i, h: M.party_prove(ctxs[i], pps[i], h, crs[i], qs[i], a_sh[i], ax_sh[i], log_m))
-    pi_a, pi_b, (wv, uv) = res[0]
+    pi_a, pi_b, pi_c = res[0]
     g1, g2 = CURVES[curve, "g1"], CURVES[curve, "g2"]
     A = g1.add(dec_g1(Fq, corc.jac_to_affine(curve, 1, pi_a)), g1.add(pk["a_query"][0], pk["alpha_g1"]))
     B = g2.add(dec_g2(Fq, corc.jac_to_affine(curve, 2, pi_b)), g2.add(pk["b_g2_query"][0], pk["beta_g2"]))
-    C = g1.add(dec_g1(Fq, corc.jac_to_affine(curve, 1, wv)), dec_g1(Fq, corc.jac_to_affine(curve, 1, uv)))
+    C = dec_g1(Fq, corc.jac_to_affine(curve, 1, pi_c))
     assert (A, B, C) == G.create_proof(curve, pk, 0, 0, r1cs, w)
     assert all(np.array_equal(r[0], res[0][0]) for r in res)      # same point on every party
+
+    # prove::A / B / C::compute with every term live (prove.rs:21-136): r, s != 0, non-identity L, N, Z, K, M --
+    # against the line-by-line restatement (oracle/pyref/groth16.py: prove_A / prove_B / prove_C over d_msm)
+    r, sv = rng.randrange(1, F.p), rng.randrange(1, F.p)
+    pts = {k: (g2 if k in "ZK" else g1).mul((g2 if k in "ZK" else g1).gen, rng.randrange(1, F.p)) for k in "LNZKM"}
+    exp = G.mpc_prove(curve, pk, r1cs, w, r=r, s=sv, **pts)
+    kw = {k: (enc_g2 if k in "ZK" else enc_g1)(Fq, [v]) for k, v in pts.items()}
+    res = net.simulate_network_round(
+        lambda i, h: M.party_prove(ctxs[i], pps[i], h, crs[i], qs[i], a_sh[i], ax_sh[i], log_m,
+                                   r=enc(F, [r]), s=enc(F, [sv]), **kw))
+    got = (dec_g1(Fq, corc.jac_to_affine(curve, 1, res[0][0])), dec_g2(Fq, corc.jac_to_affine(curve, 2, res[0][1])),
+           dec_g1(Fq, corc.jac_to_affine(curve, 1, res[0][2])))
+    assert got == exp
+    assert all(all(np.array_equal(x, y) for x, y in zip(rr, res[0])) for rr in res)
+    # ... and with the clear points that make the same three calls the blinded single-prover proof
+    fixed = dict(L=g1.add(pk["alpha_g1"], pk["a_query"][0]), N=pk["delta_g1"],
+                 Z=g2.add(pk["beta_g2"], pk["b_g2_query"][0]), K=pk["delta_g2"],
+                 M=g1.add(pk["beta_g1"], pk["b_g1_query"][0]))
+    kw = {k: (enc_g2 if k in "ZK" else enc_g1)(Fq, [v]) for k, v in fixed.items()}
+    res = net.simulate_network_round(
+        lambda i, h: M.party_prove(ctxs[i], pps[i], h, crs[i], qs[i], a_sh[i], ax_sh[i], log_m,
+                                   r=enc(F, [r]), s=enc(F, [sv]), **kw))
+    got = (dec_g1(Fq, corc.jac_to_affine(curve, 1, res[0][0])), dec_g2(Fq, corc.jac_to_affine(curve, 2, res[0][1])),
+           dec_g1(Fq, corc.jac_to_affine(curve, 1, res[0][2])))
+    assert got == G.create_proof(curve, pk, r, sv, r1cs, w)
+
+
+def test_prove_compute_length_mismatch_is_an_error_on_every_party():
+    """G::msm's Err(len) inside a d_msm of C::compute (dmsm/mod.rs:82, prove.rs:119-125) must come back as
+    DG16_ERR_LENGTH_MISMATCH from the joined call, not hang the other two channels."""
+    import dg16_amd
+    from dg16_amd import groth16_mpc as M
+    curve = "bn254"
+    ctxs, pps, net, D = parties(curve)
+    n = 8
+    pts = corc.gen_points(curve, 1, 3, n)
+    sc = corc.rand_field(curve, "fr", 3, n)
+    Aj = np.zeros((1, 12), dtype=np.uint64)
+
+    def run(i, h):
+        with pytest.raises(dg16_amd.Dg16Error) as e:
+            M.C(Aj, None, sc[:1], sc[:1], pps[i], pts, pts, pts, sc, sc[:-1], sc).compute(ctxs[i], h)
+        return e.value.code
+
+    codes = net.simulate_network_round(run)
+    assert all(c in (1, 6) for c in codes) and 1 in codes      # LENGTH_MISMATCH where it arose; NET on peers it starved
+    net.L.dg16_localnet_reset(net.h, 60)
 
 
 # ---- the reference's own sizes (dist-primitives/examples/*.rs run m = 2^15, 8 parties, l = 2) ---------------------
@@ -356,13 +403,53 @@ def test_mpc_prove_reference_size():
     ax_sh = M.pack_from_witness(pps[0], w[2:])
     res = net.simulate_network_round(
         lambda i, h: M.party_prove(ctxs[i], pps[i], h, crs[i], qs[i], a_sh[i], ax_sh[i], 15))
-    pi_a, pi_b, (wv, uv) = res[0]
+    pi_a, pi_b, pi_c = res[0]
     f1 = host(wl.fixed[:192], 8)
     f2 = host(wl.fixed[192:], 16)
     add = lambda g, p, q: corc.point_add(curve, g, p, q)   # noqa: E731
-    A = add(1, corc.jac_to_affine(curve, 1, pi_a), add(1, hpk["a_query"][0:1], f1[0:1]))
-    B = add(2, corc.jac_to_affine(curve, 2, pi_b), add(2, hpk["b_g2_query"][0:1], f2[0:1]))
-    C = add(1, corc.jac_to_affine(curve, 1, wv), corc.jac_to_affine(curve, 1, uv))
+    aff = lambda g, j: corc.jac_to_affine(curve, g, j)     # noqa: E731
+    A = add(1, aff(1, pi_a), add(1, hpk["a_query"][0:1], f1[0:1]))
+    B = add(2, aff(2, pi_b), add(2, hpk["b_g2_query"][0:1], f2[0:1]))
+    C = aff(1, pi_c)
     (eA, eB, eC), _ = bench.oracle_prove(wl, bench.cpu_threads(), 0, 0)
     assert np.array_equal(A, eA) and np.array_equal(B, eB) and np.array_equal(C, eC)
+
+    # prove::A / B / C::compute as the reference defines them (prove.rs:21-46, 62-85, 106-136), every term live:
+    # random r, s != 0 and L = alpha_g1 + a_query[0], N = delta_g1, Z = beta_g2 + b_g2_query[0], K = delta_g2,
+    # M = beta_g1 + b_g1_query[0] -- the three native calls (C's three d_msm joined on channels 0 / 1 / 2 from three
+    # host threads per party: 8 parties x 3 channels in flight) must give the BLINDED single-prover proof
+    rng = random.Random(77)
+    F = FR[curve]
+    r, sv = rng.randrange(1, F.p), rng.randrange(1, F.p)
+    L = add(1, f1[0:1], hpk["a_query"][0:1])
+    N = f1[2:3]
+    Z = add(2, f2[0:1], hpk["b_g2_query"][0:1])
+    K = f2[1:2]
+    Mp = add(1, f1[1:2], hpk["b_g1_query"][0:1])
+    res = net.simulate_network_round(
+        lambda i, h: M.party_prove(ctxs[i], pps[i], h, crs[i], qs[i], a_sh[i], ax_sh[i], 15, r=enc(F, [r]),
+                                   s=enc(F, [sv]), L=L, N=N, Z=Z, K=K, M=Mp))
+    (eA, eB, eC), _ = bench.oracle_prove(wl, bench.cpu_threads(), r, sv)
+    assert np.array_equal(aff(1, res[0][0]), eA) and np.array_equal(aff(2, res[0][1]), eB)
+    assert np.array_equal(aff(1, res[0][2]), eC)
+    assert all(all(np.array_equal(x, y) for x, y in zip(rr, res[0])) for rr in res)
+
+    # ... and with unrelated non-identity L, N, Z, K, M: the formulas of the restatement (oracle/pyref/groth16.py:
+    # prove_A / prove_B / prove_C) evaluated with the C oracle, d_msm replaced by the clear MSM it equals
+    Lr, Nr, Mr = (corc.gen_points(curve, 1, 900 + i, 1) for i in range(3))
+    Zr, Kr = (corc.gen_points(curve, 2, 910 + i, 1) for i in range(2))
+    res = net.simulate_network_round(
+        lambda i, h: M.party_prove(ctxs[i], pps[i], h, crs[i], qs[i], a_sh[i], ax_sh[i], 15, r=enc(F, [r]),
+                                   s=enc(F, [sv]), L=Lr, N=Nr, Z=Zr, K=Kr, M=Mr))
+    mul = lambda g, p, k: corc.point_mul(curve, g, p, k)   # noqa: E731
+    msm = lambda g, b, sc: corc.msm(curve, g, b, sc, scalars_mont=True)   # noqa: E731
+    hv = corc.h_poly(curve, a.copy(), b.copy(), c.copy())
+    eA = add(1, add(1, Lr, mul(1, Nr, r)), msm(1, hpk["a_query"][1:], w[1:]))
+    eB = add(2, add(2, Zr, mul(2, Kr, sv)), msm(2, hpk["b_g2_query"][1:], w[1:]))
+    eC = add(1, msm(1, hpk["l_query"], w[2:]), msm(1, hpk["h_query"], hv))
+    eC = add(1, eC, mul(1, eA, sv))
+    eC = add(1, eC, mul(1, Mr, r))
+    eC = add(1, eC, mul(1, msm(1, hpk["b_g1_query"][1:], w[1:]), r))
+    assert np.array_equal(aff(1, res[0][0]), eA) and np.array_equal(aff(2, res[0][1]), eB)
+    assert np.array_equal(aff(1, res[0][2]), eC)
     wl.pk.close()

@@ -222,6 +222,25 @@ def test_groth16_trapdoor_and_mpc_equal_single_prover():
         assert G.verify_in_exponent(r1cs, F, td, sc, (a, b, c), w)
     # groth16/examples/sha256.rs: the 8-party proof equals the arkworks proof (r = s = 0)
     assert G.mpc_prove("bn254", pk, r1cs, w) == G.create_proof("bn254", pk, 0, 0, r1cs, w)
+    # prove::A / B / C::compute with every term live (prove.rs:21-136): r, s != 0 and the clear points that make the
+    # three compute calls the blinded single-prover proof
+    r, s = rng.randrange(1, F.p), rng.randrange(1, F.p)
+    fixed = dict(L=g1.add(pk["alpha_g1"], pk["a_query"][0]), N=pk["delta_g1"],
+                 Z=g2.add(pk["beta_g2"], pk["b_g2_query"][0]), K=pk["delta_g2"],
+                 M=g1.add(pk["beta_g1"], pk["b_g1_query"][0]))
+    assert G.mpc_prove("bn254", pk, r1cs, w, r=r, s=s, **fixed) == G.create_proof("bn254", pk, r, s, r1cs, w)
+    # ... and with unrelated points: the formulas themselves, d_msm replaced by the clear MSM it equals
+    pts = {k: (g2 if k in "ZK" else g1).mul((g2 if k in "ZK" else g1).gen, rng.randrange(1, F.p)) for k in "LNZKM"}
+    A, B, Cc = G.mpc_prove("bn254", pk, r1cs, w, r=r, s=s, **pts)
+    wv = [x % F.p for x in w]
+    h = G.witness_map_from_matrices(r1cs, w, F)
+    assert A == g1.add(g1.add(pts["L"], g1.mul(pts["N"], r)), g1.msm(pk["a_query"][1:], wv[1:]))
+    assert B == g2.add(g2.add(pts["Z"], g2.mul(pts["K"], s)), g2.msm(pk["b_g2_query"][1:], wv[1:]))
+    exp = g1.add(g1.msm(pk["l_query"], wv[2:]), g1.msm(pk["h_query"], h))
+    exp = g1.add(exp, g1.mul(A, s))
+    exp = g1.add(exp, g1.mul(pts["M"], r))
+    exp = g1.add(exp, g1.mul(g1.msm(pk["b_g1_query"][1:], wv[1:]), r))
+    assert Cc == exp
 
 
 @pytest.mark.parametrize("curve,m,n_ranks", [("bn254", 16, 2), ("bn254", 16, 4), ("bn254", 64, 8), ("bls12_381", 64, 4),
