@@ -3,7 +3,8 @@
 2^20-constraint synthetic R1CS, at 1/2/4/8 GPUs).
 
     python bench.py --gpus N --steps K --warmup W [--curve bn254|bls12_381] [--log-m 20]
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    (N > 1 without WORLD_SIZE in the environment re-executes itself under
+     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
 
 A step = one complete Groth16 proof FROM THE MATRICES, the scope of the reference's
 `create_proof_with_reduction_and_matrices` (groth16/examples/sha256.rs:159): R1CS x witness (dg16_qap:
@@ -47,6 +48,35 @@ FQ_BYTES = {"bn254": 32, "bls12_381": 48}
 SCALAR_BITS = {"bn254": 254, "bls12_381": 255}
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md
 MAD_ISSUE_T = 34.4                 # T lane-op/s of v_mad_u64_u32, chip-wide (profiles/r1_ubench_instr_rate.txt)
+
+
+def valu_constants(curve):
+    """(v_mad_u64_u32 per base-field product, measured chip-wide G products/s) of the reduced-radix product the bucket
+    kernels and the NTT run (csrc/fp29.h), from the committed micro-benchmark output -- measured constants live under
+    profiles/, not in the library's ABI.  profiles/r3_valu_constants.json = tools/ubench/fe_rate on an MI355X."""
+    path = os.path.join(ROOT, "profiles", "r3_valu_constants.json")
+    if os.path.exists(path):
+        with open(path) as f:
+            d = json.load(f)[curve + "_fq"]
+        return d["mads_per_product"], d["product_G_per_s"], "profiles/r3_valu_constants.json"
+    # round-2 figure (profiles/r2_ubench_montmul29_rate.txt: E rows, best of the occupancy sweep); BN254 only
+    return {"bn254": 162, "bls12_381": 392}[curve], {"bn254": 166.02, "bls12_381": 34.4e3 / 392}[curve], \
+        "profiles/r2_ubench_montmul29_rate.txt (bls12_381: mad issue bound, unmeasured)"
+
+
+def proof_products(curve, info, log_m, nc, nnz=3, world=1):
+    """Base-field product-equivalents one proof must perform with the shipped algorithms (squares counted as products):
+    one XYZZ mixed addition per bucket entry (G1: 8M + 2S = 10; G2 over Fq2: 8 x 3 + 2 x 2 = 28), six radix-2
+    transforms (one product per butterfly = log2(m) / 2 per element) + the three w_2m^i shifts + the pointwise
+    a b - c, and the sparse R1CS x witness products."""
+    bits = SCALAR_BITS[curve]
+    win = lambda c: (bits + 1 + c - 1) // c       # noqa: E731
+    m = 1 << log_m
+    g1 = 10.0 * (3 * info["n_ab"] * win(info["c_ab"]) + info["n_h"] * win(info["c_h"]))
+    g2 = 28.0 * info["n_ab"] * win(info["c_ab"])
+    ntt = m * (6 * log_m / 2.0 + 3 + 1) / world      # `info` describes this rank's key shard: its share of the rest
+    qap = 2.0 * nnz * nc / world
+    return {"g1_msm": g1, "g2_msm": g2, "ntt": ntt, "r1cs_x_witness": qap, "total": g1 + g2 + ntt + qap}
 
 
 def rand_fr(n, dev, gen, curve=CURVE):
@@ -305,6 +335,50 @@ def extras(ctx, dev, wl, curve, res):
         sha.pk.close()
         if not ok:
             raise SystemExit("sha256-shaped proof differs from the oracle's")
+        # BASELINE config 5's curve on one GPU at the headline size: BLS12-381, 2^20 - 2 constraints, timed, with the
+        # parity gate on THE TIMED instance (the 2^24 size of config 5 is `--curve bls12_381 --log-m 24`: 126 GB of
+        # window tables on one GPU, its 8-GPU form is the driver's to run)
+        res["config5_bls12_381_2e20"] = timed_prove_with_parity(ctx, dev, "bls12_381", 20, steps=5)
+
+
+def timed_prove_with_parity(ctx, dev, curve, log_m, steps):
+    wl5 = Workload(ctx, dev, log_m, 0, 1, seed=21, curve=curve)
+    prove_once(ctx, wl5)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        gp = prove_once(ctx, wl5)
+    dt = (time.perf_counter() - t0) / steps
+    (A, B, C), t_cpu = oracle_prove(wl5, cpu_threads())
+    gA, gB, gC = gpu_proof_affine(curve, gp)
+    ok = bool(np.array_equal(A, gA) and np.array_equal(B, gB) and np.array_equal(C, gC))
+    info = wl5.pk.info()
+    out = {"ms_per_proof": dt * 1e3, "constraints_per_s": wl5.nc / dt, "steps": steps, "cpu_port_s": t_cpu,
+           "cpu_port_cores": cpu_threads(), "parity_check": "pass (the timed instance)" if ok else "FAIL",
+           "key_table_bytes": info["table_bytes"], "key_table_build_s": wl5.pk_build_s,
+           "workload": "%s Groth16 prove from the matrices, 2^%d - 2 constraints, 2^%d wires, r, s != 0; each step "
+                       "includes the device-to-host copy of the proof" % (curve.upper(), log_m, log_m)}
+    wl5.pk.close()
+    del wl5
+    torch.cuda.empty_cache()
+    if not ok:
+        raise SystemExit("%s 2^%d proof differs from the oracle's" % (curve, log_m))
+    return out
+
+
+def self_launch(n):
+    """Re-executes this command line under torch.distributed.run with n ranks on this node (rendezvous on 127.0.0.1,
+    a free port) and returns its exit status.  The children see WORLD_SIZE and take the normal path."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL between processes needs it on this driver
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -318,18 +392,22 @@ def main():
                     help="log2 size of the CPU baseline / parity instance when the timed one is larger")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--no-replicas", action="store_true",
+                    help="N > 1: skip the secondary figure (N independent proofs, one whole key per GPU)")
     ap.add_argument("--transport", default="rccl", choices=["rccl", "torch", "python"],
                     help="N > 1: native RCCL communicator of libdg16 (default), torch.distributed under the native "
                          "pipeline, or the Python-driven protocol")
     args = ap.parse_args()
     curve = args.curve
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher of N ranks (one process per GPU) and relay their output
+        raise SystemExit(self_launch(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with --nproc-per-node %d" % (args.gpus, world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: libdg16 has no CPU path")
     # DG16_BENCH_SINGLE_DEVICE=1: every rank on cuda:0 with a gloo process group -- the N > 1 flow of this file on a
@@ -354,15 +432,9 @@ def main():
 
     ctx = dg16_amd.Context(local_rank)
     wl = Workload(ctx, dev, args.log_m, rank, world, curve=curve)
-    transport = args.transport
-    try:
-        prover = make_prover(ctx, wl.pk, curve, dist, rank, world, transport=transport)
-    except dg16_amd.Dg16Error as e:          # librccl could not be bound: say so and use torch.distributed
-        if world == 1 or transport != "rccl":
-            raise
-        print("bench: native RCCL transport unavailable (%s); using torch.distributed" % e, file=sys.stderr)
-        transport = "torch"
-        prover = make_prover(ctx, wl.pk, curve, dist, rank, world, transport=transport)
+    # N > 1, --transport rccl: if librccl cannot be bound or a rank cannot join, ALL ranks fall back to
+    # torch.distributed together (make_prover decides collectively); config.parallelism says which transport ran
+    prover = make_prover(ctx, wl.pk, curve, dist, rank, world, transport=args.transport)
 
     def step():
         wl.qap()
@@ -408,8 +480,11 @@ def main():
     # one XYZZ mixed addition (8M + 2S in Fq2 = 3 x 8 + 2 x 2 = 28 Fq multiplications) per nonzero digit
     montmuls = 28.0 * n_g2 * nwin
     valu_g = montmuls / (g2_acc_ms * 1e-3) / 1e9 if g2_acc_ms else 0.0
-    mul_cost = info["fq_mul_mads"]                   # v_mad_u64_u32 per Fq product of the shipped multiply
+    mul_cost, mul_rate_g, mul_src = valu_constants(curve)   # mads per Fq product of the bucket kernels, measured G/s
     mad_bound_g = MAD_ISSUE_T * 1e3 / mul_cost       # G products/s if only the multiplier issue slots counted
+    prods = proof_products(curve, info, args.log_m, wl.nc, world=world)
+    whole_g = prods["total"] / (ms_per_step * 1e-3) / 1e9     # per GPU: `prods` is this rank's share
+    g2_kernel = "msm_accumulate_lds_kernel<Fp2<%s_fq>>" % curve
 
     # HBM traffic of that kernel: PMC counters cannot be read from inside the process; the committed summary of
     # the separate rocprofv3 --pmc passes over the same launch (same curve, group, size) supplies it.
@@ -422,6 +497,10 @@ def main():
             traffic_src = "profiles/%s (2 x FETCH_SIZE + WRITE_SIZE, separate --pmc passes)" % name
             break
 
+    if valu_g > mul_rate_g * 1.0001 or whole_g > mul_rate_g:
+        raise SystemExit("valu_roofline: achieved %.1f / %.1f G products/s exceeds the measured peak %.1f: stale "
+                         "profiles/r3_valu_constants.json?" % (valu_g, whole_g, mul_rate_g))
+    rccl_ranks = prover.rccl_ranks() if hasattr(prover, "rccl_ranks") and world > 1 else None
     res = {
         "metric": "groth16_constraints_per_sec",
         "value": value,
@@ -441,25 +520,55 @@ def main():
                                "(built once per key outside the timed region)"
                                % (curve.upper(), args.log_m, args.log_m, args.log_m),
                    "curve": curve, "log_domain": args.log_m,
-                   "parallelism": prover.describe(),
+                   "parallelism": prover.describe(), "rccl_ranks": rccl_ranks,
                    "key_table_bytes": info["table_bytes"], "key_table_build_s": wl.pk_build_s,
                    "key_window_bits": {"ab": info["c_ab"], "l": info["c_l"], "h": info["c_h"]}},
-        "roofline": {"bound": "hbm", "kernel": info["g2_kernel"] + " (G2 bucket accumulation, table mode, inside the "
+        "roofline": {"bound": "hbm", "kernel": g2_kernel + " (G2 bucket accumulation, table mode, inside the "
                      "timed proofs)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                      "kernel_ms": g2_acc_ms, "points_per_launch": n_g2,
                      "note": "%d B/point algorithmic (each point and scalar once); Pippenger gathers every point once "
                              "per window, which is what the PMC traffic shows -- the kernel is integer-VALU-bound "
                              "(see valu_roofline)" % int(g2_alg)},
-        "valu_roofline": {"unit": "G montmul/s", "achieved": valu_g, "peak": info["fq_mul_rate_g"],
-                          "frac": valu_g / info["fq_mul_rate_g"], "mad_issue_bound": mad_bound_g,
-                          "frac_of_mad_issue_bound": valu_g / mad_bound_g,
-                          "note": "28 Fq multiplications per G2 mixed add x %d points x %d windows / kernel time; peak = "
-                                  "measured chip rate of the shipped multiply (tools/ubench); mad_issue_bound = %.1f T "
-                                  "v_mad_u64_u32 lane-op/s / %d mads per product" % (n_g2, nwin, MAD_ISSUE_T, mul_cost)},
+        "valu_roofline": {"unit": "G products/s", "achieved": valu_g, "peak": mul_rate_g,
+                          "frac": valu_g / mul_rate_g, "mad_issue_bound": mad_bound_g,
+                          "frac_of_mad_issue_bound": valu_g / mad_bound_g, "peak_source": mul_src,
+                          "whole_proof_products": prods, "whole_proof_achieved": whole_g,
+                          "whole_proof_valu_frac": whole_g / mul_rate_g,
+                          "note": "28 Fq products per G2 mixed add x %d points x %d windows / kernel time; peak = measured "
+                                  "chip rate of the reduced-radix product the kernels run (fp29.h: %d v_mad_u64_u32 each); "
+                                  "mad_issue_bound = %.1f T v_mad_u64_u32 lane-op/s / %d; whole_proof_* = every product a "
+                                  "proof must perform (per GPU) / ms_per_step against the same peak: the headroom of the "
+                                  "whole pipeline, not of one kernel" % (n_g2, nwin, mul_cost, MAD_ISSUE_T, mul_cost)},
         "g1_accumulate_ms": g1_acc_ms,
         "host": {"cpu_model": cpu_model(), "nproc": os.cpu_count()},
     }
+    if world > 1 and not args.no_replicas:
+        # Secondary figure, labelled as such: N INDEPENDENT proofs, one whole resident key and one whole proof per
+        # GPU, no exchange at all (what a proving service with many statements in flight would run).  Weak scaling.
+        rwl = Workload(ctx, dev, args.log_m, 0, 1, curve=curve, seed=20 + rank)
+        rprover = make_prover(ctx, rwl.pk, curve, None, 0, 1)
+
+        def rstep():
+            rwl.qap()
+            return rprover.prove(rwl.a, rwl.b, rwl.c, rwl.w, rwl.rs, scalars_mont=False)
+
+        for _ in range(max(1, args.warmup)):
+            rstep()
+        full_sync()
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            rstep()
+        full_sync()
+        dist.barrier()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cpu" if single_dev else dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        rel = float(t.item())
+        res["replicas"] = {"mode": "replicas: %d independent proofs in flight, one per GPU, no collective" % world,
+                           "value": world * rwl.nc * args.steps / rel, "unit": "constraints/s", "scaling": "weak",
+                           "ms_per_step": rel / args.steps * 1e3, "key_table_bytes_per_gpu": rwl.pk.info()["table_bytes"]}
+        rwl.pk.close()
     if rank == 0 and world == 1 and not args.no_extras:
         extras(ctx, dev, wl, curve, res)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -62,7 +62,10 @@ def read_proving_key(ctx, data, validate=False):
     return _read(ctx, data, False, validate)
 
 
-def read_verifying_key(ctx, data, validate=False):
+def read_verifying_key(ctx, data, validate=True):
+    """The reference deserialises a VerifyingKey with Validate::Yes (mpc-api/src/main.rs:207-210, :505; only the
+    ProvingKey takes Validate::No), hence the default.  Stricter than arkworks 0.4 in one corner: an infinity-flagged
+    encoding whose x bits are not zero is rejected here (ark-serialize accepts it as the identity)."""
     return _read(ctx, data, True, validate)
 
 

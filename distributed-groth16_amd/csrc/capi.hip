@@ -45,7 +45,11 @@ int dg16_ctx_create(int device, dg16_ctx** out) {
     // run on CUs they do not share with accumulation waves.  Pays on short shards (one process per GPU), where
     // those chains ARE the proof time; costs k/256 of the throughput kernels.
     const char* re = getenv("DG16_CU_RESERVE");
-    const int reserve = re ? atoi(re) : 0;
+    int reserve = re ? atoi(re) : 0;
+    if (reserve < 0) reserve = 0;                                           // (a negative value would index past the mask)
+    if (reserve > ctx->compute_units - 1) reserve = ctx->compute_units - 1;
+    // NB: a CU-masked stream (hipExtStreamCreateWithCUMask) is a BLOCKING stream of default priority: with masking
+    // on, channel 0 synchronises with the NULL stream.  The library itself issues nothing on the NULL stream.
     std::vector<uint32_t> mask((size_t)(ctx->compute_units + 31) / 32, 0u);
     for (int cu = 0; cu < ctx->compute_units - reserve; cu++) mask[cu / 32] |= 1u << (cu % 32);
     const bool masked = reserve > 0 && reserve < ctx->compute_units;

@@ -55,8 +55,11 @@ __global__ void __launch_bounds__(256) qap_kernel(const unsigned* __restrict__ a
   if (i >= m) return;
   Fr av = Fr::zero(), bv = Fr::zero(), cv = Fr::zero();
   if (i < nc) {
-    // indices from a key file are untrusted: an entry whose column is not a wire is skipped and reported
-    // through the context's sticky flag (dg16_sync -> DG16_ERR_BAD_ARG), never dereferenced
+    // Column indices from a key file are untrusted: an entry whose column is not a wire is skipped and reported
+    // through the context's sticky flag (dg16_sync -> DG16_ERR_BAD_ARG); w[] is never read out of range.  The ROW
+    // POINTERS of the device-pointer entry points are trusted (the kernel does not know the length of the column /
+    // coefficient arrays: a row_ptr beyond them reads past their end) -- the host-pointer path and the file readers
+    // validate row_ptr against nnz before anything reaches the device (capi.hip, formats.hip)
     bool bad = false;
     const unsigned a_lo = a_ptr[i], a_hi = a_ptr[i + 1], b_lo = b_ptr[i], b_hi = b_ptr[i + 1];
     if (a_hi < a_lo || b_hi < b_lo || a_hi - a_lo > nv || b_hi - b_lo > nv) bad = true;

@@ -80,12 +80,6 @@ int dg16_pk_info_get(const dg16_pk* pk, dg16_pk_info* out) {
   out->shard = d.shard;
   out->n_shards = d.nshards;
   out->table_bytes = d.table_bytes;
-  // the shipped base-field product: 8 (BN254) / 12 x 32-bit limbs, product scanning, one v_mad_u64_u32 per
-  // partial product (csrc/fp.h); measured chip rate: tools/ubench/montmul_rate (profiles/)
-  out->fq_mul_mads = d.curve == DG16_BN254 ? 128 : 288;
-  out->fq_mul_rate_g = d.curve == DG16_BN254 ? 114.0f : 50.0f;
-  snprintf(out->g2_kernel, sizeof(out->g2_kernel), "msm_accumulate_lds_kernel<Fp2<%s_fq>>",
-           d.curve == DG16_BN254 ? "bn254" : "bls12_381");
   return DG16_OK;
 }
 

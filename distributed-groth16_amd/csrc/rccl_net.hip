@@ -30,6 +30,8 @@ struct Api {
   ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+  ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
   ncclResult_t (*GroupStart)() = nullptr;
   ncclResult_t (*GroupEnd)() = nullptr;
   ncclResult_t (*Send)(const void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
@@ -63,6 +65,8 @@ Api& api() {
     a.GetUniqueId = (decltype(a.GetUniqueId))sym("ncclGetUniqueId");
     a.CommInitRank = (decltype(a.CommInitRank))sym("ncclCommInitRank");
     a.CommDestroy = (decltype(a.CommDestroy))sym("ncclCommDestroy");
+    a.CommCount = (decltype(a.CommCount))sym("ncclCommCount");
+    a.CommUserRank = (decltype(a.CommUserRank))sym("ncclCommUserRank");
     a.GroupStart = (decltype(a.GroupStart))sym("ncclGroupStart");
     a.GroupEnd = (decltype(a.GroupEnd))sym("ncclGroupEnd");
     a.Send = (decltype(a.Send))sym("ncclSend");
@@ -211,6 +215,18 @@ int dg16_rccl_create(dg16_ctx* ctx, const void* unique_id128, unsigned n_ranks, 
   h->comm_vt = dg16_comm{h, rc_n, rc_me, rc_all_gather, rc_all_to_all};
   h->net_vt = dg16_net{h, rc_n, rc_me, rc_gather, rc_scatter, rc_is_init, rc_send_to, rc_recv_from};
   *out = h;
+  return DG16_OK;
+}
+
+// what the COMMUNICATOR reports (ncclCommCount / ncclCommUserRank), not what the caller asked for
+int dg16_rccl_ranks(dg16_rccl* h, unsigned* n_ranks, unsigned* rank) {
+  if (!h || !h->comm) return DG16_ERR_BAD_ARG;
+  int n = 0, me = 0;
+  if (!h->check(api().CommCount(h->comm, &n), "ncclCommCount") ||
+      !h->check(api().CommUserRank(h->comm, &me), "ncclCommUserRank"))
+    return DG16_ERR_NET;
+  if (n_ranks) *n_ranks = (unsigned)n;
+  if (rank) *rank = (unsigned)me;
   return DG16_OK;
 }
 

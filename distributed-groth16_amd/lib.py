@@ -42,8 +42,7 @@ class ZkeyHeader(ctypes.Structure):       # dg16_zkey_header
 class PkInfo(ctypes.Structure):           # dg16_pk_info
     _fields_ = [("n_ab", ctypes.c_uint64), ("n_l", ctypes.c_uint64), ("n_h", ctypes.c_uint64),
                 ("c_ab", ctypes.c_uint32), ("c_l", ctypes.c_uint32), ("c_h", ctypes.c_uint32),
-                ("shard", ctypes.c_uint32), ("n_shards", ctypes.c_uint32), ("table_bytes", ctypes.c_uint64),
-                ("fq_mul_mads", ctypes.c_uint32), ("fq_mul_rate_g", ctypes.c_float), ("g2_kernel", ctypes.c_char * 96)]
+                ("shard", ctypes.c_uint32), ("n_shards", ctypes.c_uint32), ("table_bytes", ctypes.c_uint64)]
 
 
 class Csr(ctypes.Structure):              # dg16_csr
@@ -170,6 +169,7 @@ def load():
     L.dg16_wire_fr_decode.argtypes = [vp, i, vp, sz, vp, ctypes.POINTER(sz), u, i]
     L.dg16_rccl_unique_id.argtypes = [vp]
     L.dg16_rccl_create.argtypes = [vp, vp, u, u, ctypes.POINTER(vp)]
+    L.dg16_rccl_ranks.argtypes = [vp, ctypes.POINTER(u), ctypes.POINTER(u)]
     L.dg16_rccl_comm.argtypes = [vp]
     L.dg16_rccl_comm.restype = vp
     L.dg16_rccl_net.argtypes = [vp]
@@ -235,7 +235,7 @@ EXPORTED = ["dg16_ctx_create", "dg16_ctx_destroy", "dg16_last_error", "dg16_set_
             "dg16_pss_create", "dg16_pss_destroy", "dg16_pss_apply", "dg16_pss_apply_exp", "dg16_d_fft",
             "dg16_d_msm", "dg16_deg_red", "dg16_d_pp", "dg16_ext_wit_h", "dg16_qap", "dg16_qap_rows",
             "dg16_h_poly_dist", "dg16_h_poly_dist_stage", "dg16_ntt_dist", "dg16_ntt_dist_stage", "dg16_groth16_msms_h", "dg16_groth16_prove_dist",
-            "dg16_rccl_unique_id", "dg16_rccl_create", "dg16_rccl_comm", "dg16_rccl_net", "dg16_rccl_destroy",
+            "dg16_rccl_unique_id", "dg16_rccl_create", "dg16_rccl_comm", "dg16_rccl_net", "dg16_rccl_destroy", "dg16_rccl_ranks",
             "dg16_rccl_error", "dg16_bases_upload", "dg16_bases_free", "dg16_bases_info", "dg16_msm_resident",
             "dg16_d_msm_resident", "dg16_codec_error", "dg16_arkkey_layout", "dg16_points_compress",
             "dg16_points_decompress", "dg16_wire_fr_bytes", "dg16_wire_fr_encode", "dg16_wire_fr_decode",
@@ -285,12 +285,10 @@ class ProvingKey:
         self.num_vars, self.num_inputs, self.domain_size = num_vars, num_inputs, domain_size
 
     def info(self):
-        """dg16_pk_info as a dict (window bits, points per launch, table bytes, the multiply the kernels use)."""
+        """dg16_pk_info as a dict (window bits, points per launch, table bytes)."""
         i = PkInfo()
         self.ctx._chk(self.ctx.L.dg16_pk_info_get(self.h, ctypes.byref(i)))
-        d = {n: getattr(i, n) for n, _ in PkInfo._fields_}
-        d["g2_kernel"] = i.g2_kernel.decode()
-        return d
+        return {n: getattr(i, n) for n, _ in PkInfo._fields_}
 
     def close(self):
         if self.h and self.ctx.h:
@@ -655,6 +653,14 @@ class RcclComm:
 
     def describe(self):
         return "native RCCL (grouped ncclSend/ncclRecv + ncclAllGather, stream-ordered)"
+
+    def ranks(self):
+        """(n_ranks, rank) as the communicator itself reports them (ncclCommCount / ncclCommUserRank)."""
+        n, me = ctypes.c_uint(0), ctypes.c_uint(0)
+        rc = self.L.dg16_rccl_ranks(self.h, ctypes.byref(n), ctypes.byref(me))
+        if rc != 0:
+            raise Dg16Error(rc, self.L.dg16_rccl_error().decode())
+        return n.value, me.value
 
     def close(self):
         if getattr(self, "h", None) and self.ctx.h:

@@ -178,6 +178,10 @@ class NativeProver:
         return "msm-shard x%d + sharded h-polynomial (2 all-to-alls) + all-gather of the records, %s" % (
             self.world, self.comm.describe())
 
+    def rccl_ranks(self):
+        """Rank count the native RCCL communicator reports; None when another transport carries the exchanges."""
+        return self.comm.ranks()[0] if hasattr(self.comm, "ranks") else None
+
     def close(self):
         if self.comm is not None:
             self.comm.close()
@@ -201,11 +205,35 @@ def make_prover(ctx, pk, curve, dist, rank, world, transport="rccl"):
     if not h_is_sharded(pk.domain_size, world) or transport == "python":
         return DistributedProver(GpuEngine(ctx, pk, curve), dist, rank, world,
                                  sharded_h=h_is_sharded(pk.domain_size, world))
+    import torch
+    comm = None
     if transport == "rccl":
-        box = [lib.rccl_unique_id() if rank == 0 else None]
+        # The choice of transport is COLLECTIVE: every rank issues the same broadcast and the same all-reduce whatever
+        # happens locally, and all ranks fall back together.  (Rank 0 raising before the broadcast while the others
+        # wait in it, or one rank failing ncclCommInitRank alone, would leave the ranks issuing different collectives.)
+        box = [None]
+        if rank == 0:
+            try:
+                box[0] = lib.rccl_unique_id()
+            except lib.Dg16Error as e:
+                box[0] = "error: %s" % e
         dist.broadcast_object_list(box, src=0)
-        comm = lib.RcclComm(ctx, box[0], world, rank)
-    else:
-        import torch
+        why = box[0] if isinstance(box[0], str) else None
+        if why is None:
+            try:
+                comm = lib.RcclComm(ctx, box[0], world, rank)
+            except lib.Dg16Error as e:
+                why = "rank %d: %s" % (rank, e)
+        ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32,
+                          device="cpu" if dist.get_backend() == "gloo" else torch.device("cuda", ctx.device))
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            if comm is not None:
+                comm.close()
+                comm = None
+            import sys
+            print("dg16: native RCCL transport unavailable (%s); every rank uses torch.distributed" %
+                  (why or "a peer failed to join"), file=sys.stderr)
+    if comm is None:
         comm = lib.TorchComm(dist, torch.device("cuda", ctx.device), world, rank)
     return NativeProver(ctx, pk, curve, comm, rank, world)

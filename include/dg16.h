@@ -174,17 +174,13 @@ void dg16_pk_destroy(dg16_pk *pk);
 
 /* What a resident key holds (for reports: bench.py prints it next to every timing, because the proof time depends
  * on the window tables built here, once per key).  n_*: points per MSM launch of this shard (slice + delta slots);
- * c_*: window bits of the tables; table_bytes: HBM held by the five tables; fq_mul_mads / fq_mul_rate_g: the
- * v_mad_u64_u32 count of one base-field product in the bucket kernels and its measured chip-wide rate in G
- * products/s (tools/ubench), i.e. the VALU roof those kernels are priced against. */
+ * c_*: window bits of the tables; table_bytes: HBM held by the five tables.  (Facts of the key only: measured
+ * rates and instruction counts of the kernels live with the benchmarks -- profiles/, bench.py -- not in the ABI.) */
 typedef struct dg16_pk_info {
   uint64_t n_ab, n_l, n_h;
   uint32_t c_ab, c_l, c_h;
   uint32_t shard, n_shards;
   uint64_t table_bytes;
-  uint32_t fq_mul_mads;
-  float fq_mul_rate_g;
-  char g2_kernel[96];
 } dg16_pk_info;
 int dg16_pk_info_get(const dg16_pk *pk, dg16_pk_info *out);
 
@@ -289,6 +285,8 @@ typedef struct dg16_rccl dg16_rccl;
 struct dg16_net;
 int dg16_rccl_unique_id(void *out128);
 int dg16_rccl_create(dg16_ctx *ctx, const void *unique_id128, unsigned n_ranks, unsigned rank, dg16_rccl **out);
+/* rank count and this rank's index as the communicator itself reports them (ncclCommCount / ncclCommUserRank) */
+int dg16_rccl_ranks(dg16_rccl *h, unsigned *n_ranks, unsigned *rank);
 const dg16_comm *dg16_rccl_comm(dg16_rccl *h);
 const struct dg16_net *dg16_rccl_net(dg16_rccl *h);
 void dg16_rccl_destroy(dg16_rccl *h);

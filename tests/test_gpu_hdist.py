@@ -233,6 +233,7 @@ def test_native_rccl_comm_world_size_one():
     comm = lib.RcclComm(c, lib.rccl_unique_id(), 1, 0)
     vt = ctypes.cast(comm.comm_ptr, ctypes.POINTER(lib.CommStruct)).contents
     assert vt.n_ranks(vt.self) == 1 and vt.rank(vt.self) == 0
+    assert comm.ranks() == (1, 0)            # what ncclCommCount / ncclCommUserRank report (bench.py's rccl_ranks)
     src = torch.arange(4096, dtype=torch.int64, device=DEV)
     dst = torch.zeros_like(src)
     st = torch.cuda.current_stream().cuda_stream

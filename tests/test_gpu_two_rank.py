@@ -36,19 +36,27 @@ def test_sharded_proof_across_processes(world, log_m, transport):
     assert "TWO_RANK_CHECK PASS" in out.stdout
 
 
-def test_bench_flow_with_two_ranks_on_one_device():
-    """bench.py's own N > 1 flow (sharded workload, native distributed prove, barriers, max over ranks, the live parity
-    gate on rank 0) with both ranks on cuda:0 and a gloo process group (DG16_BENCH_SINGLE_DEVICE: RCCL refuses two ranks
-    on one device) -- everything the 8-GPU run does except the RCCL wire."""
+@pytest.mark.parametrize("transport", ["torch", "rccl"])
+def test_bench_flow_with_two_ranks_on_one_device(transport):
+    """bench.py's own N > 1 flow launched PLAIN -- `python bench.py --gpus 2`, no torch.distributed.run in front: the
+    script re-executes itself as the launcher of two ranks -- with both ranks on cuda:0 and a gloo process group
+    (DG16_BENCH_SINGLE_DEVICE: RCCL refuses two ranks on one device): sharded workload, native distributed prove,
+    barriers, max over ranks, the live parity gate on rank 0, the replicas figure.  transport = rccl asks for the native
+    communicator, which cannot form here: the ranks must notice TOGETHER and all fall back to torch.distributed
+    (parallel.make_prover's collective decision) instead of issuing mismatched collectives."""
     import json
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
-           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--log-m", "14",
-           "--transport", "torch"]
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--log-m", "14",
+           "--transport", transport]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", DG16_BENCH_SINGLE_DEVICE="1")
+    env.pop("WORLD_SIZE", None)
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=280)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["parity_check"] == "pass" and d["scaling"] == "strong"
     assert "sharded h-polynomial" in d["config"]["parallelism"]
+    assert "torch.distributed" in d["config"]["parallelism"] and d["config"]["rccl_ranks"] is None
+    assert d["replicas"]["scaling"] == "weak" and d["replicas"]["value"] > 0
+    assert d["valu_roofline"]["frac"] <= 1.0 and d["valu_roofline"]["whole_proof_valu_frac"] <= 1.0
+    if transport == "rccl":
+        assert "native RCCL transport unavailable" in out.stderr
