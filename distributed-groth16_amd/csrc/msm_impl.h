@@ -33,11 +33,13 @@
 
 namespace dg16 {
 
-// Accumulation segments: a lane sums <= 2^seg_log consecutive entries of one bucket.  seg_log follows the
-// mean bucket occupancy (mean/8, clamped to 8..128 and by the lane count): 16 when buckets hold ~32 points (32 measured 20 %
-// slower there: lanes idle behind the longest segment of their wave), larger when buckets are large
-// (table mode), which keeps the number of partials per bucket -- the finalize work -- small.
-constexpr unsigned kMinSegLog = 3, kMaxSegLog = 7;
+// Accumulation segments: a bucket of cnt entries is cut into k = ceil(cnt / 2^seg_log) segments of EQUAL length
+// (floor / ceil of cnt / k), one lane each: the lanes of a wave run chains of nearly the same length (with fixed-length
+// segments every bucket ended in a short one and its wave idled behind the long ones), and k -- the number of partials
+// the finalize has to add per bucket -- is as small as the segment length allows.  seg_log follows the mean bucket
+// occupancy, clamped by the lane count a launch needs.  The (segment -> bucket) map is not stored: a lane finds its
+// bucket by binary search in the exclusive scan of the per-bucket segment counts.
+constexpr unsigned kMinSegLog = 3, kMaxSegLog = 9;
 constexpr unsigned kMinLanesLog = 18;    // want >= 2^18 segments (4 waves per SIMD) in an accumulation launch
 constexpr unsigned kGiantSegs = 64;      // buckets with more segments are reduced by a whole workgroup
 
@@ -259,8 +261,7 @@ __global__ void __launch_bounds__(256) msm_scatter_kernel(const int* __restrict_
                                                            const unsigned* __restrict__ offsets,
                                                            const unsigned* __restrict__ seg_off,
                                                            unsigned* __restrict__ cursor,
-                                                           unsigned* __restrict__ entries,
-                                                           unsigned* __restrict__ seg_bucket) {
+                                                           unsigned* __restrict__ entries) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const bool live = i < n;
   for (unsigned w = 0; w < g.nwin; w++) {
@@ -273,8 +274,6 @@ __global__ void __launch_bounds__(256) msm_scatter_kernel(const int* __restrict_
     if (!act) continue;
     unsigned ref = g.table ? (unsigned)((size_t)w * n + i) : (unsigned)i;   // table row 2^(c*w) * P_i
     entries[(size_t)bwin * g.region + offsets[slot] + rank] = ref | (d < 0 ? 0x80000000u : 0u);
-    if ((rank & ((1u << g.seg_log) - 1)) == 0)
-      seg_bucket[(size_t)bwin * g.seg_cap + seg_off[slot] + (rank >> g.seg_log)] = b;
   }
 }
 
@@ -453,8 +452,7 @@ __global__ void __launch_bounds__(256) msm_part_place_kernel(const uint2* __rest
                                                               MsmGeom g, const unsigned* __restrict__ offsets,
                                                               const unsigned* __restrict__ seg_off,
                                                               unsigned* __restrict__ cursor,
-                                                              unsigned* __restrict__ entries,
-                                                              unsigned* __restrict__ seg_bucket) {
+                                                              unsigned* __restrict__ entries) {
   __shared__ unsigned cnt[1u << kPartMaxLowBits];    // entries of this tile per bin
   __shared__ unsigned rank0[1u << kPartMaxLowBits];  // rank of the tile's first entry inside its bucket
   __shared__ unsigned dst0[1u << kPartMaxLowBits];   // position of the bucket's first entry
@@ -492,9 +490,6 @@ __global__ void __launch_bounds__(256) msm_part_place_kernel(const uint2* __rest
       const unsigned slot = e[j].y, b = slot & (nlow - 1);
       const unsigned rank = rank0[b] + lr[j];
       entries[dst0[b] + rank] = e[j].x;
-      if ((rank & ((1u << g.seg_log) - 1)) == 0)
-        seg_bucket[(size_t)(slot >> g.log_nb) * g.seg_cap + seg_off[slot] + (rank >> g.seg_log)] =
-            slot & ((1u << g.log_nb) - 1);
     }
     __syncthreads();
   }
@@ -519,6 +514,33 @@ __device__ __forceinline__ Affine29<F> load_internal(const uint32_t* __restrict_
   return Affine29<F>::load(w);
 }
 
+// Segment t of bucket-window w -> its bucket and its range of the bucket's entries.  seg_off is the exclusive scan of
+// the per-bucket segment counts k_b = ceil(cnt_b / 2^seg_log): the bucket is the LAST b with seg_off[b] <= t (empty
+// buckets share their offset with their successor and are skipped by construction); segment j of k covers the ranks
+// [j cnt / k, (j + 1) cnt / k).
+struct SegRange {
+  size_t bslot;        // (w << log_nb) + bucket
+  unsigned first, cnt;
+};
+__device__ __forceinline__ SegRange msm_segment(const MsmGeom& g, unsigned w, unsigned t,
+                                                const unsigned* __restrict__ counts,
+                                                const unsigned* __restrict__ seg_off) {
+  const unsigned* so = seg_off + ((size_t)w << g.log_nb);
+  unsigned lo = 0, hi = 1u << g.log_nb;          // invariant: so[lo] <= t, (hi == nb or so[hi] > t)
+  while (hi - lo > 1) {
+    const unsigned mid = (lo + hi) >> 1;
+    if (so[mid] <= t) lo = mid; else hi = mid;
+  }
+  SegRange r;
+  r.bslot = ((size_t)w << g.log_nb) + lo;
+  const unsigned c = counts[r.bslot];
+  const unsigned k = (c + (1u << g.seg_log) - 1) >> g.seg_log;
+  const unsigned j = t - so[lo];
+  r.first = (unsigned)(((uint64_t)j * c) / k);
+  r.cnt = (unsigned)(((uint64_t)(j + 1) * c) / k) - r.first;
+  return r;
+}
+
 template <class F>
 __global__ void __launch_bounds__(256, (sizeof(F) > 48 ? 2 : 1))
 msm_accumulate_kernel(const uint32_t* __restrict__ bases, size_t n,
@@ -526,19 +548,15 @@ msm_accumulate_kernel(const uint32_t* __restrict__ bases, size_t n,
                                                               const unsigned* __restrict__ counts,
                                                               const unsigned* __restrict__ seg_off,
                                                               const unsigned* __restrict__ seg_total,
-                                                              const unsigned* __restrict__ seg_bucket,
                                                               const unsigned* __restrict__ entries,
                                                               XYZZ29<F>* __restrict__ seg_sum) {
   const unsigned w = blockIdx.y;
   const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= seg_total[w]) return;
   const size_t sslot = (size_t)w * g.seg_cap + t;
-  const unsigned b = seg_bucket[sslot];
-  const size_t bslot = ((size_t)w << g.log_nb) + b;
-  const unsigned first = (t - seg_off[bslot]) << g.seg_log;   // rank of this segment's first entry
-  unsigned cnt = counts[bslot] - first;
-  if (cnt > (1u << g.seg_log)) cnt = 1u << g.seg_log;
-  const unsigned* e = entries + (size_t)w * g.region + offsets[bslot] + first;
+  const SegRange sr = msm_segment(g, w, t, counts, seg_off);
+  const unsigned cnt = sr.cnt;
+  const unsigned* e = entries + (size_t)w * g.region + offsets[sr.bslot] + sr.first;
   // Latency hiding: several waves per SIMD cover the dependent (entry -> point) gathers; only the 4-byte entry
   // index is fetched one iteration ahead (a second point in registers would cost occupancy).
   unsigned cur = e[0];
@@ -562,8 +580,7 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 ? 2 : 1))
 msm_accumulate_lds_kernel(const uint32_t* __restrict__ bases, size_t n, MsmGeom g,
                           const unsigned* __restrict__ offsets, const unsigned* __restrict__ counts,
                           const unsigned* __restrict__ seg_off, const unsigned* __restrict__ seg_total,
-                          const unsigned* __restrict__ seg_bucket, const unsigned* __restrict__ entries,
-                          XYZZ29<F>* __restrict__ seg_sum) {
+                          const unsigned* __restrict__ entries, XYZZ29<F>* __restrict__ seg_sum) {
   using FO = FieldOf<F>;
   using S = typename FO::Store;
   constexpr int BS = FO::BS;
@@ -587,12 +604,9 @@ msm_accumulate_lds_kernel(const uint32_t* __restrict__ bases, size_t n, MsmGeom 
   const unsigned t = blockIdx.x * BLOCK + threadIdx.x;
   if (t >= seg_total[w]) return;
   const size_t sslot = (size_t)w * g.seg_cap + t;
-  const unsigned b = seg_bucket[sslot];
-  const size_t bslot = ((size_t)w << g.log_nb) + b;
-  const unsigned first = (t - seg_off[bslot]) << g.seg_log;
-  unsigned cnt = counts[bslot] - first;
-  if (cnt > (1u << g.seg_log)) cnt = 1u << g.seg_log;
-  const unsigned* e = entries + (size_t)w * g.region + offsets[bslot] + first;
+  const SegRange sr = msm_segment(g, w, t, counts, seg_off);
+  const unsigned cnt = sr.cnt;
+  const unsigned* e = entries + (size_t)w * g.region + offsets[sr.bslot] + sr.first;
   bool inf = true;
   unsigned cur = e[0];
   for (unsigned j = 0; j < cnt; j++) {
@@ -784,7 +798,7 @@ struct MsmSort {
   size_t n = 0;
   int* digits = nullptr;
   unsigned *entries = nullptr, *counts = nullptr, *offsets = nullptr, *seg_off = nullptr, *cursor = nullptr;
-  unsigned *seg_total = nullptr, *seg_bucket = nullptr;
+  unsigned* seg_total = nullptr;
 };
 
 template <class Fr, int SCALAR_BITS>
@@ -803,7 +817,6 @@ MsmSort msm_sort_on(hipStream_t s, Channel& wsch, const void* scalars, size_t n,
   r.g = msm_geometry(n ? n : 1, SCALAR_BITS, table, c_fixed);
   const MsmGeom& g = r.g;
   const size_t nbw = (size_t)g.bw << g.log_nb;
-  const size_t nseg_slots = (size_t)g.bw * g.seg_cap;
   DG_REQUIRE((size_t)g.nwin * n < ((size_t)1 << 31), DG16_ERR_BAD_ARG, "W * n must be < 2^31");
   // large sorts: LDS-partitioned passes; small ones: the direct atomic path (fewer launches)
   unsigned lg_nbw = 0;
@@ -817,13 +830,12 @@ MsmSort msm_sort_on(hipStream_t s, Channel& wsch, const void* scalars, size_t n,
   pg.nblk1 = (unsigned)((n + kPartScalars - 1) / kPartScalars);
   r.digits = (int*)ws(wsch, 4, (size_t)g.nwin * n * (partitioned ? 8 : 4));
   r.entries = (unsigned*)ws(wsch, 5, (size_t)g.nwin * n * 4);
-  unsigned* tabs = (unsigned*)ws(wsch, 6, (nbw * 4 + g.bw + nseg_slots) * 4);
+  unsigned* tabs = (unsigned*)ws(wsch, 6, (nbw * 4 + g.bw) * 4);
   r.counts = tabs;
   r.offsets = r.counts + nbw;
   r.seg_off = r.offsets + nbw;
   r.cursor = r.seg_off + nbw;
   r.seg_total = r.cursor + nbw;
-  r.seg_bucket = r.seg_total + g.bw;
   DG_HIP(hipMemsetAsync(r.counts, 0, nbw * 4, s));
   uint2* part = (uint2*)r.digits;
   unsigned* blockoff = nullptr;
@@ -857,10 +869,10 @@ MsmSort msm_sort_on(hipStream_t s, Channel& wsch, const void* scalars, size_t n,
   }
   if (n && partitioned)
     hipLaunchKernelGGL(msm_part_place_kernel<0>, dim3(kPartBlocks, pg.nparts), dim3(256), 0, s, part, blockoff, pg, g,
-                       r.offsets, r.seg_off, r.cursor, r.entries, r.seg_bucket);
+                       r.offsets, r.seg_off, r.cursor, r.entries);
   else if (n)
     hipLaunchKernelGGL(msm_scatter_kernel<0>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, r.digits, n, g,
-                       r.offsets, r.seg_off, r.cursor, r.entries, r.seg_bucket);
+                       r.offsets, r.seg_off, r.cursor, r.entries);
   DG_HIP(hipGetLastError());
   return r;
 }
@@ -911,11 +923,11 @@ void msm_accumulate_phase(hipStream_t s, const MsmSort& st, const MsmBuffers<F>&
     constexpr int BLOCK = sizeof(typename FieldOf<F>::Store) * 4 * 256 <= 80 * 1024 ? 256 : 128;
     hipLaunchKernelGGL((msm_accumulate_lds_kernel<F, BLOCK>), dim3((g.seg_cap + BLOCK - 1) / BLOCK, g.bw), dim3(BLOCK),
                        0, s, (const uint32_t*)bases, st.n, g, st.offsets, st.counts, st.seg_off, st.seg_total,
-                       st.seg_bucket, st.entries, b.seg_sum);
+                       st.entries, b.seg_sum);
   } else {
     hipLaunchKernelGGL(msm_accumulate_kernel<F>, dim3((g.seg_cap + 255) / 256, g.bw), dim3(256), 0, s,
                        (const uint32_t*)bases, st.n, g, st.offsets, st.counts, st.seg_off, st.seg_total,
-                       st.seg_bucket, st.entries, b.seg_sum);
+                       st.entries, b.seg_sum);
   }
   DG_HIP(hipGetLastError());
 }
@@ -938,7 +950,11 @@ __device__ __forceinline__ void giant_geometry(unsigned nseg, unsigned& slices, 
 // a 2^20 proof = a million additions: the four-lanes-per-bucket, out-of-line-product finalize of the reduction unit
 // (built for short chains) spent 0.7 ms (G1) / 2.6 ms (G2) on them at low occupancy, next to an accumulation it
 // stretched by a millisecond; the 29-bit product runs at full rate at ONE wave per SIMD, so plain lanes do.
-template <class F>
+// TU: 0 = instantiated in msm_group.hip (products inline), 1 = in msm_reduce.hip (for G2 compiled with out-of-line
+// products, DG29_OUTLINE_MUL: an inlined Fq2 addition + doubling is 123 KB of code for BN254, twice the 64 KB
+// instruction cache two CUs share, and the inlined G2 finalize was instruction-fetch-bound: 220 us per dependent
+// addition against ~13 us of issue time).  Distinct symbols, so that both variants can live in one library.
+template <class F, int TU = 0>
 __global__ void __launch_bounds__(256) msm_finalize_thr_kernel(MsmGeom g, const unsigned* __restrict__ counts,
                                                                 const unsigned* __restrict__ seg_off,
                                                                 const XYZZ29<F>* __restrict__ seg_sum,
@@ -968,10 +984,74 @@ __global__ void __launch_bounds__(256) msm_finalize_thr_kernel(MsmGeom g, const 
   for (unsigned s = 1; s < nseg; s++) acc = acc.add(sp[s]);
   buckets[gid] = acc;
 }
+// TWO lanes per bucket: lane q sums the partials q, q + 2, ..; one exchange step adds the two halves.  The chain per
+// lane halves and the launch has two waves per SIMD, so that one wave's partial loads hide behind the other's products
+// (with one lane per bucket the kernel is a single wave per SIMD alternating between a 144 / 288-byte strided load
+// and an addition).
+template <class T>
+__device__ __forceinline__ T lane_xor_words2(const T& v, int mask) {
+  static_assert(sizeof(T) % 4 == 0, "word-sized type");
+  T r;
+  const uint32_t* src = reinterpret_cast<const uint32_t*>(&v);
+  uint32_t* dst = reinterpret_cast<uint32_t*>(&r);
+#pragma unroll
+  for (unsigned i = 0; i < sizeof(T) / 4; i++) dst[i] = (uint32_t)__shfl_xor((int)src[i], mask);
+  return r;
+}
+template <class F, int TU = 0>
+__global__ void __launch_bounds__(256) msm_finalize_thr2_kernel(MsmGeom g, const unsigned* __restrict__ counts,
+                                                                 const unsigned* __restrict__ seg_off,
+                                                                 const XYZZ29<F>* __restrict__ seg_sum,
+                                                                 XYZZ29<F>* __restrict__ buckets,
+                                                                 unsigned* __restrict__ giant_count,
+                                                                 unsigned* __restrict__ giant_list, unsigned giant_cap) {
+  const size_t gid2 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t gid = gid2 >> 1;
+  const unsigned q = (unsigned)gid2 & 1;
+  const size_t total = (size_t)g.bw << g.log_nb;
+  if (gid >= total) return;                 // pairs leave together
+  const unsigned w = (unsigned)(gid >> g.log_nb);
+  const unsigned nseg = (counts[gid] + (1u << g.seg_log) - 1) >> g.seg_log;
+  if (nseg > kGiantSegs) {
+    if (q == 0) {
+      unsigned slot = atomicAdd(giant_count, 1u);
+      if (slot < giant_cap) {
+        giant_list[slot] = (unsigned)gid;
+        unsigned slices, per;
+        giant_geometry(nseg, slices, per);
+        unsigned wb = atomicAdd(giant_count + 1, slices);
+        unsigned* work = giant_list + giant_cap;
+        for (unsigned k = 0; k < slices; k++) work[wb + k] = (slot << 6) | k;
+      }
+    }
+    return;
+  }
+  const XYZZ29<F>* sp = seg_sum + (size_t)w * g.seg_cap + seg_off[gid];
+  XYZZ29<F> acc = q < nseg ? sp[q] : XYZZ29<F>::inf();
+  const unsigned iters = (nseg + 1) >> 1;   // both lanes run the same trip count: one addition site, then the exchange
+#pragma unroll 1
+  for (unsigned it = 1; it <= iters; it++) {
+    XYZZ29<F> o;
+    if (it < iters) {
+      const unsigned sidx = q + 2 * it;
+      o = sidx < nseg ? sp[sidx] : XYZZ29<F>::inf();
+    } else {
+      o = lane_xor_words2(acc, 1);
+    }
+    acc = acc.add(o);
+  }
+  if (q == 0) buckets[gid] = acc;
+}
+
 template <class F>
 void msm_finalize_phase(hipStream_t s, const MsmSort& st, const MsmBuffers<F>& b) {
-  hipLaunchKernelGGL(msm_finalize_thr_kernel<F>, dim3((unsigned)((b.nbw + 255) / 256)), dim3(256), 0, s, st.g, st.counts,
-                     st.seg_off, b.seg_sum, b.buckets, b.giant, b.giant + 2, b.giant_cap);
+  static const int mode = [] { const char* e = getenv("DG16_FINALIZE"); return e ? atoi(e) : 0; }();
+  if (mode == 2)
+    hipLaunchKernelGGL(msm_finalize_thr2_kernel<F>, dim3((unsigned)((2 * b.nbw + 255) / 256)), dim3(256), 0, s, st.g,
+                       st.counts, st.seg_off, b.seg_sum, b.buckets, b.giant, b.giant + 2, b.giant_cap);
+  else
+    hipLaunchKernelGGL(msm_finalize_thr_kernel<F>, dim3((unsigned)((b.nbw + 255) / 256)), dim3(256), 0, s, st.g, st.counts,
+                       st.seg_off, b.seg_sum, b.buckets, b.giant, b.giant + 2, b.giant_cap);
   DG_HIP(hipGetLastError());
 }
 
@@ -979,8 +1059,12 @@ void msm_finalize_phase(hipStream_t s, const MsmSort& st, const MsmBuffers<F>& b
 // phase A so that it hides behind the next MSM's accumulation.  Defined in msm_reduce_impl.h and instantiated once per
 // (curve, group) in msm_reduce.hip -- a translation unit of its own because its kernels are compiled with out-of-line
 // field products (DG29_OUTLINE_MUL, fp29.h).
+// parts: bit 0 = finalize (+ giant buckets): throughput work, one lane per bucket; bit 1 = rows -> top -> tail: the
+// latency chain.  A caller that pipelines MSMs may run the two on different streams (prover_impl.h).
+constexpr int kBucketFinalize = 1, kBucketChain = 2, kBucketAll = 3;
 template <class F>
-void msm_bucket_phase(hipStream_t s, const MsmSort& st, const MsmBuffers<F>& b, bool out_affine, void* out_dev);
+void msm_bucket_phase(hipStream_t s, const MsmSort& st, const MsmBuffers<F>& b, bool out_affine, void* out_dev,
+                      int parts = kBucketAll);
 
 // both phases on the call's own stream and workspace
 template <class F>

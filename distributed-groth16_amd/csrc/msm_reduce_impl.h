@@ -398,12 +398,30 @@ inline void trace_point(hipStream_t s, const char* what) {
 }
 
 template <class F>
-void msm_bucket_phase(hipStream_t s, const MsmSort& st, const MsmBuffers<F>& b, bool out_affine, void* out_dev) {
+void msm_bucket_phase(hipStream_t s, const MsmSort& st, const MsmBuffers<F>& b, bool out_affine, void* out_dev,
+                      int parts) {
   const MsmGeom& g = st.g;
   trace_point(s, "(before bucket phase)");
+  if (parts & kBucketFinalize) {
   DG_HIP(hipMemsetAsync(b.giant, 0, 8, s));
-  static const bool finalize4 = [] { const char* e = getenv("DG16_FINALIZE"); return e && atoi(e) == 4; }();
-  if (!finalize4) {
+  static const int finalize_mode = [] { const char* e = getenv("DG16_FINALIZE"); return e ? atoi(e) : 0; }();
+  const bool finalize4 = finalize_mode == 4;
+  // G2: the one-lane-per-bucket finalize of THIS translation unit (out-of-line products: small code);
+  // DG16_FINALIZE=1 forces the inline-product instantiation of msm_group.hip for A/B timing
+  bool g2_outlined = false;
+  if constexpr (FieldOf<F>::EXT) {
+    if (finalize_mode != 1 && !finalize4) {
+      g2_outlined = true;
+      if (finalize_mode == 2)
+        hipLaunchKernelGGL((msm_finalize_thr2_kernel<F, 1>), dim3((unsigned)((2 * b.nbw + 255) / 256)), dim3(256), 0, s,
+                           st.g, st.counts, st.seg_off, b.seg_sum, b.buckets, b.giant, b.giant + 2, b.giant_cap);
+      else
+        hipLaunchKernelGGL((msm_finalize_thr_kernel<F, 1>), dim3((unsigned)((b.nbw + 255) / 256)), dim3(256), 0, s, st.g,
+                           st.counts, st.seg_off, b.seg_sum, b.buckets, b.giant, b.giant + 2, b.giant_cap);
+    }
+  }
+  if (g2_outlined) {
+  } else if (!finalize4) {
     // one lane per bucket, inline products (msm_impl.h: a THROUGHPUT kernel -- 2^16 buckets x ~15 partials is a
     // million full additions, not a latency chain)
     msm_finalize_phase<F>(s, st, b);
@@ -422,6 +440,11 @@ void msm_bucket_phase(hipStream_t s, const MsmSort& st, const MsmBuffers<F>& b, 
   hipLaunchKernelGGL(msm_giant_fold_kernel<F>, dim3(64), dim3(64), 0, s, g, st.counts, st.seg_off, b.seg_sum,
                      b.buckets, b.giant, b.giant + 2, b.giant_cap);
   trace_point(s, "giant + fold");
+  }
+  if (!(parts & kBucketChain)) {
+    DG_HIP(hipGetLastError());
+    return;
+  }
   hipLaunchKernelGGL(msm_row_kernel<F>, dim3(1u << b.rg.rows_log, g.bw), dim3(256), 0, s, g, b.rg, b.buckets, b.row_w,
                      b.row_r);
   trace_point(s, "row");

@@ -194,6 +194,10 @@ static void msms_typed(dg16_ctx* ctx, Call& k0, Call& k1, Call& k2, const PkDev&
   // behind the next accumulation; only the last reduction is exposed.
   hipStream_t main = k0.s(), side = k1.s(), side2 = k2.s();
   hipEvent_t* ev = ctx->pipe_ev;   // persistent (see ctx.h)
+  // DG16_FINALIZE_MAIN=1: the bucket finalize (throughput work) of every MSM stays on the main stream behind its
+  // accumulation; only the latency chain (rows -> top -> tail) goes to the side stream
+  static const bool fin_main = [] { const char* e = getenv("DG16_FINALIZE_MAIN"); return e && atoi(e) != 0; }();
+  const int side_parts = fin_main ? kBucketChain : kBucketAll;
   const Affine<Fq>* fixed_g1 = (const Affine<Fq>*)pk.fixed;
   const Affine<Fq2>* fixed_g2 = (const Affine<Fq2>*)((const uint8_t*)pk.fixed + 4 * sizeof(Affine<Fq>));
 
@@ -235,10 +239,11 @@ static void msms_typed(dg16_ctx* ctx, Call& k0, Call& k1, Call& k2, const PkDev&
   msm_accumulate_phase<Fq2>(main, st_ab, buf_b2, pk.b2_q);
   DG_HIP(hipEventRecord(k2.c.ev[3], main));
   k2.c.ev_valid[1] = true;
+  if (fin_main) msm_bucket_phase<Fq2>(main, st_ab, buf_b2, false, res_b2, kBucketFinalize);
   DG_HIP(hipEventRecord(ev[2], main));
   // side2: reduction of B, straight behind its accumulation
   DG_HIP(hipStreamWaitEvent(side2, ev[2], 0));
-  msm_bucket_phase<Fq2>(side2, st_ab, buf_b2, false, res_b2);
+  msm_bucket_phase<Fq2>(side2, st_ab, buf_b2, false, res_b2, side_parts);
   hipLaunchKernelGGL(prover_stage1_g2_kernel<Fq2>, dim3(1), dim3(64), 0, side2, res_b2, fixed_g2, first_shard);
   DG_HIP(hipEventRecord(ev[5], side2));
   if (dist) {
@@ -251,17 +256,19 @@ static void msms_typed(dg16_ctx* ctx, Call& k0, Call& k1, Call& k2, const PkDev&
   msm_accumulate_phase<Fq>(main, st_ab, buf_a, pk.a_q);
   DG_HIP(hipEventRecord(k1.c.ev[3], main));
   k1.c.ev_valid[1] = true;
+  if (fin_main) msm_bucket_phase<Fq>(main, st_ab, buf_a, false, res_a, kBucketFinalize);
   DG_HIP(hipEventRecord(ev[0], main));
   msm_accumulate_phase<Fq>(main, st_ab, buf_b1, pk.b1_q);
+  if (fin_main) msm_bucket_phase<Fq>(main, st_ab, buf_b1, false, res_b1, kBucketFinalize);
   DG_HIP(hipEventRecord(ev[1], main));
   // side: reduction of A; aux: reduction of B1, then BOTH serial scalar multiples s*A', r*B1' in one launch of two
   // waves (a millisecond each).  They used to follow their reductions on their own streams -- and H's reduction,
   // queued on `side` behind s*A', became the end of the critical path on short shards.
   DG_HIP(hipStreamWaitEvent(side, ev[0], 0));
-  msm_bucket_phase<Fq>(side, st_ab, buf_a, false, res_a);
+  msm_bucket_phase<Fq>(side, st_ab, buf_a, false, res_a, side_parts);
   DG_HIP(hipEventRecord(ev[12], side));
   DG_HIP(hipStreamWaitEvent(aux, ev[1], 0));
-  msm_bucket_phase<Fq>(aux, st_ab, buf_b1, false, res_b1);
+  msm_bucket_phase<Fq>(aux, st_ab, buf_b1, false, res_b1, side_parts);
   DG_HIP(hipStreamWaitEvent(aux, ev[12], 0));
   hipLaunchKernelGGL((prover_stage1_g1_kernel<Fq, Fr>), dim3(2), dim3(64), 0, aux, rec, fixed_g1, r_s, (int)mont,
                      first_shard);
@@ -284,11 +291,12 @@ static void msms_typed(dg16_ctx* ctx, Call& k0, Call& k1, Call& k2, const PkDev&
   MsmBuffers<Fq> buf_h = msm_buffers<Fq>(ctx->xws[0], st_h.g);
   MsmBuffers<Fq> buf_l = msm_buffers<Fq>(ctx->xws[1], st_ab.g);
   msm_accumulate_phase<Fq>(main, st_h, buf_h, pk.h_q);
+  if (fin_main) msm_bucket_phase<Fq>(main, st_h, buf_h, false, res_h, kBucketFinalize);
   DG_HIP(hipEventRecord(ev[6], main));
   msm_accumulate_phase<Fq>(main, st_ab, buf_l, pk.l_q);
   // side (behind A's reduction): H's reduction hides behind L's accumulation; L's is the exposed tail
   DG_HIP(hipStreamWaitEvent(side, ev[6], 0));
-  msm_bucket_phase<Fq>(side, st_h, buf_h, false, res_h);
+  msm_bucket_phase<Fq>(side, st_h, buf_h, false, res_h, side_parts);
   msm_bucket_phase<Fq>(main, st_ab, buf_l, false, res_l);
   DG_HIP(hipEventRecord(ev[7], side));
   DG_HIP(hipStreamWaitEvent(main, ev[7], 0));           // A, H results

@@ -59,14 +59,18 @@ static void run(const char* name, int cus, uint32_t* d_out, const uint32_t* d_in
         if (v == 0) hipLaunchKernelGGL((chain<P, 0>), dim3(blocks), dim3(256), 0, 0, d_out, d_in, it);
         else hipLaunchKernelGGL((chain<P, 1>), dim3(blocks), dim3(256), 0, 0, d_out, d_in, it);
       };
-      launch(10);
+      launch(iters);                      // warm-up at full length: clocks and power state settle under this load
       CHECK(hipDeviceSynchronize());
-      CHECK(hipEventRecord(e0));
-      launch(iters);
-      CHECK(hipEventRecord(e1));
-      CHECK(hipEventSynchronize(e1));
-      float ms;
-      CHECK(hipEventElapsedTime(&ms, e0, e1));
+      float ms = 1e30f;
+      for (int rep = 0; rep < 3; rep++) {  // best of three
+        CHECK(hipEventRecord(e0));
+        launch(iters);
+        CHECK(hipEventRecord(e1));
+        CHECK(hipEventSynchronize(e1));
+        float t;
+        CHECK(hipEventElapsedTime(&t, e0, e1));
+        if (t < ms) ms = t;
+      }
       const double g = (double)blocks * 256 * iters / (ms * 1e-3) * 1e-9;
       if (g > best[v]) best[v] = g;
       printf("%s\"%d\": %.2f", first ? "" : ", ", w, g);
@@ -90,11 +94,14 @@ int main() {
   CHECK(hipMemcpy(d_in, h.data(), h.size() * 4, hipMemcpyHostToDevice));
   printf("{\"device\": \"%s\", \"compute_units\": %d, \"source\": \"tools/ubench/fe_rate.hip (fp29.h products, dependent chain per lane)\",\n",
          p.gcnArchName, cus);
+  hipLaunchKernelGGL((chain<bn254_fr_params, 0>), dim3(cus * 8), dim3(256), 0, 0, d_out, d_in, 20000);   // ~100 ms of load
+  CHECK(hipDeviceSynchronize());
   run<bn254_fq_params>("bn254_fq", cus, d_out, d_in, false);
   run<bls12_381_fq_params>("bls12_381_fq", cus, d_out, d_in, false);
   run<bls12_377_fq_params>("bls12_377_fq", cus, d_out, d_in, false);
   run<bn254_fr_params>("bn254_fr", cus, d_out, d_in, false);
-  run<bls12_381_fr_params>("bls12_381_fr", cus, d_out, d_in, true);
+  run<bls12_381_fr_params>("bls12_381_fr", cus, d_out, d_in, false);
+  run<bn254_fq_params>("bn254_fq_again", cus, d_out, d_in, true);     // order check: the first field measured once more
   printf("}\n");
   return 0;
 }
