@@ -26,7 +26,7 @@ namespace dg16 {
 
 constexpr unsigned kTileLog = 10;         // 1024 elements per workgroup
 constexpr unsigned kTile = 1u << kTileLog;
-constexpr unsigned kMaxStepLog = 9;       // sub-FFT size limit per step
+constexpr unsigned kMaxStepLog = 10;      // sub-FFT size limit per step: 2^20 = 2^10 x 2^10 is TWO passes over the data
 constexpr unsigned kLoBits = 11;          // twiddle table split
 
 template <class F>
@@ -58,13 +58,25 @@ __device__ __forceinline__ unsigned bitrev(unsigned v, unsigned bits) {
   return bits ? (__brev(v) >> (32 - bits)) : 0;
 }
 
-// bound (in p / 64) of a tile element between butterfly steps.  The first radix-4 step takes fresh loads (< 2 p)
-// to sums below 9 p; every later radix-4 step adds < 6 p to the bound of its inputs (x + t, then x - t + 3 p, twice,
-// with t a product < 2 p) and the odd last level < 3 p.  A step has at most (kMaxStepLog - 2) / 2 = 3 later radix-4
-// steps: true values stay below (9 + 18 + 3) p = 30 p < 40 p.  The static type cannot carry a bound that grows per
-// loop iteration, so the loop re-labels its results (Fe::unsafe_assume) -- this comment is the proof obligation.
-// 40 p + 6 p < 2^SLACK p for every scalar field (SLACK >= 6), which the types of the sums check at compile time.
-constexpr int kNttBound = 40 * 64;
+// Bound (in p / 64) of a tile element between butterfly steps.  The static type of the tile cannot carry a bound that
+// grows per loop iteration, so the loops re-label their results as El = Fe<P, kNttBound> (Fe::unsafe_assume).  What makes
+// that sound is checked AT COMPILE TIME, on the types of the very expressions the kernel evaluates (NttBounds below and
+// the static_asserts next to each butterfly):
+//   * every butterfly output is ONE tile input plus products and subtraction constants whose bounds do not depend on
+//     the input's value, so a step raises the TRUE bound of an element by at most
+//     (static bound of the output) - (static bound of the input) -- kFirstOut for the first radix-4 step on fresh
+//     loads, kStepGrowth per later radix-4 step, kOddGrowth for the odd last level;
+//   * a pass has one first step, at most (kMaxStepLog - 2) / 2 later radix-4 steps and at most one odd level:
+//     kFirstOut + (kMaxStepLog - 2) / 2 * kStepGrowth + kOddGrowth <= kNttBound;
+//   * the products and subtraction constants inside a step are sized for inputs up to kNttBound (their static type),
+//     which the induction above guarantees.
+constexpr int kNttBound = 48 * 64;
+constexpr int kNttIn = 128;               // fresh loads: canonical data, or a product with a coset / shift table (< 2 p)
+constexpr int kNttFirstOut = 9 * 64;      // first radix-4 step (three trivial twiddles): sums of four fresh loads
+constexpr int kNttStepGrowth = 6 * 64 + 32;   // a later radix-4 step: x + t, then x - t + 3 p, twice (t a product < 1.5 p)
+constexpr int kNttOddGrowth = 3 * 64 + 32;    // the odd last level: x - t + 3 p
+static_assert(kNttFirstOut + (int)((kMaxStepLog - 2) / 2) * kNttStepGrowth + kNttOddGrowth <= kNttBound,
+              "NTT tile bound: a pass of kMaxStepLog levels can exceed kNttBound");
 
 template <class F>
 __global__ void __launch_bounds__(256) ntt_step_kernel(StepArgs<F> p) {
@@ -74,7 +86,9 @@ __global__ void __launch_bounds__(256) ntt_step_kernel(StepArgs<F> p) {
   using El = Fe<P, kNttBound, 1>;
   using Tw = Fe<P, 64, 1>;
   __shared__ uint32_t tile_w[kTile * N];                               // [element][limb]: stride 9 words, conflict-free
-  __shared__ uint32_t tw_w[(1u << (kMaxStepLog - 1)) * N];            // w_{2^s}^t, t < 2^(s-1): this step's butterflies
+  constexpr int NLW = T::NL;                                           // packed words per element (memory / table form)
+  __shared__ uint32_t tw_w[(1u << (kMaxStepLog - 1)) * NLW];          // w_{2^s}^t, t < 2^(s-1), packed: 36 + 16 KB of LDS
+                                                                       // = three workgroups per CU
   const unsigned tid = threadIdx.x;
   const unsigned s = p.s;
   const unsigned nj = 1u << s;
@@ -98,12 +112,7 @@ __global__ void __launch_bounds__(256) ntt_step_kernel(StepArgs<F> p) {
 #pragma unroll
     for (int j = 0; j < N; j++) tile_w[o + j] = v.l[j];
   };
-  auto ld_tw = [&](unsigned i) {
-    Tw v;
-#pragma unroll
-    for (int j = 0; j < N; j++) v.l[j] = tw_w[i * N + j];
-    return v;
-  };
+  auto ld_tw = [&](unsigned i) { return fe_from_words<P>(&tw_w[i * NLW]); };
   auto ld_packed = [&](const F* ptr) { return fe_from_words<P>(ptr->l); };   // a table entry (internal form) or data
 
   // tile origin
@@ -122,9 +131,9 @@ __global__ void __launch_bounds__(256) ntt_step_kernel(StepArgs<F> p) {
   // ---- stage this step's butterfly twiddles: w_{2^s}^t = small[t << (sm - s)] ----
   if (s >= 1)
     for (unsigned t = tid; t < (nj >> 1); t += 256) {
-      const Tw w = ld_packed(p.small + ((size_t)t << (p.sm - s)));
+      const F* w = p.small + ((size_t)t << (p.sm - s));
 #pragma unroll
-      for (int j = 0; j < N; j++) tw_w[t * N + j] = w.l[j];
+      for (int j = 0; j < NLW; j++) tw_w[t * NLW + j] = w->l[j];
     }
 
   // ---- load (bit-reversed rows so that in-place DIT yields natural order) ----
@@ -158,21 +167,28 @@ __global__ void __launch_bounds__(256) ntt_step_kernel(StepArgs<F> p) {
   if (s >= 2) {
     // first step: half = 1, k = 0 -- three of the four twiddles are 1 and the inputs are fresh loads (< 2 p: canonical
     // data, or the (1 + 3/64) p of a product with the coset table), so the sums are formed without products
-    using In = Fe<P, 128, 1>;
+    using In = Fe<P, kNttIn, 1>;
     const Tw w3 = ld_tw(1u << (s - 2));        // w_4^1
     for (unsigned q = tid; q < (elems >> 2); q += 256) {
       const unsigned t = q & (Tn - 1), pi = q >> log_t;
       const unsigned ia = (pi << (2 + log_t)) + t;
-      const In xa = ld_tile(ia).template unsafe_assume<128, 1>(), xb = ld_tile(ia + Tn).template unsafe_assume<128, 1>(),
-               xc = ld_tile(ia + 2 * Tn).template unsafe_assume<128, 1>(), xd = ld_tile(ia + 3 * Tn).template unsafe_assume<128, 1>();
+      // (the loads of this step are the fresh values the load phase stored: canonical, or < 2 p after the coset table)
+      const In xa = ld_tile(ia).template unsafe_assume<kNttIn, 1>(), xb = ld_tile(ia + Tn).template unsafe_assume<kNttIn, 1>(),
+               xc = ld_tile(ia + 2 * Tn).template unsafe_assume<kNttIn, 1>(), xd = ld_tile(ia + 3 * Tn).template unsafe_assume<kNttIn, 1>();
       const auto a1 = xa + xb;
       const auto b1 = xa - xb;
       const auto c1 = xc + xd;
       const auto te = (xc - xd) * w3;
-      st_tile(ia, norm(a1 + c1).template as<kNttBound, 1>());
-      st_tile(ia + 2 * Tn, norm(a1 - c1).template as<kNttBound, 1>());
-      st_tile(ia + Tn, norm(b1 + te).template as<kNttBound, 1>());
-      st_tile(ia + 3 * Tn, norm(b1 - te).template as<kNttBound, 1>());
+      const auto o0 = a1 + c1;
+      const auto o2 = a1 - c1;
+      const auto o1 = b1 + te;
+      const auto o3 = b1 - te;
+      static_assert(decltype(o0)::Bound <= kNttFirstOut && decltype(o1)::Bound <= kNttFirstOut &&
+                    decltype(o2)::Bound <= kNttFirstOut && decltype(o3)::Bound <= kNttFirstOut, "first radix-4 step bound");
+      st_tile(ia, norm(o0).template as<kNttBound, 1>());
+      st_tile(ia + 2 * Tn, norm(o2).template as<kNttBound, 1>());
+      st_tile(ia + Tn, norm(o1).template as<kNttBound, 1>());
+      st_tile(ia + 3 * Tn, norm(o3).template as<kNttBound, 1>());
     }
     __syncthreads();
     lv = 3;
@@ -195,11 +211,18 @@ __global__ void __launch_bounds__(256) ntt_step_kernel(StepArgs<F> p) {
       const auto d1 = xc - td;
       const auto tc = c1 * ld_tw(k << sh2);
       const auto te = d1 * ld_tw((k + half) << sh2);
-      // (see kNttBound: the static bound of each sum is within 6 p of El's; the true bound is tracked by the comment there)
-      st_tile(ia, norm(a1 + tc).template unsafe_assume<kNttBound, 1>());
-      st_tile(ia + 2 * st, norm(a1 - tc).template unsafe_assume<kNttBound, 1>());
-      st_tile(ia + st, norm(b1 + te).template unsafe_assume<kNttBound, 1>());
-      st_tile(ia + 3 * st, norm(b1 - te).template unsafe_assume<kNttBound, 1>());
+      // each output = one tile input + value-independent terms: the true bound grows by at most kNttStepGrowth (see kNttBound)
+      const auto o0 = a1 + tc;
+      const auto o2 = a1 - tc;
+      const auto o1 = b1 + te;
+      const auto o3 = b1 - te;
+      static_assert(decltype(o0)::Bound - kNttBound <= kNttStepGrowth && decltype(o1)::Bound - kNttBound <= kNttStepGrowth &&
+                    decltype(o2)::Bound - kNttBound <= kNttStepGrowth && decltype(o3)::Bound - kNttBound <= kNttStepGrowth,
+                    "radix-4 step growth");
+      st_tile(ia, norm(o0).template unsafe_assume<kNttBound, 1>());
+      st_tile(ia + 2 * st, norm(o2).template unsafe_assume<kNttBound, 1>());
+      st_tile(ia + st, norm(o1).template unsafe_assume<kNttBound, 1>());
+      st_tile(ia + 3 * st, norm(o3).template unsafe_assume<kNttBound, 1>());
     }
     __syncthreads();
   }
@@ -211,8 +234,12 @@ __global__ void __launch_bounds__(256) ntt_step_kernel(StepArgs<F> p) {
       const unsigned i0 = (k << log_t) + t, i1 = i0 + (half << log_t);
       const El x = ld_tile(i0);
       const auto ty = ld_tile(i1) * ld_tw(k);
-      st_tile(i0, norm(x + ty).template unsafe_assume<kNttBound, 1>());
-      st_tile(i1, norm(x - ty).template unsafe_assume<kNttBound, 1>());
+      const auto o0 = x + ty;
+      const auto o1 = x - ty;
+      static_assert(decltype(o0)::Bound - kNttBound <= kNttOddGrowth && decltype(o1)::Bound - kNttBound <= kNttOddGrowth,
+                    "odd level growth");
+      st_tile(i0, norm(o0).template unsafe_assume<kNttBound, 1>());
+      st_tile(i1, norm(o1).template unsafe_assume<kNttBound, 1>());
     }
     __syncthreads();
   }

@@ -201,6 +201,73 @@ static void msms_typed(dg16_ctx* ctx, Call& k0, Call& k1, Call& k2, const PkDev&
   const Affine<Fq>* fixed_g1 = (const Affine<Fq>*)pk.fixed;
   const Affine<Fq2>* fixed_g2 = (const Affine<Fq2>*)((const uint8_t*)pk.fixed + 4 * sizeof(Affine<Fq>));
 
+  static const bool overlap_sorts = [] { const char* e = getenv("DG16_SORT_OVERLAP"); return !(e && atoi(e) == 0); }();
+  if (!dist && overlap_sorts) {
+    // ---- single-GPU schedule (round 3): the two digit sorts leave the main stream --------------------------------
+    // A digit sort is ten small memory- and latency-bound launches (0.3 ms with the chip nearly idle).  Neither
+    // needs the main stream: the sort of w[1..] ++ [r, s, -rs] depends only on the assignment, so it runs on `side`
+    // underneath the h-polynomial (which now goes FIRST on main -- it needs nothing but a, b, c); the sort of h runs
+    // on `side` underneath the G2 accumulation.  Main: h-poly | B (G2) | A | B1 | L | H, only H's reduction exposed.
+    DG_HIP(hipStreamWaitEvent(side, ev[8], 0));
+    MsmSort st_ab = msm_sort_on<Fr, CT::SCALAR_BITS>(side, k1.c, sc_ab, n_ab + 3, mont, true, pk.c_ab);
+    DG_HIP(hipEventRecord(ev[13], side));
+    const Fr* h_scalars = h_in;
+    if (!h_given) {
+      Fr* h_dev = (Fr*)ws(k0.c, 3, rows * sizeof(Fr));
+      h_poly_launch(k0, CURVE, a_dev, b_dev, c_dev, log_m, h_dev);
+      h_scalars = h_dev + pk.h_lo;
+    }
+    DG_HIP(hipEventRecord(ev[14], main));
+    DG_HIP(hipStreamWaitEvent(side, ev[14], 0));
+    MsmSort st_h = msm_sort_on<Fr, CT::SCALAR_BITS>(side, k0.c, h_scalars, n_h, true, true, pk.c_h);
+    DG_HIP(hipEventRecord(ev[15], side));
+    MsmBuffers<Fq> buf_a = msm_buffers<Fq>(k0.c, st_ab.g);
+    MsmBuffers<Fq> buf_b1 = msm_buffers<Fq>(k1.c, st_ab.g);
+    MsmBuffers<Fq2> buf_b2 = msm_buffers<Fq2>(k2.c, st_ab.g);
+    MsmBuffers<Fq> buf_h = msm_buffers<Fq>(ctx->xws[0], st_h.g);
+    MsmBuffers<Fq> buf_l = msm_buffers<Fq>(ctx->xws[1], st_ab.g);
+    hipStream_t aux = ctx->aux[0];
+    DG_HIP(hipStreamWaitEvent(main, ev[13], 0));
+    DG_HIP(hipEventRecord(k2.c.ev[2], main));
+    msm_accumulate_phase<Fq2>(main, st_ab, buf_b2, pk.b2_q);
+    DG_HIP(hipEventRecord(k2.c.ev[3], main));
+    k2.c.ev_valid[1] = true;
+    DG_HIP(hipEventRecord(ev[2], main));
+    DG_HIP(hipStreamWaitEvent(side2, ev[2], 0));
+    msm_bucket_phase<Fq2>(side2, st_ab, buf_b2, false, res_b2);
+    hipLaunchKernelGGL(prover_stage1_g2_kernel<Fq2>, dim3(1), dim3(64), 0, side2, res_b2, fixed_g2, first_shard);
+    DG_HIP(hipEventRecord(ev[5], side2));
+    DG_HIP(hipEventRecord(k1.c.ev[2], main));
+    msm_accumulate_phase<Fq>(main, st_ab, buf_a, pk.a_q);
+    DG_HIP(hipEventRecord(k1.c.ev[3], main));
+    k1.c.ev_valid[1] = true;
+    DG_HIP(hipEventRecord(ev[0], main));
+    msm_accumulate_phase<Fq>(main, st_ab, buf_b1, pk.b1_q);
+    DG_HIP(hipEventRecord(ev[1], main));
+    DG_HIP(hipStreamWaitEvent(side, ev[0], 0));
+    msm_bucket_phase<Fq>(side, st_ab, buf_a, false, res_a);
+    DG_HIP(hipEventRecord(ev[12], side));
+    DG_HIP(hipStreamWaitEvent(aux, ev[1], 0));
+    msm_bucket_phase<Fq>(aux, st_ab, buf_b1, false, res_b1);
+    DG_HIP(hipStreamWaitEvent(aux, ev[12], 0));
+    hipLaunchKernelGGL((prover_stage1_g1_kernel<Fq, Fr>), dim3(2), dim3(64), 0, aux, rec, fixed_g1, r_s, (int)mont,
+                       first_shard);
+    DG_HIP(hipEventRecord(ev[10], aux));
+    msm_accumulate_phase<Fq>(main, st_ab, buf_l, pk.l_q);
+    DG_HIP(hipEventRecord(ev[6], main));
+    DG_HIP(hipStreamWaitEvent(main, ev[15], 0));
+    msm_accumulate_phase<Fq>(main, st_h, buf_h, pk.h_q);
+    // side (behind A's reduction): L's reduction hides behind H's accumulation; H's is the exposed tail
+    DG_HIP(hipStreamWaitEvent(side, ev[6], 0));
+    msm_bucket_phase<Fq>(side, st_ab, buf_l, false, res_l);
+    msm_bucket_phase<Fq>(main, st_h, buf_h, false, res_h);
+    DG_HIP(hipEventRecord(ev[7], side));
+    DG_HIP(hipStreamWaitEvent(main, ev[7], 0));           // A, L results
+    DG_HIP(hipStreamWaitEvent(main, ev[10], 0));          // B1 result, s*A, r*B1
+    DG_HIP(hipStreamWaitEvent(main, ev[5], 0));           // B result
+    DG_HIP(hipGetLastError());
+    return;
+  }
   // ONE digit sort for A, B1, B and L (same scalars w[1..] ++ [r, s, -rs]); its buffers live in channel 1
   MsmSort st_ab = msm_sort_on<Fr, CT::SCALAR_BITS>(main, k1.c, sc_ab, n_ab + 3, mont, true, pk.c_ab);
   MsmBuffers<Fq> buf_a = msm_buffers<Fq>(k0.c, st_ab.g);
