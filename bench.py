@@ -392,6 +392,8 @@ def main():
                     help="log2 size of the CPU baseline / parity instance when the timed one is larger")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--table-budget-gb", type=float, default=0.0,
+                    help="HBM budget of the key's window tables (dg16_ctx_set_table_budget); 0 = one row per window")
     ap.add_argument("--no-replicas", action="store_true",
                     help="N > 1: skip the secondary figure (N independent proofs, one whole key per GPU)")
     ap.add_argument("--transport", default="rccl", choices=["rccl", "torch", "python"],
@@ -431,6 +433,8 @@ def main():
     from dg16_amd.parallel import make_prover
 
     ctx = dg16_amd.Context(local_rank)
+    if args.table_budget_gb:
+        ctx.set_table_budget(int(args.table_budget_gb * 1e9))
     wl = Workload(ctx, dev, args.log_m, rank, world, curve=curve)
     # N > 1, --transport rccl: if librccl cannot be bound or a rank cannot join, ALL ranks fall back to
     # torch.distributed together (make_prover decides collectively); config.parallelism says which transport ran
@@ -521,7 +525,8 @@ def main():
                                % (curve.upper(), args.log_m, args.log_m, args.log_m),
                    "curve": curve, "log_domain": args.log_m,
                    "parallelism": prover.describe(), "rccl_ranks": rccl_ranks,
-                   "key_table_bytes": info["table_bytes"], "key_table_build_s": wl.pk_build_s,
+                   "key_table_bytes": info["table_bytes"], "key_table_stride": info["table_stride"],
+                   "key_table_build_s": wl.pk_build_s,
                    "key_window_bits": {"ab": info["c_ab"], "l": info["c_l"], "h": info["c_h"]}},
         "roofline": {"bound": "hbm", "kernel": g2_kernel + " (G2 bucket accumulation, table mode, inside the "
                      "timed proofs)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

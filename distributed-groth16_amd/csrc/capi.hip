@@ -265,6 +265,12 @@ int dg16_msm(dg16_ctx* ctx, int curve, int group, const void* bases, const void*
   });
 }
 
+int dg16_ctx_set_table_budget(dg16_ctx* ctx, uint64_t bytes) {
+  if (!ctx) return DG16_ERR_BAD_ARG;
+  ctx->table_budget = (size_t)bytes;
+  return DG16_OK;
+}
+
 int dg16_bases_upload(dg16_ctx* ctx, int curve, int group, const void* bases, size_t n, unsigned flags,
                       dg16_bases** out) {
   if (!ctx || !out) return DG16_ERR_BAD_ARG;
@@ -281,7 +287,7 @@ int dg16_bases_upload(dg16_ctx* ctx, int curve, int group, const void* bases, si
     h->curve = curve;
     h->group = group;
     h->n = n;
-    h->table = bases_table_launch(k, curve, group, d, n, &h->c, &h->nwin);
+    h->table = bases_table_launch(k, curve, group, d, n, ctx->table_budget, &h->c, &h->nwin, &h->stride);
     h->bytes = (size_t)h->nwin * (n ? n : 1) * pb;
     k.finish();
     DG_HIP(hipStreamSynchronize(k.s()));     // the caller may free `bases` on return
@@ -325,7 +331,8 @@ int dg16_msm_resident(dg16_ctx* ctx, const dg16_bases* h, const void* scalars, s
     Call k(ctx, channel);
     const void* ds = stage_in(k, 1, scalars, n_scalars * 32, dev);
     void* dout = dev ? out : ws(k.c, 2, ob);
-    msm_resident_launch(k, h->curve, h->group, h->table, h->n, h->c, ds, flags & DG16_F_SCALARS_MONT, aff, dout);
+    msm_resident_launch(k, h->curve, h->group, h->table, h->n, h->c, h->stride, ds, flags & DG16_F_SCALARS_MONT, aff,
+                        dout);
     if (!dev) stage_out(k, out, dout, ob, false);
     k.finish();
     if (!dev) DG_HIP(hipStreamSynchronize(k.s()));

@@ -70,6 +70,9 @@ struct dg16_ctx {
   // bits into it, dg16_sync reads it after the stream has drained).  bit 0: dg16_qap index out of range.
   unsigned* dev_flag_host = nullptr;
   unsigned* dev_flag = nullptr;
+  // HBM budget of the window tables of ONE resident key / base set built from here on (dg16_ctx_set_table_budget);
+  // 0 = unlimited (one table row per window)
+  size_t table_budget = 0;
   std::map<dg16::TwiddleKey, dg16::TwiddleSet> twiddles;
 };
 
@@ -77,7 +80,8 @@ struct dg16_bases {          // resident bases: table of window multiples (dg16_
   dg16_ctx* ctx = nullptr;
   int curve = 0, group = 1;
   size_t n = 0;
-  unsigned c = 0, nwin = 0;
+  unsigned c = 0, nwin = 0;     // window bits; table rows
+  unsigned stride = 1;          // the table keeps every stride-th window's row (1 = all)
   void* table = nullptr;
   size_t bytes = 0;
 };
@@ -209,9 +213,10 @@ void msm_launch(Call& k, int curve, int group, const void* bases, const void* sc
                 bool scalars_mont, bool out_affine, void* out_dev);
 void gen_bases_launch(Call& k, int curve, int group, uint64_t seed, size_t n, void* out_dev);
 void to_affine_launch(Call& k, int curve, int group, const void* jac, void* out, size_t n);
-void* bases_table_launch(Call& k, int curve, int group, const void* bases, size_t n, unsigned* c, unsigned* nwin);
-void msm_resident_launch(Call& k, int curve, int group, const void* table, size_t n, unsigned c, const void* scalars,
-                         bool mont, bool affine, void* out);
+void* bases_table_launch(Call& k, int curve, int group, const void* bases, size_t n, size_t budget, unsigned* c,
+                         unsigned* rows, unsigned* stride);
+void msm_resident_launch(Call& k, int curve, int group, const void* table, size_t n, unsigned c, unsigned stride,
+                         const void* scalars, bool mont, bool affine, void* out);
 size_t fq_bytes(int curve);
 size_t affine_bytes(int curve, int group);
 

@@ -305,7 +305,7 @@ static void pss_build(dg16_pss* pp) {
 namespace dg16 {
 #define DECL_G(name)                                                                                         \
   void d_msm_##name(Call&, const dg16_pss*, const dg16_net*, int, const void*, const void*, size_t, bool, void*,   \
-                    const void*, unsigned);                                                                       \
+                    const void*, unsigned, unsigned);                                                                       \
   void packexp_##name(Call&, const dg16_pss*, int, const void*, size_t, void*);                                   \
   void mpc_combine_##name(Call&, const void*, const void*, unsigned, unsigned, bool, void*);                      \
   void affine_to_jac_##name(Call&, const void*, void*);
@@ -453,7 +453,7 @@ int dg16_d_msm(dg16_ctx* ctx, const dg16_pss* pp, const dg16_net* net, int group
     const void* dscal = stage_in(k, 1, scalars, n_bases * 32, dev);
     void* dout = dev ? out : ws(k.c, 2, pb / 2 * 3);
     DISPATCH_G(d_msm, pp->curve, group, k, pp, net, channel, dbases, dscal, n_bases, flags & DG16_F_SCALARS_MONT, dout,
-               nullptr, 0u)
+               nullptr, 0u, 1u)
     if (!dev) stage_out(k, out, dout, pb / 2 * 3, false);
     k.finish();
     if (!dev) DG_HIP(hipStreamSynchronize(k.s()));
@@ -476,7 +476,7 @@ int dg16_d_msm_resident(dg16_ctx* ctx, const dg16_pss* pp, const dg16_net* net, 
     const void* dscal = stage_in(k, 1, scalars, n_scalars * 32, dev);
     void* dout = dev ? out : ws(k.c, 2, pb / 2 * 3);
     DISPATCH_G(d_msm, pp->curve, bases->group, k, pp, net, channel, nullptr, dscal, n_scalars,
-               flags & DG16_F_SCALARS_MONT, dout, bases->table, bases->c)
+               flags & DG16_F_SCALARS_MONT, dout, bases->table, bases->c, bases->stride)
     if (!dev) stage_out(k, out, dout, pb / 2 * 3, false);
     k.finish();
     if (!dev) DG_HIP(hipStreamSynchronize(k.s()));
@@ -638,7 +638,7 @@ static void d_msm_on_channel(dg16_ctx* ctx, const dg16_pss* pp, const dg16_net* 
   const void* dbases = stage_in(k, 0, bases, n_bases * pb, dev);
   const void* dscal = stage_in(k, 1, scalars, n_bases * 32, dev);
   DISPATCH_G(d_msm, pp->curve, group, k, pp, net, channel, dbases, dscal, n_bases, flags & DG16_F_SCALARS_MONT, out_dev,
-             nullptr, 0u)
+             nullptr, 0u, 1u)
   k.finish();
   DG_HIP(hipStreamSynchronize(k.s()));     // the caller combines on another channel's stream
 }

@@ -7,8 +7,8 @@ namespace dg16 {
   void msm_##name(Call&, const void*, const void*, size_t, bool, bool, void*);                  \
   void gen_bases_##name(Call&, uint64_t, size_t, void*);                                        \
   void to_affine_##name(Call&, const void*, void*, size_t);                                     \
-  void* bases_table_##name(Call&, const void*, size_t, unsigned*, unsigned*);                   \
-  void msm_resident_##name(Call&, const void*, size_t, unsigned, const void*, bool, bool, void*);
+  void* bases_table_##name(Call&, const void*, size_t, size_t, unsigned*, unsigned*, unsigned*); \
+  void msm_resident_##name(Call&, const void*, size_t, unsigned, unsigned, const void*, bool, bool, void*);
 DECL(bn254_g1) DECL(bn254_g2) DECL(bls12_381_g1) DECL(bls12_381_g2) DECL(bls12_377_g1) DECL(bls12_377_g2)
 
 #define DISPATCH(fn, ...)                                                                       \
@@ -32,21 +32,22 @@ void gen_bases_launch(Call& k, int curve, int group, uint64_t seed, size_t n, vo
 void to_affine_launch(Call& k, int curve, int group, const void* jac, void* out, size_t n) {
   DISPATCH(to_affine, k, jac, out, n)
 }
-void* bases_table_launch(Call& k, int curve, int group, const void* bases, size_t n, unsigned* c, unsigned* nwin) {
+void* bases_table_launch(Call& k, int curve, int group, const void* bases, size_t n, size_t budget, unsigned* c,
+                         unsigned* nwin, unsigned* stride) {
   void* t = nullptr;
   switch (curve * 2 + group - 1) {
-    case 0: t = bases_table_bn254_g1(k, bases, n, c, nwin); break;
-    case 1: t = bases_table_bn254_g2(k, bases, n, c, nwin); break;
-    case 2: t = bases_table_bls12_381_g1(k, bases, n, c, nwin); break;
-    case 3: t = bases_table_bls12_381_g2(k, bases, n, c, nwin); break;
-    case 4: t = bases_table_bls12_377_g1(k, bases, n, c, nwin); break;
-    case 5: t = bases_table_bls12_377_g2(k, bases, n, c, nwin); break;
+    case 0: t = bases_table_bn254_g1(k, bases, n, budget, c, nwin, stride); break;
+    case 1: t = bases_table_bn254_g2(k, bases, n, budget, c, nwin, stride); break;
+    case 2: t = bases_table_bls12_381_g1(k, bases, n, budget, c, nwin, stride); break;
+    case 3: t = bases_table_bls12_381_g2(k, bases, n, budget, c, nwin, stride); break;
+    case 4: t = bases_table_bls12_377_g1(k, bases, n, budget, c, nwin, stride); break;
+    case 5: t = bases_table_bls12_377_g2(k, bases, n, budget, c, nwin, stride); break;
     default: throw StatusError{DG16_ERR_BAD_ARG, "unknown (curve, group)"};
   }
   return t;
 }
-void msm_resident_launch(Call& k, int curve, int group, const void* table, size_t n, unsigned c, const void* scalars,
-                         bool mont, bool affine, void* out) {
-  DISPATCH(msm_resident, k, table, n, c, scalars, mont, affine, out)
+void msm_resident_launch(Call& k, int curve, int group, const void* table, size_t n, unsigned c, unsigned stride,
+                         const void* scalars, bool mont, bool affine, void* out) {
+  DISPATCH(msm_resident, k, table, n, c, stride, scalars, mont, affine, out)
 }
 }  // namespace dg16

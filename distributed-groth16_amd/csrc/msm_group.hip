@@ -23,7 +23,8 @@ using GC = CT::G2c;
 template void msm_accumulate_phase<GF>(hipStream_t, const MsmSort&, const MsmBuffers<GF>&, const void*);
 template void msm_finalize_phase<GF>(hipStream_t, const MsmSort&, const MsmBuffers<GF>&);
 template void* msm_build_table<GF>(hipStream_t, const void*, size_t, unsigned, unsigned);
-template MsmSort msm_sort_on<CT::Fr, CT::SCALAR_BITS>(hipStream_t, Channel&, const void*, size_t, bool, bool, unsigned);
+template MsmSort msm_sort_on<CT::Fr, CT::SCALAR_BITS>(hipStream_t, Channel&, const void*, size_t, bool, bool, unsigned,
+                                                      unsigned);
 
 void DG_FN(msm_)(Call& k, const void* bases, const void* scalars, size_t n, bool mont, bool affine, void* out) {
   msm_run<GF, CT::Fr, CT::SCALAR_BITS>(k, bases, scalars, n, mont, affine, out);
@@ -31,18 +32,23 @@ void DG_FN(msm_)(Call& k, const void* bases, const void* scalars, size_t n, bool
 void DG_FN(gen_bases_)(Call& k, uint64_t seed, size_t n, void* out) { gen_bases_run<GF, GC>(k, seed, n, out); }
 void DG_FN(to_affine_)(Call& k, const void* jac, void* out, size_t n) { to_affine_run<GF>(k, jac, out, n); }
 
-// resident bases: the table of window multiples (internal form) for n points; c and the window count come back
-void* DG_FN(bases_table_)(Call& k, const void* bases_dev, size_t n, unsigned* c_out, unsigned* nwin_out) {
+// resident bases: the table of window multiples (internal form) for n points; c and the row count come back.
+// budget != 0: at most that many bytes -- the table keeps every stride-th row (msm_geometry) so that it fits
+void* DG_FN(bases_table_)(Call& k, const void* bases_dev, size_t n, size_t budget, unsigned* c_out, unsigned* rows_out,
+                          unsigned* stride_out) {
   const unsigned c = msm_window_bits(n ? n : 1, true);
   const unsigned nwin = (CT::SCALAR_BITS + 1 + c - 1) / c;
+  const unsigned stride = table_stride_for((size_t)nwin * (n ? n : 1) * sizeof(Affine<GF>), budget, nwin);
+  const unsigned rows = (nwin + stride - 1) / stride;
   *c_out = c;
-  *nwin_out = nwin;
-  return msm_build_table<GF>(k.s(), bases_dev, n, c, nwin);
+  *rows_out = rows;
+  *stride_out = stride;
+  return msm_build_table<GF>(k.s(), bases_dev, n, c * stride, rows);
 }
-// MSM over a resident table: one digit sort in table mode, one bucket set, no Horner tail
-void DG_FN(msm_resident_)(Call& k, const void* table, size_t n, unsigned c, const void* scalars, bool mont, bool affine,
-                          void* out) {
-  MsmSort st = msm_sort<CT::Fr, CT::SCALAR_BITS>(k, scalars, n, mont, true, c);
+// MSM over a resident table: one digit sort in table mode; stride 1: one bucket set, no Horner tail
+void DG_FN(msm_resident_)(Call& k, const void* table, size_t n, unsigned c, unsigned stride, const void* scalars,
+                          bool mont, bool affine, void* out) {
+  MsmSort st = msm_sort<CT::Fr, CT::SCALAR_BITS>(k, scalars, n, mont, true, c, stride);
   msm_reduce<GF>(k, st, table, affine, out);
 }
 
@@ -51,13 +57,13 @@ void DG_FN(msm_resident_)(Call& k, const void* table, size_t n, unsigned c, cons
 // the constant scalars v_j = sum_i unpack2[i][j] -- then sends the same point to every party.
 // (table != nullptr: the base shares are resident, `bases` is unused)
 void DG_FN(d_msm_)(Call& k, const dg16_pss* pp, const dg16_net* net, int sid, const void* bases, const void* scalars,
-                   size_t n, bool mont, void* out_jac, const void* table, unsigned table_c) {
+                   size_t n, bool mont, void* out_jac, const void* table, unsigned table_c, unsigned table_stride) {
   using F = GF;
   using Fr = CT::Fr;
   const unsigned np = pp->n;
   Affine<F>* c_share = (Affine<F>*)ws(k.c, 18, sizeof(Affine<F>));
   if (table)
-    DG_FN(msm_resident_)(k, table, n, table_c, scalars, mont, true, c_share);
+    DG_FN(msm_resident_)(k, table, n, table_c, table_stride, scalars, mont, true, c_share);
   else
     msm_run<F, Fr, CT::SCALAR_BITS>(k, bases, scalars, n, mont, true, c_share);        // dmsm/mod.rs:82
   const bool king = net->party_id(net->self) == 0;

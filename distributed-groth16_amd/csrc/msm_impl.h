@@ -49,9 +49,11 @@ struct MsmGeom {
   unsigned log_nb;   // log2 buckets per bucket-window = c - 1
   unsigned seg_log;  // log2 entries per accumulation segment
   unsigned seg_cap;  // segment slots per bucket-window
-  unsigned bw;       // bucket-windows: W, or 1 in table mode (all digits share one bucket set)
-  unsigned table;    // 1: bases are a table T[w*n + i] = 2^(c*w) * P_i (resident keys)
-  size_t region;     // entries per bucket-window: n, or W*n in table mode
+  unsigned bw;       // bucket-windows: W (plain), 1 (full table: all digits share one bucket set), or the row stride
+                     // k of a table thinned to every k-th row (window w feeds bucket-window w % k through row w / k)
+  unsigned table;    // 1: bases are a table T[r*n + i] = 2^(c*bw*r) * P_i (resident keys)
+  unsigned rows;     // table rows R = ceil(W / bw) (1 in plain mode)
+  size_t region;     // entries per bucket-window: rows * n
 };
 
 // window size: plain mode keeps ~32 points per bucket; table mode has a single bucket set of W*n entries:
@@ -73,14 +75,20 @@ inline unsigned msm_window_bits(size_t n, bool table) {
   return (unsigned)c;
 }
 
-inline MsmGeom msm_geometry(size_t n, unsigned scalar_bits, bool table = false, unsigned c_fixed = 0) {
+// stride (table mode): 1 = every window has its table row; k > 1 = the table keeps every k-th row (HBM budget) and the
+// MSM has k bucket sets combined by a Horner tail of (k - 1) * c doublings:
+//   sum_w d_w 2^(c w) P = sum_{j < k} 2^(c j) sum_r d_{k r + j} (2^(c k r) P)
+inline MsmGeom msm_geometry(size_t n, unsigned scalar_bits, bool table = false, unsigned c_fixed = 0, unsigned stride = 1) {
   MsmGeom g;
   g.c = c_fixed ? c_fixed : msm_window_bits(n, table);
   g.nwin = (scalar_bits + 1 + g.c - 1) / g.c;   // one spare bit absorbs the last carry
   g.log_nb = g.c - 1;
   g.table = table ? 1u : 0u;
-  g.bw = table ? 1u : g.nwin;
-  g.region = table ? (size_t)g.nwin * n : n;
+  if (stride < 1) stride = 1;
+  if (stride > g.nwin) stride = g.nwin;
+  g.bw = table ? stride : g.nwin;
+  g.rows = (g.nwin + g.bw - 1) / g.bw;
+  g.region = (size_t)g.rows * n;
   {
     size_t mean = g.region >> g.log_nb;   // entries per bucket
     unsigned lm = 0;
@@ -157,7 +165,7 @@ __global__ void __launch_bounds__(256) msm_digits_kernel(const Fr* __restrict__ 
     if ((unsigned)d > half) { d -= (int)(1u << c); carry = 1; } else { carry = 0; }
     if (live) digits[(size_t)w * n + i] = d;
     unsigned b = d ? (unsigned)(d < 0 ? -d : d) - 1 : 0u;
-    unsigned slot = (g.table ? 0u : (w << g.log_nb)) + b;
+    unsigned slot = ((w % g.bw) << g.log_nb) + b;
     wave_atomic_inc(counts, slot, live && d != 0);
   }
 }
@@ -268,11 +276,11 @@ __global__ void __launch_bounds__(256) msm_scatter_kernel(const int* __restrict_
     int d = live ? digits[(size_t)w * n + i] : 0;
     const bool act = d != 0;
     unsigned b = act ? (unsigned)(d < 0 ? -d : d) - 1 : 0u;
-    const unsigned bwin = g.table ? 0u : w;
+    const unsigned bwin = w % g.bw;
     unsigned slot = (bwin << g.log_nb) + b;
     unsigned rank = wave_atomic_inc(cursor, slot, act);
     if (!act) continue;
-    unsigned ref = g.table ? (unsigned)((size_t)w * n + i) : (unsigned)i;   // table row 2^(c*w) * P_i
+    unsigned ref = (unsigned)((size_t)(w / g.bw) * n + i);   // table row w / bw = 2^(c*bw*(w/bw)) * P_i (plain: row 0)
     entries[(size_t)bwin * g.region + offsets[slot] + rank] = ref | (d < 0 ? 0x80000000u : 0u);
   }
 }
@@ -328,7 +336,7 @@ __global__ void __launch_bounds__(256) msm_part_hist_kernel(const Fr* __restrict
     for (unsigned w = 0; w < g.nwin; w++) {
       int d = msm_digit(s, w, g.c, carry);
       if (d == 0) continue;
-      unsigned slot = (g.table ? 0u : (w << g.log_nb)) + (unsigned)(d < 0 ? -d : d) - 1;
+      unsigned slot = ((w % g.bw) << g.log_nb) + (unsigned)(d < 0 ? -d : d) - 1;
       atomicAdd(&hist[slot >> pg.low_bits], 1u);
     }
   }
@@ -353,8 +361,8 @@ __global__ void __launch_bounds__(256) msm_part_scatter_kernel(const Fr* __restr
     for (unsigned w = 0; w < g.nwin; w++) {
       int d = msm_digit(s, w, g.c, carry);
       if (d == 0) continue;
-      unsigned slot = (g.table ? 0u : (w << g.log_nb)) + (unsigned)(d < 0 ? -d : d) - 1;
-      unsigned ref = g.table ? (unsigned)((size_t)w * n + i) : (unsigned)i;   // table row 2^(c*w) * P_i
+      unsigned slot = ((w % g.bw) << g.log_nb) + (unsigned)(d < 0 ? -d : d) - 1;
+      unsigned ref = (unsigned)((size_t)(w / g.bw) * n + i);   // table row w / bw (plain mode: bw = W, row 0)
       unsigned pos = atomicAdd(&cur[slot >> pg.low_bits], 1u);
       part[pos] = make_uint2(ref | (d < 0 ? 0x80000000u : 0u), slot);
     }
@@ -803,18 +811,19 @@ struct MsmSort {
 
 template <class Fr, int SCALAR_BITS>
 MsmSort msm_sort_on(hipStream_t s, Channel& wsch, const void* scalars, size_t n, bool scalars_mont, bool table,
-                    unsigned c_fixed);
+                    unsigned c_fixed, unsigned stride);
 template <class Fr, int SCALAR_BITS>
-MsmSort msm_sort(Call& k, const void* scalars, size_t n, bool scalars_mont, bool table, unsigned c_fixed = 0) {
-  return msm_sort_on<Fr, SCALAR_BITS>(k.s(), k.c, scalars, n, scalars_mont, table, c_fixed);
+MsmSort msm_sort(Call& k, const void* scalars, size_t n, bool scalars_mont, bool table, unsigned c_fixed = 0,
+                 unsigned stride = 1) {
+  return msm_sort_on<Fr, SCALAR_BITS>(k.s(), k.c, scalars, n, scalars_mont, table, c_fixed, stride);
 }
 // sort on stream `s` with the buffers of channel `wsch`
 template <class Fr, int SCALAR_BITS>
 MsmSort msm_sort_on(hipStream_t s, Channel& wsch, const void* scalars, size_t n, bool scalars_mont, bool table,
-                    unsigned c_fixed) {
+                    unsigned c_fixed, unsigned stride) {
   MsmSort r;
   r.n = n;
-  r.g = msm_geometry(n ? n : 1, SCALAR_BITS, table, c_fixed);
+  r.g = msm_geometry(n ? n : 1, SCALAR_BITS, table, c_fixed, stride);
   const MsmGeom& g = r.g;
   const size_t nbw = (size_t)g.bw << g.log_nb;
   DG_REQUIRE((size_t)g.nwin * n < ((size_t)1 << 31), DG16_ERR_BAD_ARG, "W * n must be < 2^31");
@@ -1087,7 +1096,8 @@ void msm_run(Call& k, const void* bases, const void* scalars, size_t n, bool sca
   msm_reduce<F>(k, st, internal, out_affine, out_dev);
 }
 
-// ---- table of window multiples for resident bases: T[w*n + i] = 2^(c*w) * P_i (affine) -----------------
+// ---- table of window multiples for resident bases: T[r*n + i] = 2^(c_step*r) * P_i (affine), r < rows -----------
+// (c_step = c * stride: a full table has stride 1 and one row per window; a thinned one keeps every stride-th row)
 constexpr unsigned kMaxTableWin = 64;
 template <class F>
 __global__ void __launch_bounds__(64) msm_table_kernel(const Affine<F>* __restrict__ bases, size_t n, unsigned c,
@@ -1124,6 +1134,15 @@ __global__ void __launch_bounds__(64) msm_table_kernel(const Affine<F>* __restri
   }
 }
 
+// Row stride of a table under an HBM budget: the smallest k such that ceil(nwin / k) rows fit (0 = no budget -> 1).
+inline unsigned table_stride_for(size_t full_bytes, size_t budget, unsigned nwin) {
+  if (!budget || full_bytes <= budget || nwin <= 1) return 1;
+  const size_t row = full_bytes / nwin;
+  size_t rows_fit = budget / (row ? row : 1);
+  if (rows_fit < 1) rows_fit = 1;                         // (one row -- the bases themselves -- is the floor)
+  unsigned k = (unsigned)((nwin + rows_fit - 1) / rows_fit);
+  return k < 1 ? 1 : k > nwin ? nwin : k;
+}
 // returns a device table of nwin*n affine points (caller owns it) for window size c
 template <class F>
 void* msm_build_table(hipStream_t s, const void* bases, size_t n, unsigned c, unsigned nwin) {
@@ -1252,5 +1271,5 @@ void to_affine_run(Call& k, const void* jac, void* out, size_t n) {
   DG16_MSM_EXTERN_GROUP(CT::Fq)                                                                                   \
   DG16_MSM_EXTERN_GROUP(CT::Fq2)                                                                                  \
   extern template MsmSort msm_sort_on<CT::Fr, CT::SCALAR_BITS>(hipStream_t, Channel&, const void*, size_t, bool, bool, \
-                                                              unsigned);
+                                                              unsigned, unsigned);
 

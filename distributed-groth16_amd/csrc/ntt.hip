@@ -87,8 +87,11 @@ __global__ void __launch_bounds__(256) ntt_step_kernel(StepArgs<F> p) {
   using Tw = Fe<P, 64, 1>;
   __shared__ uint32_t tile_w[kTile * N];                               // [element][limb]: stride 9 words, conflict-free
   constexpr int NLW = T::NL;                                           // packed words per element (memory / table form)
-  __shared__ uint32_t tw_w[(1u << (kMaxStepLog - 1)) * NLW];          // w_{2^s}^t, t < 2^(s-1), packed: 36 + 16 KB of LDS
-                                                                       // = three workgroups per CU
+  // w_{2^s}^t, t < 2^(s-1): this step's butterfly twiddles.  16 KB next to the 36 KB tile = three workgroups per CU.
+  // 2^9 twiddles (s = 10) only fit PACKED (8 words each, unpacked on every read: ~25 VALU next to a 200-instruction
+  // product); up to 2^8 (s <= 9) are staged unpacked, 9 limbs each.
+  __shared__ uint32_t tw_w[(1u << (kMaxStepLog - 1)) * NLW];
+  static_assert((1u << (kMaxStepLog - 2)) * N <= (1u << (kMaxStepLog - 1)) * NLW, "unpacked twiddles of the shorter steps fit");
   const unsigned tid = threadIdx.x;
   const unsigned s = p.s;
   const unsigned nj = 1u << s;
@@ -112,7 +115,14 @@ __global__ void __launch_bounds__(256) ntt_step_kernel(StepArgs<F> p) {
 #pragma unroll
     for (int j = 0; j < N; j++) tile_w[o + j] = v.l[j];
   };
-  auto ld_tw = [&](unsigned i) { return fe_from_words<P>(&tw_w[i * NLW]); };
+  const bool tw_packed = p.s == kMaxStepLog;
+  auto ld_tw = [&](unsigned i) {
+    if (tw_packed) return fe_from_words<P>(&tw_w[i * NLW]);
+    Tw v;
+#pragma unroll
+    for (int j = 0; j < N; j++) v.l[j] = tw_w[i * N + j];
+    return v;
+  };
   auto ld_packed = [&](const F* ptr) { return fe_from_words<P>(ptr->l); };   // a table entry (internal form) or data
 
   // tile origin
@@ -132,8 +142,14 @@ __global__ void __launch_bounds__(256) ntt_step_kernel(StepArgs<F> p) {
   if (s >= 1)
     for (unsigned t = tid; t < (nj >> 1); t += 256) {
       const F* w = p.small + ((size_t)t << (p.sm - s));
+      if (tw_packed) {
 #pragma unroll
-      for (int j = 0; j < NLW; j++) tw_w[t * NLW + j] = w->l[j];
+        for (int j = 0; j < NLW; j++) tw_w[t * NLW + j] = w->l[j];
+      } else {
+        const Tw u = ld_packed(w);
+#pragma unroll
+        for (int j = 0; j < N; j++) tw_w[t * N + j] = u.l[j];
+      }
     }
 
   // ---- load (bit-reversed rows so that in-place DIT yields natural order) ----

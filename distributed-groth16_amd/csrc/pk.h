@@ -23,6 +23,7 @@ struct PkDev {
   // B: [0, delta_g2, 0]; L: [0, 0, delta_g1]) so the FOUR MSMs share ONE scalar vector w[1..] ++ [r, s, -rs] and one
   // digit sort; l_q holds the identity where the slice position is a public input (l_lo, l_hi: the l_query range).
   unsigned c_ab = 0, c_l = 0, c_h = 0;   // window bits the tables were built for
+  unsigned stride = 1;                   // the tables keep every stride-th window's row (HBM budget; 1 = all rows)
   size_t table_bytes = 0;                // HBM held by the five tables
 };
 

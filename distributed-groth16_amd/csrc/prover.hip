@@ -80,6 +80,7 @@ int dg16_pk_info_get(const dg16_pk* pk, dg16_pk_info* out) {
   out->shard = d.shard;
   out->n_shards = d.nshards;
   out->table_bytes = d.table_bytes;
+  out->table_stride = d.stride;
   return DG16_OK;
 }
 

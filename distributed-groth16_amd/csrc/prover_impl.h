@@ -209,7 +209,7 @@ static void msms_typed(dg16_ctx* ctx, Call& k0, Call& k1, Call& k2, const PkDev&
     // underneath the h-polynomial (which now goes FIRST on main -- it needs nothing but a, b, c); the sort of h runs
     // on `side` underneath the G2 accumulation.  Main: h-poly | B (G2) | A | B1 | L | H, only H's reduction exposed.
     DG_HIP(hipStreamWaitEvent(side, ev[8], 0));
-    MsmSort st_ab = msm_sort_on<Fr, CT::SCALAR_BITS>(side, k1.c, sc_ab, n_ab + 3, mont, true, pk.c_ab);
+    MsmSort st_ab = msm_sort_on<Fr, CT::SCALAR_BITS>(side, k1.c, sc_ab, n_ab + 3, mont, true, pk.c_ab, pk.stride);
     DG_HIP(hipEventRecord(ev[13], side));
     const Fr* h_scalars = h_in;
     if (!h_given) {
@@ -219,7 +219,7 @@ static void msms_typed(dg16_ctx* ctx, Call& k0, Call& k1, Call& k2, const PkDev&
     }
     DG_HIP(hipEventRecord(ev[14], main));
     DG_HIP(hipStreamWaitEvent(side, ev[14], 0));
-    MsmSort st_h = msm_sort_on<Fr, CT::SCALAR_BITS>(side, k0.c, h_scalars, n_h, true, true, pk.c_h);
+    MsmSort st_h = msm_sort_on<Fr, CT::SCALAR_BITS>(side, k0.c, h_scalars, n_h, true, true, pk.c_h, pk.stride);
     DG_HIP(hipEventRecord(ev[15], side));
     MsmBuffers<Fq> buf_a = msm_buffers<Fq>(k0.c, st_ab.g);
     MsmBuffers<Fq> buf_b1 = msm_buffers<Fq>(k1.c, st_ab.g);
@@ -269,7 +269,7 @@ static void msms_typed(dg16_ctx* ctx, Call& k0, Call& k1, Call& k2, const PkDev&
     return;
   }
   // ONE digit sort for A, B1, B and L (same scalars w[1..] ++ [r, s, -rs]); its buffers live in channel 1
-  MsmSort st_ab = msm_sort_on<Fr, CT::SCALAR_BITS>(main, k1.c, sc_ab, n_ab + 3, mont, true, pk.c_ab);
+  MsmSort st_ab = msm_sort_on<Fr, CT::SCALAR_BITS>(main, k1.c, sc_ab, n_ab + 3, mont, true, pk.c_ab, pk.stride);
   MsmBuffers<Fq> buf_a = msm_buffers<Fq>(k0.c, st_ab.g);
   MsmBuffers<Fq> buf_b1 = msm_buffers<Fq>(k1.c, st_ab.g);
   MsmBuffers<Fq2> buf_b2 = msm_buffers<Fq2>(k2.c, st_ab.g);
@@ -353,7 +353,7 @@ static void msms_typed(dg16_ctx* ctx, Call& k0, Call& k1, Call& k2, const PkDev&
     }
     h_scalars = dist ? h_dev : h_dev + pk.h_lo;
   }
-  MsmSort st_h = msm_sort_on<Fr, CT::SCALAR_BITS>(main, k0.c, h_scalars, n_h, true, true, pk.c_h);
+  MsmSort st_h = msm_sort_on<Fr, CT::SCALAR_BITS>(main, k0.c, h_scalars, n_h, true, true, pk.c_h, pk.stride);
   // H and L own their bucket buffers (288 GB of HBM: a few MB more beat waiting for A's / B1's reductions)
   MsmBuffers<Fq> buf_h = msm_buffers<Fq>(ctx->xws[0], st_h.g);
   MsmBuffers<Fq> buf_l = msm_buffers<Fq>(ctx->xws[1], st_ab.g);
@@ -514,13 +514,23 @@ static void pk_build(dg16_ctx* ctx, PkDev& d, const void* a_query, const void* b
     d.c_ab = msm_window_bits(n_ab + 3, true);
     d.c_l = d.c_ab;
     d.c_h = msm_window_bits(n_h ? n_h : 1, true);
-    d.a_q = msm_build_table<Fq>(nullptr, a_plain, n_ab + 3, d.c_ab, nwin_of(d.c_ab));
-    d.b1_q = msm_build_table<Fq>(nullptr, b1_plain, n_ab + 3, d.c_ab, nwin_of(d.c_ab));
-    d.b2_q = msm_build_table<Fq2>(nullptr, b2_plain, n_ab + 3, d.c_ab, nwin_of(d.c_ab));
-    d.l_q = msm_build_table<Fq>(nullptr, l_plain, n_ab + 3, d.c_ab, nwin_of(d.c_ab));
-    d.h_q = msm_build_table<Fq>(nullptr, h_plain, n_h, d.c_h, nwin_of(d.c_h));
-    d.table_bytes = (size_t)nwin_of(d.c_ab) * (n_ab + 3) * (3 * p1 + p2) +
-                    (size_t)nwin_of(d.c_h) * (n_h ? n_h : 1) * p1;
+    // HBM budget (dg16_ctx_set_table_budget): one row stride for all five tables -- A, B1, B and L share a digit sort
+    const size_t full_bytes = (size_t)nwin_of(d.c_ab) * (n_ab + 3) * (3 * p1 + p2) +
+                              (size_t)nwin_of(d.c_h) * (n_h ? n_h : 1) * p1;
+    const unsigned wmin = nwin_of(d.c_ab) < nwin_of(d.c_h) ? nwin_of(d.c_ab) : nwin_of(d.c_h);
+    unsigned stride = 1;
+    auto rows_of = [&](unsigned c) { return (nwin_of(c) + stride - 1) / stride; };
+    auto bytes_at = [&] { return (size_t)rows_of(d.c_ab) * (n_ab + 3) * (3 * p1 + p2) + (size_t)rows_of(d.c_h) * (n_h ? n_h : 1) * p1; };
+    if (ctx->table_budget)
+      while (stride < wmin && bytes_at() > ctx->table_budget) stride++;
+    d.stride = stride;
+    (void)full_bytes;
+    d.a_q = msm_build_table<Fq>(nullptr, a_plain, n_ab + 3, d.c_ab * stride, rows_of(d.c_ab));
+    d.b1_q = msm_build_table<Fq>(nullptr, b1_plain, n_ab + 3, d.c_ab * stride, rows_of(d.c_ab));
+    d.b2_q = msm_build_table<Fq2>(nullptr, b2_plain, n_ab + 3, d.c_ab * stride, rows_of(d.c_ab));
+    d.l_q = msm_build_table<Fq>(nullptr, l_plain, n_ab + 3, d.c_ab * stride, rows_of(d.c_ab));
+    d.h_q = msm_build_table<Fq>(nullptr, h_plain, n_h, d.c_h * stride, rows_of(d.c_h));
+    d.table_bytes = bytes_at();
     DG_HIP(hipDeviceSynchronize());
   }
   DG_HIP(hipMemcpy(fixed, fx, p1, kind));                     // alpha_g1

@@ -42,7 +42,8 @@ class ZkeyHeader(ctypes.Structure):       # dg16_zkey_header
 class PkInfo(ctypes.Structure):           # dg16_pk_info
     _fields_ = [("n_ab", ctypes.c_uint64), ("n_l", ctypes.c_uint64), ("n_h", ctypes.c_uint64),
                 ("c_ab", ctypes.c_uint32), ("c_l", ctypes.c_uint32), ("c_h", ctypes.c_uint32),
-                ("shard", ctypes.c_uint32), ("n_shards", ctypes.c_uint32), ("table_bytes", ctypes.c_uint64)]
+                ("shard", ctypes.c_uint32), ("n_shards", ctypes.c_uint32), ("table_bytes", ctypes.c_uint64),
+                ("table_stride", ctypes.c_uint32)]
 
 
 class Csr(ctypes.Structure):              # dg16_csr
@@ -132,6 +133,7 @@ def load():
     L.dg16_h_poly.argtypes = [vp, i, vp, vp, vp, u, vp, u, i]
     L.dg16_msm.argtypes = [vp, i, i, vp, vp, sz, sz, u, i, vp]
     L.dg16_gen_bases.argtypes = [vp, i, i, u64, sz, vp, u, i]
+    L.dg16_ctx_set_table_budget.argtypes = [vp, u64]
     L.dg16_bases_upload.argtypes = [vp, i, i, vp, sz, u, ctypes.POINTER(vp)]
     L.dg16_bases_free.argtypes = [vp]
     L.dg16_bases_free.restype = None
@@ -242,7 +244,8 @@ EXPORTED = ["dg16_ctx_create", "dg16_ctx_destroy", "dg16_last_error", "dg16_set_
             "dg16_io_error", "dg16_r1cs_parse", "dg16_r1cs_header_get", "dg16_r1cs_matrix", "dg16_r1cs_wire_map",
             "dg16_r1cs_free", "dg16_zkey_parse", "dg16_zkey_header_get", "dg16_zkey_points", "dg16_zkey_matrix",
             "dg16_zkey_free", "dg16_serialize_error", "dg16_proof_compress", "dg16_proof_decompress",
-            "dg16_verify_error", "dg16_groth16_verify", "dg16_prove_a", "dg16_prove_b", "dg16_prove_c"]
+            "dg16_verify_error", "dg16_groth16_verify", "dg16_prove_a", "dg16_prove_b", "dg16_prove_c",
+            "dg16_ctx_set_table_budget"]
 
 
 def _ptr(x):
@@ -333,6 +336,10 @@ class Context:
     # ---- plumbing ------------------------------------------------------------------------------
     def set_stream(self, channel, stream_ptr):
         self._chk(self.L.dg16_set_stream(self.h, channel, ctypes.c_void_p(stream_ptr or 0)))
+
+    def set_table_budget(self, nbytes):
+        """HBM budget of the window tables of one resident key / base set built from now on (0 = unlimited)."""
+        self._chk(self.L.dg16_ctx_set_table_budget(self.h, int(nbytes)))
 
     def sync(self, channel=0):
         self._chk(self.L.dg16_sync(self.h, channel))

@@ -165,6 +165,12 @@ int dg16_to_affine(dg16_ctx *ctx, int curve, int group, const void *jac, void *o
  * ark-circom/src/circom/qap.rs:94-110).  fixed_points = alpha_g1 | beta_g1 | delta_g1 (G1 affine)
  * | beta_g2 | delta_g2 (G2 affine), contiguous.  The base-vector mapping follows
  * groth16/src/proving_key.rs:48-65.  flags: DG16_F_DEVICE_PTRS if every pointer is a device pointer. */
+/* HBM budget, in bytes, of the window tables of ONE resident key (dg16_pk_create*: the five tables together) or ONE
+ * base set (dg16_bases_upload) built on this context from now on; 0 (the default) = unlimited.  A full table has one
+ * row T[w] = 2^(c w) P per c-bit window (BN254, 2^20 wires, c = 17: 6.0 GB per key; BLS12-381 at 2^24: 126 GB).  Under a
+ * budget the tables keep every k-th row, the smallest k that fits: the MSMs then run k bucket sets joined by a
+ * Horner tail of (k - 1) c doublings -- same results, more bucket reductions.  k = W degenerates to the plain bases. */
+int dg16_ctx_set_table_budget(dg16_ctx *ctx, uint64_t bytes);
 typedef struct dg16_pk dg16_pk;
 int dg16_pk_create(dg16_ctx *ctx, int curve, size_t num_vars, size_t num_inputs, size_t domain_size,
                    const void *a_query, const void *b_g1_query, const void *b_g2_query,
@@ -181,6 +187,7 @@ typedef struct dg16_pk_info {
   uint32_t c_ab, c_l, c_h;
   uint32_t shard, n_shards;
   uint64_t table_bytes;
+  uint32_t table_stride; /* 1: one table row per window; k > 1: every k-th row kept (dg16_ctx_set_table_budget) */
 } dg16_pk_info;
 int dg16_pk_info_get(const dg16_pk *pk, dg16_pk_info *out);
 

@@ -222,6 +222,32 @@ def test_resident_msm_matches_oracle(curve, group, log_n):
     hb.close()
 
 
+@pytest.mark.parametrize("curve,group,log_n,rows", [("bn254", 1, 14, 8), ("bn254", 2, 13, 5), ("bn254", 1, 16, 3),
+                                                    ("bls12_381", 1, 13, 1), ("bls12_377", 2, 12, 4)])
+def test_resident_msm_under_a_table_budget(curve, group, log_n, rows):
+    """dg16_bases_upload under dg16_ctx_set_table_budget: a budget of `rows` table rows makes the table keep every
+    k-th window's row; dg16_msm_resident then runs k bucket sets and a Horner tail.  Same point as the oracle's MSM;
+    rows = 1 is the degenerate table (the bases themselves, one bucket set per window)."""
+    import dg16_amd
+    n = 1 << log_n
+    c = dg16_amd.Context(0)
+    bases = corc.gen_points(curve, group, 91 + log_n, n)
+    bases[5] = 0
+    sc = corc.rand_field(curve, "fr", 17, n, mont=False)
+    want = corc.msm(curve, group, bases, sc)
+    hb = c.bases_upload(curve, group, bases)
+    full = hb.info()
+    hb.close()
+    c.set_table_budget(bases.nbytes * rows)
+    hb = c.bases_upload(curve, group, bases)
+    info = hb.info()
+    assert info["table_bytes"] <= bases.nbytes * rows < full["table_bytes"]
+    got = c.msm_resident(hb, sc, affine=True)
+    assert np.array_equal(got.reshape(-1), np.asarray(want).reshape(-1))
+    hb.close()
+    c.close()
+
+
 def test_resident_msm_2e20_equals_plain_msm():
     """BASELINE config 2's size through the resident path: same point as dg16_msm (itself oracle-checked above)."""
     import torch

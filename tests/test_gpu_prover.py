@@ -132,6 +132,42 @@ def test_prove_medium_sizes_vs_oracle(curve, log_m):
     assert ok
 
 
+@pytest.mark.parametrize("curve,log_m,frac", [("bn254", 14, 0.5), ("bn254", 14, 0.26), ("bn254", 12, 0.01),
+                                              ("bls12_381", 12, 0.4)])
+def test_prove_under_a_table_budget(curve, log_m, frac):
+    """dg16_ctx_set_table_budget: a key whose full window tables exceed the budget keeps every k-th table row and proves
+    with k bucket sets + a Horner tail.  Same proof as the oracle's (and therefore as the unbudgeted key's), the
+    tables fit the budget, and the stride is what the budget forces (frac = 0.01: down to the plain bases)."""
+    import torch
+    import bench
+    import dg16_amd
+    c = dg16_amd.Context(0)               # a context of its own: the budget is a context setting
+    dev = torch.device("cuda", 0)
+    full = bench.Workload(c, dev, log_m, 0, 1, seed=31, curve=curve)
+    fi = full.pk.info()
+    assert fi["table_stride"] == 1
+    full.pk.close()
+    budget = int(fi["table_bytes"] * frac)
+    c.set_table_budget(budget)
+    wl = bench.Workload(c, dev, log_m, 0, 1, seed=31, curve=curve)
+    info = wl.pk.info()
+    bits = bench.SCALAR_BITS[curve]
+    nwin = (bits + 1 + info["c_ab"] - 1) // info["c_ab"]
+    assert info["table_stride"] > 1
+    # the floor is one row (the bases themselves): the budget is met unless it is below that
+    assert info["table_bytes"] <= budget or info["table_stride"] >= min(nwin, (bits + 1 + info["c_h"] - 1) // info["c_h"])
+    assert info["table_bytes"] < fi["table_bytes"]
+    if frac == 0.5:
+        assert info["table_stride"] in (2, 3)       # 17 windows: 9 rows are 53 % of the full table, 6 rows fit
+    gp = bench.prove_once(c, wl)
+    (A, B, C), _ = bench.oracle_prove(wl, bench.cpu_threads())
+    gA, gB, gC = bench.gpu_proof_affine(curve, gp)
+    assert np.array_equal(A, gA) and np.array_equal(B, gB) and np.array_equal(C, gC)
+    wl.pk.close()
+    c.set_table_budget(0)
+    c.close()
+
+
 @pytest.mark.parametrize("rs_zero", [True, False])
 def test_prove_sha256_shaped_config4(rs_zero):
     """BASELINE config 4.  The reference's fixtures/sha256/sha256.r1cs is a missing blob, so
