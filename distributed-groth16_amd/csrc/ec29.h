@@ -197,6 +197,56 @@ struct XYZZ29 {
     DG29_STAGE();
     dst->y = fit<BS>(r_ * (q_ - x3) - s1 * ppp);
   }
+  // The same addition on operands behind ACCESSORS (get(coord) loads a coordinate where a product consumes it,
+  // put(coord, v) stores one): the in-workgroup bucket tree of the accumulation kernels keeps its operands in LDS
+  // columns ([coordinate word][lane]).  coord: 0 x, 1 y, 2 zz, 3 zzz.  dst may be the accessor of a.
+  template <class D, class A, class B>
+  DG_HD static void add_acc(const D& d, const A& a, const B& b) {
+    const auto bzz = b.get(2);
+    if (limbs_all_zero(bzz)) return;                          // (dst == a in every use: nothing to copy)
+    const auto azz = a.get(2);
+    if (limbs_all_zero(azz)) {
+      d.put(0, b.get(0)); d.put(1, b.get(1)); d.put(2, bzz); d.put(3, b.get(3));
+      return;
+    }
+    const auto u1 = a.get(0) * bzz;
+    DG29_STAGE();
+    const auto p_ = norm(b.get(0) * azz - u1);
+    DG29_STAGE();
+    const auto s1 = a.get(1) * b.get(3);
+    DG29_STAGE();
+    const auto r_ = norm(b.get(1) * a.get(3) - s1);
+    DG29_STAGE();
+    if (is_zero(p_)) {
+      if (is_zero(r_)) {
+        const XYZZ29 t = XYZZ29{a.get(0), a.get(1), a.get(2), a.get(3)}.dbl_cold();
+        d.put(0, t.x); d.put(1, t.y); d.put(2, t.zz); d.put(3, t.zzz);
+      } else {
+        d.put(2, FO::zero());                                  // the identity: zz = 0
+      }
+      return;
+    }
+    const auto pp = sqr(p_);
+    const auto ppp = p_ * pp;
+    const auto zz3 = fit<BS>((azz * bzz) * pp);
+    DG29_STAGE();
+    const auto zzz3 = fit<BS>((a.get(3) * b.get(3)) * ppp);
+    DG29_STAGE();
+    d.put(2, zz3);          // every coordinate of a and b that is still needed has been read by now ...
+    d.put(3, zzz3);
+    DG29_STAGE();
+    const auto q_ = u1 * pp;
+    const auto x3 = fit<BS>(sqr(r_) - (ppp + dbl(q_)));
+    d.put(0, x3);
+    DG29_STAGE();
+    d.put(1, fit<BS>(r_ * (q_ - x3) - s1 * ppp));              // ... (s1 holds a's y)
+  }
+  // doubling behind a call: the equal-operands branch of add_acc is rare, its code must not sit in the caller's loop
+#if defined(__HIPCC__)
+  __host__ __device__ __attribute__((noinline)) XYZZ29 dbl_cold() const { return dbl_pt(); }
+#else
+  __attribute__((noinline)) XYZZ29 dbl_cold() const { return dbl_pt(); }
+#endif
   DG_HD static void dbl_mem(XYZZ29* dst, const XYZZ29* a) {
     if (a->is_inf()) {
       if (dst != a) *dst = *a;

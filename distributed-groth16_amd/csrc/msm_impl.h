@@ -528,7 +528,8 @@ __device__ __forceinline__ Affine29<F> load_internal(const uint32_t* __restrict_
 // [j cnt / k, (j + 1) cnt / k).
 struct SegRange {
   size_t bslot;        // (w << log_nb) + bucket
-  unsigned first, cnt;
+  unsigned first, cnt; // rank of the segment's first entry inside the bucket, entries in the segment
+  unsigned j, k;       // this is segment j of the bucket's k
 };
 __device__ __forceinline__ SegRange msm_segment(const MsmGeom& g, unsigned w, unsigned t,
                                                 const unsigned* __restrict__ counts,
@@ -546,36 +547,154 @@ __device__ __forceinline__ SegRange msm_segment(const MsmGeom& g, unsigned w, un
   const unsigned j = t - so[lo];
   r.first = (unsigned)(((uint64_t)j * c) / k);
   r.cnt = (unsigned)(((uint64_t)(j + 1) * c) / k) - r.first;
+  r.j = j;
+  r.k = k;
   return r;
 }
 
+// ---- in-workgroup bucket tree ---------------------------------------------------------------------------------
+// The lanes of an accumulation workgroup hold the partial sums of CONSECUTIVE segments, i.e. runs of lanes belong to
+// one bucket (~15 lanes per bucket of a 2^20-point table MSM).  Instead of writing one partial per segment and
+// summing them in a separate, latency-bound finalize launch (a million full additions per MSM, 3 ms for G2 inside a
+// proof), the workgroup adds the partials of every run in a tree, in place, in LDS columns ([coordinate word][lane]).
+// The additions of a round are COMPACTED onto the low lanes (ballot + prefix counts), so whole waves drop out:
+// 128 + 64 + 32 + 16 additions of a 256-lane workgroup are 2 + 1 + 1 + 1 wave-level additions, ~12 % on top of the
+// 4 x 16 mixed additions of the accumulation itself.  A run that covers its whole bucket writes the BUCKET; a bucket
+// that crosses a workgroup boundary leaves one partial per workgroup in the segment-sum array, at the slot of the
+// run's first lane -- the bucket's first segment slot, then the first slot of every further workgroup:
+__device__ __forceinline__ unsigned msm_nparts(unsigned first_slot, unsigned k, unsigned wg_log) {
+  return k ? ((first_slot + k - 1) >> wg_log) - (first_slot >> wg_log) + 1 : 0;
+}
+__device__ __forceinline__ unsigned msm_part_slot(unsigned first_slot, unsigned s, unsigned wg_log) {
+  return s ? ((first_slot >> wg_log) + s) << wg_log : first_slot;
+}
+template <class F, int BLOCK>
+struct ColAcc {       // one lane's XYZZ29 in the LDS columns
+  using S = typename FieldOf<F>::Store;
+  static constexpr int WORDS = sizeof(S) / 4;
+  uint32_t (*sh)[BLOCK];
+  unsigned lane;
+  __device__ __forceinline__ S get(int coord) const {
+    S v;
+    uint32_t* w = reinterpret_cast<uint32_t*>(&v);
+#pragma unroll
+    for (int i = 0; i < WORDS; i++) w[i] = sh[coord * WORDS + i][lane];
+    return v;
+  }
+  __device__ __forceinline__ void put(int coord, const S& v) const {
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(&v);
+#pragma unroll
+    for (int i = 0; i < WORDS; i++) sh[coord * WORDS + i][lane] = w[i];
+  }
+};
+// q: my index inside my run, el: end (exclusive, a lane index) of my run; lanes outside every run pass q = 0, el = lane + 1
+template <class F, int BLOCK>
+__device__ __forceinline__ void wg_bucket_tree(uint32_t (*sh)[BLOCK], unsigned short* list, unsigned* wcnt,
+                                                         unsigned lane, unsigned q, unsigned el) {
+  constexpr unsigned NW = BLOCK / 64;
+  if (lane == 0) wcnt[NW] = 0;
+  __syncthreads();
+  atomicMax(&wcnt[NW], el - (lane - q));
+  __syncthreads();
+  const unsigned maxlen = wcnt[NW];
+#pragma unroll 1
+  for (unsigned d = 1; d < maxlen; d <<= 1) {
+    const bool act = (q & (2 * d - 1)) == 0 && lane + d < el;
+    const unsigned long long m = __ballot(act);
+    const unsigned wv = lane >> 6;
+    if ((lane & 63) == 0) wcnt[wv] = (unsigned)__popcll(m);
+    __syncthreads();
+    unsigned base = 0, total = 0;
+#pragma unroll
+    for (unsigned i = 0; i < NW; i++) {
+      const unsigned c = wcnt[i];
+      base += i < wv ? c : 0u;
+      total += c;
+    }
+    if (act) list[base + (unsigned)__popcll(m & ((1ull << (lane & 63)) - 1))] = (unsigned short)lane;
+    __syncthreads();
+    if (lane < total) {
+      const unsigned a = list[lane];
+      XYZZ29<F>::add_acc(ColAcc<F, BLOCK>{sh, a}, ColAcc<F, BLOCK>{sh, a}, ColAcc<F, BLOCK>{sh, a + d});
+    }
+    __syncthreads();
+  }
+}
+
+// Several MSMs over the SAME scalars (the A, B1 and L queries of a proof share one digit sort) run as INSTANCES of one
+// launch: blockIdx.y = inst * bw + w; the sort's arrays are indexed by the bucket-window w, everything an instance
+// owns (segment sums, buckets, rows, window sums) by wy = blockIdx.y.  One launch = one ramp-down at the end instead
+// of three, and the bucket reduction behind it is ONE chain of launches for all instances.
+constexpr unsigned kMaxInst = 4;
+struct MsmBases {
+  const uint32_t* p[kMaxInst];
+};
+// log2 of the accumulation workgroup of coordinate field F (msm_accumulate_phase)
 template <class F>
-__global__ void __launch_bounds__(256, (sizeof(F) > 48 ? 2 : 1))
-msm_accumulate_kernel(const uint32_t* __restrict__ bases, size_t n,
+constexpr unsigned msm_acc_block_log() {
+  if constexpr (sizeof(F) > 48) return sizeof(typename FieldOf<F>::Store) * 4 * 256 <= 80 * 1024 ? 8u : 7u;
+  else return sizeof(typename FieldOf<F>::Store) * 4 * 256 <= 40 * 1024 ? 8u : 7u;   // G1: four workgroups' trees per CU
+}
+// Does the accumulation kernel of F add the partials of a bucket inside the workgroup (wg_bucket_tree)?  G1: yes.
+// G2: no -- its loop already takes 173 VGPRs (BN254) / 252 (BLS12-381) with the accumulator in LDS, and the tree's full
+// Fq2 addition inlined next to it spilled 0.9-1.4 KB per lane (the proof got 15 % SLOWER); every lane writes its
+// partial and the finalize adds the ~15 of a bucket as before (out-of-line products, msm_reduce.hip).
+template <class F>
+constexpr bool msm_acc_tree() { return sizeof(F) <= 48; }
+// log2 of the span of segment slots that share ONE partial (msm_part_slot): the workgroup with the tree, one slot without
+template <class F>
+constexpr unsigned msm_acc_wg_log() { return msm_acc_tree<F>() ? msm_acc_block_log<F>() : 0u; }
+
+// (waves per SIMD = 4 caps the kernel at 128 VGPRs: the loop needs 108; what the tree's full addition needs beyond
+// that is spilled INSIDE the tree, which a workgroup runs five times, not inside the loop it runs 16 x 4 times)
+template <class F, int BLOCK>
+__global__ void __launch_bounds__(BLOCK, (sizeof(F) > 32 ? 3 : 4))
+msm_accumulate_kernel(MsmBases bases, size_t n,
                                                               MsmGeom g, const unsigned* __restrict__ offsets,
                                                               const unsigned* __restrict__ counts,
                                                               const unsigned* __restrict__ seg_off,
                                                               const unsigned* __restrict__ seg_total,
                                                               const unsigned* __restrict__ entries,
-                                                              XYZZ29<F>* __restrict__ seg_sum) {
-  const unsigned w = blockIdx.y;
-  const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= seg_total[w]) return;
-  const size_t sslot = (size_t)w * g.seg_cap + t;
-  const SegRange sr = msm_segment(g, w, t, counts, seg_off);
-  const unsigned cnt = sr.cnt;
-  const unsigned* e = entries + (size_t)w * g.region + offsets[sr.bslot] + sr.first;
-  // Latency hiding: several waves per SIMD cover the dependent (entry -> point) gathers; only the 4-byte entry
-  // index is fetched one iteration ahead (a second point in registers would cost occupancy).
-  unsigned cur = e[0];
+                                                              XYZZ29<F>* __restrict__ seg_sum,
+                                                              XYZZ29<F>* __restrict__ buckets) {
+  using CA = ColAcc<F, BLOCK>;
+  __shared__ uint32_t sh[4 * CA::WORDS][BLOCK];           // the partials of the bucket tree: 36 KiB for a 254-bit field
+  __shared__ unsigned short list[BLOCK];
+  __shared__ unsigned wcnt[BLOCK / 64 + 1];
+  const unsigned w = blockIdx.y % g.bw;
+  const uint32_t* __restrict__ base_tab = bases.p[blockIdx.y / g.bw];
+  const unsigned lane = threadIdx.x;
+  const unsigned t = blockIdx.x * BLOCK + lane;
+  const bool live = t < seg_total[w];
+  SegRange sr{};
   XYZZ29<F> acc = XYZZ29<F>::inf();
-  for (unsigned j = 0; j < cnt; j++) {
-    unsigned nxt = (j + 1 < cnt) ? e[j + 1] : 0u;
-    const Affine29<F> p = load_internal<F>(bases, cur & 0x7fffffffu);
-    acc = acc.madd(p, cur >> 31);
-    cur = nxt;
+  if (live) {
+    sr = msm_segment(g, w, t, counts, seg_off);
+    const unsigned cnt = sr.cnt;
+    const unsigned* e = entries + (size_t)w * g.region + offsets[sr.bslot] + sr.first;
+    // Latency hiding: several waves per SIMD cover the dependent (entry -> point) gathers; only the 4-byte entry
+    // index is fetched one iteration ahead (a second point in registers would cost occupancy).
+    unsigned cur = e[0];
+    for (unsigned j = 0; j < cnt; j++) {
+      unsigned nxt = (j + 1 < cnt) ? e[j + 1] : 0u;
+      const Affine29<F> p = load_internal<F>(base_tab, cur & 0x7fffffffu);
+      acc = acc.madd(p, cur >> 31);
+      cur = nxt;
+    }
   }
-  seg_sum[sslot] = acc;
+  const CA me{sh, lane};
+  me.put(0, acc.x); me.put(1, acc.y); me.put(2, acc.zz); me.put(3, acc.zzz);
+  // my run: the lanes of this workgroup that hold segments of my bucket
+  const unsigned hl = live ? (lane > sr.j ? lane - sr.j : 0u) : lane;
+  const unsigned el = live ? (lane - sr.j + sr.k < (unsigned)BLOCK ? lane + sr.k - sr.j : (unsigned)BLOCK) : lane + 1;
+  wg_bucket_tree<F, BLOCK>(sh, list, wcnt, lane, lane - hl, el);
+  if (live && lane == hl) {
+    const XYZZ29<F> v{me.get(0), me.get(1), me.get(2), me.get(3)};
+    if (sr.j == 0 && lane + sr.k <= (unsigned)BLOCK)
+      buckets[((size_t)blockIdx.y << g.log_nb) + (sr.bslot & (((size_t)1 << g.log_nb) - 1))] = v;   // the whole bucket
+    else
+      seg_sum[(size_t)blockIdx.y * g.seg_cap + t] = v;      // one partial per (bucket, workgroup): msm_part_slot
+  }
 }
 
 // ---- 4 (G2): the same segment accumulation with the accumulator staged through LDS -------------------------
@@ -585,10 +704,11 @@ msm_accumulate_kernel(const uint32_t* __restrict__ bases, size_t n,
 // 4 coordinates x 2 N words x BLOCK lanes = 72 KiB for BN254 Fq2 at BLOCK = 256 (two workgroups per CU, 160 KiB LDS).
 template <class F, int BLOCK>
 __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 ? 2 : 1))
-msm_accumulate_lds_kernel(const uint32_t* __restrict__ bases, size_t n, MsmGeom g,
+msm_accumulate_lds_kernel(MsmBases bases, size_t n, MsmGeom g,
                           const unsigned* __restrict__ offsets, const unsigned* __restrict__ counts,
                           const unsigned* __restrict__ seg_off, const unsigned* __restrict__ seg_total,
-                          const unsigned* __restrict__ entries, XYZZ29<F>* __restrict__ seg_sum) {
+                          const unsigned* __restrict__ entries, XYZZ29<F>* __restrict__ seg_sum,
+                          XYZZ29<F>* __restrict__ buckets) {
   using FO = FieldOf<F>;
   using S = typename FO::Store;
   constexpr int BS = FO::BS;
@@ -608,18 +728,19 @@ msm_accumulate_lds_kernel(const uint32_t* __restrict__ bases, size_t n, MsmGeom 
     for (int i = 0; i < WORDS; i++) sh[coord * WORDS + i][lane] = w[i];
   };
 #define DG_STAGE() asm volatile("" ::: "memory")   /* keep LDS reloads where they are written */
-  const unsigned w = blockIdx.y;
+  const unsigned w = blockIdx.y % g.bw;
+  const uint32_t* __restrict__ base_tab = bases.p[blockIdx.y / g.bw];
   const unsigned t = blockIdx.x * BLOCK + threadIdx.x;
-  if (t >= seg_total[w]) return;
-  const size_t sslot = (size_t)w * g.seg_cap + t;
-  const SegRange sr = msm_segment(g, w, t, counts, seg_off);
-  const unsigned cnt = sr.cnt;
-  const unsigned* e = entries + (size_t)w * g.region + offsets[sr.bslot] + sr.first;
+  const bool live = t < seg_total[w];
+  SegRange sr{};
+  if (live) sr = msm_segment(g, w, t, counts, seg_off);
+  const unsigned cnt = live ? sr.cnt : 0u;
+  const unsigned* e = entries + (size_t)w * g.region + (live ? offsets[sr.bslot] + sr.first : 0u);
   bool inf = true;
-  unsigned cur = e[0];
+  unsigned cur = cnt ? e[0] : 0u;
   for (unsigned j = 0; j < cnt; j++) {
     unsigned nxt = (j + 1 < cnt) ? e[j + 1] : 0u;
-    const Affine29<F> q = load_internal<F>(bases, cur & 0x7fffffffu);
+    const Affine29<F> q = load_internal<F>(base_tab, cur & 0x7fffffffu);
     const bool negate = cur >> 31;
     cur = nxt;
     if (q.is_inf()) continue;
@@ -659,9 +780,13 @@ msm_accumulate_lds_kernel(const uint32_t* __restrict__ bases, size_t n, MsmGeom 
     st(1, y3);
     DG_STAGE();
   }
-  XYZZ29<F> out = XYZZ29<F>::inf();
-  if (!inf) out = XYZZ29<F>{ld(0), ld(1), ld(2), ld(3)};
-  seg_sum[sslot] = out;
+  // (no in-workgroup tree here: msm_acc_tree) one partial per segment; a one-segment bucket is written directly
+  if (live) {
+    XYZZ29<F> out = XYZZ29<F>::inf();
+    if (!inf) out = XYZZ29<F>{ld(0), ld(1), ld(2), ld(3)};
+    if (sr.k == 1) buckets[((size_t)blockIdx.y << g.log_nb) + (sr.bslot & (((size_t)1 << g.log_nb) - 1))] = out;
+    else seg_sum[(size_t)blockIdx.y * g.seg_cap + t] = out;
+  }
 #undef DG_STAGE
 }
 
@@ -897,22 +1022,26 @@ struct MsmBuffers {
   XYZZ<F>* window_sums;
   unsigned* giant;
   unsigned giant_cap;
-  size_t nbw, nrows;
+  size_t nbw, nrows;     // over all instances
+  unsigned ninst;        // MSMs sharing the sort (msm_accumulate_kernel): bucket-window index wy = inst * bw + w
   RowGeom rg;
 };
 
 template <class F>
-MsmBuffers<F> msm_buffers(Channel& wsch, const MsmGeom& g) {
+MsmBuffers<F> msm_buffers(Channel& wsch, const MsmGeom& g, unsigned ninst = 1) {
   MsmBuffers<F> b;
-  b.nbw = (size_t)g.bw << g.log_nb;
-  const size_t nseg_slots = (size_t)g.bw * g.seg_cap;
+  DG_REQUIRE(ninst >= 1 && ninst <= kMaxInst, DG16_ERR_BAD_ARG, "1..4 MSM instances per sort");
+  b.ninst = ninst;
+  const size_t bwi = (size_t)g.bw * ninst;
+  b.nbw = bwi << g.log_nb;
+  const size_t nseg_slots = bwi * g.seg_cap;
   b.giant_cap = (unsigned)(nseg_slots / kGiantSegs + 1);
   b.buckets = (XYZZ29<F>*)ws(wsch, 7, b.nbw * sizeof(XYZZ29<F>));
   b.seg_sum = (XYZZ29<F>*)ws(wsch, 17, nseg_slots * sizeof(XYZZ29<F>));
   b.rg = row_geometry(g);
-  b.nrows = (size_t)g.bw << b.rg.rows_log;
-  const size_t nfold = (size_t)g.bw * 3 * 256;
-  uint8_t* p15 = (uint8_t*)ws(wsch, 15, (2 * b.nrows + nfold) * sizeof(XYZZ29<F>) + g.bw * sizeof(XYZZ<F>));
+  b.nrows = bwi << b.rg.rows_log;
+  const size_t nfold = bwi * 3 * 256;
+  uint8_t* p15 = (uint8_t*)ws(wsch, 15, (2 * b.nrows + nfold) * sizeof(XYZZ29<F>) + bwi * sizeof(XYZZ<F>));
   b.row_w = (XYZZ29<F>*)p15;
   b.row_r = b.row_w + b.nrows;
   b.fold = b.row_r + b.nrows;
@@ -924,21 +1053,30 @@ MsmBuffers<F> msm_buffers(Channel& wsch, const MsmGeom& g) {
 
 // Phase A (saturates the GPU): segment accumulation.  `bases` is the array of n points or, in table mode, the
 // table of W*n points -- in INTERNAL form (msm_to_internal_kernel / msm_table_kernel).
+// bases: b.ninst tables (or plain base arrays), one per instance
 template <class F>
-void msm_accumulate_phase(hipStream_t s, const MsmSort& st, const MsmBuffers<F>& b, const void* bases) {
+void msm_accumulate_phase(hipStream_t s, const MsmSort& st, const MsmBuffers<F>& b, const void* const* bases) {
   const MsmGeom& g = st.g;
+  MsmBases mb{};
+  for (unsigned i = 0; i < b.ninst; i++) mb.p[i] = (const uint32_t*)bases[i];
   if constexpr (sizeof(F) > 48) {
     // G2 (Fq2 coordinates): LDS-staged accumulator; two workgroups per CU must fit the 160 KiB of LDS
-    constexpr int BLOCK = sizeof(typename FieldOf<F>::Store) * 4 * 256 <= 80 * 1024 ? 256 : 128;
-    hipLaunchKernelGGL((msm_accumulate_lds_kernel<F, BLOCK>), dim3((g.seg_cap + BLOCK - 1) / BLOCK, g.bw), dim3(BLOCK),
-                       0, s, (const uint32_t*)bases, st.n, g, st.offsets, st.counts, st.seg_off, st.seg_total,
-                       st.entries, b.seg_sum);
+    constexpr int BLOCK = 1 << msm_acc_block_log<F>();
+    hipLaunchKernelGGL((msm_accumulate_lds_kernel<F, BLOCK>), dim3((g.seg_cap + BLOCK - 1) / BLOCK, g.bw * b.ninst),
+                       dim3(BLOCK), 0, s, mb, st.n, g, st.offsets, st.counts, st.seg_off, st.seg_total, st.entries,
+                       b.seg_sum, b.buckets);
   } else {
-    hipLaunchKernelGGL(msm_accumulate_kernel<F>, dim3((g.seg_cap + 255) / 256, g.bw), dim3(256), 0, s,
-                       (const uint32_t*)bases, st.n, g, st.offsets, st.counts, st.seg_off, st.seg_total,
-                       st.entries, b.seg_sum);
+    constexpr int BLOCK = 1 << msm_acc_block_log<F>();
+    hipLaunchKernelGGL((msm_accumulate_kernel<F, BLOCK>), dim3((g.seg_cap + BLOCK - 1) / BLOCK, g.bw * b.ninst),
+                       dim3(BLOCK), 0, s, mb, st.n, g, st.offsets, st.counts, st.seg_off, st.seg_total, st.entries,
+                       b.seg_sum, b.buckets);
   }
   DG_HIP(hipGetLastError());
+}
+template <class F>
+void msm_accumulate_phase(hipStream_t s, const MsmSort& st, const MsmBuffers<F>& b, const void* bases) {
+  const void* one[1] = {bases};
+  msm_accumulate_phase<F>(s, st, b, one);
 }
 
 // ---- 4b: bucket = sum of its segment partials, as a throughput kernel -------------------------------------------
@@ -955,112 +1093,58 @@ __device__ __forceinline__ void giant_geometry(unsigned nseg, unsigned& slices, 
 }
 
 
-// One lane per bucket, full XYZZ additions with inline products in registers.  2^16 buckets x ~15 partials per MSM of
-// a 2^20 proof = a million additions: the four-lanes-per-bucket, out-of-line-product finalize of the reduction unit
-// (built for short chains) spent 0.7 ms (G1) / 2.6 ms (G2) on them at low occupancy, next to an accumulation it
-// stretched by a millisecond; the 29-bit product runs at full rate at ONE wave per SIMD, so plain lanes do.
+// What is left of the finalize after the in-workgroup bucket tree: one lane per bucket adds the partials of the
+// buckets that CROSS an accumulation workgroup (one bucket in ~17 for a 2^20 table MSM: one addition; a bucket held
+// by one workgroup was written by it, an empty one is set to the identity here).  (Round 2 / early round 3 summed
+// ~15 per-segment partials per bucket here, a million full additions per MSM at 5-18x the issue time of an
+// addition: profiles/r3_finalize_experiments.md.)
 // TU: 0 = instantiated in msm_group.hip (products inline), 1 = in msm_reduce.hip (for G2 compiled with out-of-line
-// products, DG29_OUTLINE_MUL: an inlined Fq2 addition + doubling is 123 KB of code for BN254, twice the 64 KB
-// instruction cache two CUs share, and the inlined G2 finalize was instruction-fetch-bound: 220 us per dependent
-// addition against ~13 us of issue time).  Distinct symbols, so that both variants can live in one library.
+// products, DG29_OUTLINE_MUL: an inlined Fq2 addition + doubling is 123 KB of code for BN254 and 250 KB for BLS12-381,
+// against the 64 KB instruction cache two CUs share -- a BLS12-381 2^20 proof took 38 ms instead of 26 with it).
+// Distinct symbols, so that both variants can live in one library.
+// `total` = (instances * bw) << log_nb buckets; the sort's arrays are indexed by the bucket-window w = wy % bw.
 template <class F, int TU = 0>
-__global__ void __launch_bounds__(256) msm_finalize_thr_kernel(MsmGeom g, const unsigned* __restrict__ counts,
+__global__ void __launch_bounds__(256) msm_finalize_thr_kernel(MsmGeom g, size_t total, unsigned wg_log,
+                                                                const unsigned* __restrict__ counts,
                                                                 const unsigned* __restrict__ seg_off,
                                                                 const XYZZ29<F>* __restrict__ seg_sum,
                                                                 XYZZ29<F>* __restrict__ buckets,
                                                                 unsigned* __restrict__ giant_count,
                                                                 unsigned* __restrict__ giant_list, unsigned giant_cap) {
   const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t total = (size_t)g.bw << g.log_nb;
   if (gid >= total) return;
-  const unsigned w = (unsigned)(gid >> g.log_nb);
-  const unsigned nseg = (counts[gid] + (1u << g.seg_log) - 1) >> g.seg_log;
-  if (nseg > kGiantSegs) {
+  const unsigned wy = (unsigned)(gid >> g.log_nb);
+  const size_t gs = ((size_t)(wy % g.bw) << g.log_nb) + (gid & (((size_t)1 << g.log_nb) - 1));   // the sort's bucket slot
+  const unsigned k = (counts[gs] + (1u << g.seg_log) - 1) >> g.seg_log;
+  const unsigned first = seg_off[gs];
+  const unsigned np = msm_nparts(first, k, wg_log);     // partials the accumulation workgroups left for this bucket
+  if (np == 0) {
+    buckets[gid] = XYZZ29<F>::inf();
+    return;
+  }
+  if (np == 1) return;                                  // one workgroup held the whole bucket and wrote it
+  if (np > kGiantSegs) {
     unsigned slot = atomicAdd(giant_count, 1u);
     if (slot < giant_cap) {               // (always: giant_cap >= total segments / kGiantSegs)
       giant_list[slot] = (unsigned)gid;
       unsigned slices, per;
-      giant_geometry(nseg, slices, per);
+      giant_geometry(np, slices, per);
       unsigned wb = atomicAdd(giant_count + 1, slices);   // work items: (giant, slice)
       unsigned* work = giant_list + giant_cap;
-      for (unsigned k = 0; k < slices; k++) work[wb + k] = (slot << 6) | k;
+      for (unsigned i = 0; i < slices; i++) work[wb + i] = (slot << 6) | i;
     }
     return;
   }
-  const XYZZ29<F>* sp = seg_sum + (size_t)w * g.seg_cap + seg_off[gid];
-  XYZZ29<F> acc = nseg ? sp[0] : XYZZ29<F>::inf();
+  const XYZZ29<F>* sp = seg_sum + (size_t)wy * g.seg_cap;
+  XYZZ29<F> acc = sp[first];
 #pragma unroll 1
-  for (unsigned s = 1; s < nseg; s++) acc = acc.add(sp[s]);
+  for (unsigned s = 1; s < np; s++) acc = acc.add(sp[msm_part_slot(first, s, wg_log)]);
   buckets[gid] = acc;
 }
-// TWO lanes per bucket: lane q sums the partials q, q + 2, ..; one exchange step adds the two halves.  The chain per
-// lane halves and the launch has two waves per SIMD, so that one wave's partial loads hide behind the other's products
-// (with one lane per bucket the kernel is a single wave per SIMD alternating between a 144 / 288-byte strided load
-// and an addition).
-template <class T>
-__device__ __forceinline__ T lane_xor_words2(const T& v, int mask) {
-  static_assert(sizeof(T) % 4 == 0, "word-sized type");
-  T r;
-  const uint32_t* src = reinterpret_cast<const uint32_t*>(&v);
-  uint32_t* dst = reinterpret_cast<uint32_t*>(&r);
-#pragma unroll
-  for (unsigned i = 0; i < sizeof(T) / 4; i++) dst[i] = (uint32_t)__shfl_xor((int)src[i], mask);
-  return r;
-}
-template <class F, int TU = 0>
-__global__ void __launch_bounds__(256) msm_finalize_thr2_kernel(MsmGeom g, const unsigned* __restrict__ counts,
-                                                                 const unsigned* __restrict__ seg_off,
-                                                                 const XYZZ29<F>* __restrict__ seg_sum,
-                                                                 XYZZ29<F>* __restrict__ buckets,
-                                                                 unsigned* __restrict__ giant_count,
-                                                                 unsigned* __restrict__ giant_list, unsigned giant_cap) {
-  const size_t gid2 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t gid = gid2 >> 1;
-  const unsigned q = (unsigned)gid2 & 1;
-  const size_t total = (size_t)g.bw << g.log_nb;
-  if (gid >= total) return;                 // pairs leave together
-  const unsigned w = (unsigned)(gid >> g.log_nb);
-  const unsigned nseg = (counts[gid] + (1u << g.seg_log) - 1) >> g.seg_log;
-  if (nseg > kGiantSegs) {
-    if (q == 0) {
-      unsigned slot = atomicAdd(giant_count, 1u);
-      if (slot < giant_cap) {
-        giant_list[slot] = (unsigned)gid;
-        unsigned slices, per;
-        giant_geometry(nseg, slices, per);
-        unsigned wb = atomicAdd(giant_count + 1, slices);
-        unsigned* work = giant_list + giant_cap;
-        for (unsigned k = 0; k < slices; k++) work[wb + k] = (slot << 6) | k;
-      }
-    }
-    return;
-  }
-  const XYZZ29<F>* sp = seg_sum + (size_t)w * g.seg_cap + seg_off[gid];
-  XYZZ29<F> acc = q < nseg ? sp[q] : XYZZ29<F>::inf();
-  const unsigned iters = (nseg + 1) >> 1;   // both lanes run the same trip count: one addition site, then the exchange
-#pragma unroll 1
-  for (unsigned it = 1; it <= iters; it++) {
-    XYZZ29<F> o;
-    if (it < iters) {
-      const unsigned sidx = q + 2 * it;
-      o = sidx < nseg ? sp[sidx] : XYZZ29<F>::inf();
-    } else {
-      o = lane_xor_words2(acc, 1);
-    }
-    acc = acc.add(o);
-  }
-  if (q == 0) buckets[gid] = acc;
-}
-
 template <class F>
 void msm_finalize_phase(hipStream_t s, const MsmSort& st, const MsmBuffers<F>& b) {
-  static const int mode = [] { const char* e = getenv("DG16_FINALIZE"); return e ? atoi(e) : 0; }();
-  if (mode == 2)
-    hipLaunchKernelGGL(msm_finalize_thr2_kernel<F>, dim3((unsigned)((2 * b.nbw + 255) / 256)), dim3(256), 0, s, st.g,
-                       st.counts, st.seg_off, b.seg_sum, b.buckets, b.giant, b.giant + 2, b.giant_cap);
-  else
-    hipLaunchKernelGGL(msm_finalize_thr_kernel<F>, dim3((unsigned)((b.nbw + 255) / 256)), dim3(256), 0, s, st.g, st.counts,
-                       st.seg_off, b.seg_sum, b.buckets, b.giant, b.giant + 2, b.giant_cap);
+  hipLaunchKernelGGL(msm_finalize_thr_kernel<F>, dim3((unsigned)((b.nbw + 255) / 256)), dim3(256), 0, s, st.g, b.nbw,
+                     msm_acc_wg_log<F>(), st.counts, st.seg_off, b.seg_sum, b.buckets, b.giant, b.giant + 2, b.giant_cap);
   DG_HIP(hipGetLastError());
 }
 
@@ -1068,12 +1152,9 @@ void msm_finalize_phase(hipStream_t s, const MsmSort& st, const MsmBuffers<F>& b
 // phase A so that it hides behind the next MSM's accumulation.  Defined in msm_reduce_impl.h and instantiated once per
 // (curve, group) in msm_reduce.hip -- a translation unit of its own because its kernels are compiled with out-of-line
 // field products (DG29_OUTLINE_MUL, fp29.h).
-// parts: bit 0 = finalize (+ giant buckets): throughput work, one lane per bucket; bit 1 = rows -> top -> tail: the
-// latency chain.  A caller that pipelines MSMs may run the two on different streams (prover_impl.h).
-constexpr int kBucketFinalize = 1, kBucketChain = 2, kBucketAll = 3;
+// out_dev: b.ninst results back to back (Jacobian x, y, z -- or affine x, y -- of instance 0, then instance 1, ..)
 template <class F>
-void msm_bucket_phase(hipStream_t s, const MsmSort& st, const MsmBuffers<F>& b, bool out_affine, void* out_dev,
-                      int parts = kBucketAll);
+void msm_bucket_phase(hipStream_t s, const MsmSort& st, const MsmBuffers<F>& b, bool out_affine, void* out_dev);
 
 // both phases on the call's own stream and workspace
 template <class F>
@@ -1264,7 +1345,7 @@ void to_affine_run(Call& k, const void* jac, void* out, size_t n) {
 // Translation units that only CALL the MSM phases of a curve (the prover) declare them extern so that the kernels are
 // compiled once, in msm_group.hip / msm_reduce.hip:  namespace dg16 { DG16_MSM_EXTERN(CurveTypes<0>) }
 #define DG16_MSM_EXTERN_GROUP(F)                                                                                  \
-  extern template void msm_accumulate_phase<F>(hipStream_t, const MsmSort&, const MsmBuffers<F>&, const void*);   \
+  extern template void msm_accumulate_phase<F>(hipStream_t, const MsmSort&, const MsmBuffers<F>&, const void* const*); \
   extern template void msm_finalize_phase<F>(hipStream_t, const MsmSort&, const MsmBuffers<F>&);                   \
   extern template void* msm_build_table<F>(hipStream_t, const void*, size_t, unsigned, unsigned);
 #define DG16_MSM_EXTERN(CT)                                                                                       \

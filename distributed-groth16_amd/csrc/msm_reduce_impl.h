@@ -19,7 +19,7 @@ namespace dg16 {
 // sum_b (b + 1) B_b over the 2^(c-1) buckets of a bucket-window, B_b = sum of the bucket's segment partials.
 // Every phase is a short chain of dependent group operations (a lone lane needs ~5 us per G1 addition, ~15 us per
 // G2 addition), so the work is arranged for the shortest chains, not the fewest additions:
-//   finalize4   four lanes per bucket: strided partial sums + two shuffle steps (chain ~nseg/4 + 2 instead of nseg)
+//   finalize    one lane per bucket (msm_impl.h: msm_finalize_thr_kernel)
 //   giants      buckets with > kGiantSegs partials (boolean witnesses, short top windows): device-side work list,
 //               one workgroup per slice, then one fold per giant (unchanged idea, see giant_geometry)
 //   row         one workgroup per ROW of 256 buckets: suffix scan S_c = sum_{c' >= c} B_c' (8 steps) gives the row
@@ -46,111 +46,7 @@ __device__ __forceinline__ T lane_xor_words(const T& v, int mask) {
 }
 
 template <class F>
-__global__ void __launch_bounds__(256) msm_finalize4_kernel(MsmGeom g, const unsigned* __restrict__ counts,
-                                                             const unsigned* __restrict__ seg_off,
-                                                             const XYZZ29<F>* __restrict__ seg_sum,
-                                                             XYZZ29<F>* __restrict__ buckets,
-                                                             unsigned* __restrict__ giant_count,
-                                                             unsigned* __restrict__ giant_list, unsigned giant_cap) {
-  __builtin_amdgcn_s_setprio(3);   // latency-bound chain: issue ahead of the accumulation waves sharing the SIMD
-  const size_t gid4 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t gid = gid4 >> 2;
-  const unsigned q = (unsigned)gid4 & 3;
-  const size_t total = (size_t)g.bw << g.log_nb;
-  if (gid >= total) return;                 // whole quads leave together
-  const unsigned w = (unsigned)(gid >> g.log_nb);
-  const unsigned nseg = (counts[gid] + (1u << g.seg_log) - 1) >> g.seg_log;
-  if (nseg > kGiantSegs) {
-    if (q == 0) {
-      unsigned slot = atomicAdd(giant_count, 1u);
-      if (slot < giant_cap) {               // (always: giant_cap >= total segments / kGiantSegs)
-        giant_list[slot] = (unsigned)gid;
-        unsigned slices, per;
-        giant_geometry(nseg, slices, per);
-        unsigned wb = atomicAdd(giant_count + 1, slices);   // work items: (giant, slice)
-        unsigned* work = giant_list + giant_cap;
-        for (unsigned k = 0; k < slices; k++) work[wb + k] = (slot << 6) | k;
-      }
-    }
-    return;
-  }
-  const XYZZ29<F>* sp = seg_sum + (size_t)w * g.seg_cap + seg_off[gid];
-  // one (inlined) addition site: strided partials first, then the two quad-exchange steps
-  XYZZ29<F> acc = XYZZ29<F>::inf();
-  const unsigned iters = (nseg + 3) >> 2;
-#pragma unroll 1
-  for (unsigned it = 0; it < iters + 2; it++) {
-    XYZZ29<F> o;
-    if (it < iters) {
-      const unsigned s = q + 4 * it;
-      o = s < nseg ? sp[s] : XYZZ29<F>::inf();
-    } else {
-      o = lane_xor_words(acc, 1 << (it - iters));
-    }
-    acc = acc.add(o);
-  }
-  if (q == 0) buckets[gid] = acc;
-}
-
-// The same for quadratic-extension coordinates: with the accumulator in registers an Fq2 addition needs > 256 VGPRs
-// (one wave per SIMD); here every lane's accumulator lives in LDS (add_mem reads its operands where a product
-// consumes them), and the quad exchange reads the neighbour's accumulator straight from LDS.  Lanes of a quad run in
-// lockstep inside one wave, so a compiler + LDS-counter barrier between steps is all the ordering they need.
-template <class F, int BLOCK>
-__global__ void __launch_bounds__(BLOCK) msm_finalize4_lds_kernel(MsmGeom g, const unsigned* __restrict__ counts,
-                                                                  const unsigned* __restrict__ seg_off,
-                                                                  const XYZZ29<F>* __restrict__ seg_sum,
-                                                                  XYZZ29<F>* __restrict__ buckets,
-                                                                  unsigned* __restrict__ giant_count,
-                                                                  unsigned* __restrict__ giant_list, unsigned giant_cap) {
-  __builtin_amdgcn_s_setprio(3);   // latency-bound chain: issue ahead of the accumulation waves sharing the SIMD
-  __shared__ XYZZ29<F> acc[BLOCK];
-  const size_t gid4 = (size_t)blockIdx.x * BLOCK + threadIdx.x;
-  const size_t gid = gid4 >> 2;
-  const unsigned q = (unsigned)gid4 & 3;
-  const size_t total = (size_t)g.bw << g.log_nb;
-  if (gid >= total) return;                 // whole quads leave together
-  const unsigned w = (unsigned)(gid >> g.log_nb);
-  const unsigned nseg = (counts[gid] + (1u << g.seg_log) - 1) >> g.seg_log;
-  if (nseg > kGiantSegs) {
-    if (q == 0) {
-      unsigned slot = atomicAdd(giant_count, 1u);
-      if (slot < giant_cap) {
-        giant_list[slot] = (unsigned)gid;
-        unsigned slices, per;
-        giant_geometry(nseg, slices, per);
-        unsigned wb = atomicAdd(giant_count + 1, slices);
-        unsigned* work = giant_list + giant_cap;
-        for (unsigned k = 0; k < slices; k++) work[wb + k] = (slot << 6) | k;
-      }
-    }
-    return;
-  }
-  const XYZZ29<F>* sp = seg_sum + (size_t)w * g.seg_cap + seg_off[gid];
-  XYZZ29<F>* me = &acc[threadIdx.x];
-  *me = XYZZ29<F>::inf();
-  const unsigned iters = (nseg + 3) >> 2;
-#pragma unroll 1
-  for (unsigned it = 0; it < iters + 2; it++) {
-    const XYZZ29<F>* b;
-    bool on;
-    if (it < iters) {
-      const unsigned s = q + 4 * it;
-      on = s < nseg;
-      b = sp + (on ? s : 0);
-    } else {
-      const unsigned d = 1u << (it - iters);          // 1: lanes 0, 2 take their neighbour; 2: lane 0 takes lane 2
-      on = (q & (2 * d - 1)) == 0;
-      b = me + (on ? d : 0);
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (on) XYZZ29<F>::add_mem(me, me, b);
-  }
-  if (q == 0) buckets[gid] = *me;
-}
-
-template <class F>
-__global__ void __launch_bounds__(256) msm_giant_kernel(MsmGeom g, const unsigned* __restrict__ counts,
+__global__ void __launch_bounds__(256) msm_giant_kernel(MsmGeom g, unsigned wg_log, const unsigned* __restrict__ counts,
                                                          const unsigned* __restrict__ seg_off,
                                                          XYZZ29<F>* __restrict__ seg_sum,
                                                          const unsigned* __restrict__ giant_count,
@@ -162,11 +58,13 @@ __global__ void __launch_bounds__(256) msm_giant_kernel(MsmGeom g, const unsigne
   for (unsigned wi = blockIdx.x; wi < nwork; wi += gridDim.x) {
     const unsigned item = work[wi];
     const unsigned gid = giant_list[item >> 6], slice = item & 63;
-    const unsigned w = gid >> g.log_nb;
-    const unsigned nseg = (counts[gid] + (1u << g.seg_log) - 1) >> g.seg_log;
+    const unsigned wy = gid >> g.log_nb;                                   // instance * bw + bucket-window
+    const size_t gs = ((size_t)(wy % g.bw) << g.log_nb) + (gid & ((1u << g.log_nb) - 1));   // the sort's bucket slot
+    const unsigned k = (counts[gs] + (1u << g.seg_log) - 1) >> g.seg_log, first = seg_off[gs];
+    const unsigned nseg = msm_nparts(first, k, wg_log);      // partials = one per accumulation workgroup the bucket spans
     unsigned slices, per;
     giant_geometry(nseg, slices, per);
-    XYZZ29<F>* sp = seg_sum + (size_t)w * g.seg_cap + seg_off[gid];
+    XYZZ29<F>* sp = seg_sum + (size_t)wy * g.seg_cap;
     const unsigned lo = slice * per;
     const unsigned hi = lo + per < nseg ? lo + per : nseg;
     sh[threadIdx.x] = XYZZ29<F>::inf();
@@ -180,7 +78,7 @@ __global__ void __launch_bounds__(256) msm_giant_kernel(MsmGeom g, const unsigne
       if (step < iters) {
         const unsigned s = lo + step * 256 + threadIdx.x;
         on = s < hi;
-        b = &sp[on ? s : lo];
+        b = &sp[msm_part_slot(first, on ? s : lo, wg_log)];
       } else {
         const unsigned stride = 128u >> (step - iters);
         on = threadIdx.x < stride;
@@ -189,13 +87,13 @@ __global__ void __launch_bounds__(256) msm_giant_kernel(MsmGeom g, const unsigne
       if (on) XYZZ29<F>::add_mem(&sh[threadIdx.x], &sh[threadIdx.x], b);
       __syncthreads();
     }
-    if (threadIdx.x == 0) sp[lo] = sh[0];
+    if (threadIdx.x == 0) sp[msm_part_slot(first, lo, wg_log)] = sh[0];
     __syncthreads();
   }
 }
 
 template <class F>
-__global__ void __launch_bounds__(64) msm_giant_fold_kernel(MsmGeom g, const unsigned* __restrict__ counts,
+__global__ void __launch_bounds__(64) msm_giant_fold_kernel(MsmGeom g, unsigned wg_log, const unsigned* __restrict__ counts,
                                                              const unsigned* __restrict__ seg_off,
                                                              const XYZZ29<F>* __restrict__ seg_sum,
                                                              XYZZ29<F>* __restrict__ buckets,
@@ -208,12 +106,14 @@ __global__ void __launch_bounds__(64) msm_giant_fold_kernel(MsmGeom g, const uns
   if (ng > giant_cap) ng = giant_cap;
   for (unsigned gi = blockIdx.x; gi < ng; gi += gridDim.x) {
     const unsigned gid = giant_list[gi];
-    const unsigned w = gid >> g.log_nb;
-    const unsigned nseg = (counts[gid] + (1u << g.seg_log) - 1) >> g.seg_log;
+    const unsigned wy = gid >> g.log_nb;
+    const size_t gs = ((size_t)(wy % g.bw) << g.log_nb) + (gid & ((1u << g.log_nb) - 1));
+    const unsigned k = (counts[gs] + (1u << g.seg_log) - 1) >> g.seg_log, first = seg_off[gs];
+    const unsigned nseg = msm_nparts(first, k, wg_log);
     unsigned slices, per;
     giant_geometry(nseg, slices, per);
-    const XYZZ29<F>* sp = seg_sum + (size_t)w * g.seg_cap + seg_off[gid];
-    sh[threadIdx.x] = threadIdx.x < slices ? sp[(size_t)threadIdx.x * per] : XYZZ29<F>::inf();
+    const XYZZ29<F>* sp = seg_sum + (size_t)wy * g.seg_cap;
+    sh[threadIdx.x] = threadIdx.x < slices ? sp[msm_part_slot(first, threadIdx.x * per, wg_log)] : XYZZ29<F>::inf();
     __syncthreads();
 #pragma unroll 1
     for (unsigned stride = kGiantSlices / 2; stride > 0; stride >>= 1) {
@@ -364,7 +264,9 @@ template <class F>
 __global__ void __launch_bounds__(64) msm_tail_kernel(const XYZZ<F>* __restrict__ window_sums, MsmGeom g,
                                                        int affine, F* __restrict__ out) {
   __builtin_amdgcn_s_setprio(3);   // latency-bound chain: issue ahead of the accumulation waves sharing the SIMD
-  // one wave, every lane carries the same running total
+  // one wave per MSM instance (blockIdx.x), every lane carries the same running total
+  window_sums += (size_t)blockIdx.x * g.bw;
+  out += (size_t)blockIdx.x * (affine ? 2 : 3);
   XYZZ<F> total = XYZZ<F>::inf();
   for (int w = (int)g.bw - 1; w >= 0; w--) {
     for (unsigned k = 0; k < g.c; k++) total = dbl_wave(total);
@@ -398,63 +300,36 @@ inline void trace_point(hipStream_t s, const char* what) {
 }
 
 template <class F>
-void msm_bucket_phase(hipStream_t s, const MsmSort& st, const MsmBuffers<F>& b, bool out_affine, void* out_dev,
-                      int parts) {
+void msm_bucket_phase(hipStream_t s, const MsmSort& st, const MsmBuffers<F>& b, bool out_affine, void* out_dev) {
   const MsmGeom& g = st.g;
+  const unsigned bwi = g.bw * b.ninst;      // bucket-windows over all instances
   trace_point(s, "(before bucket phase)");
-  if (parts & kBucketFinalize) {
   DG_HIP(hipMemsetAsync(b.giant, 0, 8, s));
-  static const int finalize_mode = [] { const char* e = getenv("DG16_FINALIZE"); return e ? atoi(e) : 0; }();
-  const bool finalize4 = finalize_mode == 4;
-  // G2: the one-lane-per-bucket finalize of THIS translation unit (out-of-line products: small code);
-  // DG16_FINALIZE=1 forces the inline-product instantiation of msm_group.hip for A/B timing
-  bool g2_outlined = false;
   if constexpr (FieldOf<F>::EXT) {
-    if (finalize_mode != 1 && !finalize4) {
-      g2_outlined = true;
-      if (finalize_mode == 2)
-        hipLaunchKernelGGL((msm_finalize_thr2_kernel<F, 1>), dim3((unsigned)((2 * b.nbw + 255) / 256)), dim3(256), 0, s,
-                           st.g, st.counts, st.seg_off, b.seg_sum, b.buckets, b.giant, b.giant + 2, b.giant_cap);
-      else
-        hipLaunchKernelGGL((msm_finalize_thr_kernel<F, 1>), dim3((unsigned)((b.nbw + 255) / 256)), dim3(256), 0, s, st.g,
-                           st.counts, st.seg_off, b.seg_sum, b.buckets, b.giant, b.giant + 2, b.giant_cap);
-    }
-  }
-  if (g2_outlined) {
-  } else if (!finalize4) {
-    // one lane per bucket, inline products (msm_impl.h: a THROUGHPUT kernel -- 2^16 buckets x ~15 partials is a
-    // million full additions, not a latency chain)
-    msm_finalize_phase<F>(s, st, b);
-  } else if constexpr (FieldOf<F>::EXT) {
-    constexpr int BLOCK = sizeof(XYZZ29<F>) * 256 <= 80 * 1024 ? 256 : 128;     // two workgroups per CU (160 KiB LDS)
-    hipLaunchKernelGGL((msm_finalize4_lds_kernel<F, BLOCK>), dim3((unsigned)((b.nbw * 4 + BLOCK - 1) / BLOCK)), dim3(BLOCK),
-                       0, s, g, st.counts, st.seg_off, b.seg_sum, b.buckets, b.giant, b.giant + 2, b.giant_cap);
+    // G2: the finalize of THIS translation unit (out-of-line products: small code, see msm_finalize_thr_kernel)
+    hipLaunchKernelGGL((msm_finalize_thr_kernel<F, 1>), dim3((unsigned)((b.nbw + 255) / 256)), dim3(256), 0, s, st.g,
+                       b.nbw, msm_acc_wg_log<F>(), st.counts, st.seg_off, b.seg_sum, b.buckets, b.giant, b.giant + 2,
+                       b.giant_cap);
   } else {
-    hipLaunchKernelGGL(msm_finalize4_kernel<F>, dim3((unsigned)((b.nbw * 4 + 255) / 256)), dim3(256), 0, s, g,
-                       st.counts, st.seg_off, b.seg_sum, b.buckets, b.giant, b.giant + 2, b.giant_cap);
+    msm_finalize_phase<F>(s, st, b);        // inline products (msm_group.hip)
   }
-  trace_point(s, "finalize4");
+  trace_point(s, "finalize");
   // few workgroups striding over the device-side work list: nothing to do (the common case) costs ~10 us
-  hipLaunchKernelGGL(msm_giant_kernel<F>, dim3(256), dim3(256), 0, s, g, st.counts, st.seg_off, b.seg_sum, b.giant,
-                     b.giant + 2, b.giant_cap);
-  hipLaunchKernelGGL(msm_giant_fold_kernel<F>, dim3(64), dim3(64), 0, s, g, st.counts, st.seg_off, b.seg_sum,
-                     b.buckets, b.giant, b.giant + 2, b.giant_cap);
+  hipLaunchKernelGGL(msm_giant_kernel<F>, dim3(256), dim3(256), 0, s, g, msm_acc_wg_log<F>(), st.counts, st.seg_off,
+                     b.seg_sum, b.giant, b.giant + 2, b.giant_cap);
+  hipLaunchKernelGGL(msm_giant_fold_kernel<F>, dim3(64), dim3(64), 0, s, g, msm_acc_wg_log<F>(), st.counts, st.seg_off,
+                     b.seg_sum, b.buckets, b.giant, b.giant + 2, b.giant_cap);
   trace_point(s, "giant + fold");
-  }
-  if (!(parts & kBucketChain)) {
-    DG_HIP(hipGetLastError());
-    return;
-  }
-  hipLaunchKernelGGL(msm_row_kernel<F>, dim3(1u << b.rg.rows_log, g.bw), dim3(256), 0, s, g, b.rg, b.buckets, b.row_w,
+  hipLaunchKernelGGL(msm_row_kernel<F>, dim3(1u << b.rg.rows_log, bwi), dim3(256), 0, s, g, b.rg, b.buckets, b.row_w,
                      b.row_r);
   trace_point(s, "row");
   if (b.rg.rows_log > 8)
-    hipLaunchKernelGGL(msm_rowfold_kernel<F>, dim3(8, g.bw), dim3(64), 0, s, b.rg, b.row_w, b.row_r, b.fold);
+    hipLaunchKernelGGL(msm_rowfold_kernel<F>, dim3(8, bwi), dim3(64), 0, s, b.rg, b.row_w, b.row_r, b.fold);
   constexpr int HALVES = sizeof(XYZZ29<F>) * 513 <= 160 * 1024 ? 2 : 1;
-  hipLaunchKernelGGL((msm_top_kernel<F, HALVES>), dim3(g.bw), dim3(256 * HALVES), 0, s, b.rg, b.row_w, b.row_r,
+  hipLaunchKernelGGL((msm_top_kernel<F, HALVES>), dim3(bwi), dim3(256 * HALVES), 0, s, b.rg, b.row_w, b.row_r,
                      b.fold, b.window_sums);
   trace_point(s, "top");
-  hipLaunchKernelGGL(msm_tail_kernel<F>, dim3(1), dim3(64), 0, s, b.window_sums, g, (int)out_affine, (F*)out_dev);
+  hipLaunchKernelGGL(msm_tail_kernel<F>, dim3(b.ninst), dim3(64), 0, s, b.window_sums, g, (int)out_affine, (F*)out_dev);
   trace_point(s, "tail");
   DG_HIP(hipGetLastError());
 }

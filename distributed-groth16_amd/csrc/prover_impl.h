@@ -173,9 +173,6 @@ static void msms_typed(dg16_ctx* ctx, Call& k0, Call& k1, Call& k2, const PkDev&
   const Fr* h_in = h_given ? (const Fr*)stage_in(k0, 19, h_given, n_h * sizeof(Fr), dev_ptrs) : nullptr;
   Fr* r_s = (Fr*)ws(k0.c, 22, 4096);
   Jacobian<Fq>* rec = (Jacobian<Fq>*)res_dev;
-  Jacobian<Fq>* res_a = rec + kRecA;
-  Jacobian<Fq>* res_b1 = rec + kRecB1;
-  Jacobian<Fq>* res_l = rec + kRecL;
   Jacobian<Fq>* res_h = rec + kRecH;
   Jacobian<Fq2>* res_b2 = (Jacobian<Fq2>*)(res_dev + kRecG1 * g1j);
   const int first_shard = pk.shard == 0;
@@ -187,101 +184,30 @@ static void msms_typed(dg16_ctx* ctx, Call& k0, Call& k1, Call& k2, const PkDev&
                      (int)(pk.shard + 1 == pk.nshards));
   DG_HIP(hipGetLastError());
   DG_HIP(hipEventRecord(ctx->pipe_ev[8], k0.s()));
-  // Scheduling.  Every saturating kernel of a proof (digit sorts, bucket accumulations, NTTs) goes down ONE
-  // stream (channel 0): they are all VALU-bound, and co-scheduling them was measured equal at best and up to
-  // 1.7x worse from run to run.  The latency-bound bucket reductions (finalize -> chunk -> sums -> tail: a few
-  // hundred dependent group operations on < 10 % of the SIMDs) and the serial s*A, r*B1 run on channels 1 / 2
-  // behind the next accumulation; only the last reduction is exposed.
+  // Scheduling.  Every saturating kernel of a proof (bucket accumulations, NTTs) goes down ONE stream (channel 0):
+  // they are all VALU-bound, and co-scheduling them was measured equal at best and up to 1.7x worse from run to run.
+  // The latency-bound bucket reductions and the serial s*A, r*B1 run on channels 1 / 2 behind the next accumulation;
+  // only the last reduction is exposed.
   hipStream_t main = k0.s(), side = k1.s(), side2 = k2.s();
   hipEvent_t* ev = ctx->pipe_ev;   // persistent (see ctx.h)
-  // DG16_FINALIZE_MAIN=1: the bucket finalize (throughput work) of every MSM stays on the main stream behind its
-  // accumulation; only the latency chain (rows -> top -> tail) goes to the side stream
-  static const bool fin_main = [] { const char* e = getenv("DG16_FINALIZE_MAIN"); return e && atoi(e) != 0; }();
-  const int side_parts = fin_main ? kBucketChain : kBucketAll;
   const Affine<Fq>* fixed_g1 = (const Affine<Fq>*)pk.fixed;
   const Affine<Fq2>* fixed_g2 = (const Affine<Fq2>*)((const uint8_t*)pk.fixed + 4 * sizeof(Affine<Fq>));
-
-  static const bool overlap_sorts = [] { const char* e = getenv("DG16_SORT_OVERLAP"); return !(e && atoi(e) == 0); }();
-  if (!dist && overlap_sorts) {
-    // ---- single-GPU schedule (round 3): the two digit sorts leave the main stream --------------------------------
-    // A digit sort is ten small memory- and latency-bound launches (0.3 ms with the chip nearly idle).  Neither
-    // needs the main stream: the sort of w[1..] ++ [r, s, -rs] depends only on the assignment, so it runs on `side`
-    // underneath the h-polynomial (which now goes FIRST on main -- it needs nothing but a, b, c); the sort of h runs
-    // on `side` underneath the G2 accumulation.  Main: h-poly | B (G2) | A | B1 | L | H, only H's reduction exposed.
-    DG_HIP(hipStreamWaitEvent(side, ev[8], 0));
-    MsmSort st_ab = msm_sort_on<Fr, CT::SCALAR_BITS>(side, k1.c, sc_ab, n_ab + 3, mont, true, pk.c_ab, pk.stride);
-    DG_HIP(hipEventRecord(ev[13], side));
-    const Fr* h_scalars = h_in;
-    if (!h_given) {
-      Fr* h_dev = (Fr*)ws(k0.c, 3, rows * sizeof(Fr));
-      h_poly_launch(k0, CURVE, a_dev, b_dev, c_dev, log_m, h_dev);
-      h_scalars = h_dev + pk.h_lo;
-    }
-    DG_HIP(hipEventRecord(ev[14], main));
-    DG_HIP(hipStreamWaitEvent(side, ev[14], 0));
-    MsmSort st_h = msm_sort_on<Fr, CT::SCALAR_BITS>(side, k0.c, h_scalars, n_h, true, true, pk.c_h, pk.stride);
-    DG_HIP(hipEventRecord(ev[15], side));
-    MsmBuffers<Fq> buf_a = msm_buffers<Fq>(k0.c, st_ab.g);
-    MsmBuffers<Fq> buf_b1 = msm_buffers<Fq>(k1.c, st_ab.g);
-    MsmBuffers<Fq2> buf_b2 = msm_buffers<Fq2>(k2.c, st_ab.g);
-    MsmBuffers<Fq> buf_h = msm_buffers<Fq>(ctx->xws[0], st_h.g);
-    MsmBuffers<Fq> buf_l = msm_buffers<Fq>(ctx->xws[1], st_ab.g);
-    hipStream_t aux = ctx->aux[0];
-    DG_HIP(hipStreamWaitEvent(main, ev[13], 0));
-    DG_HIP(hipEventRecord(k2.c.ev[2], main));
-    msm_accumulate_phase<Fq2>(main, st_ab, buf_b2, pk.b2_q);
-    DG_HIP(hipEventRecord(k2.c.ev[3], main));
-    k2.c.ev_valid[1] = true;
-    DG_HIP(hipEventRecord(ev[2], main));
-    DG_HIP(hipStreamWaitEvent(side2, ev[2], 0));
-    msm_bucket_phase<Fq2>(side2, st_ab, buf_b2, false, res_b2);
-    hipLaunchKernelGGL(prover_stage1_g2_kernel<Fq2>, dim3(1), dim3(64), 0, side2, res_b2, fixed_g2, first_shard);
-    DG_HIP(hipEventRecord(ev[5], side2));
-    DG_HIP(hipEventRecord(k1.c.ev[2], main));
-    msm_accumulate_phase<Fq>(main, st_ab, buf_a, pk.a_q);
-    DG_HIP(hipEventRecord(k1.c.ev[3], main));
-    k1.c.ev_valid[1] = true;
-    DG_HIP(hipEventRecord(ev[0], main));
-    msm_accumulate_phase<Fq>(main, st_ab, buf_b1, pk.b1_q);
-    DG_HIP(hipEventRecord(ev[1], main));
-    DG_HIP(hipStreamWaitEvent(side, ev[0], 0));
-    msm_bucket_phase<Fq>(side, st_ab, buf_a, false, res_a);
-    DG_HIP(hipEventRecord(ev[12], side));
-    DG_HIP(hipStreamWaitEvent(aux, ev[1], 0));
-    msm_bucket_phase<Fq>(aux, st_ab, buf_b1, false, res_b1);
-    DG_HIP(hipStreamWaitEvent(aux, ev[12], 0));
-    hipLaunchKernelGGL((prover_stage1_g1_kernel<Fq, Fr>), dim3(2), dim3(64), 0, aux, rec, fixed_g1, r_s, (int)mont,
-                       first_shard);
-    DG_HIP(hipEventRecord(ev[10], aux));
-    msm_accumulate_phase<Fq>(main, st_ab, buf_l, pk.l_q);
-    DG_HIP(hipEventRecord(ev[6], main));
-    DG_HIP(hipStreamWaitEvent(main, ev[15], 0));
-    msm_accumulate_phase<Fq>(main, st_h, buf_h, pk.h_q);
-    // side (behind A's reduction): L's reduction hides behind H's accumulation; H's is the exposed tail
-    DG_HIP(hipStreamWaitEvent(side, ev[6], 0));
-    msm_bucket_phase<Fq>(side, st_ab, buf_l, false, res_l);
-    msm_bucket_phase<Fq>(main, st_h, buf_h, false, res_h);
-    DG_HIP(hipEventRecord(ev[7], side));
-    DG_HIP(hipStreamWaitEvent(main, ev[7], 0));           // A, L results
-    DG_HIP(hipStreamWaitEvent(main, ev[10], 0));          // B1 result, s*A, r*B1
-    DG_HIP(hipStreamWaitEvent(main, ev[5], 0));           // B result
-    DG_HIP(hipGetLastError());
-    return;
-  }
-  // ONE digit sort for A, B1, B and L (same scalars w[1..] ++ [r, s, -rs]); its buffers live in channel 1
-  MsmSort st_ab = msm_sort_on<Fr, CT::SCALAR_BITS>(main, k1.c, sc_ab, n_ab + 3, mont, true, pk.c_ab, pk.stride);
-  MsmBuffers<Fq> buf_a = msm_buffers<Fq>(k0.c, st_ab.g);
-  MsmBuffers<Fq> buf_b1 = msm_buffers<Fq>(k1.c, st_ab.g);
-  MsmBuffers<Fq2> buf_b2 = msm_buffers<Fq2>(k2.c, st_ab.g);
   // FOUR streams, not more: the runtime multiplexes streams onto 4 hardware queues by default (GPU_MAX_HW_QUEUES);
   // a fifth stream shares a queue with another one and its kernels serialise behind that one's (measured: +3 ms per
-  // 2^20 proof with H's reduction on a fifth stream).  The exchanges ride on `aux`, ahead of B1's reduction.
-  hipStream_t aux = ctx->aux[0], xch = aux;
-  // The sharded h-polynomial is three local stages around two exchanges.  The stages are saturating kernels and stay
-  // on `main` like every other one (co-scheduling them with the accumulations was measured slower: the G2
-  // accumulation holds 144 of a CU's 160 KB of LDS, an NTT workgroup next to it evicts half of it); the EXCHANGES go
-  // down a stream of their own (`xch`) and the stages are interleaved with the accumulations, so that each exchange's
-  // latency hides behind an accumulation:  stage 0 | a2a 1 || B2 | stage 1 | a2a 2 || A, B1 | stage 2, sorts, H, L.
+  // 2^20 proof with H's reduction on a fifth stream).  The exchanges of a distributed proof ride on `aux`.
+  hipStream_t xch = ctx->aux[0];
+
+  // Round-3 schedule.  Main stream (every saturating kernel, back to back):
+  //     h-polynomial | B (G2) accumulation | A, B1, L accumulation -- ONE launch of three instances | H accumulation
+  //   * A, B1 and L share the digit sort of w[1..] ++ [r, s, -rs], so they are instances of one accumulation launch
+  //     and of ONE bucket-reduction chain (msm_impl.h: MsmBases): one ramp-down instead of three, 7 reduction launches
+  //     instead of 21, three times the lanes in each of them;
+  //   * the digit sorts (ten small latency-bound launches each) run on `side`: the sort of w under the h-polynomial
+  //     (which needs nothing but a, b, c and goes first), the sort of h under the G2 accumulation;
+  //   * reductions: B's on `side2` behind its accumulation (the longest chain: it has all G1 accumulations to hide
+  //     behind), A / B1 / L's on `side` followed by the two serial scalar multiples s*A', r*B1'; H's is the exposed tail.
+  // Distributed proof: the three stages of the sharded h-polynomial interleave with the accumulations so that each
+  // all-to-all hides behind one:  stage 0 | a2a 1 || B | stage 1 | a2a 2 || A, B1, L | stage 2 | sort h | H.
   const unsigned n_ranks = dist ? comm->n_ranks(comm->self) : 1, rank = dist ? comm->rank(comm->self) : 0;
   const size_t xbytes = 3 * rows * sizeof(Fr);
   void* xbuf_a = dist ? ws(k0.c, 26, xbytes) : nullptr;
@@ -293,24 +219,43 @@ static void msms_typed(dg16_ctx* ctx, Call& k0, Call& k1, Call& k2, const PkDev&
     DG_REQUIRE(rc == DG16_OK, DG16_ERR_NET, "all-to-all of the sharded h-polynomial failed");
     DG_HIP(hipEventRecord(ev[ev_done], xch));
   };
+
+  // side: the digit sort shared by A, B1, B and L; its buffers live in channel 1
+  DG_HIP(hipStreamWaitEvent(side, ev[8], 0));
+  MsmSort st_ab = msm_sort_on<Fr, CT::SCALAR_BITS>(side, k1.c, sc_ab, n_ab + 3, mont, true, pk.c_ab, pk.stride);
+  DG_HIP(hipEventRecord(ev[13], side));
+  MsmBuffers<Fq> buf_abl = msm_buffers<Fq>(k0.c, st_ab.g, 3);
+  MsmBuffers<Fq2> buf_b2 = msm_buffers<Fq2>(k2.c, st_ab.g);
+
+  // main: h (whole, or stage 0 of the sharded form)
+  Fr* h_dev = h_given ? nullptr : (Fr*)ws(k0.c, 3, rows * sizeof(Fr));
+  const Fr* h_scalars = h_in;
   if (dist) {
     const void* rows_in[3] = {a_dev, b_dev, c_dev};
     h_poly_dist_stage(k0, CURVE, log_m, rank, n_ranks, 0, rows_in, xbuf_a);
     exchange(3, 4);
+  } else if (!h_given) {
+    h_poly_launch(k0, CURVE, a_dev, b_dev, c_dev, log_m, h_dev);
+    h_scalars = h_dev + pk.h_lo;
   }
-  // B (G2) first: its bucket reduction is the longest latency chain of a proof (on a short multi-GPU shard it
-  // outlasts everything else), so it gets the whole rest of the pipeline to hide behind
-  // (timing events of channels 2 / 1 bracket the G2 / first G1 accumulation ON THE STREAM THEY RUN ON, so that
-  // dg16_last_kernel_ms(ctx, 2 or 1, 1) reports the dominant kernels of the proof that was just made)
+  MsmSort st_h;
+  if (!dist) {   // side: the sort of h, underneath the G2 accumulation
+    DG_HIP(hipEventRecord(ev[14], main));
+    DG_HIP(hipStreamWaitEvent(side, ev[14], 0));
+    st_h = msm_sort_on<Fr, CT::SCALAR_BITS>(side, k0.c, h_scalars, n_h, true, true, pk.c_h, pk.stride);
+    DG_HIP(hipEventRecord(ev[15], side));
+  }
+
+  // main: B (G2).  (The timing events of channels 2 / 1 bracket the G2 / G1 accumulation ON THE STREAM THEY RUN ON, so
+  // that dg16_last_kernel_ms(ctx, 2 or 1, 1) reports the dominant kernels of the proof that was just made.)
+  DG_HIP(hipStreamWaitEvent(main, ev[13], 0));
   DG_HIP(hipEventRecord(k2.c.ev[2], main));
   msm_accumulate_phase<Fq2>(main, st_ab, buf_b2, pk.b2_q);
   DG_HIP(hipEventRecord(k2.c.ev[3], main));
   k2.c.ev_valid[1] = true;
-  if (fin_main) msm_bucket_phase<Fq2>(main, st_ab, buf_b2, false, res_b2, kBucketFinalize);
   DG_HIP(hipEventRecord(ev[2], main));
-  // side2: reduction of B, straight behind its accumulation
   DG_HIP(hipStreamWaitEvent(side2, ev[2], 0));
-  msm_bucket_phase<Fq2>(side2, st_ab, buf_b2, false, res_b2, side_parts);
+  msm_bucket_phase<Fq2>(side2, st_ab, buf_b2, false, res_b2);
   hipLaunchKernelGGL(prover_stage1_g2_kernel<Fq2>, dim3(1), dim3(64), 0, side2, res_b2, fixed_g2, first_shard);
   DG_HIP(hipEventRecord(ev[5], side2));
   if (dist) {
@@ -319,55 +264,35 @@ static void msms_typed(dg16_ctx* ctx, Call& k0, Call& k1, Call& k2, const PkDev&
     h_poly_dist_stage(k0, CURVE, log_m, rank, n_ranks, 1, in1, xbuf_a);
     exchange(9, 11);
   }
+
+  // main: A, B1, L -- three instances of one launch; results land in rec[kRecA], rec[kRecB1], rec[kRecL]
+  static_assert(kRecA == 0 && kRecB1 == 1 && kRecL == 2, "the three-instance reduction writes rec[0..2] back to back");
+  const void* abl_tables[3] = {pk.a_q, pk.b1_q, pk.l_q};
   DG_HIP(hipEventRecord(k1.c.ev[2], main));
-  msm_accumulate_phase<Fq>(main, st_ab, buf_a, pk.a_q);
+  msm_accumulate_phase<Fq>(main, st_ab, buf_abl, abl_tables);
   DG_HIP(hipEventRecord(k1.c.ev[3], main));
   k1.c.ev_valid[1] = true;
-  if (fin_main) msm_bucket_phase<Fq>(main, st_ab, buf_a, false, res_a, kBucketFinalize);
   DG_HIP(hipEventRecord(ev[0], main));
-  msm_accumulate_phase<Fq>(main, st_ab, buf_b1, pk.b1_q);
-  if (fin_main) msm_bucket_phase<Fq>(main, st_ab, buf_b1, false, res_b1, kBucketFinalize);
-  DG_HIP(hipEventRecord(ev[1], main));
-  // side: reduction of A; aux: reduction of B1, then BOTH serial scalar multiples s*A', r*B1' in one launch of two
-  // waves (a millisecond each).  They used to follow their reductions on their own streams -- and H's reduction,
-  // queued on `side` behind s*A', became the end of the critical path on short shards.
+  // side: their reduction, then BOTH serial scalar multiples s*A', r*B1' in one launch of two waves
   DG_HIP(hipStreamWaitEvent(side, ev[0], 0));
-  msm_bucket_phase<Fq>(side, st_ab, buf_a, false, res_a, side_parts);
-  DG_HIP(hipEventRecord(ev[12], side));
-  DG_HIP(hipStreamWaitEvent(aux, ev[1], 0));
-  msm_bucket_phase<Fq>(aux, st_ab, buf_b1, false, res_b1, side_parts);
-  DG_HIP(hipStreamWaitEvent(aux, ev[12], 0));
-  hipLaunchKernelGGL((prover_stage1_g1_kernel<Fq, Fr>), dim3(2), dim3(64), 0, aux, rec, fixed_g1, r_s, (int)mont,
+  msm_bucket_phase<Fq>(side, st_ab, buf_abl, false, rec);
+  hipLaunchKernelGGL((prover_stage1_g1_kernel<Fq, Fr>), dim3(2), dim3(64), 0, side, rec, fixed_g1, r_s, (int)mont,
                      first_shard);
-  DG_HIP(hipEventRecord(ev[10], aux));
-  // h (the rest of it) and the digit sort of H
-  const Fr* h_scalars = h_in;
-  if (!h_given) {
-    Fr* h_dev = (Fr*)ws(k0.c, 3, rows * sizeof(Fr));
-    if (dist) {
-      const void* in2[1] = {xbuf_b};
-      DG_HIP(hipStreamWaitEvent(main, ev[11], 0));
-      h_poly_dist_stage(k0, CURVE, log_m, rank, n_ranks, 2, in2, h_dev);
-    } else {
-      h_poly_launch(k0, CURVE, a_dev, b_dev, c_dev, log_m, h_dev);
-    }
-    h_scalars = dist ? h_dev : h_dev + pk.h_lo;
+  DG_HIP(hipEventRecord(ev[10], side));
+
+  // main: the rest of a sharded h, the sort of h where it has not run yet, H and its reduction (the exposed tail)
+  if (dist) {
+    const void* in2[1] = {xbuf_b};
+    DG_HIP(hipStreamWaitEvent(main, ev[11], 0));
+    h_poly_dist_stage(k0, CURVE, log_m, rank, n_ranks, 2, in2, h_dev);
+    st_h = msm_sort_on<Fr, CT::SCALAR_BITS>(main, k0.c, h_dev, n_h, true, true, pk.c_h, pk.stride);
+  } else {
+    DG_HIP(hipStreamWaitEvent(main, ev[15], 0));
   }
-  MsmSort st_h = msm_sort_on<Fr, CT::SCALAR_BITS>(main, k0.c, h_scalars, n_h, true, true, pk.c_h, pk.stride);
-  // H and L own their bucket buffers (288 GB of HBM: a few MB more beat waiting for A's / B1's reductions)
   MsmBuffers<Fq> buf_h = msm_buffers<Fq>(ctx->xws[0], st_h.g);
-  MsmBuffers<Fq> buf_l = msm_buffers<Fq>(ctx->xws[1], st_ab.g);
   msm_accumulate_phase<Fq>(main, st_h, buf_h, pk.h_q);
-  if (fin_main) msm_bucket_phase<Fq>(main, st_h, buf_h, false, res_h, kBucketFinalize);
-  DG_HIP(hipEventRecord(ev[6], main));
-  msm_accumulate_phase<Fq>(main, st_ab, buf_l, pk.l_q);
-  // side (behind A's reduction): H's reduction hides behind L's accumulation; L's is the exposed tail
-  DG_HIP(hipStreamWaitEvent(side, ev[6], 0));
-  msm_bucket_phase<Fq>(side, st_h, buf_h, false, res_h, side_parts);
-  msm_bucket_phase<Fq>(main, st_ab, buf_l, false, res_l);
-  DG_HIP(hipEventRecord(ev[7], side));
-  DG_HIP(hipStreamWaitEvent(main, ev[7], 0));           // A, H results
-  DG_HIP(hipStreamWaitEvent(main, ev[10], 0));          // B1 result, s*A, r*B1
+  msm_bucket_phase<Fq>(main, st_h, buf_h, false, res_h);
+  DG_HIP(hipStreamWaitEvent(main, ev[10], 0));          // A, B1, L results, s*A, r*B1
   DG_HIP(hipStreamWaitEvent(main, ev[5], 0));           // B result
   DG_HIP(hipGetLastError());
 }
