@@ -474,7 +474,7 @@ def main():
     # ---- dominant kernel: the G2 bucket accumulation of the LAST TIMED PROOF (HIP events recorded around it on
     # the stream it ran on: dg16_last_kernel_ms, channel 2 = G2 accumulation, channel 1 = A's G1 accumulation) ----
     g2_acc_ms = ctx.last_kernel_ms(2, 1)
-    g1_acc_ms = ctx.last_kernel_ms(1, 1) / 3.0      # A, B1 and L are three instances of ONE launch: per MSM
+    g1_acc_ms = ctx.last_kernel_ms(1, 1)            # A's accumulation
     info = wl.pk.info()
     n_g2 = info["n_ab"]                              # points of this rank's A / B1 / B launches (slice + 2 delta slots)
     nwin = (SCALAR_BITS[curve] + 1 + info["c_ab"] - 1) // info["c_ab"]

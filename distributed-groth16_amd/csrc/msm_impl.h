@@ -640,7 +640,13 @@ constexpr unsigned msm_acc_block_log() {
 // Fq2 addition inlined next to it spilled 0.9-1.4 KB per lane (the proof got 15 % SLOWER); every lane writes its
 // partial and the finalize adds the ~15 of a bucket as before (out-of-line products, msm_reduce.hip).
 template <class F>
-constexpr bool msm_acc_tree() { return sizeof(F) <= 48; }
+constexpr bool msm_acc_tree() {
+#ifdef DG16_G2_TREE
+  return true;
+#else
+  return sizeof(F) <= 48;
+#endif
+}
 // log2 of the span of segment slots that share ONE partial (msm_part_slot): the workgroup with the tree, one slot without
 template <class F>
 constexpr unsigned msm_acc_wg_log() { return msm_acc_tree<F>() ? msm_acc_block_log<F>() : 0u; }
@@ -780,8 +786,23 @@ msm_accumulate_lds_kernel(MsmBases bases, size_t n, MsmGeom g,
     st(1, y3);
     DG_STAGE();
   }
-  // (no in-workgroup tree here: msm_acc_tree) one partial per segment; a one-segment bucket is written directly
-  if (live) {
+  if constexpr (msm_acc_tree<F>()) {
+    __shared__ unsigned short list[BLOCK];
+    __shared__ unsigned wcnt[BLOCK / 64 + 1];
+    if (inf) st(2, FO::zero());               // the identity for the tree: zz = 0
+    const unsigned hl = live ? (lane > sr.j ? lane - sr.j : 0u) : lane;
+    const unsigned el = live ? (lane - sr.j + sr.k < (unsigned)BLOCK ? lane + sr.k - sr.j : (unsigned)BLOCK) : lane + 1;
+    wg_bucket_tree<F, BLOCK>(sh, list, wcnt, lane, lane - hl, el);
+    if (live && lane == hl) {
+      XYZZ29<F> out = XYZZ29<F>::inf();
+      if (!limbs_all_zero(ld(2))) out = XYZZ29<F>{ld(0), ld(1), ld(2), ld(3)};
+      if (sr.j == 0 && lane + sr.k <= (unsigned)BLOCK)
+        buckets[((size_t)blockIdx.y << g.log_nb) + (sr.bslot & (((size_t)1 << g.log_nb) - 1))] = out;   // the whole bucket
+      else
+        seg_sum[(size_t)blockIdx.y * g.seg_cap + t] = out;    // one partial per (bucket, workgroup): msm_part_slot
+    }
+  } else if (live) {
+    // (no in-workgroup tree here: msm_acc_tree) one partial per segment; a one-segment bucket is written directly
     XYZZ29<F> out = XYZZ29<F>::inf();
     if (!inf) out = XYZZ29<F>{ld(0), ld(1), ld(2), ld(3)};
     if (sr.k == 1) buckets[((size_t)blockIdx.y << g.log_nb) + (sr.bslot & (((size_t)1 << g.log_nb) - 1))] = out;
@@ -1067,8 +1088,11 @@ void msm_accumulate_phase(hipStream_t s, const MsmSort& st, const MsmBuffers<F>&
                        b.seg_sum, b.buckets);
   } else {
     constexpr int BLOCK = 1 << msm_acc_block_log<F>();
+    // DG16_ACC_LDS_PAD=<KiB>: extra (unused) LDS per workgroup = fewer accumulation waves per SIMD = register room for
+    // the waves of the reduction kernels running on the side streams (experiment knob)
+    static const unsigned pad = [] { const char* e = getenv("DG16_ACC_LDS_PAD"); return e ? (unsigned)atoi(e) * 1024u : 0u; }();
     hipLaunchKernelGGL((msm_accumulate_kernel<F, BLOCK>), dim3((g.seg_cap + BLOCK - 1) / BLOCK, g.bw * b.ninst),
-                       dim3(BLOCK), 0, s, mb, st.n, g, st.offsets, st.counts, st.seg_off, st.seg_total, st.entries,
+                       dim3(BLOCK), pad, s, mb, st.n, g, st.offsets, st.counts, st.seg_off, st.seg_total, st.entries,
                        b.seg_sum, b.buckets);
   }
   DG_HIP(hipGetLastError());

@@ -224,7 +224,6 @@ static void msms_typed(dg16_ctx* ctx, Call& k0, Call& k1, Call& k2, const PkDev&
   DG_HIP(hipStreamWaitEvent(side, ev[8], 0));
   MsmSort st_ab = msm_sort_on<Fr, CT::SCALAR_BITS>(side, k1.c, sc_ab, n_ab + 3, mont, true, pk.c_ab, pk.stride);
   DG_HIP(hipEventRecord(ev[13], side));
-  MsmBuffers<Fq> buf_abl = msm_buffers<Fq>(k0.c, st_ab.g, 3);
   MsmBuffers<Fq2> buf_b2 = msm_buffers<Fq2>(k2.c, st_ab.g);
 
   // main: h (whole, or stage 0 of the sharded form)
@@ -265,20 +264,54 @@ static void msms_typed(dg16_ctx* ctx, Call& k0, Call& k1, Call& k2, const PkDev&
     exchange(9, 11);
   }
 
-  // main: A, B1, L -- three instances of one launch; results land in rec[kRecA], rec[kRecB1], rec[kRecL]
+  // main: A, B1, L.  They share the sort, so they CAN run as three instances of one launch with one reduction chain
+  // (DG16_ABL_MERGED=1; results land in rec[kRecA], rec[kRecB1], rec[kRecL]) -- measured SLOWER on one GPU (12.5 vs
+  // 11.4 ms per 2^20 proof): the reduction waves of B (G2: 230-256 VGPRs each) only get onto a SIMD when accumulation
+  // waves leave it, which happens at the end of a launch -- one 4-ms launch starves them where three 1.3-ms launches
+  // do not, and B's reduction chain becomes the critical path.  Default: three launches, three reductions on side
+  // streams (A's and L's on `side`, B1's on `aux` followed by the two serial scalar multiples s*A', r*B1').
   static_assert(kRecA == 0 && kRecB1 == 1 && kRecL == 2, "the three-instance reduction writes rec[0..2] back to back");
-  const void* abl_tables[3] = {pk.a_q, pk.b1_q, pk.l_q};
-  DG_HIP(hipEventRecord(k1.c.ev[2], main));
-  msm_accumulate_phase<Fq>(main, st_ab, buf_abl, abl_tables);
-  DG_HIP(hipEventRecord(k1.c.ev[3], main));
-  k1.c.ev_valid[1] = true;
-  DG_HIP(hipEventRecord(ev[0], main));
-  // side: their reduction, then BOTH serial scalar multiples s*A', r*B1' in one launch of two waves
-  DG_HIP(hipStreamWaitEvent(side, ev[0], 0));
-  msm_bucket_phase<Fq>(side, st_ab, buf_abl, false, rec);
-  hipLaunchKernelGGL((prover_stage1_g1_kernel<Fq, Fr>), dim3(2), dim3(64), 0, side, rec, fixed_g1, r_s, (int)mont,
-                     first_shard);
-  DG_HIP(hipEventRecord(ev[10], side));
+  static const bool merged = [] { const char* e = getenv("DG16_ABL_MERGED"); return e && atoi(e) != 0; }();
+  if (merged) {
+    MsmBuffers<Fq> buf_abl = msm_buffers<Fq>(k0.c, st_ab.g, 3);
+    const void* abl_tables[3] = {pk.a_q, pk.b1_q, pk.l_q};
+    DG_HIP(hipEventRecord(k1.c.ev[2], main));
+    msm_accumulate_phase<Fq>(main, st_ab, buf_abl, abl_tables);
+    DG_HIP(hipEventRecord(k1.c.ev[3], main));
+    k1.c.ev_valid[1] = true;
+    DG_HIP(hipEventRecord(ev[0], main));
+    DG_HIP(hipStreamWaitEvent(side, ev[0], 0));
+    msm_bucket_phase<Fq>(side, st_ab, buf_abl, false, rec);
+    hipLaunchKernelGGL((prover_stage1_g1_kernel<Fq, Fr>), dim3(2), dim3(64), 0, side, rec, fixed_g1, r_s, (int)mont,
+                       first_shard);
+    DG_HIP(hipEventRecord(ev[10], side));
+  } else {
+    MsmBuffers<Fq> buf_a = msm_buffers<Fq>(k0.c, st_ab.g);
+    MsmBuffers<Fq> buf_b1 = msm_buffers<Fq>(k1.c, st_ab.g);
+    MsmBuffers<Fq> buf_l = msm_buffers<Fq>(ctx->xws[1], st_ab.g);
+    DG_HIP(hipEventRecord(k1.c.ev[2], main));
+    msm_accumulate_phase<Fq>(main, st_ab, buf_a, pk.a_q);
+    DG_HIP(hipEventRecord(k1.c.ev[3], main));
+    k1.c.ev_valid[1] = true;
+    DG_HIP(hipEventRecord(ev[0], main));
+    msm_accumulate_phase<Fq>(main, st_ab, buf_b1, pk.b1_q);
+    DG_HIP(hipEventRecord(ev[1], main));
+    msm_accumulate_phase<Fq>(main, st_ab, buf_l, pk.l_q);
+    DG_HIP(hipEventRecord(ev[6], main));
+    DG_HIP(hipStreamWaitEvent(side, ev[0], 0));
+    msm_bucket_phase<Fq>(side, st_ab, buf_a, false, rec + kRecA);
+    DG_HIP(hipEventRecord(ev[12], side));
+    DG_HIP(hipStreamWaitEvent(xch, ev[1], 0));
+    msm_bucket_phase<Fq>(xch, st_ab, buf_b1, false, rec + kRecB1);
+    DG_HIP(hipStreamWaitEvent(xch, ev[12], 0));
+    hipLaunchKernelGGL((prover_stage1_g1_kernel<Fq, Fr>), dim3(2), dim3(64), 0, xch, rec, fixed_g1, r_s, (int)mont,
+                       first_shard);
+    DG_HIP(hipEventRecord(ev[7], xch));
+    DG_HIP(hipStreamWaitEvent(side, ev[6], 0));
+    msm_bucket_phase<Fq>(side, st_ab, buf_l, false, rec + kRecL);
+    DG_HIP(hipStreamWaitEvent(side, ev[7], 0));
+    DG_HIP(hipEventRecord(ev[10], side));             // A, B1, L, s*A', r*B1' all done
+  }
 
   // main: the rest of a sharded h, the sort of h where it has not run yet, H and its reduction (the exposed tail)
   if (dist) {

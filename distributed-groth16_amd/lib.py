@@ -133,7 +133,8 @@ def load():
     L.dg16_h_poly.argtypes = [vp, i, vp, vp, vp, u, vp, u, i]
     L.dg16_msm.argtypes = [vp, i, i, vp, vp, sz, sz, u, i, vp]
     L.dg16_gen_bases.argtypes = [vp, i, i, u64, sz, vp, u, i]
-    L.dg16_ctx_set_table_budget.argtypes = [vp, u64]
+    if hasattr(L, "dg16_ctx_set_table_budget"):      # (absent from older builds named by DG16_LIB for A/B timing)
+        L.dg16_ctx_set_table_budget.argtypes = [vp, u64]
     L.dg16_bases_upload.argtypes = [vp, i, i, vp, sz, u, ctypes.POINTER(vp)]
     L.dg16_bases_free.argtypes = [vp]
     L.dg16_bases_free.restype = None
