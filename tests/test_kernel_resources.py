@@ -21,11 +21,16 @@ def find(prefix):
     return hits
 
 
-def test_g1_bucket_accumulation_has_no_scratch_and_four_waves():
-    (r,) = find("msm_accumulate_kernel<bn254_fq>").values()
-    assert r["scratch"] == 0 and r["agprs"] == 0 and r["occupancy"] >= 4
+def test_g1_bucket_accumulation_keeps_four_waves_with_the_bucket_tree():
+    """The in-workgroup bucket tree (a full XYZZ addition on LDS columns) must not cost the accumulation LOOP its
+    occupancy: 128 VGPRs = four waves per SIMD for BN254; the only scratch is the call frame of the out-of-line
+    doubling (XYZZ29::dbl_cold: two 144-byte points + the return address), on the equal-operands branch."""
+    (r,) = find("msm_accumulate_kernel<bn254_fq,256>").values()
+    assert r["vgprs"] <= 128 and r["agprs"] == 0 and r["occupancy"] >= 4
+    assert r["scratch"] <= 2 * 144 + 32
+    assert r["lds"] == 4 * 9 * 256 * 4 + 256 * 2 + 5 * 4      # partial columns + compaction list + wave counters
     for k, r in find("msm_accumulate_kernel<bls12_").items():
-        assert r["scratch"] == 0, k
+        assert r["occupancy"] >= 3 and r["scratch"] <= 2 * 224 + 160, k
 
 
 def test_g2_bucket_accumulation_stages_through_lds_without_spilling():
@@ -38,8 +43,8 @@ def test_g2_bucket_accumulation_stages_through_lds_without_spilling():
 
 def test_ntt_and_sort_kernels_are_register_and_lds_only():
     for k, r in find("ntt_step_kernel<").items():
-        # 1024 tile elements + 256 staged twiddles, 9 limbs each: three workgroups per CU
-        assert r["scratch"] == 0 and r["lds"] == (1024 + 256) * 9 * 4 and r["occupancy"] >= 3, k
+        # 1024 tile elements of 9 limbs + 512 staged twiddles of 8 packed words: three workgroups per CU
+        assert r["scratch"] == 0 and r["lds"] == 1024 * 9 * 4 + 512 * 8 * 4 and r["occupancy"] >= 3, k
     for name in ("msm_part_hist_kernel<", "msm_part_scatter_kernel<", "msm_part_count_kernel<", "msm_part_place_kernel<",
                  "msm_digits_kernel<", "msm_scatter_kernel<"):
         for k, r in find(name).items():
