@@ -629,22 +629,31 @@ constexpr unsigned kMaxInst = 4;
 struct MsmBases {
   const uint32_t* p[kMaxInst];
 };
+template <class F>
+constexpr bool msm_acc_tree();
 // log2 of the accumulation workgroup of coordinate field F (msm_accumulate_phase)
 template <class F>
 constexpr unsigned msm_acc_block_log() {
   if constexpr (sizeof(F) > 48) return sizeof(typename FieldOf<F>::Store) * 4 * 256 <= 80 * 1024 ? 8u : 7u;
+  else if constexpr (!msm_acc_tree<F>()) return 8u;
   else return sizeof(typename FieldOf<F>::Store) * 4 * 256 <= 40 * 1024 ? 8u : 7u;   // G1: four workgroups' trees per CU
 }
 // Does the accumulation kernel of F add the partials of a bucket inside the workgroup (wg_bucket_tree)?  G1: yes.
 // G2: no -- its loop already takes 173 VGPRs (BN254) / 252 (BLS12-381) with the accumulator in LDS, and the tree's full
 // Fq2 addition inlined next to it spilled 0.9-1.4 KB per lane (the proof got 15 % SLOWER); every lane writes its
 // partial and the finalize adds the ~15 of a bucket as before (out-of-line products, msm_reduce.hip).
+// Coordinate fields up to this size get the tree: the G1 of BN254.  The 48-byte fields (BLS12-381 / -377 G1: 14 limbs,
+// 168 VGPRs in the loop already) were measured with it, same box, same call: 39.4 vs 36.8 ms per 2^20 proof, 131.9 vs
+// 126.5 ms at 2^22 -- the tree's LDS columns and spills cost the loop more than the per-segment finalize they replace.
+#ifndef DG16_TREE_MAX_BYTES
+#define DG16_TREE_MAX_BYTES 32
+#endif
 template <class F>
 constexpr bool msm_acc_tree() {
 #ifdef DG16_G2_TREE
   return true;
 #else
-  return sizeof(F) <= 48;
+  return sizeof(F) <= DG16_TREE_MAX_BYTES;
 #endif
 }
 // log2 of the span of segment slots that share ONE partial (msm_part_slot): the workgroup with the tree, one slot without
@@ -663,10 +672,6 @@ msm_accumulate_kernel(MsmBases bases, size_t n,
                                                               const unsigned* __restrict__ entries,
                                                               XYZZ29<F>* __restrict__ seg_sum,
                                                               XYZZ29<F>* __restrict__ buckets) {
-  using CA = ColAcc<F, BLOCK>;
-  __shared__ uint32_t sh[4 * CA::WORDS][BLOCK];           // the partials of the bucket tree: 36 KiB for a 254-bit field
-  __shared__ unsigned short list[BLOCK];
-  __shared__ unsigned wcnt[BLOCK / 64 + 1];
   const unsigned w = blockIdx.y % g.bw;
   const uint32_t* __restrict__ base_tab = bases.p[blockIdx.y / g.bw];
   const unsigned lane = threadIdx.x;
@@ -688,18 +693,26 @@ msm_accumulate_kernel(MsmBases bases, size_t n,
       cur = nxt;
     }
   }
-  const CA me{sh, lane};
-  me.put(0, acc.x); me.put(1, acc.y); me.put(2, acc.zz); me.put(3, acc.zzz);
-  // my run: the lanes of this workgroup that hold segments of my bucket
-  const unsigned hl = live ? (lane > sr.j ? lane - sr.j : 0u) : lane;
-  const unsigned el = live ? (lane - sr.j + sr.k < (unsigned)BLOCK ? lane + sr.k - sr.j : (unsigned)BLOCK) : lane + 1;
-  wg_bucket_tree<F, BLOCK>(sh, list, wcnt, lane, lane - hl, el);
-  if (live && lane == hl) {
-    const XYZZ29<F> v{me.get(0), me.get(1), me.get(2), me.get(3)};
-    if (sr.j == 0 && lane + sr.k <= (unsigned)BLOCK)
-      buckets[((size_t)blockIdx.y << g.log_nb) + (sr.bslot & (((size_t)1 << g.log_nb) - 1))] = v;   // the whole bucket
-    else
-      seg_sum[(size_t)blockIdx.y * g.seg_cap + t] = v;      // one partial per (bucket, workgroup): msm_part_slot
+  const size_t bucket_slot = ((size_t)blockIdx.y << g.log_nb) + (sr.bslot & (((size_t)1 << g.log_nb) - 1));
+  if constexpr (msm_acc_tree<F>()) {
+    using CA = ColAcc<F, BLOCK>;
+    __shared__ uint32_t sh[4 * CA::WORDS][BLOCK];           // the partials of the bucket tree: 36 KiB for a 254-bit field
+    __shared__ unsigned short list[BLOCK];
+    __shared__ unsigned wcnt[BLOCK / 64 + 1];
+    const CA me{sh, lane};
+    me.put(0, acc.x); me.put(1, acc.y); me.put(2, acc.zz); me.put(3, acc.zzz);
+    // my run: the lanes of this workgroup that hold segments of my bucket
+    const unsigned hl = live ? (lane > sr.j ? lane - sr.j : 0u) : lane;
+    const unsigned el = live ? (lane - sr.j + sr.k < (unsigned)BLOCK ? lane + sr.k - sr.j : (unsigned)BLOCK) : lane + 1;
+    wg_bucket_tree<F, BLOCK>(sh, list, wcnt, lane, lane - hl, el);
+    if (live && lane == hl) {
+      const XYZZ29<F> v{me.get(0), me.get(1), me.get(2), me.get(3)};
+      if (sr.j == 0 && lane + sr.k <= (unsigned)BLOCK) buckets[bucket_slot] = v;   // the whole bucket
+      else seg_sum[(size_t)blockIdx.y * g.seg_cap + t] = v;      // one partial per (bucket, workgroup): msm_part_slot
+    }
+  } else if (live) {
+    if (sr.k == 1) buckets[bucket_slot] = acc;                     // a one-segment bucket needs no finalize
+    else seg_sum[(size_t)blockIdx.y * g.seg_cap + t] = acc;
   }
 }
 
