@@ -663,7 +663,7 @@ constexpr unsigned msm_acc_wg_log() { return msm_acc_tree<F>() ? msm_acc_block_l
 // (waves per SIMD = 4 caps the kernel at 128 VGPRs: the loop needs 108; what the tree's full addition needs beyond
 // that is spilled INSIDE the tree, which a workgroup runs five times, not inside the loop it runs 16 x 4 times)
 template <class F, int BLOCK>
-__global__ void __launch_bounds__(BLOCK, (sizeof(F) > 32 ? 3 : 4))
+__global__ void __launch_bounds__(BLOCK, (sizeof(F) > 32 ? 1 : 4))
 msm_accumulate_kernel(MsmBases bases, size_t n,
                                                               MsmGeom g, const unsigned* __restrict__ offsets,
                                                               const unsigned* __restrict__ counts,

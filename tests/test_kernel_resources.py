@@ -30,7 +30,7 @@ def test_g1_bucket_accumulation_keeps_four_waves_with_the_bucket_tree():
     assert r["scratch"] <= 2 * 144 + 32
     assert r["lds"] == 4 * 9 * 256 * 4 + 256 * 2 + 5 * 4      # partial columns + compaction list + wave counters
     for k, r in find("msm_accumulate_kernel<bls12_").items():      # 48-byte fields: no tree (measured slower), no scratch
-        assert r["occupancy"] >= 3 and r["scratch"] == 0 and r["lds"] == 0, k
+        assert r["occupancy"] >= 2 and r["scratch"] == 0 and r["lds"] == 0, k
 
 
 def test_g2_bucket_accumulation_stages_through_lds_without_spilling():
