@@ -1178,10 +1178,83 @@ __global__ void __launch_bounds__(256) msm_finalize_thr_kernel(MsmGeom g, size_t
   for (unsigned s = 1; s < np; s++) acc = acc.add(sp[msm_part_slot(first, s, wg_log)]);
   buckets[gid] = acc;
 }
+// With the in-workgroup tree the finalize shrinks to a STITCH: one lane per accumulation-workgroup BOUNDARY (a few
+// thousand lanes, not one per bucket) looks at the bucket that straddles it and, if this is the first boundary that
+// bucket crosses, adds the partials its workgroups left.  Buckets held by one workgroup were written by it, empty ones
+// are zeroed by msm_empty_buckets_kernel (all-zero limbs ARE the identity: zz = 0).  A 65 536-lane finalize with nothing
+// to do still took 0.2-0.5 ms inside a proof, waiting for wave slots next to the accumulation.
+template <class F, int TU = 0>
+__global__ void __launch_bounds__(256) msm_stitch_kernel(MsmGeom g, unsigned wg_log, const unsigned* __restrict__ counts,
+                                                          const unsigned* __restrict__ seg_off,
+                                                          const unsigned* __restrict__ seg_total,
+                                                          const XYZZ29<F>* __restrict__ seg_sum,
+                                                          XYZZ29<F>* __restrict__ buckets,
+                                                          unsigned* __restrict__ giant_count,
+                                                          unsigned* __restrict__ giant_list, unsigned giant_cap) {
+  const unsigned wy = blockIdx.y, w = wy % g.bw;
+  const unsigned bd = blockIdx.x * blockDim.x + threadIdx.x + 1;      // boundary between workgroups bd - 1 and bd
+  const unsigned slot = bd << wg_log;
+  if (slot >= seg_total[w]) return;
+  const unsigned* so = seg_off + ((size_t)w << g.log_nb);
+  unsigned lo = 0, hi = 1u << g.log_nb;                                 // the bucket whose segments contain `slot`
+  while (hi - lo > 1) {
+    const unsigned mid = (lo + hi) >> 1;
+    if (so[mid] <= slot) lo = mid; else hi = mid;
+  }
+  const unsigned first = so[lo];
+  if (first == slot || (first >> wg_log) != bd - 1) return;             // starts here, or crossed an earlier boundary
+  const size_t gs = ((size_t)w << g.log_nb) + lo;
+  const size_t gid = ((size_t)wy << g.log_nb) + lo;
+  const unsigned k = (counts[gs] + (1u << g.seg_log) - 1) >> g.seg_log;
+  const unsigned np = msm_nparts(first, k, wg_log);
+  if (np > kGiantSegs) {
+    unsigned gslot = atomicAdd(giant_count, 1u);
+    if (gslot < giant_cap) {
+      giant_list[gslot] = (unsigned)gid;
+      unsigned slices, per;
+      giant_geometry(np, slices, per);
+      unsigned wb = atomicAdd(giant_count + 1, slices);
+      unsigned* work = giant_list + giant_cap;
+      for (unsigned i = 0; i < slices; i++) work[wb + i] = (gslot << 6) | i;
+    }
+    return;
+  }
+  const XYZZ29<F>* sp = seg_sum + (size_t)wy * g.seg_cap;
+  XYZZ29<F> acc = sp[first];
+#pragma unroll 1
+  for (unsigned s = 1; s < np; s++) acc = acc.add(sp[msm_part_slot(first, s, wg_log)]);
+  buckets[gid] = acc;
+}
+// ... and the empty buckets are set to the identity by a kernel of a dozen registers per lane (it fits next to any
+// accumulation wave; a memset on the main stream in front of the accumulation cost a launch boundary per MSM: +0.2 ms
+// per proof, measured)
+template <class F>
+__global__ void __launch_bounds__(256) msm_empty_buckets_kernel(MsmGeom g, size_t total, const unsigned* __restrict__ counts,
+                                                                 XYZZ29<F>* __restrict__ buckets) {
+  const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= total) return;
+  const unsigned wy = (unsigned)(gid >> g.log_nb);
+  const size_t gs = ((size_t)(wy % g.bw) << g.log_nb) + (gid & (((size_t)1 << g.log_nb) - 1));
+  if (counts[gs]) return;
+  uint4* dst = reinterpret_cast<uint4*>(buckets + gid);
+  static_assert(sizeof(XYZZ29<F>) % 16 == 0, "vector stores");
+#pragma unroll
+  for (unsigned i = 0; i < sizeof(XYZZ29<F>) / 16; i++) dst[i] = make_uint4(0u, 0u, 0u, 0u);   // zz = 0: the identity
+}
 template <class F>
 void msm_finalize_phase(hipStream_t s, const MsmSort& st, const MsmBuffers<F>& b) {
-  hipLaunchKernelGGL(msm_finalize_thr_kernel<F>, dim3((unsigned)((b.nbw + 255) / 256)), dim3(256), 0, s, st.g, b.nbw,
-                     msm_acc_wg_log<F>(), st.counts, st.seg_off, b.seg_sum, b.buckets, b.giant, b.giant + 2, b.giant_cap);
+  if constexpr (msm_acc_tree<F>()) {
+    hipLaunchKernelGGL(msm_empty_buckets_kernel<F>, dim3((unsigned)((b.nbw + 255) / 256)), dim3(256), 0, s, st.g, b.nbw,
+                       st.counts, b.buckets);
+    const unsigned nbd = (st.g.seg_cap >> msm_acc_wg_log<F>()) + 1;
+    hipLaunchKernelGGL(msm_stitch_kernel<F>, dim3((nbd + 255) / 256, st.g.bw * b.ninst), dim3(256), 0, s, st.g,
+                       msm_acc_wg_log<F>(), st.counts, st.seg_off, st.seg_total, b.seg_sum, b.buckets, b.giant,
+                       b.giant + 2, b.giant_cap);
+  } else {
+    hipLaunchKernelGGL(msm_finalize_thr_kernel<F>, dim3((unsigned)((b.nbw + 255) / 256)), dim3(256), 0, s, st.g, b.nbw,
+                       msm_acc_wg_log<F>(), st.counts, st.seg_off, b.seg_sum, b.buckets, b.giant, b.giant + 2,
+                       b.giant_cap);
+  }
   DG_HIP(hipGetLastError());
 }
 
