@@ -240,3 +240,60 @@ def test_make_prover_picks_the_driver_by_rank_count():
     assert isinstance(tiny, P.DistributedProver) and not tiny.sharded_h
     py = P.make_prover(Ctx(), Pk(1 << 10), "bn254", Dist(), 0, 4, transport="python")
     assert isinstance(py, P.DistributedProver) and py.sharded_h and "sharded h-polynomial" in py.describe()
+
+
+def _fallback_worker(rank, world, port, q, failure):
+    """One rank of the transport decision: `failure` = 'id' (rank 0 cannot make the RCCL id) or 'join' (rank 1 cannot
+    join the communicator).  Every rank must come out with the SAME transport, and a collective issued afterwards must
+    still match up across the ranks (the round-2 code left rank 0 on torch and rank 1 inside the broadcast)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    try:
+        from dg16_amd import lib, parallel as P
+
+        class Ctx:
+            device = 0
+
+        class Pk:
+            domain_size = 1 << 10
+
+        class FakeRccl:
+            def __init__(self, ctx, uid, n, r):
+                if failure == "join" and r == 1:
+                    raise lib.Dg16Error(6, "ncclCommInitRank: unhandled system error (simulated)")
+                self.closed = False
+
+            def describe(self):
+                return "native RCCL (fake)"
+
+            def close(self):
+                self.closed = True
+
+        def fake_id():
+            if failure == "id":
+                raise lib.Dg16Error(7, "librccl not found (simulated)")
+            return b"\0" * 128
+
+        lib.rccl_unique_id, lib.RcclComm = fake_id, FakeRccl
+        prover = P.make_prover(Ctx(), Pk(), "bn254", dist, rank, world, transport="rccl")
+        kind = type(prover.comm).__name__
+        t = torch.tensor([rank + 1])
+        dist.all_reduce(t)                     # the ranks are still in step
+        q.put((rank, kind, int(t.item())))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("failure", ["id", "join", "none"])
+def test_rccl_fallback_is_a_collective_decision(failure):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_fallback_worker, args=(r, 2, port, q, failure)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    want = "FakeRccl" if failure == "none" else "TorchComm"
+    assert res == [(0, want, 3), (1, want, 3)]
