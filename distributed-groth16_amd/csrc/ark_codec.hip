@@ -1,4 +1,4 @@
-// arkworks compressed key files for BN254 (`ProvingKey::<Bn254>` / `VerifyingKey::<Bn254>` written with
+// arkworks compressed key files for BN254 (and the point codec for BLS12-377 too) (`ProvingKey::<Bn254>` / `VerifyingKey::<Bn254>` written with
 // `serialize_with_mode(.., Compress::Yes)` and read back per request with `deserialize_with_mode(.., Compress::Yes,
 // Validate::No)`: mpc-api/src/main.rs:154-171, :459-512).
 //
@@ -19,14 +19,14 @@
 
 namespace dg16 {
 
-template <class F>
+template <int CURVE, class F>
 __global__ void __launch_bounds__(64) points_encode_kernel(const Affine<F>* __restrict__ in, size_t n,
                                                             uint8_t* __restrict__ out) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   constexpr size_t CB = sizeof(F);      // compressed size = one coordinate
   uint8_t buf[CB];
-  codec::encode(in[i], buf);
+  CodecT<CURVE>::encode(in[i], buf);
   for (size_t k = 0; k < CB; k++) out[i * CB + k] = buf[k];
 }
 
@@ -35,27 +35,41 @@ __device__ void report(unsigned* err, size_t i, int code) {
   const unsigned long long tag = ((unsigned long long)(i + 1) << 8) | (unsigned)code;
   atomicMin((unsigned long long*)err, tag);
 }
-__global__ void __launch_bounds__(64) points_decode_g1_kernel(const uint8_t* __restrict__ in, size_t n,
-                                                               Affine<codec::Fq>* __restrict__ out, unsigned* err) {
+template <int CURVE, class F>
+__global__ void __launch_bounds__(64) points_decode_kernel(const uint8_t* __restrict__ in, size_t n, int validate,
+                                                            Affine<F>* __restrict__ out, unsigned* err) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  uint8_t buf[32];
-  for (int k = 0; k < 32; k++) buf[k] = in[i * 32 + k];
-  Affine<codec::Fq> p;
-  const int rc = codec::decode(buf, p);
-  if (rc) { report(err, i, rc); p = Affine<codec::Fq>::inf(); }
+  constexpr size_t CB = sizeof(F);
+  uint8_t buf[CB];
+  for (size_t k = 0; k < CB; k++) buf[k] = in[i * CB + k];
+  Affine<F> p;
+  const int rc = CodecT<CURVE>::decode(buf, p, validate != 0);
+  if (rc) { report(err, i, rc); p = Affine<F>::inf(); }
   out[i] = p;
 }
-__global__ void __launch_bounds__(64) points_decode_g2_kernel(const uint8_t* __restrict__ in, size_t n, int validate,
-                                                               Affine<codec::Fq2>* __restrict__ out, unsigned* err) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  uint8_t buf[64];
-  for (int k = 0; k < 64; k++) buf[k] = in[i * 64 + k];
-  Affine<codec::Fq2> p;
-  const int rc = codec::decode(buf, p, validate != 0);
-  if (rc) { report(err, i, rc); p = Affine<codec::Fq2>::inf(); }
-  out[i] = p;
+
+template <int CURVE>
+void launch_encode(hipStream_t s, int group, const void* din, size_t n, uint8_t* dout) {
+  using C = CodecT<CURVE>;
+  const unsigned blocks = (unsigned)((n + 63) / 64);
+  if (group == 1)
+    hipLaunchKernelGGL((points_encode_kernel<CURVE, typename C::Fq>), dim3(blocks), dim3(64), 0, s,
+                       (const Affine<typename C::Fq>*)din, n, dout);
+  else
+    hipLaunchKernelGGL((points_encode_kernel<CURVE, typename C::Fq2>), dim3(blocks), dim3(64), 0, s,
+                       (const Affine<typename C::Fq2>*)din, n, dout);
+}
+template <int CURVE>
+void launch_decode(hipStream_t s, int group, const uint8_t* din, size_t n, int validate, void* dout, unsigned* err) {
+  using C = CodecT<CURVE>;
+  const unsigned blocks = (unsigned)((n + 63) / 64);
+  if (group == 1)
+    hipLaunchKernelGGL((points_decode_kernel<CURVE, typename C::Fq>), dim3(blocks), dim3(64), 0, s, din, n, validate,
+                       (Affine<typename C::Fq>*)dout, err);
+  else
+    hipLaunchKernelGGL((points_decode_kernel<CURVE, typename C::Fq2>), dim3(blocks), dim3(64), 0, s, din, n, validate,
+                       (Affine<typename C::Fq2>*)dout, err);
 }
 
 // ---- Vec<F> on the wire: ark-serialize compressed form = u64 length || canonical little-endian elements ----------
@@ -106,22 +120,18 @@ int dg16_points_compress(dg16_ctx* ctx, int curve, int group, const void* affine
   int rc = guard_channel(ctx, channel);
   if (rc) return rc;
   return guarded(ctx, [&] {
-    DG_REQUIRE(curve == DG16_BN254, DG16_ERR_UNSUPPORTED, "arkworks point compression: BN254 only");
+    DG_REQUIRE(curve == DG16_BN254 || curve == DG16_BLS12_377, DG16_ERR_UNSUPPORTED,
+               "arkworks point compression: BN254 and BLS12-377 (ark-bls12-381 uses the zcash encoding)");
     DG_REQUIRE(group == 1 || group == 2, DG16_ERR_BAD_ARG, "group must be 1 (G1) or 2 (G2)");
     DG_REQUIRE((affine && out) || n == 0, DG16_ERR_BAD_ARG, "null operand");
     const bool dev = flags & DG16_F_DEVICE_PTRS;
-    const size_t pb = 64 * group, cb = 32 * group;
+    const size_t fb = curve == DG16_BN254 ? 32 : 48, pb = 2 * fb * group, cb = fb * group;
     Call k(ctx, channel);
     const void* din = stage_in(k, 0, affine, n * pb, dev);
     uint8_t* dout = dev ? (uint8_t*)out : (uint8_t*)ws(k.c, 1, n * cb);
     if (n) {
-      const unsigned blocks = (unsigned)((n + 63) / 64);
-      if (group == 1)
-        hipLaunchKernelGGL(points_encode_kernel<codec::Fq>, dim3(blocks), dim3(64), 0, k.s(), (const Affine<codec::Fq>*)din,
-                           n, dout);
-      else
-        hipLaunchKernelGGL(points_encode_kernel<codec::Fq2>, dim3(blocks), dim3(64), 0, k.s(),
-                           (const Affine<codec::Fq2>*)din, n, dout);
+      if (curve == DG16_BN254) launch_encode<0>(k.s(), group, din, n, dout);
+      else launch_encode<2>(k.s(), group, din, n, dout);
       DG_HIP(hipGetLastError());
     }
     if (!dev) stage_out(k, out, dout, n * cb, false);
@@ -137,24 +147,20 @@ int dg16_points_decompress(dg16_ctx* ctx, int curve, int group, const void* in, 
   int rc = guard_channel(ctx, channel);
   if (rc) return rc;
   return guarded(ctx, [&] {
-    DG_REQUIRE(curve == DG16_BN254, DG16_ERR_UNSUPPORTED, "arkworks point compression: BN254 only");
+    DG_REQUIRE(curve == DG16_BN254 || curve == DG16_BLS12_377, DG16_ERR_UNSUPPORTED,
+               "arkworks point compression: BN254 and BLS12-377 (ark-bls12-381 uses the zcash encoding)");
     DG_REQUIRE(group == 1 || group == 2, DG16_ERR_BAD_ARG, "group must be 1 (G1) or 2 (G2)");
     DG_REQUIRE((in && affine_out) || n == 0, DG16_ERR_BAD_ARG, "null operand");
     const bool dev = flags & DG16_F_DEVICE_PTRS;
-    const size_t pb = 64 * group, cb = 32 * group;
+    const size_t fb = curve == DG16_BN254 ? 32 : 48, pb = 2 * fb * group, cb = fb * group;
     Call k(ctx, channel);
     const uint8_t* din = (const uint8_t*)stage_in(k, 0, in, n * cb, dev);
     void* dout = dev ? affine_out : ws(k.c, 1, n * pb);
     unsigned long long* err = (unsigned long long*)ws(k.c, 2, 16);
     DG_HIP(hipMemsetAsync(err, 0xFF, 8, k.s()));
     if (n) {
-      const unsigned blocks = (unsigned)((n + 63) / 64);
-      if (group == 1)
-        hipLaunchKernelGGL(points_decode_g1_kernel, dim3(blocks), dim3(64), 0, k.s(), din, n, (Affine<codec::Fq>*)dout,
-                           (unsigned*)err);
-      else
-        hipLaunchKernelGGL(points_decode_g2_kernel, dim3(blocks), dim3(64), 0, k.s(), din, n, validate,
-                           (Affine<codec::Fq2>*)dout, (unsigned*)err);
+      if (curve == DG16_BN254) launch_decode<0>(k.s(), group, din, n, validate, dout, (unsigned*)err);
+      else launch_decode<2>(k.s(), group, din, n, validate, dout, (unsigned*)err);
       DG_HIP(hipGetLastError());
     }
     if (!dev) stage_out(k, affine_out, dout, n * pb, false);
