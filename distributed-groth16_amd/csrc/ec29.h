@@ -241,6 +241,49 @@ struct XYZZ29 {
     DG29_STAGE();
     d.put(1, fit<BS>(r_ * (q_ - x3) - s1 * ppp));              // ... (s1 holds a's y)
   }
+  // d += b with d in LDS columns and the SMALLEST live set: U1 = X1 ZZ2 and S1 = Y1 ZZZ2 overwrite X1 / Y1 in place as
+  // soon as they exist, so that -- like the mixed addition of the accumulation loop -- only P, R, PP, PPP live across
+  // the products (add_acc keeps U1 and S1 in registers next to them: 256 VGPRs + 0.8 KB of scratch per lane for Fq2).
+  // b is read-only and intact throughout, so the rare a == b case doubles b.
+  template <class D, class B>
+  DG_HD static void add_into(const D& d, const B& b) {
+    if (limbs_all_zero(b.get(2))) return;
+    if (limbs_all_zero(d.get(2))) {
+      d.put(0, b.get(0)); d.put(1, b.get(1)); d.put(2, b.get(2)); d.put(3, b.get(3));
+      return;
+    }
+    d.put(0, fit<BS>(d.get(0) * b.get(2)));                   // U1
+    DG29_STAGE();
+    d.put(1, fit<BS>(d.get(1) * b.get(3)));                   // S1
+    DG29_STAGE();
+    const auto p_ = norm(b.get(0) * d.get(2) - d.get(0));
+    DG29_STAGE();
+    const auto r_ = norm(b.get(1) * d.get(3) - d.get(1));
+    DG29_STAGE();
+    if (is_zero(p_)) {
+      if (is_zero(r_)) {
+        const XYZZ29 t = XYZZ29{b.get(0), b.get(1), b.get(2), b.get(3)}.dbl_pt()   /* inline: a call makes the kernel take the callee's 256 VGPRs + its spills */;
+        d.put(0, t.x); d.put(1, t.y); d.put(2, t.zz); d.put(3, t.zzz);
+      } else {
+        d.put(2, FO::zero());                                  // the identity: zz = 0
+      }
+      return;
+    }
+    const auto pp = sqr(p_);
+    const auto ppp = p_ * pp;
+    DG29_STAGE();
+    d.put(2, fit<BS>((d.get(2) * b.get(2)) * pp));
+    DG29_STAGE();
+    d.put(3, fit<BS>((d.get(3) * b.get(3)) * ppp));
+    DG29_STAGE();
+    const auto q_ = d.get(0) * pp;
+    DG29_STAGE();
+    const auto x3 = fit<BS>(sqr(r_) - (ppp + dbl(q_)));
+    DG29_STAGE();
+    const auto y3 = fit<BS>(r_ * (q_ - x3) - d.get(1) * ppp);
+    d.put(0, x3);
+    d.put(1, y3);
+  }
   // doubling behind a call: the equal-operands branch of add_acc is rare, its code must not sit in the caller's loop
 #if defined(__HIPCC__)
   __host__ __device__ __attribute__((noinline)) XYZZ29 dbl_cold() const { return dbl_pt(); }

@@ -1059,6 +1059,8 @@ struct MsmBuffers {
   size_t nbw, nrows;     // over all instances
   unsigned ninst;        // MSMs sharing the sort (msm_accumulate_kernel): bucket-window index wy = inst * bw + w
   RowGeom rg;
+  hipEvent_t acc_done = nullptr;   // recorded right behind the accumulation KERNEL (in front of the G2 finalize that
+                                   // msm_accumulate_phase launches after it): the end of dg16_last_kernel_ms's bracket
 };
 
 template <class F>
@@ -1085,6 +1087,11 @@ MsmBuffers<F> msm_buffers(Channel& wsch, const MsmGeom& g, unsigned ninst = 1) {
   return b;
 }
 
+inline int msm_finalize_lds_lpb();
+template <class F>
+struct MsmBuffers;
+template <class F>
+void msm_finalize_lds_phase(hipStream_t s, const MsmSort& st, const MsmBuffers<F>& b);
 // Phase A (saturates the GPU): segment accumulation.  `bases` is the array of n points or, in table mode, the
 // table of W*n points -- in INTERNAL form (msm_to_internal_kernel / msm_table_kernel).
 // bases: b.ninst tables (or plain base arrays), one per instance
@@ -1099,6 +1106,8 @@ void msm_accumulate_phase(hipStream_t s, const MsmSort& st, const MsmBuffers<F>&
     hipLaunchKernelGGL((msm_accumulate_lds_kernel<F, BLOCK>), dim3((g.seg_cap + BLOCK - 1) / BLOCK, g.bw * b.ninst),
                        dim3(BLOCK), 0, s, mb, st.n, g, st.offsets, st.counts, st.seg_off, st.seg_total, st.entries,
                        b.seg_sum, b.buckets);
+    if (b.acc_done) DG_HIP(hipEventRecord(b.acc_done, s));
+    if (msm_finalize_lds_lpb()) msm_finalize_lds_phase<F>(s, st, b);
   } else {
     constexpr int BLOCK = 1 << msm_acc_block_log<F>();
     // DG16_ACC_LDS_PAD=<KiB>: extra (unused) LDS per workgroup = fewer accumulation waves per SIMD = register room for
@@ -1107,6 +1116,7 @@ void msm_accumulate_phase(hipStream_t s, const MsmSort& st, const MsmBuffers<F>&
     hipLaunchKernelGGL((msm_accumulate_kernel<F, BLOCK>), dim3((g.seg_cap + BLOCK - 1) / BLOCK, g.bw * b.ninst),
                        dim3(BLOCK), pad, s, mb, st.n, g, st.offsets, st.counts, st.seg_off, st.seg_total, st.entries,
                        b.seg_sum, b.buckets);
+    if (b.acc_done) DG_HIP(hipEventRecord(b.acc_done, s));
   }
   DG_HIP(hipGetLastError());
 }
@@ -1178,6 +1188,104 @@ __global__ void __launch_bounds__(256) msm_finalize_thr_kernel(MsmGeom g, size_t
   for (unsigned s = 1; s < np; s++) acc = acc.add(sp[msm_part_slot(first, s, wg_log)]);
   buckets[gid] = acc;
 }
+// The same finalize as a THROUGHPUT kernel (G2): LPB lanes per bucket, each summing its share of the bucket's partials
+// into an accumulator that lives in LDS columns between the products (the layout and register budget of
+// msm_accumulate_lds_kernel: two workgroups per CU, ~175 VGPRs), then a log2(LPB)-step tree over neighbouring columns.
+// One lane per bucket at 256 VGPRs ran ~15 dependent Fq2 additions at 70 us each on one wave per SIMD (1.0 ms alone,
+// 2.2 ms inside a proof, where its waves also take the slots of two accumulation waves each: the G1 accumulation next
+// to it stretched by 0.6 ms); here a 2^20-point table MSM is one round of 2 waves per SIMD with 8 + 1 additions per
+// lane.  Runs on the accumulation's own stream, right behind it (msm_accumulate_phase).
+template <class F>
+struct MemAcc {      // an XYZZ29 in memory behind the accessor interface of XYZZ29::add_acc
+  using S = typename FieldOf<F>::Store;
+  const XYZZ29<F>* p;
+  __device__ __forceinline__ S get(int coord) const { return coord == 0 ? p->x : coord == 1 ? p->y : coord == 2 ? p->zz : p->zzz; }
+};
+template <class F, int BLOCK, int LPB>
+__global__ void __launch_bounds__(BLOCK, (BLOCK == 256 ? 2 : 1))
+msm_finalize_lds_kernel(MsmGeom g, size_t total, unsigned wg_log, const unsigned* __restrict__ counts,
+                        const unsigned* __restrict__ seg_off, const XYZZ29<F>* __restrict__ seg_sum,
+                        XYZZ29<F>* __restrict__ buckets, unsigned* __restrict__ giant_count,
+                        unsigned* __restrict__ giant_list, unsigned giant_cap) {
+  using FO = FieldOf<F>;
+  constexpr int WORDS = sizeof(typename FO::Store) / 4;
+  __shared__ uint32_t sh[4 * WORDS][BLOCK];
+  const unsigned lane = threadIdx.x, sub = lane & (LPB - 1);
+  const size_t gid = ((size_t)blockIdx.x * BLOCK + lane) / LPB;
+  const ColAcc<F, BLOCK> me{sh, lane};
+  unsigned np = 0, first = 0;
+  unsigned wy = 0;
+  if (gid < total) {
+    wy = (unsigned)(gid >> g.log_nb);
+    const size_t gs = ((size_t)(wy % g.bw) << g.log_nb) + (gid & (((size_t)1 << g.log_nb) - 1));
+    const unsigned k = (counts[gs] + (1u << g.seg_log) - 1) >> g.seg_log;
+    first = seg_off[gs];
+    np = msm_nparts(first, k, wg_log);
+    if (sub == 0) {
+      if (np == 0) buckets[gid] = XYZZ29<F>::inf();
+      if (np > kGiantSegs) {
+        unsigned slot = atomicAdd(giant_count, 1u);
+        if (slot < giant_cap) {
+          giant_list[slot] = (unsigned)gid;
+          unsigned slices, per;
+          giant_geometry(np, slices, per);
+          unsigned wb = atomicAdd(giant_count + 1, slices);
+          unsigned* work = giant_list + giant_cap;
+          for (unsigned i = 0; i < slices; i++) work[wb + i] = (slot << 6) | i;
+        }
+      }
+    }
+  }
+  const bool work = np >= 2 && np <= kGiantSegs;      // np == 1: the accumulation wrote the bucket itself
+  const XYZZ29<F>* sp = seg_sum + (size_t)wy * g.seg_cap;
+  const unsigned lo = work ? (unsigned)(((uint64_t)sub * np) / LPB) : 0u;
+  const unsigned hi = work ? (unsigned)(((uint64_t)(sub + 1) * np) / LPB) : 0u;
+  if (lo < hi) {
+    const XYZZ29<F>* q = &sp[msm_part_slot(first, lo, wg_log)];
+    me.put(0, q->x); me.put(1, q->y); me.put(2, q->zz); me.put(3, q->zzz);
+  } else {
+    me.put(2, FO::zero());                              // the identity for add_acc: zz = 0
+  }
+#pragma unroll 1
+  for (unsigned s = lo + 1; s < hi; s++) XYZZ29<F>::add_into(me, MemAcc<F>{&sp[msm_part_slot(first, s, wg_log)]});
+#pragma unroll 1
+  for (unsigned d = 1; d < (unsigned)LPB; d <<= 1) {
+    __syncthreads();
+    if (work && (sub & (2 * d - 1)) == 0) XYZZ29<F>::add_into(me, ColAcc<F, BLOCK>{sh, lane + d});
+  }
+  if (work && sub == 0) {
+    XYZZ29<F> out = XYZZ29<F>::inf();
+    if (!limbs_all_zero(me.get(2))) out = XYZZ29<F>{me.get(0), me.get(1), me.get(2), me.get(3)};
+    buckets[gid] = out;
+  }
+}
+// G2 finalize as a throughput kernel behind the accumulation (default) or the one-lane-per-bucket kernel on the
+// reduction stream (DG16_FINALIZE_LDS=0); lanes per bucket: DG16_FINALIZE_LPB = 1, 2 (default), 4
+inline int msm_finalize_lds_lpb() {
+  static const int v = [] {
+    const char* e = getenv("DG16_FINALIZE_LDS");
+    if (e && atoi(e) == 0) return 0;
+    const char* l = getenv("DG16_FINALIZE_LPB");
+    const int lpb = l ? atoi(l) : 2;
+    return lpb == 1 || lpb == 4 ? lpb : 2;
+  }();
+  return v;
+}
+template <class F>
+void msm_finalize_lds_phase(hipStream_t s, const MsmSort& st, const MsmBuffers<F>& b) {
+  constexpr int BLOCK = 1 << msm_acc_block_log<F>();
+  const int lpb = msm_finalize_lds_lpb();
+  DG_HIP(hipMemsetAsync(b.giant, 0, 8, s));
+  const unsigned blocks = (unsigned)((b.nbw * (size_t)lpb + BLOCK - 1) / BLOCK);
+#define DG_FIN(L)                                                                                                     \
+  hipLaunchKernelGGL((msm_finalize_lds_kernel<F, BLOCK, L>), dim3(blocks), dim3(BLOCK), 0, s, st.g, b.nbw,             \
+                     msm_acc_wg_log<F>(), st.counts, st.seg_off, b.seg_sum, b.buckets, b.giant, b.giant + 2, b.giant_cap)
+  if (lpb == 1) DG_FIN(1);
+  else if (lpb == 4) DG_FIN(4);
+  else DG_FIN(2);
+#undef DG_FIN
+}
+
 // With the in-workgroup tree the finalize shrinks to a STITCH: one lane per accumulation-workgroup BOUNDARY (a few
 // thousand lanes, not one per bucket) looks at the bucket that straddles it and, if this is the first boundary that
 // bucket crosses, adds the partials its workgroups left.  Buckets held by one workgroup were written by it, empty ones
@@ -1271,8 +1379,9 @@ template <class F>
 void msm_reduce(Call& k, const MsmSort& st, const void* bases, bool out_affine, void* out_dev) {
   MsmBuffers<F> b = msm_buffers<F>(k.c, st.g);
   k.begin_dominant();
+  b.acc_done = k.c.ev[3];                    // = end_dominant(), but in front of the G2 finalize
   msm_accumulate_phase<F>(k.s(), st, b, bases);
-  k.end_dominant();
+  k.c.ev_valid[1] = true;
   msm_bucket_phase<F>(k.s(), st, b, out_affine, out_dev);
 }
 

@@ -220,10 +220,15 @@ static void msms_typed(dg16_ctx* ctx, Call& k0, Call& k1, Call& k2, const PkDev&
     DG_HIP(hipEventRecord(ev[ev_done], xch));
   };
 
+  // DG16_HPOLY_SIDE=1 (experiment): the sort of w goes down MAIN and the h-polynomial + the sort of h go down `side`,
+  // so that the G2 accumulation starts as soon as the digits exist and the (memory-bound) transforms run next to it.
+  static const bool hpoly_side = [] { const char* e = getenv("DG16_HPOLY_SIDE"); return e && atoi(e) != 0; }();
+  const bool swap_h = hpoly_side && !dist && !h_given;
   // side: the digit sort shared by A, B1, B and L; its buffers live in channel 1
+  hipStream_t sort_stream = swap_h ? main : side;
   DG_HIP(hipStreamWaitEvent(side, ev[8], 0));
-  MsmSort st_ab = msm_sort_on<Fr, CT::SCALAR_BITS>(side, k1.c, sc_ab, n_ab + 3, mont, true, pk.c_ab, pk.stride);
-  DG_HIP(hipEventRecord(ev[13], side));
+  MsmSort st_ab = msm_sort_on<Fr, CT::SCALAR_BITS>(sort_stream, k1.c, sc_ab, n_ab + 3, mont, true, pk.c_ab, pk.stride);
+  DG_HIP(hipEventRecord(ev[13], sort_stream));
   MsmBuffers<Fq2> buf_b2 = msm_buffers<Fq2>(k2.c, st_ab.g);
 
   // main: h (whole, or stage 0 of the sharded form)
@@ -234,7 +239,9 @@ static void msms_typed(dg16_ctx* ctx, Call& k0, Call& k1, Call& k2, const PkDev&
     h_poly_dist_stage(k0, CURVE, log_m, rank, n_ranks, 0, rows_in, xbuf_a);
     exchange(3, 4);
   } else if (!h_given) {
+    if (swap_h) k0.c.cur = side;          // the launches of h_poly_launch follow the channel's current stream
     h_poly_launch(k0, CURVE, a_dev, b_dev, c_dev, log_m, h_dev);
+    k0.c.cur = main;
     h_scalars = h_dev + pk.h_lo;
   }
   MsmSort st_h;
@@ -249,8 +256,8 @@ static void msms_typed(dg16_ctx* ctx, Call& k0, Call& k1, Call& k2, const PkDev&
   // that dg16_last_kernel_ms(ctx, 2 or 1, 1) reports the dominant kernels of the proof that was just made.)
   DG_HIP(hipStreamWaitEvent(main, ev[13], 0));
   DG_HIP(hipEventRecord(k2.c.ev[2], main));
+  buf_b2.acc_done = k2.c.ev[3];              // the accumulation kernel alone; its finalize follows on the same stream
   msm_accumulate_phase<Fq2>(main, st_ab, buf_b2, pk.b2_q);
-  DG_HIP(hipEventRecord(k2.c.ev[3], main));
   k2.c.ev_valid[1] = true;
   DG_HIP(hipEventRecord(ev[2], main));
   DG_HIP(hipStreamWaitEvent(side2, ev[2], 0));

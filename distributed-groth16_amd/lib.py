@@ -420,18 +420,25 @@ class Context:
         flags = F_DEVICE_PTRS | (F_SCALARS_MONT if scalars_mont else 0) | (F_OUT_AFFINE if affine else 0)
         self._chk(self.L.dg16_msm_resident(self.h, hb.h, _ptr(scalars_ptr), n, flags, channel, _ptr(out_ptr)))
 
+    @staticmethod
+    def _coord_bytes(curve):
+        return 32 if curve == "bn254" else 48
+
     def points_compress(self, curve, group, affine, channel=0):
-        """affine: uint64 array [n][8 * group] (x || y Montgomery limbs) -> bytes, 32 * group per point (arkworks)."""
-        affine = np.ascontiguousarray(affine, dtype=np.uint64).reshape(-1, 8 * group)
-        out = np.zeros(affine.shape[0] * 32 * group, dtype=np.uint8)
+        """affine: uint64 array [n][2 * limbs * group] (x || y Montgomery limbs; limbs = 4 for BN254, 6 for BLS12-377)
+        -> bytes, one coordinate (32 / 48 bytes, x2 for G2) per point (arkworks Compress::Yes)."""
+        fb = self._coord_bytes(curve)
+        affine = np.ascontiguousarray(affine, dtype=np.uint64).reshape(-1, fb // 4 * group)
+        out = np.zeros(affine.shape[0] * fb * group, dtype=np.uint8)
         self._chk(self.L.dg16_points_compress(self.h, CURVES[curve], group, _ptr(affine), affine.shape[0], _ptr(out), 0,
                                               channel))
         return out.tobytes()
 
     def points_decompress(self, curve, group, raw, validate=False, channel=0):
+        fb = self._coord_bytes(curve)
         raw = np.frombuffer(bytes(raw), dtype=np.uint8)
-        n = raw.size // (32 * group)
-        out = np.zeros((n, 8 * group), dtype=np.uint64)
+        n = raw.size // (fb * group)
+        out = np.zeros((n, fb // 4 * group), dtype=np.uint64)
         self._chk(self.L.dg16_points_decompress(self.h, CURVES[curve], group, _ptr(raw), n, int(validate), _ptr(out), 0,
                                                 channel))
         return out

@@ -130,6 +130,32 @@ template <class F> static void point_op29(int op, const Affine<F>* a, const Affi
         XYZZ29<F> na = A.dbl_pt().neg_pt(), nb = B.dbl_pt().neg_pt();
         XYZZ29<F>::add_mem(&n3, &n3, &na);
         XYZZ29<F>::add_mem(&n3, &n3, &nb);
+        // the accessor forms (in-workgroup bucket tree: add_acc; throughput finalize: add_into), incl. identity operands,
+        // equal operands (doubling) and inverse operands (identity result): 3a + 3b - 2a - 2b again, then a + a, a - a
+        {
+          struct Acc {
+            XYZZ29<F>* p;
+            typename FO::Store get(int c) const { return c == 0 ? p->x : c == 1 ? p->y : c == 2 ? p->zz : p->zzz; }
+            void put(int c, const typename FO::Store& v) const { (c == 0 ? p->x : c == 1 ? p->y : c == 2 ? p->zz : p->zzz) = v; }
+          };
+          for (int form = 0; form < 2; form++) {
+            auto plus = [&](XYZZ29<F>& d, XYZZ29<F> o) {
+              if (form == 0) XYZZ29<F>::add_acc(Acc{&d}, Acc{&d}, Acc{&o});
+              else XYZZ29<F>::add_into(Acc{&d}, Acc{&o});
+            };
+            XYZZ29<F> acc = XYZZ29<F>::inf();
+            acc.zz = FO::zero();
+            plus(acc, m3); plus(acc, B.dbl_pt().add(B)); plus(acc, na); plus(acc, nb);
+            XYZZ29<F> dd = A, zz_ = A;
+            plus(dd, A);                               // doubling branch
+            plus(dd, A.dbl_pt().neg_pt());             // -> identity (inverse operands), unless a is the identity
+            plus(zz_, XYZZ29<F>::inf());               // identity operand: unchanged
+            XYZZ<F> x = r.to_xyzz32(), y = acc.to_xyzz32(), z0 = zz_.to_xyzz32(), a0 = A.to_xyzz32();
+            Affine<F> xa = x.to_affine(), ya = y.to_affine(), za = z0.to_affine(), aa = a0.to_affine();
+            if (!(xa.x == ya.x) || !(xa.y == ya.y) || !dd.is_inf() || !(za.x == aa.x) || !(za.y == aa.y))
+              r = XYZZ29<F>::inf().madd(pa, false);    // poison
+          }
+        }
         XYZZ29<F> same = A, twice;                    // a + a through add_mem = the doubling branch
         XYZZ29<F>::add_mem(&twice, &same, &A);
         XYZZ29<F> chk = twice.add(A.dbl_pt().neg_pt());
@@ -210,4 +236,29 @@ extern "C" int ha_rr_consts(int fid, uint32_t* out, size_t cap) {
     case 18: return (int)rr_dump<bls12_377_fr_params>(out, cap);
     default: return 0;
   }
+}
+
+// ---- the arkworks point codec (csrc/codec_impl.h), host instantiation: BN254 and BLS12-377 ---------------------
+#include "../../distributed-groth16_amd/csrc/codec_impl.h"
+template <int CURVE> static int codec_run(int group, int decode, int validate, const uint8_t* in, uint8_t* out, size_t n, int* rc) {
+  using C = CodecT<CURVE>;
+  const size_t fb = C::FB;
+  for (size_t i = 0; i < n; i++) {
+    if (group == 1) {
+      using A = Affine<typename C::Fq>;
+      if (decode) { A p = A::inf(); rc[i] = C::decode(in + i * fb, p, validate != 0); memcpy(out + i * sizeof(A), &p, sizeof(A)); }
+      else { A p; memcpy(&p, in + i * sizeof(A), sizeof(A)); C::encode(p, out + i * fb); rc[i] = 0; }
+    } else {
+      using A = Affine<typename C::Fq2>;
+      if (decode) { A p = A::inf(); rc[i] = C::decode(in + i * 2 * fb, p, validate != 0); memcpy(out + i * sizeof(A), &p, sizeof(A)); }
+      else { A p; memcpy(&p, in + i * sizeof(A), sizeof(A)); C::encode(p, out + i * 2 * fb); rc[i] = 0; }
+    }
+  }
+  return 0;
+}
+// decode = 0: in = affine Montgomery limbs -> out = compressed bytes; decode = 1: the reverse, rc[i] = the codec's code
+extern "C" int ha_codec(int curve, int group, int decode, int validate, const void* in, void* out, size_t n, int* rc) {
+  if (curve == 0) return codec_run<0>(group, decode, validate, (const uint8_t*)in, (uint8_t*)out, n, rc);
+  if (curve == 2) return codec_run<2>(group, decode, validate, (const uint8_t*)in, (uint8_t*)out, n, rc);
+  return -1;
 }

@@ -118,6 +118,53 @@ def test_point_codec_matches_the_python_implementation():
 
 
 @pytest.mark.gpu
+def test_point_codec_bls12_377():
+    """ark-bls12-377 uses the same default encoding (48 / 96 bytes): the group elements of the reference's d_msm tests
+    on the wire.  Against the generic plain-Python encoder (tests/ark_points_py.py); Validate::Yes also checks G1 here
+    (cofactor != 1); BLS12-381 (zcash encoding in arkworks) is refused."""
+    import ark_points_py as A
+    from oracle import corc
+    from oracle.pyref.curves import CURVES
+    c = _ctx()
+    Fq = FQ["bls12_377"]
+    rng = random.Random(8)
+
+    def arr_of(group, pts):
+        out = np.zeros((len(pts), 12 * group), dtype=np.uint64)
+        for k, P in enumerate(pts):
+            if P is not None:
+                co = [P[0], P[1]] if group == 1 else [P[0][0], P[0][1], P[1][0], P[1][1]]
+                out[k] = corc.ints_to_arr([Fq.to_mont(v) for v in co], 6).reshape(-1)
+        return out
+
+    for group in (1, 2):
+        C = CURVES["bls12_377", "g%d" % group]
+        pts = [C.mul(C.gen, rng.randrange(1, C.order)) for _ in range(70)] + [C.mul(C.gen, k) for k in (1, 2, 3)]
+        pts += [None, C.neg(pts[0]), pts[0]]
+        arr = arr_of(group, pts)
+        want = b"".join(A.encode("bls12_377", group, P) for P in pts)
+        assert c.points_compress("bls12_377", group, arr) == want
+        assert np.array_equal(c.points_decompress("bls12_377", group, want, validate=True), arr)
+        cb = 48 * group
+        bads = [(Fq.p + 1).to_bytes(48, "little") + bytes(cb - 48)]
+        both = bytearray(cb)
+        both[-1] = 0xC0
+        bads.append(bytes(both))
+        if group == 1:
+            bads.append(A.x_off_curve("bls12_377").to_bytes(48, "little"))
+        for bad in bads:
+            with pytest.raises(dg16_amd.Dg16Error):
+                c.points_decompress("bls12_377", group, want[:cb] + bad)
+        outside = A.g1_point_outside_subgroup("bls12_377") if group == 1 else A.twist_point_outside_subgroup("bls12_377")
+        raw = A.encode("bls12_377", group, outside)
+        assert np.array_equal(c.points_decompress("bls12_377", group, raw, validate=False), arr_of(group, [outside]))
+        with pytest.raises(dg16_amd.Dg16Error, match="subgroup"):
+            c.points_decompress("bls12_377", group, raw, validate=True)
+    with pytest.raises(dg16_amd.Dg16Error):
+        c.points_compress("bls12_381", 1, np.zeros((1, 12), dtype=np.uint64))
+
+
+@pytest.mark.gpu
 def test_proving_key_file_to_proof():
     """key file (written by the Python encoder) -> read_proving_key (GPU square roots) -> dg16_pk_create -> prove ==
     the oracle's proof; write_proving_key(read(...)) gives the file back."""

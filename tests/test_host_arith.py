@@ -21,7 +21,7 @@ SO = os.path.join(HERE, "host_arith", "libhost_arith.so")
 @pytest.fixture(scope="module")
 def ha():
     hdrs = [os.path.join(HERE, "..", "distributed-groth16_amd", "csrc", f)
-            for f in ("fp.h", "fp2.h", "ec.h", "consts_gen.h", "fp29.h", "ec29.h")]
+            for f in ("fp.h", "fp2.h", "ec.h", "consts_gen.h", "fp29.h", "ec29.h", "codec_impl.h", "types.h")]
     if not os.path.exists(SO) or any(os.path.getmtime(SO) < os.path.getmtime(p) for p in [SRC] + hdrs):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", SO, SRC])
     L = ctypes.CDLL(SO)
@@ -30,6 +30,7 @@ def ha():
     L.ha_point_op.argtypes = [i, i, i, vp, vp, vp, sz]
     L.ha_field_op29.argtypes = [i, i, vp, vp, vp, sz]
     L.ha_point_op29.argtypes = [i, i, i, vp, vp, vp, sz]
+    L.ha_codec.argtypes = [i, i, i, i, vp, vp, sz, vp]
     return L
 
 
@@ -130,3 +131,69 @@ def test_reduced_radix_field_ops(ha, curve, kind):
     f = lambda op, x, y=None: corc.field_op(curve, kind, op, x, y)   # noqa: E731
     exp = f("sub", f("add", f("mul", f("add", A, B), f("sub", A, B)), f("mul", A, B)), f("sqr", B))
     assert np.array_equal(out, exp)
+
+
+# ---- arkworks compressed points: csrc/codec_impl.h on the host against the plain-Python encoder -------------------
+def _affine_arr(curve, group, pts):
+    Fq = FQ[curve]
+    nl = Fq.limbs64
+    out = np.zeros((len(pts), 2 * nl * group), dtype=np.uint64)
+    for k, P in enumerate(pts):
+        if P is None:
+            continue
+        co = [P[0], P[1]] if group == 1 else [P[0][0], P[0][1], P[1][0], P[1][1]]
+        out[k] = corc.ints_to_arr([Fq.to_mont(v) for v in co], nl).reshape(-1)
+    return out
+
+
+def _codec(ha, curve, group, decode, validate, data, n, out_bytes):
+    out = np.zeros(out_bytes, dtype=np.uint8)
+    rc = np.zeros(n, dtype=np.int32)
+    inp = np.frombuffer(bytes(data), dtype=np.uint8) if not isinstance(data, np.ndarray) else data
+    assert ha.ha_codec({"bn254": 0, "bls12_377": 2}[curve], group, decode, validate, _p(inp), _p(out), n, _p(rc)) == 0
+    return out, rc
+
+
+@pytest.mark.parametrize("curve", ["bn254", "bls12_377"])
+@pytest.mark.parametrize("group", [1, 2])
+def test_point_codec_host(ha, curve, group):
+    """encode == the Python encoder byte for byte; decode(encode(P)) == P (both signs, identity, small multiples whose
+    square roots take different Tonelli-Shanks paths); x off the curve, unreduced coordinate, both flags, and a curve
+    point outside the order-r subgroup (Validate::Yes only) are refused with the codec's codes."""
+    import ark_points_py as A
+    from oracle.pyref.curves import CURVES
+    C = CURVES[curve, "g%d" % group]
+    rng = random.Random(11 * group)
+    n = 14 if curve == "bn254" else 8
+    pts = [C.mul(C.gen, rng.randrange(1, C.order)) for _ in range(n)] + [C.mul(C.gen, k) for k in (1, 2, 3)]
+    pts += [None, C.neg(pts[0]), pts[0]]
+    fb = A.fbytes(curve)
+    cb, pb = fb * group, 2 * fb * group
+    arr = _affine_arr(curve, group, pts)
+    want = b"".join(A.encode(curve, group, P) for P in pts)
+    got, _ = _codec(ha, curve, group, 0, 0, arr.view(np.uint8).reshape(-1), len(pts), cb * len(pts))
+    assert got.tobytes() == want
+    back, rc = _codec(ha, curve, group, 1, 1, want, len(pts), pb * len(pts))
+    assert not rc.any()
+    assert np.array_equal(back.view(np.uint64).reshape(len(pts), -1), arr)
+    q = C.F.p
+    bads = [((q + 1).to_bytes(fb, "little") + bytes(cb - fb), 2)]
+    both = bytearray(cb)
+    both[-1] = 0xC0
+    bads.append((bytes(both), 1))
+    inf_x = bytearray(cb)
+    inf_x[0], inf_x[-1] = 1, 0x40
+    bads.append((bytes(inf_x), 1))                    # stricter than arkworks 0.4, documented in include/dg16.h
+    if group == 1:
+        bads.append((A.x_off_curve(curve).to_bytes(fb, "little"), 3))
+    for raw, code in bads:
+        _, rc = _codec(ha, curve, group, 1, 0, raw, 1, pb)
+        assert rc[0] == code, (raw.hex(), rc[0], code)
+    outside = A.twist_point_outside_subgroup(curve) if group == 2 else \
+        (A.g1_point_outside_subgroup(curve) if curve != "bn254" else None)
+    if outside is not None:
+        raw = A.encode(curve, group, outside)
+        dec, rc = _codec(ha, curve, group, 1, 0, raw, 1, pb)
+        assert rc[0] == 0 and np.array_equal(dec.view(np.uint64).reshape(1, -1), _affine_arr(curve, group, [outside]))
+        _, rc = _codec(ha, curve, group, 1, 1, raw, 1, pb)
+        assert rc[0] == 4
