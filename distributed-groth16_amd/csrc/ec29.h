@@ -1,6 +1,7 @@
 // Short-Weierstrass (a = 0) group arithmetic on the reduced-radix field types of fp29.h -- the bucket phases of the
 // MSM (segment accumulation, bucket reduction).  Same formulas and completeness rules as ec.h (XYZZ coordinates:
-// mixed add 8M + 2S, add 12M + 2S, doubling 6M + 3S; identity / doubling / inverse operands handled because the
+// mixed add 8M + 2S, add 12M + 2S, doubling 6M + 3S; over a prime field Y3 = R (Q - X3) - PPP Y1 is ONE dual product,
+// mul_sub: nine Montgomery reductions per mixed addition, not ten; identity / doubling / inverse operands handled because the
 // reference's own tests feed them: dist-primitives/src/dmsm/mod.rs:155-159), but every temporary carries its bounds
 // in its type (`auto`), products normalise an operand only where a column could overflow, and coordinates are
 // stored normalised below a fixed storage bound BS p: nothing is compared or conditionally subtracted between
@@ -89,7 +90,7 @@ struct XYZZ29 {
     const auto xx = sqr(qx);
     const auto m = dbl(xx) + xx;
     const auto x3 = fit<BS>(sqr(m) - dbl(s));
-    const auto y3 = m * (s - x3) - w * qy;
+    const auto y3 = mul_sub(m, s - x3, w, qy);
     return {x3, fit<BS>(y3), fit<BS>(v), fit<BS>(w)};
   }
   // 2 this                                                                 (dbl-2008-s-1, a = 0)
@@ -102,7 +103,7 @@ struct XYZZ29 {
     const auto xx = sqr(x);
     const auto m = dbl(xx) + xx;
     const auto x3 = fit<BS>(sqr(m) - dbl(s));
-    const auto y3 = m * (s - x3) - w * y;
+    const auto y3 = mul_sub(m, s - x3, w, y);
     return {x3, fit<BS>(y3), fit<BS>(v * zz), fit<BS>(w * zzz)};
   }
   // this + (negate ? -q : q), q affine                                      (madd-2008-s)
@@ -123,7 +124,7 @@ struct XYZZ29 {
     const auto ppp = p_ * pp;
     const auto q_ = x * pp;
     const auto x3 = fit<BS>(sqr(r_) - (ppp + dbl(q_)));
-    const auto y3 = r_ * (q_ - x3) - y * ppp;
+    const auto y3 = mul_sub(r_, q_ - x3, ppp, y);
     return {x3, fit<BS>(y3), fit<BS>(zz * pp), fit<BS>(zzz * ppp)};
   }
   // this + o                                                                 (add-2008-s)
@@ -144,7 +145,7 @@ struct XYZZ29 {
     const auto ppp = p_ * pp;
     const auto q_ = u1 * pp;
     const auto x3 = fit<BS>(sqr(r_) - (ppp + dbl(q_)));
-    const auto y3 = r_ * (q_ - x3) - s1 * ppp;
+    const auto y3 = mul_sub(r_, q_ - x3, ppp, s1);
     return {x3, fit<BS>(y3), fit<BS>((zz * o.zz) * pp), fit<BS>((zzz * o.zzz) * ppp)};
   }
   // ---- the same operations on operands that stay in memory (LDS / global / private) --------------------------
@@ -195,7 +196,7 @@ struct XYZZ29 {
     const auto x3 = fit<BS>(sqr(r_) - (ppp + dbl(q_)));
     dst->x = x3;
     DG29_STAGE();
-    dst->y = fit<BS>(r_ * (q_ - x3) - s1 * ppp);
+    dst->y = fit<BS>(mul_sub(r_, q_ - x3, ppp, s1));
   }
   // The same addition on operands behind ACCESSORS (get(coord) loads a coordinate where a product consumes it,
   // put(coord, v) stores one): the in-workgroup bucket tree of the accumulation kernels keeps its operands in LDS
@@ -239,7 +240,7 @@ struct XYZZ29 {
     const auto x3 = fit<BS>(sqr(r_) - (ppp + dbl(q_)));
     d.put(0, x3);
     DG29_STAGE();
-    d.put(1, fit<BS>(r_ * (q_ - x3) - s1 * ppp));              // ... (s1 holds a's y)
+    d.put(1, fit<BS>(mul_sub(r_, q_ - x3, ppp, s1)));           // ... (s1 holds a's y)
   }
   // d += b with d in LDS columns and the SMALLEST live set: U1 = X1 ZZ2 and S1 = Y1 ZZZ2 overwrite X1 / Y1 in place as
   // soon as they exist, so that -- like the mixed addition of the accumulation loop -- only P, R, PP, PPP live across
@@ -280,7 +281,7 @@ struct XYZZ29 {
     DG29_STAGE();
     const auto x3 = fit<BS>(sqr(r_) - (ppp + dbl(q_)));
     DG29_STAGE();
-    const auto y3 = fit<BS>(r_ * (q_ - x3) - d.get(1) * ppp);
+    const auto y3 = fit<BS>(mul_sub(r_, q_ - x3, ppp, d.get(1)));
     d.put(0, x3);
     d.put(1, y3);
   }
@@ -304,7 +305,7 @@ struct XYZZ29 {
     DG29_STAGE();
     const auto m = dbl(xx) + xx;
     const auto x3 = fit<BS>(sqr(m) - dbl(s));
-    const auto y3 = fit<BS>(m * (s - x3) - w * a->y);
+    const auto y3 = fit<BS>(mul_sub(m, s - x3, w, a->y));
     DG29_STAGE();
     const auto zz3 = fit<BS>(v * a->zz);
     const auto zzz3 = fit<BS>(w * a->zzz);

@@ -23,7 +23,9 @@
 //
 // Memory stays the arkworks layout at the C ABI (fp.h: 32-bit limbs, R = 2^(32 NL)); tables the library builds
 // for itself hold x R mod p of THIS representation packed into the same NL words (to_internal / from_words).
-// Plain C++ (no inline asm): the same header runs on the host in tests/host_arith.
+// Plain C++: the same header runs on the host in tests/host_arith.  On the device the products alone are explicit
+// instruction sequences (fp29_asm_gen.h, see there), checked instruction by instruction on the CPU
+// (tests/test_fp29_asm_isa.py).
 #pragma once
 #include "fp.h"
 #include "fp2.h"
@@ -311,12 +313,32 @@ constexpr int rr_mul_bound(long long b1b2) {
 template <class P>
 constexpr bool rr_cols_fit(int lu_products) { return RR<P>::N * (lu_products + 1) < RR<P>::COLCAP; }
 
+}  // namespace dg16
+// Device form of the products below, as explicit instruction sequences (generated: tools/gen_fp29_asm.py).  The host --
+// tests/host_arith -- and -DDG29_NO_ASM_MAD builds use the plain loops.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(DG29_NO_ASM_MAD)
+#define DG29_ASM_MAD 1
+#include "fp29_asm_gen.h"
+#endif
+namespace dg16 {
+
 namespace rr {
 // (a b + c d) / R mod p on raw limbs (c, d may be null); the caller has checked the column bound
 template <class P, bool DUAL>
 DG_HD void mont_inl(uint32_t* __restrict__ r, const uint32_t* a, const uint32_t* b, const uint32_t* c, const uint32_t* d) {
   using T = RR<P>;
   constexpr int N = T::N;
+#ifdef DG29_ASM_MAD
+  if constexpr (N == 9 && T::W == 29) {
+    if constexpr (DUAL) mont_asm_dual_9<P>(r, a, b, c, d);
+    else mont_asm_mul_9<P>(r, a, b);
+    return;
+  } else if constexpr (N == 14 && T::W == 28) {
+    if constexpr (DUAL) mont_asm_dual_14<P>(r, a, b, c, d);
+    else mont_asm_mul_14<P>(r, a, b);
+    return;
+  }
+#endif
   uint64_t acc = 0;
   uint32_t m[N];
 #pragma unroll
@@ -351,6 +373,15 @@ template <class P>
 DG_HD void mont_sqr_inl(uint32_t* __restrict__ r, const uint32_t* a) {
   using T = RR<P>;
   constexpr int N = T::N;
+#ifdef DG29_ASM_MAD
+  if constexpr (N == 9 && T::W == 29) {
+    mont_asm_sqr_9<P>(r, a);
+    return;
+  } else if constexpr (N == 14 && T::W == 28) {
+    mont_asm_sqr_14<P>(r, a);
+    return;
+  }
+#endif
   uint32_t a2[N];
 #pragma unroll
   for (int i = 0; i < N; i++) a2[i] = a[i] << 1;
@@ -372,6 +403,46 @@ DG_HD void mont_sqr_inl(uint32_t* __restrict__ r, const uint32_t* a) {
 #pragma unroll
     for (int i = k - N + 1; 2 * i < k; i++) acc += (uint64_t)a2[i] * a[k - i];
     if (k % 2 == 0) acc += (uint64_t)a[k / 2] * a[k / 2];
+#pragma unroll
+    for (int i = k - N + 1; i < N; i++) acc += (uint64_t)m[i] * T::PL.v[k - i];
+    r[k - N] = (uint32_t)acc & T::MASK;
+    acc >>= T::W;
+  }
+  r[N - 1] = (uint32_t)acc;
+}
+// (a b + c d + e f + g h) / R mod p with one reduction (the caller has checked the column bound)
+template <class P>
+DG_HD void mont4_inl(uint32_t* __restrict__ r, const uint32_t* a, const uint32_t* b, const uint32_t* c, const uint32_t* d,
+                     const uint32_t* e, const uint32_t* f, const uint32_t* g, const uint32_t* h) {
+  using T = RR<P>;
+  constexpr int N = T::N;
+#ifdef DG29_ASM_MAD
+  if constexpr (N == 9 && T::W == 29) {
+    mont_asm_quad_9<P>(r, a, b, c, d, e, f, g, h);
+    return;
+  } else if constexpr (N == 14 && T::W == 28) {
+    mont_asm_quad_14<P>(r, a, b, c, d, e, f, g, h);
+    return;
+  }
+#endif
+  uint64_t acc = 0;
+  uint32_t m[N];
+#pragma unroll
+  for (int k = 0; k < N; k++) {
+#pragma unroll
+    for (int i = 0; i <= k; i++)
+      acc += (uint64_t)a[i] * b[k - i] + (uint64_t)c[i] * d[k - i] + (uint64_t)e[i] * f[k - i] + (uint64_t)g[i] * h[k - i];
+#pragma unroll
+    for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * T::PL.v[k - i];
+    m[k] = ((uint32_t)acc * T::INV) & T::MASK;
+    acc += (uint64_t)m[k] * T::PL.v[0];
+    acc >>= T::W;
+  }
+#pragma unroll
+  for (int k = N; k < 2 * N - 1; k++) {
+#pragma unroll
+    for (int i = k - N + 1; i < N; i++)
+      acc += (uint64_t)a[i] * b[k - i] + (uint64_t)c[i] * d[k - i] + (uint64_t)e[i] * f[k - i] + (uint64_t)g[i] * h[k - i];
 #pragma unroll
     for (int i = k - N + 1; i < N; i++) acc += (uint64_t)m[i] * T::PL.v[k - i];
     r[k - N] = (uint32_t)acc & T::MASK;
@@ -483,6 +554,43 @@ DG_HD Fe<P, rr_mul_bound<P>((long long)B1 * B2 + (long long)B3 * B4), 1> mul_add
   } else {
     return mul_add(a, b, c, norm(d));
   }
+}
+
+// (a b + c d + e f + g h) / R with one reduction; the operand with the loosest limbs is normalised while a column
+// could overflow
+template <class P, int B1, int L1, int B2, int L2, int B3, int L3, int B4, int L4, int B5, int L5, int B6, int L6, int B7,
+          int L7, int B8, int L8>
+DG_HD auto mul_add4(const Fe<P, B1, L1>& a, const Fe<P, B2, L2>& b, const Fe<P, B3, L3>& c, const Fe<P, B4, L4>& d,
+                    const Fe<P, B5, L5>& e, const Fe<P, B6, L6>& f, const Fe<P, B7, L7>& g, const Fe<P, B8, L8>& h) {
+  if constexpr (rr_cols_fit<P>(L1 * L2 + L3 * L4 + L5 * L6 + L7 * L8)) {
+    Fe<P, rr_mul_bound<P>((long long)B1 * B2 + (long long)B3 * B4 + (long long)B5 * B6 + (long long)B7 * B8), 1> r;
+    rr::mont4_inl<P>(r.l, a.l, b.l, c.l, d.l, e.l, f.l, g.l, h.l);
+    return r;
+  } else {
+    constexpr int m12 = L1 > L2 ? L1 : L2, m34 = L3 > L4 ? L3 : L4, m56 = L5 > L6 ? L5 : L6, m78 = L7 > L8 ? L7 : L8;
+    constexpr int ma = m12 > m34 ? m12 : m34, mb = m56 > m78 ? m56 : m78, mx = ma > mb ? ma : mb;
+    static_assert(mx > 1, "mul_add4: normalised operands must fit");
+    if constexpr (L1 == mx) return mul_add4(norm(a), b, c, d, e, f, g, h);
+    else if constexpr (L2 == mx) return mul_add4(a, norm(b), c, d, e, f, g, h);
+    else if constexpr (L3 == mx) return mul_add4(a, b, norm(c), d, e, f, g, h);
+    else if constexpr (L4 == mx) return mul_add4(a, b, c, norm(d), e, f, g, h);
+    else if constexpr (L5 == mx) return mul_add4(a, b, c, d, norm(e), f, g, h);
+    else if constexpr (L6 == mx) return mul_add4(a, b, c, d, e, norm(f), g, h);
+    else if constexpr (L7 == mx) return mul_add4(a, b, c, d, e, f, norm(g), h);
+    else return mul_add4(a, b, c, d, e, f, g, norm(h));
+  }
+}
+// (a b - c d) / R.  For the 9-limb fields with ONE reduction: c is negated limb by limb (N subtractions from a multiple
+// of p that dominates it) and rides as the second product of a dual product -- the Y3 of every group addition /
+// doubling is of this form (R (Q - X3) - PPP Y1): nine reductions per mixed addition instead of ten.  The 14-limb fields
+// keep two products (d c, the operand order their kernels were measured with): their accumulation loops sit at the
+// 168 registers of three waves per SIMD and the four operands of a dual product live at once spill (44-56 B per lane).
+template <class P>
+constexpr bool rr_fuse_mul_sub() { return RR<P>::N <= 9; }
+template <class P, int B1, int L1, int B2, int L2, int B3, int L3, int B4, int L4>
+DG_HD auto mul_sub(const Fe<P, B1, L1>& a, const Fe<P, B2, L2>& b, const Fe<P, B3, L3>& c, const Fe<P, B4, L4>& d) {
+  if constexpr (rr_fuse_mul_sub<P>()) return mul_add(a, b, neg(c), d);
+  else return a * b - d * c;
 }
 
 // value < (B / 64) p  ->  the same residue below (66 / 64) p: one quotient estimate from the top limb
@@ -691,6 +799,41 @@ DG_HD auto sqr(const Fe2<P, B, LU>& a_) {
     constexpr int BO = decltype(c0)::Bound > decltype(c1)::Bound ? decltype(c0)::Bound : decltype(c1)::Bound;
     return Fe2<P, BO, 1>{c0.template as<BO, 1>(), c1.template as<BO, 1>()};
   }
+}
+
+// a b - c d in the quadratic extension.  9-limb fields, inline products: each component is ONE four-product sum
+//   (a0 b0 + (BETA a1)(-b1) + (-c0) d0 + (BETA c1) d1)  +  (a0 b1 + a1 b0 + (-c0) d1 + (-c1) d0) u
+// (two reductions instead of four; operands normalised first so that the four products of a column fit 64 bits).
+// Otherwise two products and a subtraction: the 14-limb kernels sit at their register limits (eight operands live at
+// once), and with out-of-line products (DG29_OUTLINE_MUL) eight operands by value do not fit the argument registers.
+template <class P, int B1, int L1, int B2, int L2, int B3, int L3, int B4, int L4>
+DG_HD auto mul_sub(const Fe2<P, B1, L1>& a_, const Fe2<P, B2, L2>& b_, const Fe2<P, B3, L3>& c_, const Fe2<P, B4, L4>& d_) {
+#if !defined(DG29_OUTLINE_MUL) && !defined(DG29_NO_QUAD)
+  if constexpr (rr_fuse_mul_sub<P>()) {
+    constexpr int BETA = Fq2Beta<P>::value;
+    const auto a = norm(a_);
+    const auto b = norm(b_);
+    const auto c = norm(c_);
+    const auto d = norm(d_);
+    const auto nb1 = neg(b.c1);
+    const auto nc0 = neg(c.c0);
+    const auto nc1 = neg(c.c1);
+    const auto r1 = mul_add4(a.c0, b.c1, a.c1, b.c0, nc0, d.c1, nc1, d.c0);
+    if constexpr (BETA == 1) {
+      const auto r0 = mul_add4(a.c0, b.c0, a.c1, nb1, nc0, d.c0, c.c1, d.c1);
+      constexpr int BO = decltype(r0)::Bound > decltype(r1)::Bound ? decltype(r0)::Bound : decltype(r1)::Bound;
+      return Fe2<P, BO, 1>{r0.template as<BO, 1>(), r1.template as<BO, 1>()};
+    } else {
+      const auto r0 = mul_add4(a.c0, b.c0, mul_small<BETA>(a.c1), nb1, nc0, d.c0, mul_small<BETA>(c.c1), d.c1);
+      constexpr int BO = decltype(r0)::Bound > decltype(r1)::Bound ? decltype(r0)::Bound : decltype(r1)::Bound;
+      return Fe2<P, BO, 1>{r0.template as<BO, 1>(), r1.template as<BO, 1>()};
+    }
+  } else {
+    return a_ * b_ - d_ * c_;
+  }
+#else
+  return a_ * b_ - d_ * c_;      // (d c: the operand order the Fq2 kernels were measured with -- call sites pass c = PPP, d = Y1)
+#endif
 }
 
 }  // namespace dg16

@@ -660,10 +660,16 @@ constexpr bool msm_acc_tree() {
 template <class F>
 constexpr unsigned msm_acc_wg_log() { return msm_acc_tree<F>() ? msm_acc_block_log<F>() : 0u; }
 
+// Waves per SIMD the accumulation of a 48-byte coordinate field is compiled for: 3 = 168 VGPRs.  With the products as
+// one accumulator chain per column (fp29_asm_gen.h) the loops of BLS12-381 and BLS12-377 both take 165 without a
+// spill (unconstrained: 183, two waves; before the chains 167 / 205).
+#ifndef DG16_ACC48_WAVES
+#define DG16_ACC48_WAVES 3
+#endif
 // (waves per SIMD = 4 caps the kernel at 128 VGPRs: the loop needs 108; what the tree's full addition needs beyond
 // that is spilled INSIDE the tree, which a workgroup runs five times, not inside the loop it runs 16 x 4 times)
 template <class F, int BLOCK>
-__global__ void __launch_bounds__(BLOCK, (sizeof(F) > 32 ? 1 : 4))
+__global__ void __launch_bounds__(BLOCK, (sizeof(F) > 32 ? DG16_ACC48_WAVES : 4))
 msm_accumulate_kernel(MsmBases bases, size_t n,
                                                               MsmGeom g, const unsigned* __restrict__ offsets,
                                                               const unsigned* __restrict__ counts,
@@ -795,7 +801,7 @@ msm_accumulate_lds_kernel(MsmBases bases, size_t n, MsmGeom g,
     const auto x3 = fit<BS>(sqr(r_) - (ppp + dbl(q_)));
     st(0, x3);
     DG_STAGE();
-    const auto y3 = fit<BS>(r_ * (q_ - x3) - ld(1) * ppp);
+    const auto y3 = fit<BS>(mul_sub(r_, q_ - x3, ppp, ld(1)));
     st(1, y3);
     DG_STAGE();
   }
