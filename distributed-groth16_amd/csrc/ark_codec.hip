@@ -1,4 +1,4 @@
-// arkworks compressed key files for BN254 (and the point codec for BLS12-377 too) (`ProvingKey::<Bn254>` / `VerifyingKey::<Bn254>` written with
+// arkworks compressed key files for BN254 (and the point codec for BLS12-377 and BLS12-381 too) (`ProvingKey::<Bn254>` / `VerifyingKey::<Bn254>` written with
 // `serialize_with_mode(.., Compress::Yes)` and read back per request with `deserialize_with_mode(.., Compress::Yes,
 // Validate::No)`: mpc-api/src/main.rs:154-171, :459-512).
 //
@@ -120,8 +120,7 @@ int dg16_points_compress(dg16_ctx* ctx, int curve, int group, const void* affine
   int rc = guard_channel(ctx, channel);
   if (rc) return rc;
   return guarded(ctx, [&] {
-    DG_REQUIRE(curve == DG16_BN254 || curve == DG16_BLS12_377, DG16_ERR_UNSUPPORTED,
-               "arkworks point compression: BN254 and BLS12-377 (ark-bls12-381 uses the zcash encoding)");
+    DG_REQUIRE(curve >= 0 && curve <= 2, DG16_ERR_BAD_CURVE, "unknown curve id");
     DG_REQUIRE(group == 1 || group == 2, DG16_ERR_BAD_ARG, "group must be 1 (G1) or 2 (G2)");
     DG_REQUIRE((affine && out) || n == 0, DG16_ERR_BAD_ARG, "null operand");
     const bool dev = flags & DG16_F_DEVICE_PTRS;
@@ -131,6 +130,7 @@ int dg16_points_compress(dg16_ctx* ctx, int curve, int group, const void* affine
     uint8_t* dout = dev ? (uint8_t*)out : (uint8_t*)ws(k.c, 1, n * cb);
     if (n) {
       if (curve == DG16_BN254) launch_encode<0>(k.s(), group, din, n, dout);
+      else if (curve == DG16_BLS12_381) launch_encode<1>(k.s(), group, din, n, dout);
       else launch_encode<2>(k.s(), group, din, n, dout);
       DG_HIP(hipGetLastError());
     }
@@ -147,8 +147,7 @@ int dg16_points_decompress(dg16_ctx* ctx, int curve, int group, const void* in, 
   int rc = guard_channel(ctx, channel);
   if (rc) return rc;
   return guarded(ctx, [&] {
-    DG_REQUIRE(curve == DG16_BN254 || curve == DG16_BLS12_377, DG16_ERR_UNSUPPORTED,
-               "arkworks point compression: BN254 and BLS12-377 (ark-bls12-381 uses the zcash encoding)");
+    DG_REQUIRE(curve >= 0 && curve <= 2, DG16_ERR_BAD_CURVE, "unknown curve id");
     DG_REQUIRE(group == 1 || group == 2, DG16_ERR_BAD_ARG, "group must be 1 (G1) or 2 (G2)");
     DG_REQUIRE((in && affine_out) || n == 0, DG16_ERR_BAD_ARG, "null operand");
     const bool dev = flags & DG16_F_DEVICE_PTRS;
@@ -160,6 +159,7 @@ int dg16_points_decompress(dg16_ctx* ctx, int curve, int group, const void* in, 
     DG_HIP(hipMemsetAsync(err, 0xFF, 8, k.s()));
     if (n) {
       if (curve == DG16_BN254) launch_decode<0>(k.s(), group, din, n, validate, dout, (unsigned*)err);
+      else if (curve == DG16_BLS12_381) launch_decode<1>(k.s(), group, din, n, validate, dout, (unsigned*)err);
       else launch_decode<2>(k.s(), group, din, n, validate, dout, (unsigned*)err);
       DG_HIP(hipGetLastError());
     }

@@ -1,4 +1,5 @@
-// ark-ec short-Weierstrass point (de)compression (arkworks `CanonicalSerialize` with `Compress::Yes`, default SWFlags):
+// ark-ec short-Weierstrass point (de)compression (arkworks `CanonicalSerialize` with `Compress::Yes`; default SWFlags --
+// BLS12-381's zcash form further down):
 // little-endian x with the flags in the two top bits of the last byte (bit 7: y is the "negative" root, y > -y, for
 // Fq2 compared on (c1, c0); bit 6: point at infinity).  ONE implementation for the host (proof.bin: serialize.hip,
 // pinned by the reference's own proof.bin and the coordinates its CLI prints) and for the device (batched key
@@ -19,9 +20,11 @@ namespace dg16 {
 
 // The same codec for every curve whose arkworks crate uses the DEFAULT short-Weierstrass serialisation (ark-ec 0.4
 // `SWFlags`): BN254 (ark-bn254) and BLS12-377 (ark-bls12-377 -- the curve of the reference's d_msm / d_fft tests, whose
-// MpcSerNet sends one compressed G per d_msm: dist-primitives/src/channel/mod.rs:14,49).  Not BLS12-381: ark-bls12-381
-// overrides the format with the zcash encoding (big-endian, three flag bits in the FIRST byte), and the reference does
-// not depend on that crate.
+// MpcSerNet sends one compressed G per d_msm: dist-primitives/src/channel/mod.rs:14,49).
+// BLS12-381 (BASELINE config 5's curve; not a dependency of the reference): ark-bls12-381 0.4 overrides the format with
+// the zcash / IETF encoding (its curves/util.rs): BIG-endian x, three flag bits in the FIRST byte -- bit 7 "compressed"
+// (always set here), bit 6 infinity, bit 5 "y is the lexicographically larger of (y, -y)" --, G2 as x.c1 || x.c0.  Same
+// square roots, sign rule (Fq2 ordered on (c1, c0)) and subgroup checks as the default form; only the bytes differ.
 template <int CURVE>
 struct CodecT {
   using CT = CurveTypes<CURVE>;
@@ -32,6 +35,7 @@ struct CodecT {
   static constexpr int FB = NL * 4;                        // bytes of one base-field element
   static constexpr int BETA = Fq2Beta<QP>::value;          // Fq2 = Fq[u] / (u^2 + BETA)
   static constexpr bool Q3MOD4 = (QP::P[0] & 3u) == 3u;
+  static constexpr bool ZCASH = CURVE == 1;               // BLS12-381: big-endian, flags in the first byte
 
   DG_CODEC static void canon(const Fq& a, uint32_t out[NL]) {
     Fq c = a.from_mont();
@@ -164,14 +168,42 @@ struct CodecT {
     out = t.to_mont();
     return true;
   }
+  DG_CODEC static void put_fq_be(const Fq& a, uint8_t* out) {
+    uint32_t c[NL];
+    canon(a, c);
+    for (int i = 0; i < FB; i++) out[i] = (uint8_t)(c[(FB - 1 - i) / 4] >> (8 * ((FB - 1 - i) % 4)));
+  }
+  DG_CODEC static bool get_fq_be(const uint8_t* in, Fq& out) {   // canonical big-endian, must be < q
+    uint32_t c[NL];
+    for (int i = 0; i < NL; i++) c[i] = 0;
+    for (int i = 0; i < FB; i++) c[(FB - 1 - i) / 4] |= (uint32_t)in[i] << (8 * ((FB - 1 - i) % 4));
+    if (cmp(c, QP::P) >= 0) return false;
+    Fq t = Fq::zero();
+    for (int i = 0; i < NL; i++) t.l[i] = c[i];
+    out = t.to_mont();
+    return true;
+  }
   DG_CODEC static void encode(const Affine<Fq>& p, uint8_t* out) {
     memset(out, 0, FB);
+    if constexpr (ZCASH) {
+      if (p.is_inf()) { out[0] = 0xC0; return; }
+      put_fq_be(p.x, out);
+      out[0] |= is_neg(p.y) ? 0xA0 : 0x80;
+      return;
+    }
     if (p.is_inf()) { out[FB - 1] |= 0x40; return; }
     put_fq(p.x, out);
     if (is_neg(p.y)) out[FB - 1] |= 0x80;
   }
   DG_CODEC static void encode(const Affine<Fq2>& p, uint8_t* out) {
     memset(out, 0, 2 * FB);
+    if constexpr (ZCASH) {
+      if (p.is_inf()) { out[0] = 0xC0; return; }
+      put_fq_be(p.x.c1, out);
+      put_fq_be(p.x.c0, out + FB);
+      out[0] |= is_neg(p.y) ? 0xA0 : 0x80;
+      return;
+    }
     if (p.is_inf()) { out[2 * FB - 1] |= 0x40; return; }
     put_fq(p.x.c0, out);
     put_fq(p.x.c1, out + FB);
@@ -187,11 +219,22 @@ struct CodecT {
   DG_CODEC static int decode(const uint8_t* in, Affine<Fq>& p, bool validate) {
     uint8_t b[FB];
     memcpy(b, in, FB);
-    const bool neg = b[FB - 1] & 0x80, inf = b[FB - 1] & 0x40;
-    b[FB - 1] &= 0x3F;
-    if (neg && inf) return 1;
+    bool neg, inf;
     Fq x;
-    if (!get_fq(b, x)) return 2;
+    if constexpr (ZCASH) {
+      if (!(b[0] & 0x80)) return 1;                          // an uncompressed encoding where a compressed one is read
+      inf = b[0] & 0x40;
+      neg = b[0] & 0x20;
+      b[0] &= 0x1F;
+      if (neg && inf) return 1;
+      if (!get_fq_be(b, x)) return 2;
+    } else {
+      neg = b[FB - 1] & 0x80;
+      inf = b[FB - 1] & 0x40;
+      b[FB - 1] &= 0x3F;
+      if (neg && inf) return 1;
+      if (!get_fq(b, x)) return 2;
+    }
     if (inf) {
       if (!x.is_zero()) return 1;
       p = Affine<Fq>::inf();
@@ -207,11 +250,22 @@ struct CodecT {
   DG_CODEC static int decode(const uint8_t* in, Affine<Fq2>& p, bool validate) {
     uint8_t b[2 * FB];
     memcpy(b, in, 2 * FB);
-    const bool neg = b[2 * FB - 1] & 0x80, inf = b[2 * FB - 1] & 0x40;
-    b[2 * FB - 1] &= 0x3F;
-    if (neg && inf) return 1;
+    bool neg, inf;
     Fq2 x;
-    if (!get_fq(b, x.c0) || !get_fq(b + FB, x.c1)) return 2;
+    if constexpr (ZCASH) {
+      if (!(b[0] & 0x80)) return 1;
+      inf = b[0] & 0x40;
+      neg = b[0] & 0x20;
+      b[0] &= 0x1F;
+      if (neg && inf) return 1;
+      if (!get_fq_be(b, x.c1) || !get_fq_be(b + FB, x.c0)) return 2;
+    } else {
+      neg = b[2 * FB - 1] & 0x80;
+      inf = b[2 * FB - 1] & 0x40;
+      b[2 * FB - 1] &= 0x3F;
+      if (neg && inf) return 1;
+      if (!get_fq(b, x.c0) || !get_fq(b + FB, x.c1)) return 2;
+    }
     if (inf) {
       if (!x.is_zero()) return 1;
       p = Affine<Fq2>::inf();

@@ -457,7 +457,7 @@ const char *dg16_serialize_error(void);
 int dg16_proof_compress(int curve, const void *proof_jacobian, void *out128);
 int dg16_proof_decompress(int curve, const void *in128, int validate, void *proof_affine);
 
-/* ---- arkworks compressed key files (BN254) and compressed points (BN254, BLS12-377) ----------------------------------
+/* ---- arkworks compressed key files (BN254) and compressed points (BN254, BLS12-377, BLS12-381) ----------------------
  *   <- pk.serialize_with_mode(.., Compress::Yes) / ProvingKey::deserialize_with_mode(.., Compress::Yes, Validate::No)
  *      and the same for VerifyingKey                               mpc-api/src/main.rs:154-171, :459-512
  * dg16_arkkey_layout (host code) walks the container: struct field order of ark-groth16's derive, a u64 little-endian
@@ -467,8 +467,12 @@ int dg16_proof_decompress(int curve, const void *in128, int validate, void *proo
  * with the identity as zeros on one side (the layout dg16_pk_create and dg16_bases_upload take), 32 (G1) / 64 (G2)
  * bytes per point on the other; for BLS12-377 (ark-bls12-377 uses the same default SWFlags encoding -- the group
  * elements the reference's d_msm tests put on the wire, dist-primitives/examples/dmsm_test.rs) 48 / 96 bytes, and
- * validate != 0 checks the subgroup for G1 as well (cofactor != 1).  BLS12-381 is refused: ark-bls12-381 overrides
- * the encoding with the zcash one and the reference does not use that crate.  dg16_points_decompress is synchronous: a coordinate that is not reduced, bad flags
+ * validate != 0 checks the subgroup for G1 as well (cofactor != 1).  BLS12-381 (BASELINE config 5's curve; not a
+ * dependency of the reference): ark-bls12-381 0.4 overrides the format with the zcash / IETF encoding -- 48 / 96 bytes,
+ * BIG-endian x (G2: x.c1 || x.c0), flags in the three top bits of the FIRST byte: 0x80 compressed (always written, and
+ * required when reading), 0x40 infinity, 0x20 y is the larger of (y, -y).  In every form an infinity encoding must
+ * carry x = 0 and no sign flag (stricter than arkworks 0.4, which ignores the rest of an infinity encoding).
+ * dg16_points_decompress is synchronous: a coordinate that is not reduced, bad flags
  * or an x off the curve return DG16_ERR_BAD_ARG (dg16_codec_error names the first failing point), like the Err of
  * deserialize_with_mode; validate != 0 adds the order-r subgroup check for G2 (Validate::Yes). */
 typedef struct dg16_arkkey_layout_t {

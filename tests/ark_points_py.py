@@ -35,6 +35,33 @@ def encode(curve, group, P):
     return bytes(out)
 
 
+def encode_zcash(group, P):
+    """ark-bls12-381 0.4 (curves/util.rs) = the zcash / IETF BLS12-381 encoding: big-endian x (G2: x.c1 || x.c0), flag
+    bits in the first byte: 0x80 compressed, 0x40 infinity, 0x20 y is the lexicographically larger of (y, -y)."""
+    C = CURVES["bls12_381", "g%d" % group]
+    p, fb = C.F.p, 48
+    if P is None:
+        return bytes([0xC0]) + bytes(fb * group - 1)
+    x, y = P
+    if group == 1:
+        out = bytearray(x.to_bytes(fb, "big"))
+        big = _neg_is_smaller(p, y)
+    else:
+        out = bytearray(x[1].to_bytes(fb, "big") + x[0].to_bytes(fb, "big"))
+        big = _neg_is_smaller(p, y[1]) if y[1] != 0 else _neg_is_smaller(p, y[0])
+    out[0] |= 0xA0 if big else 0x80
+    return bytes(out)
+
+
+# The generators in that encoding as every BLS12-381 implementation prints them (zcash "BLS12-381 for the rest of us" /
+# draft-irtf-cfrg-pairing-friendly-curves, appendix "ZCash serialization format"): known answers from outside this repo.
+ZCASH_G1_GENERATOR = bytes.fromhex(
+    "97f1d3a73197d7942695638c4fa9ac0fc3688c4f9774b905a14e3a3f171bac586c55e83ff97a1aeffb3af00adb22c6bb")
+ZCASH_G2_GENERATOR = bytes.fromhex(
+    "93e02b6052719f607dacd3a088274f65596bd0d09920b61ab5da61bbdc7f5049334cf11213945d57e5ac7d055d042b7e"
+    "024aa2b2f08f0a91260805272dc51051c6e47ad4fa403b02b4510b647ae3d1770bac0326a805bbefd48056c8c121bdb8")
+
+
 def sqrt_fq(p, a):
     """Tonelli-Shanks with a brute-force non-residue (any p)."""
     a %= p

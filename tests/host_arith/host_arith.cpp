@@ -238,7 +238,7 @@ extern "C" int ha_rr_consts(int fid, uint32_t* out, size_t cap) {
   }
 }
 
-// ---- the arkworks point codec (csrc/codec_impl.h), host instantiation: BN254 and BLS12-377 ---------------------
+// ---- the arkworks point codec (csrc/codec_impl.h), host instantiation: BN254, BLS12-381 (zcash form), BLS12-377 ---------------------
 #include "../../distributed-groth16_amd/csrc/codec_impl.h"
 template <int CURVE> static int codec_run(int group, int decode, int validate, const uint8_t* in, uint8_t* out, size_t n, int* rc) {
   using C = CodecT<CURVE>;
@@ -259,6 +259,7 @@ template <int CURVE> static int codec_run(int group, int decode, int validate, c
 // decode = 0: in = affine Montgomery limbs -> out = compressed bytes; decode = 1: the reverse, rc[i] = the codec's code
 extern "C" int ha_codec(int curve, int group, int decode, int validate, const void* in, void* out, size_t n, int* rc) {
   if (curve == 0) return codec_run<0>(group, decode, validate, (const uint8_t*)in, (uint8_t*)out, n, rc);
+  if (curve == 1) return codec_run<1>(group, decode, validate, (const uint8_t*)in, (uint8_t*)out, n, rc);
   if (curve == 2) return codec_run<2>(group, decode, validate, (const uint8_t*)in, (uint8_t*)out, n, rc);
   return -1;
 }

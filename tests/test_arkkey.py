@@ -121,7 +121,7 @@ def test_point_codec_matches_the_python_implementation():
 def test_point_codec_bls12_377():
     """ark-bls12-377 uses the same default encoding (48 / 96 bytes): the group elements of the reference's d_msm tests
     on the wire.  Against the generic plain-Python encoder (tests/ark_points_py.py); Validate::Yes also checks G1 here
-    (cofactor != 1); BLS12-381 (zcash encoding in arkworks) is refused."""
+    (cofactor != 1)."""
     import ark_points_py as A
     from oracle import corc
     from oracle.pyref.curves import CURVES
@@ -160,8 +160,56 @@ def test_point_codec_bls12_377():
         assert np.array_equal(c.points_decompress("bls12_377", group, raw, validate=False), arr_of(group, [outside]))
         with pytest.raises(dg16_amd.Dg16Error, match="subgroup"):
             c.points_decompress("bls12_377", group, raw, validate=True)
-    with pytest.raises(dg16_amd.Dg16Error):
-        c.points_compress("bls12_381", 1, np.zeros((1, 12), dtype=np.uint64))
+
+
+@pytest.mark.gpu
+def test_point_codec_bls12_381_zcash_form():
+    """BLS12-381 (BASELINE config 5's curve) in the encoding ark-bls12-381 0.4 uses -- zcash / IETF: big-endian x, G2 as
+    x.c1 || x.c0, flags 0x80 compressed / 0x40 infinity / 0x20 larger y in the FIRST byte -- through the C ABI on the
+    GPU: the generators give the published strings, random points the independent Python encoder's bytes, decode is
+    the inverse; malformed encodings and points outside the order-r subgroup (Validate::Yes) are refused."""
+    import ark_points_py as A
+    from oracle import corc
+    from oracle.pyref.curves import CURVES
+    c = _ctx()
+    Fq = FQ["bls12_381"]
+    rng = random.Random(9)
+
+    def arr_of(group, pts):
+        out = np.zeros((len(pts), 12 * group), dtype=np.uint64)
+        for k, P in enumerate(pts):
+            if P is not None:
+                co = [P[0], P[1]] if group == 1 else [P[0][0], P[0][1], P[1][0], P[1][1]]
+                out[k] = corc.ints_to_arr([Fq.to_mont(v) for v in co], 6).reshape(-1)
+        return out
+
+    for group in (1, 2):
+        C = CURVES["bls12_381", "g%d" % group]
+        pts = [C.gen] + [C.mul(C.gen, rng.randrange(1, C.order)) for _ in range(70)] + [C.mul(C.gen, k) for k in (2, 3)]
+        pts += [None, C.neg(pts[1]), pts[1]]
+        arr = arr_of(group, pts)
+        want = b"".join(A.encode_zcash(group, P) for P in pts)
+        cb = 48 * group
+        assert want[:cb] == (A.ZCASH_G1_GENERATOR if group == 1 else A.ZCASH_G2_GENERATOR)
+        assert c.points_compress("bls12_381", group, arr) == want
+        assert np.array_equal(c.points_decompress("bls12_381", group, want, validate=True), arr)
+        unc = bytearray(want[:cb])
+        unc[0] &= 0x7F                                                    # not flagged as compressed
+        big = bytearray((Fq.p + 1).to_bytes(48, "big") + bytes(cb - 48))
+        big[0] |= 0x80                                                    # coordinate not reduced
+        bads = [bytes(unc), bytes(big), bytes([0xE0]) + bytes(cb - 1), bytes([0xC0]) + bytes(cb - 2) + b"\x01"]
+        if group == 1:
+            off = bytearray(A.x_off_curve("bls12_381").to_bytes(48, "big"))
+            off[0] |= 0x80
+            bads.append(bytes(off))
+        for bad in bads:
+            with pytest.raises(dg16_amd.Dg16Error):
+                c.points_decompress("bls12_381", group, want[:cb] + bad)
+        outside = A.g1_point_outside_subgroup("bls12_381") if group == 1 else A.twist_point_outside_subgroup("bls12_381")
+        raw = A.encode_zcash(group, outside)
+        assert np.array_equal(c.points_decompress("bls12_381", group, raw, validate=False), arr_of(group, [outside]))
+        with pytest.raises(dg16_amd.Dg16Error, match="subgroup"):
+            c.points_decompress("bls12_381", group, raw, validate=True)
 
 
 @pytest.mark.gpu

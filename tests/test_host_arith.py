@@ -150,7 +150,7 @@ def _codec(ha, curve, group, decode, validate, data, n, out_bytes):
     out = np.zeros(out_bytes, dtype=np.uint8)
     rc = np.zeros(n, dtype=np.int32)
     inp = np.frombuffer(bytes(data), dtype=np.uint8) if not isinstance(data, np.ndarray) else data
-    assert ha.ha_codec({"bn254": 0, "bls12_377": 2}[curve], group, decode, validate, _p(inp), _p(out), n, _p(rc)) == 0
+    assert ha.ha_codec({"bn254": 0, "bls12_381": 1, "bls12_377": 2}[curve], group, decode, validate, _p(inp), _p(out), n, _p(rc)) == 0
     return out, rc
 
 
@@ -197,3 +197,53 @@ def test_point_codec_host(ha, curve, group):
         assert rc[0] == 0 and np.array_equal(dec.view(np.uint64).reshape(1, -1), _affine_arr(curve, group, [outside]))
         _, rc = _codec(ha, curve, group, 1, 1, raw, 1, pb)
         assert rc[0] == 4
+
+
+@pytest.mark.parametrize("group", [1, 2])
+def test_point_codec_host_bls12_381_zcash_form(ha, group):
+    """BLS12-381 in the encoding ark-bls12-381 0.4 uses (zcash / IETF: big-endian, flags in the first byte).  The
+    generators encode to the published strings (known answers from outside this repository), random points to the
+    independent Python encoder's bytes; decode is the inverse (both signs, identity); an encoding without the
+    "compressed" bit, both flags, a flagged infinity with x != 0, an unreduced x, an x off the curve and a curve point
+    outside the order-r subgroup (Validate::Yes) are refused with the codec's codes."""
+    import ark_points_py as A
+    from oracle.pyref.curves import CURVES
+    curve = "bls12_381"
+    C = CURVES[curve, "g%d" % group]
+    rng = random.Random(5 * group)
+    pts = [C.gen] + [C.mul(C.gen, rng.randrange(1, C.order)) for _ in range(8)] + [C.mul(C.gen, k) for k in (2, 3)]
+    pts += [None, C.neg(pts[1]), pts[1]]
+    fb = 48
+    cb, pb = fb * group, 2 * fb * group
+    arr = _affine_arr(curve, group, pts)
+    want = b"".join(A.encode_zcash(group, P) for P in pts)
+    assert want[:cb] == (A.ZCASH_G1_GENERATOR if group == 1 else A.ZCASH_G2_GENERATOR)
+    got, _ = _codec(ha, curve, group, 0, 0, arr.view(np.uint8).reshape(-1), len(pts), cb * len(pts))
+    assert got.tobytes() == want
+    back, rc = _codec(ha, curve, group, 1, 1, want, len(pts), pb * len(pts))
+    assert not rc.any()
+    assert np.array_equal(back.view(np.uint64).reshape(len(pts), -1), arr)
+    q = C.F.p
+    gen = bytearray(want[:cb])
+    bads = []
+    unc = bytearray(gen)
+    unc[0] &= 0x7F
+    bads.append((bytes(unc), 1))                                           # not flagged as compressed
+    bads.append((bytes([0xE0]) + bytes(cb - 1), 1))                        # infinity + sign
+    bads.append((bytes([0xC0]) + bytes(cb - 2) + b"\x01", 1))             # infinity with x != 0
+    big = bytearray((q + 1).to_bytes(fb, "big") + bytes(cb - fb))
+    big[0] |= 0x80
+    bads.append((bytes(big), 2))                                           # coordinate not reduced (q + 1 < 2^381 fits under the flags)
+    if group == 1:
+        off = bytearray(A.x_off_curve(curve).to_bytes(fb, "big"))
+        off[0] |= 0x80
+        bads.append((bytes(off), 3))
+    for raw, code in bads:
+        _, rc = _codec(ha, curve, group, 1, 0, raw, 1, pb)
+        assert rc[0] == code, (raw.hex(), rc[0], code)
+    outside = A.twist_point_outside_subgroup(curve) if group == 2 else A.g1_point_outside_subgroup(curve)
+    raw = A.encode_zcash(group, outside)
+    dec, rc = _codec(ha, curve, group, 1, 0, raw, 1, pb)
+    assert rc[0] == 0 and np.array_equal(dec.view(np.uint64).reshape(1, -1), _affine_arr(curve, group, [outside]))
+    _, rc = _codec(ha, curve, group, 1, 1, raw, 1, pb)
+    assert rc[0] == 4
