@@ -620,19 +620,29 @@ DG_HD Fe<P, BS, 1> fit(const Fe<P, B, LU>& a) {
   else return reduce(a).template as<BS, 1>();
 }
 
-// a == 0 (mod p) for a normalised value: compare with every multiple of p below the bound; the low limb rejects
-// almost always, the full comparison runs only for lanes whose low limb matches
+// a == 0 (mod p) for a normalised value below J p: a = k p for some k < J, and the low limb rejects almost always; the
+// full comparison runs only for lanes whose low limb matches a candidate.
+// 9-limb fields: the low limb NAMES the only candidate -- a.l[0] = k p[0] mod 2^W  <=>  k = -(a.l[0] INV) mod 2^W
+// (INV = -p^-1) -- one multiplication, a mask and a compare (the accumulation loop asks this once per addition with
+// J = 10: the chain of ten compares and scalar branches it replaces was 680 SALU + 120 VALU instructions of the G1 loop).
+// 14-limb fields keep the compare chain: with the one-compare filter hipcc's schedule of their accumulation loop needs
+// more than the 168 registers of three waves (a dozen scratch accesses per iteration; none with the chain).
 template <class P, int B>
 DG_HD bool is_zero(const Fe<P, B, 1>& a) {
   using T = RR<P>;
   constexpr int J = rr_ceil_div(B, 64);   // candidates 0, p, .., (J - 1) p  (value < (B/64) p <= J p)
-  bool hit = false;
+  if constexpr (T::N <= 9) {
+    const uint32_t k = (0u - a.l[0] * T::INV) & T::MASK;
+    if (k >= (uint32_t)J) return false;
+  } else {
+    bool hit = false;
 #pragma unroll
-  for (int j = 0; j < J; j++) {
-    const uint32_t low = (uint32_t)(((uint64_t)T::PL.v[0] * (uint32_t)j) & T::MASK);
-    hit = hit || (a.l[0] == low);
+    for (int j = 0; j < J; j++) {
+      const uint32_t low = (uint32_t)(((uint64_t)T::PL.v[0] * (uint32_t)j) & T::MASK);
+      hit = hit || (a.l[0] == low);
+    }
+    if (!hit) return false;
   }
-  if (!hit) return false;
   for (int j = 0; j < J; j++) {
     uint64_t carry = 0;
     uint32_t diff = 0;
