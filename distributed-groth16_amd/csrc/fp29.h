@@ -585,8 +585,15 @@ DG_HD auto mul_add4(const Fe<P, B1, L1>& a, const Fe<P, B2, L2>& b, const Fe<P, 
 // doubling is of this form (R (Q - X3) - PPP Y1): nine reductions per mixed addition instead of ten.  The 14-limb fields
 // keep two products (d c, the operand order their kernels were measured with): their accumulation loops sit at the
 // 168 registers of three waves per SIMD and the four operands of a dual product live at once spill (44-56 B per lane).
+// (-DDG29_FUSE_ALL fuses for every field, for an A/B of the 14-limb loops at two waves per SIMD: -DDG16_ACC48_WAVES=2)
 template <class P>
-constexpr bool rr_fuse_mul_sub() { return RR<P>::N <= 9; }
+constexpr bool rr_fuse_mul_sub() {
+#ifdef DG29_FUSE_ALL
+  return true;
+#else
+  return RR<P>::N <= 9;
+#endif
+}
 template <class P, int B1, int L1, int B2, int L2, int B3, int L3, int B4, int L4>
 DG_HD auto mul_sub(const Fe<P, B1, L1>& a, const Fe<P, B2, L2>& b, const Fe<P, B3, L3>& c, const Fe<P, B4, L4>& d) {
   if constexpr (rr_fuse_mul_sub<P>()) return mul_add(a, b, neg(c), d);
