@@ -81,7 +81,7 @@ extern "C" int ha_point_op(int curve, int group, int op, const void* a, const vo
 
 
 // ---- reduced-radix types (fp29.h / ec29.h): same operations, through the 29/28-bit-limb representation ------------
-// field: op 0 add, 1 sub, 2 mul, 3 sqr, 7 neg, 8 = mul through a long lazy chain ((a + b)(a - b) + a b - b^2 == a^2 - 2b^2 + ab)
+// field: op 0 add, 1 sub, 2 mul, 3 sqr, 7 neg, 9 = mul_sub / mul_add4 on loose operands, 8 = mul through a long lazy chain ((a + b)(a - b) + a b - b^2 == a^2 - 2b^2 + ab)
 template <class P> static void field_op29(int op, const Fp<P>* a, const Fp<P>* b, Fp<P>* o, size_t n) {
   for (size_t i = 0; i < n; i++) {
     const auto x = fe_from_fp(a[i]);
@@ -92,6 +92,17 @@ template <class P> static void field_op29(int op, const Fp<P>* a, const Fp<P>* b
       case 2: o[i] = fe_to_fp(x * y); break;
       case 3: o[i] = fe_to_fp(sqr(x)); break;
       case 7: o[i] = fe_to_fp(neg(x)); break;
+      case 9: {   // the fused forms on operands with loose limbs: (x + y)(x - y) - (y + y + x) x, once as mul_sub (one
+                  // reduction for the 9-limb fields), once as the four-product sum with explicit negations; must agree
+        const auto u = x + y;                 // limbs < 2 2^W
+        const auto v = x - y;                 // limbs < 3 2^W
+        const auto w = y + y + x;             // limbs < 3 2^W
+        const auto r1 = mul_sub(u, v, w, x);
+        const auto r2 = mul_add4(u, x, u, neg(y), neg(w), x, fe_one<P>() - fe_one<P>(), y);   // u x - u y - w x + 0 y
+        o[i] = fe_to_fp(r1);
+        if (!is_zero(norm(r1 - r2))) o[i].l[0] ^= 0xbeef;
+        break;
+      }
       default: {
         const auto t = norm(norm((x + y) * (x - y) + x * y) - sqr(y));
         const auto t4 = norm(dbl(dbl(t)));

@@ -131,6 +131,11 @@ def test_reduced_radix_field_ops(ha, curve, kind):
     f = lambda op, x, y=None: corc.field_op(curve, kind, op, x, y)   # noqa: E731
     exp = f("sub", f("add", f("mul", f("add", A, B), f("sub", A, B)), f("mul", A, B)), f("sqr", B))
     assert np.array_equal(out, exp)
+    # op 9: (a + b)(a - b) - (2 b + a) a through mul_sub (fused for the 9-limb fields) and through mul_add4 with loose limbs
+    out = np.empty_like(A)
+    assert ha.ha_field_op29(corc.fid(curve, kind), 9, _p(A), _p(B), _p(out), n) == 0
+    exp = f("sub", f("mul", f("add", A, B), f("sub", A, B)), f("mul", f("add", f("add", B, B), A), A))
+    assert np.array_equal(out, exp)
 
 
 # ---- arkworks compressed points: csrc/codec_impl.h on the host against the plain-Python encoder -------------------
