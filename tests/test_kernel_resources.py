@@ -29,8 +29,10 @@ def test_g1_bucket_accumulation_keeps_four_waves_with_the_bucket_tree():
     assert r["vgprs"] <= 128 and r["agprs"] == 0 and r["occupancy"] >= 4
     assert r["scratch"] <= 2 * 144 + 32
     assert r["lds"] == 4 * 9 * 256 * 4 + 256 * 2 + 5 * 4      # partial columns + compaction list + wave counters
-    for k, r in find("msm_accumulate_kernel<bls12_").items():      # 48-byte fields: no tree (measured slower), no scratch
-        assert r["occupancy"] >= 2 and r["scratch"] == 0 and r["lds"] == 0, k
+    # 48-byte fields: no tree (measured slower), no scratch, and -- with the products as one accumulator chain per column
+    # (fp29_asm_gen.h) -- the 168 registers of THREE waves per SIMD for BLS12-381 and BLS12-377 alike (DG16_ACC48_WAVES)
+    for k, r in find("msm_accumulate_kernel<bls12_").items():
+        assert r["occupancy"] >= 3 and r["scratch"] == 0 and r["lds"] == 0, k
 
 
 def test_g2_bucket_accumulation_stages_through_lds_without_spilling():
@@ -39,12 +41,19 @@ def test_g2_bucket_accumulation_stages_through_lds_without_spilling():
     assert r["scratch"] == 0 and r["agprs"] == 0
     (r,) = find("msm_accumulate_lds_kernel<Fp2<bls12_381_fq>,128>").values()
     assert r["scratch"] == 0 and r["agprs"] == 0 and r["lds"] == 4 * 28 * 128 * 4
+    # the throughput finalize of G2 (two lanes per bucket, add_into with the four-product Y3): two waves per SIMD, and
+    # since the products are chains neither scratch (BN254: was 16 B) nor a full AGPR file + scratch (BLS12-377)
+    for k, r in find("msm_finalize_lds_kernel<Fp2<bn254_fq>,256,").items():
+        assert r["occupancy"] == 2 and r["scratch"] == 0 and r["agprs"] == 0, k
+    for k, r in find("msm_finalize_lds_kernel<Fp2<bls12_").items():
+        assert r["scratch"] == 0 and r["agprs"] <= 128, k
 
 
 def test_ntt_and_sort_kernels_are_register_and_lds_only():
     for k, r in find("ntt_step_kernel<").items():
         # 1024 tile elements of 9 limbs + 512 staged twiddles of 8 packed words: three workgroups per CU
         assert r["scratch"] == 0 and r["lds"] == 1024 * 9 * 4 + 512 * 8 * 4 and r["occupancy"] >= 3, k
+        assert r["vgprs"] <= 80, k          # 72 with one accumulator per product (94-101 with hipcc's 17 column chains)
     for name in ("msm_part_hist_kernel<", "msm_part_scatter_kernel<", "msm_part_count_kernel<", "msm_part_place_kernel<",
                  "msm_digits_kernel<", "msm_scatter_kernel<"):
         for k, r in find(name).items():
