@@ -1,0 +1,91 @@
+"""CPU: the hot blocks of the accumulation kernels, read from the objects `make` built (tools/isa_report.py: device
+bundle -> llvm-objdump -> basic blocks).  hipcc's resource report (tests/test_kernel_resources.py) gives a kernel's
+scratch SIZE; whether a spill sits on the path every lane runs sixteen times per segment, or in the doubling branch no
+lane takes, is only visible in the code.  The blocks are identified by their v_mad_u64_u32 count, which the formulas fix:
+a mixed addition is [U2, S2 = two products] then [everything else], N limbs -> product 2 N^2, square N (N + 1) / 2 +
+N^2, reduction alone N^2 (bench.add_mads has the same arithmetic for the roofline)."""
+
+import os
+import shutil
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import isa_report  # noqa: E402
+
+CSRC = os.path.join(ROOT, "distributed-groth16_amd", "csrc")
+pytestmark = pytest.mark.skipif(not (os.path.exists(isa_report.OBJDUMP) and os.path.exists(os.path.join(CSRC, "msm_bn254_g1.o"))),
+                                reason="needs llvm-objdump and the built objects (make -C distributed-groth16_amd/csrc)")
+
+
+def kernel(obj, needle):
+    ks = isa_report.kernels(os.path.join(CSRC, obj))
+    hits = [v for k, v in ks.items() if needle in k]
+    assert len(hits) == 1, (obj, needle, [k for k in ks if needle in k])
+    return hits[0]
+
+
+def block_with(blks, mads):
+    hits = [b for b in blks if b["mads"] == mads]
+    assert hits, "no block with %d v_mad_u64_u32 (the formulas or the compiler's block layout changed): %s" % (
+        mads, sorted({b["mads"] for b in blks if b["mads"] > 100}))
+    return hits
+
+
+def counts(n, fused):
+    prod, sqr, red = 2 * n * n, n * (n + 1) // 2 + n * n, n * n
+    g1 = 8 * prod + 2 * sqr - (red if fused else 0)
+    g2 = 8 * 3 * prod + 2 * 2 * prod - (2 * red if fused else 0)
+    return prod, g1, g2
+
+
+def test_bn254_g1_accumulation_hot_path():
+    prod, g1, _ = counts(9, True)
+    assert g1 == 1467
+    blks = kernel("msm_bn254_g1.o", "msm_accumulate_kernel")
+    head, rest = block_with(blks, 2 * prod)[0], block_with(blks, g1 - 2 * prod)[0]
+    for b in (head, rest):
+        assert b["scratch"] == 0 and b["lds"] == 0 and b["lshl_add_u64"] == 0, b
+    # 1467 mads in ~2090 instructions: the products as chains, the fused Y3, the one-compare zero test (round 3's
+    # kernel before them: ~2400 with 1548 mads)
+    assert head["instr"] + rest["instr"] <= 2200
+    # the tree's full addition on LDS columns (12 products + 2 squares - 1 reduction = 2115 mads: [U1, U2, S1, S2] then
+    # the rest) does not spill either
+    sqr, red = 9 * 10 // 2 + 81, 81
+    full = 12 * prod + 2 * sqr - red
+    assert full == 2115
+    for b in block_with(blks, 4 * prod) + block_with(blks, full - 4 * prod):
+        assert b["scratch"] == 0, b
+
+
+def test_bn254_g2_accumulation_hot_path():
+    prod, _, g2 = counts(9, True)
+    assert g2 == 4374
+    blks = kernel("msm_bn254_g2.o", "msm_accumulate_lds_kernel")
+    head, rest = block_with(blks, 2 * 3 * prod)[0], block_with(blks, g2 - 2 * 3 * prod)[0]
+    for b in (head, rest):
+        assert b["scratch"] == 0 and b["vmem"] == 0, b
+    assert head["instr"] + rest["instr"] <= 6100           # (6525 with 4536 mads before the chains and the fused Y3)
+    assert sum(b["scratch"] for b in blks) == 0
+
+
+@pytest.mark.parametrize("curve", ["bls12_381", "bls12_377"])
+def test_48_byte_g1_accumulation_hot_path(curve):
+    prod, g1, _ = counts(14, False)
+    blks = kernel("msm_%s_g1.o" % curve, "msm_accumulate_kernel")
+    head, rest = block_with(blks, 2 * prod)[0], block_with(blks, g1 - 2 * prod)[0]
+    for b in (head, rest):
+        assert b["scratch"] == 0 and b["lshl_add_u64"] == 0, b
+    assert sum(b["scratch"] for b in blks) == 0
+
+
+def test_ntt_step_has_no_scratch_and_no_column_joins():
+    for needle in ("bn254_fr", "bls12_381_fr"):
+        blks = kernel("ntt.o", "ntt_step_kernelINS_2FpINS_%d%s" % (len(needle) + 7, needle))
+        s = isa_report.summary(blks)
+        assert s["scratch"] == 0
+        # v_lshl_add_u64 is now address arithmetic only: a product no longer joins its columns with 64-bit additions
+        # (443 in this kernel before the chains)
+        assert s["lshl_add_u64"] <= 200 and s["mads"] >= 17 * 162
