@@ -522,6 +522,32 @@ __device__ __forceinline__ Affine29<F> load_internal(const uint32_t* __restrict_
   return Affine29<F>::load(w);
 }
 
+// The same load in two halves -- the raw packed words now, the limbs when the addition needs them -- for a loop that
+// keeps the NEXT point's words in registers while it adds the current one (msm_accumulate_lds_kernel).
+template <class F>
+struct RawPoint {
+  uint4 v[2 * FieldOf<F>::WORDS / 4];
+};
+template <class F>
+__device__ __forceinline__ RawPoint<F> load_raw(const uint32_t* __restrict__ bases, unsigned idx) {
+  constexpr int PW = 2 * FieldOf<F>::WORDS;
+  RawPoint<F> r;
+  const uint4* src = reinterpret_cast<const uint4*>(bases + (size_t)idx * PW);
+#pragma unroll
+  for (int i = 0; i < PW / 4; i++) r.v[i] = src[i];
+  return r;
+}
+template <class F>
+__device__ __forceinline__ Affine29<F> unpack_raw(const RawPoint<F>& r) {
+  constexpr int PW = 2 * FieldOf<F>::WORDS;
+  uint32_t w[PW];
+#pragma unroll
+  for (int i = 0; i < PW / 4; i++) {
+    w[4 * i] = r.v[i].x; w[4 * i + 1] = r.v[i].y; w[4 * i + 2] = r.v[i].z; w[4 * i + 3] = r.v[i].w;
+  }
+  return Affine29<F>::load(w);
+}
+
 // Segment t of bucket-window w -> its bucket and its range of the bucket's entries.  seg_off is the exclusive scan of
 // the per-bucket segment counts k_b = ceil(cnt_b / 2^seg_log): the bucket is the LAST b with seg_off[b] <= t (empty
 // buckets share their offset with their successor and are skipped by construction); segment j of k covers the ranks
@@ -762,12 +788,31 @@ msm_accumulate_lds_kernel(MsmBases bases, size_t n, MsmGeom g,
   const unsigned cnt = live ? sr.cnt : 0u;
   const unsigned* e = entries + (size_t)w * g.region + (live ? offsets[sr.bslot] + sr.first : 0u);
   bool inf = true;
+  // Gather latency.  This kernel runs two waves per SIMD (LDS-bound) with registers to spare (175 of 256 for BN254), so
+  // for 64-byte coordinates the NEXT point's 32 packed words are gathered while the current addition runs (its entry
+  // index was fetched an iteration earlier, the index after it is fetched now): the dependent entry -> point load no
+  // longer sits in front of every addition.  An index past the segment is 0 (a valid row).  48-byte-field Fq2 (252
+  // registers, one wave) has no room for it and loads at the top of the iteration as before.
+  // UNMEASURED (written when the round's GPU minutes were spent); -DDG16_NO_POINT_PREFETCH restores the plain loop.
+#ifdef DG16_NO_POINT_PREFETCH
+  constexpr bool PREFETCH = false;
+#else
+  constexpr bool PREFETCH = sizeof(F) <= 64;
+#endif
   unsigned cur = cnt ? e[0] : 0u;
+  unsigned nxt = cnt > 1 ? e[1] : 0u;
+  RawPoint<F> raw_cur{};
+  if (PREFETCH && cnt) raw_cur = load_raw<F>(base_tab, cur & 0x7fffffffu);
   for (unsigned j = 0; j < cnt; j++) {
-    unsigned nxt = (j + 1 < cnt) ? e[j + 1] : 0u;
-    const Affine29<F> q = load_internal<F>(base_tab, cur & 0x7fffffffu);
+    const unsigned nn = (j + 2 < cnt) ? e[j + 2] : 0u;
+    RawPoint<F> raw_nxt{};
+    if (PREFETCH) raw_nxt = load_raw<F>(base_tab, nxt & 0x7fffffffu);
+    else raw_cur = load_raw<F>(base_tab, cur & 0x7fffffffu);
+    const Affine29<F> q = unpack_raw<F>(raw_cur);
     const bool negate = cur >> 31;
     cur = nxt;
+    nxt = nn;
+    if (PREFETCH) raw_cur = raw_nxt;
     if (q.is_inf()) continue;
     const auto nqy = neg(q.y);
     const auto qy = select(negate, nqy, q.y.template as<decltype(nqy)::Bound, decltype(nqy)::Limb>());

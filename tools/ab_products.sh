@@ -1,6 +1,6 @@
 # First measurement owed by round 3's last session (the GPU minutes of that round were spent when the field products
 # became explicit v_mad_u64_u32 chains: profiles/r3c_static_products_as_instruction_chains.md).  ONE gpurun call:
-#   (here, before the call)  bash tools/build_variant.sh noasm "-DDG29_NO_ASM_MAD -DDG29_NO_QUAD"
+#   (here, before the call)  bash tools/build_variant.sh noasm "-DDG29_NO_ASM_MAD -DDG29_NO_QUAD -DDG16_NO_POINT_PREFETCH"
 #   gpurun --timeout 900 -- 'bash tools/ab_products.sh'
 # -> gpurun_out/ab_products/: the product rate of both forms (tools/ubench/fe_rate, compiled on the box), the bench line
 #    of both libraries, kernel stats of both.  Then: refresh profiles/*_valu_constants.json from fe_rate_chain.json.
