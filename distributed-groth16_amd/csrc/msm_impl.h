@@ -717,6 +717,21 @@ msm_accumulate_kernel(MsmBases bases, size_t n,
     const unsigned* e = entries + (size_t)w * g.region + offsets[sr.bslot] + sr.first;
     // Latency hiding: several waves per SIMD cover the dependent (entry -> point) gathers; only the 4-byte entry
     // index is fetched one iteration ahead (a second point in registers would cost occupancy).
+#ifdef DG16_G1_POINT_PREFETCH
+    // (experiment switch: the next point's packed words gathered one iteration ahead, as in msm_accumulate_lds_kernel)
+    unsigned cur = e[0];
+    unsigned nxt = cnt > 1 ? e[1] : 0u;
+    RawPoint<F> raw_cur = load_raw<F>(base_tab, cur & 0x7fffffffu);
+    for (unsigned j = 0; j < cnt; j++) {
+      const unsigned nn = (j + 2 < cnt) ? e[j + 2] : 0u;
+      const RawPoint<F> raw_nxt = load_raw<F>(base_tab, nxt & 0x7fffffffu);
+      const Affine29<F> p = unpack_raw<F>(raw_cur);
+      acc = acc.madd(p, cur >> 31);
+      cur = nxt;
+      nxt = nn;
+      raw_cur = raw_nxt;
+    }
+#else
     unsigned cur = e[0];
     for (unsigned j = 0; j < cnt; j++) {
       unsigned nxt = (j + 1 < cnt) ? e[j + 1] : 0u;
@@ -724,6 +739,7 @@ msm_accumulate_kernel(MsmBases bases, size_t n,
       acc = acc.madd(p, cur >> 31);
       cur = nxt;
     }
+#endif
   }
   const size_t bucket_slot = ((size_t)blockIdx.y << g.log_nb) + (sr.bslot & (((size_t)1 << g.log_nb) - 1));
   if constexpr (msm_acc_tree<F>()) {
