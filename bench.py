@@ -53,14 +53,17 @@ MAD_ISSUE_T = 34.4                 # T lane-op/s of v_mad_u64_u32, chip-wide (pr
 def valu_constants(curve):
     """(v_mad_u64_u32 per base-field product, measured chip-wide G products/s) of the reduced-radix product
     (csrc/fp29.h), from the committed micro-benchmark output -- measured constants live under profiles/, not in the
-    library's ABI.  profiles/r3_valu_constants.json = tools/ubench/fe_rate on an MI355X, taken on the product code as
-    hipcc compiled it from C++ (before csrc/fp29_asm_gen.h): an auxiliary figure of the line, NOT its peak -- the peak
-    is the issue rate of the instruction itself (MAD_ISSUE_T), which no rewrite of the product can move."""
-    path = os.path.join(ROOT, "profiles", "r3_valu_constants.json")
-    if os.path.exists(path):
-        with open(path) as f:
-            d = json.load(f)[curve + "_fq"]
-        return d["mads_per_product"], d["product_G_per_s"], "profiles/r3_valu_constants.json"
+    library's ABI.  profiles/r3c_valu_constants.json = tools/ubench/fe_rate on an MI355X with the product as the
+    library ships it (explicit v_mad_u64_u32 chains, csrc/fp29_asm_gen.h: 174.9 G/s for the 9-limb fields);
+    r3_valu_constants.json = the same benchmark on the C++-compiled product it replaced (169.3).  An auxiliary figure of
+    the line, NOT its peak -- the peak is the issue rate of the instruction itself (MAD_ISSUE_T), which no rewrite of the
+    product can move."""
+    for name in ("r3c_valu_constants.json", "r3_valu_constants.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(path):
+            with open(path) as f:
+                d = json.load(f)[curve + "_fq"]
+            return d["mads_per_product"], d["product_G_per_s"], "profiles/" + name
     # round-2 figure (profiles/r2_ubench_montmul29_rate.txt: E rows, best of the occupancy sweep); BN254 only
     return {"bn254": 162, "bls12_381": 392}[curve], {"bn254": 166.02, "bls12_381": 34.4e3 / 392}[curve], \
         "profiles/r2_ubench_montmul29_rate.txt (bls12_381: mad issue bound, unmeasured)"
@@ -563,8 +566,7 @@ def main():
                           "note": "%d v_mad_u64_u32 per G2 mixed add x %d points x %d windows / kernel time against the "
                                   "chip-wide issue rate of that instruction (%.1f T lane-op/s: the bound no rewrite of the "
                                   "product can move).  product_equivalents = achieved / %d mads; measured_product_rate = "
-                                  "tools/ubench/fe_rate on the C++-compiled product of the start of round 3 -- the device "
-                                  "products are explicit instruction chains since (csrc/fp29_asm_gen.h), to be re-measured. "
+                                  "tools/ubench/fe_rate (a dependent chain of the library's own product per lane). "
                                   "whole_proof_* = every v_mad_u64_u32 a proof must issue (per GPU) / ms_per_step: the "
                                   "headroom of the whole pipeline, not of one kernel"
                                   % (g2_add_mads, n_g2, nwin, MAD_ISSUE_T, mul_cost)},
