@@ -319,6 +319,13 @@ constexpr bool rr_cols_fit(int lu_products) { return RR<P>::N * (lu_products + 1
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(DG29_NO_ASM_MAD)
 #define DG29_ASM_MAD 1
 #include "fp29_asm_gen.h"
+// -DDG29_ASM_WHOLE: every product as ONE statement with its accumulator in fixed registers (no s_nop inside; an A/B
+// candidate, see tools/gen_fp29_asm.py); default: one statement per column
+#ifdef DG29_ASM_WHOLE
+#define DG29_SEQ(kind, n) mont_asmw_##kind##_##n
+#else
+#define DG29_SEQ(kind, n) mont_asm_##kind##_##n
+#endif
 #endif
 namespace dg16 {
 
@@ -330,12 +337,12 @@ DG_HD void mont_inl(uint32_t* __restrict__ r, const uint32_t* a, const uint32_t*
   constexpr int N = T::N;
 #ifdef DG29_ASM_MAD
   if constexpr (N == 9 && T::W == 29) {
-    if constexpr (DUAL) mont_asm_dual_9<P>(r, a, b, c, d);
-    else mont_asm_mul_9<P>(r, a, b);
+    if constexpr (DUAL) DG29_SEQ(dual, 9)<P>(r, a, b, c, d);
+    else DG29_SEQ(mul, 9)<P>(r, a, b);
     return;
   } else if constexpr (N == 14 && T::W == 28) {
-    if constexpr (DUAL) mont_asm_dual_14<P>(r, a, b, c, d);
-    else mont_asm_mul_14<P>(r, a, b);
+    if constexpr (DUAL) DG29_SEQ(dual, 14)<P>(r, a, b, c, d);
+    else DG29_SEQ(mul, 14)<P>(r, a, b);
     return;
   }
 #endif
@@ -375,10 +382,10 @@ DG_HD void mont_sqr_inl(uint32_t* __restrict__ r, const uint32_t* a) {
   constexpr int N = T::N;
 #ifdef DG29_ASM_MAD
   if constexpr (N == 9 && T::W == 29) {
-    mont_asm_sqr_9<P>(r, a);
+    DG29_SEQ(sqr, 9)<P>(r, a);
     return;
   } else if constexpr (N == 14 && T::W == 28) {
-    mont_asm_sqr_14<P>(r, a);
+    DG29_SEQ(sqr, 14)<P>(r, a);
     return;
   }
 #endif
@@ -418,10 +425,10 @@ DG_HD void mont4_inl(uint32_t* __restrict__ r, const uint32_t* a, const uint32_t
   constexpr int N = T::N;
 #ifdef DG29_ASM_MAD
   if constexpr (N == 9 && T::W == 29) {
-    mont_asm_quad_9<P>(r, a, b, c, d, e, f, g, h);
+    DG29_SEQ(quad, 9)<P>(r, a, b, c, d, e, f, g, h);
     return;
   } else if constexpr (N == 14 && T::W == 28) {
-    mont_asm_quad_14<P>(r, a, b, c, d, e, f, g, h);
+    DG29_SEQ(quad, 14)<P>(r, a, b, c, d, e, f, g, h);
     return;
   }
 #endif
