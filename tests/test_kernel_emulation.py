@@ -1,0 +1,189 @@
+"""CPU: the bucket-accumulation KERNELS as hipcc compiled them for gfx950, executed for one lane on the CPU
+(tools/gfx950_emu.py) against the oracle's curve arithmetic -- a pre-flight of the device code when no GPU is at hand.
+
+What it covers that no host test can: the kernel bodies themselves (segment lookup, the entry / point gathers with the
+next point fetched ahead, the LDS-staged accumulator of G2, the mixed addition with its fused Y3, the zero test, the
+doubling and identity branches, the write of the bucket), on the exact instructions the library ships, including the
+field products that exist only as gfx950 instruction sequences (csrc/fp29_asm_gen.h).  One lane, one bucket, a handful
+of entries: plain and negated points, the same point twice (doubling branch), P then -P (identity in the middle), a
+single entry.  The emulator was first run on the kernel of the commit before the instruction-sequence products -- a
+binary the GPU tests had passed on hardware -- and reproduced the oracle's sums there.
+
+The translation units are compiled to assembly once per source state (a cache directory under /tmp keyed by the hash of
+csrc/): ~1.5 minutes of hipcc on the first run, seconds afterwards."""
+
+import hashlib
+import os
+import subprocess
+import sys
+import time
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import gfx950_emu as E  # noqa: E402
+
+CSRC = os.path.join(ROOT, "distributed-groth16_amd", "csrc")
+HIPCC = "/opt/rocm/bin/hipcc"
+CURVE_ID = {"bn254": 0, "bls12_381": 1, "bls12_377": 2}
+pytestmark = pytest.mark.skipif(not os.path.exists(HIPCC), reason="no hipcc")
+
+
+def source_key():
+    h = hashlib.sha1()
+    for f in sorted(os.listdir(CSRC)):
+        if f.endswith((".h", ".hip")):
+            h.update(f.encode())
+            h.update(open(os.path.join(CSRC, f), "rb").read())
+    h.update(open(os.path.join(ROOT, "include", "dg16.h"), "rb").read())
+    return h.hexdigest()[:16]
+
+
+CASES = [
+    ("bn254", 2, "msm_accumulate_lds_kernel"),        # LDS-staged accumulator, four-product Y3, next point fetched ahead
+    ("bn254", 1, "msm_accumulate_kernel"),            # fused Y3, one-compare zero test; the bucket tree degenerates (one lane)
+    ("bls12_381", 1, "msm_accumulate_kernel"),        # 14 limbs: the other limb shape of the instruction sequences
+]
+
+
+def assembly(curve, group):
+    """msm_group.hip of (curve, group) as gfx950 assembly text.  All translation units of CASES are compiled together
+    (one hipcc each, in parallel) the first time any is asked for, once per source state; safe under pytest-xdist."""
+    cache = os.path.join("/tmp", "dg16_emu_cache", source_key())
+    os.makedirs(cache, exist_ok=True)
+    path = lambda c, g: os.path.join(cache, "msm_%s_g%d.s" % (c, g))     # noqa: E731
+    jobs = []
+    for c, g, _ in CASES:
+        out = path(c, g)
+        if os.path.exists(out):
+            continue
+        try:
+            fd = os.open(out + ".lock", os.O_CREAT | os.O_EXCL | os.O_WRONLY)
+        except FileExistsError:
+            continue                                   # another worker compiles this one
+        os.close(fd)
+        proc = subprocess.Popen([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-DDG_CURVE=%d" % CURVE_ID[c],
+                                 "-DDG_GROUP=%d" % g, "-DDG_NAME=%s_g%d" % (c, g), "--cuda-device-only", "-S",
+                                 os.path.join(CSRC, "msm_group.hip"), "-o", out + ".tmp"],
+                                stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        jobs.append((proc, out))
+    for proc, out in jobs:
+        log = proc.communicate()[0]
+        try:
+            assert proc.returncode == 0, log[-2000:]
+            os.replace(out + ".tmp", out)
+        finally:
+            os.unlink(out + ".lock")
+    out = path(curve, group)
+    for _ in range(900):                               # compiled by another worker
+        if os.path.exists(out):
+            break
+        time.sleep(1)
+    assert os.path.exists(out), "assembly of %s g%d was not produced" % (curve, group)
+    return open(out).read()
+
+
+def limb_shape(p):
+    bits = p.bit_length()
+    w = 29 if bits <= 256 else 28
+    return (bits + 5 + w - 1) // w, w
+
+
+def run_bucket(text, kernel, curve, group, spec):
+    """One lane of workgroup (0, 0): bucket 3 of a 16-bucket window holds the entries `spec` = [(point index, negate)].
+    -> (affine sum the kernel wrote or None for the identity, instructions executed)"""
+    from oracle.pyref.curves import CURVES
+    C = CURVES[curve, "g%d" % group]
+    Fq_p = C.F.p
+    n_limbs, w = limb_shape(Fq_p)
+    nw = (Fq_p.bit_length() + 31) // 32            # packed words per base-field element
+    R = 1 << (w * n_limbs)
+    ext = group == 2
+    prog = E.Program(text, kernel)
+    lane = E.Lane(prog)
+    npts = 6
+    pts = [C.mul(C.gen, i + 1) for i in range(npts)]
+
+    def words(v):
+        return [(v >> (32 * i)) & 0xFFFFFFFF for i in range(nw)]
+
+    TAB, OFFS, CNTS, SOFF, STOT, ENT, SSUM, BUCK, KARG = (0x100000 * k for k in range(1, 10))
+    pw = 2 * nw * (2 if ext else 1)                # words per table point
+    for i, P in enumerate(pts):
+        comps = [P[0][0], P[0][1], P[1][0], P[1][1]] if ext else [P[0], P[1]]
+        wlist = []
+        for c in comps:
+            wlist += words(c * R % Fq_p)
+        for k, v in enumerate(wlist):
+            lane.mem[TAB + 4 * pw * i + 4 * k] = v
+    log_nb, bucket = 4, 3
+    for b in range(16):
+        lane.mem[OFFS + 4 * b] = 0
+        lane.mem[CNTS + 4 * b] = len(spec) if b == bucket else 0
+        lane.mem[SOFF + 4 * b] = 0 if b <= bucket else 1
+    lane.mem[STOT] = 1
+    for j, (idx, neg) in enumerate(spec):
+        lane.mem[ENT + 4 * j] = idx | (0x80000000 if neg else 0)
+    karg = [0] * 34
+
+    def put64(off, v):
+        karg[off // 4], karg[off // 4 + 1] = v & 0xFFFFFFFF, v >> 32
+
+    for k in range(4):                                             # MsmBases: four instance pointers
+        put64(8 * k, TAB)
+    put64(0x20, npts)                                              # n
+    for k, v in enumerate([5, 1, log_nb, 4, 64, 1, 1, 1]):         # MsmGeom: c, nwin, log_nb, seg_log, seg_cap, bw, table, rows
+        karg[0x28 // 4 + k] = v
+    put64(0x48, npts)                                              # region
+    for k, base in enumerate([OFFS, CNTS, SOFF, STOT, ENT, SSUM, BUCK]):
+        put64(0x50 + 8 * k, base)
+    for k, v in enumerate(karg):
+        lane.mem[KARG + 4 * k] = v
+    lane.s[0], lane.s[1] = KARG & 0xFFFFFFFF, KARG >> 32          # kernarg segment pointer (the only user SGPR pair)
+    lane.s[2], lane.s[3] = 0, 0                                    # workgroup id x, y
+    lane.v[0] = 0                                                  # work-item id
+    lane.run()
+    ncoord = n_limbs * (2 if ext else 1)
+    out = [lane.mem.get(BUCK + 4 * 4 * ncoord * bucket + 4 * k) for k in range(4 * ncoord)]
+    assert all(v is not None for v in out), "the bucket was not written"
+
+    def fe(ws):
+        return sum(v << (w * i) for i, v in enumerate(ws)) % Fq_p
+
+    F = C.F
+    if ext:
+        co = [(fe(out[ncoord * c:ncoord * c + n_limbs]), fe(out[ncoord * c + n_limbs:ncoord * (c + 1)])) for c in range(4)]
+        zero = (0, 0)
+    else:
+        co = [fe(out[ncoord * c:ncoord * (c + 1)]) for c in range(4)]
+        zero = 0
+    if co[2] == zero:
+        return None, pts, lane.count
+    inv = F.inv if ext else (lambda v: pow(v, Fq_p - 2, Fq_p))
+    mul = F.mul if ext else (lambda x, y: x * y % Fq_p)
+    return (mul(co[0], inv(co[2])), mul(co[1], inv(co[3]))), pts, lane.count
+
+
+SPECS = [
+    [(1, False), (2, True), (0, False), (4, False), (5, True)],
+    [(1, False), (1, False), (3, True)],              # the same point twice: the doubling branch
+    [(2, False), (2, True), (4, False)],              # P then -P: the accumulator passes through the identity
+    [(3, True)],
+    [(0, False), (0, True)],                          # the bucket sums to the identity
+]
+
+
+@pytest.mark.parametrize("curve,group,kernel", CASES)
+def test_accumulation_kernel_on_the_cpu(curve, group, kernel):
+    from oracle.pyref.curves import CURVES
+    C = CURVES[curve, "g%d" % group]
+    text = assembly(curve, group)
+    for spec in SPECS:
+        got, pts, count = run_bucket(text, kernel, curve, group, spec)
+        exp = None
+        for idx, neg in spec:
+            exp = C.add(exp, C.neg(pts[idx]) if neg else pts[idx])
+        assert got == exp, (curve, group, spec)
+        assert count > 300
