@@ -46,6 +46,9 @@ CASES = [
     ("bn254", 1, "msm_accumulate_kernel"),            # fused Y3, one-compare zero test; the bucket tree degenerates (one lane)
     ("bls12_381", 1, "msm_accumulate_kernel"),        # 14 limbs: the other limb shape of the instruction sequences
 ]
+if os.environ.get("DG16_EMU_ALL"):                    # the other three accumulation kernels: +3 minutes of hipcc on a cold cache
+    CASES += [("bls12_381", 2, "msm_accumulate_lds_kernel"), ("bls12_377", 1, "msm_accumulate_kernel"),
+              ("bls12_377", 2, "msm_accumulate_lds_kernel")]
 
 
 def assembly(curve, group):

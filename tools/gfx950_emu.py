@@ -95,6 +95,7 @@ class Lane:
     def __init__(self, prog):
         self.p = prog
         self.v = [0] * 512
+        self.a = [0] * 512           # accumulation registers (hipcc spills VGPRs into them)
         self.s = [0] * 128
         self.vcc = 0
         self.exec = 1
@@ -104,6 +105,7 @@ class Lane:
         self.scratch = {}
         self.other_lanes = {}
         self.clamp = False
+        self.bitop3 = None
         self.count = 0
         self.sym_addr = {}
         base = 0x7000_0000_0000
@@ -131,6 +133,12 @@ class Lane:
             return self.v[int(tok[1:])]
         if re.fullmatch(r"s\d+", tok):
             return self.s[int(tok[1:])]
+        m = re.fullmatch(r"a\[(\d+):(\d+)\]", tok)
+        if m:
+            lo, hi = int(m.group(1)), int(m.group(2))
+            return sum(self.a[lo + i] << (32 * i) for i in range(hi - lo + 1))
+        if re.fullmatch(r"a\d+", tok):
+            return self.a[int(tok[1:])]
         if tok == "vcc":
             return self.vcc
         if tok == "exec":
@@ -162,8 +170,16 @@ class Lane:
             for i in range(hi - lo + 1):
                 self.s[lo + i] = (val >> (32 * i)) & M32
             return
+        m = re.fullmatch(r"a\[(\d+):(\d+)\]", tok)
+        if m:
+            lo, hi = int(m.group(1)), int(m.group(2))
+            for i in range(hi - lo + 1):
+                self.a[lo + i] = (val >> (32 * i)) & M32
+            return
         if re.fullmatch(r"v\d+", tok):
             self.v[int(tok[1:])] = val & M32
+        elif re.fullmatch(r"a\d+", tok):
+            self.a[int(tok[1:])] = val & M32
         elif re.fullmatch(r"s\d+", tok):
             self.s[int(tok[1:])] = val & M32
         elif tok == "vcc":
@@ -212,6 +228,10 @@ class Lane:
                     mods[key] = int(m.group(1))
                     rest = rest[:m.start()] + rest[m.end():]
             rest = re.sub(r"\s(glc|slc|nt|sc0|sc1)\b", "", rest)
+            m = re.search(r"\sbitop3:(0x[0-9a-fA-F]+|\d+)", rest)
+            self.bitop3 = int(m.group(1), 0) if m else None
+            if m:
+                rest = rest[:m.start()] + rest[m.end():]
             self.clamp = bool(re.search(r"\sclamp\b", rest))
             rest = re.sub(r"\sclamp\b", "", rest)
             a = [x.strip() for x in rest.split(",")] if rest.strip() else []
@@ -486,6 +506,15 @@ class Lane:
             wr(a[0], (m_ & x) | (~m_ & y))
         elif base in ("v_mbcnt_lo_u32_b32", "v_mbcnt_hi_u32_b32"):     # bits of the mask BELOW this lane: lane 0 has none
             wr(a[0], rd(a[2]))
+        elif base == "v_bitop3_b32":            # truth table over (s0, s1, s2) = (0xF0, 0xCC, 0xAA): bit (s0 << 2 | s1 << 1 | s2)
+            x, y, z, tt = rd(a[1]) & M32, rd(a[2]) & M32, rd(a[3]) & M32, self.bitop3
+            r = 0
+            for idx in range(8):
+                if (tt >> idx) & 1:
+                    r |= (x if idx & 4 else ~x) & (y if idx & 2 else ~y) & (z if idx & 1 else ~z)
+            wr(a[0], r & M32)
+        elif base in ("v_accvgpr_write_b32", "v_accvgpr_read_b32", "v_accvgpr_mov_b32"):
+            wr(a[0], rd(a[1]))
         elif base == "v_not_b32":
             wr(a[0], ~rd(a[1]))
         elif base == "v_lshlrev_b32":
@@ -513,6 +542,13 @@ class Lane:
             x = x - (1 << 24) if x & 0x800000 else x
             y = y - (1 << 24) if y & 0x800000 else y
             wr(a[0], x * y)
+        elif base == "v_mul_hi_i32_i24":
+            x, y = rd(a[1]) & 0xFFFFFF, rd(a[2]) & 0xFFFFFF
+            x = x - (1 << 24) if x & 0x800000 else x
+            y = y - (1 << 24) if y & 0x800000 else y
+            wr(a[0], (x * y) >> 32)
+        elif base == "v_mul_hi_u32_u24":
+            wr(a[0], ((rd(a[1]) & 0xFFFFFF) * (rd(a[2]) & 0xFFFFFF)) >> 32)
         elif base == "v_mul_u32_u24":
             wr(a[0], (rd(a[1]) & 0xFFFFFF) * (rd(a[2]) & 0xFFFFFF))
         elif base == "v_mad_u32_u24":
