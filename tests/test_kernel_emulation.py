@@ -148,6 +148,7 @@ def run_bucket(text, kernel, curve, group, spec):
     lane.s[2], lane.s[3] = 0, 0                                    # workgroup id x, y
     lane.v[0] = 0                                                  # work-item id
     lane.run()
+    run_bucket.last_hist = dict(lane.hist)
     ncoord = n_limbs * (2 if ext else 1)
     out = [lane.mem.get(BUCK + 4 * 4 * ncoord * bucket + 4 * k) for k in range(4 * ncoord)]
     assert all(v is not None for v in out), "the bucket was not written"

@@ -107,6 +107,7 @@ class Lane:
         self.clamp = False
         self.bitop3 = None
         self.count = 0
+        self.hist = {}              # opcode -> times executed
         self.sym_addr = {}
         base = 0x7000_0000_0000
         for name, words in prog.data.items():
@@ -219,6 +220,7 @@ class Lane:
             assert pc < len(ins), "ran off the end"
             text = ins[pc]
             self.count += 1
+            self.hist[text.split(' ', 1)[0]] = self.hist.get(text.split(' ', 1)[0], 0) + 1
             assert self.count < limit, "instruction limit"
             op, _, rest = text.partition(" ")
             mods = {}
