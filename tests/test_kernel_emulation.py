@@ -191,3 +191,69 @@ def test_accumulation_kernel_on_the_cpu(curve, group, kernel):
             exp = C.add(exp, C.neg(pts[idx]) if neg else pts[idx])
         assert got == exp, (curve, group, spec)
         assert count > 300
+
+
+def test_g1_accumulation_workgroup_with_the_bucket_tree():
+    """The whole 256-lane workgroup of the BN254 G1 accumulation (four waves in lockstep, barriers, LDS, ballots: the
+    Workgroup emulator): a bucket of 40 entries is cut into three segments held by lanes 0-2, whose partial sums the
+    in-workgroup bucket tree must add before lane 0 writes the bucket; a second bucket of 5 entries sits in lane 3.
+    Both buckets == the oracle's sums."""
+    import random
+    from oracle.pyref.curves import CURVES
+    curve, group = "bn254", 1
+    C = CURVES[curve, "g1"]
+    p = C.F.p
+    n_limbs, w = limb_shape(p)
+    R = 1 << (w * n_limbs)
+    prog = E.Program(assembly(curve, group), "msm_accumulate_kernel")
+    TAB, OFFS, CNTS, SOFF, STOT, ENT, SSUM, BUCK, KARG = (0x100000 * k for k in range(1, 10))
+    wg = E.Workgroup(prog, 256, wg_id=(0, 0), kernarg_addr=KARG)
+    mem = wg.mem
+    npts = 12
+    pts = [C.mul(C.gen, 3 * i + 1) for i in range(npts)]
+    for i, P in enumerate(pts):
+        for c, coord in enumerate(P):
+            v = coord * R % p
+            for k in range(8):
+                mem[TAB + 64 * i + 32 * c + 4 * k] = (v >> (32 * k)) & 0xFFFFFFFF
+    rng = random.Random(3)
+    spec = {3: [(rng.randrange(npts), rng.random() < 0.5) for _ in range(40)],
+            7: [(rng.randrange(npts), rng.random() < 0.5) for _ in range(5)]}
+    log_nb, seg_log = 4, 4
+    seg_running, ent_running = 0, 0
+    for b in range(16):
+        cnt = len(spec.get(b, []))
+        mem[CNTS + 4 * b] = cnt
+        mem[OFFS + 4 * b] = ent_running
+        mem[SOFF + 4 * b] = seg_running
+        for j, (idx, neg) in enumerate(spec.get(b, [])):
+            mem[ENT + 4 * (ent_running + j)] = idx | (0x80000000 if neg else 0)
+        ent_running += cnt
+        seg_running += (cnt + (1 << seg_log) - 1) >> seg_log
+    mem[STOT] = seg_running
+    assert seg_running == 4
+    karg = [0] * 34
+
+    def put64(off, v):
+        karg[off // 4], karg[off // 4 + 1] = v & 0xFFFFFFFF, v >> 32
+
+    for k in range(4):
+        put64(8 * k, TAB)
+    put64(0x20, npts)
+    for k, v in enumerate([5, 1, log_nb, seg_log, 64, 1, 1, 1]):
+        karg[0x28 // 4 + k] = v
+    put64(0x48, 64)                                                # region: room for the 45 entries
+    for k, base in enumerate([OFFS, CNTS, SOFF, STOT, ENT, SSUM, BUCK]):
+        put64(0x50 + 8 * k, base)
+    for k, v in enumerate(karg):
+        mem[KARG + 4 * k] = v
+    wg.run()
+    for b, entries in spec.items():
+        out = [mem.get(BUCK + 144 * b + 4 * k) for k in range(36)]
+        assert all(v is not None for v in out), "bucket %d was not written" % b
+        co = [sum(v << (w * i) for i, v in enumerate(out[9 * c:9 * c + 9])) % p for c in range(4)]
+        exp = None
+        for idx, neg in entries:
+            exp = C.add(exp, C.neg(pts[idx]) if neg else pts[idx])
+        got = None if co[2] == 0 else (co[0] * pow(co[2], p - 2, p) % p, co[1] * pow(co[3], p - 2, p) % p)
+        assert got == exp, "bucket %d" % b

@@ -17,6 +17,8 @@ import struct
 
 M32 = 0xFFFFFFFF
 M64 = 0xFFFFFFFFFFFFFFFF
+PRIVATE_BASE = 0x0000_5000_0000_0000      # flat addresses in [base, base + 4 GiB) are this lane's scratch
+SHARED_BASE = 0x0000_5100_0000_0000
 
 
 def f32(bits):
@@ -40,22 +42,28 @@ def s64(x):
     return x - (1 << 64) if x & (1 << 63) else x
 
 
+CODE_BASE = 0x0000_6000_0000_0000            # "address" of instruction i = CODE_BASE + 4 i (function calls, returns)
+
+
 class Program:
-    """One kernel of a .s file: instructions, label -> index, and the data symbols of the file."""
+    """The code of a .s file -- every function, one instruction list, labels and function entry points -- with one
+    kernel chosen as the entry, and the data symbols (constant arrays) of the file."""
 
     def __init__(self, text, kernel_substr):
         lines = text.split("\n")
-        start = None
-        for i, l in enumerate(lines):
-            m = re.match(r"^(_Z\S+):", l)
-            if m and kernel_substr in m.group(1) and ".amdhsa" not in l:
-                start, self.name = i, m.group(1)
-                break
-        assert start is not None, "kernel %r not found" % kernel_substr
-        self.ins, self.labels = [], {}
-        i = start + 1
-        while i < len(lines) and not lines[i].startswith(".Lfunc_end"):
-            l = lines[i]
+        self.ins, self.labels, self.funcs = [], {}, {}
+        in_func = False
+        for l in lines:
+            m = re.match(r"^([A-Za-z_]\w*):\s*(;.*)?$", l)
+            if m and not in_func:
+                in_func, name = True, m.group(1)
+                self.funcs[name] = len(self.ins)
+                continue
+            if not in_func:
+                continue
+            if l.startswith(".Lfunc_end"):
+                in_func = False
+                continue
             m = re.match(r"^(\.L\w+):", l)
             if m:
                 self.labels[m.group(1)] = len(self.ins)
@@ -63,7 +71,12 @@ class Program:
                 body = l.split(";")[0].strip()
                 if body and not body.startswith("."):
                     self.ins.append(body)
-            i += 1
+        # a "function" without instructions is a data symbol that happened to parse as one
+        self.funcs = {k: v for k, v in self.funcs.items() if k.startswith("_Z") or k.startswith("probe_")}
+        hits = [k for k in self.funcs if kernel_substr in k]
+        assert hits, "kernel %r not found" % kernel_substr
+        self.name = hits[0]
+        self.entry = self.funcs[self.name]
         # data symbols (constant arrays): "sym:\n\t.long 1\n\t.long 2 ..." until the next non-data line
         self.data = {}
         cur = None
@@ -108,6 +121,7 @@ class Lane:
         self.bitop3 = None
         self.count = 0
         self.hist = {}              # opcode -> times executed
+        self.lane_no = 0            # this lane's bit in EXEC / VCC / SGPR-pair masks
         self.sym_addr = {}
         base = 0x7000_0000_0000
         for name, words in prog.data.items():
@@ -150,6 +164,8 @@ class Lane:
             return ((self.vcc if tok[0] == "v" else self.exec) >> 32) & M32
         if tok == "scc":
             return self.scc
+        if tok in ("src_private_base", "src_shared_base"):     # apertures of flat addressing (64-bit: the window's base)
+            return PRIVATE_BASE if "private" in tok else SHARED_BASE
         if re.fullmatch(r"-?(0x[0-9a-fA-F]+|\d+)", tok):
             v = int(tok, 0)
             return v & (M64 if width == 64 else M32)
@@ -198,6 +214,22 @@ class Lane:
         else:
             raise AssertionError("destination %r" % tok)
 
+    def mbit(self, mask):
+        return (mask >> self.lane_no) & 1
+
+    def wr_mbit(self, tok, bit):
+        """this lane's bit of a mask destination (vcc or an SGPR pair); the other lanes' bits stay"""
+        cur = self.rd(tok, 64) if tok.startswith("s[") else (self.vcc if tok == "vcc" else None)
+        assert cur is not None, "mask destination %r" % tok
+        self.wr(tok, (cur & ~(1 << self.lane_no)) | ((bit & 1) << self.lane_no))
+
+    def flat_space(self, op, addr):
+        if op.startswith("flat_") and (addr >> 32) == (PRIVATE_BASE >> 32):
+            return self.scratch, addr & M32
+        if op.startswith("flat_") and (addr >> 32) == (SHARED_BASE >> 32):
+            return self.lds, addr & M32
+        return self.mem, addr
+
     def load(self, space, addr, n):
         out = 0
         for i in range(n):
@@ -213,249 +245,284 @@ class Lane:
             space[addr + 4 * i] = (val >> (32 * i)) & M32
 
     # ---- execution -----------------------------------------------------------------------------------------------
-    def run(self, limit=5_000_000):
-        pc = 0
-        ins, labels = self.p.ins, self.p.labels
-        while True:
-            assert pc < len(ins), "ran off the end"
-            text = ins[pc]
-            self.count += 1
-            self.hist[text.split(' ', 1)[0]] = self.hist.get(text.split(' ', 1)[0], 0) + 1
-            assert self.count < limit, "instruction limit"
-            op, _, rest = text.partition(" ")
-            mods = {}
-            for key in ("offset0", "offset1", "offset"):
-                m = re.search(r"\s%s:(\d+)" % key, rest)
-                if m:
-                    mods[key] = int(m.group(1))
-                    rest = rest[:m.start()] + rest[m.end():]
-            rest = re.sub(r"\s(glc|slc|nt|sc0|sc1)\b", "", rest)
-            m = re.search(r"\sbitop3:(0x[0-9a-fA-F]+|\d+)", rest)
-            self.bitop3 = int(m.group(1), 0) if m else None
+    _parsed = None
+
+    def parse(self, pc):
+        """instruction pc -> (op, operands, modifiers, text); cached per program"""
+        cache = self.p.__dict__.setdefault("_parse_cache", {})
+        if pc in cache:
+            return cache[pc]
+        text = self.p.ins[pc]
+        op, _, rest = text.partition(" ")
+        mods = {}
+        for key in ("offset0", "offset1", "offset"):
+            m = re.search(r"\s%s:(\d+)" % key, rest)
             if m:
+                mods[key] = int(m.group(1))
                 rest = rest[:m.start()] + rest[m.end():]
-            self.clamp = bool(re.search(r"\sclamp\b", rest))
-            rest = re.sub(r"\sclamp\b", "", rest)
-            a = [x.strip() for x in rest.split(",")] if rest.strip() else []
-            nxt = pc + 1
-            live = self.exec & 1
+        rest = re.sub(r"\s(glc|slc|nt|sc0|sc1)\b", "", rest)
+        m = re.search(r"\sbitop3:(0x[0-9a-fA-F]+|\d+)", rest)
+        mods["bitop3"] = int(m.group(1), 0) if m else None
+        if m:
+            rest = rest[:m.start()] + rest[m.end():]
+        mods["clamp"] = bool(re.search(r"\sclamp\b", rest))
+        rest = re.sub(r"\sclamp\b", "", rest)
+        a = [x.strip() for x in rest.split(",")] if rest.strip() else []
+        cache[pc] = (op, a, mods, text)
+        return cache[pc]
 
-            # -------- program flow
-            if op == "s_endpgm":
-                return
-            if op in ("s_waitcnt", "s_nop", "s_barrier", "s_setprio", "s_sleep", "s_waitcnt_depctr", "s_setreg_imm32_b32"):
-                pc = nxt
-                continue
-            if op == "s_branch":
-                pc = labels[a[0]]
-                continue
-            if op.startswith("s_cbranch_"):
-                cond = {"s_cbranch_scc0": self.scc == 0, "s_cbranch_scc1": self.scc == 1,
-                        "s_cbranch_execz": live == 0, "s_cbranch_execnz": live == 1,
-                        "s_cbranch_vccz": (self.vcc & 1) == 0, "s_cbranch_vccnz": (self.vcc & 1) == 1}[op]
-                pc = labels[a[0]] if cond else nxt
-                continue
-            if op == "s_getpc_b64":
-                # long branch (.. s_add_u32 label-.Lpost_getpc ..) or the address of a data symbol (sym@rel32@lo+4)
-                add = ins[pc + 1]
-                m = re.search(r"\((\.LBB\w+)-\.Lpost_getpc\d+\)", add)
-                if m:
-                    assert ins[pc + 3].startswith("s_setpc_b64")
-                    pc = labels[m.group(1)]
-                    continue
-                m = re.search(r"(\w+)@rel32@lo\+(\d+)", add)          # sym@rel32@lo+4 = the symbol itself, +36 = sym + 32
-                assert m and m.group(1) in self.sym_addr, "s_getpc_b64 followed by %r" % add
-                self.wr(a[0], self.sym_addr[m.group(1)] + int(m.group(2)) - 4)
-                assert ins[pc + 2].startswith("s_addc_u32")
-                pc += 3
-                continue
+    def run(self, limit=5_000_000):
+        """one lane, alone: lane 0 of its wave"""
+        pc = self.p.entry
+        while pc is not None:
+            assert pc < len(self.p.ins), "ran off the end"
+            op, a, mods, text = self.parse(pc)
+            self.count += 1
+            self.hist[op] = self.hist.get(op, 0) + 1
+            assert self.count < limit, "instruction limit"
+            pc = self.exec_one(pc, op, a, mods, text, self.exec & 1)
 
-            # -------- scalar ALU
-            if op == "s_mov_b32":
-                self.wr(a[0], self.rd(a[1]))
-            elif op == "s_mov_b64":
-                v = self.rd(a[1], 64)
-                self.wr(a[0], M64 if a[1] == "-1" else v)
-            elif op == "s_movk_i32":
-                v = int(a[1], 0) & 0xFFFF
-                self.wr(a[0], v - 0x10000 if v & 0x8000 else v)
-            elif op == "s_mulk_i32":
-                v = int(a[1], 0) & 0xFFFF
-                self.wr(a[0], s32(self.rd(a[0])) * (v - 0x10000 if v & 0x8000 else v))
-            elif op == "s_brev_b32":
-                self.wr(a[0], int("{:032b}".format(self.rd(a[1]) & M32)[::-1], 2))
-            elif op in ("s_add_u32", "s_add_i32"):
-                r = (self.rd(a[1]) & M32) + (self.rd(a[2]) & M32)
-                self.wr(a[0], r)
-                self.scc = (r >> 32) & 1 if op == "s_add_u32" else int(not (-2**31 <= s32(self.rd(a[1])) + s32(self.rd(a[2])) < 2**31))
-            elif op == "s_addc_u32":
-                r = (self.rd(a[1]) & M32) + (self.rd(a[2]) & M32) + self.scc
-                self.wr(a[0], r)
-                self.scc = (r >> 32) & 1
-            elif op in ("s_sub_u32", "s_sub_i32"):
-                x, y = self.rd(a[1]) & M32, self.rd(a[2]) & M32
-                self.wr(a[0], x - y)
-                self.scc = int(y > x) if op == "s_sub_u32" else int(not (-2**31 <= s32(x) - s32(y) < 2**31))
-            elif op == "s_subb_u32":
-                x, y = self.rd(a[1]) & M32, (self.rd(a[2]) & M32) + self.scc
-                self.wr(a[0], x - y)
-                self.scc = int(y > x)
-            elif op == "s_mul_i32":
-                self.wr(a[0], (self.rd(a[1]) & M32) * (self.rd(a[2]) & M32))
-            elif op == "s_mul_hi_u32":
-                self.wr(a[0], ((self.rd(a[1]) & M32) * (self.rd(a[2]) & M32)) >> 32)
-            elif op in ("s_lshl_b32", "s_lshr_b32", "s_ashr_i32"):
-                x, sh = self.rd(a[1]) & M32, self.rd(a[2]) & 31
-                r = (x << sh) & M32 if op == "s_lshl_b32" else (x >> sh) if op == "s_lshr_b32" else (s32(x) >> sh) & M32
-                self.wr(a[0], r)
-                self.scc = int(r != 0)
-            elif op in ("s_lshl_b64", "s_lshr_b64"):
-                x, sh = self.rd(a[1], 64) & M64, self.rd(a[2]) & 63
-                r = (x << sh) & M64 if op == "s_lshl_b64" else x >> sh
-                self.wr(a[0], r)
-                self.scc = int(r != 0)
-            elif op in ("s_and_b32", "s_or_b32", "s_xor_b32", "s_andn2_b32", "s_and_b64", "s_or_b64", "s_xor_b64",
-                        "s_andn2_b64", "s_orn2_b64"):
-                w = 64 if op.endswith("b64") else 32
-                mask = M64 if w == 64 else M32
-                x = M64 if a[1] == "-1" else self.rd(a[1], w)
-                y = M64 if a[2] == "-1" else self.rd(a[2], w)
-                x &= mask
-                y &= mask
-                kind = op[2:-4]
-                r = {"and": x & y, "or": x | y, "xor": x ^ y, "andn2": x & ~y, "orn2": x | ~y}[kind] & mask
-                self.wr(a[0], r)
-                self.scc = int(r != 0)
-            elif op == "s_not_b64":
-                r = ~self.rd(a[1], 64) & M64
-                self.wr(a[0], r)
-                self.scc = int(r != 0)
-            elif op in ("s_and_saveexec_b64", "s_or_saveexec_b64", "s_andn2_saveexec_b64", "s_xor_saveexec_b64"):
-                src = M64 if a[1] == "-1" else self.rd(a[1], 64)
-                old = self.exec
-                kind = op[2:-13]
-                new = {"and": src & old, "or": src | old, "andn2": src & ~old, "xor": src ^ old}[kind] & M64
-                self.wr(a[0], old)
-                self.exec = new
-                self.scc = int(new != 0)
-            elif op in ("s_ff1_i32_b64", "s_ff1_i32_b32"):
-                x = self.rd(a[1], 64 if op.endswith("b64") else 32)
-                self.wr(a[0], (x & -x).bit_length() - 1 if x else M32)
-            elif op in ("s_bcnt1_i32_b64", "s_bcnt1_i32_b32"):
-                r = bin(self.rd(a[1], 64 if op.endswith("b64") else 32)).count("1")
-                self.wr(a[0], r)
-                self.scc = int(r != 0)
-            elif op in ("s_flbit_i32_b32", "s_flbit_i32_b64"):
-                wd = 64 if op.endswith("b64") else 32
-                x = self.rd(a[1], wd)
-                self.wr(a[0], wd - x.bit_length() if x else M32)
-            elif op in ("s_min_u32", "s_max_u32"):
-                x, y = self.rd(a[1]) & M32, self.rd(a[2]) & M32
-                r = min(x, y) if "min" in op else max(x, y)
-                self.wr(a[0], r)
-                self.scc = int(r == x)
-            elif op in ("s_bfe_u32",):
-                x, ctl = self.rd(a[1]) & M32, self.rd(a[2])
-                r = (x >> (ctl & 31)) & ((1 << ((ctl >> 16) & 0x7F)) - 1)
-                self.wr(a[0], r)
-                self.scc = int(r != 0)
-            elif op == "s_cselect_b32":
-                self.wr(a[0], self.rd(a[1]) if self.scc else self.rd(a[2]))
-            elif op == "s_cselect_b64":
-                self.wr(a[0], self.rd(a[1], 64) if self.scc else self.rd(a[2], 64))
-            elif op.startswith("s_cmp_"):
-                kind, ty = op[6:].rsplit("_", 1)
-                x, y = self.rd(a[0]), self.rd(a[1])
-                if ty == "i32":
-                    x, y = s32(x), s32(y)
-                else:
-                    x, y = x & M32, y & M32
-                self.scc = int({"eq": x == y, "lg": x != y, "gt": x > y, "ge": x >= y, "lt": x < y, "le": x <= y}[kind])
-            elif op.startswith("s_load_dword"):
-                n = {"": 1, "x2": 2, "x4": 4, "x8": 8, "x16": 16}[op[len("s_load_dword"):]]
-                off = self.rd(a[2]) if len(a) > 2 else 0
-                self.wr(a[0] if n > 1 else a[0], self.load(self.mem, self.rd(a[1], 64) + off + mods.get("offset", 0), n))
+    def exec_one(self, pc, op, a, mods, text, live):
+        """executes instruction pc for this lane (scalar state included) -> next pc, None at s_endpgm"""
+        ins, labels = self.p.ins, self.p.labels
+        nxt = pc + 1
+        self.bitop3, self.clamp = mods["bitop3"], mods["clamp"]
 
-            # -------- vector memory / LDS
-            elif op.startswith(("global_load_dword", "flat_load_dword")):
-                if live:
-                    n = {"": 1, "x2": 2, "x3": 3, "x4": 4}[op.split("_dword")[1]]
-                    if len(a) >= 3 and a[2] != "off":
-                        addr = self.rd(a[2], 64) + (self.rd(a[1]) & M32)
-                    else:
-                        addr = self.rd(a[1], 64)
-                    self.wr(a[0], self.load(self.mem, addr + mods.get("offset", 0), n))
-            elif op.startswith(("global_store_dword", "flat_store_dword")):
-                if live:
-                    n = {"": 1, "x2": 2, "x3": 3, "x4": 4}[op.split("_dword")[1]]
-                    if len(a) >= 3 and a[2] != "off":
-                        addr = self.rd(a[2], 64) + (self.rd(a[0]) & M32)
-                    else:
-                        addr = self.rd(a[0], 64)
-                    self.store(self.mem, addr + mods.get("offset", 0), self.rd(a[1]), n)
-            elif op.startswith("scratch_load_dword"):
-                if live:
-                    n = {"": 1, "x2": 2, "x3": 3, "x4": 4}[op[len("scratch_load_dword"):]]
-                    base = (0 if a[1] == "off" else self.rd(a[1])) + (0 if a[2] == "off" else self.rd(a[2]))
-                    self.wr(a[0], self.load(self.scratch, base + mods.get("offset", 0), n))
-            elif op.startswith("scratch_store_dword"):
-                if live:
-                    n = {"": 1, "x2": 2, "x3": 3, "x4": 4}[op[len("scratch_store_dword"):]]
-                    base = (0 if a[0] == "off" else self.rd(a[0])) + (0 if a[2] == "off" else self.rd(a[2]))
-                    self.store(self.scratch, base + mods.get("offset", 0), self.rd(a[1]), n)
-            elif op in ("ds_read_b32", "ds_read_b64", "ds_read_b128"):
-                if live:
-                    n = {"b32": 1, "b64": 2, "b128": 4}[op[8:]]
-                    self.wr(a[0], self.load(self.lds, (self.rd(a[1]) & M32) + mods.get("offset", 0), n))
-            elif op in ("ds_write_b32", "ds_write_b64", "ds_write_b128"):
-                if live:
-                    n = {"b32": 1, "b64": 2, "b128": 4}[op[9:]]
-                    self.store(self.lds, (self.rd(a[0]) & M32) + mods.get("offset", 0), self.rd(a[1]), n)
-            elif op in ("ds_read2_b32", "ds_read2st64_b32"):
-                if live:
-                    unit = 4 * (64 if "st64" in op else 1)
-                    base = self.rd(a[1]) & M32
-                    lo = self.load(self.lds, base + unit * mods.get("offset0", 0), 1)
-                    hi = self.load(self.lds, base + unit * mods.get("offset1", 0), 1)
-                    self.wr(a[0], lo | (hi << 32))
-            elif op in ("ds_write2_b32", "ds_write2st64_b32"):
-                if live:
-                    unit = 4 * (64 if "st64" in op else 1)
-                    base = self.rd(a[0]) & M32
-                    self.store(self.lds, base + unit * mods.get("offset0", 0), self.rd(a[1]), 1)
-                    self.store(self.lds, base + unit * mods.get("offset1", 0), self.rd(a[2]), 1)
+        # -------- program flow
+        if op == "s_endpgm":
+            return None
+        if op in ("s_waitcnt", "s_nop", "s_barrier", "s_setprio", "s_sleep", "s_waitcnt_depctr", "s_setreg_imm32_b32"):
+            return nxt
+        if op == "s_branch":
+            return labels[a[0]]
+        if op.startswith("s_cbranch_"):
+            cond = {"s_cbranch_scc0": self.scc == 0, "s_cbranch_scc1": self.scc == 1,
+                    "s_cbranch_execz": live == 0, "s_cbranch_execnz": live == 1,
+                    "s_cbranch_vccz": (self.vcc & 1) == 0, "s_cbranch_vccnz": (self.vcc & 1) == 1}[op]
+            return labels[a[0]] if cond else nxt
+        if op == "s_getpc_b64":
+            # long branch (.. s_add_u32 label-.Lpost_getpc ..) or the address of a data symbol (sym@rel32@lo+4)
+            add = ins[pc + 1]
+            m = re.search(r"\((\.LBB\w+)-\.Lpost_getpc\d+\)", add)
+            if m:
+                assert ins[pc + 3].startswith("s_setpc_b64")
+                return labels[m.group(1)]
+            m = re.search(r"(\w+)@rel32@lo\+(\d+)", add)          # sym@rel32@lo+4 = the symbol itself, +36 = sym + 32
+            assert m, "s_getpc_b64 followed by %r" % add
+            if m.group(1) not in self.sym_addr:               # a function of the file
+                assert m.group(1) in self.p.funcs, "unknown symbol %r" % m.group(1)
+                self.sym_addr[m.group(1)] = CODE_BASE + 4 * self.p.funcs[m.group(1)]
+            self.wr(a[0], self.sym_addr[m.group(1)] + int(m.group(2)) - 4)
+            assert ins[pc + 2].startswith("s_addc_u32")
+            return pc + 3
 
-            elif re.fullmatch(r"ds_(add|sub|max|min|or|and)(_rtn)?_(u32|b32)", op):
-                if live:                                # LDS atomics; a cell nobody wrote yet reads as 0 (the other lanes' job)
-                    kind, rtn = re.fullmatch(r"ds_(\w+?)(_rtn)?_(u32|b32)", op).group(1, 2)
-                    dst = a[0] if rtn else None
-                    addr_tok, val_tok = (a[1], a[2]) if rtn else (a[0], a[1])
-                    addr = (self.rd(addr_tok) & M32) + mods.get("offset", 0)
-                    old = self.lds.get(addr, 0)
-                    x = self.rd(val_tok) & M32
-                    new = {"add": old + x, "sub": old - x, "max": max(old, x), "min": min(old, x), "or": old | x,
-                           "and": old & x}[kind] & M32
-                    self.lds[addr] = new
-                    if dst:
-                        self.wr(dst, old)
+        if op == "s_swappc_b64":                 # call: return address into a[0], jump to the function at a[1]
+            target = self.rd(a[1], 64)
+            assert (target - CODE_BASE) % 4 == 0 and 0 <= (target - CODE_BASE) // 4 < len(ins), "call to 0x%x" % target
+            self.wr(a[0], CODE_BASE + 4 * nxt)
+            return (target - CODE_BASE) // 4
+        if op == "s_setpc_b64":                  # return (the long-branch use of s_setpc_b64 is taken at its s_getpc_b64)
+            target = self.rd(a[0], 64)
+            assert (target - CODE_BASE) % 4 == 0, "s_setpc_b64 to 0x%x" % target
+            return (target - CODE_BASE) // 4
 
-            # -------- vector ALU (skipped when the lane is masked off)
-            elif op == "v_readfirstlane_b32":
-                self.wr(a[0], self.rd(a[1]))
-            elif op == "v_writelane_b32":           # hipcc spills SGPRs into the lanes of a VGPR: lanes other than 0 live here
-                vreg, lane_no = int(a[0][1:]), self.rd(a[2]) & 63
-                self.other_lanes[(vreg, lane_no)] = self.rd(a[1]) & M32
-                if lane_no == 0:
-                    self.v[vreg] = self.rd(a[1]) & M32
-            elif op == "v_readlane_b32":
-                vreg, lane_no = int(a[1][1:]), self.rd(a[2]) & 63
-                self.wr(a[0], self.v[vreg] if lane_no == 0 else self.other_lanes[(vreg, lane_no)])
-            elif op.startswith("v_"):
-                if live:
-                    self.valu(op, a, text)
+        # -------- scalar ALU
+        if op == "s_mov_b32":
+            self.wr(a[0], self.rd(a[1]))
+        elif op == "s_mov_b64":
+            v = self.rd(a[1], 64)
+            self.wr(a[0], M64 if a[1] == "-1" else v)
+        elif op == "s_movk_i32":
+            v = int(a[1], 0) & 0xFFFF
+            self.wr(a[0], v - 0x10000 if v & 0x8000 else v)
+        elif op == "s_mulk_i32":
+            v = int(a[1], 0) & 0xFFFF
+            self.wr(a[0], s32(self.rd(a[0])) * (v - 0x10000 if v & 0x8000 else v))
+        elif op == "s_brev_b32":
+            self.wr(a[0], int("{:032b}".format(self.rd(a[1]) & M32)[::-1], 2))
+        elif op in ("s_add_u32", "s_add_i32"):
+            r = (self.rd(a[1]) & M32) + (self.rd(a[2]) & M32)
+            self.wr(a[0], r)
+            self.scc = (r >> 32) & 1 if op == "s_add_u32" else int(not (-2**31 <= s32(self.rd(a[1])) + s32(self.rd(a[2])) < 2**31))
+        elif op == "s_addc_u32":
+            r = (self.rd(a[1]) & M32) + (self.rd(a[2]) & M32) + self.scc
+            self.wr(a[0], r)
+            self.scc = (r >> 32) & 1
+        elif op in ("s_sub_u32", "s_sub_i32"):
+            x, y = self.rd(a[1]) & M32, self.rd(a[2]) & M32
+            self.wr(a[0], x - y)
+            self.scc = int(y > x) if op == "s_sub_u32" else int(not (-2**31 <= s32(x) - s32(y) < 2**31))
+        elif op == "s_subb_u32":
+            x, y = self.rd(a[1]) & M32, (self.rd(a[2]) & M32) + self.scc
+            self.wr(a[0], x - y)
+            self.scc = int(y > x)
+        elif op == "s_mul_i32":
+            self.wr(a[0], (self.rd(a[1]) & M32) * (self.rd(a[2]) & M32))
+        elif op == "s_mul_hi_u32":
+            self.wr(a[0], ((self.rd(a[1]) & M32) * (self.rd(a[2]) & M32)) >> 32)
+        elif op in ("s_lshl_b32", "s_lshr_b32", "s_ashr_i32"):
+            x, sh = self.rd(a[1]) & M32, self.rd(a[2]) & 31
+            r = (x << sh) & M32 if op == "s_lshl_b32" else (x >> sh) if op == "s_lshr_b32" else (s32(x) >> sh) & M32
+            self.wr(a[0], r)
+            self.scc = int(r != 0)
+        elif op in ("s_lshl_b64", "s_lshr_b64"):
+            x, sh = self.rd(a[1], 64) & M64, self.rd(a[2]) & 63
+            r = (x << sh) & M64 if op == "s_lshl_b64" else x >> sh
+            self.wr(a[0], r)
+            self.scc = int(r != 0)
+        elif op in ("s_and_b32", "s_or_b32", "s_xor_b32", "s_andn2_b32", "s_and_b64", "s_or_b64", "s_xor_b64",
+                    "s_andn2_b64", "s_orn2_b64"):
+            w = 64 if op.endswith("b64") else 32
+            mask = M64 if w == 64 else M32
+            x = M64 if a[1] == "-1" else self.rd(a[1], w)
+            y = M64 if a[2] == "-1" else self.rd(a[2], w)
+            x &= mask
+            y &= mask
+            kind = op[2:-4]
+            r = {"and": x & y, "or": x | y, "xor": x ^ y, "andn2": x & ~y, "orn2": x | ~y}[kind] & mask
+            self.wr(a[0], r)
+            self.scc = int(r != 0)
+        elif op == "s_not_b64":
+            r = ~self.rd(a[1], 64) & M64
+            self.wr(a[0], r)
+            self.scc = int(r != 0)
+        elif op in ("s_and_saveexec_b64", "s_or_saveexec_b64", "s_andn2_saveexec_b64", "s_xor_saveexec_b64"):
+            src = M64 if a[1] == "-1" else self.rd(a[1], 64)
+            old = self.exec
+            kind = op[2:-13]
+            new = {"and": src & old, "or": src | old, "andn2": src & ~old, "xor": src ^ old}[kind] & M64
+            self.wr(a[0], old)
+            self.exec = new
+            self.scc = int(new != 0)
+        elif op in ("s_ff1_i32_b64", "s_ff1_i32_b32"):
+            x = self.rd(a[1], 64 if op.endswith("b64") else 32)
+            self.wr(a[0], (x & -x).bit_length() - 1 if x else M32)
+        elif op in ("s_bcnt1_i32_b64", "s_bcnt1_i32_b32"):
+            r = bin(self.rd(a[1], 64 if op.endswith("b64") else 32)).count("1")
+            self.wr(a[0], r)
+            self.scc = int(r != 0)
+        elif op in ("s_flbit_i32_b32", "s_flbit_i32_b64"):
+            wd = 64 if op.endswith("b64") else 32
+            x = self.rd(a[1], wd)
+            self.wr(a[0], wd - x.bit_length() if x else M32)
+        elif op in ("s_min_u32", "s_max_u32"):
+            x, y = self.rd(a[1]) & M32, self.rd(a[2]) & M32
+            r = min(x, y) if "min" in op else max(x, y)
+            self.wr(a[0], r)
+            self.scc = int(r == x)
+        elif op in ("s_bfe_u32",):
+            x, ctl = self.rd(a[1]) & M32, self.rd(a[2])
+            r = (x >> (ctl & 31)) & ((1 << ((ctl >> 16) & 0x7F)) - 1)
+            self.wr(a[0], r)
+            self.scc = int(r != 0)
+        elif op == "s_cselect_b32":
+            self.wr(a[0], self.rd(a[1]) if self.scc else self.rd(a[2]))
+        elif op == "s_cselect_b64":
+            self.wr(a[0], self.rd(a[1], 64) if self.scc else self.rd(a[2], 64))
+        elif op.startswith("s_cmp_"):
+            kind, ty = op[6:].rsplit("_", 1)
+            x, y = self.rd(a[0]), self.rd(a[1])
+            if ty == "i32":
+                x, y = s32(x), s32(y)
             else:
-                raise AssertionError("the emulator does not know %r: %s" % (op, text))
-            pc = nxt
+                x, y = x & M32, y & M32
+            self.scc = int({"eq": x == y, "lg": x != y, "gt": x > y, "ge": x >= y, "lt": x < y, "le": x <= y}[kind])
+        elif op.startswith("s_load_dword"):
+            n = {"": 1, "x2": 2, "x4": 4, "x8": 8, "x16": 16}[op[len("s_load_dword"):]]
+            off = self.rd(a[2]) if len(a) > 2 else 0
+            self.wr(a[0] if n > 1 else a[0], self.load(self.mem, self.rd(a[1], 64) + off + mods.get("offset", 0), n))
+
+        # -------- vector memory / LDS
+        elif op.startswith(("global_load_dword", "flat_load_dword")):
+            if live:
+                n = {"": 1, "x2": 2, "x3": 3, "x4": 4}[op.split("_dword")[1]]
+                if len(a) >= 3 and a[2] != "off":
+                    addr = self.rd(a[2], 64) + (self.rd(a[1]) & M32)
+                else:
+                    addr = self.rd(a[1], 64)
+                space, addr = self.flat_space(op, addr + mods.get("offset", 0))
+                self.wr(a[0], self.load(space, addr, n))
+        elif op.startswith(("global_store_dword", "flat_store_dword")):
+            if live:
+                n = {"": 1, "x2": 2, "x3": 3, "x4": 4}[op.split("_dword")[1]]
+                if len(a) >= 3 and a[2] != "off":
+                    addr = self.rd(a[2], 64) + (self.rd(a[0]) & M32)
+                else:
+                    addr = self.rd(a[0], 64)
+                space, addr = self.flat_space(op, addr + mods.get("offset", 0))
+                self.store(space, addr, self.rd(a[1]), n)
+        elif op.startswith("scratch_load_dword"):
+            if live:
+                n = {"": 1, "x2": 2, "x3": 3, "x4": 4}[op[len("scratch_load_dword"):]]
+                base = (0 if a[1] == "off" else self.rd(a[1])) + (0 if a[2] == "off" else self.rd(a[2]))
+                self.wr(a[0], self.load(self.scratch, base + mods.get("offset", 0), n))
+        elif op.startswith("scratch_store_dword"):
+            if live:
+                n = {"": 1, "x2": 2, "x3": 3, "x4": 4}[op[len("scratch_store_dword"):]]
+                base = (0 if a[0] == "off" else self.rd(a[0])) + (0 if a[2] == "off" else self.rd(a[2]))
+                self.store(self.scratch, base + mods.get("offset", 0), self.rd(a[1]), n)
+        elif op in ("ds_read_b32", "ds_read_b64", "ds_read_b128"):
+            if live:
+                n = {"b32": 1, "b64": 2, "b128": 4}[op[8:]]
+                self.wr(a[0], self.load(self.lds, (self.rd(a[1]) & M32) + mods.get("offset", 0), n))
+        elif op in ("ds_write_b32", "ds_write_b64", "ds_write_b128"):
+            if live:
+                n = {"b32": 1, "b64": 2, "b128": 4}[op[9:]]
+                self.store(self.lds, (self.rd(a[0]) & M32) + mods.get("offset", 0), self.rd(a[1]), n)
+        elif op in ("ds_read_u16", "ds_write_b16"):
+            if live:
+                if op == "ds_read_u16":
+                    addr = (self.rd(a[1]) & M32) + mods.get("offset", 0)
+                    self.wr(a[0], (self.lds.get(addr & ~3, 0) >> (8 * (addr & 2))) & 0xFFFF)
+                else:
+                    addr = (self.rd(a[0]) & M32) + mods.get("offset", 0)
+                    sh = 8 * (addr & 2)
+                    self.lds[addr & ~3] = (self.lds.get(addr & ~3, 0) & ~(0xFFFF << sh)) | ((self.rd(a[1]) & 0xFFFF) << sh)
+        elif op in ("ds_read2_b32", "ds_read2st64_b32"):
+            if live:
+                unit = 4 * (64 if "st64" in op else 1)
+                base = self.rd(a[1]) & M32
+                lo = self.load(self.lds, base + unit * mods.get("offset0", 0), 1)
+                hi = self.load(self.lds, base + unit * mods.get("offset1", 0), 1)
+                self.wr(a[0], lo | (hi << 32))
+        elif op in ("ds_write2_b32", "ds_write2st64_b32"):
+            if live:
+                unit = 4 * (64 if "st64" in op else 1)
+                base = self.rd(a[0]) & M32
+                self.store(self.lds, base + unit * mods.get("offset0", 0), self.rd(a[1]), 1)
+                self.store(self.lds, base + unit * mods.get("offset1", 0), self.rd(a[2]), 1)
+
+        elif re.fullmatch(r"ds_(add|sub|max|min|or|and)(_rtn)?_(u32|b32)", op):
+            if live:                                # LDS atomics; a cell nobody wrote yet reads as 0 (the other lanes' job)
+                kind, rtn = re.fullmatch(r"ds_(\w+?)(_rtn)?_(u32|b32)", op).group(1, 2)
+                dst = a[0] if rtn else None
+                addr_tok, val_tok = (a[1], a[2]) if rtn else (a[0], a[1])
+                addr = (self.rd(addr_tok) & M32) + mods.get("offset", 0)
+                old = self.lds.get(addr, 0)
+                x = self.rd(val_tok) & M32
+                new = {"add": old + x, "sub": old - x, "max": max(old, x), "min": min(old, x), "or": old | x,
+                       "and": old & x}[kind] & M32
+                self.lds[addr] = new
+                if dst:
+                    self.wr(dst, old)
+
+        # -------- vector ALU (skipped when the lane is masked off)
+        elif op == "v_readfirstlane_b32":
+            self.wr(a[0], self.rd(a[1]))
+        elif op == "v_writelane_b32":           # hipcc spills SGPRs into the lanes of a VGPR: lanes other than 0 live here
+            vreg, lane_no = int(a[0][1:]), self.rd(a[2]) & 63
+            self.other_lanes[(vreg, lane_no)] = self.rd(a[1]) & M32
+            if lane_no == 0:
+                self.v[vreg] = self.rd(a[1]) & M32
+        elif op == "v_readlane_b32":
+            vreg, lane_no = int(a[1][1:]), self.rd(a[2]) & 63
+            self.wr(a[0], self.v[vreg] if lane_no == 0 else self.other_lanes[(vreg, lane_no)])
+        elif op.startswith("v_"):
+            if live:
+                self.valu(op, a, text)
+        else:
+            raise AssertionError("the emulator does not know %r: %s" % (op, text))
+        return nxt
 
     def valu(self, op, a, text):
         rd, wr = self.rd, self.wr
@@ -473,7 +540,7 @@ class Lane:
         elif base in ("v_add_co_u32", "v_addc_co_u32", "v_sub_co_u32", "v_subb_co_u32", "v_subrev_co_u32", "v_subbrev_co_u32"):
             # vdst, carry-out, src0, src1[, carry-in]
             x, y = rd(a[2]) & M32, rd(a[3]) & M32
-            cin = (rd(a[4], 64) & 1) if len(a) > 4 else 0
+            cin = self.mbit(rd(a[4], 64)) if len(a) > 4 else 0
             if "rev" in base:
                 x, y = y, x
             if base.startswith("v_add"):
@@ -483,7 +550,7 @@ class Lane:
                 r = x - y - cin
                 cout = int(y + cin > x)
             wr(a[0], r)
-            wr(a[1], cout)
+            self.wr_mbit(a[1], cout)
         elif base == "v_add3_u32":
             wr(a[0], rd(a[1]) + rd(a[2]) + rd(a[3]))
         elif base == "v_lshl_add_u32":
@@ -506,8 +573,12 @@ class Lane:
         elif base == "v_bfi_b32":               # (s0 & s1) | (~s0 & s2)
             m_, x, y = rd(a[1]), rd(a[2]), rd(a[3])
             wr(a[0], (m_ & x) | (~m_ & y))
-        elif base in ("v_mbcnt_lo_u32_b32", "v_mbcnt_hi_u32_b32"):     # bits of the mask BELOW this lane: lane 0 has none
-            wr(a[0], rd(a[2]))
+        elif base in ("v_mbcnt_lo_u32_b32", "v_mbcnt_hi_u32_b32"):     # bits of the mask BELOW this lane, low / high half
+            below = (1 << self.lane_no) - 1
+            half = (below & M32) if "lo" in base else (below >> 32)
+            wr(a[0], bin(rd(a[1]) & M32 & half).count("1") + rd(a[2]))
+        elif base == "v_bcnt_u32_b32":
+            wr(a[0], bin(rd(a[1]) & M32).count("1") + rd(a[2]))
         elif base == "v_bitop3_b32":            # truth table over (s0, s1, s2) = (0xF0, 0xCC, 0xAA): bit (s0 << 2 | s1 << 1 | s2)
             x, y, z, tt = rd(a[1]) & M32, rd(a[2]) & M32, rd(a[3]) & M32, self.bitop3
             r = 0
@@ -563,7 +634,7 @@ class Lane:
             x, y = rd(a[1]) & M32, rd(a[2]) & M32
             wr(a[0], min(x, y) if "min" in base else max(x, y))
         elif base == "v_cndmask_b32":
-            sel = (rd(a[3], 64) if len(a) > 3 else self.vcc) & 1
+            sel = self.mbit(rd(a[3], 64) if len(a) > 3 else self.vcc)
             wr(a[0], rd(a[2]) if sel else rd(a[1]))
         elif base.startswith("v_cmp_"):                      # v_cmp_<op>_<type> dst (vcc | s[a:b]), src0, src1
             kind, ty = base[6:].rsplit("_", 1)
@@ -577,7 +648,7 @@ class Lane:
                 xv, yv = xv & mask, yv & mask
             res = {"eq": xv == yv, "ne": xv != yv, "lg": xv != yv, "gt": xv > yv, "ge": xv >= yv, "lt": xv < yv,
                    "le": xv <= yv}[kind]
-            wr(a[0], int(res))
+            self.wr_mbit(a[0], int(res))
         elif base == "v_cvt_f32_u32":
             wr(a[0], bits_of(float(rd(a[1]) & M32)))
         elif base == "v_cvt_u32_f32":
@@ -611,3 +682,107 @@ class Lane:
             wr(a[0], out)
         else:
             raise AssertionError("the emulator does not know %r: %s" % (op, text))
+
+
+class Workgroup:
+    """A workgroup of 64-lane waves in lockstep per wave, waves interleaved at s_barrier: for kernels whose lanes talk
+    through LDS, ballots and barriers (the in-workgroup bucket tree).  Every lane is a Lane; the lanes of a wave share
+    the SGPR file (one list object), VCC / EXEC / SCC live in the wave's scalar context, LDS and global memory are
+    shared by all.  Vector and memory instructions run lane by lane under EXEC; everything else once per wave."""
+
+    MASK_WRITERS = ("v_cmp_", "v_add_co", "v_addc_co", "v_sub_co", "v_subb_co", "v_subrev_co", "v_subbrev_co")
+
+    def __init__(self, prog, n_threads, wg_id=(0, 0), kernarg_addr=0):
+        assert n_threads % 64 == 0
+        self.p = prog
+        self.mem, self.lds = {}, {}
+        self.waves = []
+        first = Lane(prog)                                  # places the constant arrays of the file in memory
+        self.mem.update(first.mem)
+        self.sym_addr = first.sym_addr
+        for w in range(n_threads // 64):
+            sc = Lane(prog)                                 # the wave's scalar context
+            sc.mem, sc.lds, sc.sym_addr = self.mem, self.lds, self.sym_addr
+            sc.exec = M64
+            sc.s[0], sc.s[1] = kernarg_addr & M32, kernarg_addr >> 32
+            sc.s[2], sc.s[3] = wg_id
+            lanes = []
+            for l in range(64):
+                ln = Lane(prog)
+                ln.mem, ln.lds, ln.sym_addr = self.mem, self.lds, self.sym_addr
+                ln.s = sc.s
+                ln.lane_no = l
+                ln.v[0] = 64 * w + l                        # work-item id x
+                lanes.append(ln)
+            self.waves.append({"sc": sc, "lanes": lanes, "pc": prog.entry, "state": "run"})
+        self.count = 0
+
+    def step(self, wv):
+        sc, lanes, pc = wv["sc"], wv["lanes"], wv["pc"]
+        op, a, mods, text = sc.parse(pc)
+        self.count += 1
+        if op == "s_barrier":
+            wv["pc"], wv["state"] = pc + 1, "barrier"
+            return
+        if op in ("s_cbranch_execz", "s_cbranch_execnz", "s_cbranch_vccz", "s_cbranch_vccnz"):
+            cond = {"s_cbranch_execz": sc.exec == 0, "s_cbranch_execnz": sc.exec != 0, "s_cbranch_vccz": sc.vcc == 0,
+                    "s_cbranch_vccnz": sc.vcc != 0}[op]
+            wv["pc"] = self.p.labels[a[0]] if cond else pc + 1
+            return
+        if op == "v_readfirstlane_b32":
+            src = next((l for l in range(64) if (sc.exec >> l) & 1), 0)
+            sc.wr(a[0], lanes[src].rd(a[1]))
+        elif op == "v_readlane_b32":
+            sc.wr(a[0], lanes[sc.rd(a[2]) & 63].rd(a[1]))
+        elif op == "v_writelane_b32":
+            lanes[sc.rd(a[2]) & 63].wr(a[0], sc.rd(a[1]))
+        elif op.startswith(("v_", "ds_", "global_", "flat_", "scratch_")):
+            # an instruction that writes a lane mask (compare, carry-out): every lane must see the ORIGINAL value of
+            # the destination registers (v_cmp_lt_u32 s[0:1], s0, v73 reads s0), inactive lanes end up as 0
+            dst = None
+            if op.startswith(self.MASK_WRITERS):
+                dst = a[0] if op.startswith("v_cmp_") else a[1]
+                orig = sc.vcc if dst == "vcc" else sc.rd(dst, 64)
+                acc = 0
+            for l in range(64):
+                if (sc.exec >> l) & 1:
+                    ln = lanes[l]
+                    if dst is not None:
+                        if dst == "vcc":
+                            sc.vcc = orig
+                        else:
+                            sc.wr(dst, orig)
+                    ln.vcc, ln.scc, ln.exec = sc.vcc, sc.scc, sc.exec
+                    nxt = ln.exec_one(pc, op, a, mods, text, 1)
+                    assert nxt == pc + 1
+                    sc.vcc = ln.vcc
+                    if dst is not None:
+                        acc |= (((sc.vcc if dst == "vcc" else sc.rd(dst, 64)) >> l) & 1) << l
+            if dst is not None:
+                if dst == "vcc":
+                    sc.vcc = acc
+                else:
+                    sc.wr(dst, acc)
+        else:
+            nxt = sc.exec_one(pc, op, a, mods, text, int(sc.exec != 0))
+            if nxt is None:
+                wv["state"] = "done"
+                return
+            wv["pc"] = nxt
+            return
+        wv["pc"] = pc + 1
+
+    def run(self, limit=50_000_000):
+        while True:
+            running = [w for w in self.waves if w["state"] == "run"]
+            if not running:
+                waiting = [w for w in self.waves if w["state"] == "barrier"]
+                if not waiting:
+                    return
+                for w in waiting:                           # every wave that is still alive has arrived
+                    w["state"] = "run"
+                continue
+            for w in running:
+                while w["state"] == "run":
+                    self.step(w)
+                    assert self.count < limit, "instruction limit"
