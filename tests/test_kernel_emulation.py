@@ -257,3 +257,79 @@ def test_g1_accumulation_workgroup_with_the_bucket_tree():
             exp = C.add(exp, C.neg(pts[idx]) if neg else pts[idx])
         got = None if co[2] == 0 else (co[0] * pow(co[2], p - 2, p) % p, co[1] * pow(co[3], p - 2, p) % p)
         assert got == exp, "bucket %d" % b
+
+
+def test_g2_finalize_workgroup():
+    """msm_finalize_lds_kernel<Fp2<bn254>, 256, 2> (the throughput finalize behind the G2 accumulation: two lanes per
+    bucket, each adding its share of the bucket's partial sums into an accumulator in LDS columns -- XYZZ29::add_into
+    with the four-product Y3 --, then one tree step across the two lanes behind a barrier) on the Workgroup emulator:
+    buckets with 5, 2, 1 and 0 partials, partials in XYZZ form with Z != 1 -> the buckets the oracle's sums predict."""
+    import random
+    from oracle.pyref.curves import CURVES
+    C = CURVES["bn254", "g2"]
+    F2 = C.F
+    p = F2.p
+    n_limbs, w = limb_shape(p)
+    R = 1 << (w * n_limbs)
+    prog = E.Program(assembly("bn254", 2), "msm_finalize_lds_kernelINS_3Fp2INS_2FpINS_15bn254_fq_paramsEEEEELi256ELi2E")
+    CNTS, SOFF, SSUM, BUCK, GCNT, GLIST, KARG = (0x100000 * k for k in range(1, 8))
+    wg = E.Workgroup(prog, 256, wg_id=(0, 0), kernarg_addr=KARG)
+    mem = wg.mem
+    rng = random.Random(11)
+    log_nb, seg_log = 4, 4
+    parts = {2: 5, 5: 2, 9: 1, 12: 0}                         # bucket -> number of partial sums (segments)
+    expect, slot = {}, 0
+
+    def limbs(v):
+        v = v * R % p
+        return [(v >> (w * i)) & ((1 << w) - 1) for i in range(n_limbs - 1)] + [v >> (w * (n_limbs - 1))]
+
+    for b in range(16):
+        k = parts.get(b, 0)
+        mem[CNTS + 4 * b] = 16 * k                              # k full segments
+        mem[SOFF + 4 * b] = slot
+        total = None
+        for s in range(k):
+            P = C.mul(C.gen, rng.randrange(1, 1000))
+            z = (rng.randrange(1, p), rng.randrange(p))
+            zz = F2.sqr(z)
+            zzz = F2.mul(zz, z)
+            coords = [F2.mul(P[0], zz), F2.mul(P[1], zzz), zz, zzz]
+            words = []
+            for c in coords:
+                words += limbs(c[0]) + limbs(c[1])
+            for i, v in enumerate(words):
+                mem[SSUM + 288 * (slot + s) + 4 * i] = v
+            total = C.add(total, P)
+        expect[b] = total
+        slot += k
+    for i in range(4):
+        mem[GCNT + 4 * i] = 0
+    karg = [0] * 27
+    for k, v in enumerate([5, 1, log_nb, seg_log, 64, 1, 1, 1]):    # MsmGeom: c, nwin, log_nb, seg_log, seg_cap, bw, table, rows
+        karg[k] = v
+
+    def put64(off, v):
+        karg[off // 4], karg[off // 4 + 1] = v & 0xFFFFFFFF, v >> 32
+
+    put64(0x20, 64)                                                # region
+    put64(0x28, 16)                                                # total buckets
+    karg[0x30 // 4] = 0                                            # wg_log: one slot per segment (no tree in the G2 accumulation)
+    for k, base in enumerate([CNTS, SOFF, SSUM, BUCK, GCNT, GLIST]):
+        put64(0x38 + 8 * k, base)
+    karg[0x68 // 4] = 16                                           # giant_cap
+    for k, v in enumerate(karg):
+        mem[KARG + 4 * k] = v
+    wg.run()
+    for b, k in parts.items():
+        if k == 1:
+            continue                                               # a one-segment bucket is written by the accumulation itself
+        out = [mem.get(BUCK + 288 * b + 4 * i) for i in range(72)]
+        assert all(v is not None for v in out), "bucket %d was not written" % b
+
+        def fe(ws):
+            return sum(v << (w * i) for i, v in enumerate(ws)) % p
+
+        co = [(fe(out[18 * c:18 * c + 9]), fe(out[18 * c + 9:18 * c + 18])) for c in range(4)]
+        got = None if co[2] == (0, 0) else (F2.mul(co[0], F2.inv(co[2])), F2.mul(co[1], F2.inv(co[3])))
+        assert got == expect[b], "bucket %d" % b
