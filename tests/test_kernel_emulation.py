@@ -51,15 +51,19 @@ if os.environ.get("DG16_EMU_ALL"):                    # the other three accumula
               ("bls12_377", 2, "msm_accumulate_lds_kernel")]
 
 
-def assembly(curve, group):
-    """msm_group.hip of (curve, group) as gfx950 assembly text.  All translation units of CASES are compiled together
-    (one hipcc each, in parallel) the first time any is asked for, once per source state; safe under pytest-xdist."""
+def assembly(curve, group, source="msm_group.hip"):
+    """`source` of (curve, group) as gfx950 assembly text.  All translation units the tests need are compiled together
+    (one hipcc each, in parallel) the first time any is asked for, once per source state; safe under pytest-xdist.
+    msm_reduce.hip is built as the Makefile builds it (G2: out-of-line field products)."""
     cache = os.path.join("/tmp", "dg16_emu_cache", source_key())
     os.makedirs(cache, exist_ok=True)
-    path = lambda c, g: os.path.join(cache, "msm_%s_g%d.s" % (c, g))     # noqa: E731
+    path = lambda c, g, f: os.path.join(cache, "%s_%s_g%d.s" % (f.split(".")[0], c, g))     # noqa: E731
+    units = [(c, g, "msm_group.hip") for c, g, _ in CASES] + [("bn254", 1, "msm_reduce.hip")]
+    if (curve, group, source) not in units:
+        units.append((curve, group, source))
     jobs = []
-    for c, g, _ in CASES:
-        out = path(c, g)
+    for c, g, f in units:
+        out = path(c, g, f)
         if os.path.exists(out):
             continue
         try:
@@ -67,9 +71,11 @@ def assembly(curve, group):
         except FileExistsError:
             continue                                   # another worker compiles this one
         os.close(fd)
-        proc = subprocess.Popen([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-DDG_CURVE=%d" % CURVE_ID[c],
-                                 "-DDG_GROUP=%d" % g, "-DDG_NAME=%s_g%d" % (c, g), "--cuda-device-only", "-S",
-                                 os.path.join(CSRC, "msm_group.hip"), "-o", out + ".tmp"],
+        flags = ["-DDG_CURVE=%d" % CURVE_ID[c], "-DDG_GROUP=%d" % g, "-DDG_NAME=%s_g%d" % (c, g)]
+        if f == "msm_reduce.hip" and g == 2:
+            flags.append("-DDG29_OUTLINE_MUL")
+        proc = subprocess.Popen([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17"] + flags + ["--cuda-device-only", "-S",
+                                 os.path.join(CSRC, f), "-o", out + ".tmp"],
                                 stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         jobs.append((proc, out))
     for proc, out in jobs:
@@ -79,12 +85,12 @@ def assembly(curve, group):
             os.replace(out + ".tmp", out)
         finally:
             os.unlink(out + ".lock")
-    out = path(curve, group)
+    out = path(curve, group, source)
     for _ in range(900):                               # compiled by another worker
         if os.path.exists(out):
             break
         time.sleep(1)
-    assert os.path.exists(out), "assembly of %s g%d was not produced" % (curve, group)
+    assert os.path.exists(out), "assembly of %s %s g%d was not produced" % (source, curve, group)
     return open(out).read()
 
 
@@ -333,3 +339,67 @@ def test_g2_finalize_workgroup():
         co = [(fe(out[18 * c:18 * c + 9]), fe(out[18 * c + 9:18 * c + 18])) for c in range(4)]
         got = None if co[2] == (0, 0) else (F2.mul(co[0], F2.inv(co[2])), F2.mul(co[1], F2.inv(co[3])))
         assert got == expect[b], "bucket %d" % b
+
+
+def test_g1_bucket_reduction_workgroups():
+    """The bucket reduction of a G1 window on the Workgroup emulator: msm_row_kernel (one 256-lane workgroup per row of
+    256 buckets: suffix scan + tree over LDS, XYZZ29::add_mem) for both rows of a 512-bucket window, then msm_top_kernel
+    (512 lanes: sum W and sum r R on its two halves, doublings, the conversion to the 32-bit arkworks form) ->
+    the window sum == sum_b (b + 1) B_b from the oracle.  A dozen buckets are occupied, in XYZZ form with Z != 1."""
+    import random
+    from oracle.pyref.curves import CURVES
+    C = CURVES["bn254", "g1"]
+    p = C.F.p
+    n_limbs, w = limb_shape(p)
+    R = 1 << (w * n_limbs)
+    text = assembly("bn254", 1, "msm_reduce.hip")
+    BUCK, ROWW, ROWR, FOLD, WSUM, KARG = (0x100000 * k for k in range(1, 7))
+    rng = random.Random(5)
+    log_nb = 9
+    occupied = sorted(rng.sample(range(512), 10) + [0, 511])
+    mem0 = {}
+    expect = None
+    for b in range(512):
+        for i in range(36):
+            mem0[BUCK + 144 * b + 4 * i] = 0                       # all-zero limbs: the identity
+    for b in occupied:
+        P = C.mul(C.gen, rng.randrange(1, 10**6))
+        z = rng.randrange(1, p)
+        zz, zzz = z * z % p, z * z * z % p
+        for c, val in enumerate([P[0] * zz % p, P[1] * zzz % p, zz, zzz]):
+            v = val * R % p
+            for i in range(9):
+                mem0[BUCK + 144 * b + 36 * c + 4 * i] = (v >> (29 * i)) & ((1 << 29) - 1) if i < 8 else v >> 232
+        expect = C.add(expect, C.mul(P, b + 1))
+    geom = [10, 1, log_nb, 4, 64, 1, 1, 1]
+    # ---- rows
+    for row in range(2):
+        wg = E.Workgroup(E.Program(text, "msm_row_kernel"), 256, wg_id=(row, 0), kernarg_addr=KARG)
+        wg.mem.update(mem0)
+        karg = [0] * 18
+        for k, v in enumerate(geom):
+            karg[k] = v
+        karg[0x20 // 4] = 64                                        # region (unused here)
+        karg[0x28 // 4], karg[0x2c // 4] = 8, 1                     # RowGeom: row_log, rows_log
+        for k, base in enumerate([BUCK, ROWW, ROWR]):
+            karg[0x30 // 4 + 2 * k], karg[0x30 // 4 + 2 * k + 1] = base, 0
+        for k, v in enumerate(karg):
+            wg.mem[KARG + 4 * k] = v
+        wg.run()
+        for a, v in wg.mem.items():
+            if ROWW <= a < ROWW + 0x200000:
+                mem0[a] = v
+    # ---- top
+    wg = E.Workgroup(E.Program(text, "msm_top_kernel"), 512, wg_id=(0, 0), kernarg_addr=KARG)
+    wg.mem.update(mem0)
+    karg = [8, 1] + [0] * 8
+    for k, base in enumerate([ROWW, ROWR, FOLD, WSUM]):
+        karg[2 + 2 * k] = base
+    for k, v in enumerate(karg):
+        wg.mem[KARG + 4 * k] = v
+    wg.run()
+    out = [wg.mem.get(WSUM + 4 * i) for i in range(32)]
+    assert all(v is not None for v in out), "the window sum was not written"
+    co = [sum(v << (32 * i) for i, v in enumerate(out[8 * c:8 * c + 8])) % p for c in range(4)]
+    got = (co[0] * pow(co[2], p - 2, p) % p, co[1] * pow(co[3], p - 2, p) % p)
+    assert got == expect

@@ -478,6 +478,25 @@ class Lane:
                     addr = (self.rd(a[0]) & M32) + mods.get("offset", 0)
                     sh = 8 * (addr & 2)
                     self.lds[addr & ~3] = (self.lds.get(addr & ~3, 0) & ~(0xFFFF << sh)) | ((self.rd(a[1]) & 0xFFFF) << sh)
+        elif op in ("ds_read2_b64", "ds_read2st64_b64"):
+            if live:
+                unit = 8 * (64 if "st64" in op else 1)
+                base = self.rd(a[1]) & M32
+                lo = self.load(self.lds, base + unit * mods.get("offset0", 0), 2)
+                hi = self.load(self.lds, base + unit * mods.get("offset1", 0), 2)
+                self.wr(a[0], lo | (hi << 64))
+        elif op in ("ds_write2_b64", "ds_write2st64_b64"):
+            if live:
+                unit = 8 * (64 if "st64" in op else 1)
+                base = self.rd(a[0]) & M32
+                self.store(self.lds, base + unit * mods.get("offset0", 0), self.rd(a[1]), 2)
+                self.store(self.lds, base + unit * mods.get("offset1", 0), self.rd(a[2]), 2)
+        elif op in ("ds_read_b96", "ds_write_b96"):
+            if live:
+                if op == "ds_read_b96":
+                    self.wr(a[0], self.load(self.lds, (self.rd(a[1]) & M32) + mods.get("offset", 0), 3))
+                else:
+                    self.store(self.lds, (self.rd(a[0]) & M32) + mods.get("offset", 0), self.rd(a[1]), 3)
         elif op in ("ds_read2_b32", "ds_read2st64_b32"):
             if live:
                 unit = 4 * (64 if "st64" in op else 1)
