@@ -341,35 +341,46 @@ def test_g2_finalize_workgroup():
         assert got == expect[b], "bucket %d" % b
 
 
-def test_g1_bucket_reduction_workgroups():
-    """The bucket reduction of a G1 window on the Workgroup emulator: msm_row_kernel (one 256-lane workgroup per row of
-    256 buckets: suffix scan + tree over LDS, XYZZ29::add_mem) for both rows of a 512-bucket window, then msm_top_kernel
+@pytest.mark.parametrize("group", [1] + ([2] if os.environ.get("DG16_EMU_ALL") else []))
+def test_bucket_reduction_workgroups(group):
+    """The bucket reduction of a window on the Workgroup emulator: msm_row_kernel (one 256-lane workgroup per row of 256
+    buckets: suffix scan + tree over LDS, XYZZ29::add_mem) for both rows of a 512-bucket window, then msm_top_kernel
     (512 lanes: sum W and sum r R on its two halves, doublings, the conversion to the 32-bit arkworks form) ->
-    the window sum == sum_b (b + 1) B_b from the oracle.  A dozen buckets are occupied, in XYZZ form with Z != 1."""
+    the window sum == sum_b (b + 1) B_b from the oracle.  A dozen buckets are occupied, in XYZZ form with Z != 1.
+    G2 (DG16_EMU_ALL=1): the same kernels with the field products behind calls (DG29_OUTLINE_MUL, as the Makefile builds)."""
     import random
     from oracle.pyref.curves import CURVES
-    C = CURVES["bn254", "g1"]
+    C = CURVES["bn254", "g%d" % group]
+    ext = group == 2
     p = C.F.p
     n_limbs, w = limb_shape(p)
     R = 1 << (w * n_limbs)
-    text = assembly("bn254", 1, "msm_reduce.hip")
+    text = assembly("bn254", group, "msm_reduce.hip")
     BUCK, ROWW, ROWR, FOLD, WSUM, KARG = (0x100000 * k for k in range(1, 7))
     rng = random.Random(5)
     log_nb = 9
+    ncomp = 2 if ext else 1
+    pt_words = 4 * 9 * ncomp
     occupied = sorted(rng.sample(range(512), 10) + [0, 511])
     mem0 = {}
     expect = None
     for b in range(512):
-        for i in range(36):
-            mem0[BUCK + 144 * b + 4 * i] = 0                       # all-zero limbs: the identity
+        for i in range(pt_words):
+            mem0[BUCK + 4 * pt_words * b + 4 * i] = 0               # all-zero limbs: the identity
+    F = C.F
+    mul = F.mul if ext else (lambda x, y: x * y % p)
     for b in occupied:
         P = C.mul(C.gen, rng.randrange(1, 10**6))
-        z = rng.randrange(1, p)
-        zz, zzz = z * z % p, z * z * z % p
-        for c, val in enumerate([P[0] * zz % p, P[1] * zzz % p, zz, zzz]):
+        z = (rng.randrange(1, p), rng.randrange(p)) if ext else rng.randrange(1, p)
+        zz = mul(z, z)
+        zzz = mul(zz, z)
+        comps = []
+        for val in (mul(P[0], zz), mul(P[1], zzz), zz, zzz):
+            comps += list(val) if ext else [val]
+        for c, val in enumerate(comps):
             v = val * R % p
             for i in range(9):
-                mem0[BUCK + 144 * b + 36 * c + 4 * i] = (v >> (29 * i)) & ((1 << 29) - 1) if i < 8 else v >> 232
+                mem0[BUCK + 4 * pt_words * b + 36 * c + 4 * i] = (v >> (29 * i)) & ((1 << 29) - 1) if i < 8 else v >> 232
         expect = C.add(expect, C.mul(P, b + 1))
     geom = [10, 1, log_nb, 4, 64, 1, 1, 1]
     # ---- rows
@@ -398,8 +409,13 @@ def test_g1_bucket_reduction_workgroups():
     for k, v in enumerate(karg):
         wg.mem[KARG + 4 * k] = v
     wg.run()
-    out = [wg.mem.get(WSUM + 4 * i) for i in range(32)]
+    nout = 4 * 8 * ncomp
+    out = [wg.mem.get(WSUM + 4 * i) for i in range(nout)]
     assert all(v is not None for v in out), "the window sum was not written"
-    co = [sum(v << (32 * i) for i, v in enumerate(out[8 * c:8 * c + 8])) % p for c in range(4)]
-    got = (co[0] * pow(co[2], p - 2, p) % p, co[1] * pow(co[3], p - 2, p) % p)
+    vals = [sum(v << (32 * i) for i, v in enumerate(out[8 * c:8 * c + 8])) % p for c in range(4 * ncomp)]
+    if ext:
+        co = [(vals[2 * c], vals[2 * c + 1]) for c in range(4)]
+        got = (F.mul(co[0], F.inv(co[2])), F.mul(co[1], F.inv(co[3])))
+    else:
+        got = (vals[0] * pow(vals[2], p - 2, p) % p, vals[1] * pow(vals[3], p - 2, p) % p)
     assert got == expect

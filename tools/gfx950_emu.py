@@ -118,6 +118,8 @@ class Lane:
         self.scratch = {}
         self.other_lanes = {}
         self.clamp = False
+        self.tmp = {}               # pre-selected SDWA operands
+        self.mods = {}
         self.bitop3 = None
         self.count = 0
         self.hist = {}              # opcode -> times executed
@@ -133,6 +135,8 @@ class Lane:
     # ---- operands ------------------------------------------------------------------------------------------------
     def rd(self, tok, width=32):
         tok = tok.strip()
+        if tok in self.tmp:
+            return self.tmp[tok]
         neg = False
         if tok.startswith("-") and not re.match(r"^-\d", tok):
             neg, tok = True, tok[1:]
@@ -265,6 +269,11 @@ class Lane:
         mods["bitop3"] = int(m.group(1), 0) if m else None
         if m:
             rest = rest[:m.start()] + rest[m.end():]
+        for key in ("dst_sel", "dst_unused", "src0_sel", "src1_sel"):          # SDWA
+            m = re.search(r"\s%s:(\w+)" % key, rest)
+            if m:
+                mods[key] = m.group(1)
+                rest = rest[:m.start()] + rest[m.end():]
         mods["clamp"] = bool(re.search(r"\sclamp\b", rest))
         rest = re.sub(r"\sclamp\b", "", rest)
         a = [x.strip() for x in rest.split(",")] if rest.strip() else []
@@ -286,7 +295,7 @@ class Lane:
         """executes instruction pc for this lane (scalar state included) -> next pc, None at s_endpgm"""
         ins, labels = self.p.ins, self.p.labels
         nxt = pc + 1
-        self.bitop3, self.clamp = mods["bitop3"], mods["clamp"]
+        self.bitop3, self.clamp, self.mods = mods["bitop3"], mods["clamp"], mods
 
         # -------- program flow
         if op == "s_endpgm":
@@ -545,6 +554,26 @@ class Lane:
 
     def valu(self, op, a, text):
         rd, wr = self.rd, self.wr
+        if op.endswith("_sdwa"):                # sub-dword operand selection, then the plain operation
+            def sel(v, how):
+                v &= M32
+                if how.startswith("BYTE_"):
+                    return (v >> (8 * int(how[5]))) & 0xFF
+                if how.startswith("WORD_"):
+                    return (v >> (16 * int(how[5]))) & 0xFFFF
+                assert how == "DWORD", how
+                return v
+            assert self.mods.get("dst_sel", "DWORD") == "DWORD", text
+            self.tmp = {"__s0": sel(rd(a[1]), self.mods.get("src0_sel", "DWORD"))}
+            args = [a[0], "__s0"]
+            if len(a) > 2:
+                self.tmp["__s1"] = sel(rd(a[2]), self.mods.get("src1_sel", "DWORD"))
+                args.append("__s1")
+            try:
+                self.valu(op[:-5], args + a[3:], text)
+            finally:
+                self.tmp = {}
+            return
         base = re.sub(r"_e(32|64)$", "", op)
         if base in ("v_mov_b32", "v_mov_b64"):
             wr(a[0], rd(a[1], 64 if base.endswith("64") else 32))
