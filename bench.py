@@ -54,11 +54,12 @@ def valu_constants(curve):
     """(v_mad_u64_u32 per base-field product, measured chip-wide G products/s) of the reduced-radix product
     (csrc/fp29.h), from the committed micro-benchmark output -- measured constants live under profiles/, not in the
     library's ABI.  profiles/r3c_valu_constants.json = tools/ubench/fe_rate on an MI355X with the product as the
-    library ships it (explicit v_mad_u64_u32 chains, csrc/fp29_asm_gen.h: 174.9 G/s for the 9-limb fields);
-    r3_valu_constants.json = the same benchmark on the C++-compiled product it replaced (169.3).  An auxiliary figure of
+    library ships it (explicit v_mad_u64_u32 chains, csrc/fp29_asm_gen.h: 174.9 G/s for the 9-limb fields; r4a_*: the
+    same benchmark in round 4's first GPU call, 177.1); r3_valu_constants.json = the same benchmark on the C++-compiled
+    product it replaced (169.3).  An auxiliary figure of
     the line, NOT its peak -- the peak is the issue rate of the instruction itself (MAD_ISSUE_T), which no rewrite of the
     product can move."""
-    for name in ("r3c_valu_constants.json", "r3_valu_constants.json"):
+    for name in ("r4a_valu_constants.json", "r3c_valu_constants.json", "r3_valu_constants.json"):
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
             with open(path) as f:
@@ -312,24 +313,46 @@ def extras(ctx, dev, wl, curve, res):
     del x
     # BASELINE config 2: plain MSM over fresh bases (dg16_msm: sort + accumulate + reductions + Horner tail) and the
     # resident form (dg16_bases_upload once, then dg16_msm_resident: window tables, no tail)
+    # Every timed call is checked: the result of the LAST timed call against the oracle's MSM of the same inputs, and
+    # the oracle ("port": C, OpenMP, Pippenger parallel over windows like arkworks) is timed beside it.
+    from oracle import corc
     n = wl.nv - 1
     msm = {}
+    w_host = to_host_u64(wl.w, 4)[1:]
+    msm_ok = True
     for g, bases in ((1, wl.aq), (2, wl.b2q)):
         pb = 2 * fqb * g
+        bases_host = to_host_u64(bases, fqb // 8 * 2 * g)[1:]
+        t0 = time.perf_counter()
+        want = corc.msm(curve, g, bases_host, w_host, threads=cpu_threads())
+        t_cpu = time.perf_counter() - t0
+        msm["g%d_cpu_port_pts_per_s" % g] = n / t_cpu
+        msm["g%d_cpu_port_cores" % g] = cpu_threads()
         out = torch.empty(3 * fqb * g, dtype=torch.uint8, device=dev)
         call_ms, acc_ms = time_call(ctx, lambda: ctx.msm_dev(curve, g, bases.data_ptr() + pb, wl.w.data_ptr() + 32, n,
                                                               out.data_ptr(), channel=1), 1)
         msm["g%d_plain_pts_per_s" % g] = n / (call_ms * 1e-3)
         msm["g%d_plain_ms" % g] = call_ms
+        ok = bool(np.array_equal(corc.jac_to_affine(curve, g, out.cpu().numpy().view(np.uint64)), want))
         if hasattr(ctx, "bases_upload"):
             hb = ctx.bases_upload(curve, g, bases.data_ptr() + pb, n, device_ptrs=True)
+            out.zero_()
+            torch.cuda.synchronize()
             call_ms, acc_ms = time_call(ctx, lambda: ctx.msm_resident_dev(hb, wl.w.data_ptr() + 32, n, out.data_ptr(),
                                                                           channel=1), 1)
             msm["g%d_resident_pts_per_s" % g] = n / (call_ms * 1e-3)
             msm["g%d_resident_ms" % g] = call_ms
+            ok = ok and bool(np.array_equal(corc.jac_to_affine(curve, g, out.cpu().numpy().view(np.uint64)), want))
             hb.close()
+        msm["g%d_parity" % g] = "pass (the timed calls' results == the oracle's MSM)" if ok else "FAIL"
+        msm_ok = msm_ok and ok
     msm["n"] = n
     res["msm_pts_per_s"] = msm
+    res["msm_cpu_port"] = msm_cpu_port(curve, wl, w_host)
+    res["msm_sweep"] = msm_sweep(ctx, dev)
+    if not msm_ok or "FAIL" in json.dumps(res["msm_sweep"]):
+        print(json.dumps(res))
+        raise SystemExit("a timed MSM differs from the oracle's")
     # BASELINE config 4: sha256-shaped prove (29 823 wires, 2 instance variables, domain 2^15; the real r1cs is a
     # missing blob of the reference tree: SURVEY.md section 0), parity against the oracle, r = s = 0 and random
     if curve == "bn254":
@@ -359,6 +382,81 @@ def extras(ctx, dev, wl, curve, res):
         # parity gate on THE TIMED instance (the 2^24 size of config 5 is `--curve bls12_381 --log-m 24`: 126 GB of
         # window tables on one GPU, its 8-GPU form is the driver's to run)
         res["config5_bls12_381_2e20"] = timed_prove_with_parity(ctx, dev, "bls12_381", 20, steps=5)
+
+
+def msm_cpu_port(curve, wl, w_host):
+    """BASELINE config 1 (G1 MSM of 2^16 random points and scalars, single-process CPU: dmsm_test.rs:49-50 calls the
+    plain G::msm next to d_msm) and the same at 2^20, on the oracle's MSM ("port"), one thread and all the threads
+    the port uses -- the CPU figures the GPU pts/s of this line stand beside."""
+    from oracle import corc
+    fqb = FQ_BYTES[curve]
+    bases = to_host_u64(wl.aq, fqb // 8 * 2)[1:]
+    out = {"kind": "port", "group": "%s G1" % curve, "cpu_model": cpu_model()}
+    for log_n in (16, 20):
+        n = min(1 << log_n, bases.shape[0])
+        for threads in (1, cpu_threads()):
+            t0 = time.perf_counter()
+            corc.msm(curve, 1, bases[:n], w_host[:n], threads=threads)
+            dt = time.perf_counter() - t0
+            out["2^%d_%d_threads" % (log_n, threads)] = {"n": n, "seconds": dt, "pts_per_s": n / dt}
+    return out
+
+
+def msm_sweep(ctx, dev):
+    """dist-primitives/examples/msm_bench.rs:24-29: G::msm of 2^10 .. 2^19 random BLS12-377 G1 points and scalars (the
+    reference times nothing itself: it is run under `time`).  Here: dg16_msm on fresh device-resident bases (whole call
+    by the library's HIP events, median of 3), the oracle's MSM on the host cores beside it, and the GPU result
+    compared with the oracle's at every size."""
+    from oracle import corc
+    curve, fqb = "bls12_377", 48
+    nmax = 1 << 19
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1019)
+    lo = torch.randint(-2**63, 2**63 - 1, (nmax, 3), dtype=torch.int64, device=dev, generator=gen)
+    hi = torch.randint(0, 0x12AB655E9A2CA556, (nmax, 1), dtype=torch.int64, device=dev, generator=gen)  # < top limb of r
+    scal = torch.cat([lo, hi], dim=1).contiguous()
+    bases = torch.empty(nmax * 2 * fqb, dtype=torch.uint8, device=dev)
+    ctx.gen_bases_dev(curve, 1, 377, nmax, bases.data_ptr())
+    ctx.sync(0)
+    torch.cuda.synchronize()
+    bh, sh = to_host_u64(bases, 12), to_host_u64(scal, 4)
+    out = torch.empty(3 * fqb, dtype=torch.uint8, device=dev)
+    rows = []
+    for log_n in range(10, 20):
+        n = 1 << log_n
+        call_ms, _ = time_call(ctx, lambda: ctx.msm_dev(curve, 1, bases.data_ptr(), scal.data_ptr(), n, out.data_ptr(),
+                                                        channel=1), 1)
+        t0 = time.perf_counter()
+        want = corc.msm(curve, 1, bh[:n], sh[:n], threads=cpu_threads())
+        t_cpu = time.perf_counter() - t0
+        ok = bool(np.array_equal(corc.jac_to_affine(curve, 1, out.cpu().numpy().view(np.uint64)), want))
+        rows.append({"log_n": log_n, "gpu_ms": call_ms, "gpu_pts_per_s": n / (call_ms * 1e-3), "cpu_port_ms": t_cpu * 1e3,
+                     "cpu_port_pts_per_s": n / t_cpu, "parity": "pass" if ok else "FAIL"})
+    return {"curve": "bls12_377 G1 (msm_bench.rs)", "cpu_port_cores": cpu_threads(), "rows": rows}
+
+
+def host_pointer_figure(ctx, wl, prover, steps):
+    """The reference entry point takes host memory (create_proof_with_reduction_and_matrices: matrices and key fixed per
+    circuit, the full assignment new per proof, groth16/examples/sha256.rs:159).  Secondary figure: the same step with
+    the assignment copied host -> device (pinned source) and the proof copied device -> host INSIDE the step."""
+    w_host = wl.w.cpu().pin_memory()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(steps + 1):
+        t0 = time.perf_counter()
+        wl.w.copy_(w_host, non_blocking=True)
+        torch.cuda.synchronize()                 # torch's stream -> the library's stream
+        wl.qap()
+        proof = prover.prove(wl.a, wl.b, wl.c, wl.w, wl.rs, scalars_mont=False)
+        for ch in range(3):
+            ctx.sync(ch)
+        proof.cpu()
+        ts.append(time.perf_counter() - t0)
+    dt = sum(ts[1:]) / steps
+    return {"ms_per_step": dt * 1e3, "constraints_per_s": wl.nc / dt, "steps": steps,
+            "includes": "H2D copy of the %d-byte full assignment from pinned host memory, R1CS x witness, the proof, D2H "
+                        "copy of the %d-byte proof; matrices and proving key resident (fixed per circuit)"
+                        % (w_host.numel() * 8, wl.proof_bytes())}
 
 
 def timed_prove_with_parity(ctx, dev, curve, log_m, steps):
@@ -410,6 +508,8 @@ def main():
     ap.add_argument("--log-m", type=int, default=20)
     ap.add_argument("--cpu-sample-log", type=int, default=20,
                     help="log2 size of the CPU baseline / parity instance when the timed one is larger")
+    ap.add_argument("--full-parity", action="store_true",
+                    help="prove the TIMED instance with the oracle whatever its size (2^24: minutes of host time)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--table-budget-gb", type=float, default=0.0,
@@ -421,6 +521,8 @@ def main():
                          "pipeline, or the Python-driven protocol")
     args = ap.parse_args()
     curve = args.curve
+    if args.full_parity:
+        args.cpu_sample_log = max(args.cpu_sample_log, args.log_m)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # plain `python bench.py --gpus N`: become the launcher of N ranks (one process per GPU) and relay their output
@@ -513,7 +615,8 @@ def main():
     # HBM traffic of that kernel: PMC counters cannot be read from inside the process; the committed summary of
     # the separate rocprofv3 --pmc passes over the same launch (same curve, group, size) supplies it.
     traffic, traffic_src = None, None
-    for name in ("r3_pmc_g2_accumulate.json", "r2_pmc_g2_accumulate.json", "r1_pmc_g2_accumulate.json"):
+    for name in ("r4c_pmc_g2_accumulate.json", "r4a_pmc_g2_accumulate.json", "r3_pmc_g2_accumulate.json", "r2_pmc_g2_accumulate.json",
+                 "r1_pmc_g2_accumulate.json"):
         pmc_path = os.path.join(ROOT, "profiles", name)
         if args.log_m == 20 and curve == "bn254" and world == 1 and os.path.exists(pmc_path):
             with open(pmc_path) as f:
@@ -599,6 +702,8 @@ def main():
                            "value": world * rwl.nc * args.steps / rel, "unit": "constraints/s", "scaling": "weak",
                            "ms_per_step": rel / args.steps * 1e3, "key_table_bytes_per_gpu": rwl.pk.info()["table_bytes"]}
         rwl.pk.close()
+    if rank == 0 and world == 1:
+        res["host_pointer_step"] = host_pointer_figure(ctx, wl, prover, min(args.steps, 10))
     if rank == 0 and world == 1 and not args.no_extras:
         extras(ctx, dev, wl, curve, res)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -53,11 +53,16 @@ int dg16_ctx_create(int device, dg16_ctx** out) {
     std::vector<uint32_t> mask((size_t)(ctx->compute_units + 31) / 32, 0u);
     for (int cu = 0; cu < ctx->compute_units - reserve; cu++) mask[cu / 32] |= 1u << (cu % 32);
     const bool masked = reserve > 0 && reserve < ctx->compute_units;
+    // DG16_MAIN2=1: aux[1] becomes a second lane for saturating kernels BELOW channel 0's priority (prover_impl.h,
+    // DG16_EXP bit 16): channel 0 moves to the middle of the priority range, aux[1] takes the lowest
+    const char* m2 = getenv("DG16_MAIN2");
+    const bool main2 = m2 && atoi(m2) != 0 && prio_lo - prio_hi >= 2;
+    const int prio_main = main2 ? (prio_lo + prio_hi) / 2 : prio_lo;
     for (int i = 0; i < kChannels; i++) {
       if (i == 0 && masked)
         DG_HIP(hipExtStreamCreateWithCUMask(&ctx->ch[i].own, (uint32_t)mask.size(), mask.data()));
       else
-      DG_HIP(hipStreamCreateWithPriority(&ctx->ch[i].own, hipStreamNonBlocking, (i > 0 && side_prio) ? prio_hi : prio_lo));
+      DG_HIP(hipStreamCreateWithPriority(&ctx->ch[i].own, hipStreamNonBlocking, (i > 0 && side_prio) ? prio_hi : prio_main));
       ctx->ch[i].cur = ctx->ch[i].own;
       for (int e = 0; e < 4; e++) DG_HIP(hipEventCreate(&ctx->ch[i].ev[e]));
     }
@@ -66,7 +71,7 @@ int dg16_ctx_create(int device, dg16_ctx** out) {
     if (masked)
       DG_HIP(hipExtStreamCreateWithCUMask(&ctx->aux[1], (uint32_t)mask.size(), mask.data()));
     else
-      DG_HIP(hipStreamCreateWithPriority(&ctx->aux[1], hipStreamNonBlocking, side_prio ? prio_hi : prio_lo));
+      DG_HIP(hipStreamCreateWithPriority(&ctx->aux[1], hipStreamNonBlocking, (side_prio && !main2) ? prio_hi : prio_lo));
     DG_HIP(hipHostMalloc((void**)&ctx->dev_flag_host, sizeof(unsigned), hipHostMallocMapped));
     *ctx->dev_flag_host = 0;
     DG_HIP(hipHostGetDevicePointer((void**)&ctx->dev_flag, ctx->dev_flag_host, 0));

@@ -58,12 +58,13 @@ struct dg16_ctx {
   std::string name;
   dg16::Channel ch[dg16::kChannels];
   std::mutex mu;  // guards err + twiddle cache
+  std::mutex mpc_mu;  // one prove::A / B / C::compute at a time per context (they share the term buffers of dist.hip)
   std::string err;
   // Long-lived events for cross-stream dependencies inside one call (prover pipeline).  They are never
   // destroyed while the context lives: destroying an event right after hipStreamWaitEvent() let later
   // launches overtake the wait once all buffers were warm (second proof on a context differed from the
   // oracle; the first one was masked by the implicit synchronisation of hipMalloc).
-  hipEvent_t pipe_ev[16] = {};
+  hipEvent_t pipe_ev[24] = {};
   hipStream_t aux[2] = {};   // extra internal streams of the prover pipeline (never handed out)
   dg16::Channel xws[2];      // workspace-only (no stream): the bucket buffers of the H and L MSMs of a proof
   // Sticky argument-error flag of stream-ordered calls (pinned host word mapped into the device: kernels OR

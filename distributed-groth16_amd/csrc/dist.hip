@@ -650,9 +650,14 @@ struct MpcTerms {
   void* scalar(unsigned i) const { return base + 8 * jb + i * 32; }
   void* result() const { return base + 8 * jb + 8 * 32; }
 };
+// The buffer has ONE size for every curve and group (the largest Jacobian point is 6 x 48 bytes), so the grow-only slot
+// is allocated once per context and never moves; ctx->mpc_mu serialises the prove_* calls of a context, which are the
+// only users (a party runs A, B, C one after another: groth16/examples/sha256.rs:45-92).
+constexpr size_t kMpcTermsBytes = 9 * 288 + 8 * 32;
 static MpcTerms mpc_terms(Channel& c, int curve, int group) {
   const size_t jb = affine_bytes(curve, group) / 2 * 3;
-  return MpcTerms{(uint8_t*)ws(c, 29 + (group - 1), 9 * jb + 8 * 32), jb};
+  static_assert(kMpcTermsBytes >= 9 * 288 + 8 * 32, "term buffer");
+  return MpcTerms{(uint8_t*)ws(c, 29 + (group - 1), kMpcTermsBytes), jb};
 }
 // affine point handed over by the caller (host or device) -> Jacobian term slot
 static void put_affine_term(Call& k, int curve, int group, const void* pt, bool dev, int stage_slot, void* term) {
@@ -669,6 +674,7 @@ static void prove_ab(dg16_ctx* ctx, const dg16_pss* pp, const dg16_net* net, int
   DG_REQUIRE(pp && net && fixed0 && fixed1 && k1 && out, DG16_ERR_BAD_ARG, "bad argument");
   DG_REQUIRE(net->n_parties(net->self) == pp->n, DG16_ERR_BAD_ARG, "net.n_parties() != pp.n");
   const bool dev = flags & DG16_F_DEVICE_PTRS;
+  std::lock_guard<std::mutex> whole_call(ctx->mpc_mu);
   MpcTerms t;
   {
     Call k(ctx, channel);
@@ -715,6 +721,7 @@ int dg16_prove_c(dg16_ctx* ctx, const dg16_pss* pp, const dg16_net* net, const v
     DG_REQUIRE(pp && net && A && M && s && r && out, DG16_ERR_BAD_ARG, "bad argument");
     DG_REQUIRE(net->n_parties(net->self) == pp->n, DG16_ERR_BAD_ARG, "net.n_parties() != pp.n");
     const bool dev = flags & DG16_F_DEVICE_PTRS;
+    std::lock_guard<std::mutex> whole_call(ctx->mpc_mu);
     MpcTerms t;
     {
       Call k(ctx, 0);
@@ -724,19 +731,25 @@ int dg16_prove_c(dg16_ctx* ctx, const dg16_pss* pp, const dg16_net* net, const v
     struct Job { const void *bases, *scalars; size_t nb, ns; unsigned slot; } jobs[3] = {
         {W, ax, n_W, n_ax, 0}, {U, h, n_U, n_h, 1}, {H, a, n_H, n_a, 4}};
     StatusError errs[3] = {{DG16_OK, ""}, {DG16_OK, ""}, {DG16_OK, ""}};
-    std::thread th[3];
-    for (int c = 0; c < 3; c++)
-      th[c] = std::thread([&, c] {
-        try {
-          d_msm_on_channel(ctx, pp, net, 1, jobs[c].bases, jobs[c].scalars, jobs[c].nb, jobs[c].ns, flags, c,
-                           t.term(jobs[c].slot));
-        } catch (const StatusError& e) {
-          errs[c] = e;
-        } catch (const std::exception& e) {
-          errs[c] = StatusError{DG16_ERR_HIP, e.what()};
-        }
-      });
-    for (auto& x : th) x.join();
+    auto run = [&](int c) {
+      try {
+        d_msm_on_channel(ctx, pp, net, 1, jobs[c].bases, jobs[c].scalars, jobs[c].nb, jobs[c].ns, flags, c,
+                         t.term(jobs[c].slot));
+      } catch (const StatusError& e) {
+        errs[c] = e;
+      } catch (const std::exception& e) {
+        errs[c] = StatusError{DG16_ERR_HIP, e.what()};
+      }
+    };
+    if (flags & DG16_F_SERIAL_CHANNELS) {
+      // a transport whose channels are NOT independent (one ordered pipe for all of them): the three d_msm one after
+      // another in the fixed order 0, 1, 2 on every party -- same result, no concurrency
+      for (int c = 0; c < 3 && (c == 0 || errs[c - 1].code == DG16_OK); c++) run(c);
+    } else {
+      std::thread th[3];
+      for (int c = 0; c < 3; c++) th[c] = std::thread(run, c);
+      for (auto& x : th) x.join();
+    }
     for (const auto& e : errs)
       if (e.code != DG16_OK) throw e;
     Call k(ctx, 0);

@@ -319,13 +319,7 @@ constexpr bool rr_cols_fit(int lu_products) { return RR<P>::N * (lu_products + 1
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(DG29_NO_ASM_MAD)
 #define DG29_ASM_MAD 1
 #include "fp29_asm_gen.h"
-// -DDG29_ASM_WHOLE: every product as ONE statement with its accumulator in fixed registers (no s_nop inside; an A/B
-// candidate, see tools/gen_fp29_asm.py); default: one statement per column
-#ifdef DG29_ASM_WHOLE
-#define DG29_SEQ(kind, n) mont_asmw_##kind##_##n
-#else
 #define DG29_SEQ(kind, n) mont_asm_##kind##_##n
-#endif
 #endif
 namespace dg16 {
 

@@ -809,12 +809,9 @@ msm_accumulate_lds_kernel(MsmBases bases, size_t n, MsmGeom g,
   // index was fetched an iteration earlier, the index after it is fetched now): the dependent entry -> point load no
   // longer sits in front of every addition.  An index past the segment is 0 (a valid row).  48-byte-field Fq2 (252
   // registers, one wave) has no room for it and loads at the top of the iteration as before.
-  // UNMEASURED (written when the round's GPU minutes were spent); -DDG16_NO_POINT_PREFETCH restores the plain loop.
-#ifdef DG16_NO_POINT_PREFETCH
-  constexpr bool PREFETCH = false;
-#else
+  // Measured against the plain loop in round 4 (profiles/r4a_ab_variants.md): 2.871-2.883 ms per launch against
+  // 2.877-2.909, same box, same call -- inside the noise, ahead on both passes: kept, the build switch is gone.
   constexpr bool PREFETCH = sizeof(F) <= 64;
-#endif
   unsigned cur = cnt ? e[0] : 0u;
   unsigned nxt = cnt > 1 ? e[1] : 0u;
   RawPoint<F> raw_cur{};
@@ -1262,26 +1259,39 @@ __global__ void __launch_bounds__(256) msm_finalize_thr_kernel(MsmGeom g, size_t
 // 2.2 ms inside a proof, where its waves also take the slots of two accumulation waves each: the G1 accumulation next
 // to it stretched by 0.6 ms); here a 2^20-point table MSM is one round of 2 waves per SIMD with 8 + 1 additions per
 // lane.  Runs on the accumulation's own stream, right behind it (msm_accumulate_phase).
-template <class F>
-struct MemAcc {      // an XYZZ29 in memory behind the accessor interface of XYZZ29::add_acc
+// One addition SITE: the serial partials (global memory) and the tree partners (LDS columns) go through the same
+// accessor, told apart at run time -- the kernel with one add_into per operand kind and LPB as a template parameter was
+// 227 KB of code (two inlined Fq2 additions, each with its inlined doubling branch) against the 64 KB instruction cache
+// two CUs share, and ran at a quarter of its issue rate (0.68 ms per 2^20-point G2 MSM; 0.42 ms before the products
+// became longer instruction sequences).
+template <class F, int BLOCK>
+struct PartialAcc {      // an XYZZ29 behind the accessor interface of XYZZ29::add_into: memory if p, else LDS column
   using S = typename FieldOf<F>::Store;
   const XYZZ29<F>* p;
-  __device__ __forceinline__ S get(int coord) const { return coord == 0 ? p->x : coord == 1 ? p->y : coord == 2 ? p->zz : p->zzz; }
+  ColAcc<F, BLOCK> col;
+  __device__ __forceinline__ S get(int coord) const {
+    if (p) return coord == 0 ? p->x : coord == 1 ? p->y : coord == 2 ? p->zz : p->zzz;
+    return col.get(coord);
+  }
 };
-template <class F, int BLOCK, int LPB>
+template <class F, int BLOCK>
 __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 ? 2 : 1))
-msm_finalize_lds_kernel(MsmGeom g, size_t total, unsigned wg_log, const unsigned* __restrict__ counts,
+msm_finalize_lds_kernel(MsmGeom g, size_t total, unsigned wg_log, unsigned lpb_log,
+                        const unsigned* __restrict__ counts,
                         const unsigned* __restrict__ seg_off, const XYZZ29<F>* __restrict__ seg_sum,
                         XYZZ29<F>* __restrict__ buckets, unsigned* __restrict__ giant_count,
                         unsigned* __restrict__ giant_list, unsigned giant_cap) {
   using FO = FieldOf<F>;
   constexpr int WORDS = sizeof(typename FO::Store) / 4;
   __shared__ uint32_t sh[4 * WORDS][BLOCK];
+  __shared__ unsigned max_serial;
+  const unsigned LPB = 1u << lpb_log;
   const unsigned lane = threadIdx.x, sub = lane & (LPB - 1);
-  const size_t gid = ((size_t)blockIdx.x * BLOCK + lane) / LPB;
+  const size_t gid = ((size_t)blockIdx.x * BLOCK + lane) >> lpb_log;
   const ColAcc<F, BLOCK> me{sh, lane};
   unsigned np = 0, first = 0;
   unsigned wy = 0;
+  if (lane == 0) max_serial = 0;
   if (gid < total) {
     wy = (unsigned)(gid >> g.log_nb);
     const size_t gs = ((size_t)(wy % g.bw) << g.log_nb) + (gid & (((size_t)1 << g.log_nb) - 1));
@@ -1305,20 +1315,32 @@ msm_finalize_lds_kernel(MsmGeom g, size_t total, unsigned wg_log, const unsigned
   }
   const bool work = np >= 2 && np <= kGiantSegs;      // np == 1: the accumulation wrote the bucket itself
   const XYZZ29<F>* sp = seg_sum + (size_t)wy * g.seg_cap;
-  const unsigned lo = work ? (unsigned)(((uint64_t)sub * np) / LPB) : 0u;
-  const unsigned hi = work ? (unsigned)(((uint64_t)(sub + 1) * np) / LPB) : 0u;
+  const unsigned lo = work ? (unsigned)(((uint64_t)sub * np) >> lpb_log) : 0u;
+  const unsigned hi = work ? (unsigned)(((uint64_t)(sub + 1) * np) >> lpb_log) : 0u;
   if (lo < hi) {
     const XYZZ29<F>* q = &sp[msm_part_slot(first, lo, wg_log)];
     me.put(0, q->x); me.put(1, q->y); me.put(2, q->zz); me.put(3, q->zzz);
   } else {
-    me.put(2, FO::zero());                              // the identity for add_acc: zz = 0
+    me.put(2, FO::zero());                              // the identity for add_into: zz = 0
   }
+  const unsigned nser = lo < hi ? hi - lo - 1 : 0u;     // this lane's serial additions
+  __syncthreads();
+  atomicMax(&max_serial, nser);
+  __syncthreads();
+  const unsigned ms = max_serial;
+  // steps 0 .. ms - 1: my share of the bucket's partials, one after another; then lpb_log tree steps over
+  // neighbouring columns (behind a barrier each)
 #pragma unroll 1
-  for (unsigned s = lo + 1; s < hi; s++) XYZZ29<F>::add_into(me, MemAcc<F>{&sp[msm_part_slot(first, s, wg_log)]});
-#pragma unroll 1
-  for (unsigned d = 1; d < (unsigned)LPB; d <<= 1) {
-    __syncthreads();
-    if (work && (sub & (2 * d - 1)) == 0) XYZZ29<F>::add_into(me, ColAcc<F, BLOCK>{sh, lane + d});
+  for (unsigned step = 0; step < ms + lpb_log; step++) {
+    const bool tree = step >= ms;
+    if (tree) __syncthreads();
+    const unsigned d = tree ? 1u << (step - ms) : 0u;
+    const bool on = tree ? (work && (sub & (2 * d - 1)) == 0) : step < nser;
+    if (on) {
+      const PartialAcc<F, BLOCK> b{tree ? nullptr : &sp[msm_part_slot(first, lo + 1 + step, wg_log)],
+                                   ColAcc<F, BLOCK>{sh, lane + d}};
+      XYZZ29<F>::add_into(me, b);
+    }
   }
   if (work && sub == 0) {
     XYZZ29<F> out = XYZZ29<F>::inf();
@@ -1342,15 +1364,12 @@ template <class F>
 void msm_finalize_lds_phase(hipStream_t s, const MsmSort& st, const MsmBuffers<F>& b) {
   constexpr int BLOCK = 1 << msm_acc_block_log<F>();
   const int lpb = msm_finalize_lds_lpb();
+  const unsigned lpb_log = lpb == 4 ? 2u : lpb == 2 ? 1u : 0u;
   DG_HIP(hipMemsetAsync(b.giant, 0, 8, s));
   const unsigned blocks = (unsigned)((b.nbw * (size_t)lpb + BLOCK - 1) / BLOCK);
-#define DG_FIN(L)                                                                                                     \
-  hipLaunchKernelGGL((msm_finalize_lds_kernel<F, BLOCK, L>), dim3(blocks), dim3(BLOCK), 0, s, st.g, b.nbw,             \
-                     msm_acc_wg_log<F>(), st.counts, st.seg_off, b.seg_sum, b.buckets, b.giant, b.giant + 2, b.giant_cap)
-  if (lpb == 1) DG_FIN(1);
-  else if (lpb == 4) DG_FIN(4);
-  else DG_FIN(2);
-#undef DG_FIN
+  hipLaunchKernelGGL((msm_finalize_lds_kernel<F, BLOCK>), dim3(blocks), dim3(BLOCK), 0, s, st.g, b.nbw,
+                     msm_acc_wg_log<F>(), lpb_log, st.counts, st.seg_off, b.seg_sum, b.buckets, b.giant, b.giant + 2,
+                     b.giant_cap);
 }
 
 // With the in-workgroup tree the finalize shrinks to a STITCH: one lane per accumulation-workgroup BOUNDARY (a few

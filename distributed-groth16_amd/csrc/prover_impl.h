@@ -224,6 +224,11 @@ static void msms_typed(dg16_ctx* ctx, Call& k0, Call& k1, Call& k2, const PkDev&
   // so that the G2 accumulation starts as soon as the digits exist and the (memory-bound) transforms run next to it.
   static const bool hpoly_side = [] { const char* e = getenv("DG16_HPOLY_SIDE"); return e && atoi(e) != 0; }();
   const bool swap_h = hpoly_side && !dist && !h_given;
+  // DG16_EXP=<bits> (TIMING experiments of the schedule; bits 0, 1, 3 give a WRONG proof -- they bound what a reduction
+  // chain costs the kernels it runs next to):  1 skip B's (G2) bucket reduction, 2 skip the G1 reductions of A, B1, L
+  // and the two scalar multiples, 4 B's reduction starts only after H's accumulation (runs next to H's reduction at
+  // the end of the proof instead of under the G1 accumulations), 8 skip the two scalar multiples only
+  static const unsigned exp_bits = [] { const char* e = getenv("DG16_EXP"); return e ? (unsigned)atoi(e) : 0u; }();
   // side: the digit sort shared by A, B1, B and L; its buffers live in channel 1
   hipStream_t sort_stream = swap_h ? main : side;
   DG_HIP(hipStreamWaitEvent(side, ev[8], 0));
@@ -260,10 +265,13 @@ static void msms_typed(dg16_ctx* ctx, Call& k0, Call& k1, Call& k2, const PkDev&
   msm_accumulate_phase<Fq2>(main, st_ab, buf_b2, pk.b2_q);
   k2.c.ev_valid[1] = true;
   DG_HIP(hipEventRecord(ev[2], main));
-  DG_HIP(hipStreamWaitEvent(side2, ev[2], 0));
-  msm_bucket_phase<Fq2>(side2, st_ab, buf_b2, false, res_b2);
-  hipLaunchKernelGGL(prover_stage1_g2_kernel<Fq2>, dim3(1), dim3(64), 0, side2, res_b2, fixed_g2, first_shard);
-  DG_HIP(hipEventRecord(ev[5], side2));
+  auto b_reduction = [&] {
+    DG_HIP(hipStreamWaitEvent(side2, ev[2], 0));
+    if (!(exp_bits & 1u)) msm_bucket_phase<Fq2>(side2, st_ab, buf_b2, false, res_b2);
+    hipLaunchKernelGGL(prover_stage1_g2_kernel<Fq2>, dim3(1), dim3(64), 0, side2, res_b2, fixed_g2, first_shard);
+    DG_HIP(hipEventRecord(ev[5], side2));
+  };
+  if (!(exp_bits & 4u)) b_reduction();
   if (dist) {
     const void* in1[1] = {xbuf_b};
     DG_HIP(hipStreamWaitEvent(main, ev[4], 0));
@@ -279,6 +287,13 @@ static void msms_typed(dg16_ctx* ctx, Call& k0, Call& k1, Call& k2, const PkDev&
   // streams (A's and L's on `side`, B1's on `aux` followed by the two serial scalar multiples s*A', r*B1').
   static_assert(kRecA == 0 && kRecB1 == 1 && kRecL == 2, "the three-instance reduction writes rec[0..2] back to back");
   static const bool merged = [] { const char* e = getenv("DG16_ABL_MERGED"); return e && atoi(e) != 0; }();
+  // DG16_EXP bit 16 (with DG16_MAIN2=1 at context creation and GPU_MAX_HW_QUEUES >= 5 in the environment): a SECOND lane
+  // of saturating kernels on a stream of LOWER priority than `main` -- the accumulations of B1 and H go there, those of
+  // B, A and L stay on main.  Kernels of one stream run strictly one after another, so every accumulation launch ends
+  // in a ramp-down with the chip half empty (a workgroup lives ~0.3 ms, a launch ~1.3 ms); the low-priority lane's
+  // workgroups are dispatched exactly when main has none left to dispatch, i.e. into those ramps.
+  const bool two_lane = (exp_bits & 16u) && !dist && !merged;
+  hipStream_t lane2 = two_lane ? ctx->aux[1] : main;
   if (merged) {
     MsmBuffers<Fq> buf_abl = msm_buffers<Fq>(k0.c, st_ab.g, 3);
     const void* abl_tables[3] = {pk.a_q, pk.b1_q, pk.l_q};
@@ -288,9 +303,10 @@ static void msms_typed(dg16_ctx* ctx, Call& k0, Call& k1, Call& k2, const PkDev&
     k1.c.ev_valid[1] = true;
     DG_HIP(hipEventRecord(ev[0], main));
     DG_HIP(hipStreamWaitEvent(side, ev[0], 0));
-    msm_bucket_phase<Fq>(side, st_ab, buf_abl, false, rec);
-    hipLaunchKernelGGL((prover_stage1_g1_kernel<Fq, Fr>), dim3(2), dim3(64), 0, side, rec, fixed_g1, r_s, (int)mont,
-                       first_shard);
+    if (!(exp_bits & 2u)) msm_bucket_phase<Fq>(side, st_ab, buf_abl, false, rec);
+    if (!(exp_bits & 10u))
+      hipLaunchKernelGGL((prover_stage1_g1_kernel<Fq, Fr>), dim3(2), dim3(64), 0, side, rec, fixed_g1, r_s, (int)mont,
+                         first_shard);
     DG_HIP(hipEventRecord(ev[10], side));
   } else {
     MsmBuffers<Fq> buf_a = msm_buffers<Fq>(k0.c, st_ab.g);
@@ -301,21 +317,23 @@ static void msms_typed(dg16_ctx* ctx, Call& k0, Call& k1, Call& k2, const PkDev&
     DG_HIP(hipEventRecord(k1.c.ev[3], main));
     k1.c.ev_valid[1] = true;
     DG_HIP(hipEventRecord(ev[0], main));
-    msm_accumulate_phase<Fq>(main, st_ab, buf_b1, pk.b1_q);
-    DG_HIP(hipEventRecord(ev[1], main));
+    if (two_lane) DG_HIP(hipStreamWaitEvent(lane2, ev[13], 0));      // the shared sort
+    msm_accumulate_phase<Fq>(lane2, st_ab, buf_b1, pk.b1_q);
+    DG_HIP(hipEventRecord(ev[1], lane2));
     msm_accumulate_phase<Fq>(main, st_ab, buf_l, pk.l_q);
     DG_HIP(hipEventRecord(ev[6], main));
     DG_HIP(hipStreamWaitEvent(side, ev[0], 0));
-    msm_bucket_phase<Fq>(side, st_ab, buf_a, false, rec + kRecA);
+    if (!(exp_bits & 2u)) msm_bucket_phase<Fq>(side, st_ab, buf_a, false, rec + kRecA);
     DG_HIP(hipEventRecord(ev[12], side));
     DG_HIP(hipStreamWaitEvent(xch, ev[1], 0));
-    msm_bucket_phase<Fq>(xch, st_ab, buf_b1, false, rec + kRecB1);
+    if (!(exp_bits & 2u)) msm_bucket_phase<Fq>(xch, st_ab, buf_b1, false, rec + kRecB1);
     DG_HIP(hipStreamWaitEvent(xch, ev[12], 0));
-    hipLaunchKernelGGL((prover_stage1_g1_kernel<Fq, Fr>), dim3(2), dim3(64), 0, xch, rec, fixed_g1, r_s, (int)mont,
-                       first_shard);
+    if (!(exp_bits & 10u))
+      hipLaunchKernelGGL((prover_stage1_g1_kernel<Fq, Fr>), dim3(2), dim3(64), 0, xch, rec, fixed_g1, r_s, (int)mont,
+                         first_shard);
     DG_HIP(hipEventRecord(ev[7], xch));
     DG_HIP(hipStreamWaitEvent(side, ev[6], 0));
-    msm_bucket_phase<Fq>(side, st_ab, buf_l, false, rec + kRecL);
+    if (!(exp_bits & 2u)) msm_bucket_phase<Fq>(side, st_ab, buf_l, false, rec + kRecL);
     DG_HIP(hipStreamWaitEvent(side, ev[7], 0));
     DG_HIP(hipEventRecord(ev[10], side));             // A, B1, L, s*A', r*B1' all done
   }
@@ -327,11 +345,19 @@ static void msms_typed(dg16_ctx* ctx, Call& k0, Call& k1, Call& k2, const PkDev&
     h_poly_dist_stage(k0, CURVE, log_m, rank, n_ranks, 2, in2, h_dev);
     st_h = msm_sort_on<Fr, CT::SCALAR_BITS>(main, k0.c, h_dev, n_h, true, true, pk.c_h, pk.stride);
   } else {
-    DG_HIP(hipStreamWaitEvent(main, ev[15], 0));
+    DG_HIP(hipStreamWaitEvent(lane2, ev[15], 0));
   }
   MsmBuffers<Fq> buf_h = msm_buffers<Fq>(ctx->xws[0], st_h.g);
-  msm_accumulate_phase<Fq>(main, st_h, buf_h, pk.h_q);
-  msm_bucket_phase<Fq>(main, st_h, buf_h, false, res_h);
+  msm_accumulate_phase<Fq>(lane2, st_h, buf_h, pk.h_q);
+  if (exp_bits & 4u) {
+    DG_HIP(hipEventRecord(ev[2], lane2));      // (re-recorded: B's accumulation is long done; the wait is on H's)
+    b_reduction();
+  }
+  msm_bucket_phase<Fq>(lane2, st_h, buf_h, false, res_h);
+  if (two_lane) {
+    DG_HIP(hipEventRecord(ev[16], lane2));
+    DG_HIP(hipStreamWaitEvent(main, ev[16], 0));
+  }
   DG_HIP(hipStreamWaitEvent(main, ev[10], 0));          // A, B1, L results, s*A, r*B1
   DG_HIP(hipStreamWaitEvent(main, ev[5], 0));           // B result
   DG_HIP(hipGetLastError());

@@ -7,9 +7,19 @@
 // a gather to the king is n - 1 concurrent link transfers, an all-to-all uses all seven links of every GPU), ordered
 // on the HIP stream the payload was produced on.  Nothing here synchronises the host.
 //
+// ONE COMMUNICATOR PER CHANNEL.  MpcNet's three MultiplexedStreamIDs (mpc-net/src/lib.rs:29-33) are independent
+// streams: prove::C joins three d_msm on them (groth16/src/prove.rs:113-125) and the library's dg16_prove_c drives them
+// from three host threads whose interleaving differs from party to party.  NCCL matches the point-to-point calls of
+// one communicator in issue order and allows one host thread at a time per communicator -- so channel c owns
+// communicator c (the first is formed by ncclCommInitRank and also serves the dg16_comm collectives, the other two are
+// ncclCommSplit duplicates of it; a librccl without ncclCommSplit gets two fresh ids broadcast over the first), every
+// call holds that communicator's mutex while it enqueues, and a payload of channel 1 can never meet a receive of
+// channel 0 whatever the thread schedule is.
+//
 // librccl is bound at run time: a process that has torch loaded already holds torch's copy (same soname) and gets
 // that one; a plain C consumer gets /opt/rocm's.  Linking it would make every libdg16 user load RCCL.
 #include <dlfcn.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <mutex>
@@ -37,6 +47,8 @@ struct Api {
   ncclResult_t (*Send)(const void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*Recv)(void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*AllGather)(const void*, void*, size_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Broadcast)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*CommSplit)(ncclComm_t, int, int, ncclComm_t*, void*) = nullptr;     // optional (NCCL >= 2.18)
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
   std::string why;
 };
@@ -72,6 +84,8 @@ Api& api() {
     a.Send = (decltype(a.Send))sym("ncclSend");
     a.Recv = (decltype(a.Recv))sym("ncclRecv");
     a.AllGather = (decltype(a.AllGather))sym("ncclAllGather");
+    a.Broadcast = (decltype(a.Broadcast))sym("ncclBroadcast");
+    a.CommSplit = (decltype(a.CommSplit))dlsym(a.lib, "ncclCommSplit");
     a.GetErrorString = (decltype(a.GetErrorString))sym("ncclGetErrorString");
   });
   return a;
@@ -88,9 +102,13 @@ bool api_ok() {
 
 }  // namespace
 
+constexpr int kChannels = 3;      // MultiplexedStreamID::{Zero, One, Two}
+
 struct dg16_rccl {
   dg16_ctx* ctx = nullptr;
-  ncclComm_t comm = nullptr;
+  ncclComm_t comm[kChannels] = {nullptr, nullptr, nullptr};   // [c]: channel c; [0] also: the dg16_comm collectives
+  std::mutex mu[kChannels];                                   // one enqueuing host thread per communicator
+  bool split = false;                                         // channels 1, 2 made by ncclCommSplit (else: fresh ids)
   unsigned n = 0, me = 0;
   dg16_comm comm_vt{};
   dg16_net net_vt{};
@@ -105,25 +123,46 @@ namespace {
 
 unsigned rc_n(void* self) { return ((dg16_rccl*)self)->n; }
 unsigned rc_me(void* self) { return ((dg16_rccl*)self)->me; }
-int rc_is_init(void* self) { return ((dg16_rccl*)self)->comm != nullptr; }
+int rc_is_init(void* self) {
+  auto* h = (dg16_rccl*)self;
+  return h->comm[0] && h->comm[1] && h->comm[2];
+}
+
+// The enqueue of one call on one communicator: the device of the context, the communicator's mutex (NCCL allows one
+// host thread at a time per communicator; the lock covers the enqueue only -- completion is stream-ordered).
+struct Enq {
+  dg16_rccl* h;
+  ncclComm_t comm;
+  std::unique_lock<std::mutex> lock;
+  bool dev_ok;
+  Enq(dg16_rccl* h_, int channel) : h(h_), comm(h_->comm[channel]), lock(h_->mu[channel]) {
+    dev_ok = hipSetDevice(h->ctx->device) == hipSuccess;
+  }
+};
+bool channel_ok(int channel) {
+  if (channel >= 0 && channel < kChannels) return true;
+  g_err = "channel must be 0, 1 or 2 (MultiplexedStreamID)";
+  return false;
+}
 
 int rc_all_gather(void* self, const void* send, size_t bytes, void* recv, void* stream) {
-  auto* h = (dg16_rccl*)self;
-  if (hipSetDevice(h->ctx->device) != hipSuccess) return DG16_ERR_HIP;
-  return h->check(api().AllGather(send, recv, bytes, kNcclInt8, h->comm, (hipStream_t)stream), "ncclAllGather")
+  Enq e((dg16_rccl*)self, 0);
+  if (!e.dev_ok) return DG16_ERR_HIP;
+  return e.h->check(api().AllGather(send, recv, bytes, kNcclInt8, e.comm, (hipStream_t)stream), "ncclAllGather")
              ? DG16_OK
              : DG16_ERR_NET;
 }
 
 int rc_all_to_all(void* self, const void* send, void* recv, size_t bytes_per_peer, void* stream) {
-  auto* h = (dg16_rccl*)self;
+  Enq e((dg16_rccl*)self, 0);
+  auto* h = e.h;
   Api& a = api();
-  if (hipSetDevice(h->ctx->device) != hipSuccess) return DG16_ERR_HIP;
+  if (!e.dev_ok) return DG16_ERR_HIP;
   bool ok = h->check(a.GroupStart(), "ncclGroupStart");
   for (unsigned p = 0; ok && p < h->n; p++) {
-    ok = h->check(a.Send((const uint8_t*)send + p * bytes_per_peer, bytes_per_peer, kNcclInt8, (int)p, h->comm,
+    ok = h->check(a.Send((const uint8_t*)send + p * bytes_per_peer, bytes_per_peer, kNcclInt8, (int)p, e.comm,
                          (hipStream_t)stream), "ncclSend") &&
-         h->check(a.Recv((uint8_t*)recv + p * bytes_per_peer, bytes_per_peer, kNcclInt8, (int)p, h->comm,
+         h->check(a.Recv((uint8_t*)recv + p * bytes_per_peer, bytes_per_peer, kNcclInt8, (int)p, e.comm,
                          (hipStream_t)stream), "ncclRecv");
   }
   // the group is always closed, also after a failed call inside it (an open group would swallow later collectives)
@@ -132,50 +171,102 @@ int rc_all_to_all(void* self, const void* send, void* recv, size_t bytes_per_pee
 }
 
 // client_send_or_king_receive (mpc-net/src/lib.rs:61-99): n - 1 sends meet n - 1 receives on the king; the king's
-// own block is a device copy on the same stream.  `channel` needs no tag: calls on one communicator are matched
-// in issue order, and every party issues the collectives of a protocol in the same order.
-int rc_gather(void* self, int, const void* send, size_t bytes, void* recv, void* stream) {
-  auto* h = (dg16_rccl*)self;
+// own block is a device copy on the same stream.  The calls of `channel` go to that channel's communicator: within it
+// every party issues the collectives of a protocol in the same order (the d_* functions are straight-line code per
+// channel), so issue-order matching is exact; across channels nothing is shared.
+int rc_gather(void* self, int channel, const void* send, size_t bytes, void* recv, void* stream) {
+  if (!channel_ok(channel)) return DG16_ERR_BAD_ARG;
+  Enq e((dg16_rccl*)self, channel);
+  auto* h = e.h;
   Api& a = api();
   hipStream_t s = (hipStream_t)stream;
-  if (hipSetDevice(h->ctx->device) != hipSuccess) return DG16_ERR_HIP;
-  if (h->me != 0) return h->check(a.Send(send, bytes, kNcclInt8, 0, h->comm, s), "ncclSend") ? DG16_OK : DG16_ERR_NET;
+  if (!e.dev_ok) return DG16_ERR_HIP;
+  if (h->me != 0) return h->check(a.Send(send, bytes, kNcclInt8, 0, e.comm, s), "ncclSend") ? DG16_OK : DG16_ERR_NET;
   if (hipMemcpyAsync(recv, send, bytes, hipMemcpyDeviceToDevice, s) != hipSuccess) return DG16_ERR_HIP;
   bool ok = h->check(a.GroupStart(), "ncclGroupStart");
   for (unsigned p = 1; ok && p < h->n; p++)
-    ok = h->check(a.Recv((uint8_t*)recv + p * bytes, bytes, kNcclInt8, (int)p, h->comm, s), "ncclRecv");
+    ok = h->check(a.Recv((uint8_t*)recv + p * bytes, bytes, kNcclInt8, (int)p, e.comm, s), "ncclRecv");
   const bool closed = h->check(a.GroupEnd(), "ncclGroupEnd");
   return ok && closed ? DG16_OK : DG16_ERR_NET;
 }
 
 // client_receive_or_king_send (mpc-net/src/lib.rs:102-140)
-int rc_scatter(void* self, int, const void* send, size_t bytes, void* recv, void* stream) {
-  auto* h = (dg16_rccl*)self;
+int rc_scatter(void* self, int channel, const void* send, size_t bytes, void* recv, void* stream) {
+  if (!channel_ok(channel)) return DG16_ERR_BAD_ARG;
+  Enq e((dg16_rccl*)self, channel);
+  auto* h = e.h;
   Api& a = api();
   hipStream_t s = (hipStream_t)stream;
-  if (hipSetDevice(h->ctx->device) != hipSuccess) return DG16_ERR_HIP;
-  if (h->me != 0) return h->check(a.Recv(recv, bytes, kNcclInt8, 0, h->comm, s), "ncclRecv") ? DG16_OK : DG16_ERR_NET;
+  if (!e.dev_ok) return DG16_ERR_HIP;
+  if (h->me != 0) return h->check(a.Recv(recv, bytes, kNcclInt8, 0, e.comm, s), "ncclRecv") ? DG16_OK : DG16_ERR_NET;
   if (hipMemcpyAsync(recv, send, bytes, hipMemcpyDeviceToDevice, s) != hipSuccess) return DG16_ERR_HIP;
   bool ok = h->check(a.GroupStart(), "ncclGroupStart");
   for (unsigned p = 1; ok && p < h->n; p++)
-    ok = h->check(a.Send((const uint8_t*)send + p * bytes, bytes, kNcclInt8, (int)p, h->comm, s), "ncclSend");
+    ok = h->check(a.Send((const uint8_t*)send + p * bytes, bytes, kNcclInt8, (int)p, e.comm, s), "ncclSend");
   const bool closed = h->check(a.GroupEnd(), "ncclGroupEnd");
   return ok && closed ? DG16_OK : DG16_ERR_NET;
 }
 
-int rc_send_to(void* self, unsigned peer, int, const void* send, size_t bytes, void* stream) {
+int rc_send_to(void* self, unsigned peer, int channel, const void* send, size_t bytes, void* stream) {
   auto* h = (dg16_rccl*)self;
-  if (peer >= h->n || peer == h->me) return DG16_ERR_BAD_ARG;
-  if (hipSetDevice(h->ctx->device) != hipSuccess) return DG16_ERR_HIP;
-  return h->check(api().Send(send, bytes, kNcclInt8, (int)peer, h->comm, (hipStream_t)stream), "ncclSend") ? DG16_OK
-                                                                                                            : DG16_ERR_NET;
+  if (peer >= h->n || peer == h->me || !channel_ok(channel)) return DG16_ERR_BAD_ARG;
+  Enq e(h, channel);
+  if (!e.dev_ok) return DG16_ERR_HIP;
+  return h->check(api().Send(send, bytes, kNcclInt8, (int)peer, e.comm, (hipStream_t)stream), "ncclSend") ? DG16_OK
+                                                                                                           : DG16_ERR_NET;
 }
-int rc_recv_from(void* self, unsigned peer, int, void* recv, size_t bytes, void* stream) {
+int rc_recv_from(void* self, unsigned peer, int channel, void* recv, size_t bytes, void* stream) {
   auto* h = (dg16_rccl*)self;
-  if (peer >= h->n || peer == h->me) return DG16_ERR_BAD_ARG;
-  if (hipSetDevice(h->ctx->device) != hipSuccess) return DG16_ERR_HIP;
-  return h->check(api().Recv(recv, bytes, kNcclInt8, (int)peer, h->comm, (hipStream_t)stream), "ncclRecv") ? DG16_OK
-                                                                                                            : DG16_ERR_NET;
+  if (peer >= h->n || peer == h->me || !channel_ok(channel)) return DG16_ERR_BAD_ARG;
+  Enq e(h, channel);
+  if (!e.dev_ok) return DG16_ERR_HIP;
+  return h->check(api().Recv(recv, bytes, kNcclInt8, (int)peer, e.comm, (hipStream_t)stream), "ncclRecv") ? DG16_OK
+                                                                                                           : DG16_ERR_NET;
+}
+
+// Communicators of channels 1 and 2.  ncclCommSplit(color 0, key = rank) duplicates the first communicator (a
+// collective over it, no out-of-band exchange).  Without that entry point (or with DG16_RCCL_NO_SPLIT=1, which the
+// tests use to run this branch): rank 0 makes two fresh ids, broadcasts them over the first communicator and every
+// rank joins them with ncclCommInitRank.
+bool make_channel_comms(dg16_rccl* h) {
+  Api& a = api();
+  const char* no_split = getenv("DG16_RCCL_NO_SPLIT");
+  if (a.CommSplit && !(no_split && no_split[0] == '1')) {
+    for (int c = 1; c < kChannels; c++)
+      if (!h->check(a.CommSplit(h->comm[0], 0, (int)h->me, &h->comm[c], nullptr), "ncclCommSplit")) return false;
+    h->split = true;
+    return true;
+  }
+  constexpr size_t kIds = (kChannels - 1) * sizeof(ncclUniqueId);
+  ncclUniqueId ids[kChannels - 1];
+  if (h->me == 0)
+    for (auto& id : ids)
+      if (!h->check(a.GetUniqueId(&id), "ncclGetUniqueId")) return false;
+  void* dbuf = nullptr;
+  if (hipMalloc(&dbuf, kIds) != hipSuccess) {
+    g_err = "hipMalloc (channel ids)";
+    return false;
+  }
+  bool ok = hipMemcpy(dbuf, ids, kIds, hipMemcpyHostToDevice) == hipSuccess &&
+            h->check(a.Broadcast(dbuf, dbuf, kIds, kNcclInt8, 0, h->comm[0], (hipStream_t) nullptr), "ncclBroadcast") &&
+            hipStreamSynchronize(nullptr) == hipSuccess && hipMemcpy(ids, dbuf, kIds, hipMemcpyDeviceToHost) == hipSuccess;
+  hipFree(dbuf);
+  if (!ok) {
+    if (g_err.empty()) g_err = "broadcast of the channel ids failed";
+    return false;
+  }
+  for (int c = 1; c < kChannels; c++)
+    if (!h->check(a.CommInitRank(&h->comm[c], (int)h->n, ids[c - 1], (int)h->me), "ncclCommInitRank (channel)"))
+      return false;
+  return true;
+}
+
+void destroy_comms(dg16_rccl* h) {
+  for (int c = kChannels - 1; c >= 0; c--)
+    if (h->comm[c]) {
+      api().CommDestroy(h->comm[c]);
+      h->comm[c] = nullptr;
+    }
 }
 
 }  // namespace
@@ -208,7 +299,9 @@ int dg16_rccl_create(dg16_ctx* ctx, const void* unique_id128, unsigned n_ranks, 
   h->me = rank;
   ncclUniqueId id;
   memcpy(id.internal, unique_id128, sizeof(id.internal));
-  if (!h->check(api().CommInitRank(&h->comm, (int)n_ranks, id, (int)rank), "ncclCommInitRank")) {
+  if (!h->check(api().CommInitRank(&h->comm[0], (int)n_ranks, id, (int)rank), "ncclCommInitRank") ||
+      !make_channel_comms(h)) {
+    destroy_comms(h);
     delete h;
     return DG16_ERR_NET;
   }
@@ -218,28 +311,40 @@ int dg16_rccl_create(dg16_ctx* ctx, const void* unique_id128, unsigned n_ranks, 
   return DG16_OK;
 }
 
-// what the COMMUNICATOR reports (ncclCommCount / ncclCommUserRank), not what the caller asked for
+// what the COMMUNICATORS report (ncclCommCount / ncclCommUserRank), not what the caller asked for: all three must agree
 int dg16_rccl_ranks(dg16_rccl* h, unsigned* n_ranks, unsigned* rank) {
-  if (!h || !h->comm) return DG16_ERR_BAD_ARG;
-  int n = 0, me = 0;
-  if (!h->check(api().CommCount(h->comm, &n), "ncclCommCount") ||
-      !h->check(api().CommUserRank(h->comm, &me), "ncclCommUserRank"))
-    return DG16_ERR_NET;
-  if (n_ranks) *n_ranks = (unsigned)n;
-  if (rank) *rank = (unsigned)me;
+  if (!h || !h->comm[0]) return DG16_ERR_BAD_ARG;
+  int n0 = 0, me0 = 0;
+  for (int c = 0; c < kChannels; c++) {
+    int n = 0, me = 0;
+    if (!h->comm[c] || !h->check(api().CommCount(h->comm[c], &n), "ncclCommCount") ||
+        !h->check(api().CommUserRank(h->comm[c], &me), "ncclCommUserRank"))
+      return DG16_ERR_NET;
+    if (c == 0) {
+      n0 = n;
+      me0 = me;
+    } else if (n != n0 || me != me0) {
+      g_err = "channel communicators disagree on the rank layout";
+      return DG16_ERR_NET;
+    }
+  }
+  if (n_ranks) *n_ranks = (unsigned)n0;
+  if (rank) *rank = (unsigned)me0;
   return DG16_OK;
 }
+
+/* 1 if channels 1 and 2 are ncclCommSplit duplicates of the first communicator, 0 if they were joined through fresh
+ * broadcast ids */
+int dg16_rccl_channels_split(dg16_rccl* h) { return h && h->split ? 1 : 0; }
 
 const dg16_comm* dg16_rccl_comm(dg16_rccl* h) { return h ? &h->comm_vt : nullptr; }
 const dg16_net* dg16_rccl_net(dg16_rccl* h) { return h ? &h->net_vt : nullptr; }
 
 void dg16_rccl_destroy(dg16_rccl* h) {
   if (!h) return;
-  if (h->comm) {
-    hipSetDevice(h->ctx->device);
-    hipDeviceSynchronize();
-    api().CommDestroy(h->comm);
-  }
+  hipSetDevice(h->ctx->device);
+  hipDeviceSynchronize();
+  destroy_comms(h);
   delete h;
 }
 

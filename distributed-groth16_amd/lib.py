@@ -173,6 +173,8 @@ def load():
     L.dg16_rccl_unique_id.argtypes = [vp]
     L.dg16_rccl_create.argtypes = [vp, vp, u, u, ctypes.POINTER(vp)]
     L.dg16_rccl_ranks.argtypes = [vp, ctypes.POINTER(u), ctypes.POINTER(u)]
+    if hasattr(L, "dg16_rccl_channels_split"):          # (absent from A/B builds made before round 4: DG16_LIB)
+        L.dg16_rccl_channels_split.argtypes = [vp]
     L.dg16_rccl_comm.argtypes = [vp]
     L.dg16_rccl_comm.restype = vp
     L.dg16_rccl_net.argtypes = [vp]
@@ -239,6 +241,7 @@ EXPORTED = ["dg16_ctx_create", "dg16_ctx_destroy", "dg16_last_error", "dg16_set_
             "dg16_d_msm", "dg16_deg_red", "dg16_d_pp", "dg16_ext_wit_h", "dg16_qap", "dg16_qap_rows",
             "dg16_h_poly_dist", "dg16_h_poly_dist_stage", "dg16_ntt_dist", "dg16_ntt_dist_stage", "dg16_groth16_msms_h", "dg16_groth16_prove_dist",
             "dg16_rccl_unique_id", "dg16_rccl_create", "dg16_rccl_comm", "dg16_rccl_net", "dg16_rccl_destroy", "dg16_rccl_ranks",
+            "dg16_rccl_channels_split",
             "dg16_rccl_error", "dg16_bases_upload", "dg16_bases_free", "dg16_bases_info", "dg16_msm_resident",
             "dg16_d_msm_resident", "dg16_codec_error", "dg16_arkkey_layout", "dg16_points_compress",
             "dg16_points_decompress", "dg16_wire_fr_bytes", "dg16_wire_fr_encode", "dg16_wire_fr_decode",
@@ -758,3 +761,100 @@ class TorchComm:
             else:
                 self.dist.all_to_all_single(dst, src)
         return self._run(stream, fn)
+
+
+class TorchNet:
+    """dg16_net (the MpcNet vtable: mpc-net/src/lib.rs:36-140) implemented by the caller with torch.distributed, one
+    process per party, king = rank 0.  ONE PROCESS GROUP PER CHANNEL: the three MultiplexedStreamIDs
+    (mpc-net/src/lib.rs:29-33) are independent streams and dg16_prove_c drives them from three host threads at once
+    (groth16/src/prove.rs:113-125), in an order that differs from party to party -- a collective of channel c is only
+    ever matched against the peers' collectives of channel c.  `nccl` groups stay stream-ordered, `gloo` groups stage
+    through host memory (several parties can then share ONE GPU: the multi-process tests).  `before` (optional):
+    called as before(channel, op) ahead of every exchange -- the tests inject per-channel delays there."""
+
+    def __init__(self, dist, device, n_parties, party_id, before=None):
+        import torch
+        self.torch, self.dist, self.device = torch, dist, device
+        self.n, self.me, self.before = n_parties, party_id, before
+        self.on_host = torch.device(device).type == "cpu"
+        self.backend = dist.get_backend()
+        ranks = list(range(n_parties))
+        self.groups = [dist.new_group(ranks=ranks, backend=self.backend) for _ in range(3)]   # collective: all ranks
+        self.errors = []
+        self._cb = (_COMM_N(lambda _s: n_parties), _COMM_N(lambda _s: party_id), _NET_COLL(self._gather),
+                    _NET_COLL(self._scatter), ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p)(lambda _s: 1),
+                    _NET_P2P(self._send_to), _NET_P2P(self._recv_from))
+        self.struct = NetStruct(None, *self._cb)
+        self.net_ptr = ctypes.cast(ctypes.pointer(self.struct), ctypes.c_void_p)
+
+    def describe(self):
+        return "torch.distributed (%s), one process group per channel" % self.backend
+
+    def _tensor(self, ptr, nbytes):
+        if self.on_host:      # host buffers (the transport's own CPU tests: no GPU involved)
+            return self.torch.frombuffer((ctypes.c_uint8 * nbytes).from_address(int(ptr)), dtype=self.torch.uint8)
+        return TorchComm._tensor(self, ptr, nbytes)
+
+    def _run(self, channel, op, stream, fn):
+        torch = self.torch
+        try:
+            if not 0 <= channel < 3:
+                raise ValueError("channel must be 0, 1 or 2")
+            if self.before is not None:
+                self.before(channel, op)
+            if self.on_host:
+                fn(True, self.groups[channel])
+                return 0
+            ext = torch.cuda.ExternalStream(int(stream), device=self.device) if stream else None
+            if self.backend == "nccl" and ext is not None:
+                with torch.cuda.stream(ext):
+                    fn(False, self.groups[channel])
+            else:
+                (ext.synchronize() if ext is not None else torch.cuda.synchronize(self.device))
+                fn(True, self.groups[channel])
+                torch.cuda.synchronize(self.device)
+            return 0
+        except Exception as e:                       # never let an exception cross the C ABI
+            self.errors.append("channel %d %s: %r" % (channel, op, e))
+            return 6
+
+    def _gather(self, _s, channel, send, nbytes, recv, stream):          # client_send_or_king_receive, lib.rs:61-99
+        def fn(host, group):
+            src = self._tensor(send, nbytes)
+            src = src.cpu() if host else src
+            if self.me == 0:
+                parts = [self.torch.empty_like(src) for _ in range(self.n)]
+                self.dist.gather(src, gather_list=parts, dst=0, group=group)
+                self._tensor(recv, nbytes * self.n).copy_(self.torch.cat(parts))
+            else:
+                self.dist.gather(src, dst=0, group=group)
+        return self._run(channel, "gather", stream, fn)
+
+    def _scatter(self, _s, channel, send, nbytes, recv, stream):         # client_receive_or_king_send, lib.rs:102-140
+        def fn(host, group):
+            dst = self._tensor(recv, nbytes)
+            out = self.torch.empty(nbytes, dtype=self.torch.uint8) if host else dst
+            if self.me == 0:
+                allbuf = self._tensor(send, nbytes * self.n)
+                allbuf = allbuf.cpu() if host else allbuf
+                self.dist.scatter(out, scatter_list=list(allbuf.view(self.n, nbytes).unbind(0)), src=0, group=group)
+            else:
+                self.dist.scatter(out, src=0, group=group)
+            if host:
+                dst.copy_(out)
+        return self._run(channel, "scatter", stream, fn)
+
+    def _send_to(self, _s, peer, channel, send, nbytes, stream):
+        def fn(host, group):
+            src = self._tensor(send, nbytes)
+            self.dist.send(src.cpu() if host else src, dst=peer, group=group)
+        return self._run(channel, "send_to", stream, fn)
+
+    def _recv_from(self, _s, peer, channel, recv, nbytes, stream):
+        def fn(host, group):
+            dst = self._tensor(recv, nbytes)
+            out = self.torch.empty(nbytes, dtype=self.torch.uint8) if host else dst
+            self.dist.recv(out, src=peer, group=group)
+            if host:
+                dst.copy_(out)
+        return self._run(channel, "recv_from", stream, fn)

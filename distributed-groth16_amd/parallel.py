@@ -193,6 +193,26 @@ class NativeProver:
         return proof
 
 
+def rccl_precondition(ctx, rank):
+    """(host, device identity, error or None) of this rank: what the ranks compare before they form a communicator."""
+    import socket
+    from . import lib
+    err = None
+    try:
+        lib.rccl_unique_id()          # binds librccl in this process (the id itself is discarded)
+    except lib.Dg16Error as e:
+        err = "rank %d: %s" % (rank, e)
+    ident = ctx.device
+    try:
+        import torch
+        p = torch.cuda.get_device_properties(ctx.device)
+        ident = str(getattr(p, "uuid", None) or (getattr(p, "pci_domain_id", 0), getattr(p, "pci_bus_id", ctx.device),
+                                                 getattr(p, "pci_device_id", 0)))
+    except Exception:                 # no torch device view (CPU tests): the index is all there is
+        pass
+    return socket.gethostname(), ident, err
+
+
 def make_prover(ctx, pk, curve, dist, rank, world, transport="rccl"):
     """The prover bench.py and the tools drive.  N = 1 is the plain resident-key prover behind the same interface.
     transport: "rccl" (native communicator; the unique id travels through torch.distributed's object broadcast),
@@ -219,6 +239,19 @@ def make_prover(ctx, pk, curve, dist, rank, world, transport="rccl"):
                 box[0] = "error: %s" % e
         dist.broadcast_object_list(box, src=0)
         why = box[0] if isinstance(box[0], str) else None
+        # Preconditions are checked TOGETHER before anyone enters ncclCommInitRank: that call blocks until every rank has
+        # joined, so a rank that failed it alone (librccl missing there, two ranks on one device) would leave its peers
+        # inside it while it moved on to the all-reduce below.  Failures that only show inside ncclCommInitRank on some
+        # ranks (a link going down mid-join) are not recoverable here: the join itself has no timeout.
+        pre = [None] * world
+        dist.all_gather_object(pre, rccl_precondition(ctx, rank))
+        if why is None:
+            bad = [p[2] for p in pre if p[2]]
+            ids = [p[:2] for p in pre]
+            if bad:
+                why = bad[0]
+            elif len(set(ids)) != world:
+                why = "two ranks share one device (%s): RCCL needs one GPU per rank" % (ids,)
         if why is None:
             try:
                 comm = lib.RcclComm(ctx, box[0], world, rank)

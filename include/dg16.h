@@ -66,8 +66,11 @@ enum dg16_flags {
   DG16_F_SCALARS_MONT = 1u, /* scalars are in Montgomery form (arkworks memory) */
   DG16_F_DEVICE_PTRS = 2u,  /* all data pointers are device pointers */
   DG16_F_OUT_AFFINE = 4u,   /* group result as affine x || y (one inversion on the device) */
-  DG16_F_H_CYCLIC = 8u      /* dg16_pk_create_shard: this shard's h_query bases are h_query[shard + n_shards * j]
+  DG16_F_H_CYCLIC = 8u,     /* dg16_pk_create_shard: this shard's h_query bases are h_query[shard + n_shards * j]
                                (the output layout of the sharded h-polynomial) instead of a contiguous slice */
+  DG16_F_SERIAL_CHANNELS = 16u /* dg16_prove_c: run the three d_msm one after another (channel 0, 1, 2 in that order
+                               on every party) instead of joined from three host threads -- for a dg16_net whose
+                               channels are not independent (one ordered pipe); the result is the same */
 };
 
 /* field ids for dg16_field_op: curve for the base field Fq, 16 + curve for the scalar field Fr */
@@ -284,16 +287,22 @@ int dg16_groth16_prove_dist(dg16_ctx *ctx, const dg16_pk *pk, const dg16_comm *c
 
 /* Native RCCL transport.  Rank 0 makes the 128-byte id (dg16_rccl_unique_id) and hands it to the other ranks out
  * of band (the launcher's rendezvous); every rank then calls dg16_rccl_create on its own context (blocking until all
- * ranks have joined).  dg16_rccl_comm serves dg16_h_poly_dist / dg16_groth16_prove_dist; dg16_rccl_net is the same
- * communicator behind the MpcNet vtable below (king = rank 0), so that d_fft / d_msm / d_pp / ext_wit::h run one
- * party per GPU.  librccl is bound at run time (dlopen): without it these return DG16_ERR_UNSUPPORTED and the rest
- * of the library is unaffected. */
+ * ranks have joined).  dg16_rccl_comm serves dg16_h_poly_dist / dg16_groth16_prove_dist; dg16_rccl_net is the MpcNet
+ * vtable below (king = rank 0), so that d_fft / d_msm / d_pp / ext_wit::h / prove::A,B,C run one party per GPU.
+ * The handle holds THREE communicators, one per MultiplexedStreamID (mpc-net/src/lib.rs:29-33): channel c of the
+ * vtable only ever touches communicator c, under that communicator's mutex, so the three d_msm that prove::C joins
+ * (groth16/src/prove.rs:113-125; dg16_prove_c drives them from three host threads) cannot meet each other's
+ * payloads whatever order the threads run in on each party.  Communicator 0 also carries the dg16_comm collectives.
+ * Channels 1 and 2 are ncclCommSplit duplicates of the first communicator (dg16_rccl_channels_split() == 1) or, on a
+ * librccl without that entry point, joined through two fresh ids broadcast over it.  librccl is bound at run time
+ * (dlopen): without it these return DG16_ERR_UNSUPPORTED and the rest of the library is unaffected. */
 typedef struct dg16_rccl dg16_rccl;
 struct dg16_net;
 int dg16_rccl_unique_id(void *out128);
 int dg16_rccl_create(dg16_ctx *ctx, const void *unique_id128, unsigned n_ranks, unsigned rank, dg16_rccl **out);
 /* rank count and this rank's index as the communicator itself reports them (ncclCommCount / ncclCommUserRank) */
 int dg16_rccl_ranks(dg16_rccl *h, unsigned *n_ranks, unsigned *rank);
+int dg16_rccl_channels_split(dg16_rccl *h);
 const dg16_comm *dg16_rccl_comm(dg16_rccl *h);
 const struct dg16_net *dg16_rccl_net(dg16_rccl *h);
 void dg16_rccl_destroy(dg16_rccl *h);

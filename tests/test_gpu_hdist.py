@@ -254,6 +254,48 @@ def test_native_rccl_comm_world_size_one():
     comm.close()
 
 
+@pytest.mark.parametrize("no_split", [False, True])
+def test_rccl_net_one_communicator_per_channel_world_one(no_split, monkeypatch):
+    """dg16_rccl_net holds one communicator per MultiplexedStreamID (mpc-net/src/lib.rs:29-33), made by ncclCommSplit or
+    -- DG16_RCCL_NO_SPLIT=1, the branch for a librccl without it -- joined through two ids broadcast over the first.
+    Three host threads drive the three channels at once (what dg16_prove_c does, prove.rs:113-125); a fourth channel
+    is refused."""
+    from dg16_amd import lib
+    monkeypatch.setenv("DG16_RCCL_NO_SPLIT", "1" if no_split else "0")
+    c = ctx()
+    comm = lib.RcclComm(c, lib.rccl_unique_id(), 1, 0)
+    assert c.L.dg16_rccl_channels_split(comm.h) == (0 if no_split else 1)
+    assert comm.ranks() == (1, 0)                       # all three communicators agree
+    net = ctypes.cast(comm.net_ptr, ctypes.POINTER(lib.NetStruct)).contents
+    assert net.is_init(net.self) == 1
+    srcs = [torch.full((4096,), 100 + ch, dtype=torch.int64, device=DEV) for ch in range(3)]
+    mids = [torch.zeros(4096, dtype=torch.int64, device=DEV) for _ in range(3)]
+    dsts = [torch.zeros(4096, dtype=torch.int64, device=DEV) for _ in range(3)]
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    torch.cuda.synchronize()
+    rcs = [None] * 3
+
+    def drive(ch):
+        st = streams[ch].cuda_stream
+        out = []
+        for _ in range(8):
+            out.append(net.gather_to_king(net.self, ch, srcs[ch].data_ptr(), 4096 * 8, mids[ch].data_ptr(), st))
+            out.append(net.scatter_from_king(net.self, ch, mids[ch].data_ptr(), 4096 * 8, dsts[ch].data_ptr(), st))
+        streams[ch].synchronize()
+        rcs[ch] = out
+
+    ts = [threading.Thread(target=drive, args=(ch,)) for ch in (2, 0, 1)]
+    [t.start() for t in ts]
+    [t.join(120) for t in ts]
+    assert rcs == [[0] * 16] * 3
+    for ch in range(3):
+        assert torch.equal(dsts[ch], srcs[ch])
+    st = torch.cuda.current_stream().cuda_stream
+    assert net.gather_to_king(net.self, 3, srcs[0].data_ptr(), 64, mids[0].data_ptr(), st) == 3      # DG16_ERR_BAD_ARG
+    assert net.send_to(net.self, 0, 1, srcs[0].data_ptr(), 64, st) == 3                              # peer == me
+    comm.close()
+
+
 def test_prove_dist_through_rccl_world_one_equals_prove():
     import bench
     from dg16_amd import lib

@@ -60,3 +60,18 @@ def test_bench_flow_with_two_ranks_on_one_device(transport):
     assert d["valu_roofline"]["frac"] <= 1.0 and d["valu_roofline"]["whole_proof_valu_frac"] <= 1.0
     if transport == "rccl":
         assert "native RCCL transport unavailable" in out.stderr
+
+
+@pytest.mark.parametrize("parties,l,mode", [(4, 1, "joined"), (4, 1, "serial"), (8, 2, "joined")])
+def test_mpc_parties_as_processes_with_adversarial_channel_order(parties, l, mode):
+    """ext_wit::h, prove::A / B / C::compute with ONE PROCESS PER PARTY over a multi-process dg16_net (lib.TorchNet: one
+    gloo process group per MultiplexedStreamID) whose channels are delayed in a different order on every party, while
+    dg16_prove_c issues its three d_msm from three host threads (prove.rs:113-125): the proof elements equal the
+    oracle's.  'serial' = DG16_F_SERIAL_CHANNELS (the three d_msm one after another, for a transport with one pipe)."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(parties),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "tests", "mpc_rank_check.py"), str(l), "6", "40"] + (["serial"] if mode == "serial" else [])
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=280)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert "MPC_RANK_CHECK PASS" in out.stdout

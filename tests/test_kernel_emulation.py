@@ -266,9 +266,10 @@ def test_g1_accumulation_workgroup_with_the_bucket_tree():
 
 
 def test_g2_finalize_workgroup():
-    """msm_finalize_lds_kernel<Fp2<bn254>, 256, 2> (the throughput finalize behind the G2 accumulation: two lanes per
-    bucket, each adding its share of the bucket's partial sums into an accumulator in LDS columns -- XYZZ29::add_into
-    with the four-product Y3 --, then one tree step across the two lanes behind a barrier) on the Workgroup emulator:
+    """msm_finalize_lds_kernel<Fp2<bn254>, 256> with two lanes per bucket (the throughput finalize behind the G2
+    accumulation: each lane adds its share of the bucket's partial sums into an accumulator in LDS columns --
+    XYZZ29::add_into with the four-product Y3, ONE addition site for the serial partials and the tree partners --, then
+    one tree step across the two lanes behind a barrier) on the Workgroup emulator:
     buckets with 5, 2, 1 and 0 partials, partials in XYZZ form with Z != 1 -> the buckets the oracle's sums predict."""
     import random
     from oracle.pyref.curves import CURVES
@@ -277,7 +278,7 @@ def test_g2_finalize_workgroup():
     p = F2.p
     n_limbs, w = limb_shape(p)
     R = 1 << (w * n_limbs)
-    prog = E.Program(assembly("bn254", 2), "msm_finalize_lds_kernelINS_3Fp2INS_2FpINS_15bn254_fq_paramsEEEEELi256ELi2E")
+    prog = E.Program(assembly("bn254", 2), "msm_finalize_lds_kernelINS_3Fp2INS_2FpINS_15bn254_fq_paramsEEEEELi256EE")
     CNTS, SOFF, SSUM, BUCK, GCNT, GLIST, KARG = (0x100000 * k for k in range(1, 8))
     wg = E.Workgroup(prog, 256, wg_id=(0, 0), kernarg_addr=KARG)
     mem = wg.mem
@@ -321,6 +322,7 @@ def test_g2_finalize_workgroup():
     put64(0x20, 64)                                                # region
     put64(0x28, 16)                                                # total buckets
     karg[0x30 // 4] = 0                                            # wg_log: one slot per segment (no tree in the G2 accumulation)
+    karg[0x34 // 4] = 1                                            # lpb_log: two lanes per bucket
     for k, base in enumerate([CNTS, SOFF, SSUM, BUCK, GCNT, GLIST]):
         put64(0x38 + 8 * k, base)
     karg[0x68 // 4] = 16                                           # giant_cap

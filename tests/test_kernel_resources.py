@@ -43,7 +43,7 @@ def test_g2_bucket_accumulation_stages_through_lds_without_spilling():
     assert r["scratch"] == 0 and r["agprs"] == 0 and r["lds"] == 4 * 28 * 128 * 4
     # the throughput finalize of G2 (two lanes per bucket, add_into with the four-product Y3): two waves per SIMD, and
     # since the products are chains neither scratch (BN254: was 16 B) nor a full AGPR file + scratch (BLS12-377)
-    for k, r in find("msm_finalize_lds_kernel<Fp2<bn254_fq>,256,").items():
+    for k, r in find("msm_finalize_lds_kernel<Fp2<bn254_fq>,256>").items():
         assert r["occupancy"] == 2 and r["scratch"] == 0 and r["agprs"] == 0, k
     for k, r in find("msm_finalize_lds_kernel<Fp2<bls12_").items():
         assert r["scratch"] == 0 and r["agprs"] <= 128, k

@@ -243,8 +243,9 @@ def test_make_prover_picks_the_driver_by_rank_count():
 
 
 def _fallback_worker(rank, world, port, q, failure):
-    """One rank of the transport decision: `failure` = 'id' (rank 0 cannot make the RCCL id) or 'join' (rank 1 cannot
-    join the communicator).  Every rank must come out with the SAME transport, and a collective issued afterwards must
+    """One rank of the transport decision: `failure` = 'id' (rank 0 cannot make the RCCL id), 'join' (rank 1 fails
+    inside the join, promptly), 'load1' (librccl is missing on rank 1 only) or 'samedev' (both ranks sit on one device) --
+    the last two are preconditions the ranks compare BEFORE anyone enters the blocking join.  Every rank must come out with the SAME transport, and a collective issued afterwards must
     still match up across the ranks (the round-2 code left rank 0 on torch and rank 1 inside the broadcast)."""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group(backend="gloo", rank=rank, world_size=world)
@@ -252,13 +253,15 @@ def _fallback_worker(rank, world, port, q, failure):
         from dg16_amd import lib, parallel as P
 
         class Ctx:
-            device = 0
+            device = 0 if failure == "samedev" else rank      # (no torch device here: the index is the identity)
 
         class Pk:
             domain_size = 1 << 10
 
         class FakeRccl:
             def __init__(self, ctx, uid, n, r):
+                # a precondition failure must keep EVERY rank out of the (blocking) join
+                assert failure not in ("load1", "samedev"), "ncclCommInitRank entered although a precondition failed"
                 if failure == "join" and r == 1:
                     raise lib.Dg16Error(6, "ncclCommInitRank: unhandled system error (simulated)")
                 self.closed = False
@@ -270,7 +273,7 @@ def _fallback_worker(rank, world, port, q, failure):
                 self.closed = True
 
         def fake_id():
-            if failure == "id":
+            if failure == "id" or (failure == "load1" and rank == 1):
                 raise lib.Dg16Error(7, "librccl not found (simulated)")
             return b"\0" * 128
 
@@ -284,7 +287,7 @@ def _fallback_worker(rank, world, port, q, failure):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("failure", ["id", "join", "none"])
+@pytest.mark.parametrize("failure", ["id", "join", "load1", "samedev", "none"])
 def test_rccl_fallback_is_a_collective_decision(failure):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -297,3 +300,85 @@ def test_rccl_fallback_is_a_collective_decision(failure):
         p.join(timeout=60)
     want = "FakeRccl" if failure == "none" else "TorchComm"
     assert res == [(0, want, 3), (1, want, 3)]
+
+
+def _torchnet_worker(rank, world, port, q):
+    """One party of three concurrent 'protocols', one per channel, each a gather to the king followed by a scatter from
+    it (the shape of d_msm's exchange, dmsm/mod.rs:88-97), driven from three host threads whose per-channel delays are
+    ordered differently on every party -- all payloads have the same size, so a cross-matched channel would not fail,
+    it would deliver another channel's bytes."""
+    import ctypes
+    import threading
+    import time
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    try:
+        from dg16_amd import lib
+        rng = random.Random(1000 + rank)
+        lock = threading.Lock()
+
+        def before(channel, op):
+            with lock:
+                d = rng.uniform(0.0, 0.02) + 0.03 * ((channel + rank) % 3)     # the slow channel differs per party
+            time.sleep(d)
+
+        net = lib.TorchNet(dist, torch.device("cpu"), world, rank, before=before)
+        vt = net.struct
+        nbytes = 96
+        ok = [True] * 3
+
+        def protocol(c):
+            for it in range(4):
+                send = np.full(nbytes, 16 * c + rank + 64 * it, dtype=np.uint8)
+                gathered = np.zeros(nbytes * world, dtype=np.uint8)
+                rc = vt.gather_to_king(None, c, send.ctypes.data, nbytes, gathered.ctypes.data if rank == 0 else None,
+                                       None)
+                if rank == 0:
+                    want = np.concatenate([np.full(nbytes, 16 * c + p + 64 * it, dtype=np.uint8) for p in range(world)])
+                    ok[c] &= rc == 0 and np.array_equal(gathered, want)
+                    back = np.concatenate([np.full(nbytes, 200 - 16 * c - p - it, dtype=np.uint8) for p in range(world)])
+                else:
+                    ok[c] &= rc == 0
+                    back = None
+                got = np.zeros(nbytes, dtype=np.uint8)
+                rc = vt.scatter_from_king(None, c, back.ctypes.data if rank == 0 else None, nbytes, got.ctypes.data, None)
+                ok[c] &= rc == 0 and bool((got == 200 - 16 * c - rank - it).all())
+            # MpcNet's required pair on the same channel: a ring
+            nxt, prv = (rank + 1) % world, (rank - 1) % world
+            mine = np.full(nbytes, 7 * c + rank, dtype=np.uint8)
+            got = np.zeros(nbytes, dtype=np.uint8)
+            if rank == 0:
+                a = vt.send_to(None, nxt, c, mine.ctypes.data, nbytes, None)
+                b = vt.recv_from(None, prv, c, got.ctypes.data, nbytes, None)
+            else:
+                b = vt.recv_from(None, prv, c, got.ctypes.data, nbytes, None)
+                a = vt.send_to(None, nxt, c, mine.ctypes.data, nbytes, None)
+            ok[c] &= a == 0 and b == 0 and bool((got == 7 * c + prv).all())
+
+        order = [(rank + i) % 3 for i in range(3)]            # thread start order differs per party as well
+        ths = [threading.Thread(target=protocol, args=(c,)) for c in order]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join(100)
+        bad = vt.gather_to_king(None, 3, None, 0, None, None)      # not a MultiplexedStreamID
+        q.put((rank, all(ok), net.errors[:-1], bad))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_torchnet_channels_are_independent():
+    """lib.TorchNet (the caller-side MpcNet vtable over torch.distributed): one process group per MultiplexedStreamID
+    (mpc-net/src/lib.rs:29-33).  Three parties x three channels, all in flight at once, each party completing its
+    channels in a different order: every payload arrives on its own channel."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    world = 3
+    procs = [ctx.Process(target=_torchnet_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert res == [(r, True, [], 6) for r in range(world)]

@@ -16,10 +16,10 @@ one scalar source), everything else VGPRs.  No instruction in a statement reads 
 statement writes except the accumulator (v_mad_u64_u32 -> v_mad_u64_u32 / v_lshrrev_b64 on the same pair needs no wait
 state on gfx950: hipcc itself emits them back to back).
 
-A second form of every sequence, `mont_asmw_*` (built with -DDG29_ASM_WHOLE; an A/B candidate, not the default): the WHOLE
-product as one statement, so that no s_nop is needed inside it.  m[k] = (lo(acc) INV) & MASK needs the low half of the
-accumulator pair by name, which an asm operand cannot give; the accumulator and the m[k] therefore live in FIXED
-caller-saved registers outside the argument range (v32-v39, v48-v55: clobbers of the statement).
+(Measured and removed in round 4: every product as ONE statement with the accumulator and the m[k] in fixed registers,
+so that no s_nop is needed inside it -- 10.89-10.98 ms per 2^20 BN254 proof against 10.76-10.79 for this form, same box,
+same call: the fixed registers cost the allocator more than the ~170 s_nop per addition cost the scalar issue port;
+profiles/r4a_ab_variants.md.)
 
 Kinds: `mul` a b, `dual` a b + c d, `quad` a b + c d + e f + g h (one reduction each), `sqr` a^2 with the doubled
 operand.  Shapes: (N, W) = (9, 29) for the 254 / 255 / 253-bit fields, (14, 28) for the 377 / 381-bit ones.
@@ -139,64 +139,6 @@ def gen_function(kind, n, w):
     return out
 
 
-TEMP_REGS = list(range(32, 40)) + list(range(48, 56))     # caller-saved, not argument registers (AMDGPU calling convention)
-
-
-def gen_function_whole(kind, n, w):
-    """The same arithmetic as gen_function in ONE asm statement: accumulator v[32:33], m[k] in the registers after it."""
-    npair = {"mul": 1, "dual": 2, "quad": 4, "sqr": 1}[kind]
-    args = ", ".join("const uint32_t* %s" % nm for pr in PAIR_NAMES[:npair] for nm in pr) if kind != "sqr" else "const uint32_t* a"
-    assert n + 2 <= len(TEMP_REGS)
-    acc = "v[%d:%d]" % (TEMP_REGS[0], TEMP_REGS[1])
-    acc_lo = "v%d" % TEMP_REGS[0]
-    mreg = ["v%d" % TEMP_REGS[2 + i] for i in range(n)]
-    mask = "0x%x" % ((1 << w) - 1)
-    ops, index = [], {}
-
-    def operand(constraint, expr):
-        key = (constraint, expr)
-        if key not in index:
-            index[key] = len(ops)
-            ops.append(key)
-        return "%%%d" % index[key]
-
-    outs = [operand("=&v", "r[%d]" % i) for i in range(n)]       # operands 0 .. n-1
-    lines = []
-    first = True
-    for k in range(2 * n - 1):
-        if 1 <= k <= n:
-            lines.append("v_mad_u64_u32 %s, vcc, %s, %s, %s" % (acc, mreg[k - 1], operand("s", "T::PL.v[0]"), acc))
-        if k >= 1:
-            lines.append("v_lshrrev_b64 %s, %d, %s" % (acc, w, acc))
-        for x, y in column_terms(kind, n, k):
-            lines.append("v_mad_u64_u32 %s, vcc, %s, %s, %s" % (acc, operand("v", x), operand("v", y), "0" if first else acc))
-            first = False
-        for i, j in reduction_terms(n, k):
-            lines.append("v_mad_u64_u32 %s, vcc, %s, %s, %s" % (acc, mreg[i], operand("s", "T::PL.v[%d]" % j), acc))
-        if k < n:
-            lines.append("v_mul_lo_u32 %s, %s, %s" % (mreg[k], acc_lo, operand("s", "T::INV")))
-            lines.append("v_and_b32 %s, %s, %s" % (mreg[k], mask, mreg[k]))
-        else:
-            lines.append("v_and_b32 %s, %s, %s" % (outs[k - n], mask, acc_lo))
-    lines.append("v_lshrrev_b64 %s, %d, %s" % (acc, w, acc))
-    lines.append("v_mov_b32 %s, %s" % (outs[n - 1], acc_lo))
-    out = []
-    out.append("template <class P>")
-    out.append("__device__ __forceinline__ void mont_asmw_%s_%d(uint32_t* __restrict__ r, %s) {" % (kind, n, args))
-    out.append("  using T = RR<P>;")
-    out.append('  static_assert(T::N == %d && T::W == %d, "limb shape of this instruction sequence");' % (n, w))
-    if kind == "sqr":
-        out.append("  uint32_t a2[%d];" % n)
-        out.append("#pragma unroll")
-        out.append("  for (int i = 0; i < %d; i++) a2[i] = a[i] << 1;" % n)
-    out.append('  asm("%s"' % "\\n\\t".join(lines).replace("\\\\", "\\"))
-    out.append("      : %s" % ", ".join('"%s"(%s)' % (c, e) for c, e in ops if c == "=&v"))
-    out.append("      : %s" % ", ".join('"%s"(%s)' % (c, e) for c, e in ops if c != "=&v"))
-    out.append("      : %s);" % ", ".join(['"vcc"'] + ['"v%d"' % t for t in TEMP_REGS[:n + 2]]))
-    out.append("}")
-    return out
-
-
 def generate():
     out = []
     out.append("// GENERATED by tools/gen_fp29_asm.py -- do not edit (tests/test_fp29_asm_isa.py checks that it is current).")
@@ -208,22 +150,6 @@ def generate():
     for n, w in SHAPES:
         for kind in ("mul", "dual", "quad", "sqr"):
             out.extend(gen_function(kind, n, w))
-            out.append("")
-    out.append("// ---- whole-product statements (-DDG29_ASM_WHOLE): accumulator and m[k] in fixed registers, no s_nop inside ----")
-    for n, w in SHAPES:
-        for kind in ("mul", "dual", "quad", "sqr"):
-            if (kind, n) == ("quad", 14):
-                # 112 input registers + 14 early-clobber outputs + 16 fixed temporaries in one statement: hipcc's register
-                # allocator does not terminate on it (and no kernel fuses four 14-limb products): the column form serves
-                out.append("template <class P>")
-                out.append("__device__ __forceinline__ void mont_asmw_quad_14(uint32_t* __restrict__ r, const uint32_t* a, "
-                           "const uint32_t* b, const uint32_t* c, const uint32_t* d, const uint32_t* e, const uint32_t* f, "
-                           "const uint32_t* g, const uint32_t* h) {")
-                out.append("  mont_asm_quad_14<P>(r, a, b, c, d, e, f, g, h);")
-                out.append("}")
-                out.append("")
-                continue
-            out.extend(gen_function_whole(kind, n, w))
             out.append("")
     out.append("}  // namespace rr")
     out.append("}  // namespace dg16")

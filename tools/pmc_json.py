@@ -1,0 +1,28 @@
+"""pmc_raw.txt (tools/pmc_sum.py lines of the FETCH_SIZE and WRITE_SIZE passes) -> the JSON bench.py reads
+`roofline.traffic` from.  usage: python tools/pmc_json.py pmc_raw.txt <tag>"""
+import json
+import sys
+
+raw = {}
+for ln in open(sys.argv[1]):
+    f = ln.split()
+    if len(f) == 6 and f[2] == "launches":
+        raw.setdefault(f[1], {})[f[0]] = {"launches": int(f[3]), "KB_per_launch": float(f[5])}
+g2 = raw.get("msm_accumulate_lds_kernel", {})
+fetch = g2.get("FETCH_SIZE", {}).get("KB_per_launch", 0.0)
+write = g2.get("WRITE_SIZE", {}).get("KB_per_launch", 0.0)
+print(json.dumps({
+    "tag": sys.argv[2] if len(sys.argv) > 2 else "",
+    "kernel": "msm_accumulate_lds_kernel<Fp2<bn254_fq>>",
+    "workload": "BN254 Groth16 proof at 2^20 (tools/shard_timing.py 20 3 bn254 1): the G2 bucket accumulation in table "
+                "mode (c = 17, 15 windows, 1 048 578 points, balanced segments of <= 16 entries)",
+    "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE (separate passes) --output-format csv -- "
+               "python tools/shard_timing.py 20 3 bn254 1; tools/pmc_sum.py (tools/evidence_run.sh)",
+    "correction": "gfx950: FETCH_SIZE x2 for this kernel's 128-byte point gathers (the guide: requests are tallied at "
+                  "64 B); WRITE_SIZE taken as is; KB = 1024 B",
+    "FETCH_SIZE_KB_raw_per_launch": fetch,
+    "WRITE_SIZE_KB_raw_per_launch": write,
+    "traffic_bytes_per_launch": (2 * fetch + write) * 1024,
+    "launches": g2.get("FETCH_SIZE", {}).get("launches", 0),
+    "other_kernels_raw": {k: v for k, v in raw.items() if k != "msm_accumulate_lds_kernel"},
+}, indent=1))
