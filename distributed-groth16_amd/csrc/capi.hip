@@ -112,7 +112,8 @@ void dg16_ctx_destroy(dg16_ctx* ctx) {
     if (kv.second.hi_scaled) hipFree(kv.second.hi_scaled);
     hipFree(kv.second.small);
     hipFree(kv.second.n_inv);
-    for (void* q : {kv.second.lo_i, kv.second.hi_i, kv.second.hi_scaled_i, kv.second.small_i, kv.second.n_inv_i})
+    for (void* q : {kv.second.lo_i, kv.second.hi_i, kv.second.hi_scaled_i, kv.second.small_i, kv.second.n_inv_i,
+                    kv.second.full[0], kv.second.full[1], kv.second.shift_full})
       if (q) hipFree(q);
   }
   delete ctx;

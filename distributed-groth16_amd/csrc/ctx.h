@@ -48,6 +48,10 @@ struct TwiddleSet {   // all device pointers, 32-byte Fr elements
   // the same tables in the reduced-radix Montgomery form of fp29.h (x R, R = 2^261; packed, canonical): what the
   // NTT kernels multiply by -- the arkworks-form tables above serve the dist-primitives mirror (dist_impl.h)
   void *lo_i = nullptr, *hi_i = nullptr, *hi_scaled_i = nullptr, *small_i = nullptr, *n_inv_i = nullptr;
+  // the inter-step twiddles of the first / second step of a multi-step plan as ONE table each, in the step's data layout
+  // (ntt.hip: full_twiddle_kernel), and w^o for o < n / 2 flattened (the w_2m shift of the h-polynomial); null = not built
+  void* full[2] = {nullptr, nullptr};
+  void* shift_full = nullptr;
 };
 
 }  // namespace dg16

@@ -1010,6 +1010,117 @@ __device__ __forceinline__ XYZZ<F> scalar_mul_wave(const XYZZ<F>& p, const uint3
   return acc;
 }
 
+// ---- the same wave-cooperative operations on the reduced-radix types (XYZZ29, internal Montgomery form) -------------
+// The 32-bit forms above pay a 454-slot out-of-line product per dependency level (128 mads behind carry chains): 4.4 us
+// per doubling on a lone wave, 1.12 ms for the 240 doublings of a 2^20-point G1 Horner tail -- as long as the bucket
+// accumulation itself (profiles/r4b_msm_g1_2e20_kernel_stats.md).  Here a level is ONE 162-mad column-chain product
+// (fp29_asm_gen.h) per lane; coordinates stay below the storage bound BS p between levels (fit<BS>: a carry pass, or one
+// multiply-subtract pass where a sum exceeds it), so every slot's operand has the same static type.
+template <class P, int B>
+__device__ __forceinline__ Fe<P, B, 1> bcast29(const Fe<P, B, 1>& v, int src) {   // src: wave-uniform lane index
+  Fe<P, B, 1> r;
+#pragma unroll
+  for (int i = 0; i < RR<P>::N; i++) r.l[i] = (uint32_t)__builtin_amdgcn_readlane((int)v.l[i], src);
+  return r;
+}
+template <class P, int B>
+__device__ __forceinline__ Fe2<P, B, 1> bcast29(const Fe2<P, B, 1>& v, int src) {
+  return {bcast29(v.c0, src), bcast29(v.c1, src)};
+}
+template <class P, int B>
+__device__ __forceinline__ Fe<P, B, 1> lane_get29(const Fe<P, B, 1>& v, int src) {   // src: per-lane index
+  Fe<P, B, 1> r;
+#pragma unroll
+  for (int i = 0; i < RR<P>::N; i++) r.l[i] = (uint32_t)__shfl((int)v.l[i], src);
+  return r;
+}
+// product per slot (slot = lane / 4; operands equal across the quad); an Fq2 product is three base-field products on
+// three lanes of the quad (Karatsuba), joined with ds_bpermute
+template <class P, int B>
+__device__ __forceinline__ Fe<P, B, 1> slot_mul29(const Fe<P, B, 1>& a, const Fe<P, B, 1>& b) { return fit<B>(a * b); }
+template <class P, int B>
+__device__ __forceinline__ Fe2<P, B, 1> slot_mul29(const Fe2<P, B, 1>& a, const Fe2<P, B, 1>& b) {
+  constexpr int BETA = Fq2Beta<P>::value;
+  const unsigned q = __lane_id() & 3;
+  const Fe<P, B, 1> sa = fit<B>(a.c0 + a.c1), sb = fit<B>(b.c0 + b.c1);
+  const Fe<P, B, 1> x = select(q == 0, a.c0, select(q == 1, a.c1, sa));
+  const Fe<P, B, 1> y = select(q == 0, b.c0, select(q == 1, b.c1, sb));
+  const Fe<P, B, 1> t = fit<B>(x * y);
+  const int base = (int)(__lane_id() & ~3u);
+  const Fe<P, B, 1> t0 = lane_get29(t, base), t1 = lane_get29(t, base + 1), t2 = lane_get29(t, base + 2);
+  if constexpr (BETA == 1) return {fit<B>(t0 - t1), fit<B>(t2 - (t0 + t1))};          // u^2 = -BETA (fp2.h)
+  else return {fit<B>(t0 - mul_small<BETA>(t1)), fit<B>(t2 - (t0 + t1))};
+}
+// 2 p, p (and the result) uniform across the wave                       (dbl-2008-s-1, a = 0)
+template <class F>
+__device__ __forceinline__ XYZZ29<F> dbl_wave29(const XYZZ29<F>& p) {
+  constexpr int BS = XYZZ29<F>::BS;
+  if (p.is_inf()) return p;
+  const unsigned slot = __lane_id() >> 2;
+  const auto u = fit<BS>(dbl(p.y));
+  // level 1: v = u^2 | xx = x^2
+  const auto a1 = select(slot == 0, u, p.x);
+  const auto r1 = slot_mul29(a1, a1);
+  const auto v = bcast29(r1, 0), xx = bcast29(r1, 4);
+  const auto m = fit<BS>(dbl(xx) + xx);
+  // level 2: w = u v | s = x v | m^2 | zz' = v zz
+  const auto a2 = select(slot == 0, u, select(slot == 1, p.x, select(slot == 2, m, v)));
+  const auto b2 = select(slot <= 1, v, select(slot == 2, m, p.zz));
+  const auto r2 = slot_mul29(a2, b2);
+  const auto w = bcast29(r2, 0), sv = bcast29(r2, 4), mm = bcast29(r2, 8), zz3 = bcast29(r2, 12);
+  const auto x3 = fit<BS>(mm - dbl(sv));
+  // level 3: m (s - x3) | w y | zzz' = w zzz
+  const auto a3 = select(slot == 0, m, w);
+  const auto b3 = select(slot == 0, fit<BS>(sv - x3), select(slot == 1, p.y, p.zzz));
+  const auto r3 = slot_mul29(a3, b3);
+  const auto y3 = fit<BS>(bcast29(r3, 0) - bcast29(r3, 4));
+  return {x3, y3, zz3, bcast29(r3, 8)};
+}
+// p + o, both (and the result) uniform across the wave: 14 products in 4 levels       (add-2008-s)
+template <class F>
+__device__ __forceinline__ XYZZ29<F> add_wave29(const XYZZ29<F>& p, const XYZZ29<F>& o) {
+  constexpr int BS = XYZZ29<F>::BS;
+  if (o.is_inf()) return p;
+  if (p.is_inf()) return o;
+  const unsigned slot = __lane_id() >> 2;
+  // level 1: u1 = x1 zz2 | u2 = x2 zz1 | s1 = y1 zzz2 | s2 = y2 zzz1
+  const auto a1 = select(slot == 0, p.x, select(slot == 1, o.x, select(slot == 2, p.y, o.y)));
+  const auto b1 = select(slot == 0, o.zz, select(slot == 1, p.zz, select(slot == 2, o.zzz, p.zzz)));
+  const auto r1 = slot_mul29(a1, b1);
+  const auto u1 = bcast29(r1, 0), u2 = bcast29(r1, 4), s1 = bcast29(r1, 8), s2 = bcast29(r1, 12);
+  const auto pd = fit<BS>(u2 - u1), rd = fit<BS>(s2 - s1);
+  if (is_zero(pd)) {
+    if (is_zero(rd)) return dbl_wave29(p);
+    return XYZZ29<F>::inf();
+  }
+  // level 2: pp = p^2 | rr = r^2 | zz1 zz2 | zzz1 zzz2
+  const auto a2 = select(slot == 0, pd, select(slot == 1, rd, select(slot == 2, p.zz, p.zzz)));
+  const auto b2 = select(slot == 0, pd, select(slot == 1, rd, select(slot == 2, o.zz, o.zzz)));
+  const auto r2 = slot_mul29(a2, b2);
+  const auto pp = bcast29(r2, 0), rr = bcast29(r2, 4), zzp = bcast29(r2, 8), zzzp = bcast29(r2, 12);
+  // level 3: ppp = p pp | q = u1 pp | zz3 = (zz1 zz2) pp
+  const auto a3 = select(slot == 0, pd, select(slot == 1, u1, zzp));
+  const auto r3 = slot_mul29(a3, pp);
+  const auto ppp = bcast29(r3, 0), q = bcast29(r3, 4), zz3 = bcast29(r3, 8);
+  const auto x3 = fit<BS>(rr - (ppp + dbl(q)));
+  // level 4: r (q - x3) | s1 ppp | zzz3 = (zzz1 zzz2) ppp
+  const auto a4 = select(slot == 0, rd, select(slot == 1, s1, zzzp));
+  const auto b4 = select(slot == 0, fit<BS>(q - x3), ppp);
+  const auto r4 = slot_mul29(a4, b4);
+  return {x3, fit<BS>(bcast29(r4, 0) - bcast29(r4, 4)), zz3, bcast29(r4, 8)};
+}
+// k p by double-and-add on one wave; k = NW little-endian 32-bit words (plain integer), uniform
+template <class F, int NW>
+__device__ __forceinline__ XYZZ29<F> scalar_mul_wave29(const XYZZ29<F>& p, const uint32_t* k) {
+  XYZZ29<F> acc = XYZZ29<F>::inf();
+#pragma unroll 1
+  for (int i = NW * 32 - 1; i >= 0; i--) {
+    acc = dbl_wave29(acc);
+    if ((k[i / 32] >> (i % 32)) & 1) acc = add_wave29(acc, p);
+  }
+  return acc;
+}
+
 // rows of 2^kRowLog buckets
 constexpr unsigned kRowLog = 8;
 struct RowGeom {
@@ -1117,7 +1228,7 @@ struct MsmBuffers {
   XYZZ29<F>* row_w;
   XYZZ29<F>* row_r;
   XYZZ29<F>* fold;
-  XYZZ<F>* window_sums;
+  XYZZ29<F>* window_sums;    // internal form: the tail's wave-cooperative chain runs on the reduced-radix types
   unsigned* giant;
   unsigned giant_cap;
   size_t nbw, nrows;     // over all instances
@@ -1141,11 +1252,11 @@ MsmBuffers<F> msm_buffers(Channel& wsch, const MsmGeom& g, unsigned ninst = 1) {
   b.rg = row_geometry(g);
   b.nrows = bwi << b.rg.rows_log;
   const size_t nfold = bwi * 3 * 256;
-  uint8_t* p15 = (uint8_t*)ws(wsch, 15, (2 * b.nrows + nfold) * sizeof(XYZZ29<F>) + bwi * sizeof(XYZZ<F>));
+  uint8_t* p15 = (uint8_t*)ws(wsch, 15, (2 * b.nrows + nfold + bwi) * sizeof(XYZZ29<F>));
   b.row_w = (XYZZ29<F>*)p15;
   b.row_r = b.row_w + b.nrows;
   b.fold = b.row_r + b.nrows;
-  b.window_sums = (XYZZ<F>*)(b.fold + nfold);
+  b.window_sums = b.fold + nfold;
   // [0] giants, [1] work items, then giant_cap bucket ids, then <= 2 * giant_cap (giant, slice) work items
   b.giant = (unsigned*)ws(wsch, 10, ((size_t)b.giant_cap * 3 + 2) * 4);
   return b;

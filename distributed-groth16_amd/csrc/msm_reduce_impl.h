@@ -154,6 +154,74 @@ __global__ void __launch_bounds__(256) msm_row_kernel(MsmGeom g, RowGeom rg, con
   }
 }
 
+// Many rows (the plain MSM: one bucket set PER WINDOW, 2048 rows of 256 buckets at 2^20 points): msm_row_kernel's
+// suffix scan does 8 x 256 additions per row on lanes that are mostly switched off -- 3.8 M full additions per G1 MSM, a
+// third of the accumulation's work, 0.76 ms (G2: 3.3 ms of a 12-ms MSM; profiles/r4b_msm_g*_2e20_*).  Here a lane OWNS
+// 2^k consecutive buckets and runs the work-efficient serial form over them (run += B_i from the top, acc += run:
+// r_j = sum_i B_i, w_j = sum_i (i + 1) B_i; 2 additions per bucket), and the workgroup (LANES lanes = LANES 2^k buckets)
+// finishes with ONE suffix scan over the r_j and two trees side by side on the two halves of the lanes:
+//   bucket b = (sr LANES + j) 2^k + i:  sum (b + 1) B_b = sum_sr [ W1_sr + 2^k ( T_sr + LANES sr R_sr ) ],
+//   W1 = sum_j w_j,  R = sum_j r_j,  T = sum_j j r_j = sum_{u >= 1} suffix_u(r)
+// written as (W, run, local) = (W1, R, T) entries of `fold` for the top kernel's folded mode (per = LANES, final
+// doublings k).  2 x 2^k + 2 log2 LANES dependent steps on 1/2^k of the workgroups.
+template <class F, int LANES>
+__global__ void __launch_bounds__(LANES) msm_rowchunk_kernel(unsigned log_nb, unsigned k_log,
+                                                              const XYZZ29<F>* __restrict__ buckets,
+                                                              XYZZ29<F>* __restrict__ fold /* [bw][3][256]: W1, R, T */) {
+  __builtin_amdgcn_s_setprio(3);   // latency-bound chain: issue ahead of the accumulation waves sharing the SIMD
+  constexpr unsigned LL = LANES == 256 ? 8u : 7u;
+  static_assert(LANES == 256 || LANES == 128, "workgroup of 256 or 128 lanes");
+  __shared__ XYZZ29<F> s_r[LANES];      // run -> r_j -> suffix sums -> tree (T)
+  __shared__ XYZZ29<F> s_w[LANES];      // acc -> w_j -> tree (W1)
+  const unsigned j = threadIdx.x, K = 1u << k_log;
+  const XYZZ29<F>* B = buckets + ((size_t)blockIdx.y << log_nb) + (((size_t)blockIdx.x * LANES + j) << k_log);
+  XYZZ29<F>* out = fold + (size_t)blockIdx.y * 3 * 256;
+  s_r[j] = XYZZ29<F>::inf();
+  s_w[j] = XYZZ29<F>::inf();
+  __syncthreads();
+  const unsigned s_scan = 2 * K, s_tree = s_scan + LL, n_steps = s_tree + LL;
+#pragma unroll 1
+  for (unsigned step = 0; step < n_steps; step++) {
+    const XYZZ29<F>*a, *b;
+    XYZZ29<F>* dst;
+    bool on = true;
+    if (step < s_scan) {                       // even: run += B_i (i from the top); odd: acc += run
+      const bool even = (step & 1) == 0;
+      dst = even ? &s_r[j] : &s_w[j];
+      a = dst;
+      b = even ? &B[K - 1 - (step >> 1)] : &s_r[j];
+    } else if (step < s_tree) {                // inclusive suffix scan of the r_j
+      const unsigned d = 1u << (step - s_scan);
+      on = j + d < (unsigned)LANES;
+      dst = &s_r[j];
+      a = dst;
+      b = &s_r[(j + d) & (LANES - 1)];
+    } else {                                   // two trees at once: T on the low half of the lanes, W1 on the high half
+      if (step == s_tree) {
+        if (j == 0) {
+          out[1 * 256 + blockIdx.x] = s_r[0];  // R = suffix_0
+          s_r[0] = XYZZ29<F>::inf();           // weight j starts at 0: drop suffix_0
+        }
+        __syncthreads();
+      }
+      const unsigned d = (unsigned)LANES >> (step - s_tree + 1);
+      const unsigned c = j & (LANES / 2 - 1);
+      XYZZ29<F>* arr = j < LANES / 2 ? s_r : s_w;
+      on = c < d;
+      dst = &arr[c];
+      a = dst;
+      b = &arr[(c + d) & (LANES - 1)];
+    }
+    XYZZ29<F> v;
+    if (on) XYZZ29<F>::add_mem(&v, a, b);
+    __syncthreads();
+    if (on) *dst = v;
+    __syncthreads();
+  }
+  if (j == 0) out[2 * 256 + blockIdx.x] = s_r[0];
+  if (j == LANES / 2) out[0 * 256 + blockIdx.x] = s_w[0];
+}
+
 // Bucket-windows with more than 256 rows (tables with c >= 18): every lane of the top kernel owns `per` consecutive
 // rows; their plain sums (W: half 0, R: half 1) and, for R, the lane-local weighted sum sum_j j R_j, are taken here
 // (serial running sums: 2 per operations) so that the top kernel always starts from <= 256 entries per half.
@@ -189,19 +257,26 @@ __global__ void __launch_bounds__(64) msm_rowfold_kernel(RowGeom rg, const XYZZ2
 // the same time; HALVES = 1 (types whose 512 LDS slots exceed the 160 KiB: BLS12-381 G2): 256 lanes, one pass after
 // the other.  window sum = sum W + 2^row_log * sum r R, written in the 32-bit arkworks form the tail / the C ABI read.
 //   sum_r r R_r = sum_t local_t + per * sum_t t run_t,   sum_t t run_t = sum_{u >= 1} suffix_u(run)
+// What the top kernel sums (host side: top_geometry below).  Plain rows: `lanes` = rows per bucket-window, entries
+// (W_r, R_r) from row_w / row_r, total = sum W + 2^final_log sum r R.  Folded (msm_rowfold_kernel: > 256 rows; or
+// msm_rowchunk_kernel: lanes that own 2^k buckets each): entries (W_t, run_t, local_t) from `fold`,
+// sum_r r R_r = sum_t local_t + 2^per_log sum_t t run_t.
+struct TopGeom {
+  unsigned folded, per_log, lanes, final_log, rows_log;
+};
 template <class F, int HALVES>
-__global__ void __launch_bounds__(256 * HALVES) msm_top_kernel(RowGeom rg, const XYZZ29<F>* __restrict__ row_w,
+__global__ void __launch_bounds__(256 * HALVES) msm_top_kernel(TopGeom tg, const XYZZ29<F>* __restrict__ row_w,
                                                                 const XYZZ29<F>* __restrict__ row_r,
                                                                 const XYZZ29<F>* __restrict__ fold,
-                                                                XYZZ<F>* __restrict__ window_sums) {
+                                                                XYZZ29<F>* __restrict__ window_sums) {
   __builtin_amdgcn_s_setprio(3);   // latency-bound chain: issue ahead of the accumulation waves sharing the SIMD
   __shared__ XYZZ29<F> sh[256 * HALVES];
   __shared__ XYZZ29<F> keep;                       // HALVES == 1: sum W while the second pass runs
   const unsigned t = threadIdx.x & 255;
-  const bool folded = rg.rows_log > 8;
-  const unsigned per_log = folded ? rg.rows_log - 8 : 0;
-  const unsigned lanes = folded ? 256u : 1u << rg.rows_log;       // entries per half
-  const size_t base = (size_t)blockIdx.x << rg.rows_log;
+  const bool folded = tg.folded != 0;
+  const unsigned per_log = tg.per_log;
+  const unsigned lanes = tg.lanes;                                // entries per half
+  const size_t base = (size_t)blockIdx.x << tg.rows_log;
   const XYZZ29<F>* fb = fold + (size_t)blockIdx.x * 3 * 256;
   XYZZ29<F>* me = &sh[threadIdx.x];
 #pragma unroll 1
@@ -211,7 +286,7 @@ __global__ void __launch_bounds__(256 * HALVES) msm_top_kernel(RowGeom rg, const
     __syncthreads();
     // schedule: 8 scan steps (weighted half) | drop suffix_0 | per_log doublings | + local (folded) | 8 tree steps |
     // weighted half's lane 0 only: row_log doublings | + sum W  (total = sum W + 2^row_log * sum r R)
-    const unsigned s_tree = 9 + per_log, s_fin = s_tree + 8, n_steps = s_fin + rg.row_log + 1;
+    const unsigned s_tree = 9 + per_log, s_fin = s_tree + 8, n_steps = s_fin + tg.final_log + 1;
     const XYZZ29<F>* wsum = HALVES == 2 ? &sh[0] : &keep;
 #pragma unroll 1
     for (unsigned step = 0; step < n_steps; step++) {
@@ -226,15 +301,15 @@ __global__ void __launch_bounds__(256 * HALVES) msm_top_kernel(RowGeom rg, const
         on = half == 1;
         is_dbl = true;
       } else if (step == 8 + per_log) {
-        on = half == 1 && folded;
-        b = fb + 2 * 256 + t;
+        on = half == 1 && folded && t < lanes;     // (chunk mode fills only `lanes` entries of the fold array)
+        b = fb + 2 * 256 + (on ? t : 0);
       } else if (step < s_fin) {
         const unsigned stride = 128u >> (step - s_tree);
         on = t < stride;
         b = me + (on ? stride : 0);
       } else {
         on = half == 1 && t == 0;
-        is_dbl = step < s_fin + rg.row_log;
+        is_dbl = step < s_fin + tg.final_log;
         b = wsum;
       }
       if (step == 8 && half == 1 && t == 0) *me = XYZZ29<F>::inf();   // weight t starts at 0: drop suffix_0
@@ -251,7 +326,7 @@ __global__ void __launch_bounds__(256 * HALVES) msm_top_kernel(RowGeom rg, const
       __syncthreads();
     }
   }
-  if (threadIdx.x == (HALVES == 2 ? 256u : 0u)) window_sums[blockIdx.x] = sh[threadIdx.x].to_xyzz32();
+  if (threadIdx.x == (HALVES == 2 ? 256u : 0u)) window_sums[blockIdx.x] = sh[threadIdx.x];
 }
 
 // ---- 6: Horner tail ---------------------------------------------------------------------------------
@@ -259,29 +334,36 @@ __global__ void __launch_bounds__(256 * HALVES) msm_top_kernel(RowGeom rg, const
 // chain; the 9 multiplications of an XYZZ doubling form 3 dependency levels (2 | 4 | 3 products), each level
 // is evaluated by different lanes at once and shared with readlane.  An Fq2 product is itself spread over three
 // lanes of a quad (Karatsuba).  One thread per MSM took 2.5 ms (G1) / 10.2 ms (G2) for the 256 doublings of a
-// 2^20-point MSM, as long as the bucket accumulation itself.
+// 2^20-point MSM, as long as the bucket accumulation itself.  (Round 4: the chain runs on the reduced-radix types.)
 template <class F>
-__global__ void __launch_bounds__(64) msm_tail_kernel(const XYZZ<F>* __restrict__ window_sums, MsmGeom g,
+__global__ void __launch_bounds__(64) msm_tail_kernel(const XYZZ29<F>* __restrict__ window_sums, MsmGeom g,
                                                        int affine, F* __restrict__ out) {
   __builtin_amdgcn_s_setprio(3);   // latency-bound chain: issue ahead of the accumulation waves sharing the SIMD
-  // one wave per MSM instance (blockIdx.x), every lane carries the same running total
+  // one wave per MSM instance (blockIdx.x), every lane carries the same running total (internal form: dbl_wave29)
   window_sums += (size_t)blockIdx.x * g.bw;
   out += (size_t)blockIdx.x * (affine ? 2 : 3);
-  XYZZ<F> total = XYZZ<F>::inf();
+  XYZZ29<F> acc = XYZZ29<F>::inf();
+#pragma unroll 1
   for (int w = (int)g.bw - 1; w >= 0; w--) {
-    for (unsigned k = 0; k < g.c; k++) total = dbl_wave(total);
-    total = add_wave(total, window_sums[w]);
+#pragma unroll 1
+    for (unsigned k = 0; k < g.c; k++) acc = dbl_wave29(acc);
+    acc = add_wave29(acc, window_sums[w]);
   }
   if (threadIdx.x != 0) return;
+  using FO = FieldOf<F>;
   if (affine) {
-    Affine<F> a = total.to_affine();
+    Affine<F> a = acc.to_xyzz32().to_affine();
     out[0] = a.x;
     out[1] = a.y;
+  } else if (acc.is_inf()) {
+    out[0] = F::one();
+    out[1] = F::one();
+    out[2] = F::zero();
   } else {
-    Jacobian<F> j = total.to_jacobian();
-    out[0] = j.x;
-    out[1] = j.y;
-    out[2] = j.z;
+    // (X ZZ, Y ZZZ, ZZ) is the same point in Jacobian coordinates with Z = ZZ (ec.h: XYZZ::to_jacobian)
+    out[0] = FO::to32(fit<FO::BS>(acc.x * acc.zz));
+    out[1] = FO::to32(fit<FO::BS>(acc.y * acc.zzz));
+    out[2] = FO::to32(acc.zz);
   }
 }
 
@@ -324,13 +406,44 @@ void msm_bucket_phase(hipStream_t s, const MsmSort& st, const MsmBuffers<F>& b, 
   hipLaunchKernelGGL(msm_giant_fold_kernel<F>, dim3(64), dim3(64), 0, s, g, msm_acc_wg_log<F>(), st.counts, st.seg_off,
                      b.seg_sum, b.buckets, b.giant, b.giant + 2, b.giant_cap);
   trace_point(s, "giant + fold");
-  hipLaunchKernelGGL(msm_row_kernel<F>, dim3(1u << b.rg.rows_log, bwi), dim3(256), 0, s, g, b.rg, b.buckets, b.row_w,
-                     b.row_r);
-  trace_point(s, "row");
-  if (b.rg.rows_log > 8)
-    hipLaunchKernelGGL(msm_rowfold_kernel<F>, dim3(8, bwi), dim3(64), 0, s, b.rg, b.row_w, b.row_r, b.fold);
+  // many rows over all bucket-windows (plain MSMs): lanes that own 2^k buckets each (msm_rowchunk_kernel), k so that
+  // ~256 workgroups remain; few rows (one bucket set of a resident table): one lane per bucket, 16 steps
+  constexpr int CH_LANES = sizeof(XYZZ29<F>) * 2 * 256 <= 150 * 1024 ? 256 : 128;
+  constexpr unsigned CH_LL = CH_LANES == 256 ? 8u : 7u;
+  unsigned k_log = 0;
+  static const int chunk_force = [] { const char* e = getenv("DG16_ROW_CHUNK"); return e ? atoi(e) : -1; }();   // -1 auto, 0 off, 1..3 = k
+  if (b.rg.row_log == kRowLog && g.log_nb >= CH_LL + 1) {
+    const size_t total_rows = (size_t)bwi << b.rg.rows_log;
+    while (k_log < 3 && (total_rows >> (k_log + 1)) >= 256 && g.log_nb >= CH_LL + k_log + 1) k_log++;
+    if (total_rows < 1024) k_log = 0;
+    if (chunk_force >= 0) k_log = (unsigned)chunk_force <= g.log_nb - CH_LL ? (unsigned)chunk_force : g.log_nb - CH_LL;
+    if (k_log > 3) k_log = 3;
+  }
+  TopGeom tg{};
+  tg.rows_log = b.rg.rows_log;
+  tg.final_log = b.rg.row_log;
+  if (k_log) {
+    const unsigned nsr_log = g.log_nb - k_log - CH_LL;          // chunk workgroups per bucket-window (<= 256: log_nb <= 19)
+    DG_REQUIRE(nsr_log <= 8, DG16_ERR_UNSUPPORTED, "row chunks: more than 256 per bucket-window");
+    hipLaunchKernelGGL((msm_rowchunk_kernel<F, CH_LANES>), dim3(1u << nsr_log, bwi), dim3(CH_LANES), 0, s, g.log_nb, k_log,
+                       b.buckets, b.fold);
+    trace_point(s, "row (chunks)");
+    tg.folded = 1;
+    tg.per_log = CH_LL;
+    tg.lanes = 1u << nsr_log;
+    tg.final_log = k_log;
+  } else {
+    hipLaunchKernelGGL(msm_row_kernel<F>, dim3(1u << b.rg.rows_log, bwi), dim3(256), 0, s, g, b.rg, b.buckets, b.row_w,
+                       b.row_r);
+    trace_point(s, "row");
+    tg.folded = b.rg.rows_log > 8;
+    tg.per_log = tg.folded ? b.rg.rows_log - 8 : 0;
+    tg.lanes = tg.folded ? 256u : 1u << b.rg.rows_log;
+    if (b.rg.rows_log > 8)
+      hipLaunchKernelGGL(msm_rowfold_kernel<F>, dim3(8, bwi), dim3(64), 0, s, b.rg, b.row_w, b.row_r, b.fold);
+  }
   constexpr int HALVES = sizeof(XYZZ29<F>) * 513 <= 160 * 1024 ? 2 : 1;
-  hipLaunchKernelGGL((msm_top_kernel<F, HALVES>), dim3(bwi), dim3(256 * HALVES), 0, s, b.rg, b.row_w, b.row_r,
+  hipLaunchKernelGGL((msm_top_kernel<F, HALVES>), dim3(bwi), dim3(256 * HALVES), 0, s, tg, b.row_w, b.row_r,
                      b.fold, b.window_sums);
   trace_point(s, "top");
   hipLaunchKernelGGL(msm_tail_kernel<F>, dim3(b.ninst), dim3(64), 0, s, b.window_sums, g, (int)out_affine, (F*)out_dev);

@@ -41,6 +41,9 @@ struct StepArgs {
   const F* tw_lo;            // inter-step twiddles: w^e = lo[e & mask] * hi[e >> lb]
   const F* tw_hi;
   unsigned lb;
+  const F* tw_full;          // the same twiddles as ONE table in the step's own layout, [k][b] = w^((b k) << log_a) (times
+                             // n^-1 where tw_hi would carry it), or null: a 32-byte coalesced read instead of a product
+  const F* post_full;        // post_lo / post_hi as one table indexed by the output position, or null
   const F* pre_lo;           // optional: x[i] *= g^i on load (first step)
   const F* pre_hi;
   const F* post_lo;          // optional: out[o] *= g^o on store (last step)
@@ -270,7 +273,11 @@ __global__ void __launch_bounds__(256) ntt_step_kernel(StepArgs<F> p) {
     if (!p.last) {
       size_t b = b0 + t;
       size_t e = (b * k) << p.log_a;   // < N
-      if (e) {
+      if (p.tw_full) {
+        // (the table holds n^-1 at e == 0 when the step carries the scale, 1 otherwise: skipped then)
+        if (e || p.scale) out = canon(v * ld_packed(p.tw_full + (((size_t)k << p.log_b) + b)));
+        else out = canon(v);
+      } else if (e) {
         const auto w = ld_packed(p.tw_lo + (e & ((1u << p.lb) - 1))) * ld_packed(p.tw_hi + (e >> p.lb));
         out = canon(v * w);
       } else if (p.scale) {
@@ -282,7 +289,11 @@ __global__ void __launch_bounds__(256) ntt_step_kernel(StepArgs<F> p) {
       g = ((((a << s) + k) << p.log_b) + b);
     } else {
       g = (k1_0 + t) + (k2 << p.log_n1) + ((size_t)k << (p.log_n1 + p.log_n2));
-      if (p.scale && p.post_lo) {
+      if (p.post_full) {
+        const auto w = ld_packed(p.post_full + g);
+        if (p.scale) out = canon((v * ld_packed(p.scale)) * w);
+        else out = canon(v * w);
+      } else if (p.scale && p.post_lo) {
         const auto w = ld_packed(p.post_lo + (g & ((1u << p.plb) - 1))) * ld_packed(p.post_hi + (g >> p.plb));
         out = canon((v * ld_packed(p.scale)) * w);
       } else if (p.scale) {
@@ -359,6 +370,61 @@ __global__ void n_inv_kernel(F* out, unsigned log_n) {
   *out = half.pow_u64(log_n);
 }
 
+struct Plan {
+  unsigned nsteps;
+  unsigned s[3];
+};
+static Plan make_plan(unsigned log_n) {
+  Plan pl{};
+  if (log_n <= kTileLog && log_n <= kMaxStepLog) {
+    pl.nsteps = 1;
+    pl.s[0] = log_n;
+  } else if (log_n <= 2 * kMaxStepLog) {
+    pl.nsteps = 2;
+    pl.s[0] = log_n / 2;
+    pl.s[1] = log_n - pl.s[0];
+  } else {
+    pl.nsteps = 3;
+    pl.s[0] = log_n / 3;
+    pl.s[1] = (log_n - pl.s[0]) / 2;
+    pl.s[2] = log_n - pl.s[0] - pl.s[1];
+  }
+  return pl;
+}
+
+// Inter-step twiddles as ONE table per step, in the step's own data layout: out[(k << log_b) + b] =
+// lo[e & mask] * hi[e >> lb], e = (b k) << log_a (internal form in, internal form out: (x R)(y R) / R = x y R; `hi` is
+// the n^-1-scaled table where the step carries the scale).  The composed form costs a 227-instruction product per
+// element and step in a kernel that is VALU-bound (ntt_step_kernel ran at ~80 % of its instruction-issue bound and
+// 7 % of HBM); the table costs 32 bytes of coalesced read.  Sizes: 2^(log_n - log_a) elements -- 32 MB for the first
+// step of a 2^20 transform, 512 MB at 2^24.  Not built above kFullTwiddleMaxLog (the composed form serves).
+constexpr unsigned kFullTwiddleMaxLog = 24;
+template <class F>
+__global__ void __launch_bounds__(256) full_twiddle_kernel(F* __restrict__ out, size_t count, unsigned log_a, unsigned log_b,
+                                                            const F* __restrict__ lo, const F* __restrict__ hi, unsigned lb) {
+  using P = typename F::Params;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= count) return;
+  const size_t k = idx >> log_b, b = idx & (((size_t)1 << log_b) - 1);
+  const size_t e = (b * k) << log_a;
+  const auto w = fe_from_words<P>(lo[e & (((size_t)1 << lb) - 1)].l) * fe_from_words<P>(hi[e >> lb].l);
+  F o;
+  fe_to_words<P>(canon(w), o.l);
+  out[idx] = o;
+}
+// out[o] = lo[o & mask] * hi[o >> lb], o < count: a split power table flattened (the w_2m^o shift of the h-polynomial)
+template <class F>
+__global__ void __launch_bounds__(256) flat_powers_kernel(F* __restrict__ out, size_t count, const F* __restrict__ lo,
+                                                           const F* __restrict__ hi, unsigned lb) {
+  using P = typename F::Params;
+  const size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= count) return;
+  const auto w = fe_from_words<P>(lo[o & (((size_t)1 << lb) - 1)].l) * fe_from_words<P>(hi[o >> lb].l);
+  F r;
+  fe_to_words<P>(canon(w), r.l);
+  out[o] = r;
+}
+
 template <class F>
 static const TwiddleSet& get_twiddles(Call& k, int curve, unsigned log_n, int inverse) {
   std::lock_guard<std::mutex> g(k.ctx->mu);
@@ -394,6 +460,18 @@ static const TwiddleSet& get_twiddles(Call& k, int curve, unsigned log_n, int in
   if (inverse) ts.hi_scaled_i = internal_copy<F>(s, ts.hi_scaled, nhi);
   ts.small_i = internal_copy<F>(s, ts.small, nsm);
   ts.n_inv_i = internal_copy<F>(s, ts.n_inv, 1);
+  {
+    const Plan pl = make_plan(log_n);
+    unsigned consumed = 0;
+    for (unsigned j = 0; j + 1 < pl.nsteps && log_n <= kFullTwiddleMaxLog; j++) {
+      const size_t cnt = (size_t)1 << (log_n - consumed);
+      DG_HIP(hipMalloc(&ts.full[j], cnt * sizeof(F)));
+      hipLaunchKernelGGL(full_twiddle_kernel<F>, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, s, (F*)ts.full[j], cnt,
+                         consumed, log_n - consumed - pl.s[j], (const F*)ts.lo_i,
+                         (const F*)((inverse && j == 0) ? ts.hi_scaled_i : ts.hi_i), ts.lb);
+      consumed += pl.s[j];
+    }
+  }
   DG_HIP(hipGetLastError());
   DG_HIP(hipStreamSynchronize(s));   // tables are shared by all channels from here on
   return k.ctx->twiddles.emplace(key, ts).first->second;
@@ -416,28 +494,6 @@ static void build_power_tables(Call& k, const F* g_dev, unsigned log_n, F* lo, F
 template <class F>
 __global__ void inv_one_kernel(F* out, const F* in) { *out = in->inv(); }
 
-struct Plan {
-  unsigned nsteps;
-  unsigned s[3];
-};
-static Plan make_plan(unsigned log_n) {
-  Plan pl{};
-  if (log_n <= kTileLog && log_n <= kMaxStepLog) {
-    pl.nsteps = 1;
-    pl.s[0] = log_n;
-  } else if (log_n <= 2 * kMaxStepLog) {
-    pl.nsteps = 2;
-    pl.s[0] = log_n / 2;
-    pl.s[1] = log_n - pl.s[0];
-  } else {
-    pl.nsteps = 3;
-    pl.s[0] = log_n / 3;
-    pl.s[1] = (log_n - pl.s[0]) / 2;
-    pl.s[2] = log_n - pl.s[0] - pl.s[1];
-  }
-  return pl;
-}
-
 // data[i] <- transform(in[i]) for i < nb (in may equal data); tmp[i] are scratch buffers of the same size
 // (multi-step plans ping-pong).  The nb transforms share every launch (grid.y = nb): a 2^20 transform alone is
 // only 1024 workgroups = 4 per CU.  pre_* / post_*: power tables or null; see StepArgs.
@@ -445,7 +501,7 @@ template <class F>
 static void ntt_run_batch(Call& k, int curve, unsigned nb, const F* const* in, F* const* data, F* const* tmp,
                           unsigned log_n, int inverse, const F* pre_lo, const F* pre_hi, const F* post_lo,
                           const F* post_hi, unsigned plb, unsigned src_piece_log = 0, size_t src_piece_stride = 0,
-                          unsigned dst_piece_log = 0, size_t dst_piece_stride = 0) {
+                          unsigned dst_piece_log = 0, size_t dst_piece_stride = 0, const F* post_full = nullptr) {
   DG_REQUIRE(log_n <= 3 * kMaxStepLog, DG16_ERR_UNSUPPORTED, "log_n > 27 not supported yet");
   DG_REQUIRE(nb >= 1 && nb <= 3, DG16_ERR_BAD_ARG, "1..3 transforms per batch");
   const TwiddleSet& ts = get_twiddles<F>(k, curve, log_n, inverse);
@@ -467,11 +523,12 @@ static void ntt_run_batch(Call& k, int curve, unsigned nb, const F* const* in, F
     bool fold_scale = inverse && pl.nsteps > 1 && j == 0;
     a.tw_hi = (const F*)(fold_scale ? ts.hi_scaled_i : ts.hi_i);
     a.lb = ts.lb;
+    a.tw_full = (!a.last && j < 2) ? (const F*)ts.full[j] : nullptr;
     a.scale = nullptr;
     if (fold_scale) a.scale = (const F*)ts.n_inv_i;                  // marks "tw_hi carries n^-1"
     if (inverse && pl.nsteps == 1) a.scale = (const F*)ts.n_inv_i;   // explicit multiply at the store
     if (j == 0) { a.pre_lo = pre_lo; a.pre_hi = pre_hi; a.src_piece_log = src_piece_log; a.src_piece_stride = src_piece_stride; }
-    if (a.last) { a.post_lo = post_lo; a.post_hi = post_hi; a.dst_piece_log = dst_piece_log; a.dst_piece_stride = dst_piece_stride; }
+    if (a.last) { a.post_lo = post_lo; a.post_hi = post_hi; a.post_full = post_full; a.dst_piece_log = dst_piece_log; a.dst_piece_stride = dst_piece_stride; }
     a.plb = plb;
     // ping-pong: first step in -> tmp (same layout), middle step in place on tmp, last step tmp -> data;
     // a single step goes in -> data (one workgroup holds the whole vector in LDS before storing)
@@ -552,6 +609,22 @@ __global__ void __launch_bounds__(256) mul_sub_kernel(const F* __restrict__ a, c
     out[i] = a[i] * b[i] - c[i];
 }
 
+// w_2m^o for o < m as ONE table (internal form), cached in the twiddle set of the 2m domain
+template <class F>
+static const F* flat_shift_table(Call& k, const TwiddleSet& t2, unsigned log_m) {
+  std::lock_guard<std::mutex> g(k.ctx->mu);
+  TwiddleSet& w = const_cast<TwiddleSet&>(t2);       // (the cache entry; guarded by ctx->mu like its creation)
+  if (!w.shift_full) {
+    const size_t m = (size_t)1 << log_m;
+    DG_HIP(hipMalloc(&w.shift_full, m * sizeof(F)));
+    hipLaunchKernelGGL(flat_powers_kernel<F>, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, k.s(), (F*)w.shift_full, m,
+                       (const F*)t2.lo_i, (const F*)t2.hi_i, t2.lb);
+    DG_HIP(hipGetLastError());
+    DG_HIP(hipStreamSynchronize(k.s()));               // shared by all channels from here on
+  }
+  return (const F*)w.shift_full;
+}
+
 template <class F>
 static void h_poly_typed(Call& k, int curve, const void* a, const void* b, const void* c, unsigned log_m,
                          void* out) {
@@ -562,10 +635,12 @@ static void h_poly_typed(Call& k, int curve, const void* a, const void* b, const
   const F* in[3] = {(const F*)a, (const F*)b, (const F*)c};
   // shift tables: powers of w_{2m} (the forward 2m-domain root), applied on the iNTT's store
   const TwiddleSet& t2 = get_twiddles<F>(k, curve, log_m + 1, 0);
-  // lo/hi of the 2m domain cover exponents < 2m; we only need o < m
+  // lo/hi of the 2m domain cover exponents < 2m; we only need o < m -- flattened once into one table (w_2m^o, o < m)
+  const F* shift = log_m + 1 <= kFullTwiddleMaxLog + 1 ? flat_shift_table<F>(k, t2, log_m) : nullptr;
   k.begin_dominant();
   // a, b, c go through every step together; the first iNTT step reads the caller's vectors in place
-  ntt_run_batch<F>(k, curve, 3, in, v, tmp, log_m, 1, nullptr, nullptr, (const F*)t2.lo_i, (const F*)t2.hi_i, t2.lb);
+  ntt_run_batch<F>(k, curve, 3, in, v, tmp, log_m, 1, nullptr, nullptr, (const F*)t2.lo_i, (const F*)t2.hi_i, t2.lb,
+                   0, 0, 0, 0, shift);
   ntt_run_batch<F>(k, curve, 3, v, v, tmp, log_m, 0, nullptr, nullptr, nullptr, nullptr, 0);
   size_t n = (size_t)1 << log_m;
   size_t blocks = (n + 255) / 256;

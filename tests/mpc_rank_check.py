@@ -116,7 +116,21 @@ if rank == 0:
     aff = lambda g, j: corc.jac_to_affine(curve, g, j)              # noqa: E731
     h_shares = np.stack([np.frombuffer(e[3], dtype=np.uint64).reshape(-1, 4) for e in everyone], axis=1)
     h_clear = pp.unpack(h_shares).reshape(m, 4)
-    ok &= np.array_equal(h_clear, corc.h_poly(curve, a_v.copy(), b_v.copy(), c_v.copy()))
+    # every party's h SHARES == the line-by-line restatement of ext_wit::h (oracle/pyref/groth16.py:216-236) ...
+    from oracle.pyref.fields import FR
+    from oracle.pyref.pss import PackedSharingParams as RefPSS
+    from oracle.pyref.poly import Domain
+    from oracle.pyref import groth16 as G
+    F = FR[curve]
+    ints = lambda arr: [F.from_mont(v) for v in corc.arr_to_ints(np.asarray(arr).reshape(-1, 4))]   # noqa: E731
+    ref = RefPSS(F, l)
+    exp_sh = G.ext_wit_h(G.qap_pss(ints(a_v), ints(b_v), ints(c_v), ref), Domain(F, m), ref)
+    ok &= all(ints(np.frombuffer(e[3], dtype=np.uint64)) == exp_sh[i] for i, e in enumerate(everyone))
+    # ... and, for l = 2 (t = 1), the h-polynomial itself: `s1.swap(i, i * l + t)` (ext_wit.rs:74-76) picks the odd
+    # positions of the 2m evaluations -- the coset -- only then; with l = 1 the swap is the identity and the protocol's
+    # output is the product on the first m points of the 2m domain, on the reference as on this library
+    if l == 2:
+        ok &= np.array_equal(h_clear, corc.h_poly(curve, a_v.copy(), b_v.copy(), c_v.copy()))
     eA = add(1, add(1, Lp, mul(1, Np, r_i)), msm(1, S, wa))
     eB = add(2, add(2, Zp, mul(2, Kp, s_i)), msm(2, V, wa))
     eC = add(1, msm(1, W, wax), msm(1, U, h_clear))

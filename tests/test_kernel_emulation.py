@@ -343,12 +343,14 @@ def test_g2_finalize_workgroup():
         assert got == expect[b], "bucket %d" % b
 
 
-@pytest.mark.parametrize("group", [1] + ([2] if os.environ.get("DG16_EMU_ALL") else []))
-def test_bucket_reduction_workgroups(group):
+@pytest.mark.parametrize("group,chunked", [(1, False), (1, True)] + ([(2, False), (2, True)] if os.environ.get("DG16_EMU_ALL") else []))
+def test_bucket_reduction_workgroups(group, chunked):
     """The bucket reduction of a window on the Workgroup emulator: msm_row_kernel (one 256-lane workgroup per row of 256
     buckets: suffix scan + tree over LDS, XYZZ29::add_mem) for both rows of a 512-bucket window, then msm_top_kernel
-    (512 lanes: sum W and sum r R on its two halves, doublings, the conversion to the 32-bit arkworks form) ->
-    the window sum == sum_b (b + 1) B_b from the oracle.  A dozen buckets are occupied, in XYZZ form with Z != 1.
+    (512 lanes: sum W and sum r R on its two halves, doublings) -> the window sum (internal form) == sum_b (b + 1) B_b
+    from the oracle.  A dozen buckets are occupied, in XYZZ form with Z != 1.
+    chunked: msm_rowchunk_kernel instead of the rows (the plain MSM's path: every lane owns two consecutive buckets,
+    serial running sums, one suffix scan, two trees side by side) and the top kernel in its folded mode.
     G2 (DG16_EMU_ALL=1): the same kernels with the field products behind calls (DG29_OUTLINE_MUL, as the Makefile builds)."""
     import random
     from oracle.pyref.curves import CURVES
@@ -386,7 +388,17 @@ def test_bucket_reduction_workgroups(group):
         expect = C.add(expect, C.mul(P, b + 1))
     geom = [10, 1, log_nb, 4, 64, 1, 1, 1]
     # ---- rows
-    for row in range(2):
+    if chunked:
+        wg = E.Workgroup(E.Program(text, "msm_rowchunk_kernel"), 256, wg_id=(0, 0), kernarg_addr=KARG)
+        wg.mem.update(mem0)
+        karg = [log_nb, 1, BUCK, 0, FOLD, 0]                        # log_nb, k_log, buckets, fold
+        for k, v in enumerate(karg):
+            wg.mem[KARG + 4 * k] = v
+        wg.run()
+        for a, v in wg.mem.items():
+            if FOLD <= a < FOLD + 0x100000:
+                mem0[a] = v
+    for row in range(0 if chunked else 2):
         wg = E.Workgroup(E.Program(text, "msm_row_kernel"), 256, wg_id=(row, 0), kernarg_addr=KARG)
         wg.mem.update(mem0)
         karg = [0] * 18
@@ -405,19 +417,66 @@ def test_bucket_reduction_workgroups(group):
     # ---- top
     wg = E.Workgroup(E.Program(text, "msm_top_kernel"), 512, wg_id=(0, 0), kernarg_addr=KARG)
     wg.mem.update(mem0)
-    karg = [8, 1] + [0] * 8
+    # TopGeom: folded, per_log, lanes, final_log, rows_log (+ padding), then row_w, row_r, fold, window_sums
+    karg = ([1, 8, 1, 1, 1, 0] if chunked else [0, 0, 2, 8, 1, 0]) + [0] * 8
     for k, base in enumerate([ROWW, ROWR, FOLD, WSUM]):
-        karg[2 + 2 * k] = base
+        karg[6 + 2 * k] = base
     for k, v in enumerate(karg):
         wg.mem[KARG + 4 * k] = v
     wg.run()
-    nout = 4 * 8 * ncomp
+    nout = 4 * 9 * ncomp
     out = [wg.mem.get(WSUM + 4 * i) for i in range(nout)]
     assert all(v is not None for v in out), "the window sum was not written"
-    vals = [sum(v << (32 * i) for i, v in enumerate(out[8 * c:8 * c + 8])) % p for c in range(4 * ncomp)]
+    r_inv = pow(R, p - 2, p)
+    vals = [sum(v << (29 * i) for i, v in enumerate(out[9 * c:9 * c + 9])) * r_inv % p for c in range(4 * ncomp)]
     if ext:
         co = [(vals[2 * c], vals[2 * c + 1]) for c in range(4)]
         got = (F.mul(co[0], F.inv(co[2])), F.mul(co[1], F.inv(co[3])))
     else:
         got = (vals[0] * pow(vals[2], p - 2, p) % p, vals[1] * pow(vals[3], p - 2, p) % p)
     assert got == expect
+
+
+def test_horner_tail_on_one_wave():
+    """msm_tail_kernel (G1 of BN254) on the Workgroup emulator: one wave runs the Horner chain over the window sums with
+    the wave-cooperative operations on the reduced-radix types (msm_impl.h: dbl_wave29 / add_wave29 -- a dependency level
+    is one product per lane, the slots are joined with v_readlane): 2^c (2^c S_2 + S_1) + S_0 == the oracle's, for window
+    sums in XYZZ form with Z != 1, one of them the identity's neighbour case S_1 = S_2 (the addition's doubling branch)."""
+    import random
+    from oracle.pyref.curves import CURVES
+    C = CURVES["bn254", "g1"]
+    p = C.F.p
+    n_limbs, w = limb_shape(p)
+    R = 1 << (w * n_limbs)
+    text = assembly("bn254", 1, "msm_reduce.hip")
+    WSUM, OUT, KARG = 0x100000, 0x200000, 0x300000
+    rng = random.Random(11)
+    c_bits, bw = 1, 3
+    P2 = C.mul(C.gen, rng.randrange(1, 10**6))
+    pts = [C.mul(C.gen, rng.randrange(1, 10**6)), C.add(P2, P2), P2]      # S_0, S_1 = 2 S_2, S_2: 2 S_2 + S_1 doubles
+    mem0 = {}
+    for k, P in enumerate(pts):
+        z = rng.randrange(1, p)
+        zz = z * z % p
+        zzz = zz * z % p
+        for cidx, val in enumerate((P[0] * zz % p, P[1] * zzz % p, zz, zzz)):
+            v = val * R % p
+            for i in range(9):
+                mem0[WSUM + 4 * (36 * k + 9 * cidx + i)] = (v >> (29 * i)) & ((1 << 29) - 1) if i < 8 else v >> 232
+    expect = None
+    for P in reversed(pts):
+        for _ in range(c_bits):
+            expect = C.add(expect, expect) if expect is not None else None
+        expect = C.add(expect, P)
+    wg = E.Workgroup(E.Program(text, "msm_tail_kernel"), 64, wg_id=(0, 0), kernarg_addr=KARG)
+    wg.mem.update(mem0)
+    karg = [WSUM, 0] + [c_bits, bw, 1, 4, 64, bw, 0, 1, 64, 0] + [0, 0] + [OUT, 0]   # ptr | MsmGeom (+ region) | affine, pad | ptr
+    for k, v in enumerate(karg):
+        wg.mem[KARG + 4 * k] = v
+    wg.run()
+    out = [wg.mem.get(OUT + 4 * i) for i in range(24)]
+    assert all(v is not None for v in out), "the result was not written"
+    r32_inv = pow(1 << 256, p - 2, p)
+    X, Y, Z = (sum(v << (32 * i) for i, v in enumerate(out[8 * k:8 * k + 8])) * r32_inv % p for k in range(3))
+    zi = pow(Z, p - 2, p)
+    assert (X * zi * zi % p, Y * zi * zi * zi % p) == expect

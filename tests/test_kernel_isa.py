@@ -88,4 +88,4 @@ def test_ntt_step_has_no_scratch_and_no_column_joins():
         assert s["scratch"] == 0
         # v_lshl_add_u64 is now address arithmetic only: a product no longer joins its columns with 64-bit additions
         # (443 in this kernel before the chains)
-        assert s["lshl_add_u64"] <= 200 and s["mads"] >= 17 * 162
+        assert s["lshl_add_u64"] <= 260 and s["mads"] >= 17 * 162   # (229-240 with the direct twiddle tables: two more address chains)

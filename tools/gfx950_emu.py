@@ -369,9 +369,16 @@ class Lane:
             self.wr(a[0], (self.rd(a[1]) & M32) * (self.rd(a[2]) & M32))
         elif op == "s_mul_hi_u32":
             self.wr(a[0], ((self.rd(a[1]) & M32) * (self.rd(a[2]) & M32)) >> 32)
+        elif op == "s_mul_hi_i32":
+            self.wr(a[0], ((s32(self.rd(a[1])) * s32(self.rd(a[2]))) >> 32) & M32)
         elif op in ("s_lshl_b32", "s_lshr_b32", "s_ashr_i32"):
             x, sh = self.rd(a[1]) & M32, self.rd(a[2]) & 31
             r = (x << sh) & M32 if op == "s_lshl_b32" else (x >> sh) if op == "s_lshr_b32" else (s32(x) >> sh) & M32
+            self.wr(a[0], r)
+            self.scc = int(r != 0)
+        elif op == "s_ashr_i64":
+            x, sh = self.rd(a[1], 64) & M64, self.rd(a[2]) & 63
+            r = ((x - (1 << 64) if x >> 63 else x) >> sh) & M64
             self.wr(a[0], r)
             self.scc = int(r != 0)
         elif op in ("s_lshl_b64", "s_lshr_b64"):
@@ -393,6 +400,13 @@ class Lane:
             self.scc = int(r != 0)
         elif op == "s_not_b64":
             r = ~self.rd(a[1], 64) & M64
+            self.wr(a[0], r)
+            self.scc = int(r != 0)
+        elif op in ("s_bitcmp0_b32", "s_bitcmp1_b32"):
+            bit = (self.rd(a[0]) >> (self.rd(a[1]) & 31)) & 1
+            self.scc = int(bit == (1 if op == "s_bitcmp1_b32" else 0))
+        elif op == "s_not_b32":
+            r = ~self.rd(a[1]) & M32
             self.wr(a[0], r)
             self.scc = int(r != 0)
         elif op in ("s_and_saveexec_b64", "s_or_saveexec_b64", "s_andn2_saveexec_b64", "s_xor_saveexec_b64"):
@@ -636,6 +650,8 @@ class Lane:
             wr(a[0], r & M32)
         elif base in ("v_accvgpr_write_b32", "v_accvgpr_read_b32", "v_accvgpr_mov_b32"):
             wr(a[0], rd(a[1]))
+        elif base == "v_bfrev_b32":
+            wr(a[0], int("{:032b}".format(rd(a[1]) & M32)[::-1], 2))
         elif base == "v_not_b32":
             wr(a[0], ~rd(a[1]))
         elif base == "v_lshlrev_b32":
@@ -784,6 +800,13 @@ class Workgroup:
             sc.wr(a[0], lanes[sc.rd(a[2]) & 63].rd(a[1]))
         elif op == "v_writelane_b32":
             lanes[sc.rd(a[2]) & 63].wr(a[0], sc.rd(a[1]))
+        elif op == "ds_bpermute_b32":                       # dst[l] = data[(addr[l] / 4) % 64], all reads before any write
+            vals = [ln.rd(a[2]) & M32 for ln in lanes]
+            off = int(str(mods.get("offset", 0)), 0)
+            picks = [vals[(((ln.rd(a[1]) + off) & M32) >> 2) & 63] for ln in lanes]
+            for l in range(64):
+                if (sc.exec >> l) & 1:
+                    lanes[l].wr(a[0], picks[l])
         elif op.startswith(("v_", "ds_", "global_", "flat_", "scratch_")):
             # an instruction that writes a lane mask (compare, carry-out): every lane must see the ORIGINAL value of
             # the destination registers (v_cmp_lt_u32 s[0:1], s0, v73 reads s0), inactive lanes end up as 0
