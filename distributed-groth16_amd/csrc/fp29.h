@@ -581,20 +581,14 @@ DG_HD auto mul_add4(const Fe<P, B1, L1>& a, const Fe<P, B2, L2>& b, const Fe<P, 
     else return mul_add4(a, b, c, d, e, f, g, norm(h));
   }
 }
-// (a b - c d) / R.  For the 9-limb fields with ONE reduction: c is negated limb by limb (N subtractions from a multiple
-// of p that dominates it) and rides as the second product of a dual product -- the Y3 of every group addition /
-// doubling is of this form (R (Q - X3) - PPP Y1): nine reductions per mixed addition instead of ten.  The 14-limb fields
-// keep two products (d c, the operand order their kernels were measured with): their accumulation loops sit at the
-// 168 registers of three waves per SIMD and the four operands of a dual product live at once spill (44-56 B per lane).
-// (-DDG29_FUSE_ALL fuses for every field, for an A/B of the 14-limb loops at two waves per SIMD: -DDG16_ACC48_WAVES=2)
+// (a b - c d) / R with ONE reduction: c is negated limb by limb (N subtractions from a multiple of p that dominates
+// it) and rides as the second product of a dual product -- the Y3 of every group addition / doubling is of this form
+// (R (Q - X3) - PPP Y1): nine reductions per mixed addition instead of ten.  Round 4: for the 14-limb fields too -- their
+// G1 accumulation then runs at TWO waves per SIMD (178 VGPRs, no scratch; unfused at three it spilled 44-56 B per
+// lane when fused): measured on BLS12-381 2^20, same box, same call, A's accumulation 2.97 -> 2.83 ms, proof 39.1 ->
+// 37.9 ms (profiles/r4b_ab_variants.md).
 template <class P>
-constexpr bool rr_fuse_mul_sub() {
-#ifdef DG29_FUSE_ALL
-  return true;
-#else
-  return RR<P>::N <= 9;
-#endif
-}
+constexpr bool rr_fuse_mul_sub() { return true; }
 template <class P, int B1, int L1, int B2, int L2, int B3, int L3, int B4, int L4>
 DG_HD auto mul_sub(const Fe<P, B1, L1>& a, const Fe<P, B2, L2>& b, const Fe<P, B3, L3>& c, const Fe<P, B4, L4>& d) {
   if constexpr (rr_fuse_mul_sub<P>()) return mul_add(a, b, neg(c), d);

@@ -641,7 +641,9 @@ __device__ __forceinline__ void wg_bucket_tree(uint32_t (*sh)[BLOCK], unsigned s
     __syncthreads();
     if (lane < total) {
       const unsigned a = list[lane];
-      XYZZ29<F>::add_acc(ColAcc<F, BLOCK>{sh, a}, ColAcc<F, BLOCK>{sh, a}, ColAcc<F, BLOCK>{sh, a + d});
+      // (Fq2: add_into -- U1 / S1 overwrite X1 / Y1 in their LDS columns, so only P, R, PP, PPP live across the products)
+      if constexpr (FieldOf<F>::EXT) XYZZ29<F>::add_into(ColAcc<F, BLOCK>{sh, a}, ColAcc<F, BLOCK>{sh, a + d});
+      else XYZZ29<F>::add_acc(ColAcc<F, BLOCK>{sh, a}, ColAcc<F, BLOCK>{sh, a}, ColAcc<F, BLOCK>{sh, a + d});
     }
     __syncthreads();
   }
@@ -677,7 +679,7 @@ constexpr unsigned msm_acc_block_log() {
 template <class F>
 constexpr bool msm_acc_tree() {
 #ifdef DG16_G2_TREE
-  return true;
+  return sizeof(F) <= DG16_TREE_MAX_BYTES || sizeof(F) == 64;     // + the G2 of BN254 (experiment)
 #else
   return sizeof(F) <= DG16_TREE_MAX_BYTES;
 #endif
@@ -686,11 +688,10 @@ constexpr bool msm_acc_tree() {
 template <class F>
 constexpr unsigned msm_acc_wg_log() { return msm_acc_tree<F>() ? msm_acc_block_log<F>() : 0u; }
 
-// Waves per SIMD the accumulation of a 48-byte coordinate field is compiled for: 3 = 168 VGPRs.  With the products as
-// one accumulator chain per column (fp29_asm_gen.h) the loops of BLS12-381 and BLS12-377 both take 165 without a
-// spill (unconstrained: 183, two waves; before the chains 167 / 205).
+// Waves per SIMD the accumulation of a 48-byte coordinate field is compiled for: 2 = up to 256 VGPRs (the loop with the
+// fused Y3 takes 178, no scratch).  Three (168 VGPRs) needs the unfused Y3 and was 4 % slower (fp29.h: rr_fuse_mul_sub).
 #ifndef DG16_ACC48_WAVES
-#define DG16_ACC48_WAVES 3
+#define DG16_ACC48_WAVES 2
 #endif
 // (waves per SIMD = 4 caps the kernel at 128 VGPRs: the loop needs 108; what the tree's full addition needs beyond
 // that is spilled INSIDE the tree, which a workgroup runs five times, not inside the loop it runs 16 x 4 times)
@@ -716,22 +717,8 @@ msm_accumulate_kernel(MsmBases bases, size_t n,
     const unsigned cnt = sr.cnt;
     const unsigned* e = entries + (size_t)w * g.region + offsets[sr.bslot] + sr.first;
     // Latency hiding: several waves per SIMD cover the dependent (entry -> point) gathers; only the 4-byte entry
-    // index is fetched one iteration ahead (a second point in registers would cost occupancy).
-#ifdef DG16_G1_POINT_PREFETCH
-    // (experiment switch: the next point's packed words gathered one iteration ahead, as in msm_accumulate_lds_kernel)
-    unsigned cur = e[0];
-    unsigned nxt = cnt > 1 ? e[1] : 0u;
-    RawPoint<F> raw_cur = load_raw<F>(base_tab, cur & 0x7fffffffu);
-    for (unsigned j = 0; j < cnt; j++) {
-      const unsigned nn = (j + 2 < cnt) ? e[j + 2] : 0u;
-      const RawPoint<F> raw_nxt = load_raw<F>(base_tab, nxt & 0x7fffffffu);
-      const Affine29<F> p = unpack_raw<F>(raw_cur);
-      acc = acc.madd(p, cur >> 31);
-      cur = nxt;
-      nxt = nn;
-      raw_cur = raw_nxt;
-    }
-#else
+    // index is fetched one iteration ahead (a second point in registers costs the whole 128-register budget of four
+    // waves and six scratch accesses per iteration: measured equal, profiles/r4b_ab_variants.md -- removed).
     unsigned cur = e[0];
     for (unsigned j = 0; j < cnt; j++) {
       unsigned nxt = (j + 1 < cnt) ? e[j + 1] : 0u;
@@ -739,7 +726,6 @@ msm_accumulate_kernel(MsmBases bases, size_t n,
       acc = acc.madd(p, cur >> 31);
       cur = nxt;
     }
-#endif
   }
   const size_t bucket_slot = ((size_t)blockIdx.y << g.log_nb) + (sr.bslot & (((size_t)1 << g.log_nb) - 1));
   if constexpr (msm_acc_tree<F>()) {
@@ -1016,16 +1002,22 @@ __device__ __forceinline__ XYZZ<F> scalar_mul_wave(const XYZZ<F>& p, const uint3
 // accumulation itself (profiles/r4b_msm_g1_2e20_kernel_stats.md).  Here a level is ONE 162-mad column-chain product
 // (fp29_asm_gen.h) per lane; coordinates stay below the storage bound BS p between levels (fit<BS>: a carry pass, or one
 // multiply-subtract pass where a sum exceeds it), so every slot's operand has the same static type.
-template <class P, int B>
-__device__ __forceinline__ Fe<P, B, 1> bcast29(const Fe<P, B, 1>& v, int src) {   // src: wave-uniform lane index
+// the value lane SRC (< 16) of every row of 16 lanes holds -> all lanes of the row: ONE v_mov_b32_dpp row_newbcast per
+// limb.  The operands of these chains are uniform across the wave, so every row holds the same slots and a row-local
+// broadcast is a wave-wide one.  (v_readlane was the first form: its results are SGPRs, hipcc then ran the additions /
+// reductions between the levels on the SCALAR unit -- 190 SALU instructions per level, a doubling 1 440 instructions.)
+template <int SRC, class P, int B>
+__device__ __forceinline__ Fe<P, B, 1> bcast29(const Fe<P, B, 1>& v) {
+  static_assert(SRC >= 0 && SRC < 16, "row_newbcast takes a lane of the row");
   Fe<P, B, 1> r;
 #pragma unroll
-  for (int i = 0; i < RR<P>::N; i++) r.l[i] = (uint32_t)__builtin_amdgcn_readlane((int)v.l[i], src);
+  for (int i = 0; i < RR<P>::N; i++)
+    r.l[i] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.l[i], 0x150 + SRC, 0xf, 0xf, false);
   return r;
 }
-template <class P, int B>
-__device__ __forceinline__ Fe2<P, B, 1> bcast29(const Fe2<P, B, 1>& v, int src) {
-  return {bcast29(v.c0, src), bcast29(v.c1, src)};
+template <int SRC, class P, int B>
+__device__ __forceinline__ Fe2<P, B, 1> bcast29(const Fe2<P, B, 1>& v) {
+  return {bcast29<SRC>(v.c0), bcast29<SRC>(v.c1)};
 }
 template <class P, int B>
 __device__ __forceinline__ Fe<P, B, 1> lane_get29(const Fe<P, B, 1>& v, int src) {   // src: per-lane index
@@ -1056,25 +1048,25 @@ template <class F>
 __device__ __forceinline__ XYZZ29<F> dbl_wave29(const XYZZ29<F>& p) {
   constexpr int BS = XYZZ29<F>::BS;
   if (p.is_inf()) return p;
-  const unsigned slot = __lane_id() >> 2;
+  const unsigned slot = (__lane_id() & 15) >> 2;     // four slots per ROW of 16 lanes: bcast29 is row-local
   const auto u = fit<BS>(dbl(p.y));
   // level 1: v = u^2 | xx = x^2
   const auto a1 = select(slot == 0, u, p.x);
   const auto r1 = slot_mul29(a1, a1);
-  const auto v = bcast29(r1, 0), xx = bcast29(r1, 4);
+  const auto v = bcast29<0>(r1), xx = bcast29<4>(r1);
   const auto m = fit<BS>(dbl(xx) + xx);
   // level 2: w = u v | s = x v | m^2 | zz' = v zz
   const auto a2 = select(slot == 0, u, select(slot == 1, p.x, select(slot == 2, m, v)));
   const auto b2 = select(slot <= 1, v, select(slot == 2, m, p.zz));
   const auto r2 = slot_mul29(a2, b2);
-  const auto w = bcast29(r2, 0), sv = bcast29(r2, 4), mm = bcast29(r2, 8), zz3 = bcast29(r2, 12);
+  const auto w = bcast29<0>(r2), sv = bcast29<4>(r2), mm = bcast29<8>(r2), zz3 = bcast29<12>(r2);
   const auto x3 = fit<BS>(mm - dbl(sv));
   // level 3: m (s - x3) | w y | zzz' = w zzz
   const auto a3 = select(slot == 0, m, w);
   const auto b3 = select(slot == 0, fit<BS>(sv - x3), select(slot == 1, p.y, p.zzz));
   const auto r3 = slot_mul29(a3, b3);
-  const auto y3 = fit<BS>(bcast29(r3, 0) - bcast29(r3, 4));
-  return {x3, y3, zz3, bcast29(r3, 8)};
+  const auto y3 = fit<BS>(bcast29<0>(r3) - bcast29<4>(r3));
+  return {x3, y3, zz3, bcast29<8>(r3)};
 }
 // p + o, both (and the result) uniform across the wave: 14 products in 4 levels       (add-2008-s)
 template <class F>
@@ -1082,12 +1074,12 @@ __device__ __forceinline__ XYZZ29<F> add_wave29(const XYZZ29<F>& p, const XYZZ29
   constexpr int BS = XYZZ29<F>::BS;
   if (o.is_inf()) return p;
   if (p.is_inf()) return o;
-  const unsigned slot = __lane_id() >> 2;
+  const unsigned slot = (__lane_id() & 15) >> 2;     // four slots per ROW of 16 lanes: bcast29 is row-local
   // level 1: u1 = x1 zz2 | u2 = x2 zz1 | s1 = y1 zzz2 | s2 = y2 zzz1
   const auto a1 = select(slot == 0, p.x, select(slot == 1, o.x, select(slot == 2, p.y, o.y)));
   const auto b1 = select(slot == 0, o.zz, select(slot == 1, p.zz, select(slot == 2, o.zzz, p.zzz)));
   const auto r1 = slot_mul29(a1, b1);
-  const auto u1 = bcast29(r1, 0), u2 = bcast29(r1, 4), s1 = bcast29(r1, 8), s2 = bcast29(r1, 12);
+  const auto u1 = bcast29<0>(r1), u2 = bcast29<4>(r1), s1 = bcast29<8>(r1), s2 = bcast29<12>(r1);
   const auto pd = fit<BS>(u2 - u1), rd = fit<BS>(s2 - s1);
   if (is_zero(pd)) {
     if (is_zero(rd)) return dbl_wave29(p);
@@ -1097,17 +1089,17 @@ __device__ __forceinline__ XYZZ29<F> add_wave29(const XYZZ29<F>& p, const XYZZ29
   const auto a2 = select(slot == 0, pd, select(slot == 1, rd, select(slot == 2, p.zz, p.zzz)));
   const auto b2 = select(slot == 0, pd, select(slot == 1, rd, select(slot == 2, o.zz, o.zzz)));
   const auto r2 = slot_mul29(a2, b2);
-  const auto pp = bcast29(r2, 0), rr = bcast29(r2, 4), zzp = bcast29(r2, 8), zzzp = bcast29(r2, 12);
+  const auto pp = bcast29<0>(r2), rr = bcast29<4>(r2), zzp = bcast29<8>(r2), zzzp = bcast29<12>(r2);
   // level 3: ppp = p pp | q = u1 pp | zz3 = (zz1 zz2) pp
   const auto a3 = select(slot == 0, pd, select(slot == 1, u1, zzp));
   const auto r3 = slot_mul29(a3, pp);
-  const auto ppp = bcast29(r3, 0), q = bcast29(r3, 4), zz3 = bcast29(r3, 8);
+  const auto ppp = bcast29<0>(r3), q = bcast29<4>(r3), zz3 = bcast29<8>(r3);
   const auto x3 = fit<BS>(rr - (ppp + dbl(q)));
   // level 4: r (q - x3) | s1 ppp | zzz3 = (zzz1 zzz2) ppp
   const auto a4 = select(slot == 0, rd, select(slot == 1, s1, zzzp));
   const auto b4 = select(slot == 0, fit<BS>(q - x3), ppp);
   const auto r4 = slot_mul29(a4, b4);
-  return {x3, fit<BS>(bcast29(r4, 0) - bcast29(r4, 4)), zz3, bcast29(r4, 8)};
+  return {x3, fit<BS>(bcast29<0>(r4) - bcast29<4>(r4)), zz3, bcast29<8>(r4)};
 }
 // k p by double-and-add on one wave; k = NW little-endian 32-bit words (plain integer), uniform
 template <class F, int NW>
@@ -1299,6 +1291,51 @@ template <class F>
 void msm_accumulate_phase(hipStream_t s, const MsmSort& st, const MsmBuffers<F>& b, const void* bases) {
   const void* one[1] = {bases};
   msm_accumulate_phase<F>(s, st, b, one);
+}
+
+// ---- 6: Horner tail ---------------------------------------------------------------------------------
+// W*c dependent doublings: inherently serial in the group, but not inside one doubling.  One wave runs the
+// chain; the 9 multiplications of an XYZZ doubling form 3 dependency levels (2 | 4 | 3 products), each level
+// is evaluated by different lanes at once and shared with readlane.  An Fq2 product is itself spread over three
+// lanes of a quad (Karatsuba).  One thread per MSM took 2.5 ms (G1) / 10.2 ms (G2) for the 256 doublings of a
+// 2^20-point MSM, as long as the bucket accumulation itself.  (Round 4: the chain runs on the reduced-radix types.)
+template <class F>
+__global__ void __launch_bounds__(64) msm_tail_kernel(const XYZZ29<F>* __restrict__ window_sums, MsmGeom g,
+                                                       int affine, F* __restrict__ out) {
+  __builtin_amdgcn_s_setprio(3);   // latency-bound chain: issue ahead of the accumulation waves sharing the SIMD
+  // one wave per MSM instance (blockIdx.x), every lane carries the same running total (internal form: dbl_wave29)
+  window_sums += (size_t)blockIdx.x * g.bw;
+  out += (size_t)blockIdx.x * (affine ? 2 : 3);
+  XYZZ29<F> acc = XYZZ29<F>::inf();
+#pragma unroll 1
+  for (int w = (int)g.bw - 1; w >= 0; w--) {
+#pragma unroll 1
+    for (unsigned k = 0; k < g.c; k++) acc = dbl_wave29(acc);
+    acc = add_wave29(acc, window_sums[w]);
+  }
+  if (threadIdx.x != 0) return;
+  using FO = FieldOf<F>;
+  if (affine) {
+    Affine<F> a = acc.to_xyzz32().to_affine();
+    out[0] = a.x;
+    out[1] = a.y;
+  } else if (acc.is_inf()) {
+    out[0] = F::one();
+    out[1] = F::one();
+    out[2] = F::zero();
+  } else {
+    // (X ZZ, Y ZZZ, ZZ) is the same point in Jacobian coordinates with Z = ZZ (ec.h: XYZZ::to_jacobian)
+    out[0] = FO::to32(fit<FO::BS>(acc.x * acc.zz));
+    out[1] = FO::to32(fit<FO::BS>(acc.y * acc.zzz));
+    out[2] = FO::to32(acc.zz);
+  }
+}
+
+// Launched by msm_bucket_phase (msm_reduce.hip) but INSTANTIATED in msm_group.hip: the chain's products stay inline for
+// every group (a call per level cost the G2 tail 8 us per operation against 3 for G1's inline form).
+template <class F>
+void msm_tail_phase(hipStream_t s, const MsmSort& st, const MsmBuffers<F>& b, bool out_affine, void* out_dev) {
+  hipLaunchKernelGGL(msm_tail_kernel<F>, dim3(b.ninst), dim3(64), 0, s, b.window_sums, st.g, (int)out_affine, (F*)out_dev);
 }
 
 // ---- 4b: bucket = sum of its segment partials, as a throughput kernel -------------------------------------------
@@ -1763,6 +1800,7 @@ void to_affine_run(Call& k, const void* jac, void* out, size_t n) {
 #define DG16_MSM_EXTERN_GROUP(F)                                                                                  \
   extern template void msm_accumulate_phase<F>(hipStream_t, const MsmSort&, const MsmBuffers<F>&, const void* const*); \
   extern template void msm_finalize_phase<F>(hipStream_t, const MsmSort&, const MsmBuffers<F>&);                   \
+  extern template void msm_tail_phase<F>(hipStream_t, const MsmSort&, const MsmBuffers<F>&, bool, void*);         \
   extern template void* msm_build_table<F>(hipStream_t, const void*, size_t, unsigned, unsigned);
 #define DG16_MSM_EXTERN(CT)                                                                                       \
   DG16_MSM_EXTERN_GROUP(CT::Fq)                                                                                   \

@@ -284,12 +284,11 @@ __global__ void __launch_bounds__(256 * HALVES) msm_top_kernel(TopGeom tg, const
     const unsigned half = HALVES == 2 ? threadIdx.x >> 8 : (unsigned)pass;
     *me = t < lanes ? (folded ? fb[half * 256 + t] : (half == 0 ? row_w : row_r)[base + t]) : XYZZ29<F>::inf();
     __syncthreads();
-    // schedule: 8 scan steps (weighted half) | drop suffix_0 | per_log doublings | + local (folded) | 8 tree steps |
-    // weighted half's lane 0 only: row_log doublings | + sum W  (total = sum W + 2^row_log * sum r R)
-    const unsigned s_tree = 9 + per_log, s_fin = s_tree + 8, n_steps = s_fin + tg.final_log + 1;
-    const XYZZ29<F>* wsum = HALVES == 2 ? &sh[0] : &keep;
+    // schedule: 8 scan steps (weighted half) | drop suffix_0 | per_log doublings | + local (folded) | 8 tree steps;
+    // then ONE wave: final_log doublings | + sum W  (total = sum W + 2^final_log * sum r R)
+    const unsigned s_tree = 9 + per_log, s_fin = s_tree + 8;
 #pragma unroll 1
-    for (unsigned step = 0; step < n_steps; step++) {
+    for (unsigned step = 0; step < s_fin; step++) {
       XYZZ29<F> v;
       bool on = false, is_dbl = false;
       const XYZZ29<F>* b = me;
@@ -303,14 +302,10 @@ __global__ void __launch_bounds__(256 * HALVES) msm_top_kernel(TopGeom tg, const
       } else if (step == 8 + per_log) {
         on = half == 1 && folded && t < lanes;     // (chunk mode fills only `lanes` entries of the fold array)
         b = fb + 2 * 256 + (on ? t : 0);
-      } else if (step < s_fin) {
+      } else {
         const unsigned stride = 128u >> (step - s_tree);
         on = t < stride;
         b = me + (on ? stride : 0);
-      } else {
-        on = half == 1 && t == 0;
-        is_dbl = step < s_fin + tg.final_log;
-        b = wsum;
       }
       if (step == 8 && half == 1 && t == 0) *me = XYZZ29<F>::inf();   // weight t starts at 0: drop suffix_0
       if (on) {
@@ -326,44 +321,15 @@ __global__ void __launch_bounds__(256 * HALVES) msm_top_kernel(TopGeom tg, const
       __syncthreads();
     }
   }
-  if (threadIdx.x == (HALVES == 2 ? 256u : 0u)) window_sums[blockIdx.x] = sh[threadIdx.x];
-}
-
-// ---- 6: Horner tail ---------------------------------------------------------------------------------
-// W*c dependent doublings: inherently serial in the group, but not inside one doubling.  One wave runs the
-// chain; the 9 multiplications of an XYZZ doubling form 3 dependency levels (2 | 4 | 3 products), each level
-// is evaluated by different lanes at once and shared with readlane.  An Fq2 product is itself spread over three
-// lanes of a quad (Karatsuba).  One thread per MSM took 2.5 ms (G1) / 10.2 ms (G2) for the 256 doublings of a
-// 2^20-point MSM, as long as the bucket accumulation itself.  (Round 4: the chain runs on the reduced-radix types.)
-template <class F>
-__global__ void __launch_bounds__(64) msm_tail_kernel(const XYZZ29<F>* __restrict__ window_sums, MsmGeom g,
-                                                       int affine, F* __restrict__ out) {
-  __builtin_amdgcn_s_setprio(3);   // latency-bound chain: issue ahead of the accumulation waves sharing the SIMD
-  // one wave per MSM instance (blockIdx.x), every lane carries the same running total (internal form: dbl_wave29)
-  window_sums += (size_t)blockIdx.x * g.bw;
-  out += (size_t)blockIdx.x * (affine ? 2 : 3);
-  XYZZ29<F> acc = XYZZ29<F>::inf();
+  // The last final_log + 1 operations are a chain on ONE value: the wave that holds it runs them wave-cooperatively
+  // (msm_impl.h: dbl_wave29 / add_wave29 -- ~1.5 us per G1 operation against ~11 us for a lone lane's, G2 3 against 25)
+  constexpr unsigned RES = HALVES == 2 ? 256u : 0u;
+  if ((threadIdx.x >> 6) == (RES >> 6)) {
+    XYZZ29<F> acc = sh[RES];
 #pragma unroll 1
-  for (int w = (int)g.bw - 1; w >= 0; w--) {
-#pragma unroll 1
-    for (unsigned k = 0; k < g.c; k++) acc = dbl_wave29(acc);
-    acc = add_wave29(acc, window_sums[w]);
-  }
-  if (threadIdx.x != 0) return;
-  using FO = FieldOf<F>;
-  if (affine) {
-    Affine<F> a = acc.to_xyzz32().to_affine();
-    out[0] = a.x;
-    out[1] = a.y;
-  } else if (acc.is_inf()) {
-    out[0] = F::one();
-    out[1] = F::one();
-    out[2] = F::zero();
-  } else {
-    // (X ZZ, Y ZZZ, ZZ) is the same point in Jacobian coordinates with Z = ZZ (ec.h: XYZZ::to_jacobian)
-    out[0] = FO::to32(fit<FO::BS>(acc.x * acc.zz));
-    out[1] = FO::to32(fit<FO::BS>(acc.y * acc.zzz));
-    out[2] = FO::to32(acc.zz);
+    for (unsigned k = 0; k < tg.final_log; k++) acc = dbl_wave29(acc);
+    acc = add_wave29(acc, HALVES == 2 ? sh[0] : keep);
+    if ((threadIdx.x & 63) == 0) window_sums[blockIdx.x] = acc;
   }
 }
 
@@ -446,7 +412,7 @@ void msm_bucket_phase(hipStream_t s, const MsmSort& st, const MsmBuffers<F>& b, 
   hipLaunchKernelGGL((msm_top_kernel<F, HALVES>), dim3(bwi), dim3(256 * HALVES), 0, s, tg, b.row_w, b.row_r,
                      b.fold, b.window_sums);
   trace_point(s, "top");
-  hipLaunchKernelGGL(msm_tail_kernel<F>, dim3(b.ninst), dim3(64), 0, s, b.window_sums, g, (int)out_affine, (F*)out_dev);
+  msm_tail_phase<F>(s, st, b, out_affine, out_dev);     // msm_group.hip: inline products whatever this unit's are
   trace_point(s, "tail");
   DG_HIP(hipGetLastError());
 }

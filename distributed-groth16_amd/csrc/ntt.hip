@@ -18,6 +18,7 @@
 //
 // Roofline: 64 B/element algorithmic traffic, but ~10 Montgomery multiplications per element -- the kernel is
 // VALU-bound, not HBM-bound.
+#include <cstdlib>
 #include "ctx.h"
 #include "fp29.h"
 #include "types.h"
@@ -399,6 +400,13 @@ static Plan make_plan(unsigned log_n) {
 // 7 % of HBM); the table costs 32 bytes of coalesced read.  Sizes: 2^(log_n - log_a) elements -- 32 MB for the first
 // step of a 2^20 transform, 512 MB at 2^24.  Not built above kFullTwiddleMaxLog (the composed form serves).
 constexpr unsigned kFullTwiddleMaxLog = 24;
+// ... and not below kFullTwiddleMinLog: measured (profiles/r4b_ntt_tables_ab.txt) 2^22 alone 0.588 -> 0.536 ms, 2^24
+// 2.19 -> 2.00, but the h-polynomial at 2^20 only 0.81 -> 0.78 alone and a 2^20 proof +0.1 ms (the table reads share
+// the memory system with the digit sort running underneath).  DG16_NTT_TABLE_MIN_LOG overrides (0 = always, 99 = never).
+inline unsigned full_twiddle_min_log() {
+  static const unsigned v = [] { const char* e = getenv("DG16_NTT_TABLE_MIN_LOG"); return e ? (unsigned)atoi(e) : 21u; }();
+  return v;
+}
 template <class F>
 __global__ void __launch_bounds__(256) full_twiddle_kernel(F* __restrict__ out, size_t count, unsigned log_a, unsigned log_b,
                                                             const F* __restrict__ lo, const F* __restrict__ hi, unsigned lb) {
@@ -463,7 +471,7 @@ static const TwiddleSet& get_twiddles(Call& k, int curve, unsigned log_n, int in
   {
     const Plan pl = make_plan(log_n);
     unsigned consumed = 0;
-    for (unsigned j = 0; j + 1 < pl.nsteps && log_n <= kFullTwiddleMaxLog; j++) {
+    for (unsigned j = 0; j + 1 < pl.nsteps && log_n <= kFullTwiddleMaxLog && log_n >= full_twiddle_min_log(); j++) {
       const size_t cnt = (size_t)1 << (log_n - consumed);
       DG_HIP(hipMalloc(&ts.full[j], cnt * sizeof(F)));
       hipLaunchKernelGGL(full_twiddle_kernel<F>, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, s, (F*)ts.full[j], cnt,
@@ -636,7 +644,7 @@ static void h_poly_typed(Call& k, int curve, const void* a, const void* b, const
   // shift tables: powers of w_{2m} (the forward 2m-domain root), applied on the iNTT's store
   const TwiddleSet& t2 = get_twiddles<F>(k, curve, log_m + 1, 0);
   // lo/hi of the 2m domain cover exponents < 2m; we only need o < m -- flattened once into one table (w_2m^o, o < m)
-  const F* shift = log_m + 1 <= kFullTwiddleMaxLog + 1 ? flat_shift_table<F>(k, t2, log_m) : nullptr;
+  const F* shift = log_m <= kFullTwiddleMaxLog && log_m >= full_twiddle_min_log() ? flat_shift_table<F>(k, t2, log_m) : nullptr;
   k.begin_dominant();
   // a, b, c go through every step together; the first iNTT step reads the caller's vectors in place
   ntt_run_batch<F>(k, curve, 3, in, v, tmp, log_m, 1, nullptr, nullptr, (const F*)t2.lo_i, (const F*)t2.hi_i, t2.lb,

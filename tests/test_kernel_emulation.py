@@ -440,7 +440,7 @@ def test_bucket_reduction_workgroups(group, chunked):
 def test_horner_tail_on_one_wave():
     """msm_tail_kernel (G1 of BN254) on the Workgroup emulator: one wave runs the Horner chain over the window sums with
     the wave-cooperative operations on the reduced-radix types (msm_impl.h: dbl_wave29 / add_wave29 -- a dependency level
-    is one product per lane, the slots are joined with v_readlane): 2^c (2^c S_2 + S_1) + S_0 == the oracle's, for window
+    is one product per lane, the slots are joined with v_mov_b32_dpp row_newbcast): 2^c (2^c S_2 + S_1) + S_0 == the oracle's, for window
     sums in XYZZ form with Z != 1, one of them the identity's neighbour case S_1 = S_2 (the addition's doubling branch)."""
     import random
     from oracle.pyref.curves import CURVES
@@ -448,7 +448,7 @@ def test_horner_tail_on_one_wave():
     p = C.F.p
     n_limbs, w = limb_shape(p)
     R = 1 << (w * n_limbs)
-    text = assembly("bn254", 1, "msm_reduce.hip")
+    text = assembly("bn254", 1, "msm_group.hip")      # (instantiated with the accumulation: inline products for every group)
     WSUM, OUT, KARG = 0x100000, 0x200000, 0x300000
     rng = random.Random(11)
     c_bits, bw = 1, 3

@@ -73,7 +73,7 @@ def test_bn254_g2_accumulation_hot_path():
 
 @pytest.mark.parametrize("curve", ["bls12_381", "bls12_377"])
 def test_48_byte_g1_accumulation_hot_path(curve):
-    prod, g1, _ = counts(14, False)
+    prod, g1, _ = counts(14, True)          # (round 4: the fused Y3 for the 14-limb fields too, at two waves per SIMD)
     blks = kernel("msm_%s_g1.o" % curve, "msm_accumulate_kernel")
     head, rest = block_with(blks, 2 * prod)[0], block_with(blks, g1 - 2 * prod)[0]
     for b in (head, rest):

@@ -29,24 +29,26 @@ def test_g1_bucket_accumulation_keeps_four_waves_with_the_bucket_tree():
     assert r["vgprs"] <= 128 and r["agprs"] == 0 and r["occupancy"] >= 4
     assert r["scratch"] <= 2 * 144 + 32
     assert r["lds"] == 4 * 9 * 256 * 4 + 256 * 2 + 5 * 4      # partial columns + compaction list + wave counters
-    # 48-byte fields: no tree (measured slower), no scratch, and -- with the products as one accumulator chain per column
-    # (fp29_asm_gen.h) -- the 168 registers of THREE waves per SIMD for BLS12-381 and BLS12-377 alike (DG16_ACC48_WAVES)
+    # 48-byte fields: no tree (measured slower), no scratch; round 4: the fused Y3 (one reduction less per addition) at
+    # TWO waves per SIMD -- 178 VGPRs -- measured 4 % ahead of the unfused loop at three (DG16_ACC48_WAVES)
     for k, r in find("msm_accumulate_kernel<bls12_").items():
-        assert r["occupancy"] >= 3 and r["scratch"] == 0 and r["lds"] == 0, k
+        assert r["occupancy"] >= 2 and r["vgprs"] <= 192 and r["scratch"] == 0 and r["lds"] == 0, k
 
 
 def test_g2_bucket_accumulation_stages_through_lds_without_spilling():
     (r,) = find("msm_accumulate_lds_kernel<Fp2<bn254_fq>,256>").values()
     assert r["lds"] == 4 * 18 * 256 * 4 and r["occupancy"] == 2   # 4 coordinates x 2 x 9 limbs x 256 lanes: 2 blocks / CU
     assert r["scratch"] == 0 and r["agprs"] == 0
+    # (14-limb G2 with the products out of line -- make OUTLINE_GROUPS=..., the box-independent form -- has a 176-byte
+    # call frame per lane instead)
     (r,) = find("msm_accumulate_lds_kernel<Fp2<bls12_381_fq>,128>").values()
-    assert r["scratch"] == 0 and r["agprs"] == 0 and r["lds"] == 4 * 28 * 128 * 4
+    assert r["scratch"] <= 192 and r["lds"] == 4 * 28 * 128 * 4
     # the throughput finalize of G2 (two lanes per bucket, add_into with the four-product Y3): two waves per SIMD, and
     # since the products are chains neither scratch (BN254: was 16 B) nor a full AGPR file + scratch (BLS12-377)
     for k, r in find("msm_finalize_lds_kernel<Fp2<bn254_fq>,256>").items():
         assert r["occupancy"] == 2 and r["scratch"] == 0 and r["agprs"] == 0, k
     for k, r in find("msm_finalize_lds_kernel<Fp2<bls12_").items():
-        assert r["scratch"] == 0 and r["agprs"] <= 128, k
+        assert r["scratch"] <= 192 and r["agprs"] <= 128, k        # (out-of-line products: the call frame)
 
 
 def test_ntt_and_sort_kernels_are_register_and_lds_only():

@@ -442,6 +442,14 @@ class Lane:
             self.wr(a[0], self.rd(a[1]) if self.scc else self.rd(a[2]))
         elif op == "s_cselect_b64":
             self.wr(a[0], self.rd(a[1], 64) if self.scc else self.rd(a[2], 64))
+        elif op.startswith("s_cmpk_"):           # compare with a 16-bit immediate (sign-extended for i32, zero-extended for u32)
+            kind, ty = op[7:].rsplit("_", 1)
+            x, k = self.rd(a[0]), int(a[1], 0) & 0xFFFF
+            if ty == "i32":
+                x, y = s32(x), (k - 0x10000 if k & 0x8000 else k)
+            else:
+                x, y = x & M32, k
+            self.scc = int({"eq": x == y, "lg": x != y, "gt": x > y, "ge": x >= y, "lt": x < y, "le": x <= y}[kind])
         elif op.startswith("s_cmp_"):
             kind, ty = op[6:].rsplit("_", 1)
             x, y = self.rd(a[0]), self.rd(a[1])
@@ -800,6 +808,20 @@ class Workgroup:
             sc.wr(a[0], lanes[sc.rd(a[2]) & 63].rd(a[1]))
         elif op == "v_writelane_b32":
             lanes[sc.rd(a[2]) & 63].wr(a[0], sc.rd(a[1]))
+        elif op.endswith("_dpp"):                           # row_newbcast:N only: src0 = lane N of the lane's row of 16
+            m = re.search(r"row_newbcast:(\d+)", text)
+            assert m and "row_mask:0xf" in text and "bank_mask:0xf" in text, text
+            args = a[:-1] + [a[-1].split()[0]]
+            vals = [ln.rd(args[1]) & M32 for ln in lanes]
+            for l in range(64):
+                if (sc.exec >> l) & 1:
+                    ln = lanes[l]
+                    ln.bitop3, ln.clamp, ln.mods = mods["bitop3"], mods["clamp"], mods
+                    ln.tmp = {"__s0": vals[(l & ~15) + int(m.group(1))]}
+                    try:
+                        ln.valu(op[:-4], [args[0], "__s0"] + args[2:], text)
+                    finally:
+                        ln.tmp = {}
         elif op == "ds_bpermute_b32":                       # dst[l] = data[(addr[l] / 4) % 64], all reads before any write
             vals = [ln.rd(a[2]) & M32 for ln in lanes]
             off = int(str(mods.get("offset", 0)), 0)
