@@ -641,9 +641,7 @@ __device__ __forceinline__ void wg_bucket_tree(uint32_t (*sh)[BLOCK], unsigned s
     __syncthreads();
     if (lane < total) {
       const unsigned a = list[lane];
-      // (Fq2: add_into -- U1 / S1 overwrite X1 / Y1 in their LDS columns, so only P, R, PP, PPP live across the products)
-      if constexpr (FieldOf<F>::EXT) XYZZ29<F>::add_into(ColAcc<F, BLOCK>{sh, a}, ColAcc<F, BLOCK>{sh, a + d});
-      else XYZZ29<F>::add_acc(ColAcc<F, BLOCK>{sh, a}, ColAcc<F, BLOCK>{sh, a}, ColAcc<F, BLOCK>{sh, a + d});
+      XYZZ29<F>::add_acc(ColAcc<F, BLOCK>{sh, a}, ColAcc<F, BLOCK>{sh, a}, ColAcc<F, BLOCK>{sh, a + d});
     }
     __syncthreads();
   }
@@ -662,14 +660,22 @@ constexpr bool msm_acc_tree();
 // log2 of the accumulation workgroup of coordinate field F (msm_accumulate_phase)
 template <class F>
 constexpr unsigned msm_acc_block_log() {
+#ifdef DG16_G2_BLOCK256
+  if constexpr (sizeof(F) > 48) return 8u;     // (experiment: one 256-lane workgroup per CU for the 14-limb Fq2, 114 KB of LDS)
+#else
   if constexpr (sizeof(F) > 48) return sizeof(typename FieldOf<F>::Store) * 4 * 256 <= 80 * 1024 ? 8u : 7u;
+#endif
   else if constexpr (!msm_acc_tree<F>()) return 8u;
   else return sizeof(typename FieldOf<F>::Store) * 4 * 256 <= 40 * 1024 ? 8u : 7u;   // G1: four workgroups' trees per CU
 }
 // Does the accumulation kernel of F add the partials of a bucket inside the workgroup (wg_bucket_tree)?  G1: yes.
 // G2: no -- its loop already takes 173 VGPRs (BN254) / 252 (BLS12-381) with the accumulator in LDS, and the tree's full
-// Fq2 addition inlined next to it spilled 0.9-1.4 KB per lane (the proof got 15 % SLOWER); every lane writes its
-// partial and the finalize adds the ~15 of a bucket as before (out-of-line products, msm_reduce.hip).
+// Fq2 addition inlined next to it spilled 0.9-1.4 KB per lane (the proof got 15 % SLOWER).  Round 4 tried it again
+// with XYZZ29::add_into on the LDS columns (U1 / S1 overwrite X1 / Y1 in place: 215 VGPRs, NO scratch, still two waves
+// per SIMD): the accumulation went 2.91 -> 3.50 ms per 2^20-point launch for a 0.45-ms finalize saved -- a 2^20 proof
+// 10.36 -> 10.59 ms, same box, same call (profiles/r4d_ab.md): the tree's 92 KB of code run five times per workgroup
+// next to a 47-KB loop costs more than the separate throughput finalize.  Removed; every lane writes its partial and
+// msm_finalize_lds_kernel adds the ~15 of a bucket.
 // Coordinate fields up to this size get the tree: the G1 of BN254.  The 48-byte fields (BLS12-381 / -377 G1: 14 limbs,
 // 168 VGPRs in the loop already) were measured with it, same box, same call: 39.4 vs 36.8 ms per 2^20 proof, 131.9 vs
 // 126.5 ms at 2^22 -- the tree's LDS columns and spills cost the loop more than the per-segment finalize they replace.
@@ -678,11 +684,7 @@ constexpr unsigned msm_acc_block_log() {
 #endif
 template <class F>
 constexpr bool msm_acc_tree() {
-#ifdef DG16_G2_TREE
-  return sizeof(F) <= DG16_TREE_MAX_BYTES || sizeof(F) == 64;     // + the G2 of BN254 (experiment)
-#else
   return sizeof(F) <= DG16_TREE_MAX_BYTES;
-#endif
 }
 // log2 of the span of segment slots that share ONE partial (msm_part_slot): the workgroup with the tree, one slot without
 template <class F>
@@ -756,7 +758,7 @@ msm_accumulate_kernel(MsmBases bases, size_t n,
 // consecutive banks, conflict-free ds_read/write_b32) the live set is the loaded point and ~6 temporaries.
 // 4 coordinates x 2 N words x BLOCK lanes = 72 KiB for BN254 Fq2 at BLOCK = 256 (two workgroups per CU, 160 KiB LDS).
 template <class F, int BLOCK>
-__global__ void __launch_bounds__(BLOCK, (BLOCK == 256 ? 2 : 1))
+__global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && sizeof(F) <= 64 ? 2 : 1))
 msm_accumulate_lds_kernel(MsmBases bases, size_t n, MsmGeom g,
                           const unsigned* __restrict__ offsets, const unsigned* __restrict__ counts,
                           const unsigned* __restrict__ seg_off, const unsigned* __restrict__ seg_total,
@@ -802,7 +804,29 @@ msm_accumulate_lds_kernel(MsmBases bases, size_t n, MsmGeom g,
   unsigned nxt = cnt > 1 ? e[1] : 0u;
   RawPoint<F> raw_cur{};
   if (PREFETCH && cnt) raw_cur = load_raw<F>(base_tab, cur & 0x7fffffffu);
-  for (unsigned j = 0; j < cnt; j++) {
+  // 14-limb Fq2: the loop body is 22 300 instructions = 180 KB against a 64 KB instruction cache shared by two CUs, so
+  // every wave streams the whole loop from L2 once per addition.  LOCKSTEP: the waves of a workgroup pass a barrier at
+  // the top of every iteration and run the body side by side -- one stream of instruction fetches serves all of them
+  // (experiment switch -DDG16_G2_LOCKSTEP; trips = the longest segment of the workgroup, shorter lanes idle).
+#ifdef DG16_G2_LOCKSTEP
+  constexpr bool LOCKSTEP = sizeof(F) > 64;
+#else
+  constexpr bool LOCKSTEP = false;
+#endif
+  unsigned trips = cnt;
+  if constexpr (LOCKSTEP) {
+    __shared__ unsigned wg_trips;
+    if (lane == 0) wg_trips = 0;
+    __syncthreads();
+    atomicMax(&wg_trips, cnt);
+    __syncthreads();
+    trips = wg_trips;
+  }
+  for (unsigned j = 0; j < trips; j++) {
+    if constexpr (LOCKSTEP) {
+      __syncthreads();
+      if (j >= cnt) continue;
+    }
     const unsigned nn = (j + 2 < cnt) ? e[j + 2] : 0u;
     RawPoint<F> raw_nxt{};
     if (PREFETCH) raw_nxt = load_raw<F>(base_tab, nxt & 0x7fffffffu);
@@ -849,22 +873,7 @@ msm_accumulate_lds_kernel(MsmBases bases, size_t n, MsmGeom g,
     st(1, y3);
     DG_STAGE();
   }
-  if constexpr (msm_acc_tree<F>()) {
-    __shared__ unsigned short list[BLOCK];
-    __shared__ unsigned wcnt[BLOCK / 64 + 1];
-    if (inf) st(2, FO::zero());               // the identity for the tree: zz = 0
-    const unsigned hl = live ? (lane > sr.j ? lane - sr.j : 0u) : lane;
-    const unsigned el = live ? (lane - sr.j + sr.k < (unsigned)BLOCK ? lane + sr.k - sr.j : (unsigned)BLOCK) : lane + 1;
-    wg_bucket_tree<F, BLOCK>(sh, list, wcnt, lane, lane - hl, el);
-    if (live && lane == hl) {
-      XYZZ29<F> out = XYZZ29<F>::inf();
-      if (!limbs_all_zero(ld(2))) out = XYZZ29<F>{ld(0), ld(1), ld(2), ld(3)};
-      if (sr.j == 0 && lane + sr.k <= (unsigned)BLOCK)
-        buckets[((size_t)blockIdx.y << g.log_nb) + (sr.bslot & (((size_t)1 << g.log_nb) - 1))] = out;   // the whole bucket
-      else
-        seg_sum[(size_t)blockIdx.y * g.seg_cap + t] = out;    // one partial per (bucket, workgroup): msm_part_slot
-    }
-  } else if (live) {
+  if (live) {
     // (no in-workgroup tree here: msm_acc_tree) one partial per segment; a one-segment bucket is written directly
     XYZZ29<F> out = XYZZ29<F>::inf();
     if (!inf) out = XYZZ29<F>{ld(0), ld(1), ld(2), ld(3)};
@@ -1002,17 +1011,24 @@ __device__ __forceinline__ XYZZ<F> scalar_mul_wave(const XYZZ<F>& p, const uint3
 // accumulation itself (profiles/r4b_msm_g1_2e20_kernel_stats.md).  Here a level is ONE 162-mad column-chain product
 // (fp29_asm_gen.h) per lane; coordinates stay below the storage bound BS p between levels (fit<BS>: a carry pass, or one
 // multiply-subtract pass where a sum exceeds it), so every slot's operand has the same static type.
-// the value lane SRC (< 16) of every row of 16 lanes holds -> all lanes of the row: ONE v_mov_b32_dpp row_newbcast per
-// limb.  The operands of these chains are uniform across the wave, so every row holds the same slots and a row-local
-// broadcast is a wave-wide one.  (v_readlane was the first form: its results are SGPRs, hipcc then ran the additions /
-// reductions between the levels on the SCALAR unit -- 190 SALU instructions per level, a doubling 1 440 instructions.)
+// the value lane SRC (< 16) holds -> every lane (the operands of these chains are uniform across the wave and every row of
+// 16 lanes holds the same four slots).  v_readlane: the results are SGPRs, and hipcc runs the additions / reductions
+// between the levels on the scalar unit (~190 SALU instructions per level, a doubling 1 440 instructions).  The VALU
+// form -- v_mov_b32_dpp row_newbcast:SRC, one instruction per limb, 1 230 instructions per doubling -- is behind
+// -DDG16_BCAST_DPP: it passed every emulated run and produced WRONG sums on the device (the instruction itself does
+// what its name says there: tools/ubench/dpp_probe.hip), so some hazard between the inline-asm products and a DPP
+// read is not covered by hipcc's recogniser; not shipped until it is understood (profiles/r4d_dpp.md).
 template <int SRC, class P, int B>
 __device__ __forceinline__ Fe<P, B, 1> bcast29(const Fe<P, B, 1>& v) {
   static_assert(SRC >= 0 && SRC < 16, "row_newbcast takes a lane of the row");
   Fe<P, B, 1> r;
 #pragma unroll
   for (int i = 0; i < RR<P>::N; i++)
+#ifdef DG16_BCAST_DPP
     r.l[i] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.l[i], 0x150 + SRC, 0xf, 0xf, false);
+#else
+    r.l[i] = (uint32_t)__builtin_amdgcn_readlane((int)v.l[i], SRC);
+#endif
   return r;
 }
 template <int SRC, class P, int B>
@@ -1048,7 +1064,7 @@ template <class F>
 __device__ __forceinline__ XYZZ29<F> dbl_wave29(const XYZZ29<F>& p) {
   constexpr int BS = XYZZ29<F>::BS;
   if (p.is_inf()) return p;
-  const unsigned slot = (__lane_id() & 15) >> 2;     // four slots per ROW of 16 lanes: bcast29 is row-local
+  const unsigned slot = (__lane_id() & 15) >> 2;     // four slots per row of 16 lanes (the same in every row)
   const auto u = fit<BS>(dbl(p.y));
   // level 1: v = u^2 | xx = x^2
   const auto a1 = select(slot == 0, u, p.x);
@@ -1074,7 +1090,7 @@ __device__ __forceinline__ XYZZ29<F> add_wave29(const XYZZ29<F>& p, const XYZZ29
   constexpr int BS = XYZZ29<F>::BS;
   if (o.is_inf()) return p;
   if (p.is_inf()) return o;
-  const unsigned slot = (__lane_id() & 15) >> 2;     // four slots per ROW of 16 lanes: bcast29 is row-local
+  const unsigned slot = (__lane_id() & 15) >> 2;     // four slots per row of 16 lanes (the same in every row)
   // level 1: u1 = x1 zz2 | u2 = x2 zz1 | s1 = y1 zzz2 | s2 = y2 zzz1
   const auto a1 = select(slot == 0, p.x, select(slot == 1, o.x, select(slot == 2, p.y, o.y)));
   const auto b1 = select(slot == 0, o.zz, select(slot == 1, p.zz, select(slot == 2, o.zzz, p.zzz)));
@@ -1299,14 +1315,19 @@ void msm_accumulate_phase(hipStream_t s, const MsmSort& st, const MsmBuffers<F>&
 // is evaluated by different lanes at once and shared with readlane.  An Fq2 product is itself spread over three
 // lanes of a quad (Karatsuba).  One thread per MSM took 2.5 ms (G1) / 10.2 ms (G2) for the 256 doublings of a
 // 2^20-point MSM, as long as the bucket accumulation itself.  (Round 4: the chain runs on the reduced-radix types.)
+// carry_in: the running total of the windows ABOVE this launch's (a pipelined MSM runs the chain in two launches);
+// carry_out: where to leave the running total instead of converting it (the launch is not the last one)
 template <class F>
 __global__ void __launch_bounds__(64) msm_tail_kernel(const XYZZ29<F>* __restrict__ window_sums, MsmGeom g,
-                                                       int affine, F* __restrict__ out) {
+                                                       int affine, F* __restrict__ out,
+                                                       const XYZZ29<F>* __restrict__ carry_in,
+                                                       XYZZ29<F>* __restrict__ carry_out) {
   __builtin_amdgcn_s_setprio(3);   // latency-bound chain: issue ahead of the accumulation waves sharing the SIMD
   // one wave per MSM instance (blockIdx.x), every lane carries the same running total (internal form: dbl_wave29)
   window_sums += (size_t)blockIdx.x * g.bw;
   out += (size_t)blockIdx.x * (affine ? 2 : 3);
   XYZZ29<F> acc = XYZZ29<F>::inf();
+  if (carry_in) acc = carry_in[blockIdx.x];
 #pragma unroll 1
   for (int w = (int)g.bw - 1; w >= 0; w--) {
 #pragma unroll 1
@@ -1314,6 +1335,10 @@ __global__ void __launch_bounds__(64) msm_tail_kernel(const XYZZ29<F>* __restric
     acc = add_wave29(acc, window_sums[w]);
   }
   if (threadIdx.x != 0) return;
+  if (carry_out) {
+    carry_out[blockIdx.x] = acc;
+    return;
+  }
   using FO = FieldOf<F>;
   if (affine) {
     Affine<F> a = acc.to_xyzz32().to_affine();
@@ -1334,8 +1359,10 @@ __global__ void __launch_bounds__(64) msm_tail_kernel(const XYZZ29<F>* __restric
 // Launched by msm_bucket_phase (msm_reduce.hip) but INSTANTIATED in msm_group.hip: the chain's products stay inline for
 // every group (a call per level cost the G2 tail 8 us per operation against 3 for G1's inline form).
 template <class F>
-void msm_tail_phase(hipStream_t s, const MsmSort& st, const MsmBuffers<F>& b, bool out_affine, void* out_dev) {
-  hipLaunchKernelGGL(msm_tail_kernel<F>, dim3(b.ninst), dim3(64), 0, s, b.window_sums, st.g, (int)out_affine, (F*)out_dev);
+void msm_tail_phase(hipStream_t s, const MsmSort& st, const MsmBuffers<F>& b, bool out_affine, void* out_dev,
+                    const void* carry_in, void* carry_out) {
+  hipLaunchKernelGGL(msm_tail_kernel<F>, dim3(b.ninst), dim3(64), 0, s, b.window_sums, st.g, (int)out_affine, (F*)out_dev,
+                     (const XYZZ29<F>*)carry_in, (XYZZ29<F>*)carry_out);
 }
 
 // ---- 4b: bucket = sum of its segment partials, as a throughput kernel -------------------------------------------
@@ -1423,7 +1450,7 @@ struct PartialAcc {      // an XYZZ29 behind the accessor interface of XYZZ29::a
   }
 };
 template <class F, int BLOCK>
-__global__ void __launch_bounds__(BLOCK, (BLOCK == 256 ? 2 : 1))
+__global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && sizeof(F) <= 64 ? 2 : 1))
 msm_finalize_lds_kernel(MsmGeom g, size_t total, unsigned wg_log, unsigned lpb_log,
                         const unsigned* __restrict__ counts,
                         const unsigned* __restrict__ seg_off, const XYZZ29<F>* __restrict__ seg_sum,
@@ -1605,8 +1632,10 @@ void msm_finalize_phase(hipStream_t s, const MsmSort& st, const MsmBuffers<F>& b
 // (curve, group) in msm_reduce.hip -- a translation unit of its own because its kernels are compiled with out-of-line
 // field products (DG29_OUTLINE_MUL, fp29.h).
 // out_dev: b.ninst results back to back (Jacobian x, y, z -- or affine x, y -- of instance 0, then instance 1, ..)
+// with_tail = false: stop at the window sums (b.window_sums); the caller runs msm_tail_phase itself (msm_run_pipelined)
 template <class F>
-void msm_bucket_phase(hipStream_t s, const MsmSort& st, const MsmBuffers<F>& b, bool out_affine, void* out_dev);
+void msm_bucket_phase(hipStream_t s, const MsmSort& st, const MsmBuffers<F>& b, bool out_affine, void* out_dev,
+                      bool with_tail = true);
 
 // both phases on the call's own stream and workspace
 template <class F>
@@ -1619,6 +1648,78 @@ void msm_reduce(Call& k, const MsmSort& st, const void* bases, bool out_affine, 
   msm_bucket_phase<F>(k.s(), st, b, out_affine, out_dev);
 }
 
+// The windows [w0, w0 + nw) of a plain-mode sort / of its buffers as a sort / buffer set of their own (every array of the
+// bucket phases is laid out window by window, and the kernels index windows from 0)
+inline MsmSort msm_sort_windows(const MsmSort& st, unsigned w0, unsigned nw) {
+  MsmSort v = st;
+  const size_t nb = (size_t)1 << st.g.log_nb;
+  v.g.bw = nw;
+  v.entries += (size_t)w0 * st.g.region;
+  v.counts += w0 * nb;
+  v.offsets += w0 * nb;
+  v.seg_off += w0 * nb;
+  v.cursor += w0 * nb;
+  v.seg_total += w0;
+  return v;
+}
+template <class F>
+MsmBuffers<F> msm_buffer_windows(const MsmBuffers<F>& b, const MsmGeom& g, unsigned w0, unsigned nw, unsigned* giant,
+                                 unsigned giant_cap) {
+  MsmBuffers<F> v = b;
+  v.buckets += (size_t)w0 << g.log_nb;
+  v.seg_sum += (size_t)w0 * g.seg_cap;
+  v.row_w += (size_t)w0 << b.rg.rows_log;
+  v.row_r += (size_t)w0 << b.rg.rows_log;
+  v.fold += (size_t)w0 * 3 * 256;
+  v.window_sums += w0;
+  v.nbw = (size_t)nw << g.log_nb;
+  v.nrows = (size_t)nw << b.rg.rows_log;
+  v.giant = giant;
+  v.giant_cap = giant_cap;
+  return v;
+}
+
+// Plain MSM with the upper half of the windows one stage ahead.  Pippenger's Horner tail -- (W - 1) c dependent doublings,
+// ~0.8 ms of a 3-ms G1 MSM at 2^20 on ONE wave -- and the latency-bound bucket reduction in front of it can only hide
+// behind work of the same MSM: the accumulation runs as two launches (upper windows first), the upper half's reduction
+// and its share of the chain go down a side stream underneath the lower half's accumulation, and the lower half's tail
+// starts from the carried total:   main:  sort | acc HI | acc LO | reduce LO | (wait) tail LO
+//                                   side:            | reduce HI | tail HI -> carry
+template <class F>
+void msm_reduce_pipelined(Call& k, const MsmSort& st, const void* bases, bool out_affine, void* out_dev) {
+  const MsmGeom& g = st.g;
+  const unsigned W = g.bw, n_lo = W / 2, n_hi = W - n_lo;
+  MsmBuffers<F> b = msm_buffers<F>(k.c, g);
+  unsigned* giant2 = (unsigned*)ws(k.c, 30, ((size_t)b.giant_cap * 3 + 2) * 4);
+  XYZZ29<F>* carry = (XYZZ29<F>*)ws(k.c, 31, sizeof(XYZZ29<F>));
+  const MsmSort st_hi = msm_sort_windows(st, n_lo, n_hi), st_lo = msm_sort_windows(st, 0, n_lo);
+  MsmBuffers<F> b_hi = msm_buffer_windows<F>(b, g, n_lo, n_hi, giant2, b.giant_cap);
+  MsmBuffers<F> b_lo = msm_buffer_windows<F>(b, g, 0, n_lo, b.giant, b.giant_cap);
+  if (!k.c.side) {                                // (the channel is locked by this call)
+    int prio_lo = 0, prio_hi = 0;
+    DG_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+    DG_HIP(hipStreamCreateWithPriority(&k.c.side, hipStreamNonBlocking, prio_hi));
+    for (auto& e : k.c.pev) DG_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  }
+  hipStream_t main = k.s(), side = k.c.side;
+  hipEvent_t ev_hi = k.c.pev[0], ev_carry = k.c.pev[1];
+  k.begin_dominant();
+  b_hi.acc_done = nullptr;
+  b_lo.acc_done = k.c.ev[3];                      // dg16_last_kernel_ms: both accumulation launches
+  msm_accumulate_phase<F>(main, st_hi, b_hi, bases);
+  DG_HIP(hipEventRecord(ev_hi, main));
+  DG_HIP(hipStreamWaitEvent(side, ev_hi, 0));
+  msm_bucket_phase<F>(side, st_hi, b_hi, false, nullptr, false);
+  msm_tail_phase<F>(side, st_hi, b_hi, false, nullptr, nullptr, carry);
+  DG_HIP(hipEventRecord(ev_carry, side));
+  msm_accumulate_phase<F>(main, st_lo, b_lo, bases);
+  k.c.ev_valid[1] = true;
+  msm_bucket_phase<F>(main, st_lo, b_lo, false, nullptr, false);
+  DG_HIP(hipStreamWaitEvent(main, ev_carry, 0));
+  msm_tail_phase<F>(main, st_lo, b_lo, out_affine, out_dev, carry, nullptr);
+  DG_HIP(hipGetLastError());
+}
+
 template <class F, class Fr, int SCALAR_BITS>
 void msm_run(Call& k, const void* bases, const void* scalars, size_t n, bool scalars_mont, bool out_affine,
              void* out_dev) {
@@ -1627,7 +1728,12 @@ void msm_run(Call& k, const void* bases, const void* scalars, size_t n, bool sca
   if (n)
     hipLaunchKernelGGL(msm_to_internal_kernel<F>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, k.s(),
                        (const Affine<F>*)bases, n, internal);
-  msm_reduce<F>(k, st, internal, out_affine, out_dev);
+  // large MSMs: the upper windows one stage ahead (DG16_MSM_PIPELINE=0 switches it off)
+  static const bool pipeline = [] { const char* e = getenv("DG16_MSM_PIPELINE"); return !e || atoi(e) != 0; }();
+  if (pipeline && st.g.bw >= 8 && !st.g.table && (size_t)st.g.nwin * n >= ((size_t)1 << 22))
+    msm_reduce_pipelined<F>(k, st, internal, out_affine, out_dev);
+  else
+    msm_reduce<F>(k, st, internal, out_affine, out_dev);
 }
 
 // ---- table of window multiples for resident bases: T[r*n + i] = 2^(c_step*r) * P_i (affine), r < rows -----------
@@ -1800,7 +1906,7 @@ void to_affine_run(Call& k, const void* jac, void* out, size_t n) {
 #define DG16_MSM_EXTERN_GROUP(F)                                                                                  \
   extern template void msm_accumulate_phase<F>(hipStream_t, const MsmSort&, const MsmBuffers<F>&, const void* const*); \
   extern template void msm_finalize_phase<F>(hipStream_t, const MsmSort&, const MsmBuffers<F>&);                   \
-  extern template void msm_tail_phase<F>(hipStream_t, const MsmSort&, const MsmBuffers<F>&, bool, void*);         \
+  extern template void msm_tail_phase<F>(hipStream_t, const MsmSort&, const MsmBuffers<F>&, bool, void*, const void*, void*); \
   extern template void* msm_build_table<F>(hipStream_t, const void*, size_t, unsigned, unsigned);
 #define DG16_MSM_EXTERN(CT)                                                                                       \
   DG16_MSM_EXTERN_GROUP(CT::Fq)                                                                                   \
