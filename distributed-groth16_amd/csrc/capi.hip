@@ -96,9 +96,6 @@ void dg16_ctx_destroy(dg16_ctx* ctx) {
       if (ctx->ch[i].slot[s]) hipFree(ctx->ch[i].slot[s]);
     for (int e = 0; e < 4; e++)
       if (ctx->ch[i].ev[e]) hipEventDestroy(ctx->ch[i].ev[e]);
-    for (auto& e : ctx->ch[i].pev)
-      if (e) hipEventDestroy(e);
-    if (ctx->ch[i].side) hipStreamDestroy(ctx->ch[i].side);
     if (ctx->ch[i].own) hipStreamDestroy(ctx->ch[i].own);
   }
   for (auto& x : ctx->xws)

@@ -26,10 +26,6 @@ struct Channel {
   size_t slot_bytes[kSlots] = {};
   hipEvent_t ev[4] = {};
   bool ev_valid[2] = {false, false};  // [0] whole call (ev0..ev1), [1] dominant kernel (ev2..ev3)
-  // a second stream of the channel's own, for calls that run a latency-bound chain next to their saturating kernels
-  // (the pipelined plain MSM: msm_impl.h) -- created on first use, highest priority; pev: its two cross-stream events
-  hipStream_t side = nullptr;
-  hipEvent_t pev[2] = {};
 };
 
 struct TwiddleKey {

@@ -22,7 +22,7 @@ using GC = CT::G2c;
 // the host-side phases other translation units (the prover) call for this pair: instantiated here, `extern` there
 template void msm_accumulate_phase<GF>(hipStream_t, const MsmSort&, const MsmBuffers<GF>&, const void* const*);
 template void msm_finalize_phase<GF>(hipStream_t, const MsmSort&, const MsmBuffers<GF>&);
-template void msm_tail_phase<GF>(hipStream_t, const MsmSort&, const MsmBuffers<GF>&, bool, void*, const void*, void*);
+template void msm_tail_phase<GF>(hipStream_t, const MsmSort&, const MsmBuffers<GF>&, bool, void*);
 template void* msm_build_table<GF>(hipStream_t, const void*, size_t, unsigned, unsigned);
 template MsmSort msm_sort_on<CT::Fr, CT::SCALAR_BITS>(hipStream_t, Channel&, const void*, size_t, bool, bool, unsigned,
                                                       unsigned);

@@ -660,11 +660,7 @@ constexpr bool msm_acc_tree();
 // log2 of the accumulation workgroup of coordinate field F (msm_accumulate_phase)
 template <class F>
 constexpr unsigned msm_acc_block_log() {
-#ifdef DG16_G2_BLOCK256
-  if constexpr (sizeof(F) > 48) return 8u;     // (experiment: one 256-lane workgroup per CU for the 14-limb Fq2, 114 KB of LDS)
-#else
   if constexpr (sizeof(F) > 48) return sizeof(typename FieldOf<F>::Store) * 4 * 256 <= 80 * 1024 ? 8u : 7u;
-#endif
   else if constexpr (!msm_acc_tree<F>()) return 8u;
   else return sizeof(typename FieldOf<F>::Store) * 4 * 256 <= 40 * 1024 ? 8u : 7u;   // G1: four workgroups' trees per CU
 }
@@ -758,7 +754,7 @@ msm_accumulate_kernel(MsmBases bases, size_t n,
 // consecutive banks, conflict-free ds_read/write_b32) the live set is the loaded point and ~6 temporaries.
 // 4 coordinates x 2 N words x BLOCK lanes = 72 KiB for BN254 Fq2 at BLOCK = 256 (two workgroups per CU, 160 KiB LDS).
 template <class F, int BLOCK>
-__global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && sizeof(F) <= 64 ? 2 : 1))
+__global__ void __launch_bounds__(BLOCK, (BLOCK == 256 ? 2 : 1))
 msm_accumulate_lds_kernel(MsmBases bases, size_t n, MsmGeom g,
                           const unsigned* __restrict__ offsets, const unsigned* __restrict__ counts,
                           const unsigned* __restrict__ seg_off, const unsigned* __restrict__ seg_total,
@@ -804,29 +800,12 @@ msm_accumulate_lds_kernel(MsmBases bases, size_t n, MsmGeom g,
   unsigned nxt = cnt > 1 ? e[1] : 0u;
   RawPoint<F> raw_cur{};
   if (PREFETCH && cnt) raw_cur = load_raw<F>(base_tab, cur & 0x7fffffffu);
-  // 14-limb Fq2: the loop body is 22 300 instructions = 180 KB against a 64 KB instruction cache shared by two CUs, so
-  // every wave streams the whole loop from L2 once per addition.  LOCKSTEP: the waves of a workgroup pass a barrier at
-  // the top of every iteration and run the body side by side -- one stream of instruction fetches serves all of them
-  // (experiment switch -DDG16_G2_LOCKSTEP; trips = the longest segment of the workgroup, shorter lanes idle).
-#ifdef DG16_G2_LOCKSTEP
-  constexpr bool LOCKSTEP = sizeof(F) > 64;
-#else
-  constexpr bool LOCKSTEP = false;
-#endif
-  unsigned trips = cnt;
-  if constexpr (LOCKSTEP) {
-    __shared__ unsigned wg_trips;
-    if (lane == 0) wg_trips = 0;
-    __syncthreads();
-    atomicMax(&wg_trips, cnt);
-    __syncthreads();
-    trips = wg_trips;
-  }
-  for (unsigned j = 0; j < trips; j++) {
-    if constexpr (LOCKSTEP) {
-      __syncthreads();
-      if (j >= cnt) continue;
-    }
+  // (14-limb Fq2: the loop body is 22 300 instructions = 180 KB against a 64 KB instruction cache shared by two CUs, at one
+  // wave per SIMD: 9.4 ms per 2^20-point launch on some boxes of the pool, 18.9 on others.  Measured on a slow box and
+  // removed: the waves of a workgroup in LOCKSTEP behind a barrier per iteration, so that one stream of instruction
+  // fetches serves all of them -- 17.87 ms against 17.86 with two waves per workgroup, 20.8 with four: the fetches are
+  // latency-, not bandwidth-bound.  Out-of-line products: 14.4 ms on both kinds of box (Makefile: OUTLINE_GROUPS).)
+  for (unsigned j = 0; j < cnt; j++) {
     const unsigned nn = (j + 2 < cnt) ? e[j + 2] : 0u;
     RawPoint<F> raw_nxt{};
     if (PREFETCH) raw_nxt = load_raw<F>(base_tab, nxt & 0x7fffffffu);
@@ -1315,19 +1294,14 @@ void msm_accumulate_phase(hipStream_t s, const MsmSort& st, const MsmBuffers<F>&
 // is evaluated by different lanes at once and shared with readlane.  An Fq2 product is itself spread over three
 // lanes of a quad (Karatsuba).  One thread per MSM took 2.5 ms (G1) / 10.2 ms (G2) for the 256 doublings of a
 // 2^20-point MSM, as long as the bucket accumulation itself.  (Round 4: the chain runs on the reduced-radix types.)
-// carry_in: the running total of the windows ABOVE this launch's (a pipelined MSM runs the chain in two launches);
-// carry_out: where to leave the running total instead of converting it (the launch is not the last one)
 template <class F>
 __global__ void __launch_bounds__(64) msm_tail_kernel(const XYZZ29<F>* __restrict__ window_sums, MsmGeom g,
-                                                       int affine, F* __restrict__ out,
-                                                       const XYZZ29<F>* __restrict__ carry_in,
-                                                       XYZZ29<F>* __restrict__ carry_out) {
+                                                       int affine, F* __restrict__ out) {
   __builtin_amdgcn_s_setprio(3);   // latency-bound chain: issue ahead of the accumulation waves sharing the SIMD
   // one wave per MSM instance (blockIdx.x), every lane carries the same running total (internal form: dbl_wave29)
   window_sums += (size_t)blockIdx.x * g.bw;
   out += (size_t)blockIdx.x * (affine ? 2 : 3);
   XYZZ29<F> acc = XYZZ29<F>::inf();
-  if (carry_in) acc = carry_in[blockIdx.x];
 #pragma unroll 1
   for (int w = (int)g.bw - 1; w >= 0; w--) {
 #pragma unroll 1
@@ -1335,10 +1309,6 @@ __global__ void __launch_bounds__(64) msm_tail_kernel(const XYZZ29<F>* __restric
     acc = add_wave29(acc, window_sums[w]);
   }
   if (threadIdx.x != 0) return;
-  if (carry_out) {
-    carry_out[blockIdx.x] = acc;
-    return;
-  }
   using FO = FieldOf<F>;
   if (affine) {
     Affine<F> a = acc.to_xyzz32().to_affine();
@@ -1359,10 +1329,8 @@ __global__ void __launch_bounds__(64) msm_tail_kernel(const XYZZ29<F>* __restric
 // Launched by msm_bucket_phase (msm_reduce.hip) but INSTANTIATED in msm_group.hip: the chain's products stay inline for
 // every group (a call per level cost the G2 tail 8 us per operation against 3 for G1's inline form).
 template <class F>
-void msm_tail_phase(hipStream_t s, const MsmSort& st, const MsmBuffers<F>& b, bool out_affine, void* out_dev,
-                    const void* carry_in, void* carry_out) {
-  hipLaunchKernelGGL(msm_tail_kernel<F>, dim3(b.ninst), dim3(64), 0, s, b.window_sums, st.g, (int)out_affine, (F*)out_dev,
-                     (const XYZZ29<F>*)carry_in, (XYZZ29<F>*)carry_out);
+void msm_tail_phase(hipStream_t s, const MsmSort& st, const MsmBuffers<F>& b, bool out_affine, void* out_dev) {
+  hipLaunchKernelGGL(msm_tail_kernel<F>, dim3(b.ninst), dim3(64), 0, s, b.window_sums, st.g, (int)out_affine, (F*)out_dev);
 }
 
 // ---- 4b: bucket = sum of its segment partials, as a throughput kernel -------------------------------------------
@@ -1450,7 +1418,7 @@ struct PartialAcc {      // an XYZZ29 behind the accessor interface of XYZZ29::a
   }
 };
 template <class F, int BLOCK>
-__global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && sizeof(F) <= 64 ? 2 : 1))
+__global__ void __launch_bounds__(BLOCK, (BLOCK == 256 ? 2 : 1))
 msm_finalize_lds_kernel(MsmGeom g, size_t total, unsigned wg_log, unsigned lpb_log,
                         const unsigned* __restrict__ counts,
                         const unsigned* __restrict__ seg_off, const XYZZ29<F>* __restrict__ seg_sum,
@@ -1632,10 +1600,8 @@ void msm_finalize_phase(hipStream_t s, const MsmSort& st, const MsmBuffers<F>& b
 // (curve, group) in msm_reduce.hip -- a translation unit of its own because its kernels are compiled with out-of-line
 // field products (DG29_OUTLINE_MUL, fp29.h).
 // out_dev: b.ninst results back to back (Jacobian x, y, z -- or affine x, y -- of instance 0, then instance 1, ..)
-// with_tail = false: stop at the window sums (b.window_sums); the caller runs msm_tail_phase itself (msm_run_pipelined)
 template <class F>
-void msm_bucket_phase(hipStream_t s, const MsmSort& st, const MsmBuffers<F>& b, bool out_affine, void* out_dev,
-                      bool with_tail = true);
+void msm_bucket_phase(hipStream_t s, const MsmSort& st, const MsmBuffers<F>& b, bool out_affine, void* out_dev);
 
 // both phases on the call's own stream and workspace
 template <class F>
@@ -1648,78 +1614,6 @@ void msm_reduce(Call& k, const MsmSort& st, const void* bases, bool out_affine, 
   msm_bucket_phase<F>(k.s(), st, b, out_affine, out_dev);
 }
 
-// The windows [w0, w0 + nw) of a plain-mode sort / of its buffers as a sort / buffer set of their own (every array of the
-// bucket phases is laid out window by window, and the kernels index windows from 0)
-inline MsmSort msm_sort_windows(const MsmSort& st, unsigned w0, unsigned nw) {
-  MsmSort v = st;
-  const size_t nb = (size_t)1 << st.g.log_nb;
-  v.g.bw = nw;
-  v.entries += (size_t)w0 * st.g.region;
-  v.counts += w0 * nb;
-  v.offsets += w0 * nb;
-  v.seg_off += w0 * nb;
-  v.cursor += w0 * nb;
-  v.seg_total += w0;
-  return v;
-}
-template <class F>
-MsmBuffers<F> msm_buffer_windows(const MsmBuffers<F>& b, const MsmGeom& g, unsigned w0, unsigned nw, unsigned* giant,
-                                 unsigned giant_cap) {
-  MsmBuffers<F> v = b;
-  v.buckets += (size_t)w0 << g.log_nb;
-  v.seg_sum += (size_t)w0 * g.seg_cap;
-  v.row_w += (size_t)w0 << b.rg.rows_log;
-  v.row_r += (size_t)w0 << b.rg.rows_log;
-  v.fold += (size_t)w0 * 3 * 256;
-  v.window_sums += w0;
-  v.nbw = (size_t)nw << g.log_nb;
-  v.nrows = (size_t)nw << b.rg.rows_log;
-  v.giant = giant;
-  v.giant_cap = giant_cap;
-  return v;
-}
-
-// Plain MSM with the upper half of the windows one stage ahead.  Pippenger's Horner tail -- (W - 1) c dependent doublings,
-// ~0.8 ms of a 3-ms G1 MSM at 2^20 on ONE wave -- and the latency-bound bucket reduction in front of it can only hide
-// behind work of the same MSM: the accumulation runs as two launches (upper windows first), the upper half's reduction
-// and its share of the chain go down a side stream underneath the lower half's accumulation, and the lower half's tail
-// starts from the carried total:   main:  sort | acc HI | acc LO | reduce LO | (wait) tail LO
-//                                   side:            | reduce HI | tail HI -> carry
-template <class F>
-void msm_reduce_pipelined(Call& k, const MsmSort& st, const void* bases, bool out_affine, void* out_dev) {
-  const MsmGeom& g = st.g;
-  const unsigned W = g.bw, n_lo = W / 2, n_hi = W - n_lo;
-  MsmBuffers<F> b = msm_buffers<F>(k.c, g);
-  unsigned* giant2 = (unsigned*)ws(k.c, 30, ((size_t)b.giant_cap * 3 + 2) * 4);
-  XYZZ29<F>* carry = (XYZZ29<F>*)ws(k.c, 31, sizeof(XYZZ29<F>));
-  const MsmSort st_hi = msm_sort_windows(st, n_lo, n_hi), st_lo = msm_sort_windows(st, 0, n_lo);
-  MsmBuffers<F> b_hi = msm_buffer_windows<F>(b, g, n_lo, n_hi, giant2, b.giant_cap);
-  MsmBuffers<F> b_lo = msm_buffer_windows<F>(b, g, 0, n_lo, b.giant, b.giant_cap);
-  if (!k.c.side) {                                // (the channel is locked by this call)
-    int prio_lo = 0, prio_hi = 0;
-    DG_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
-    DG_HIP(hipStreamCreateWithPriority(&k.c.side, hipStreamNonBlocking, prio_hi));
-    for (auto& e : k.c.pev) DG_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-  }
-  hipStream_t main = k.s(), side = k.c.side;
-  hipEvent_t ev_hi = k.c.pev[0], ev_carry = k.c.pev[1];
-  k.begin_dominant();
-  b_hi.acc_done = nullptr;
-  b_lo.acc_done = k.c.ev[3];                      // dg16_last_kernel_ms: both accumulation launches
-  msm_accumulate_phase<F>(main, st_hi, b_hi, bases);
-  DG_HIP(hipEventRecord(ev_hi, main));
-  DG_HIP(hipStreamWaitEvent(side, ev_hi, 0));
-  msm_bucket_phase<F>(side, st_hi, b_hi, false, nullptr, false);
-  msm_tail_phase<F>(side, st_hi, b_hi, false, nullptr, nullptr, carry);
-  DG_HIP(hipEventRecord(ev_carry, side));
-  msm_accumulate_phase<F>(main, st_lo, b_lo, bases);
-  k.c.ev_valid[1] = true;
-  msm_bucket_phase<F>(main, st_lo, b_lo, false, nullptr, false);
-  DG_HIP(hipStreamWaitEvent(main, ev_carry, 0));
-  msm_tail_phase<F>(main, st_lo, b_lo, out_affine, out_dev, carry, nullptr);
-  DG_HIP(hipGetLastError());
-}
-
 template <class F, class Fr, int SCALAR_BITS>
 void msm_run(Call& k, const void* bases, const void* scalars, size_t n, bool scalars_mont, bool out_affine,
              void* out_dev) {
@@ -1728,12 +1622,12 @@ void msm_run(Call& k, const void* bases, const void* scalars, size_t n, bool sca
   if (n)
     hipLaunchKernelGGL(msm_to_internal_kernel<F>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, k.s(),
                        (const Affine<F>*)bases, n, internal);
-  // large MSMs: the upper windows one stage ahead (DG16_MSM_PIPELINE=0 switches it off)
-  static const bool pipeline = [] { const char* e = getenv("DG16_MSM_PIPELINE"); return !e || atoi(e) != 0; }();
-  if (pipeline && st.g.bw >= 8 && !st.g.table && (size_t)st.g.nwin * n >= ((size_t)1 << 22))
-    msm_reduce_pipelined<F>(k, st, internal, out_affine, out_dev);
-  else
-    msm_reduce<F>(k, st, internal, out_affine, out_dev);
+  // (Measured and removed in round 4: the accumulation as two launches, upper half of the windows first, with that half's
+  // bucket reduction and its share of the Horner chain on a side stream underneath the lower half's accumulation.  The
+  // split costs the accumulation 0.19 ms (two ramp-downs), and the side chain runs 1.7 ms instead of 0.9 next to a
+  // saturating launch -- it becomes the critical path: 3.71 against 3.45 ms per 2^20 G1 MSM, 10.1 against 9.8 for G2,
+  // same box, same call: profiles/r4e_msm_pipeline_ab.md.)
+  msm_reduce<F>(k, st, internal, out_affine, out_dev);
 }
 
 // ---- table of window multiples for resident bases: T[r*n + i] = 2^(c_step*r) * P_i (affine), r < rows -----------
@@ -1906,7 +1800,7 @@ void to_affine_run(Call& k, const void* jac, void* out, size_t n) {
 #define DG16_MSM_EXTERN_GROUP(F)                                                                                  \
   extern template void msm_accumulate_phase<F>(hipStream_t, const MsmSort&, const MsmBuffers<F>&, const void* const*); \
   extern template void msm_finalize_phase<F>(hipStream_t, const MsmSort&, const MsmBuffers<F>&);                   \
-  extern template void msm_tail_phase<F>(hipStream_t, const MsmSort&, const MsmBuffers<F>&, bool, void*, const void*, void*); \
+  extern template void msm_tail_phase<F>(hipStream_t, const MsmSort&, const MsmBuffers<F>&, bool, void*);         \
   extern template void* msm_build_table<F>(hipStream_t, const void*, size_t, unsigned, unsigned);
 #define DG16_MSM_EXTERN(CT)                                                                                       \
   DG16_MSM_EXTERN_GROUP(CT::Fq)                                                                                   \

@@ -11,6 +11,6 @@ using GF = CT::Fq;
 using GF = CT::Fq2;
 #endif
 extern template void msm_finalize_phase<GF>(hipStream_t, const MsmSort&, const MsmBuffers<GF>&);   // msm_group.hip
-extern template void msm_tail_phase<GF>(hipStream_t, const MsmSort&, const MsmBuffers<GF>&, bool, void*, const void*, void*);
-template void msm_bucket_phase<GF>(hipStream_t, const MsmSort&, const MsmBuffers<GF>&, bool, void*, bool);
+extern template void msm_tail_phase<GF>(hipStream_t, const MsmSort&, const MsmBuffers<GF>&, bool, void*);
+template void msm_bucket_phase<GF>(hipStream_t, const MsmSort&, const MsmBuffers<GF>&, bool, void*);
 }  // namespace dg16

@@ -348,8 +348,7 @@ inline void trace_point(hipStream_t s, const char* what) {
 }
 
 template <class F>
-void msm_bucket_phase(hipStream_t s, const MsmSort& st, const MsmBuffers<F>& b, bool out_affine, void* out_dev,
-                      bool with_tail) {
+void msm_bucket_phase(hipStream_t s, const MsmSort& st, const MsmBuffers<F>& b, bool out_affine, void* out_dev) {
   const MsmGeom& g = st.g;
   const unsigned bwi = g.bw * b.ninst;      // bucket-windows over all instances
   trace_point(s, "(before bucket phase)");
@@ -413,7 +412,7 @@ void msm_bucket_phase(hipStream_t s, const MsmSort& st, const MsmBuffers<F>& b, 
   hipLaunchKernelGGL((msm_top_kernel<F, HALVES>), dim3(bwi), dim3(256 * HALVES), 0, s, tg, b.row_w, b.row_r,
                      b.fold, b.window_sums);
   trace_point(s, "top");
-  if (with_tail) msm_tail_phase<F>(s, st, b, out_affine, out_dev, nullptr, nullptr);   // msm_group.hip: inline products
+  msm_tail_phase<F>(s, st, b, out_affine, out_dev);     // msm_group.hip: inline products whatever this unit's are
   trace_point(s, "tail");
   DG_HIP(hipGetLastError());
 }
