@@ -997,19 +997,66 @@ __device__ __forceinline__ XYZZ<F> scalar_mul_wave(const XYZZ<F>& p, const uint3
 // -DDG16_BCAST_DPP: it passed every emulated run and produced WRONG sums on the device (the instruction itself does
 // what its name says there: tools/ubench/dpp_probe.hip), so some hazard between the inline-asm products and a DPP
 // read is not covered by hipcc's recogniser; not shipped until it is understood (profiles/r4d_dpp.md).
+#ifdef DG16_BCAST_DPP
+// The DPP form as ONE asm statement per element: two wait states (a DPP read needs them after the VALU write of its
+// source, and hipcc cannot see a DPP inside an asm), then a v_mov_b32_dpp per limb -- opaque to hipcc's DPP combiner, which
+// turned the builtin form into v_sub_u32_dpp / v_subrev_u32_dpp ... row_newbcast (the build that gave wrong sums).
+template <int SRC, class P, int B>
+__device__ __forceinline__ Fe<P, B, 1> bcast29(const Fe<P, B, 1>& v) {
+  static_assert(SRC >= 0 && SRC < 16, "row_newbcast takes a lane of the row");
+  static_assert(RR<P>::N == 9 || RR<P>::N == 14, "limb count");
+  Fe<P, B, 1> r;
+  if constexpr (RR<P>::N == 9) {
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_mov_b32_dpp %0, %9 row_newbcast:%18 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b32_dpp %1, %10 row_newbcast:%18 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b32_dpp %2, %11 row_newbcast:%18 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b32_dpp %3, %12 row_newbcast:%18 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b32_dpp %4, %13 row_newbcast:%18 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b32_dpp %5, %14 row_newbcast:%18 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b32_dpp %6, %15 row_newbcast:%18 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b32_dpp %7, %16 row_newbcast:%18 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b32_dpp %8, %17 row_newbcast:%18 row_mask:0xf bank_mask:0xf"
+        : "=&v"(r.l[0]), "=&v"(r.l[1]), "=&v"(r.l[2]), "=&v"(r.l[3]), "=&v"(r.l[4]), "=&v"(r.l[5]), "=&v"(r.l[6]),
+          "=&v"(r.l[7]), "=&v"(r.l[8])
+        : "v"(v.l[0]), "v"(v.l[1]), "v"(v.l[2]), "v"(v.l[3]), "v"(v.l[4]), "v"(v.l[5]), "v"(v.l[6]), "v"(v.l[7]),
+          "v"(v.l[8]), "n"(SRC));
+  } else {
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_mov_b32_dpp %0, %14 row_newbcast:%28 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b32_dpp %1, %15 row_newbcast:%28 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b32_dpp %2, %16 row_newbcast:%28 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b32_dpp %3, %17 row_newbcast:%28 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b32_dpp %4, %18 row_newbcast:%28 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b32_dpp %5, %19 row_newbcast:%28 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b32_dpp %6, %20 row_newbcast:%28 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b32_dpp %7, %21 row_newbcast:%28 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b32_dpp %8, %22 row_newbcast:%28 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b32_dpp %9, %23 row_newbcast:%28 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b32_dpp %10, %24 row_newbcast:%28 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b32_dpp %11, %25 row_newbcast:%28 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b32_dpp %12, %26 row_newbcast:%28 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b32_dpp %13, %27 row_newbcast:%28 row_mask:0xf bank_mask:0xf"
+        : "=&v"(r.l[0]), "=&v"(r.l[1]), "=&v"(r.l[2]), "=&v"(r.l[3]), "=&v"(r.l[4]), "=&v"(r.l[5]), "=&v"(r.l[6]),
+          "=&v"(r.l[7]), "=&v"(r.l[8]), "=&v"(r.l[9]), "=&v"(r.l[10]), "=&v"(r.l[11]), "=&v"(r.l[12]), "=&v"(r.l[13])
+        : "v"(v.l[0]), "v"(v.l[1]), "v"(v.l[2]), "v"(v.l[3]), "v"(v.l[4]), "v"(v.l[5]), "v"(v.l[6]), "v"(v.l[7]),
+          "v"(v.l[8]), "v"(v.l[9]), "v"(v.l[10]), "v"(v.l[11]), "v"(v.l[12]), "v"(v.l[13]), "n"(SRC));
+  }
+  return r;
+}
+#else
 template <int SRC, class P, int B>
 __device__ __forceinline__ Fe<P, B, 1> bcast29(const Fe<P, B, 1>& v) {
   static_assert(SRC >= 0 && SRC < 16, "row_newbcast takes a lane of the row");
   Fe<P, B, 1> r;
 #pragma unroll
   for (int i = 0; i < RR<P>::N; i++)
-#ifdef DG16_BCAST_DPP
-    r.l[i] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.l[i], 0x150 + SRC, 0xf, 0xf, false);
-#else
     r.l[i] = (uint32_t)__builtin_amdgcn_readlane((int)v.l[i], SRC);
-#endif
   return r;
 }
+#endif
 template <int SRC, class P, int B>
 __device__ __forceinline__ Fe2<P, B, 1> bcast29(const Fe2<P, B, 1>& v) {
   return {bcast29<SRC>(v.c0), bcast29<SRC>(v.c1)};

@@ -384,6 +384,9 @@ void msm_bucket_phase(hipStream_t s, const MsmSort& st, const MsmBuffers<F>& b, 
     if (total_rows < 1024) k_log = 0;
     if (chunk_force >= 0) k_log = (unsigned)chunk_force <= g.log_nb - CH_LL ? (unsigned)chunk_force : g.log_nb - CH_LL;
     if (k_log > 3) k_log = 3;
+    // the top kernel's folded mode takes <= 256 chunk workgroups per bucket-window: beyond that (one bucket set of
+    // 2^20 buckets: the table of a 2^24-point key) the rows + msm_rowfold_kernel path serves
+    if (k_log && g.log_nb - k_log - CH_LL > 8) k_log = 0;
   }
   TopGeom tg{};
   tg.rows_log = b.rg.rows_log;
