@@ -990,17 +990,18 @@ __device__ __forceinline__ XYZZ<F> scalar_mul_wave(const XYZZ<F>& p, const uint3
 // accumulation itself (profiles/r4b_msm_g1_2e20_kernel_stats.md).  Here a level is ONE 162-mad column-chain product
 // (fp29_asm_gen.h) per lane; coordinates stay below the storage bound BS p between levels (fit<BS>: a carry pass, or one
 // multiply-subtract pass where a sum exceeds it), so every slot's operand has the same static type.
-// the value lane SRC (< 16) holds -> every lane (the operands of these chains are uniform across the wave and every row of
-// 16 lanes holds the same four slots).  v_readlane: the results are SGPRs, and hipcc runs the additions / reductions
-// between the levels on the scalar unit (~190 SALU instructions per level, a doubling 1 440 instructions).  The VALU
-// form -- v_mov_b32_dpp row_newbcast:SRC, one instruction per limb, 1 230 instructions per doubling -- is behind
-// -DDG16_BCAST_DPP: it passed every emulated run and produced WRONG sums on the device (the instruction itself does
-// what its name says there: tools/ubench/dpp_probe.hip), so some hazard between the inline-asm products and a DPP
-// read is not covered by hipcc's recogniser; not shipped until it is understood (profiles/r4d_dpp.md).
-#ifdef DG16_BCAST_DPP
-// The DPP form as ONE asm statement per element: two wait states (a DPP read needs them after the VALU write of its
-// source, and hipcc cannot see a DPP inside an asm), then a v_mov_b32_dpp per limb -- opaque to hipcc's DPP combiner, which
-// turned the builtin form into v_sub_u32_dpp / v_subrev_u32_dpp ... row_newbcast (the build that gave wrong sums).
+// the value lane SRC (< 16) of every row of 16 lanes holds -> all lanes of the row: v_mov_b32_dpp row_newbcast:SRC, one
+// VALU instruction per limb (the operands of these chains are uniform across the wave and every row holds the same four
+// slots, so a row-local broadcast is a wave-wide one).  History (profiles/r4b_ab_variants.md, r4h_dpp.md):
+//   * v_readlane (first form): the results are SGPRs and hipcc runs the additions / reductions between the levels on
+//     the scalar unit -- ~190 SALU instructions per level, a doubling 1 440 instructions;
+//   * __builtin_amdgcn_update_dpp: 1 230 instructions per doubling, every emulated run passed -- and every MSM on the
+//     device was WRONG: hipcc's DPP combiner folds the broadcast into the subtraction that consumes it,
+//     v_subrev_u32_dpp ... row_newbcast, and that instruction does not compute S1 - dpp(S0) on gfx950 (60 of 64 lanes
+//     wrong in tools/ubench/dpp_probe.hip; v_mov_b32_dpp and v_sub_u32_dpp with the same control are right);
+//   * shipped: the moves as ONE opaque asm statement per element -- two wait states first (a DPP read needs them after
+//     the VALU write of its source and hipcc cannot see a DPP inside an asm), then a v_mov_b32_dpp per limb; nothing for
+//     the combiner to fold.  Same call, same box: plain 2^20 MSM 3.41 -> 3.15 ms (G1), 9.63 -> 9.00 ms (G2).
 template <int SRC, class P, int B>
 __device__ __forceinline__ Fe<P, B, 1> bcast29(const Fe<P, B, 1>& v) {
   static_assert(SRC >= 0 && SRC < 16, "row_newbcast takes a lane of the row");
@@ -1046,17 +1047,6 @@ __device__ __forceinline__ Fe<P, B, 1> bcast29(const Fe<P, B, 1>& v) {
   }
   return r;
 }
-#else
-template <int SRC, class P, int B>
-__device__ __forceinline__ Fe<P, B, 1> bcast29(const Fe<P, B, 1>& v) {
-  static_assert(SRC >= 0 && SRC < 16, "row_newbcast takes a lane of the row");
-  Fe<P, B, 1> r;
-#pragma unroll
-  for (int i = 0; i < RR<P>::N; i++)
-    r.l[i] = (uint32_t)__builtin_amdgcn_readlane((int)v.l[i], SRC);
-  return r;
-}
-#endif
 template <int SRC, class P, int B>
 __device__ __forceinline__ Fe2<P, B, 1> bcast29(const Fe2<P, B, 1>& v) {
   return {bcast29<SRC>(v.c0), bcast29<SRC>(v.c1)};
