@@ -23,6 +23,7 @@
 // histogram/offsets uint32 [W][2^(c-1)]; segment map uint32 and segment sums XYZZ [W][2^(c-1)+n/16];
 // buckets XYZZ [W][2^(c-1)].
 #pragma once
+#include <atomic>
 #include <stdio.h>
 
 #include <chrono>
@@ -753,7 +754,9 @@ msm_accumulate_kernel(MsmBases bases, size_t n,
 // SIMD, AGPR spills); with the coordinates in LDS between uses (layout [coordinate word][lane]: consecutive lanes ->
 // consecutive banks, conflict-free ds_read/write_b32) the live set is the loaded point and ~6 temporaries.
 // 4 coordinates x 2 N words x BLOCK lanes = 72 KiB for BN254 Fq2 at BLOCK = 256 (two workgroups per CU, 160 KiB LDS).
-template <class F, int BLOCK>
+// TU: 0 = instantiated in msm_group.hip (products as that unit compiles them: inline by default), 1 = in
+// msm_group_outl.hip (the 14-limb curves' second form, field products out of line) -- distinct symbols, both in the library
+template <class F, int BLOCK, int TU = 0>
 __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 ? 2 : 1))
 msm_accumulate_lds_kernel(MsmBases bases, size_t n, MsmGeom g,
                           const unsigned* __restrict__ offsets, const unsigned* __restrict__ counts,
@@ -1291,6 +1294,11 @@ template <class F>
 struct MsmBuffers;
 template <class F>
 void msm_finalize_lds_phase(hipStream_t s, const MsmSort& st, const MsmBuffers<F>& b);
+// the 14-limb Fq2 accumulation with out-of-line field products: defined (as explicit specialisations) in msm_group_outl.hip
+template <class F>
+void msm_accumulate_lds_outl(hipStream_t s, dim3 grid, MsmBases mb, size_t n, MsmGeom g, const unsigned* offsets,
+                             const unsigned* counts, const unsigned* seg_off, const unsigned* seg_total,
+                             const unsigned* entries, XYZZ29<F>* seg_sum, XYZZ29<F>* buckets);
 // Phase A (saturates the GPU): segment accumulation.  `bases` is the array of n points or, in table mode, the
 // table of W*n points -- in INTERNAL form (msm_to_internal_kernel / msm_table_kernel).
 // bases: b.ninst tables (or plain base arrays), one per instance
@@ -1302,9 +1310,53 @@ void msm_accumulate_phase(hipStream_t s, const MsmSort& st, const MsmBuffers<F>&
   if constexpr (sizeof(F) > 48) {
     // G2 (Fq2 coordinates): LDS-staged accumulator; two workgroups per CU must fit the 160 KiB of LDS
     constexpr int BLOCK = 1 << msm_acc_block_log<F>();
-    hipLaunchKernelGGL((msm_accumulate_lds_kernel<F, BLOCK>), dim3((g.seg_cap + BLOCK - 1) / BLOCK, g.bw * b.ninst),
-                       dim3(BLOCK), 0, s, mb, st.n, g, st.offsets, st.counts, st.seg_off, st.seg_total, st.entries,
-                       b.seg_sum, b.buckets);
+    const dim3 grid((g.seg_cap + BLOCK - 1) / BLOCK, g.bw * b.ninst);
+    auto inline_form = [&] {
+      hipLaunchKernelGGL((msm_accumulate_lds_kernel<F, BLOCK>), grid, dim3(BLOCK), 0, s, mb, st.n, g, st.offsets, st.counts,
+                         st.seg_off, st.seg_total, st.entries, b.seg_sum, b.buckets);
+    };
+    if constexpr (sizeof(F) > 64) {
+      // 14-limb Fq2: TWO forms of the kernel are in the library and the device picks.  Inline products: a 180-KB loop
+      // against a 64-KB instruction cache at one wave per SIMD -- 9.4 ms per 2^20-point launch on some boxes of the pool,
+      // 18.9 on others, same binary.  Products out of line (msm_group_outl.hip): 14.4 ms on both kinds.  The first
+      // launch of at least 2^20 entries on a device runs BOTH (the kernel is idempotent: it only writes its partials),
+      // timed with events, and the faster one serves from then on (one blocking measurement per process and curve;
+      // DG16_G2_14LIMB=inline|outline pins the choice).
+      static std::atomic<int> pick{[] {
+        const char* e = getenv("DG16_G2_14LIMB");
+        return !e ? -1 : (e[0] == 'o' ? 1 : e[0] == 'i' ? 0 : -1);
+      }()};
+      auto outline_form = [&] {
+        msm_accumulate_lds_outl<F>(s, grid, mb, st.n, g, st.offsets, st.counts, st.seg_off, st.seg_total, st.entries,
+                                   b.seg_sum, b.buckets);
+      };
+      int p = pick.load();
+      if (p < 0 && (size_t)g.rows * st.n * g.bw >= ((size_t)1 << 20)) {
+        hipEvent_t e0, e1, e2;
+        DG_HIP(hipEventCreate(&e0)); DG_HIP(hipEventCreate(&e1)); DG_HIP(hipEventCreate(&e2));
+        DG_HIP(hipEventRecord(e0, s));
+        inline_form();
+        DG_HIP(hipEventRecord(e1, s));
+        outline_form();
+        DG_HIP(hipEventRecord(e2, s));
+        DG_HIP(hipEventSynchronize(e2));
+        float t_in = 0, t_out = 0;
+        DG_HIP(hipEventElapsedTime(&t_in, e0, e1));
+        DG_HIP(hipEventElapsedTime(&t_out, e1, e2));
+        hipEventDestroy(e0); hipEventDestroy(e1); hipEventDestroy(e2);
+        p = t_out < 0.97f * t_in ? 1 : 0;
+        pick.store(p);
+        if (const char* v = getenv("DG16_VERBOSE"); v && atoi(v))
+          fprintf(stderr, "[dg16] 14-limb G2 accumulation: inline %.3f ms, out of line %.3f ms -> %s\n", t_in, t_out,
+                  p ? "out of line" : "inline");
+      } else if (p == 1) {
+        outline_form();
+      } else {
+        inline_form();
+      }
+    } else {
+      inline_form();
+    }
     if (b.acc_done) DG_HIP(hipEventRecord(b.acc_done, s));
     if (msm_finalize_lds_lpb()) msm_finalize_lds_phase<F>(s, st, b);
   } else {
