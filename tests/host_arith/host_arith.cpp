@@ -7,6 +7,7 @@
 #include "../../distributed-groth16_amd/csrc/consts_gen.h"
 #include "../../distributed-groth16_amd/csrc/ec.h"
 #include "../../distributed-groth16_amd/csrc/ec29.h"
+#include "../../distributed-groth16_amd/csrc/glv.h"
 
 using namespace dg16;
 
@@ -273,4 +274,17 @@ extern "C" int ha_codec(int curve, int group, int decode, int validate, const vo
   if (curve == 1) return codec_run<1>(group, decode, validate, (const uint8_t*)in, (uint8_t*)out, n, rc);
   if (curve == 2) return codec_run<2>(group, decode, validate, (const uint8_t*)in, (uint8_t*)out, n, rc);
   return -1;
+}
+
+// glv::split (csrc/glv.h) on n 8-word scalars: h1 / h2 = |k1| / |k2| with the sign in bit 255
+extern "C" int ha_glv_split(int curve, const uint32_t* k, uint32_t* h1, uint32_t* h2, size_t n) {
+  for (size_t i = 0; i < n; i++) {
+    switch (curve) {
+      case 0: glv::split<bn254_glv_consts>(k + 8 * i, h1 + 8 * i, h2 + 8 * i); break;
+      case 1: glv::split<bls12_381_glv_consts>(k + 8 * i, h1 + 8 * i, h2 + 8 * i); break;
+      case 2: glv::split<bls12_377_glv_consts>(k + 8 * i, h1 + 8 * i, h2 + 8 * i); break;
+      default: return -1;
+    }
+  }
+  return 0;
 }

@@ -256,6 +256,34 @@ def test_curve_constants_recomputed(curve, group):
             raise AssertionError("r is composite?")
 
 
+@pytest.mark.parametrize("curve", ["bn254", "bls12_381", "bls12_377"])
+def test_glv_constants_recomputed(curve):
+    """<curve>_glv_consts (csrc/glv.h): BETA and LAMBDA are primitive cube roots of unity of Fq / Fr with
+    (BETA x, y) = LAMBDA (x, y) on the generator (long-hand affine ladder, nothing of the oracle), (a1, b1), (a2, b2) lie
+    in the lattice {a + b LAMBDA = 0 mod r}, have determinant +r and the orientation b1 < 0 < b2 glv::split assumes, are
+    SHORT (every entry below 2^128: the halves' bound), and G1 / G2 are the nearest integers to 2^256 b2 / r, 2^256 |b1| / r."""
+    q, r = family(curve)
+    nl = NL64[curve]
+    Rinv = egcd_inv(doubling_pow2(64 * nl, q), q)
+    text = open(HIP_H).read()
+    blk = text[text.index("struct %s_glv_consts {" % curve):]
+    blk = blk[:blk.index("\n};")]
+    val = {m.group(1): sum(int(x.strip().rstrip("u"), 16) << (32 * i) for i, x in enumerate(m.group(2).split(",")))
+           for m in re.finditer(r"static constexpr uint32_t (\w+)\[\d+\] = \{([^}]*)\}", blk)}
+    neg = {m.group(1): m.group(2) == "true" for m in re.finditer(r"static constexpr bool (\w+)_NEG = (\w+);", blk)}
+    beta, lam = val["BETA"] * Rinv % q, val["LAMBDA"]
+    assert beta != 1 and sqmul(beta, 3, q) == 1 and lam != 1 and sqmul(lam, 3, r) == 1 and 1 < lam < r
+    g = HIP["%s_g1_consts" % curve]
+    G = (g["GX"] * Rinv % q, g["GY"] * Rinv % q)
+    assert ladder(Fp1(q), G, lam) == (beta * G[0] % q, G[1])
+    a1, b1, a2, b2 = ((-val[k] if neg[k] else val[k]) for k in ("A1", "B1", "A2", "B2"))
+    assert (a1 + b1 * lam) % r == 0 and (a2 + b2 * lam) % r == 0
+    assert a1 * b2 - a2 * b1 == r and b1 < 0 < b2
+    assert max(abs(v) for v in (a1, b1, a2, b2)) < 1 << 128
+    for gk, b in (("G1", b2), ("G2", -b1)):
+        assert abs(val[gk] * r - (b << 256)) * 2 <= r
+
+
 # ---- the compile-time constants of fp29.h (RR<P>) -------------------------------------------------------------------------
 SRC = os.path.join(HERE, "host_arith", "host_arith.cpp")
 SO = os.path.join(HERE, "host_arith", "libhost_arith.so")

@@ -21,7 +21,7 @@ SO = os.path.join(HERE, "host_arith", "libhost_arith.so")
 @pytest.fixture(scope="module")
 def ha():
     hdrs = [os.path.join(HERE, "..", "distributed-groth16_amd", "csrc", f)
-            for f in ("fp.h", "fp2.h", "ec.h", "consts_gen.h", "fp29.h", "ec29.h", "codec_impl.h", "types.h")]
+            for f in ("fp.h", "fp2.h", "ec.h", "consts_gen.h", "fp29.h", "ec29.h", "codec_impl.h", "types.h", "glv.h")]
     if not os.path.exists(SO) or any(os.path.getmtime(SO) < os.path.getmtime(p) for p in [SRC] + hdrs):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", SO, SRC])
     L = ctypes.CDLL(SO)
@@ -31,6 +31,7 @@ def ha():
     L.ha_field_op29.argtypes = [i, i, vp, vp, vp, sz]
     L.ha_point_op29.argtypes = [i, i, i, vp, vp, vp, sz]
     L.ha_codec.argtypes = [i, i, i, i, vp, vp, sz, vp]
+    L.ha_glv_split.argtypes = [i, vp, vp, vp, sz]
     return L
 
 
@@ -252,3 +253,38 @@ def test_point_codec_host_bls12_381_zcash_form(ha, group):
     assert rc[0] == 0 and np.array_equal(dec.view(np.uint64).reshape(1, -1), _affine_arr(curve, group, [outside]))
     _, rc = _codec(ha, curve, group, 1, 1, raw, 1, pb)
     assert rc[0] == 4
+
+
+@pytest.mark.parametrize("curve", ["bn254", "bls12_381", "bls12_377"])
+def test_glv_split_is_exact_and_short(ha, curve):
+    """csrc/glv.h: k = k1 + k2 LAMBDA (mod r) for every scalar, the halves equal the same integer arithmetic done with
+    Python integers on the constants of the header (division-free rounding included), and |k1|, |k2| < 2^127 -- the
+    bound kGlvBits of msm_impl.h rests on -- over edge values, every 255-bit corner and 200 000 random scalars."""
+    import re
+    hdr = os.path.join(HERE, "..", "distributed-groth16_amd", "csrc", "consts_gen.h")
+    text = open(hdr).read()
+    blk = text[text.index("struct %s_glv_consts {" % curve):]
+    blk = blk[:blk.index("\n};")]
+    val = {}
+    for m in re.finditer(r"static constexpr uint32_t (\w+)\[\d+\] = \{([^}]*)\}", blk):
+        val[m.group(1)] = sum(int(x.strip().rstrip("u"), 16) << (32 * i) for i, x in enumerate(m.group(2).split(",")))
+    sign = {m.group(1): -1 if m.group(2) == "true" else 1 for m in re.finditer(r"static constexpr bool (\w+)_NEG = (\w+);", blk)}
+    a1, b1, a2, b2 = (sign[k] * val[k] for k in ("A1", "B1", "A2", "B2"))
+    lam, r = val["LAMBDA"], FR[curve].p
+    rng = random.Random(17)
+    ks = [0, 1, 2, r - 1, r - 2, (r - 1) // 2, (r + 1) // 2, lam, r - lam, lam - 1, (1 << 254) - 1, (1 << 255) - 1, 1 << 254,
+          val["B2"], val["B1"], r // 3, 2 * r // 3]
+    ks += [rng.randrange(r) for _ in range(200000)] + [rng.randrange(1 << 255) for _ in range(20000)]
+    K = corc.ints_to_arr(ks, 4)
+    H1, H2 = np.zeros_like(K), np.zeros_like(K)
+    assert ha.ha_glv_split({"bn254": 0, "bls12_381": 1, "bls12_377": 2}[curve], _p(K), _p(H1), _p(H2), len(ks)) == 0
+    g1, g2 = corc.arr_to_ints(H1), corc.arr_to_ints(H2)
+    worst = 0
+    for k, x1, x2 in zip(ks, g1, g2):
+        c1, c2 = (val["G1"] * k + (1 << 255)) >> 256, (val["G2"] * k + (1 << 255)) >> 256
+        k1, k2 = k - c1 * a1 - c2 * a2, -c1 * b1 - c2 * b2
+        assert (k1 + k2 * lam - k) % r == 0
+        dec = lambda x: -(x & ((1 << 255) - 1)) if x >> 255 else x      # noqa: E731
+        assert (dec(x1), dec(x2)) == (k1, k2), hex(k)
+        worst = max(worst, abs(k1), abs(k2))
+    assert worst < 1 << 127, worst.bit_length()
