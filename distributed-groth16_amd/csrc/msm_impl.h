@@ -1708,9 +1708,39 @@ void msm_reduce(Call& k, const MsmSort& st, const void* bases, bool out_affine, 
 
 // ---- GLV for the plain G1 MSM (glv.h): 2n points (P_i, phi(P_i)), 127-bit half scalars, half the windows ------------
 template <class F> struct GlvOf { static constexpr bool enabled = false; };
-template <> struct GlvOf<Fp<bn254_fq_params>> { static constexpr bool enabled = true; using C = bn254_glv_consts; };
-template <> struct GlvOf<Fp<bls12_381_fq_params>> { static constexpr bool enabled = true; using C = bls12_381_glv_consts; };
-template <> struct GlvOf<Fp<bls12_377_fq_params>> { static constexpr bool enabled = true; using C = bls12_377_glv_consts; };
+// G1 of the three curves (j = 0): phi(x, y) = (BETA x, y)
+template <class P, class GC>
+struct GlvG1 {
+  static constexpr bool enabled = true;
+  using C = GC;
+  DG_HD static void endo(Affine<Fp<P>>& p) {
+    Fp<P> beta;
+#pragma unroll
+    for (int k = 0; k < Fp<P>::NL; k++) beta.l[k] = GC::BETA[k];
+    p.x = p.x * beta;
+  }
+};
+template <> struct GlvOf<Fp<bn254_fq_params>> : GlvG1<bn254_fq_params, bn254_glv_consts> {};
+template <> struct GlvOf<Fp<bls12_381_fq_params>> : GlvG1<bls12_381_fq_params, bls12_381_glv_consts> {};
+template <> struct GlvOf<Fp<bls12_377_fq_params>> : GlvG1<bls12_377_fq_params, bls12_377_glv_consts> {};
+// G2 of BN254: psi(x, y) = (GAMMA_X conj(x), GAMMA_Y conj(y)) = LAMBDA (x, y), LAMBDA = +-q mod r ~ 2^127 (a BLS12 curve
+// has q = u mod r, 64 bits: its two-dimensional lattice is lopsided and the four-dimensional form is not built)
+template <> struct GlvOf<Fp2<Fp<bn254_fq_params>>> {
+  static constexpr bool enabled = true;
+  using C = bn254_g2_glv_consts;
+  using Fq = Fp<bn254_fq_params>;
+  DG_HD static void endo(Affine<Fp2<Fq>>& p) {
+    Fp2<Fq> gx, gy;
+#pragma unroll
+    for (int k = 0; k < Fq::NL; k++) {
+      gx.c0.l[k] = C::GAMMA_X_C0[k]; gx.c1.l[k] = C::GAMMA_X_C1[k];
+      gy.c0.l[k] = C::GAMMA_Y_C0[k]; gy.c1.l[k] = C::GAMMA_Y_C1[k];
+    }
+    if (p.is_inf()) return;
+    p.x = Fp2<Fq>{p.x.c0, p.x.c1.neg()} * gx;
+    p.y = Fp2<Fq>{p.y.c0, p.y.c1.neg()} * gy;
+  }
+};
 constexpr int kGlvBits = 127;      // |k1|, |k2| < 2^127 (measured bound: 0.81 x 2^127 over all 255-bit inputs; tests/test_host_arith.py)
 
 template <class Fr, class GC>
@@ -1725,8 +1755,8 @@ __global__ void __launch_bounds__(256) glv_split_kernel(const Fr* __restrict__ s
   halves[i] = h1;
   halves[n + i] = h2;
 }
-// bases -> internal form, twice: P_i at i, phi(P_i) = (BETA x_i, y_i) at n + i (the identity (0, 0) maps to itself)
-template <class F, class GC>
+// bases -> internal form, twice: P_i at i, its image under the endomorphism at n + i (the identity (0, 0) maps to itself)
+template <class F>
 __global__ void __launch_bounds__(256) msm_to_internal_glv_kernel(const Affine<F>* __restrict__ in, size_t n,
                                                                    uint32_t* __restrict__ out) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1738,10 +1768,7 @@ __global__ void __launch_bounds__(256) msm_to_internal_glv_kernel(const Affine<F
   uint4* dst = reinterpret_cast<uint4*>(out + i * PW);
 #pragma unroll
   for (int k = 0; k < PW / 4; k++) dst[k] = make_uint4(w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]);
-  F beta;
-#pragma unroll
-  for (int k = 0; k < F::NL; k++) beta.l[k] = GC::BETA[k];
-  p.x = p.x * beta;
+  GlvOf<F>::endo(p);
   affine_to_internal(p, w);
   dst = reinterpret_cast<uint4*>(out + (n + i) * PW);
 #pragma unroll
@@ -1752,7 +1779,7 @@ template <class F, class Fr, int SCALAR_BITS>
 void msm_run(Call& k, const void* bases, const void* scalars, size_t n, bool scalars_mont, bool out_affine,
              void* out_dev) {
   if constexpr (GlvOf<F>::enabled) {
-    // G1: split every scalar with the curve's endomorphism (DG16_MSM_GLV=0 switches it off).  Same number of bucket
+    // G1 (and BN254's G2): split every scalar with the curve's endomorphism (DG16_MSM_GLV=0 switches it off).  Same number of bucket
     // entries (2n points x half the windows), half the windows: half the dependent doublings of the Horner tail, half the
     // bucket sets to reduce, twice the entries per bucket (longer, better balanced accumulation segments).
     static const bool glv_on = [] { const char* e = getenv("DG16_MSM_GLV"); return !e || atoi(e) != 0; }();
@@ -1763,7 +1790,7 @@ void msm_run(Call& k, const void* bases, const void* scalars, size_t n, bool sca
                          (const Fr*)scalars, n, (int)scalars_mont, halves);
       MsmSort st = msm_sort<Fr, kGlvBits>(k, halves, 2 * n, false, false);
       uint32_t* internal = (uint32_t*)ws(k.c, 24, 2 * n * sizeof(Affine<F>));
-      hipLaunchKernelGGL((msm_to_internal_glv_kernel<F, GC>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, k.s(),
+      hipLaunchKernelGGL(msm_to_internal_glv_kernel<F>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, k.s(),
                          (const Affine<F>*)bases, n, internal);
       msm_reduce<F>(k, st, internal, out_affine, out_dev);
       return;

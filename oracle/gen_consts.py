@@ -101,6 +101,65 @@ def glv_entries(cname):
     return dict(LAMBDA=lam, BETA=beta, A1=a1, B1=b1, A2=a2, B2=b2, G1=g1, G2=g2)
 
 
+def glv_lattice(r, lam):
+    """reduced basis of {(a, b): a + b lam = 0 mod r} with det = +r, b1 < 0 < b2, and the rounding multipliers"""
+    import math
+    seq, r0, r1, t0, t1 = [], r, lam, 0, 1
+    while r1:
+        qq = r0 // r1
+        r0, r1, t0, t1 = r1, r0 - qq * r1, t1, t0 - qq * t1
+        seq.append((r0, -t0))
+    i = next(j for j, (ri, _) in enumerate(seq) if ri < math.isqrt(r))
+    v1 = seq[i]
+    v2 = min([seq[i - 1]] + ([seq[i + 1]] if i + 1 < len(seq) else []), key=lambda v: v[0] ** 2 + v[1] ** 2)
+    if v1[1] > 0:
+        v1 = (-v1[0], -v1[1])
+    if v2[1] < 0:
+        v2 = (-v2[0], -v2[1])
+    if v1[0] * v2[1] - v2[0] * v1[1] < 0:
+        v1, v2 = (-v2[0], -v2[1]), (-v1[0], -v1[1])
+    (a1, b1), (a2, b2) = v1, v2
+    assert b1 < 0 < b2 and a1 * b2 - a2 * b1 == r and (a1 + b1 * lam) % r == 0 and (a2 + b2 * lam) % r == 0
+    return dict(LAMBDA=lam, A1=a1, B1=b1, A2=a2, B2=b2, G1=((b2 << 256) + r // 2) // r, G2=((-b1 << 256) + r // 2) // r)
+
+
+def glv_g2_entries(cname):
+    """BN254's G2: psi(x, y) = (GAMMA_X conj(x), GAMMA_Y conj(y)) -- untwist, Frobenius, twist: GAMMA_X = xi^((q-1)/3),
+    GAMMA_Y = xi^((q-1)/2) or their inverses -- acts on the order-r subgroup as multiplication by LAMBDA = +-q mod r
+    (~2^127 for a BN curve, so the two-dimensional lattice is balanced; a BLS12 curve has q = u mod r, 64 bits, and
+    needs the four-dimensional form: not built).  The combination is found on the generator."""
+    assert cname == "bn254"
+    C = CURVES[cname, "g2"]
+    F2, r = C.F, FR[cname].p
+    q = F2.p
+
+    def f2pow(a, e):
+        res = (1, 0)
+        while e:
+            if e & 1:
+                res = F2.mul(res, a)
+            a = F2.mul(a, a)
+            e >>= 1
+        return res
+
+    conj = lambda a: (a[0], (-a[1]) % q)   # noqa: E731
+    xi = (9, 1)
+    gx, gy = f2pow(xi, (q - 1) // 3), f2pow(xi, (q - 1) // 2)
+    G = C.gen
+    hits = []
+    for cx in (gx, F2.inv(gx)):
+        for cy in (gy, F2.inv(gy)):
+            P = (F2.mul(cx, conj(G[0])), F2.mul(cy, conj(G[1])))
+            for lam in (q % r, (-q) % r):
+                if C.mul(G, lam) == P:
+                    hits.append((cx, cy, lam))
+    assert len(hits) == 1, hits
+    cx, cy, lam = hits[0]
+    e = glv_lattice(r, lam)
+    e.update(GAMMA_X=cx, GAMMA_Y=cy)
+    return e
+
+
 def emit_c64():
     o = ["/* GENERATED by oracle/gen_consts.py -- do not edit. 64-bit limbs, little endian;",
          "   field elements are in Montgomery form with R = 2^(64*limbs). */",
@@ -189,6 +248,24 @@ def emit_hip32():
             o.append("  static constexpr uint32_t %s[5] = %s;" % (k, arr(e[k], 5, 32)))
         o.append("};")
         o.append("")
+    e = glv_g2_entries("bn254")
+    F = FQ["bn254"]
+    n = 2 * F.limbs64
+    o.append("struct bn254_g2_glv_consts {")
+    for nm in ("GAMMA_X", "GAMMA_Y"):
+        for ci in (0, 1):
+            o.append("  static constexpr uint32_t %s_C%d[%d] = %s;   // arkworks Montgomery form" %
+                     (nm, ci, n, arr(e[nm][ci] * F.R % F.p, n, 32)))
+    o.append("  static constexpr uint32_t LAMBDA[8] = %s;   // plain integer" % arr(e["LAMBDA"], 8, 32))
+    for k in ("A1", "B1", "A2", "B2"):
+        assert abs(e[k]) < 1 << 160
+        o.append("  static constexpr uint32_t %s[5] = %s;   // |%s|" % (k, arr(abs(e[k]), 5, 32), k.lower()))
+        o.append("  static constexpr bool %s_NEG = %s;" % (k, "true" if e[k] < 0 else "false"))
+    for k in ("G1", "G2"):
+        assert e[k] < 1 << 160
+        o.append("  static constexpr uint32_t %s[5] = %s;" % (k, arr(e[k], 5, 32)))
+    o.append("};")
+    o.append("")
     o.append("}  // namespace dg16")
     return "\n".join(o) + "\n"
 

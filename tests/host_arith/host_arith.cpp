@@ -283,6 +283,7 @@ extern "C" int ha_glv_split(int curve, const uint32_t* k, uint32_t* h1, uint32_t
       case 0: glv::split<bn254_glv_consts>(k + 8 * i, h1 + 8 * i, h2 + 8 * i); break;
       case 1: glv::split<bls12_381_glv_consts>(k + 8 * i, h1 + 8 * i, h2 + 8 * i); break;
       case 2: glv::split<bls12_377_glv_consts>(k + 8 * i, h1 + 8 * i, h2 + 8 * i); break;
+      case 3: glv::split<bn254_g2_glv_consts>(k + 8 * i, h1 + 8 * i, h2 + 8 * i); break;
       default: return -1;
     }
   }

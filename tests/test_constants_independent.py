@@ -284,6 +284,44 @@ def test_glv_constants_recomputed(curve):
         assert abs(val[gk] * r - (b << 256)) * 2 <= r
 
 
+def test_glv_constants_of_bn254_g2_recomputed():
+    """bn254_g2_glv_consts: psi(x, y) = (GAMMA_X conj(x), GAMMA_Y conj(y)) is multiplication by LAMBDA on the generator of
+    G2 (long-hand ladder over Fq2), LAMBDA = +-q mod r, GAMMA_X^3 and GAMMA_Y^2 are what untwist-Frobenius-twist makes them
+    (xi^(q-1) up to inversion), and the lattice / multipliers satisfy what glv::split assumes."""
+    q, r = family("bn254")
+    Rinv = egcd_inv(doubling_pow2(256, q), q)
+    text = open(HIP_H).read()
+    blk = text[text.index("struct bn254_g2_glv_consts {"):]
+    blk = blk[:blk.index("\n};")]
+    val = {m.group(1): sum(int(x.strip().rstrip("u"), 16) << (32 * i) for i, x in enumerate(m.group(2).split(",")))
+           for m in re.finditer(r"static constexpr uint32_t (\w+)\[\d+\] = \{([^}]*)\}", blk)}
+    neg = {m.group(1): m.group(2) == "true" for m in re.finditer(r"static constexpr bool (\w+)_NEG = (\w+);", blk)}
+    F = Fp2(q, 1)
+    dec = lambda k: (val[k + "_C0"] * Rinv % q, val[k + "_C1"] * Rinv % q)     # noqa: E731
+    gx, gy, lam = dec("GAMMA_X"), dec("GAMMA_Y"), val["LAMBDA"]
+    assert lam in (q % r, (-q) % r)
+    g = HIP["bn254_g2_consts"]
+    one = lambda k: (g[k + "_C0"] * Rinv % q, g[k + "_C1"] * Rinv % q)         # noqa: E731
+    G = (one("GX"), one("GY"))
+    conj = lambda a: (a[0], (-a[1]) % q)                                        # noqa: E731
+    assert ladder(F, G, lam) == (F.mul(gx, conj(G[0])), F.mul(gy, conj(G[1])))
+    # xi^(q-1) = GAMMA_X^(+-3) = GAMMA_Y^(+-2), xi = 9 + u
+    def f2pow(a, e):
+        acc = (1, 0)
+        for bit in bin(e)[2:]:
+            acc = F.mul(acc, acc)
+            if bit == "1":
+                acc = F.mul(acc, a)
+        return acc
+    xq = f2pow((9, 1), q - 1)
+    assert f2pow(gx, 3) in (xq, F.inv(xq)) and f2pow(gy, 2) in (xq, F.inv(xq))
+    a1, b1, a2, b2 = ((-val[k] if neg[k] else val[k]) for k in ("A1", "B1", "A2", "B2"))
+    assert (a1 + b1 * lam) % r == 0 and (a2 + b2 * lam) % r == 0 and a1 * b2 - a2 * b1 == r and b1 < 0 < b2
+    assert max(abs(v) for v in (a1, b1, a2, b2)) < 1 << 128
+    for gk, b in (("G1", b2), ("G2", -b1)):
+        assert abs(val[gk] * r - (b << 256)) * 2 <= r
+
+
 # ---- the compile-time constants of fp29.h (RR<P>) -------------------------------------------------------------------------
 SRC = os.path.join(HERE, "host_arith", "host_arith.cpp")
 SO = os.path.join(HERE, "host_arith", "libhost_arith.so")

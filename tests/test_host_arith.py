@@ -255,7 +255,7 @@ def test_point_codec_host_bls12_381_zcash_form(ha, group):
     assert rc[0] == 4
 
 
-@pytest.mark.parametrize("curve", ["bn254", "bls12_381", "bls12_377"])
+@pytest.mark.parametrize("curve", ["bn254", "bls12_381", "bls12_377", "bn254_g2"])
 def test_glv_split_is_exact_and_short(ha, curve):
     """csrc/glv.h: k = k1 + k2 LAMBDA (mod r) for every scalar, the halves equal the same integer arithmetic done with
     Python integers on the constants of the header (division-free rounding included), and |k1|, |k2| < 2^127 -- the
@@ -270,14 +270,14 @@ def test_glv_split_is_exact_and_short(ha, curve):
         val[m.group(1)] = sum(int(x.strip().rstrip("u"), 16) << (32 * i) for i, x in enumerate(m.group(2).split(",")))
     sign = {m.group(1): -1 if m.group(2) == "true" else 1 for m in re.finditer(r"static constexpr bool (\w+)_NEG = (\w+);", blk)}
     a1, b1, a2, b2 = (sign[k] * val[k] for k in ("A1", "B1", "A2", "B2"))
-    lam, r = val["LAMBDA"], FR[curve].p
+    lam, r = val["LAMBDA"], FR[curve.split("_g2")[0]].p
     rng = random.Random(17)
     ks = [0, 1, 2, r - 1, r - 2, (r - 1) // 2, (r + 1) // 2, lam, r - lam, lam - 1, (1 << 254) - 1, (1 << 255) - 1, 1 << 254,
           val["B2"], val["B1"], r // 3, 2 * r // 3]
     ks += [rng.randrange(r) for _ in range(200000)] + [rng.randrange(1 << 255) for _ in range(20000)]
     K = corc.ints_to_arr(ks, 4)
     H1, H2 = np.zeros_like(K), np.zeros_like(K)
-    assert ha.ha_glv_split({"bn254": 0, "bls12_381": 1, "bls12_377": 2}[curve], _p(K), _p(H1), _p(H2), len(ks)) == 0
+    assert ha.ha_glv_split({"bn254": 0, "bls12_381": 1, "bls12_377": 2, "bn254_g2": 3}[curve], _p(K), _p(H1), _p(H2), len(ks)) == 0
     g1, g2 = corc.arr_to_ints(H1), corc.arr_to_ints(H2)
     worst = 0
     for k, x1, x2 in zip(ks, g1, g2):
