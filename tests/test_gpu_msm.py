@@ -248,6 +248,32 @@ def test_resident_msm_under_a_table_budget(curve, group, log_n, rows):
     c.close()
 
 
+def test_resident_msm_2e22_rows_in_chunks():
+    """A 2^22-point resident table has ONE bucket set of 2^18 buckets = 1024 rows: the size from which the bucket reduction
+    runs msm_rowchunk_kernel + the top kernel's folded mode on a table's bucket set (256 chunk workgroups, k = 2).  Checked
+    against the plain MSM of the same inputs (GLV: 2^23 points, 8 windows of 2^15 buckets -- the two paths share no
+    reduction geometry) and against the oracle's MSM."""
+    import torch
+    curve, n = "bn254", 1 << 22
+    c = ctx()
+    dev = torch.device("cuda:0")
+    bases = torch.empty(n * 64, dtype=torch.uint8, device=dev)
+    c.gen_bases_dev(curve, 1, 78, n, bases.data_ptr())
+    c.sync(0)
+    sc_h = corc.rand_field(curve, "fr", 6, n, mont=False)
+    sc = torch.from_numpy(sc_h.view(np.int64)).to(dev)
+    out = torch.empty((2, 64), dtype=torch.uint8, device=dev)
+    hb = c.bases_upload(curve, 1, bases.data_ptr(), n=n, device_ptrs=True)
+    c.msm_resident_dev(hb, sc.data_ptr(), n, out[0].data_ptr(), affine=True)
+    c.msm_dev(curve, 1, bases.data_ptr(), sc.data_ptr(), n, out[1].data_ptr(), affine=True)
+    c.sync(0)
+    o = out.cpu().numpy()
+    assert np.array_equal(o[0], o[1]) and o[0].any()
+    exp = corc.msm(curve, 1, bases.cpu().numpy().view(np.uint64).reshape(n, 8), sc_h, threads=32)
+    assert np.array_equal(o[0].view(np.uint64).reshape(1, 8), exp)
+    hb.close()
+
+
 def test_resident_msm_2e20_equals_plain_msm():
     """BASELINE config 2's size through the resident path: same point as dg16_msm (itself oracle-checked above)."""
     import torch
