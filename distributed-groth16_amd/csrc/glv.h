@@ -98,5 +98,43 @@ DG_HD void split(const uint32_t* k, uint32_t* h1, uint32_t* h2) {
   if (n2) h2[7] |= 0x80000000u;
 }
 
+// The four-dimensional form for G2 (psi, psi^2, psi^3: <curve>_g2_glv4_consts): k -> four quarters of at most 64 bits,
+//     k = k0 + k1 LAMBDA + k2 LAMBDA^2 + k3 LAMBDA^3 (mod r)
+// Babai rounding on an LLL-reduced basis B: c_i = round(k A_i / det) through the multipliers G_i (the sign of c_i is a
+// constant of the curve), k_j = [j = 0] k - sum_i c_i B[i][j].  Outputs as in split(): magnitude, sign in bit 255.
+template <class GC>
+DG_HD void split4(const uint32_t* k, uint32_t* h0, uint32_t* h1, uint32_t* h2, uint32_t* h3) {
+  uint32_t c[4][7];
+  {
+    uint32_t t[15];
+    uint32_t half[15];
+#pragma unroll
+    for (int i = 0; i < 15; i++) half[i] = i == 7 ? 0x80000000u : 0u;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      mul_words<7, 8>(GC::G[i], k, t);
+      add_words<15>(t, half, false);
+#pragma unroll
+      for (int w = 0; w < 7; w++) c[i][w] = t[8 + w];
+    }
+  }
+  uint32_t* out[4] = {h0, h1, h2, h3};
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    uint32_t acc[11];
+#pragma unroll
+    for (int w = 0; w < 11; w++) acc[w] = (j == 0 && w < 8) ? k[w] : 0u;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      uint32_t p[11];
+      mul_words<7, 3>(c[i], GC::B[4 * i + j], p);
+      p[10] = 0;
+      // the term c_i B[i][j] is negative iff exactly one of its factors is; k_j -= term
+      add_words<11>(acc, p, GC::C_NEG[i] == GC::B_NEG[4 * i + j]);
+    }
+    if (magnitude<11>(acc, out[j])) out[j][7] |= 0x80000000u;
+  }
+}
+
 }  // namespace glv
 }  // namespace dg16

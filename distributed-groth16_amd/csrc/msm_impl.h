@@ -1712,6 +1712,7 @@ template <class F> struct GlvOf { static constexpr bool enabled = false; };
 template <class P, class GC>
 struct GlvG1 {
   static constexpr bool enabled = true;
+  static constexpr int DIM = 2;
   using C = GC;
   DG_HD static void endo(Affine<Fp<P>>& p) {
     Fp<P> beta;
@@ -1723,25 +1724,36 @@ struct GlvG1 {
 template <> struct GlvOf<Fp<bn254_fq_params>> : GlvG1<bn254_fq_params, bn254_glv_consts> {};
 template <> struct GlvOf<Fp<bls12_381_fq_params>> : GlvG1<bls12_381_fq_params, bls12_381_glv_consts> {};
 template <> struct GlvOf<Fp<bls12_377_fq_params>> : GlvG1<bls12_377_fq_params, bls12_377_glv_consts> {};
-// G2 of BN254: psi(x, y) = (GAMMA_X conj(x), GAMMA_Y conj(y)) = LAMBDA (x, y), LAMBDA = +-q mod r ~ 2^127 (a BLS12 curve
-// has q = u mod r, 64 bits: its two-dimensional lattice is lopsided and the four-dimensional form is not built)
-template <> struct GlvOf<Fp2<Fp<bn254_fq_params>>> {
+// G2 of the three curves: psi(x, y) = (GAMMA_X conj(x), GAMMA_Y conj(y)) = LAMBDA (x, y) (untwist, Frobenius, twist),
+// LAMBDA a root of x^4 - x^2 + 1 mod r.  DIM = 4: the four-dimensional split (glv.h: split4) -- 4n points P, psi P,
+// psi^2 P, psi^3 P and quarters of at most 65 bits; DIM = 2: split() over psi alone.
+template <class P, class GC, int D>
+struct GlvG2 {
   static constexpr bool enabled = true;
-  using C = bn254_g2_glv_consts;
-  using Fq = Fp<bn254_fq_params>;
+  static constexpr int DIM = D;
+  using C = GC;
+  using Fq = Fp<P>;
   DG_HD static void endo(Affine<Fp2<Fq>>& p) {
+    if (p.is_inf()) return;
     Fp2<Fq> gx, gy;
 #pragma unroll
     for (int k = 0; k < Fq::NL; k++) {
-      gx.c0.l[k] = C::GAMMA_X_C0[k]; gx.c1.l[k] = C::GAMMA_X_C1[k];
-      gy.c0.l[k] = C::GAMMA_Y_C0[k]; gy.c1.l[k] = C::GAMMA_Y_C1[k];
+      gx.c0.l[k] = GC::GAMMA_X_C0[k]; gx.c1.l[k] = GC::GAMMA_X_C1[k];
+      gy.c0.l[k] = GC::GAMMA_Y_C0[k]; gy.c1.l[k] = GC::GAMMA_Y_C1[k];
     }
-    if (p.is_inf()) return;
     p.x = Fp2<Fq>{p.x.c0, p.x.c1.neg()} * gx;
     p.y = Fp2<Fq>{p.y.c0, p.y.c1.neg()} * gy;
   }
 };
+// BN254: LAMBDA ~ 2^127, so the TWO-dimensional split over psi alone is balanced too, and it is the faster one there
+// (2^20 points: 6.93 ms against 7.24 for the four-dimensional form, same call -- twice the points to sort and convert
+// and a fifth, nearly empty window cost more than the shorter tail saves: profiles/r4n_glv4_ab.txt).  A BLS12 curve has
+// q = u mod r, 64 bits: only the four-dimensional form is balanced (BLS12-381 2^20: 19.8 -> 16.2 ms).
+template <> struct GlvOf<Fp2<Fp<bn254_fq_params>>> : GlvG2<bn254_fq_params, bn254_g2_glv_consts, 2> {};
+template <> struct GlvOf<Fp2<Fp<bls12_381_fq_params>>> : GlvG2<bls12_381_fq_params, bls12_381_g2_glv4_consts, 4> {};
+template <> struct GlvOf<Fp2<Fp<bls12_377_fq_params>>> : GlvG2<bls12_377_fq_params, bls12_377_g2_glv4_consts, 4> {};
 constexpr int kGlvBits = 127;      // |k1|, |k2| < 2^127 (measured bound: 0.81 x 2^127 over all 255-bit inputs; tests/test_host_arith.py)
+constexpr int kGlv4Bits = 65;      // the quarters of split4: < 2^65 (BLS12-381: 0.52 x 2^64 for canonical scalars; one spare bit for non-canonical 255-bit inputs)
 
 template <class Fr, class GC>
 __global__ void __launch_bounds__(256) glv_split_kernel(const Fr* __restrict__ scalars, size_t n, int mont,
@@ -1755,7 +1767,21 @@ __global__ void __launch_bounds__(256) glv_split_kernel(const Fr* __restrict__ s
   halves[i] = h1;
   halves[n + i] = h2;
 }
-// bases -> internal form, twice: P_i at i, its image under the endomorphism at n + i (the identity (0, 0) maps to itself)
+template <class Fr, class GC>
+__global__ void __launch_bounds__(256) glv_split4_kernel(const Fr* __restrict__ scalars, size_t n, int mont,
+                                                          Fr* __restrict__ quarters /* [4 n]: |k0| .., |k1| .., .. */) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Fr s = scalars[i];
+  if (mont) s = s.from_mont();
+  Fr h0, h1, h2, h3;
+  glv::split4<GC>(s.l, h0.l, h1.l, h2.l, h3.l);
+  quarters[i] = h0;
+  quarters[n + i] = h1;
+  quarters[2 * n + i] = h2;
+  quarters[3 * n + i] = h3;
+}
+// bases -> internal form, DIM times: P_i at i, its images under the endomorphism at n + i, 2n + i, .. (the identity maps to itself)
 template <class F>
 __global__ void __launch_bounds__(256) msm_to_internal_glv_kernel(const Affine<F>* __restrict__ in, size_t n,
                                                                    uint32_t* __restrict__ out) {
@@ -1768,11 +1794,14 @@ __global__ void __launch_bounds__(256) msm_to_internal_glv_kernel(const Affine<F
   uint4* dst = reinterpret_cast<uint4*>(out + i * PW);
 #pragma unroll
   for (int k = 0; k < PW / 4; k++) dst[k] = make_uint4(w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]);
-  GlvOf<F>::endo(p);
-  affine_to_internal(p, w);
-  dst = reinterpret_cast<uint4*>(out + (n + i) * PW);
+#pragma unroll 1
+  for (int img = 1; img < GlvOf<F>::DIM; img++) {
+    GlvOf<F>::endo(p);
+    affine_to_internal(p, w);
+    dst = reinterpret_cast<uint4*>(out + ((size_t)img * n + i) * PW);
 #pragma unroll
-  for (int k = 0; k < PW / 4; k++) dst[k] = make_uint4(w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]);
+    for (int k = 0; k < PW / 4; k++) dst[k] = make_uint4(w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]);
+  }
 }
 
 template <class F, class Fr, int SCALAR_BITS>
@@ -1783,13 +1812,21 @@ void msm_run(Call& k, const void* bases, const void* scalars, size_t n, bool sca
     // entries (2n points x half the windows), half the windows: half the dependent doublings of the Horner tail, half the
     // bucket sets to reduce, twice the entries per bucket (longer, better balanced accumulation segments).
     static const bool glv_on = [] { const char* e = getenv("DG16_MSM_GLV"); return !e || atoi(e) != 0; }();
-    if (glv_on && n && 2 * n * 40 < ((size_t)1 << 31)) {
+    constexpr size_t DIM = GlvOf<F>::DIM;
+    if (glv_on && n && DIM * n * 40 < ((size_t)1 << 31)) {
       using GC = typename GlvOf<F>::C;
-      Fr* halves = (Fr*)ws(k.c, 30, 2 * n * sizeof(Fr));
-      hipLaunchKernelGGL((glv_split_kernel<Fr, GC>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, k.s(),
-                         (const Fr*)scalars, n, (int)scalars_mont, halves);
-      MsmSort st = msm_sort<Fr, kGlvBits>(k, halves, 2 * n, false, false);
-      uint32_t* internal = (uint32_t*)ws(k.c, 24, 2 * n * sizeof(Affine<F>));
+      Fr* halves = (Fr*)ws(k.c, 30, DIM * n * sizeof(Fr));
+      MsmSort st;
+      if constexpr (DIM == 2) {
+        hipLaunchKernelGGL((glv_split_kernel<Fr, GC>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, k.s(),
+                           (const Fr*)scalars, n, (int)scalars_mont, halves);
+        st = msm_sort<Fr, kGlvBits>(k, halves, 2 * n, false, false);
+      } else {
+        hipLaunchKernelGGL((glv_split4_kernel<Fr, GC>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, k.s(),
+                           (const Fr*)scalars, n, (int)scalars_mont, halves);
+        st = msm_sort<Fr, kGlv4Bits>(k, halves, 4 * n, false, false);
+      }
+      uint32_t* internal = (uint32_t*)ws(k.c, 24, DIM * n * sizeof(Affine<F>));
       hipLaunchKernelGGL(msm_to_internal_glv_kernel<F>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, k.s(),
                          (const Affine<F>*)bases, n, internal);
       msm_reduce<F>(k, st, internal, out_affine, out_dev);

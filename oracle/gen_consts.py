@@ -160,6 +160,108 @@ def glv_g2_entries(cname):
     return e
 
 
+def _lll(B):
+    """integer LLL (delta = 3/4) on the rows of B, exact arithmetic: four rows, once per curve"""
+    from fractions import Fraction
+    n = len(B)
+    B = [list(r) for r in B]
+
+    def gs():
+        Bs, mu = [], [[Fraction(0)] * n for _ in range(n)]
+        for i in range(n):
+            v = [Fraction(x) for x in B[i]]
+            for j in range(i):
+                mu[i][j] = sum(Fraction(B[i][k]) * Bs[j][k] for k in range(n)) / sum(x * x for x in Bs[j])
+                v = [v[k] - mu[i][j] * Bs[j][k] for k in range(n)]
+            Bs.append(v)
+        return Bs, mu
+
+    k = 1
+    while k < n:
+        Bs, mu = gs()
+        for j in range(k - 1, -1, -1):
+            q = round(mu[k][j])
+            if q:
+                B[k] = [B[k][i] - q * B[j][i] for i in range(n)]
+                Bs, mu = gs()
+        if sum(x * x for x in Bs[k]) >= (Fraction(3, 4) - mu[k][k - 1] ** 2) * sum(x * x for x in Bs[k - 1]):
+            k += 1
+        else:
+            B[k], B[k - 1] = B[k - 1], B[k]
+            k = max(k - 1, 1)
+    return B
+
+
+def _det(M):
+    from fractions import Fraction
+    n = len(M)
+    M = [[Fraction(x) for x in r] for r in M]
+    d = Fraction(1)
+    for i in range(n):
+        p = next((r for r in range(i, n) if M[r][i] != 0), None)
+        if p is None:
+            return 0
+        if p != i:
+            M[i], M[p] = M[p], M[i]
+            d = -d
+        d *= M[i][i]
+        for r in range(i + 1, n):
+            f = M[r][i] / M[i][i]
+            M[r] = [M[r][c] - f * M[i][c] for c in range(n)]
+    assert d.denominator == 1
+    return int(d)
+
+
+XI = {"bn254": (9, 1), "bls12_381": (1, 1), "bls12_377": (0, 1)}       # the twist's non-residue xi in Fq2
+
+
+def glv4_g2_entries(cname):
+    """G2 of a BN / BLS12 curve: psi(x, y) = (GAMMA_X conj(x), GAMMA_Y conj(y)) (untwist, Frobenius, twist) acts on the
+    order-r subgroup as multiplication by LAMBDA = +-q mod r, a root of x^4 - x^2 + 1, so every scalar has a FOUR-
+    dimensional split k = k0 + k1 LAMBDA + k2 LAMBDA^2 + k3 LAMBDA^3 with |k_j| < 2^64: an LLL-reduced basis B (rows)
+    of {x: sum x_j LAMBDA^j = 0 mod r}, Babai rounding c_i = round(k A_i / det B) with A = the first row of adj(B), and
+    k_j = [j = 0] k - sum_i c_i B[i][j] (csrc/glv.h: split4; the identity holds for any integers c_i).  Emitted:
+    magnitudes + signs of B, the multipliers G_i = round(2^256 |A_i| / r) and the sign of each c_i."""
+    C = CURVES[cname, "g2"]
+    F2, r = C.F, FR[cname].p
+    q = F2.p
+
+    def f2pow(a, e):
+        res = (1, 0)
+        while e:
+            if e & 1:
+                res = F2.mul(res, a)
+            a = F2.mul(a, a)
+            e >>= 1
+        return res
+
+    conj = lambda a: (a[0], (-a[1]) % q)   # noqa: E731
+    gx, gy = f2pow(XI[cname], (q - 1) // 3), f2pow(XI[cname], (q - 1) // 2)
+    G = C.gen
+    hits = []
+    for cx in (gx, F2.inv(gx)):
+        for cy in (gy, F2.inv(gy)):
+            P = (F2.mul(cx, conj(G[0])), F2.mul(cy, conj(G[1])))
+            for lam in (q % r, (-q) % r):
+                if C.mul(G, lam) == P:
+                    hits.append((cx, cy, lam))
+    assert hits, "no psi on " + cname
+    cx, cy, lam = hits[0]
+    assert (lam ** 4 - lam ** 2 + 1) % r == 0
+    B = _lll([[r, 0, 0, 0], [-lam % r, 1, 0, 0], [-(lam * lam) % r, 0, 1, 0], [-(lam ** 3) % r, 0, 0, 1]])
+    for row in B:
+        assert sum(x * lam ** j for j, x in enumerate(row)) % r == 0
+    d = _det(B)
+    assert abs(d) == r
+    A = []
+    for i in range(4):                       # (e0 B^-1)_i = cofactor(i, 0) / det
+        minor = [[B[rr][c] for c in range(1, 4)] for rr in range(4) if rr != i]
+        A.append((-1) ** i * _det(minor))
+    assert all(sum(A[i] * B[i][j] for i in range(4)) == (d if j == 0 else 0) for j in range(4))
+    return dict(GAMMA_X=cx, GAMMA_Y=cy, LAMBDA=lam, B=B,
+                G=[((abs(a) << 256) + r // 2) // r for a in A], C_NEG=[(a < 0) != (d < 0) for a in A])
+
+
 def emit_c64():
     o = ["/* GENERATED by oracle/gen_consts.py -- do not edit. 64-bit limbs, little endian;",
          "   field elements are in Montgomery form with R = 2^(64*limbs). */",
@@ -266,6 +368,24 @@ def emit_hip32():
         o.append("  static constexpr uint32_t %s[5] = %s;" % (k, arr(e[k], 5, 32)))
     o.append("};")
     o.append("")
+    for cname in ("bls12_381", "bls12_377"):      # (BN254's G2 keeps the two-dimensional form: measured faster there)
+        e = glv4_g2_entries(cname)
+        F = FQ[cname]
+        n = 2 * F.limbs64
+        o.append("struct %s_g2_glv4_consts {" % cname)
+        for nm in ("GAMMA_X", "GAMMA_Y"):
+            for ci in (0, 1):
+                o.append("  static constexpr uint32_t %s_C%d[%d] = %s;   // arkworks Montgomery form" %
+                         (nm, ci, n, arr(e[nm][ci] * F.R % F.p, n, 32)))
+        o.append("  static constexpr uint32_t LAMBDA[8] = %s;   // plain integer" % arr(e["LAMBDA"], 8, 32))
+        flat = [x for row in e["B"] for x in row]
+        assert all(abs(x) < 1 << 96 for x in flat) and all(g < 1 << 224 for g in e["G"])
+        o.append("  static constexpr uint32_t B[16][3] = {%s};   // |B[i][j]| at 4 i + j" % ", ".join(arr(abs(x), 3, 32) for x in flat))
+        o.append("  static constexpr bool B_NEG[16] = {%s};" % ", ".join("true" if x < 0 else "false" for x in flat))
+        o.append("  static constexpr uint32_t G[4][7] = {%s};" % ", ".join(arr(g, 7, 32) for g in e["G"]))
+        o.append("  static constexpr bool C_NEG[4] = {%s};" % ", ".join("true" if x else "false" for x in e["C_NEG"]))
+        o.append("};")
+        o.append("")
     o.append("}  // namespace dg16")
     return "\n".join(o) + "\n"
 

@@ -289,3 +289,15 @@ extern "C" int ha_glv_split(int curve, const uint32_t* k, uint32_t* h1, uint32_t
   }
   return 0;
 }
+
+// glv::split4 (csrc/glv.h) on n 8-word scalars: h[j] = |k_j| with the sign in bit 255, j < 4 (h: 4 arrays of n x 8 words)
+extern "C" int ha_glv_split4(int curve, const uint32_t* k, uint32_t* h0, uint32_t* h1, uint32_t* h2, uint32_t* h3, size_t n) {
+  for (size_t i = 0; i < n; i++) {
+    switch (curve) {
+      case 1: glv::split4<bls12_381_g2_glv4_consts>(k + 8 * i, h0 + 8 * i, h1 + 8 * i, h2 + 8 * i, h3 + 8 * i); break;
+      case 2: glv::split4<bls12_377_g2_glv4_consts>(k + 8 * i, h0 + 8 * i, h1 + 8 * i, h2 + 8 * i, h3 + 8 * i); break;
+      default: return -1;
+    }
+  }
+  return 0;
+}

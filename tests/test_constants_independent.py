@@ -322,6 +322,48 @@ def test_glv_constants_of_bn254_g2_recomputed():
         assert abs(val[gk] * r - (b << 256)) * 2 <= r
 
 
+@pytest.mark.parametrize("curve", ["bls12_381", "bls12_377"])
+def test_glv4_constants_of_g2_recomputed(curve):
+    """<curve>_g2_glv4_consts: psi(x, y) = (GAMMA_X conj(x), GAMMA_Y conj(y)) is multiplication by LAMBDA on the generator of
+    G2 (long-hand ladder over Fq2), LAMBDA = +-q mod r is a root of x^4 - x^2 + 1, every row of B lies in the lattice
+    {x: sum x_j LAMBDA^j = 0 mod r}, |det B| = r (cofactor expansion), the entries are below 2^65, G_i is the nearest integer
+    to 2^256 |A_i| / r for the first row A of adj(B), and C_NEG is the sign of A_i / det."""
+    q, r = family(curve)
+    Rinv = egcd_inv(doubling_pow2(64 * NL64[curve], q), q)
+    text = open(HIP_H).read()
+    blk = text[text.index("struct %s_g2_glv4_consts {" % curve):]
+    blk = blk[:blk.index("\n};")]
+    words = lambda body: sum(int(x.strip().rstrip("u"), 16) << (32 * i) for i, x in enumerate(body.split(",")))   # noqa: E731
+    one = lambda name: words(re.search(r" %s\[\d+\] = \{([^}]*)\}" % name, blk).group(1))                          # noqa: E731
+    beta = 5 if curve == "bls12_377" else 1
+    F = Fp2(q, beta)
+    gx = (one("GAMMA_X_C0") * Rinv % q, one("GAMMA_X_C1") * Rinv % q)
+    gy = (one("GAMMA_Y_C0") * Rinv % q, one("GAMMA_Y_C1") * Rinv % q)
+    lam = one("LAMBDA")
+    assert lam in (q % r, (-q) % r) and (lam ** 4 - lam ** 2 + 1) % r == 0
+    g = HIP["%s_g2_consts" % curve]
+    G = tuple((g[k + "_C0"] * Rinv % q, g[k + "_C1"] * Rinv % q) for k in ("GX", "GY"))
+    conj = lambda a: (a[0], (-a[1]) % q)                                                                            # noqa: E731
+    assert ladder(F, G, lam) == (F.mul(gx, conj(G[0])), F.mul(gy, conj(G[1])))
+    Bm = [words(m) for m in re.findall(r"\{([^{}]*)\}", re.search(r" B\[16\]\[3\] = \{(.*)\};", blk).group(1))]
+    Bn = [x.strip() == "true" for x in re.search(r"B_NEG\[16\] = \{([^}]*)\}", blk).group(1).split(",")]
+    Gm = [words(m) for m in re.findall(r"\{([^{}]*)\}", re.search(r" G\[4\]\[7\] = \{(.*)\};", blk).group(1))]
+    Cn = [x.strip() == "true" for x in re.search(r"C_NEG\[4\] = \{([^}]*)\}", blk).group(1).split(",")]
+    B = [[(-Bm[4 * i + j] if Bn[4 * i + j] else Bm[4 * i + j]) for j in range(4)] for i in range(4)]
+    assert all(sum(x * lam ** j for j, x in enumerate(row)) % r == 0 for row in B)
+    assert max(abs(x) for row in B for x in row) < 1 << 65
+
+    def det3(m):
+        return (m[0][0] * (m[1][1] * m[2][2] - m[1][2] * m[2][1]) - m[0][1] * (m[1][0] * m[2][2] - m[1][2] * m[2][0])
+                + m[0][2] * (m[1][0] * m[2][1] - m[1][1] * m[2][0]))
+    A = [(-1) ** i * det3([[B[rr][c] for c in range(1, 4)] for rr in range(4) if rr != i]) for i in range(4)]
+    d = sum(A[i] * B[i][0] for i in range(4))                         # cofactor expansion along the first column
+    assert abs(d) == r
+    for i in range(4):
+        assert abs(Gm[i] * r - (abs(A[i]) << 256)) * 2 <= r
+        assert A[i] == 0 or Cn[i] == ((A[i] < 0) != (d < 0))
+
+
 # ---- the compile-time constants of fp29.h (RR<P>) -------------------------------------------------------------------------
 SRC = os.path.join(HERE, "host_arith", "host_arith.cpp")
 SO = os.path.join(HERE, "host_arith", "libhost_arith.so")

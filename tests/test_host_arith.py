@@ -32,6 +32,7 @@ def ha():
     L.ha_point_op29.argtypes = [i, i, i, vp, vp, vp, sz]
     L.ha_codec.argtypes = [i, i, i, i, vp, vp, sz, vp]
     L.ha_glv_split.argtypes = [i, vp, vp, vp, sz]
+    L.ha_glv_split4.argtypes = [i, vp, vp, vp, vp, vp, sz]
     return L
 
 
@@ -288,3 +289,41 @@ def test_glv_split_is_exact_and_short(ha, curve):
         assert (dec(x1), dec(x2)) == (k1, k2), hex(k)
         worst = max(worst, abs(k1), abs(k2))
     assert worst < 1 << 127, worst.bit_length()
+
+
+@pytest.mark.parametrize("curve", ["bls12_381", "bls12_377"])
+def test_glv_split4_is_exact_and_short(ha, curve):
+    """csrc/glv.h: the four-dimensional split of G2 scalars -- k = sum_j k_j LAMBDA^j (mod r) for every scalar, the quarters
+    equal the same integer arithmetic done with Python integers on the constants of the header, and |k_j| < 2^65 (the
+    bound kGlv4Bits of msm_impl.h rests on)."""
+    import re
+    hdr = os.path.join(HERE, "..", "distributed-groth16_amd", "csrc", "consts_gen.h")
+    text = open(hdr).read()
+    blk = text[text.index("struct %s_g2_glv4_consts {" % curve):]
+    blk = blk[:blk.index("\n};")]
+    words = lambda body: [int(x.strip().rstrip("u"), 16) for x in body.split(",")]          # noqa: E731
+    val = lambda ws: sum(v << (32 * i) for i, v in enumerate(ws))                             # noqa: E731
+    lam = val(words(re.search(r"LAMBDA\[8\] = \{([^}]*)\}", blk).group(1)))
+    Bm = [val(words(m)) for m in re.findall(r"\{([^{}]*)\}", re.search(r" B\[16\]\[3\] = \{(.*)\};", blk).group(1))]
+    Bn = [x.strip() == "true" for x in re.search(r"B_NEG\[16\] = \{([^}]*)\}", blk).group(1).split(",")]
+    Gm = [val(words(m)) for m in re.findall(r"\{([^{}]*)\}", re.search(r" G\[4\]\[7\] = \{(.*)\};", blk).group(1))]
+    Cn = [x.strip() == "true" for x in re.search(r"C_NEG\[4\] = \{([^}]*)\}", blk).group(1).split(",")]
+    B = [[(-Bm[4 * i + j] if Bn[4 * i + j] else Bm[4 * i + j]) for j in range(4)] for i in range(4)]
+    r = FR[curve].p
+    assert (lam ** 4 - lam ** 2 + 1) % r == 0
+    rng = random.Random(23)
+    ks = [0, 1, 2, r - 1, r - 2, (r - 1) // 2, lam, r - lam, (1 << 254) - 1, (1 << 255) - 1, 1 << 254, r // 3]
+    ks += [rng.randrange(r) for _ in range(100000)] + [rng.randrange(1 << 255) for _ in range(10000)]
+    K = corc.ints_to_arr(ks, 4)
+    H = [np.zeros_like(K) for _ in range(4)]
+    assert ha.ha_glv_split4({"bn254": 0, "bls12_381": 1, "bls12_377": 2}[curve], _p(K), *[_p(h) for h in H], len(ks)) == 0
+    got = [corc.arr_to_ints(h) for h in H]
+    dec = lambda x: -(x & ((1 << 255) - 1)) if x >> 255 else x      # noqa: E731
+    worst = 0
+    for n_, k in enumerate(ks):
+        c = [(-1 if Cn[i] else 1) * ((Gm[i] * k + (1 << 255)) >> 256) for i in range(4)]
+        q = [(k if j == 0 else 0) - sum(c[i] * B[i][j] for i in range(4)) for j in range(4)]
+        assert sum(q[j] * lam ** j for j in range(4)) % r == k % r
+        assert [dec(got[j][n_]) for j in range(4)] == q, hex(k)
+        worst = max(worst, max(abs(x) for x in q))
+    assert worst < 1 << 65, worst.bit_length()
