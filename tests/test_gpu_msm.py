@@ -37,6 +37,39 @@ def test_msm_matches_oracle(curve, group, n):
     check(curve, group, bases, scalars)
 
 
+def test_msm_without_the_scalar_split_in_a_process_of_its_own():
+    """dg16_msm with DG16_MSM_GLV=0 (read once per process, hence the child): the plain Pippenger over n points and all
+    the windows -- the path that also serves MSMs too large for the split's index range -- equals the oracle's MSM for
+    G1 and G2 of BN254 and the G2 of BLS12-381, and equals what the splitting path of THIS process returns."""
+    import subprocess
+    import sys
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "import dg16_amd\n"
+        "from oracle import corc\n"
+        "c = dg16_amd.Context(0)\n"
+        "for curve, group, n in (('bn254', 1, 1 << 15), ('bn254', 2, 1 << 14), ('bls12_381', 2, 1 << 13), ('bn254', 1, 33)):\n"
+        "    bases = corc.gen_points(curve, group, 40 + n, n) if n < 1 << 14 else c.gen_bases(curve, group, 40 + n, n)\n"
+        "    sc = corc.rand_field(curve, 'fr', 50 + n, n, mont=False)\n"
+        "    got = corc.jac_to_affine(curve, group, c.msm(curve, group, bases, sc))\n"
+        "    assert np.array_equal(got, corc.msm(curve, group, bases, sc)), (curve, group, n)\n"
+        "    print('NOSPLIT', curve, group, n, got.tobytes().hex()[:32])\n" % root)
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, DG16_MSM_GLV="0"), cwd=root,
+                         capture_output=True, text=True, timeout=280)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+    lines = [ln.split() for ln in out.stdout.splitlines() if ln.startswith("NOSPLIT")]
+    assert len(lines) == 4
+    for _, curve, group, n, head in lines:
+        group, n = int(group), int(n)
+        bases = corc.gen_points(curve, group, 40 + n, n) if n < 1 << 14 else ctx().gen_bases(curve, group, 40 + n, n)
+        sc = corc.rand_field(curve, "fr", 50 + n, n, mont=False)
+        mine = corc.jac_to_affine(curve, group, ctx().msm(curve, group, bases, sc))
+        assert mine.tobytes().hex()[:32] == head
+
+
 def test_gen_bases_equals_oracle_generator():
     # the large cases above take their bases from dg16_gen_bases: pin it to the oracle's walk bit for bit
     for curve, group in GROUPS:
