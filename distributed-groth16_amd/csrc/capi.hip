@@ -408,7 +408,7 @@ int dg16_qap_rows(dg16_ctx* ctx, int curve, size_t num_constraints, size_t num_i
     DG_REQUIRE(num_constraints + num_inputs <= m && num_inputs <= num_vars, DG16_ERR_BAD_ARG,
                "domain smaller than num_constraints + num_inputs");
     bool dev = flags & DG16_F_DEVICE_PTRS;
-    Call k(ctx, channel);
+    Call k(ctx, channel, /*tail_ok=*/dev);      // on device pointers this call touches no workspace (ctx.h: tail_pending)
     // Matrix indices are checked before they index the assignment: a malformed key file must end in
     // DG16_ERR_BAD_ARG, not in an out-of-bounds device read (the reference's Rust indexing panics).  Host
     // pointers: checked here.  Device pointers: no read-back (the call stays stream-ordered); the kernel skips

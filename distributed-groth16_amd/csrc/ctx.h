@@ -7,6 +7,7 @@
 #include <stdint.h>
 
 #include <map>
+#include <atomic>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -69,6 +70,11 @@ struct dg16_ctx {
   // launches overtake the wait once all buffers were warm (second proof on a context differed from the
   // oracle; the first one was masked by the implicit synchronisation of hipMalloc).
   hipEvent_t pipe_ev[24] = {};
+  // DG16_F_OVERLAP_TAIL (prover_impl.h: prove_typed): the last proof's H reduction + assembly + copy-out may still be
+  // running on channel 2's stream when the call returns; pipe_ev[18] is recorded behind them.  Every later call on this
+  // context waits for it on its own stream (Call) -- except the calls that are known not to touch what the tail uses
+  // (R1CS x witness on device pointers; the next overlapped proof, which places the waits itself).
+  std::atomic<bool> tail_pending{false};
   hipStream_t aux[2] = {};   // extra internal streams of the prover pipeline (never handed out)
   dg16::Channel xws[2];      // workspace-only (no stream): the bucket buffers of the H and L MSMs of a proof
   // Sticky argument-error flag of stream-ordered calls (pinned host word mapped into the device: kernels OR
@@ -133,9 +139,11 @@ struct Call {
   dg16_ctx* ctx;
   Channel& c;
   std::unique_lock<std::mutex> lk;
-  Call(dg16_ctx* ctx_, int channel)
+  Call(dg16_ctx* ctx_, int channel, bool tail_ok = false)
       : ctx(ctx_), c(ctx_->ch[channel]), lk(ctx_->ch[channel].mu) {
     DG_HIP(hipSetDevice(ctx->device));
+    if (!tail_ok && ctx->tail_pending.load(std::memory_order_acquire))
+      DG_HIP(hipStreamWaitEvent(c.cur, ctx->pipe_ev[18], 0));      // an overlapped proof's tail (see dg16_ctx::tail_pending)
     c.ev_valid[0] = c.ev_valid[1] = false;
     DG_HIP(hipEventRecord(c.ev[0], c.cur));
   }

@@ -7,7 +7,8 @@
 namespace dg16 {
 #define DECL_P(name)                                                                                                   \
   void pk_build_##name(dg16_ctx*, PkDev&, const void*, const void*, const void*, const void*, const void*, const void*, bool); \
-  void prove_##name(dg16_ctx*, const PkDev&, const void*, const void*, const void*, const void*, const void*, bool, bool, void*); \
+  void prove_##name(dg16_ctx*, const PkDev&, const void*, const void*, const void*, const void*, const void*, bool, bool, void*, \
+                    bool); \
   void msms_##name(dg16_ctx*, Call&, Call&, Call&, const PkDev&, const void*, const void*, const void*, const void*,    \
                    const void*, bool, bool, uint8_t*, const dg16_comm*, const void*);                                   \
   void prove_dist_##name(dg16_ctx*, const PkDev&, const dg16_comm*, const void*, const void*, const void*, const void*, \
@@ -99,10 +100,11 @@ int dg16_groth16_prove(dg16_ctx* ctx, const dg16_pk* pk, const void* a, const vo
     DG_REQUIRE(pk->ctx == ctx, DG16_ERR_BAD_ARG, "proving key belongs to another context");
     DG_REQUIRE(a && b && c && full_assignment && r_s && proof_out, DG16_ERR_BAD_ARG, "null operand");
     bool mont = flags & DG16_F_SCALARS_MONT, dev = flags & DG16_F_DEVICE_PTRS;
+    const bool overlap = (flags & DG16_F_OVERLAP_TAIL) && dev;
     if (pk->d.curve == DG16_BN254)
-      prove_bn254(ctx, pk->d, a, b, c, full_assignment, r_s, mont, dev, proof_out);
+      prove_bn254(ctx, pk->d, a, b, c, full_assignment, r_s, mont, dev, proof_out, overlap);
     else
-      prove_bls12_381(ctx, pk->d, a, b, c, full_assignment, r_s, mont, dev, proof_out);
+      prove_bls12_381(ctx, pk->d, a, b, c, full_assignment, r_s, mont, dev, proof_out, overlap);
   });
 }
 

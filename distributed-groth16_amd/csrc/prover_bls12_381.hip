@@ -11,7 +11,9 @@ namespace dg16 {
 void pk_build_bls12_381(dg16_ctx* ctx, PkDev& d, const void* a, const void* b1, const void* b2, const void* h, const void* l,
                  const void* fx, bool dev) { pk_build<1>(ctx, d, a, b1, b2, h, l, fx, dev); }
 void prove_bls12_381(dg16_ctx* ctx, const PkDev& pk, const void* a, const void* b, const void* c, const void* w,
-              const void* rs, bool mont, bool dev, void* out) { prove_typed<1>(ctx, pk, a, b, c, w, rs, mont, dev, out); }
+              const void* rs, bool mont, bool dev, void* out, bool overlap) {
+  prove_typed<1>(ctx, pk, a, b, c, w, rs, mont, dev, out, overlap);
+}
 void msms_bls12_381(dg16_ctx* ctx, Call& k0, Call& k1, Call& k2, const PkDev& pk, const void* a, const void* b, const void* c,
              const void* w, const void* rs, bool mont, bool dev, uint8_t* res, const dg16_comm* comm, const void* h_given) {
   msms_typed<1>(ctx, k0, k1, k2, pk, a, b, c, w, rs, mont, dev, res, comm, h_given);

@@ -143,10 +143,17 @@ static size_t msm_results_bytes() {
 //   comm with > 1 rank  sharded h-polynomial (ntt.hip: h_poly_dist_launch): a, b, c are this rank's cyclic rows and
 //                      the key is a DG16_F_H_CYCLIC shard
 //   otherwise          the whole h-polynomial from the whole a, b, c; the key's slice of it is used
+// overlap_tail (DG16_F_OVERLAP_TAIL, one GPU): H's bucket reduction -- the exposed tail of a proof, ~0.6 ms of latency-bound
+// launches on an otherwise idle chip -- goes down channel 2's stream instead of channel 0's, so that what the caller
+// enqueues next on channel 0 (the next proof's R1CS x witness and h-polynomial) runs under it.  Returns true when it did:
+// H's result is then ordered on channel 2's stream, everything else on channel 0's as before.  The buffers the tail
+// still reads when the next proof starts (H's buckets and digit-sort metadata, the results record) are fenced with
+// pipe_ev[18] at their first reuse (marked "tail fence" below); other entry points wait in Call().
 template <int CURVE>
-static void msms_typed(dg16_ctx* ctx, Call& k0, Call& k1, Call& k2, const PkDev& pk, const void* a, const void* b,
+static bool msms_typed(dg16_ctx* ctx, Call& k0, Call& k1, Call& k2, const PkDev& pk, const void* a, const void* b,
                        const void* c, const void* witness, const void* r_s_host, bool mont, bool dev_ptrs,
-                       uint8_t* res_dev, const dg16_comm* comm = nullptr, const void* h_given = nullptr) {
+                       uint8_t* res_dev, const dg16_comm* comm = nullptr, const void* h_given = nullptr,
+                       bool overlap_tail = false) {
   using CT = CurveTypes<CURVE>;
   using Fq = typename CT::Fq;
   using Fq2 = typename CT::Fq2;
@@ -251,9 +258,13 @@ static void msms_typed(dg16_ctx* ctx, Call& k0, Call& k1, Call& k2, const PkDev&
     h_scalars = h_dev + pk.h_lo;
   }
   MsmSort st_h;
+  const bool tail_fence = overlap_tail && ctx->tail_pending.load(std::memory_order_acquire);
   if (!dist) {   // side: the sort of h, underneath the G2 accumulation
     DG_HIP(hipEventRecord(ev[14], main));
     DG_HIP(hipStreamWaitEvent(side, ev[14], 0));
+    // tail fence: the last proof's H reduction reads the digit-sort metadata this sort rewrites (and, further down this
+    // stream, A's and L's reductions write the results record its assembly reads)
+    if (tail_fence) DG_HIP(hipStreamWaitEvent(side, ev[18], 0));
     st_h = msm_sort_on<Fr, CT::SCALAR_BITS>(side, k0.c, h_scalars, n_h, true, true, pk.c_h, pk.stride);
     DG_HIP(hipEventRecord(ev[15], side));
   }
@@ -327,6 +338,7 @@ static void msms_typed(dg16_ctx* ctx, Call& k0, Call& k1, Call& k2, const PkDev&
     if (!(exp_bits & 2u)) msm_bucket_phase<Fq>(side, st_ab, buf_a, false, rec + kRecA);
     DG_HIP(hipEventRecord(ev[12], side));
     DG_HIP(hipStreamWaitEvent(xch, ev[1], 0));
+    if (tail_fence) DG_HIP(hipStreamWaitEvent(xch, ev[18], 0));     // tail fence: rec[kRecB1] is read by the last assembly
     if (!(exp_bits & 2u)) msm_bucket_phase<Fq>(xch, st_ab, buf_b1, false, rec + kRecB1);
     DG_HIP(hipStreamWaitEvent(xch, ev[12], 0));
     if (!(exp_bits & 10u))
@@ -349,12 +361,21 @@ static void msms_typed(dg16_ctx* ctx, Call& k0, Call& k1, Call& k2, const PkDev&
     DG_HIP(hipStreamWaitEvent(lane2, ev[15], 0));
   }
   MsmBuffers<Fq> buf_h = msm_buffers<Fq>(ctx->xws[0], st_h.g);
+  if (tail_fence) DG_HIP(hipStreamWaitEvent(lane2, ev[18], 0));     // tail fence: H's buckets
   msm_accumulate_phase<Fq>(lane2, st_h, buf_h, pk.h_q);
   if (exp_bits & 4u) {
     DG_HIP(hipEventRecord(ev[2], lane2));      // (re-recorded: B's accumulation is long done; the wait is on H's)
     b_reduction();
   }
-  msm_bucket_phase<Fq>(lane2, st_h, buf_h, false, res_h);
+  const bool tail_on_side2 = overlap_tail && !dist && !h_given && !two_lane && !merged;
+  if (tail_on_side2) {
+    DG_HIP(hipEventRecord(ev[17], main));
+    DG_HIP(hipStreamWaitEvent(side2, ev[17], 0));
+    msm_bucket_phase<Fq>(side2, st_h, buf_h, false, res_h);
+    DG_HIP(hipStreamWaitEvent(side2, ev[10], 0));       // A, B1, L results, s*A, r*B1 (B's are in order on side2 itself)
+  } else {
+    msm_bucket_phase<Fq>(lane2, st_h, buf_h, false, res_h);
+  }
   if (two_lane) {
     DG_HIP(hipEventRecord(ev[16], lane2));
     DG_HIP(hipStreamWaitEvent(main, ev[16], 0));
@@ -362,16 +383,18 @@ static void msms_typed(dg16_ctx* ctx, Call& k0, Call& k1, Call& k2, const PkDev&
   DG_HIP(hipStreamWaitEvent(main, ev[10], 0));          // A, B1, L results, s*A, r*B1
   DG_HIP(hipStreamWaitEvent(main, ev[5], 0));           // B result
   DG_HIP(hipGetLastError());
+  return tail_on_side2;
 }
 
 // proof = assemble(sum of the shards' MSM results).  res_dev: msm_results_bytes() on the device.
 template <int CURVE>
-static void assemble_typed(Call& k0, const uint8_t* gathered_dev, size_t n_shards, uint8_t* proof_dev) {
+static void assemble_typed(Call& k0, const uint8_t* gathered_dev, size_t n_shards, uint8_t* proof_dev,
+                           hipStream_t stream = nullptr) {
   using CT = CurveTypes<CURVE>;
   using Fq = typename CT::Fq;
   using Fq2 = typename CT::Fq2;
   const size_t g1j = sizeof(Jacobian<Fq>), g2j = sizeof(Jacobian<Fq2>);
-  hipLaunchKernelGGL((prover_assemble_kernel<Fq, Fq2>), dim3(1), dim3(384), 0, k0.s(), gathered_dev, n_shards,
+  hipLaunchKernelGGL((prover_assemble_kernel<Fq, Fq2>), dim3(1), dim3(384), 0, stream ? stream : k0.s(), gathered_dev, n_shards,
                      msm_results_bytes<CURVE>(), (Jacobian<Fq>*)proof_dev, (Jacobian<Fq2>*)(proof_dev + g1j),
                      (Jacobian<Fq>*)(proof_dev + g1j + g2j));
   DG_HIP(hipGetLastError());
@@ -379,16 +402,32 @@ static void assemble_typed(Call& k0, const uint8_t* gathered_dev, size_t n_shard
 
 template <int CURVE>
 static void prove_typed(dg16_ctx* ctx, const PkDev& pk, const void* a, const void* b, const void* c,
-                        const void* witness, const void* r_s_host, bool mont, bool dev_ptrs, void* proof_out) {
+                        const void* witness, const void* r_s_host, bool mont, bool dev_ptrs, void* proof_out,
+                        bool overlap_tail = false) {
   using CT = CurveTypes<CURVE>;
   const size_t g1j = sizeof(Jacobian<typename CT::Fq>), g2j = sizeof(Jacobian<typename CT::Fq2>);
   DG_REQUIRE(pk.nshards == 1, DG16_ERR_BAD_ARG, "dg16_groth16_prove needs an unsharded key; use _msms + _assemble");
-  Call k0(ctx, 0), k1(ctx, 1), k2(ctx, 2);
+  overlap_tail = overlap_tail && dev_ptrs;      // a host-pointer call ends in a synchronisation anyway
+  Call k0(ctx, 0, overlap_tail), k1(ctx, 1, overlap_tail), k2(ctx, 2, overlap_tail);
   uint8_t* buf = (uint8_t*)ws(k0.c, 16, 8192);
   uint8_t* res_dev = buf;
   uint8_t* proof_dev = buf + 4096;
   k0.begin_dominant();
-  msms_typed<CURVE>(ctx, k0, k1, k2, pk, a, b, c, witness, r_s_host, mont, dev_ptrs, res_dev);
+  const bool tail = msms_typed<CURVE>(ctx, k0, k1, k2, pk, a, b, c, witness, r_s_host, mont, dev_ptrs, res_dev, nullptr,
+                                      nullptr, overlap_tail);
+  if (tail) {
+    // the proof is complete on channel 2's stream (dg16.h: DG16_F_OVERLAP_TAIL); channel 0 is free for the next one
+    k0.end_dominant();
+    assemble_typed<CURVE>(k0, res_dev, 1, proof_dev, k2.s());
+    if (proof_out != proof_dev)
+      DG_HIP(hipMemcpyAsync(proof_out, proof_dev, 2 * g1j + g2j, hipMemcpyDeviceToDevice, k2.s()));
+    DG_HIP(hipEventRecord(ctx->pipe_ev[18], k2.s()));
+    ctx->tail_pending.store(true, std::memory_order_release);
+    k0.finish();
+    k1.finish();
+    k2.finish();
+    return;
+  }
   assemble_typed<CURVE>(k0, res_dev, 1, proof_dev);
   k0.end_dominant();
   stage_out(k0, proof_out, proof_dev, 2 * g1j + g2j, dev_ptrs);

@@ -19,6 +19,8 @@ F_SCALARS_MONT = 1
 F_DEVICE_PTRS = 2
 F_OUT_AFFINE = 4
 F_H_CYCLIC = 8
+F_SERIAL_CHANNELS = 16
+F_OVERLAP_TAIL = 32
 
 STATUS = {1: "LENGTH_MISMATCH", 2: "BAD_CURVE", 3: "BAD_ARG", 4: "OOM", 5: "HIP", 6: "NET",
           7: "UNSUPPORTED"}
@@ -611,11 +613,13 @@ class Context:
                                             F_SCALARS_MONT if scalars_mont else 0, _ptr(out)))
         return out[:3 * nl].reshape(1, -1), out[3 * nl:9 * nl].reshape(1, -1), out[9 * nl:].reshape(1, -1)
 
-    def prove_dev(self, pk, a_ptr, b_ptr, c_ptr, w_ptr, rs_host, out_ptr, scalars_mont=True):
+    def prove_dev(self, pk, a_ptr, b_ptr, c_ptr, w_ptr, rs_host, out_ptr, scalars_mont=True, overlap_tail=False):
+        """overlap_tail (DG16_F_OVERLAP_TAIL): the proof is complete on channel 2's stream (sync(2)), and the work
+        enqueued next on channel 0 -- the next proof of a queue -- starts under this one's last bucket reduction."""
         rs_host = np.ascontiguousarray(rs_host, dtype=np.uint64)
+        flags = F_DEVICE_PTRS | (F_SCALARS_MONT if scalars_mont else 0) | (F_OVERLAP_TAIL if overlap_tail else 0)
         self._chk(self.L.dg16_groth16_prove(self.h, pk.h, _ptr(a_ptr), _ptr(b_ptr), _ptr(c_ptr), _ptr(w_ptr),
-                                            _ptr(rs_host), F_DEVICE_PTRS | (F_SCALARS_MONT if scalars_mont else 0),
-                                            _ptr(out_ptr)))
+                                            _ptr(rs_host), flags, _ptr(out_ptr)))
 
     # ---- device-pointer API (stream-ordered) ----------------------------------------------------------
     def msm_dev(self, curve, group, bases_ptr, scalars_ptr, n, out_ptr, scalars_mont=False, affine=False,

@@ -171,6 +171,8 @@ class NativeProver:
         self.rank, self.world = rank, world
         self.device = torch.device("cuda", ctx.device)
         self.nl = 4 if curve == "bn254" else 6
+        # one GPU, a queue of proofs: DG16_F_OVERLAP_TAIL (the proof is then complete on channel 2's stream)
+        self.overlap_tail = False
 
     def describe(self):
         if self.world == 1:
@@ -188,6 +190,10 @@ class NativeProver:
 
     def prove(self, a, b, c, w, rs_host, scalars_mont=True):
         proof = self.torch.empty(12 * self.nl * 8, dtype=self.torch.uint8, device=self.device)
+        if self.world == 1 and self.overlap_tail:
+            self.ctx.prove_dev(self.pk, a.data_ptr(), b.data_ptr(), c.data_ptr(), w.data_ptr(), rs_host, proof.data_ptr(),
+                               scalars_mont=scalars_mont, overlap_tail=True)
+            return proof
         self.ctx.prove_dist_dev(self.pk, self.comm, a.data_ptr(), b.data_ptr(), c.data_ptr(), w.data_ptr(), rs_host,
                                 proof.data_ptr(), scalars_mont=scalars_mont)
         return proof

@@ -68,9 +68,15 @@ enum dg16_flags {
   DG16_F_OUT_AFFINE = 4u,   /* group result as affine x || y (one inversion on the device) */
   DG16_F_H_CYCLIC = 8u,     /* dg16_pk_create_shard: this shard's h_query bases are h_query[shard + n_shards * j]
                                (the output layout of the sharded h-polynomial) instead of a contiguous slice */
-  DG16_F_SERIAL_CHANNELS = 16u /* dg16_prove_c: run the three d_msm one after another (channel 0, 1, 2 in that order
+  DG16_F_SERIAL_CHANNELS = 16u, /* dg16_prove_c: run the three d_msm one after another (channel 0, 1, 2 in that order
                                on every party) instead of joined from three host threads -- for a dg16_net whose
                                channels are not independent (one ordered pipe); the result is the same */
+  DG16_F_OVERLAP_TAIL = 32u /* dg16_groth16_prove with DG16_F_DEVICE_PTRS, for a queue of proofs on one context: the last
+                               MSM's bucket reduction, the assembly and the copy to proof_out are ordered on CHANNEL 2's
+                               stream instead of channel 0's, so the work enqueued next on channel 0 (the next proof's
+                               dg16_qap and h-polynomial) starts under that latency-bound tail.  proof_out is complete
+                               after dg16_sync(ctx, 2) (or stream-ordered work on channel 2); every other call on the
+                               context orders itself behind the tail.  Ignored with host pointers. */
 };
 
 /* field ids for dg16_field_op: curve for the base field Fq, 16 + curve for the scalar field Fr */

@@ -217,3 +217,73 @@ def test_sharded_prove_large_vs_oracle(curve, log_m, world):
     assert np.array_equal(A, gA) and np.array_equal(B, gB) and np.array_equal(C, gC)
     for wl in shards:
         wl.pk.close()
+
+
+@pytest.mark.parametrize("curve,log_m", [("bn254", 14), ("bn254", 17), ("bls12_381", 12)])
+def test_queue_of_proofs_with_overlapped_tail(curve, log_m):
+    """DG16_F_OVERLAP_TAIL: five proofs of different witnesses and different (r, s) queued on one context with NO host
+    synchronisation in between -- each proof's last bucket reduction and assembly run on channel 2's stream while the next
+    proof's R1CS x witness, h-polynomial and first accumulations run on channel 0's -- plus an unrelated MSM on channel 0
+    in the middle of the queue (which reuses channel-0 workspace and must order itself behind the tail).  Every queued
+    proof must equal the proof of the plain, synchronised call on the same inputs; the first and the last of those are
+    checked against the oracle."""
+    import torch
+    import bench
+    c = ctx()
+    dev = torch.device("cuda", 0)
+    wl = bench.Workload(c, dev, log_m, 0, 1, seed=31, curve=curve)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(5)
+    K = 5
+    ws, rss = [], []
+    for k in range(K):
+        w = bench.rand_fr(wl.nv, dev, gen, curve)
+        w[0] = 0
+        w[0, 0] = 1
+        ws.append(w)
+        rss.append(np.array([[3 + k, 1, 4, 1], [5, 9 + k, 2, 6]], dtype=np.uint64))
+    # an unrelated MSM (fresh bases, channel 0)
+    n_msm = 1 << 10
+    fqb = bench.FQ_BYTES[curve]
+    bases = torch.empty(n_msm * 2 * fqb, dtype=torch.uint8, device=dev)
+    c.gen_bases_dev(curve, 1, 77, n_msm, bases.data_ptr())
+    c.sync(0)
+    sc = bench.rand_fr(n_msm, dev, gen, curve)
+    msm_ref = torch.empty(3 * fqb, dtype=torch.uint8, device=dev)
+    msm_out = torch.empty_like(msm_ref)
+    torch.cuda.synchronize()
+    c.msm_dev(curve, 1, bases.data_ptr(), sc.data_ptr(), n_msm, msm_ref.data_ptr())
+    c.sync(0)
+
+    refs = []
+    for k in range(K):
+        wl.w = ws[k]
+        refs.append(bench.prove_once(c, wl, rss[k]))
+    for k in (0, K - 1):
+        wl.w = ws[k]
+        r = int(sum(int(x) << (64 * i) for i, x in enumerate(rss[k][0])))
+        s = int(sum(int(x) << (64 * i) for i, x in enumerate(rss[k][1])))
+        (A, B, C), _ = bench.oracle_prove(wl, bench.cpu_threads(), r, s)
+        gA, gB, gC = bench.gpu_proof_affine(curve, refs[k])
+        assert np.array_equal(A, gA) and np.array_equal(B, gB) and np.array_equal(C, gC), "plain proof %d vs oracle" % k
+
+    outs = [torch.zeros(wl.proof_bytes(), dtype=torch.uint8, device=dev) for _ in range(K)]
+    torch.cuda.synchronize()
+    for k in range(K):
+        wl.w = ws[k]
+        wl.qap()
+        c.prove_dev(wl.pk, wl.a.data_ptr(), wl.b.data_ptr(), wl.c.data_ptr(), wl.w.data_ptr(), rss[k],
+                    outs[k].data_ptr(), scalars_mont=False, overlap_tail=True)
+        if k == 2:
+            c.msm_dev(curve, 1, bases.data_ptr(), sc.data_ptr(), n_msm, msm_out.data_ptr())
+    for ch in range(3):
+        c.sync(ch)
+    nl = fqb // 8
+    assert np.array_equal(corc.jac_to_affine(curve, 1, msm_out.cpu().numpy().view(np.uint64)[:3 * nl]),
+                          corc.jac_to_affine(curve, 1, msm_ref.cpu().numpy().view(np.uint64)[:3 * nl])), \
+        "the MSM issued in the middle of the queue"
+    for k in range(K):
+        got = bench.gpu_proof_affine(curve, outs[k].cpu().numpy())
+        want = bench.gpu_proof_affine(curve, refs[k])
+        assert all(np.array_equal(g, w_) for g, w_ in zip(got, want)), "queued proof %d" % k
+    wl.pk.close()
