@@ -645,7 +645,7 @@ def main():
     # HBM traffic of that kernel: PMC counters cannot be read from inside the process; the committed summary of
     # the separate rocprofv3 --pmc passes over the same launch (same curve, group, size) supplies it.
     traffic, traffic_src = None, None
-    for name in ("r4p_pmc_g2_accumulate.json", "r4l_pmc_g2_accumulate.json", "r4f_pmc_g2_accumulate.json", "r4a_pmc_g2_accumulate.json", "r3_pmc_g2_accumulate.json", "r2_pmc_g2_accumulate.json",
+    for name in ("r4v_pmc_g2_accumulate.json", "r4p_pmc_g2_accumulate.json", "r4l_pmc_g2_accumulate.json", "r4f_pmc_g2_accumulate.json", "r4a_pmc_g2_accumulate.json", "r3_pmc_g2_accumulate.json", "r2_pmc_g2_accumulate.json",
                  "r1_pmc_g2_accumulate.json"):
         pmc_path = os.path.join(ROOT, "profiles", name)
         if args.log_m == 20 and curve == "bn254" and world == 1 and os.path.exists(pmc_path):
