@@ -60,7 +60,8 @@ struct MsmGeom {
 
 // window size: plain mode keeps ~32 points per bucket; table mode has a single bucket set of W*n entries:
 // c = log2(n) - 3 keeps the bucket reduction at a few percent of the MSM (measured at 2^20: c = 17 beats
-// both 16 and 20)
+// both 16 and 20; again in round 4 with the last reduction off the critical path, profiles/r4w_table_window_sweep.txt:
+// 17: 10.19 ms per proof, 18: 11.10, 19: 11.35, 20: 11.83; H alone at 19 / 20: 10.28 / 10.38)
 inline unsigned msm_window_bits(size_t n, bool table) {
   unsigned lg = 0;
   while (((size_t)1 << (lg + 1)) <= n) lg++;
