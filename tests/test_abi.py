@@ -26,6 +26,24 @@ def test_header_symbols_exported():
     assert sorted(EXPORTED) == decl, "python binding list and header disagree"
 
 
+def test_flag_constants_agree_with_the_header():
+    """enum dg16_flags of include/dg16.h == the F_* constants the Python binding passes (and the Rust block of
+    INTEGRATION.md, for the flags it lists)."""
+    from dg16_amd import lib
+    txt = open(os.path.join(ROOT, "include", "dg16.h")).read()
+    body = re.search(r"enum dg16_flags \{(.*?)\};", txt, flags=re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    hdr = {k: int(v) for k, v in re.findall(r"DG16_(F_[A-Z_]+)\s*=\s*(\d+)u", body)}
+    assert len(hdr) >= 6 and len(set(hdr.values())) == len(hdr)
+    for v in hdr.values():
+        assert v & (v - 1) == 0, "flags are single bits"
+    for name, value in hdr.items():
+        assert getattr(lib, name) == value, name
+    rust = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    for name, value in re.findall(r"pub const DG16_(F_[A-Z_]+): c_uint = (\d+);", rust):
+        assert hdr[name] == int(value), name
+
+
 def test_no_cpu_fallback():
     import torch
     if torch.cuda.is_available():
