@@ -40,7 +40,7 @@ int dg16_ctx_create(int device, dg16_ctx** out) {
     DG_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
     const char* pe = getenv("DG16_SIDE_PRIORITY");
     const bool side_prio = !(pe && atoi(pe) == 0);
-    // DG16_CU_RESERVE=k: the streams of the saturating kernels (channel 0 and the prep stream) are confined to all but
+    // DG16_CU_RESERVE=k: the stream of the saturating kernels (channel 0) is confined to all but
     // the last k compute units, so that the latency-bound chains on the side streams (bucket reductions, s*A, r*B1)
     // run on CUs they do not share with accumulation waves.  Pays on short shards (one process per GPU), where
     // those chains ARE the proof time; costs k/256 of the throughput kernels.
@@ -53,25 +53,16 @@ int dg16_ctx_create(int device, dg16_ctx** out) {
     std::vector<uint32_t> mask((size_t)(ctx->compute_units + 31) / 32, 0u);
     for (int cu = 0; cu < ctx->compute_units - reserve; cu++) mask[cu / 32] |= 1u << (cu % 32);
     const bool masked = reserve > 0 && reserve < ctx->compute_units;
-    // DG16_MAIN2=1: aux[1] becomes a second lane for saturating kernels BELOW channel 0's priority (prover_impl.h,
-    // DG16_EXP bit 16): channel 0 moves to the middle of the priority range, aux[1] takes the lowest
-    const char* m2 = getenv("DG16_MAIN2");
-    const bool main2 = m2 && atoi(m2) != 0 && prio_lo - prio_hi >= 2;
-    const int prio_main = main2 ? (prio_lo + prio_hi) / 2 : prio_lo;
     for (int i = 0; i < kChannels; i++) {
       if (i == 0 && masked)
         DG_HIP(hipExtStreamCreateWithCUMask(&ctx->ch[i].own, (uint32_t)mask.size(), mask.data()));
       else
-      DG_HIP(hipStreamCreateWithPriority(&ctx->ch[i].own, hipStreamNonBlocking, (i > 0 && side_prio) ? prio_hi : prio_main));
+      DG_HIP(hipStreamCreateWithPriority(&ctx->ch[i].own, hipStreamNonBlocking, (i > 0 && side_prio) ? prio_hi : prio_lo));
       ctx->ch[i].cur = ctx->ch[i].own;
       for (int e = 0; e < 4; e++) DG_HIP(hipEventCreate(&ctx->ch[i].ev[e]));
     }
     for (auto& e : ctx->pipe_ev) DG_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     DG_HIP(hipStreamCreateWithPriority(&ctx->aux[0], hipStreamNonBlocking, side_prio ? prio_hi : prio_lo));
-    if (masked)
-      DG_HIP(hipExtStreamCreateWithCUMask(&ctx->aux[1], (uint32_t)mask.size(), mask.data()));
-    else
-      DG_HIP(hipStreamCreateWithPriority(&ctx->aux[1], hipStreamNonBlocking, (side_prio && !main2) ? prio_hi : prio_lo));
     DG_HIP(hipHostMalloc((void**)&ctx->dev_flag_host, sizeof(unsigned), hipHostMallocMapped));
     *ctx->dev_flag_host = 0;
     DG_HIP(hipHostGetDevicePointer((void**)&ctx->dev_flag, ctx->dev_flag_host, 0));

@@ -75,7 +75,7 @@ struct dg16_ctx {
   // context waits for it on its own stream (Call) -- except the calls that are known not to touch what the tail uses
   // (R1CS x witness on device pointers; the next overlapped proof, which places the waits itself).
   std::atomic<bool> tail_pending{false};
-  hipStream_t aux[2] = {};   // extra internal streams of the prover pipeline (never handed out)
+  hipStream_t aux[1] = {};   // extra internal stream of the prover pipeline (never handed out): B1's reduction, the exchanges
   dg16::Channel xws[2];      // workspace-only (no stream): the bucket buffers of the H and L MSMs of a proof
   // Sticky argument-error flag of stream-ordered calls (pinned host word mapped into the device: kernels OR
   // bits into it, dg16_sync reads it after the stream has drained).  bit 0: dg16_qap index out of range.

@@ -205,15 +205,17 @@ static bool msms_typed(dg16_ctx* ctx, Call& k0, Call& k1, Call& k2, const PkDev&
   // 2^20 proof with H's reduction on a fifth stream).  The exchanges of a distributed proof ride on `aux`.
   hipStream_t xch = ctx->aux[0];
 
-  // Round-3 schedule.  Main stream (every saturating kernel, back to back):
-  //     h-polynomial | B (G2) accumulation | A, B1, L accumulation -- ONE launch of three instances | H accumulation
-  //   * A, B1 and L share the digit sort of w[1..] ++ [r, s, -rs], so they are instances of one accumulation launch
-  //     and of ONE bucket-reduction chain (msm_impl.h: MsmBases): one ramp-down instead of three, 7 reduction launches
-  //     instead of 21, three times the lanes in each of them;
+  // Schedule.  Main stream (every saturating kernel, back to back):
+  //     h-polynomial | B (G2) accumulation | A | B1 | L accumulations | H accumulation
+  //   * A, B1, B and L share the digit sort of w[1..] ++ [r, s, -rs];
   //   * the digit sorts (ten small latency-bound launches each) run on `side`: the sort of w under the h-polynomial
   //     (which needs nothing but a, b, c and goes first), the sort of h under the G2 accumulation;
   //   * reductions: B's on `side2` behind its accumulation (the longest chain: it has all G1 accumulations to hide
-  //     behind), A / B1 / L's on `side` followed by the two serial scalar multiples s*A', r*B1'; H's is the exposed tail.
+  //     behind), A's and L's on `side`, B1's on `xch` followed by the two serial scalar multiples s*A', r*B1'; H's is
+  //     the exposed tail (or, with overlap_tail, runs on `side2` under the next proof).
+  // Measured and removed (rounds 2-4): A / B1 / L as three instances of ONE launch with one reduction
+  // chain (12.5 vs 11.4 ms: the 4-ms launch starves B's reduction waves of SIMD slots), a second low-priority lane of
+  // saturating kernels, the h-polynomial on a side stream, B's reduction after H's accumulation.
   // Distributed proof: the three stages of the sharded h-polynomial interleave with the accumulations so that each
   // all-to-all hides behind one:  stage 0 | a2a 1 || B | stage 1 | a2a 2 || A, B1, L | stage 2 | sort h | H.
   const unsigned n_ranks = dist ? comm->n_ranks(comm->self) : 1, rank = dist ? comm->rank(comm->self) : 0;
@@ -228,20 +230,10 @@ static bool msms_typed(dg16_ctx* ctx, Call& k0, Call& k1, Call& k2, const PkDev&
     DG_HIP(hipEventRecord(ev[ev_done], xch));
   };
 
-  // DG16_HPOLY_SIDE=1 (experiment): the sort of w goes down MAIN and the h-polynomial + the sort of h go down `side`,
-  // so that the G2 accumulation starts as soon as the digits exist and the (memory-bound) transforms run next to it.
-  static const bool hpoly_side = [] { const char* e = getenv("DG16_HPOLY_SIDE"); return e && atoi(e) != 0; }();
-  const bool swap_h = hpoly_side && !dist && !h_given;
-  // DG16_EXP=<bits> (TIMING experiments of the schedule; bits 0, 1, 3 give a WRONG proof -- they bound what a reduction
-  // chain costs the kernels it runs next to):  1 skip B's (G2) bucket reduction, 2 skip the G1 reductions of A, B1, L
-  // and the two scalar multiples, 4 B's reduction starts only after H's accumulation (runs next to H's reduction at
-  // the end of the proof instead of under the G1 accumulations), 8 skip the two scalar multiples only
-  static const unsigned exp_bits = [] { const char* e = getenv("DG16_EXP"); return e ? (unsigned)atoi(e) : 0u; }();
   // side: the digit sort shared by A, B1, B and L; its buffers live in channel 1
-  hipStream_t sort_stream = swap_h ? main : side;
   DG_HIP(hipStreamWaitEvent(side, ev[8], 0));
-  MsmSort st_ab = msm_sort_on<Fr, CT::SCALAR_BITS>(sort_stream, k1.c, sc_ab, n_ab + 3, mont, true, pk.c_ab, pk.stride);
-  DG_HIP(hipEventRecord(ev[13], sort_stream));
+  MsmSort st_ab = msm_sort_on<Fr, CT::SCALAR_BITS>(side, k1.c, sc_ab, n_ab + 3, mont, true, pk.c_ab, pk.stride);
+  DG_HIP(hipEventRecord(ev[13], side));
   MsmBuffers<Fq2> buf_b2 = msm_buffers<Fq2>(k2.c, st_ab.g);
 
   // main: h (whole, or stage 0 of the sharded form)
@@ -252,9 +244,7 @@ static bool msms_typed(dg16_ctx* ctx, Call& k0, Call& k1, Call& k2, const PkDev&
     h_poly_dist_stage(k0, CURVE, log_m, rank, n_ranks, 0, rows_in, xbuf_a);
     exchange(3, 4);
   } else if (!h_given) {
-    if (swap_h) k0.c.cur = side;          // the launches of h_poly_launch follow the channel's current stream
     h_poly_launch(k0, CURVE, a_dev, b_dev, c_dev, log_m, h_dev);
-    k0.c.cur = main;
     h_scalars = h_dev + pk.h_lo;
   }
   MsmSort st_h;
@@ -277,13 +267,10 @@ static bool msms_typed(dg16_ctx* ctx, Call& k0, Call& k1, Call& k2, const PkDev&
   msm_accumulate_phase<Fq2>(main, st_ab, buf_b2, pk.b2_q);
   k2.c.ev_valid[1] = true;
   DG_HIP(hipEventRecord(ev[2], main));
-  auto b_reduction = [&] {
-    DG_HIP(hipStreamWaitEvent(side2, ev[2], 0));
-    if (!(exp_bits & 1u)) msm_bucket_phase<Fq2>(side2, st_ab, buf_b2, false, res_b2);
-    hipLaunchKernelGGL(prover_stage1_g2_kernel<Fq2>, dim3(1), dim3(64), 0, side2, res_b2, fixed_g2, first_shard);
-    DG_HIP(hipEventRecord(ev[5], side2));
-  };
-  if (!(exp_bits & 4u)) b_reduction();
+  DG_HIP(hipStreamWaitEvent(side2, ev[2], 0));
+  msm_bucket_phase<Fq2>(side2, st_ab, buf_b2, false, res_b2);
+  hipLaunchKernelGGL(prover_stage1_g2_kernel<Fq2>, dim3(1), dim3(64), 0, side2, res_b2, fixed_g2, first_shard);
+  DG_HIP(hipEventRecord(ev[5], side2));
   if (dist) {
     const void* in1[1] = {xbuf_b};
     DG_HIP(hipStreamWaitEvent(main, ev[4], 0));
@@ -291,36 +278,9 @@ static bool msms_typed(dg16_ctx* ctx, Call& k0, Call& k1, Call& k2, const PkDev&
     exchange(9, 11);
   }
 
-  // main: A, B1, L.  They share the sort, so they CAN run as three instances of one launch with one reduction chain
-  // (DG16_ABL_MERGED=1; results land in rec[kRecA], rec[kRecB1], rec[kRecL]) -- measured SLOWER on one GPU (12.5 vs
-  // 11.4 ms per 2^20 proof): the reduction waves of B (G2: 230-256 VGPRs each) only get onto a SIMD when accumulation
-  // waves leave it, which happens at the end of a launch -- one 4-ms launch starves them where three 1.3-ms launches
-  // do not, and B's reduction chain becomes the critical path.  Default: three launches, three reductions on side
-  // streams (A's and L's on `side`, B1's on `aux` followed by the two serial scalar multiples s*A', r*B1').
-  static_assert(kRecA == 0 && kRecB1 == 1 && kRecL == 2, "the three-instance reduction writes rec[0..2] back to back");
-  static const bool merged = [] { const char* e = getenv("DG16_ABL_MERGED"); return e && atoi(e) != 0; }();
-  // DG16_EXP bit 16 (with DG16_MAIN2=1 at context creation and GPU_MAX_HW_QUEUES >= 5 in the environment): a SECOND lane
-  // of saturating kernels on a stream of LOWER priority than `main` -- the accumulations of B1 and H go there, those of
-  // B, A and L stay on main.  Kernels of one stream run strictly one after another, so every accumulation launch ends
-  // in a ramp-down with the chip half empty (a workgroup lives ~0.3 ms, a launch ~1.3 ms); the low-priority lane's
-  // workgroups are dispatched exactly when main has none left to dispatch, i.e. into those ramps.
-  const bool two_lane = (exp_bits & 16u) && !dist && !merged;
-  hipStream_t lane2 = two_lane ? ctx->aux[1] : main;
-  if (merged) {
-    MsmBuffers<Fq> buf_abl = msm_buffers<Fq>(k0.c, st_ab.g, 3);
-    const void* abl_tables[3] = {pk.a_q, pk.b1_q, pk.l_q};
-    DG_HIP(hipEventRecord(k1.c.ev[2], main));
-    msm_accumulate_phase<Fq>(main, st_ab, buf_abl, abl_tables);
-    DG_HIP(hipEventRecord(k1.c.ev[3], main));
-    k1.c.ev_valid[1] = true;
-    DG_HIP(hipEventRecord(ev[0], main));
-    DG_HIP(hipStreamWaitEvent(side, ev[0], 0));
-    if (!(exp_bits & 2u)) msm_bucket_phase<Fq>(side, st_ab, buf_abl, false, rec);
-    if (!(exp_bits & 10u))
-      hipLaunchKernelGGL((prover_stage1_g1_kernel<Fq, Fr>), dim3(2), dim3(64), 0, side, rec, fixed_g1, r_s, (int)mont,
-                         first_shard);
-    DG_HIP(hipEventRecord(ev[10], side));
-  } else {
+  // main: A, B1, L -- three launches, three reductions on side streams (A's and L's on `side`, B1's on `xch` followed
+  // by the two serial scalar multiples s*A', r*B1')
+  {
     MsmBuffers<Fq> buf_a = msm_buffers<Fq>(k0.c, st_ab.g);
     MsmBuffers<Fq> buf_b1 = msm_buffers<Fq>(k1.c, st_ab.g);
     MsmBuffers<Fq> buf_l = msm_buffers<Fq>(ctx->xws[1], st_ab.g);
@@ -329,24 +289,22 @@ static bool msms_typed(dg16_ctx* ctx, Call& k0, Call& k1, Call& k2, const PkDev&
     DG_HIP(hipEventRecord(k1.c.ev[3], main));
     k1.c.ev_valid[1] = true;
     DG_HIP(hipEventRecord(ev[0], main));
-    if (two_lane) DG_HIP(hipStreamWaitEvent(lane2, ev[13], 0));      // the shared sort
-    msm_accumulate_phase<Fq>(lane2, st_ab, buf_b1, pk.b1_q);
-    DG_HIP(hipEventRecord(ev[1], lane2));
+    msm_accumulate_phase<Fq>(main, st_ab, buf_b1, pk.b1_q);
+    DG_HIP(hipEventRecord(ev[1], main));
     msm_accumulate_phase<Fq>(main, st_ab, buf_l, pk.l_q);
     DG_HIP(hipEventRecord(ev[6], main));
     DG_HIP(hipStreamWaitEvent(side, ev[0], 0));
-    if (!(exp_bits & 2u)) msm_bucket_phase<Fq>(side, st_ab, buf_a, false, rec + kRecA);
+    msm_bucket_phase<Fq>(side, st_ab, buf_a, false, rec + kRecA);
     DG_HIP(hipEventRecord(ev[12], side));
     DG_HIP(hipStreamWaitEvent(xch, ev[1], 0));
     if (tail_fence) DG_HIP(hipStreamWaitEvent(xch, ev[18], 0));     // tail fence: rec[kRecB1] is read by the last assembly
-    if (!(exp_bits & 2u)) msm_bucket_phase<Fq>(xch, st_ab, buf_b1, false, rec + kRecB1);
+    msm_bucket_phase<Fq>(xch, st_ab, buf_b1, false, rec + kRecB1);
     DG_HIP(hipStreamWaitEvent(xch, ev[12], 0));
-    if (!(exp_bits & 10u))
-      hipLaunchKernelGGL((prover_stage1_g1_kernel<Fq, Fr>), dim3(2), dim3(64), 0, xch, rec, fixed_g1, r_s, (int)mont,
-                         first_shard);
+    hipLaunchKernelGGL((prover_stage1_g1_kernel<Fq, Fr>), dim3(2), dim3(64), 0, xch, rec, fixed_g1, r_s, (int)mont,
+                       first_shard);
     DG_HIP(hipEventRecord(ev[7], xch));
     DG_HIP(hipStreamWaitEvent(side, ev[6], 0));
-    if (!(exp_bits & 2u)) msm_bucket_phase<Fq>(side, st_ab, buf_l, false, rec + kRecL);
+    msm_bucket_phase<Fq>(side, st_ab, buf_l, false, rec + kRecL);
     DG_HIP(hipStreamWaitEvent(side, ev[7], 0));
     DG_HIP(hipEventRecord(ev[10], side));             // A, B1, L, s*A', r*B1' all done
   }
@@ -358,27 +316,19 @@ static bool msms_typed(dg16_ctx* ctx, Call& k0, Call& k1, Call& k2, const PkDev&
     h_poly_dist_stage(k0, CURVE, log_m, rank, n_ranks, 2, in2, h_dev);
     st_h = msm_sort_on<Fr, CT::SCALAR_BITS>(main, k0.c, h_dev, n_h, true, true, pk.c_h, pk.stride);
   } else {
-    DG_HIP(hipStreamWaitEvent(lane2, ev[15], 0));
+    DG_HIP(hipStreamWaitEvent(main, ev[15], 0));
   }
   MsmBuffers<Fq> buf_h = msm_buffers<Fq>(ctx->xws[0], st_h.g);
-  if (tail_fence) DG_HIP(hipStreamWaitEvent(lane2, ev[18], 0));     // tail fence: H's buckets
-  msm_accumulate_phase<Fq>(lane2, st_h, buf_h, pk.h_q);
-  if (exp_bits & 4u) {
-    DG_HIP(hipEventRecord(ev[2], lane2));      // (re-recorded: B's accumulation is long done; the wait is on H's)
-    b_reduction();
-  }
-  const bool tail_on_side2 = overlap_tail && !dist && !h_given && !two_lane && !merged;
+  if (tail_fence) DG_HIP(hipStreamWaitEvent(main, ev[18], 0));     // tail fence: H's buckets
+  msm_accumulate_phase<Fq>(main, st_h, buf_h, pk.h_q);
+  const bool tail_on_side2 = overlap_tail && !dist && !h_given;
   if (tail_on_side2) {
     DG_HIP(hipEventRecord(ev[17], main));
     DG_HIP(hipStreamWaitEvent(side2, ev[17], 0));
     msm_bucket_phase<Fq>(side2, st_h, buf_h, false, res_h);
     DG_HIP(hipStreamWaitEvent(side2, ev[10], 0));       // A, B1, L results, s*A, r*B1 (B's are in order on side2 itself)
   } else {
-    msm_bucket_phase<Fq>(lane2, st_h, buf_h, false, res_h);
-  }
-  if (two_lane) {
-    DG_HIP(hipEventRecord(ev[16], lane2));
-    DG_HIP(hipStreamWaitEvent(main, ev[16], 0));
+    msm_bucket_phase<Fq>(main, st_h, buf_h, false, res_h);
   }
   DG_HIP(hipStreamWaitEvent(main, ev[10], 0));          // A, B1, L results, s*A, r*B1
   DG_HIP(hipStreamWaitEvent(main, ev[5], 0));           // B result
