@@ -26,6 +26,12 @@ def test_header_symbols_exported():
     assert sorted(EXPORTED) == decl, "python binding list and header disagree"
 
 
+def test_rust_extern_block_lists_the_header_symbols():
+    """INTEGRATION.md section 1 (the `extern "C"` block a maintainer would paste into dg16-sys) == include/dg16.h."""
+    rust = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    assert sorted(set(re.findall(r"pub fn (dg16_[a-z0-9_]+)\s*\(", rust))) == declared_symbols()
+
+
 def test_flag_constants_agree_with_the_header():
     """enum dg16_flags of include/dg16.h == the F_* constants the Python binding passes (and the Rust block of
     INTEGRATION.md, for the flags it lists)."""
