@@ -96,7 +96,8 @@ inline MsmGeom msm_geometry(size_t n, unsigned scalar_bits, bool table = false, 
     size_t mean = g.region >> g.log_nb;   // entries per bucket
     unsigned lm = 0;
     while (((size_t)2 << lm) <= mean) lm++;
-    int sl = (int)lm - 3;      // mean/8: 2^20-point table, mean 240 -> 16 (measured 18.8 ms per proof; 32: 19.5; 8: 19.6)
+    int sl = (int)lm - 3;      // mean/8: 2^20-point table, mean 240 -> 16 (measured 18.8 ms per proof; 32: 19.5; 8: 19.6;
+                               // round 4, profiles/r4seg_segment_length_ab.txt: 16: 10.01-10.04 ms, 32: 10.14-10.19)
     if (sl < 4) sl = 4;
     // ... but never so long that the launch runs out of lanes (a 2^17-point shard with 32-entry segments has
     // 1.2 waves per SIMD: measured 0.62 ms per G1 accumulation instead of 0.25)
