@@ -114,7 +114,10 @@ class Workload:
     does not depend on the R1CS being satisfied (qap.rs:44-91 sets c = a o b), so A, B are uniform sparse rows."""
 
     def __init__(self, ctx, dev, log_m, rank=0, world=1, seed=20, curve=CURVE, nv=None, nc=None, ni=2, nnz=3,
-                 h_sharded=None):
+                 h_sharded=None, share=None):
+        """share: another Workload of the same shape and seed -- its bases, matrices and assignment are reused (the N
+        shard keys of one proving key held in ONE process: sharded_prove_in_process); only the key shard and this
+        rank's a, b, c rows are new."""
         import dg16_amd  # noqa: F401
         self.ctx, self.dev, self.curve = ctx, dev, curve
         self.m = 1 << log_m
@@ -131,11 +134,16 @@ class Workload:
             ctx.gen_bases_dev(curve, group, seed * 100 + s, cnt, t.data_ptr())
             return t
 
-        self.aq, self.b1q, self.b2q = bases(1, nv, 1), bases(1, nv, 2), bases(2, nv, 3)
-        self.hq, self.lq = bases(1, m, 4), bases(1, nv - ni, 5)
-        f1, f2 = bases(1, 3, 6), bases(2, 2, 7)
-        ctx.sync(0)          # the generators ran on the library's stream: finish before torch touches them
-        self.fixed = torch.cat([f1, f2])
+        if share is not None:
+            assert (share.curve, share.m, share.nv, share.nc, share.ni) == (curve, m, nv, nc, ni)
+            self.aq, self.b1q, self.b2q, self.hq, self.lq, self.fixed = (share.aq, share.b1q, share.b2q, share.hq,
+                                                                         share.lq, share.fixed)
+        else:
+            self.aq, self.b1q, self.b2q = bases(1, nv, 1), bases(1, nv, 2), bases(2, nv, 3)
+            self.hq, self.lq = bases(1, m, 4), bases(1, nv - ni, 5)
+            f1, f2 = bases(1, 3, 6), bases(2, 2, 7)
+            ctx.sync(0)          # the generators ran on the library's stream: finish before torch touches them
+            self.fixed = torch.cat([f1, f2])
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         # N > 1 (2 / 4 / 8 ranks): the h-polynomial is sharded -- this rank evaluates only its cyclic rows of a, b, c
@@ -147,17 +155,21 @@ class Workload:
                                 self.hq.data_ptr(), self.lq.data_ptr(), self.fixed.data_ptr(), device_ptrs=True,
                                 shard=rank, n_shards=world, h_cyclic=self.h_sharded)
         self.pk_build_s = time.perf_counter() - t0
-        gen = torch.Generator(device=dev)
-        gen.manual_seed(seed)
-        # CSR matrices A, B (Montgomery coefficients) and the full assignment (canonical integers, w[0] = 1)
-        self.row_ptr = (torch.arange(nc + 1, dtype=torch.int64, device=dev) * nnz).to(torch.int32)
-        self.a_col = torch.randint(0, nv, (nc * nnz,), dtype=torch.int32, device=dev, generator=gen)
-        self.b_col = torch.randint(0, nv, (nc * nnz,), dtype=torch.int32, device=dev, generator=gen)
-        self.a_val = rand_fr(nc * nnz, dev, gen, curve)
-        self.b_val = rand_fr(nc * nnz, dev, gen, curve)
-        self.w = rand_fr(nv, dev, gen, curve)
-        self.w[0] = 0
-        self.w[0, 0] = 1
+        if share is not None:
+            self.row_ptr, self.a_col, self.b_col, self.a_val, self.b_val, self.w = (
+                share.row_ptr, share.a_col, share.b_col, share.a_val, share.b_val, share.w)
+        else:
+            gen = torch.Generator(device=dev)
+            gen.manual_seed(seed)
+            # CSR matrices A, B (Montgomery coefficients) and the full assignment (canonical integers, w[0] = 1)
+            self.row_ptr = (torch.arange(nc + 1, dtype=torch.int64, device=dev) * nnz).to(torch.int32)
+            self.a_col = torch.randint(0, nv, (nc * nnz,), dtype=torch.int32, device=dev, generator=gen)
+            self.b_col = torch.randint(0, nv, (nc * nnz,), dtype=torch.int32, device=dev, generator=gen)
+            self.a_val = rand_fr(nc * nnz, dev, gen, curve)
+            self.b_val = rand_fr(nc * nnz, dev, gen, curve)
+            self.w = rand_fr(nv, dev, gen, curve)
+            self.w[0] = 0
+            self.w[0, 0] = 1
         self.a = torch.empty((m // world if self.h_sharded else m, 4), dtype=torch.int64, device=dev)
         self.b = torch.empty_like(self.a)
         self.c = torch.empty_like(self.a)
@@ -247,6 +259,183 @@ def prove_once(ctx, wl, rs=None):
     for ch in range(3):
         ctx.sync(ch)
     return proof.cpu().numpy()
+
+
+
+def _all_to_all_in_process(bufs):
+    """bufs[r]: rank r's send buffer [peer][...] -> receive buffers [src][...] (what the all-to-all over xGMI moves)."""
+    n = len(bufs)
+    chunks = [b.view(n, -1) for b in bufs]
+    return [torch.stack([chunks[src][dst] for src in range(n)]).contiguous().view(-1) for dst in range(n)]
+
+
+class ShardedInProcess:
+    """BASELINE config 5's data path with all N ranks played by ONE process on one GPU: N shard keys of one proving
+    key (DG16_F_H_CYCLIC: 1/N of every MSM's bases as window tables, the h bases h_query[rank + N j]), cyclic QAP rows
+    (dg16_qap_rows), the three stages of the sharded h-polynomial with the two all-to-alls as device transposes,
+    dg16_groth16_msms_h per shard, the N records concatenated as the all-gather would, dg16_groth16_assemble.  Same
+    entry points, same kernels, same shard sizes as one process per GPU -- only the wire is a device copy.  Bases,
+    matrices and assignment are generated once and shared by the N shard Workloads.
+    (local_groth_bench.rs:83-158 is the reference shape: FFTs + five MSMs on a BLS curve.)"""
+
+    def __init__(self, ctx, dev, curve, log_m, world, seed=33):
+        from dg16_amd.parallel import h_is_sharded
+        assert h_is_sharded(1 << log_m, world), "power-of-two rank count and m >= N^2"
+        self.ctx, self.dev, self.curve, self.log_m, self.world = ctx, dev, curve, log_m, world
+        first = Workload(ctx, dev, log_m, 0, world, seed=seed, curve=curve)
+        self.shards = [first] + [Workload(ctx, dev, log_m, k, world, seed=seed, curve=curve, share=first)
+                                 for k in range(1, world)]
+        self.M = (1 << log_m) // world
+        assert all(wl.h_sharded and wl.pk.info()["n_h"] == self.M for wl in self.shards)
+        i64 = dict(dtype=torch.int64, device=dev)
+        self.send = [torch.empty(3 * self.M * 4, **i64) for _ in range(world)]
+        self.h = [torch.empty(self.M * 4, **i64) for _ in range(world)]
+        self.recs = [torch.empty(ctx.results_bytes(curve), dtype=torch.uint8, device=dev) for _ in range(world)]
+        self.proof = torch.empty(first.proof_bytes(), dtype=torch.uint8, device=dev)
+
+    def table_bytes(self):
+        return sum(wl.pk.info()["table_bytes"] for wl in self.shards)
+
+    def _sync(self):
+        for ch in range(3):
+            self.ctx.sync(ch)
+        torch.cuda.synchronize()
+
+    def prove(self):
+        """One proof; returns (proof tensor, seconds per rank [list]): the time each rank's kernels took between the
+        exchanges (qap_rows + stage 0, stage 1, stage 2 + the five partial MSMs), the exchanges themselves excluded."""
+        c, curve, log_m, world = self.ctx, self.curve, self.log_m, self.world
+        per_rank = [0.0] * world
+
+        def timed(r, fn):
+            self._sync()
+            t0 = time.perf_counter()
+            fn()
+            self._sync()
+            per_rank[r] += time.perf_counter() - t0
+
+        for r, wl in enumerate(self.shards):
+            def stage0(wl=wl, r=r):
+                wl.qap()
+                c.h_poly_dist_stage_dev(curve, log_m, r, world, 0, [wl.a.data_ptr(), wl.b.data_ptr(), wl.c.data_ptr()],
+                                        self.send[r].data_ptr())
+            timed(r, stage0)
+        recv = _all_to_all_in_process(self.send)
+        torch.cuda.synchronize()
+        for r in range(world):
+            timed(r, lambda r=r: c.h_poly_dist_stage_dev(curve, log_m, r, world, 1, [recv[r].data_ptr()],
+                                                         self.send[r].data_ptr()))
+        recv = _all_to_all_in_process(self.send)
+        torch.cuda.synchronize()
+        for r, wl in enumerate(self.shards):
+            def stage2(wl=wl, r=r):
+                c.h_poly_dist_stage_dev(curve, log_m, r, world, 2, [recv[r].data_ptr()], self.h[r].data_ptr())
+                c.groth16_msms_h_dev(wl.pk, self.h[r].data_ptr(), wl.w.data_ptr(), wl.rs, self.recs[r].data_ptr(),
+                                     scalars_mont=False)
+            timed(r, stage2)
+        gathered = torch.cat(self.recs)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        c.groth16_assemble_dev(self.shards[0].pk, gathered.data_ptr(), world, self.shards[0].rs, self.proof.data_ptr(),
+                               scalars_mont=False)
+        self._sync()
+        assemble = time.perf_counter() - t0
+        return self.proof, per_rank, assemble
+
+    def close(self):
+        for wl in self.shards:
+            wl.pk.close()
+        self.shards = []
+
+
+def sharded_in_process_line(ctx, dev, curve, log_m, world, steps, parity=True):
+    """`bench.py --shards-in-process N`: the sharded proof of a 2^log_m instance over N shard keys on one GPU, proved
+    `steps` times; the oracle proves the same instance (parity gate).  The figure is the slowest rank's compute per
+    proof (what an N-GPU node would run between its exchanges) -- NOT an N-GPU throughput: no byte crosses a link."""
+    t0 = time.perf_counter()
+    sp = ShardedInProcess(ctx, dev, curve, log_m, world)
+    build_s = time.perf_counter() - t0
+    sp.prove()
+    worst, asm = [], []
+    for _ in range(steps):
+        proof, per_rank, assemble = sp.prove()
+        worst.append(max(per_rank))
+        asm.append(assemble)
+    wl = sp.shards[0]
+    res = {"mode": "sharded proof, %d shard keys in one process on one GPU (exchanges = device copies)" % world,
+           "curve": curve, "log_domain": log_m, "shards": world,
+           "slowest_rank_compute_ms": sum(worst) / len(worst) * 1e3, "assemble_ms": sum(asm) / len(asm) * 1e3,
+           "all_ranks_compute_ms_last": [t * 1e3 for t in per_rank],
+           "key_table_bytes_all_shards": sp.table_bytes(), "keys_build_s": build_s, "steps": steps,
+           "exchange_bytes_per_rank": {"all_to_all_x2": 3 * 32 * sp.M, "all_gather_record": ctx.results_bytes(curve)}}
+    if parity:
+        (A, B, C), t_cpu = oracle_prove(wl, cpu_threads())
+        gA, gB, gC = gpu_proof_affine(curve, proof.cpu().numpy())
+        ok = bool(np.array_equal(A, gA) and np.array_equal(B, gB) and np.array_equal(C, gC))
+        res["parity_check"] = "pass (the oracle proved the same 2^%d instance: %.1f s on %d threads)" % (
+            log_m, t_cpu, cpu_threads()) if ok else "FAIL"
+    sp.close()
+    return res
+
+
+
+def table_window_bits(n):
+    """csrc/msm_impl.h: msm_window_bits(n, table = true)."""
+    lg = max(n, 1).bit_length() - 1
+    if n > (3 << lg) // 2:
+        lg += 1
+    c = lg - 3
+    if c < 16:
+        c = min(lg + 1, 16)
+    return max(4, min(20, c))
+
+
+def dry_run_plan(curve, log_m, world, steps, warmup):
+    """`bench.py --gpus N --dry-run`: what an N-GPU run of this command WILL do, without touching a GPU -- per-rank key
+    shard (points per MSM, window bits, table bytes: the formulas of csrc/prover_impl.h), the bytes each exchange
+    moves, and the exact command lines for the headline and for BASELINE config 5.  For the first run on a multi-GPU
+    node: nothing here has ever crossed a link."""
+    from dg16_amd.parallel import shard_bounds, h_is_sharded
+    m = 1 << log_m
+    nv, ni = m, 2
+    fq = FQ_BYTES[curve]
+    p1, p2 = 2 * fq, 4 * fq
+    bits = SCALAR_BITS[curve]
+    ranks = []
+    for r in range(world):
+        lo, hi = shard_bounds(nv - 1, r, world)
+        n_ab = hi - lo
+        n_h = m // world
+        c_ab, c_h = table_window_bits(n_ab + 3), table_window_bits(n_h)
+        w_ab, w_h = (bits + c_ab) // c_ab, (bits + c_h) // c_h
+        ranks.append({"rank": r, "n_ab": n_ab + 3, "n_h": n_h, "window_bits": {"ab": c_ab, "h": c_h},
+                      "windows": {"ab": w_ab, "h": w_h},
+                      "table_bytes": w_ab * (n_ab + 3) * (3 * p1 + p2) + w_h * n_h * p1})
+    sharded = world > 1 and h_is_sharded(m, world)
+    rec = (6 * 3 * fq + 3 * 2 * fq)           # A', B1', L, H, s A', r B1' (G1 Jacobian) + B' (G2 Jacobian)
+    exch = {"h_polynomial": ("two all-to-alls of %d bytes per rank (3 vectors x 32 B x m / N), %d bytes to each peer"
+                             % (3 * 32 * m // world, 3 * 32 * m // world // world)) if sharded else
+            "replicated on every rank (N not in {2, 4, 8} or m < N^2): no exchange",
+            "results": "one all-gather of %d-byte records (%d bytes received per rank)" % (rec, rec * world)} if world > 1 \
+        else {}
+    me = os.path.basename(__file__)
+    launch = ("python -m torch.distributed.run --nnodes=1 --nproc-per-node %d --master-addr 127.0.0.1 --master-port 29500 "
+              % world) if world > 1 else "python "
+    return {"dry_run": True, "curve": curve, "log_domain": log_m, "n_gpus": world, "steps": steps, "warmup": warmup,
+            "h_polynomial_sharded": sharded, "ranks": ranks,
+            "table_bytes_per_rank_max": max(r["table_bytes"] for r in ranks),
+            "hbm_per_gpu_bytes": 288 * 10**9, "exchanges_per_proof": exch,
+            "transport": "native RCCL communicator of libdg16 (dlopen of librccl); every rank falls back to "
+                         "torch.distributed together if it cannot be bound or a rank cannot join; config.rccl_ranks on "
+                         "the line = what the communicator itself reports, asserted == n_gpus",
+            "commands": {
+                "this_run": "%s%s --gpus %d --steps %d --warmup %d --curve %s --log-m %d" % (
+                    launch, me, world, steps, warmup, curve, log_m),
+                "headline_bn254_2e20": "python %s --gpus %d --steps 20 --warmup 3" % (me, world),
+                "config5_bls12_381_2e24": "python %s --gpus 8 --curve bls12_381 --log-m 24 --steps 3 --warmup 1 "
+                                          "--no-replicas [--full-parity]" % me,
+                "config5_data_path_on_one_gpu": "python %s --curve bls12_381 --log-m 24 --shards-in-process 8 --steps 2 "
+                                                "--full-parity" % me}}
 
 
 def cpu_threads():
@@ -519,6 +708,13 @@ def main():
     ap.add_argument("--no-overlap", action="store_true",
                     help="N = 1: do not pass DG16_F_OVERLAP_TAIL (each proof's last bucket reduction and assembly then "
                          "finish on channel 0 before the next proof's first kernel, as in rounds 1-3)")
+    ap.add_argument("--shards-in-process", type=int, default=0, metavar="N",
+                    help="N = 1 only: prove the instance over N shard keys (2, 4, 8) held by THIS process -- config 5's "
+                         "data path (cyclic h shards, dg16_qap_rows, three h stages, N records, assembly) with device "
+                         "copies for the exchanges -- against the oracle's proof of the same instance, and print that line")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="print the plan of this command (per-rank key shard and table bytes, exchange sizes, command "
+                         "lines) as JSON and exit -- no GPU is touched")
     ap.add_argument("--transport", default="rccl", choices=["rccl", "torch", "python"],
                     help="N > 1: native RCCL communicator of libdg16 (default), torch.distributed under the native "
                          "pipeline, or the Python-driven protocol")
@@ -527,6 +723,9 @@ def main():
     if args.full_parity:
         args.cpu_sample_log = max(args.cpu_sample_log, args.log_m)
 
+    if args.dry_run:
+        print(json.dumps(dry_run_plan(curve, args.log_m, args.gpus, args.steps, args.warmup), indent=1))
+        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # plain `python bench.py --gpus N`: become the launcher of N ranks (one process per GPU) and relay their output
         raise SystemExit(self_launch(args.gpus))
@@ -560,6 +759,16 @@ def main():
     ctx = dg16_amd.Context(local_rank)
     if args.table_budget_gb:
         ctx.set_table_budget(int(args.table_budget_gb * 1e9))
+    if args.shards_in_process:
+        if world != 1:
+            raise SystemExit("--shards-in-process plays all ranks in one process: use it with --gpus 1")
+        res = sharded_in_process_line(ctx, dev, curve, args.log_m, args.shards_in_process, args.steps,
+                                      parity=not args.no_cpu_baseline and
+                                      (args.log_m <= max(args.cpu_sample_log, 22) or args.full_parity))
+        print(json.dumps(res))
+        if res.get("parity_check", "pass").startswith("FAIL"):
+            raise SystemExit("sharded in-process proof differs from the oracle proof")
+        return
     wl = Workload(ctx, dev, args.log_m, rank, world, curve=curve)
     # N > 1, --transport rccl: if librccl cannot be bound or a rank cannot join, ALL ranks fall back to
     # torch.distributed together (make_prover decides collectively); config.parallelism says which transport ran
@@ -658,6 +867,8 @@ def main():
     # still printed (a timed run must not vanish in an accounting check), with the fact on it.
     valu_over = valu_t > MAD_ISSUE_T * 1.0001 or whole_t > MAD_ISSUE_T
     rccl_ranks = prover.rccl_ranks() if hasattr(prover, "rccl_ranks") and world > 1 else None
+    if rccl_ranks is not None and rccl_ranks != world:
+        raise SystemExit("the RCCL communicator reports %s ranks, the job has %d" % (rccl_ranks, world))
     res = {
         "metric": "groth16_constraints_per_sec",
         "value": value,

@@ -35,34 +35,18 @@ int dg16_ctx_create(int device, dg16_ctx** out) {
     ctx->name = p.gcnArchName;
     // Channel 0 carries the saturating kernels of a proof; channels 1, 2 and the aux streams carry the latency-bound
     // bucket reductions that hide behind them: those get the higher priority, so that their few waves are scheduled
-    // ahead of the thousands of queued accumulation waves (DG16_SIDE_PRIORITY=0 switches it off).
+    // ahead of the thousands of queued accumulation waves.  (Measured and settled in round 4,
+    // profiles/r4prio_side_priority_cu_reserve_ab.txt: no priority, or channel 0 confined to all but k CUs through
+    // hipExtStreamCreateWithCUMask, changed nothing under the queue schedule -- the switches are gone.)
     int prio_lo = 0, prio_hi = 0;
     DG_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
-    const char* pe = getenv("DG16_SIDE_PRIORITY");
-    const bool side_prio = !(pe && atoi(pe) == 0);
-    // DG16_CU_RESERVE=k: the stream of the saturating kernels (channel 0) is confined to all but
-    // the last k compute units, so that the latency-bound chains on the side streams (bucket reductions, s*A, r*B1)
-    // run on CUs they do not share with accumulation waves.  Pays on short shards (one process per GPU), where
-    // those chains ARE the proof time; costs k/256 of the throughput kernels.
-    const char* re = getenv("DG16_CU_RESERVE");
-    int reserve = re ? atoi(re) : 0;
-    if (reserve < 0) reserve = 0;                                           // (a negative value would index past the mask)
-    if (reserve > ctx->compute_units - 1) reserve = ctx->compute_units - 1;
-    // NB: a CU-masked stream (hipExtStreamCreateWithCUMask) is a BLOCKING stream of default priority: with masking
-    // on, channel 0 synchronises with the NULL stream.  The library itself issues nothing on the NULL stream.
-    std::vector<uint32_t> mask((size_t)(ctx->compute_units + 31) / 32, 0u);
-    for (int cu = 0; cu < ctx->compute_units - reserve; cu++) mask[cu / 32] |= 1u << (cu % 32);
-    const bool masked = reserve > 0 && reserve < ctx->compute_units;
     for (int i = 0; i < kChannels; i++) {
-      if (i == 0 && masked)
-        DG_HIP(hipExtStreamCreateWithCUMask(&ctx->ch[i].own, (uint32_t)mask.size(), mask.data()));
-      else
-      DG_HIP(hipStreamCreateWithPriority(&ctx->ch[i].own, hipStreamNonBlocking, (i > 0 && side_prio) ? prio_hi : prio_lo));
+      DG_HIP(hipStreamCreateWithPriority(&ctx->ch[i].own, hipStreamNonBlocking, i > 0 ? prio_hi : prio_lo));
       ctx->ch[i].cur = ctx->ch[i].own;
       for (int e = 0; e < 4; e++) DG_HIP(hipEventCreate(&ctx->ch[i].ev[e]));
     }
     for (auto& e : ctx->pipe_ev) DG_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    DG_HIP(hipStreamCreateWithPriority(&ctx->aux[0], hipStreamNonBlocking, side_prio ? prio_hi : prio_lo));
+    DG_HIP(hipStreamCreateWithPriority(&ctx->aux[0], hipStreamNonBlocking, prio_hi));
     DG_HIP(hipHostMalloc((void**)&ctx->dev_flag_host, sizeof(unsigned), hipHostMallocMapped));
     *ctx->dev_flag_host = 0;
     DG_HIP(hipHostGetDevicePointer((void**)&ctx->dev_flag, ctx->dev_flag_host, 0));
@@ -255,7 +239,7 @@ int dg16_msm(dg16_ctx* ctx, int curve, int group, const void* bases, const void*
     const void* dbases = stage_in(k, 0, bases, n_bases * pb, dev);
     const void* dscal = stage_in(k, 1, scalars, n_bases * 32, dev);
     void* dout = dev ? out : ws(k.c, 2, ob);
-    msm_launch(k, curve, group, dbases, dscal, n_bases, flags & DG16_F_SCALARS_MONT, affine, dout);
+    msm_launch(k, curve, group, dbases, dscal, n_bases, msm_mode(flags), affine, dout);
     if (!dev) stage_out(k, out, dout, ob, false);
     k.finish();
     if (!dev) DG_HIP(hipStreamSynchronize(k.s()));

@@ -222,8 +222,13 @@ void ntt_dist_launch(Call& k, int curve, const dg16_comm* comm, const void* in, 
 void ntt_launch(Call& k, int curve, void* data, unsigned log_n, int inverse, const void* coset_host);
 void h_poly_launch(Call& k, int curve, const void* a, const void* b, const void* c, unsigned log_m,
                    void* out);
+bool net_is_rccl(const dg16_net* net);     // rccl_net.hip: the library's own RCCL transport
+// `mode` of the plain-MSM entry points: bit 0 = scalars in Montgomery form, bit 1 = DG16_F_BASES_IN_SUBGROUP
+inline unsigned msm_mode(unsigned flags) {
+  return ((flags & DG16_F_SCALARS_MONT) ? 1u : 0u) | ((flags & DG16_F_BASES_IN_SUBGROUP) ? 2u : 0u);
+}
 void msm_launch(Call& k, int curve, int group, const void* bases, const void* scalars, size_t n,
-                bool scalars_mont, bool out_affine, void* out_dev);
+                unsigned mode, bool out_affine, void* out_dev);
 void gen_bases_launch(Call& k, int curve, int group, uint64_t seed, size_t n, void* out_dev);
 void to_affine_launch(Call& k, int curve, int group, const void* jac, void* out, size_t n);
 void* bases_table_launch(Call& k, int curve, int group, const void* bases, size_t n, size_t budget, unsigned* c,

@@ -304,7 +304,7 @@ static void pss_build(dg16_pss* pp) {
 // per-(curve, group) entry points defined in msm_<curve>_g<k>.hip
 namespace dg16 {
 #define DECL_G(name)                                                                                         \
-  void d_msm_##name(Call&, const dg16_pss*, const dg16_net*, int, const void*, const void*, size_t, bool, void*,   \
+  void d_msm_##name(Call&, const dg16_pss*, const dg16_net*, int, const void*, const void*, size_t, unsigned, void*, \
                     const void*, unsigned, unsigned);                                                                       \
   void packexp_##name(Call&, const dg16_pss*, int, const void*, size_t, void*);                                   \
   void mpc_combine_##name(Call&, const void*, const void*, unsigned, unsigned, bool, void*);                      \
@@ -452,7 +452,7 @@ int dg16_d_msm(dg16_ctx* ctx, const dg16_pss* pp, const dg16_net* net, int group
     const void* dbases = stage_in(k, 0, bases, n_bases * pb, dev);
     const void* dscal = stage_in(k, 1, scalars, n_bases * 32, dev);
     void* dout = dev ? out : ws(k.c, 2, pb / 2 * 3);
-    DISPATCH_G(d_msm, pp->curve, group, k, pp, net, channel, dbases, dscal, n_bases, flags & DG16_F_SCALARS_MONT, dout,
+    DISPATCH_G(d_msm, pp->curve, group, k, pp, net, channel, dbases, dscal, n_bases, msm_mode(flags), dout,
                nullptr, 0u, 1u)
     if (!dev) stage_out(k, out, dout, pb / 2 * 3, false);
     k.finish();
@@ -476,7 +476,7 @@ int dg16_d_msm_resident(dg16_ctx* ctx, const dg16_pss* pp, const dg16_net* net, 
     const void* dscal = stage_in(k, 1, scalars, n_scalars * 32, dev);
     void* dout = dev ? out : ws(k.c, 2, pb / 2 * 3);
     DISPATCH_G(d_msm, pp->curve, bases->group, k, pp, net, channel, nullptr, dscal, n_scalars,
-               flags & DG16_F_SCALARS_MONT, dout, bases->table, bases->c, bases->stride)
+               msm_mode(flags), dout, bases->table, bases->c, bases->stride)
     if (!dev) stage_out(k, out, dout, pb / 2 * 3, false);
     k.finish();
     if (!dev) DG_HIP(hipStreamSynchronize(k.s()));
@@ -637,7 +637,7 @@ static void d_msm_on_channel(dg16_ctx* ctx, const dg16_pss* pp, const dg16_net* 
   Call k(ctx, channel);
   const void* dbases = stage_in(k, 0, bases, n_bases * pb, dev);
   const void* dscal = stage_in(k, 1, scalars, n_bases * 32, dev);
-  DISPATCH_G(d_msm, pp->curve, group, k, pp, net, channel, dbases, dscal, n_bases, flags & DG16_F_SCALARS_MONT, out_dev,
+  DISPATCH_G(d_msm, pp->curve, group, k, pp, net, channel, dbases, dscal, n_bases, msm_mode(flags), out_dev,
              nullptr, 0u, 1u)
   k.finish();
   DG_HIP(hipStreamSynchronize(k.s()));     // the caller combines on another channel's stream
@@ -741,7 +741,12 @@ int dg16_prove_c(dg16_ctx* ctx, const dg16_pss* pp, const dg16_net* net, const v
         errs[c] = StatusError{DG16_ERR_HIP, e.what()};
       }
     };
-    if (flags & DG16_F_SERIAL_CHANNELS) {
+    // The library's own RCCL net runs the channels IN ORDER unless DG16_RCCL_JOIN_CHANNELS=1: three communicators driven
+    // concurrently from three host threads in an order that differs per rank is NCCL's documented deadlock hazard (all
+    // their kernels must be co-resident), each d_msm saturates the device anyway, and no multi-GPU box has ever run the
+    // joined form -- the safe form is the default there, the joined one an opt-in.
+    static const bool rccl_join = [] { const char* e = getenv("DG16_RCCL_JOIN_CHANNELS"); return e && e[0] == '1'; }();
+    if ((flags & DG16_F_SERIAL_CHANNELS) || (net_is_rccl(net) && !rccl_join)) {
       // a transport whose channels are NOT independent (one ordered pipe for all of them): the three d_msm one after
       // another in the fixed order 0, 1, 2 on every party -- same result, no concurrency
       for (int c = 0; c < 3 && (c == 0 || errs[c - 1].code == DG16_OK); c++) run(c);

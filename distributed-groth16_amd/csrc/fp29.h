@@ -661,6 +661,35 @@ DG_HD bool is_zero(const Fe<P, B, 1>& a) {
 }
 template <class P, int B, int LU>
 DG_HD bool is_zero(const Fe<P, B, LU>& a) { return is_zero(norm(a)); }
+// The same test with the full comparison as a ROLLED loop over the candidates (cold code; unrolled it is ~420
+// instructions per call for a 14-limb field: 1 700 inside the step loop of msm_accumulate_steps_kernel, whose code
+// must fit the instruction cache).
+template <class P, int B>
+DG_HD bool is_zero_compact(const Fe<P, B, 1>& a) {
+  using T = RR<P>;
+  constexpr int J = rr_ceil_div(B, 64);
+  bool hit = false;
+#pragma unroll
+  for (int j = 0; j < J; j++) {
+    const uint32_t low = (uint32_t)(((uint64_t)T::PL.v[0] * (uint32_t)j) & T::MASK);
+    hit = hit || (a.l[0] == low);
+  }
+  if (!hit) return false;
+#pragma unroll 1
+  for (int j = 0; j < J; j++) {
+    uint64_t carry = 0;
+    uint32_t diff = 0;
+#pragma unroll
+    for (int i = 0; i < T::N; i++) {
+      const uint64_t v = (uint64_t)T::PL.v[i] * (uint32_t)j + carry;
+      const uint32_t limb = i < T::N - 1 ? (uint32_t)(v & T::MASK) : (uint32_t)v;
+      carry = v >> T::W;
+      diff |= limb ^ a.l[i];
+    }
+    if (diff == 0) return true;
+  }
+  return false;
+}
 
 // fully reduced representative in [0, p)
 template <class P, int B, int LU>
@@ -777,6 +806,8 @@ template <int BS, class P, int B, int LU>
 DG_HD Fe2<P, BS, 1> fit(const Fe2<P, B, LU>& a) { return {fit<BS>(a.c0), fit<BS>(a.c1)}; }
 template <class P, int B, int LU>
 DG_HD bool is_zero(const Fe2<P, B, LU>& a) { return is_zero(a.c0) && is_zero(a.c1); }
+template <class P, int B>
+DG_HD bool is_zero_compact(const Fe2<P, B, 1>& a) { return is_zero_compact(a.c0) && is_zero_compact(a.c1); }
 // (a0 b0 - BETA a1 b1) + (a0 b1 + a1 b0) u: two dual products, one reduction each; b.c1 is the component negated
 // (pass the tighter operand second), BETA rides on a.c1 (N small multiplications)
 template <class P, int B1, int L1, int B2, int L2>

@@ -4,7 +4,7 @@
 
 namespace dg16 {
 #define DECL(name)                                                                              \
-  void msm_##name(Call&, const void*, const void*, size_t, bool, bool, void*);                  \
+  void msm_##name(Call&, const void*, const void*, size_t, unsigned, bool, void*);                  \
   void gen_bases_##name(Call&, uint64_t, size_t, void*);                                        \
   void to_affine_##name(Call&, const void*, void*, size_t);                                     \
   void* bases_table_##name(Call&, const void*, size_t, size_t, unsigned*, unsigned*, unsigned*); \
@@ -22,9 +22,9 @@ DECL(bn254_g1) DECL(bn254_g2) DECL(bls12_381_g1) DECL(bls12_381_g2) DECL(bls12_3
     default: throw StatusError{DG16_ERR_BAD_ARG, "unknown (curve, group)"};                     \
   }
 
-void msm_launch(Call& k, int curve, int group, const void* bases, const void* scalars, size_t n, bool mont,
+void msm_launch(Call& k, int curve, int group, const void* bases, const void* scalars, size_t n, unsigned mode,
                 bool affine, void* out) {
-  DISPATCH(msm, k, bases, scalars, n, mont, affine, out)
+  DISPATCH(msm, k, bases, scalars, n, mode, affine, out)
 }
 void gen_bases_launch(Call& k, int curve, int group, uint64_t seed, size_t n, void* out) {
   DISPATCH(gen_bases, k, seed, n, out)

@@ -24,11 +24,11 @@ template void msm_accumulate_phase<GF>(hipStream_t, const MsmSort&, const MsmBuf
 template void msm_finalize_phase<GF>(hipStream_t, const MsmSort&, const MsmBuffers<GF>&);
 template void msm_tail_phase<GF>(hipStream_t, const MsmSort&, const MsmBuffers<GF>&, bool, void*);
 template void* msm_build_table<GF>(hipStream_t, const void*, size_t, unsigned, unsigned);
-template MsmSort msm_sort_on<CT::Fr, CT::SCALAR_BITS>(hipStream_t, Channel&, const void*, size_t, bool, bool, unsigned,
+template MsmSort msm_sort_on<CT::Fr, CT::SCALAR_BITS>(hipStream_t, Channel&, const void*, size_t, unsigned, bool, unsigned,
                                                       unsigned);
 
-void DG_FN(msm_)(Call& k, const void* bases, const void* scalars, size_t n, bool mont, bool affine, void* out) {
-  msm_run<GF, CT::Fr, CT::SCALAR_BITS>(k, bases, scalars, n, mont, affine, out);
+void DG_FN(msm_)(Call& k, const void* bases, const void* scalars, size_t n, unsigned mode, bool affine, void* out) {
+  msm_run<GF, CT::Fr, CT::SCALAR_BITS>(k, bases, scalars, n, mode, affine, out);
 }
 void DG_FN(gen_bases_)(Call& k, uint64_t seed, size_t n, void* out) { gen_bases_run<GF, GC>(k, seed, n, out); }
 void DG_FN(to_affine_)(Call& k, const void* jac, void* out, size_t n) { to_affine_run<GF>(k, jac, out, n); }
@@ -58,7 +58,8 @@ void DG_FN(msm_resident_)(Call& k, const void* table, size_t n, unsigned c, unsi
 // the constant scalars v_j = sum_i unpack2[i][j] -- then sends the same point to every party.
 // (table != nullptr: the base shares are resident, `bases` is unused)
 void DG_FN(d_msm_)(Call& k, const dg16_pss* pp, const dg16_net* net, int sid, const void* bases, const void* scalars,
-                   size_t n, bool mont, void* out_jac, const void* table, unsigned table_c, unsigned table_stride) {
+                   size_t n, unsigned mode, void* out_jac, const void* table, unsigned table_c, unsigned table_stride) {
+  const bool mont = mode & 1u;
   using F = GF;
   using Fr = CT::Fr;
   const unsigned np = pp->n;
@@ -66,7 +67,7 @@ void DG_FN(d_msm_)(Call& k, const dg16_pss* pp, const dg16_net* net, int sid, co
   if (table)
     DG_FN(msm_resident_)(k, table, n, table_c, table_stride, scalars, mont, true, c_share);
   else
-    msm_run<F, Fr, CT::SCALAR_BITS>(k, bases, scalars, n, mont, true, c_share);        // dmsm/mod.rs:82
+    msm_run<F, Fr, CT::SCALAR_BITS>(k, bases, scalars, n, mode, true, c_share);        // dmsm/mod.rs:82
   const bool king = net->party_id(net->self) == 0;
   Affine<F>* shares = king ? (Affine<F>*)ws(k.c, 19, np * sizeof(Affine<F>)) : nullptr;
   if (net->gather_to_king(net->self, sid, c_share, sizeof(Affine<F>), shares, k.s()) != DG16_OK)

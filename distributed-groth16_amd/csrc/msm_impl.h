@@ -105,7 +105,6 @@ inline MsmGeom msm_geometry(size_t n, unsigned scalar_bits, bool table = false, 
     while (((size_t)2 << le) <= (size_t)g.nwin * n) le++;
     const int cap = (int)le - (int)kMinLanesLog;
     if (sl > cap) sl = cap;
-    if (const char* e = getenv("DG16_MSM_SEG_LOG")) sl = atoi(e);
     g.seg_log = (unsigned)(sl < (int)kMinSegLog ? (int)kMinSegLog : sl > (int)kMaxSegLog ? (int)kMaxSegLog : sl);
   }
   g.seg_cap = (1u << g.log_nb) + (unsigned)((g.region + (1u << g.seg_log) - 1) >> g.seg_log);
@@ -151,8 +150,9 @@ __global__ void __launch_bounds__(256) msm_digits_kernel(const Fr* __restrict__ 
   Fr s = Fr::zero();
   if (live) {
     s = scalars[i];
-    if (mont) s = s.from_mont();
+    if (mont & 1) s = s.from_mont();
   }
+  const bool flip = (mont & 2) && (s.l[Fr::NL - 1] >> 31);   // bit 255 = "negate this scalar": ONLY for the halves glv.h makes
   const unsigned c = g.c;
   const unsigned half = 1u << (c - 1);
   unsigned carry = 0;
@@ -167,7 +167,7 @@ __global__ void __launch_bounds__(256) msm_digits_kernel(const Fr* __restrict__ 
     }
     int d = (int)((unsigned)v & ((1u << c) - 1)) + (int)carry;
     if ((unsigned)d > half) { d -= (int)(1u << c); carry = 1; } else { carry = 0; }
-    if (s.l[Fr::NL - 1] >> 31) d = -d;        // bit 255 = "negate this scalar" (the halves of glv.h; never set otherwise)
+    if (flip) d = -d;
     if (live) digits[(size_t)w * n + i] = d;
     unsigned b = d ? (unsigned)(d < 0 ? -d : d) - 1 : 0u;
     unsigned slot = ((w % g.bw) << g.log_nb) + b;
@@ -336,7 +336,7 @@ __global__ void __launch_bounds__(256) msm_part_hist_kernel(const Fr* __restrict
     size_t i = (size_t)blockIdx.x * kPartScalars + k * 256 + threadIdx.x;
     if (i >= n) continue;
     Fr s = scalars[i];
-    if (mont) s = s.from_mont();
+    if (mont & 1) s = s.from_mont();
     unsigned carry = 0;
     for (unsigned w = 0; w < g.nwin; w++) {
       int d = msm_digit(s, w, g.c, carry);
@@ -361,7 +361,8 @@ __global__ void __launch_bounds__(256) msm_part_scatter_kernel(const Fr* __restr
     size_t i = (size_t)blockIdx.x * kPartScalars + k * 256 + threadIdx.x;
     if (i >= n) continue;
     Fr s = scalars[i];
-    if (mont) s = s.from_mont();
+    if (mont & 1) s = s.from_mont();
+    const bool flip = (mont & 2) && (s.l[Fr::NL - 1] >> 31);   // bit 255 = "negate this scalar": ONLY for the halves glv.h makes
     unsigned carry = 0;
     for (unsigned w = 0; w < g.nwin; w++) {
       int d = msm_digit(s, w, g.c, carry);
@@ -369,8 +370,7 @@ __global__ void __launch_bounds__(256) msm_part_scatter_kernel(const Fr* __restr
       unsigned slot = ((w % g.bw) << g.log_nb) + (unsigned)(d < 0 ? -d : d) - 1;
       unsigned ref = (unsigned)((size_t)(w / g.bw) * n + i);   // table row w / bw (plain mode: bw = W, row 0)
       unsigned pos = atomicAdd(&cur[slot >> pg.low_bits], 1u);
-      // (bit 255 of the scalar = "negate this scalar": the halves of glv.h; a canonical field element never has it set)
-      part[pos] = make_uint2(ref | (((d < 0) != ((s.l[Fr::NL - 1] >> 31) != 0)) ? 0x80000000u : 0u), slot);
+      part[pos] = make_uint2(ref | (((d < 0) != flip) ? 0x80000000u : 0u), slot);
     }
   }
 }
@@ -870,6 +870,182 @@ msm_accumulate_lds_kernel(MsmBases bases, size_t n, MsmGeom g,
 #undef DG_STAGE
 }
 
+// ---- 4 (G2 of the 14-limb curves): the same accumulation as ONE Fq2-product site visited ten times -------------------
+// msm_accumulate_lds_kernel<Fp2<bls12_381>> is a 100-KB loop (12 700 instructions: eleven inlined 14-limb Fq2 products)
+// run by one wave per SIMD against the 64-KB instruction cache two CUs share: every iteration streams the loop from L2
+// again -- 9.4 ms per 2^20-point launch on some boxes of the pool and 18.9 on others with the same binary, 26-51 % of
+// the v_mad_u64_u32 issue roof (BN254's 47-KB loop: 68-72 %).  Products behind calls (round 4's second form) cost a
+// dozen scratch accesses per call for the calling convention: 14.4 ms everywhere.
+// Here a mixed addition is a loop of TEN visits of one generic product c = a b on operands of one static type
+// (Fe2<P, BG, 1>): a wave-uniform switch in front of the site routes the operands (four register temporaries t0..t3 and
+// the accumulator's LDS columns), a second one behind it routes the result:
+//     0  P   = x2 ZZ  - X1        1  R  = y2 ZZZ - Y1        2  PP = P P         3  PPP = P PP
+//     4  ZZ  = ZZ PP              5  ZZZ = ZZZ PPP           6  Q  = X1 PP       7  X3 = R R - PPP - 2 Q
+//     8  T   = R (Q - X3)         9  Y3 = T - PPP Y1
+// -- the two squarings run as products and the fused four-product Y3 as two products: 11 760 v_mad_u64_u32 per addition
+// instead of 10 584 (+11 %), for a loop of ~2 600 instructions (21 KB) that stays in the instruction cache.  Values and
+// the order of operations inside a product are those of the straight-line form; results are congruent, and equal after
+// the final canonicalisation (parity tests unchanged).  Replaces BOTH round-4 forms and the timing-based choice.
+// A file of field elements parked in ACCUMULATION registers (gfx950: 256 AGPRs next to the 256 VGPRs of a wave at one wave
+// per SIMD), at FIXED register numbers a[kAccFileBase + 28 slot + i] named in asm statements: the temporaries of
+// msm_accumulate_steps_kernel are machine state the compiler does not see -- as C++ values (in VGPRs, or in AGPRs through
+// "=a" / "+a" operands) the step switch turned them into phis that hipcc merged with 270-330 copies per visit of a site
+// against the 84 the routing needs.  The kernel declares the file's registers clobbered once (resource accounting: the
+// wave is allocated them); the compiler's own AGPR use (spills) must stay below kAccFileBase --
+// tests/test_kernel_isa.py checks every AGPR reference of the built kernel.
+constexpr int kAccFileBase = 144;
+template <int SLOT, class P, int B>
+__device__ __forceinline__ void acc_set(const Fe2<P, B, 1>& v) {
+  constexpr int N = RR<P>::N;
+#pragma unroll
+  for (int i = 0; i < N; i++) {
+    asm volatile("v_accvgpr_write_b32 a[%1], %0" ::"v"(v.c0.l[i]), "n"(kAccFileBase + 2 * N * SLOT + i));
+    asm volatile("v_accvgpr_write_b32 a[%1], %0" ::"v"(v.c1.l[i]), "n"(kAccFileBase + 2 * N * SLOT + N + i));
+  }
+}
+template <int SLOT, class P, int B>
+__device__ __forceinline__ Fe2<P, B, 1> acc_get() {
+  constexpr int N = RR<P>::N;
+  Fe2<P, B, 1> v;
+#pragma unroll
+  for (int i = 0; i < N; i++) {
+    asm volatile("v_accvgpr_read_b32 %0, a[%1]" : "=v"(v.c0.l[i]) : "n"(kAccFileBase + 2 * N * SLOT + i));
+    asm volatile("v_accvgpr_read_b32 %0, a[%1]" : "=v"(v.c1.l[i]) : "n"(kAccFileBase + 2 * N * SLOT + N + i));
+  }
+  return v;
+}
+template <class F, int BLOCK>
+__global__ void __launch_bounds__(BLOCK, 1)
+msm_accumulate_steps_kernel(MsmBases bases, size_t n, MsmGeom g,
+                            const unsigned* __restrict__ offsets, const unsigned* __restrict__ counts,
+                            const unsigned* __restrict__ seg_off, const unsigned* __restrict__ seg_total,
+                            const unsigned* __restrict__ entries, XYZZ29<F>* __restrict__ seg_sum,
+                            XYZZ29<F>* __restrict__ buckets) {
+  using FO = FieldOf<F>;
+  using P = typename FO::Params;
+  using S = typename FO::Store;
+  constexpr int BS = FO::BS;
+  constexpr int BG = 640;                    // every operand of a site is below 10 p (P, R, Q - X3: < 9.3 p)
+  using G = Fe2<P, BG, 1>;
+  static_assert(kAccFileBase + 4 * 2 * RR<P>::N <= 256, "four temporaries in the accumulation registers");
+  constexpr int WORDS = sizeof(S) / 4;
+  __shared__ uint32_t sh[4 * WORDS][BLOCK];
+  const unsigned lane = threadIdx.x;
+  auto ld = [&](int coord) {
+    S v;
+    uint32_t* w = reinterpret_cast<uint32_t*>(&v);
+#pragma unroll
+    for (int i = 0; i < WORDS; i++) w[i] = sh[coord * WORDS + i][lane];
+    return v;
+  };
+  auto ldg = [&](int coord) { return ld(coord).template as<BG, 1>(); };
+  auto st = [&](int coord, const S& v) {
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(&v);
+#pragma unroll
+    for (int i = 0; i < WORDS; i++) sh[coord * WORDS + i][lane] = w[i];
+  };
+  const unsigned w = blockIdx.y % g.bw;
+  const uint32_t* __restrict__ base_tab = bases.p[blockIdx.y / g.bw];
+  const unsigned t = blockIdx.x * BLOCK + threadIdx.x;
+  const bool live = t < seg_total[w];
+  SegRange sr{};
+  if (live) sr = msm_segment(g, w, t, counts, seg_off);
+  const unsigned cnt = live ? sr.cnt : 0u;
+  const unsigned* e = entries + (size_t)w * g.region + (live ? offsets[sr.bslot] + sr.first : 0u);
+  asm volatile("" ::: "a144", "a255");   // the temporaries' registers belong to this wave (acc_set / acc_get)
+  bool inf = true;
+  unsigned cur = cnt ? e[0] : 0u;
+  for (unsigned j = 0; j < cnt; j++) {
+    const unsigned nxt = (j + 1 < cnt) ? e[j + 1] : 0u;
+    const unsigned ent = cur;
+    cur = nxt;
+    const bool negate = ent >> 31;
+    {
+      const Affine29<F> q = load_internal<F>(base_tab, ent & 0x7fffffffu);
+      if (q.is_inf()) continue;
+      const auto nqy = neg(q.y);
+      const auto qy = select(negate, nqy, q.y.template as<decltype(nqy)::Bound, decltype(nqy)::Limb>());
+      if (inf) {
+        st(0, q.x.template as<BS, 1>()); st(1, fit<BS>(qy)); st(2, FO::one()); st(3, FO::one());
+        inf = false;
+        continue;
+      }
+      acc_set<0>(q.x.template as<BG, 1>());
+      acc_set<1>(fit<BG>(qy));
+    }
+    int special = 0;                          // 1: the same point again (double it), 2: its inverse (identity)
+    bool p_zero = false;
+#pragma unroll 1
+    for (int step = 0; step < 9; step++) {
+      asm volatile("" : "+s"(step));          // opaque: the sites must not be cloned per step
+      if (step == 2 || step == 7) {
+        // ---- the squaring site: PP = P^2, then X3 = R^2 - PPP - 2 Q
+        const G a = step == 2 ? acc_get<0, P, BG>() : acc_get<1, P, BG>();
+        const auto c = sqr(a);
+        if (step == 2) {
+          acc_set<2>(c.template as<BG, 1>());
+        } else {
+          const auto ppp = acc_get<3, P, 128>(), q_ = acc_get<0, P, 128>();   // products: below 2 p
+          const auto x3 = fit<BS>(c - (ppp + dbl(q_)));
+          st(0, x3);
+          acc_set<2>(fit<BG>(q_ - x3));                                 // Q - X3
+        }
+      } else if (step == 8) {
+        // ---- the fused site: Y3 = R (Q - X3) - PPP Y1, one reduction per component
+        const auto r_ = acc_get<1, P, BG>(), d_ = acc_get<2, P, BG>();
+        const auto ppp = acc_get<3, P, 128>();
+        st(1, fit<BS>(mul_sub(r_, d_, ppp, ld(1))));
+      } else {
+        // ---- the product site
+        G a, b;
+        switch (step) {
+          case 0: a = acc_get<0, P, BG>(); b = ldg(2); break;              // x2 ZZ
+          case 1: a = acc_get<1, P, BG>(); b = ldg(3); break;              // y2 ZZZ
+          case 3: a = acc_get<0, P, BG>(); b = acc_get<2, P, BG>(); break;  // P PP
+          case 4: a = ldg(2); b = acc_get<2, P, BG>(); break;              // ZZ PP
+          case 5: a = ldg(3); b = acc_get<3, P, BG>(); break;              // ZZZ PPP
+          default: a = ldg(0); b = acc_get<2, P, BG>(); break;             // X1 PP
+        }
+        const auto c = a * b;
+        switch (step) {
+          case 0: {
+            const auto p_ = fit<BG>(c - ld(0));                           // P = U2 - X1
+            p_zero = is_zero_compact(p_);
+            acc_set<0>(p_);
+            break;
+          }
+          case 1: {
+            const auto r_ = fit<BG>(c - ld(1));                           // R = S2 - Y1
+            if (p_zero) special = is_zero_compact(r_) ? 1 : 2;
+            acc_set<1>(r_);
+            break;
+          }
+          case 3: acc_set<3>(c.template as<BG, 1>()); break;            // PPP
+          case 4: st(2, c.template as<BS, 1>()); break;                   // ZZ3
+          case 5: st(3, c.template as<BS, 1>()); break;                   // ZZZ3
+          default: acc_set<0>(c.template as<BG, 1>()); break;           // Q
+        }
+        if (special) break;
+      }
+    }
+    if (special == 1) {
+      const Affine29<F> q2 = load_internal<F>(base_tab, ent & 0x7fffffffu);
+      const auto nq2 = neg(q2.y);
+      const auto qy2 = select(negate, nq2, q2.y.template as<decltype(nq2)::Bound, decltype(nq2)::Limb>());
+      const XYZZ29<F> d = XYZZ29<F>::dbl_affine(q2.x, qy2);
+      st(0, d.x); st(1, d.y); st(2, d.zz); st(3, d.zzz);
+    } else if (special == 2) {
+      inf = true;
+    }
+  }
+  if (live) {
+    XYZZ29<F> out = XYZZ29<F>::inf();
+    if (!inf) out = XYZZ29<F>{ld(0), ld(1), ld(2), ld(3)};
+    if (sr.k == 1) buckets[((size_t)blockIdx.y << g.log_nb) + (sr.bslot & (((size_t)1 << g.log_nb) - 1))] = out;
+    else seg_sum[(size_t)blockIdx.y * g.seg_cap + t] = out;
+  }
+}
+
 // arkworks-form bases (C ABI) -> internal form for the accumulation kernels (plain dg16_msm: one pass per call,
 // 2 field products per point against ~10 W in the accumulation; resident keys convert once, in the table builder)
 template <class F>
@@ -1175,17 +1351,18 @@ struct MsmSort {
   unsigned* seg_total = nullptr;
 };
 
+// scalars_mont: bit 0 = Montgomery form, bit 1 = bit 255 of a scalar is a sign flag (the halves of glv.h)
 template <class Fr, int SCALAR_BITS>
-MsmSort msm_sort_on(hipStream_t s, Channel& wsch, const void* scalars, size_t n, bool scalars_mont, bool table,
+MsmSort msm_sort_on(hipStream_t s, Channel& wsch, const void* scalars, size_t n, unsigned scalars_mont, bool table,
                     unsigned c_fixed, unsigned stride);
 template <class Fr, int SCALAR_BITS>
-MsmSort msm_sort(Call& k, const void* scalars, size_t n, bool scalars_mont, bool table, unsigned c_fixed = 0,
+MsmSort msm_sort(Call& k, const void* scalars, size_t n, unsigned scalars_mont, bool table, unsigned c_fixed = 0,
                  unsigned stride = 1) {
   return msm_sort_on<Fr, SCALAR_BITS>(k.s(), k.c, scalars, n, scalars_mont, table, c_fixed, stride);
 }
 // sort on stream `s` with the buffers of channel `wsch`
 template <class Fr, int SCALAR_BITS>
-MsmSort msm_sort_on(hipStream_t s, Channel& wsch, const void* scalars, size_t n, bool scalars_mont, bool table,
+MsmSort msm_sort_on(hipStream_t s, Channel& wsch, const void* scalars, size_t n, unsigned scalars_mont, bool table,
                     unsigned c_fixed, unsigned stride) {
   MsmSort r;
   r.n = n;
@@ -1299,11 +1476,6 @@ template <class F>
 struct MsmBuffers;
 template <class F>
 void msm_finalize_lds_phase(hipStream_t s, const MsmSort& st, const MsmBuffers<F>& b);
-// the 14-limb Fq2 accumulation with out-of-line field products: defined (as explicit specialisations) in msm_group_outl.hip
-template <class F>
-void msm_accumulate_lds_outl(hipStream_t s, dim3 grid, MsmBases mb, size_t n, MsmGeom g, const unsigned* offsets,
-                             const unsigned* counts, const unsigned* seg_off, const unsigned* seg_total,
-                             const unsigned* entries, XYZZ29<F>* seg_sum, XYZZ29<F>* buckets);
 // Phase A (saturates the GPU): segment accumulation.  `bases` is the array of n points or, in table mode, the
 // table of W*n points -- in INTERNAL form (msm_to_internal_kernel / msm_table_kernel).
 // bases: b.ninst tables (or plain base arrays), one per instance
@@ -1321,44 +1493,13 @@ void msm_accumulate_phase(hipStream_t s, const MsmSort& st, const MsmBuffers<F>&
                          st.seg_off, st.seg_total, st.entries, b.seg_sum, b.buckets);
     };
     if constexpr (sizeof(F) > 64) {
-      // 14-limb Fq2: TWO forms of the kernel are in the library and the device picks.  Inline products: a 180-KB loop
-      // against a 64-KB instruction cache at one wave per SIMD -- 9.4 ms per 2^20-point launch on some boxes of the pool,
-      // 18.9 on others, same binary.  Products out of line (msm_group_outl.hip): 14.4 ms on both kinds.  The first
-      // launch of at least 2^20 entries on a device runs BOTH (the kernel is idempotent: it only writes its partials),
-      // timed with events, and the faster one serves from then on (one blocking measurement per process and curve;
-      // DG16_G2_14LIMB=inline|outline pins the choice).
-      static std::atomic<int> pick{[] {
-        const char* e = getenv("DG16_G2_14LIMB");
-        return !e ? -1 : (e[0] == 'o' ? 1 : e[0] == 'i' ? 0 : -1);
-      }()};
-      auto outline_form = [&] {
-        msm_accumulate_lds_outl<F>(s, grid, mb, st.n, g, st.offsets, st.counts, st.seg_off, st.seg_total, st.entries,
-                                   b.seg_sum, b.buckets);
-      };
-      int p = pick.load();
-      if (p < 0 && (size_t)g.rows * st.n * g.bw >= ((size_t)1 << 20)) {
-        hipEvent_t e0, e1, e2;
-        DG_HIP(hipEventCreate(&e0)); DG_HIP(hipEventCreate(&e1)); DG_HIP(hipEventCreate(&e2));
-        DG_HIP(hipEventRecord(e0, s));
-        inline_form();
-        DG_HIP(hipEventRecord(e1, s));
-        outline_form();
-        DG_HIP(hipEventRecord(e2, s));
-        DG_HIP(hipEventSynchronize(e2));
-        float t_in = 0, t_out = 0;
-        DG_HIP(hipEventElapsedTime(&t_in, e0, e1));
-        DG_HIP(hipEventElapsedTime(&t_out, e1, e2));
-        hipEventDestroy(e0); hipEventDestroy(e1); hipEventDestroy(e2);
-        p = t_out < 0.97f * t_in ? 1 : 0;
-        pick.store(p);
-        if (const char* v = getenv("DG16_VERBOSE"); v && atoi(v))
-          fprintf(stderr, "[dg16] 14-limb G2 accumulation: inline %.3f ms, out of line %.3f ms -> %s\n", t_in, t_out,
-                  p ? "out of line" : "inline");
-      } else if (p == 1) {
-        outline_form();
-      } else {
-        inline_form();
-      }
+      // 14-limb Fq2: ONE product site visited ten times per addition (msm_accumulate_steps_kernel: a loop that fits the
+      // instruction cache).  DG16_G2_14LIMB=inline runs round 4's straight-line loop instead (A/B only).
+      static const bool straight = [] { const char* e = getenv("DG16_G2_14LIMB"); return e && e[0] == 'i'; }();
+      if (straight) inline_form();
+      else
+        hipLaunchKernelGGL((msm_accumulate_steps_kernel<F, BLOCK>), grid, dim3(BLOCK), 0, s, mb, st.n, g, st.offsets,
+                           st.counts, st.seg_off, st.seg_total, st.entries, b.seg_sum, b.buckets);
     } else {
       inline_form();
     }
@@ -1366,11 +1507,8 @@ void msm_accumulate_phase(hipStream_t s, const MsmSort& st, const MsmBuffers<F>&
     if (msm_finalize_lds_lpb()) msm_finalize_lds_phase<F>(s, st, b);
   } else {
     constexpr int BLOCK = 1 << msm_acc_block_log<F>();
-    // DG16_ACC_LDS_PAD=<KiB>: extra (unused) LDS per workgroup = fewer accumulation waves per SIMD = register room for
-    // the waves of the reduction kernels running on the side streams (experiment knob)
-    static const unsigned pad = [] { const char* e = getenv("DG16_ACC_LDS_PAD"); return e ? (unsigned)atoi(e) * 1024u : 0u; }();
     hipLaunchKernelGGL((msm_accumulate_kernel<F, BLOCK>), dim3((g.seg_cap + BLOCK - 1) / BLOCK, g.bw * b.ninst),
-                       dim3(BLOCK), pad, s, mb, st.n, g, st.offsets, st.counts, st.seg_off, st.seg_total, st.entries,
+                       dim3(BLOCK), 0, s, mb, st.n, g, st.offsets, st.counts, st.seg_off, st.seg_total, st.entries,
                        b.seg_sum, b.buckets);
     if (b.acc_done) DG_HIP(hipEventRecord(b.acc_done, s));
   }
@@ -1585,18 +1723,10 @@ msm_finalize_lds_kernel(MsmGeom g, size_t total, unsigned wg_log, unsigned lpb_l
     buckets[gid] = out;
   }
 }
-// G2 finalize as a throughput kernel behind the accumulation (default) or the one-lane-per-bucket kernel on the
-// reduction stream (DG16_FINALIZE_LDS=0); lanes per bucket: DG16_FINALIZE_LPB = 1, 2 (default), 4
-inline int msm_finalize_lds_lpb() {
-  static const int v = [] {
-    const char* e = getenv("DG16_FINALIZE_LDS");
-    if (e && atoi(e) == 0) return 0;
-    const char* l = getenv("DG16_FINALIZE_LPB");
-    const int lpb = l ? atoi(l) : 2;
-    return lpb == 1 || lpb == 4 ? lpb : 2;
-  }();
-  return v;
-}
+// G2 finalize as a throughput kernel behind the accumulation, two lanes per bucket (measured in round 4 against one and
+// four lanes and against the one-lane-per-bucket kernel on the reduction stream: profiles/r4r_finalize_lpb_ab.txt,
+// r3b_finalize_lds_ab.txt -- the switches are gone)
+inline int msm_finalize_lds_lpb() { return 2; }
 template <class F>
 void msm_finalize_lds_phase(hipStream_t s, const MsmSort& st, const MsmBuffers<F>& b) {
   constexpr int BLOCK = 1 << msm_acc_block_log<F>();
@@ -1710,6 +1840,12 @@ void msm_reduce(Call& k, const MsmSort& st, const void* bases, bool out_affine, 
 
 // ---- GLV for the plain G1 MSM (glv.h): 2n points (P_i, phi(P_i)), 127-bit half scalars, half the windows ------------
 template <class F> struct GlvOf { static constexpr bool enabled = false; };
+// phi(P) = LAMBDA P (psi(P) = LAMBDA P) holds for P in the order-r subgroup ONLY.  A group of cofactor one is that subgroup
+// (BN254 G1); for every other group the split needs the caller's word that the bases are in it
+// (DG16_F_BASES_IN_SUBGROUP) -- an on-curve point outside the subgroup (decoded with validate = 0, say) must still give
+// the group element VariableBaseMSM::msm gives, so without the flag those groups run the unsplit path.
+template <class F> struct GlvCofactorOne { static constexpr bool value = false; };
+template <> struct GlvCofactorOne<Fp<bn254_fq_params>> { static constexpr bool value = true; };
 // G1 of the three curves (j = 0): phi(x, y) = (BETA x, y)
 template <class P, class GC>
 struct GlvG1 {
@@ -1806,27 +1942,29 @@ __global__ void __launch_bounds__(256) msm_to_internal_glv_kernel(const Affine<F
   }
 }
 
+// mode: bit 0 = scalars in Montgomery form, bit 1 = every base is in the order-r subgroup (ctx.h: msm_mode)
 template <class F, class Fr, int SCALAR_BITS>
-void msm_run(Call& k, const void* bases, const void* scalars, size_t n, bool scalars_mont, bool out_affine,
+void msm_run(Call& k, const void* bases, const void* scalars, size_t n, unsigned mode, bool out_affine,
              void* out_dev) {
-  if constexpr (GlvOf<F>::enabled) {
-    // G1 (and BN254's G2): split every scalar with the curve's endomorphism (DG16_MSM_GLV=0 switches it off).  Same number of bucket
+  const bool scalars_mont = mode & 1u;
+  if (GlvOf<F>::enabled && (GlvCofactorOne<F>::value || (mode & 2u))) {
+   if constexpr (GlvOf<F>::enabled) {
+    // Split every scalar with the curve's endomorphism.  Same number of bucket
     // entries (2n points x half the windows), half the windows: half the dependent doublings of the Horner tail, half the
     // bucket sets to reduce, twice the entries per bucket (longer, better balanced accumulation segments).
-    static const bool glv_on = [] { const char* e = getenv("DG16_MSM_GLV"); return !e || atoi(e) != 0; }();
     constexpr size_t DIM = GlvOf<F>::DIM;
-    if (glv_on && n && DIM * n * 40 < ((size_t)1 << 31)) {
+    if (n && DIM * n * 40 < ((size_t)1 << 31)) {
       using GC = typename GlvOf<F>::C;
       Fr* halves = (Fr*)ws(k.c, 30, DIM * n * sizeof(Fr));
       MsmSort st;
       if constexpr (DIM == 2) {
         hipLaunchKernelGGL((glv_split_kernel<Fr, GC>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, k.s(),
                            (const Fr*)scalars, n, (int)scalars_mont, halves);
-        st = msm_sort<Fr, kGlvBits>(k, halves, 2 * n, false, false);
+        st = msm_sort<Fr, kGlvBits>(k, halves, 2 * n, 2u, false);
       } else {
         hipLaunchKernelGGL((glv_split4_kernel<Fr, GC>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, k.s(),
                            (const Fr*)scalars, n, (int)scalars_mont, halves);
-        st = msm_sort<Fr, kGlv4Bits>(k, halves, 4 * n, false, false);
+        st = msm_sort<Fr, kGlv4Bits>(k, halves, 4 * n, 2u, false);
       }
       uint32_t* internal = (uint32_t*)ws(k.c, 24, DIM * n * sizeof(Affine<F>));
       hipLaunchKernelGGL(msm_to_internal_glv_kernel<F>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, k.s(),
@@ -1834,8 +1972,9 @@ void msm_run(Call& k, const void* bases, const void* scalars, size_t n, bool sca
       msm_reduce<F>(k, st, internal, out_affine, out_dev);
       return;
     }
+   }
   }
-  MsmSort st = msm_sort<Fr, SCALAR_BITS>(k, scalars, n, scalars_mont, false);
+  MsmSort st = msm_sort<Fr, SCALAR_BITS>(k, scalars, n, scalars_mont ? 1u : 0u, false);
   uint32_t* internal = (uint32_t*)ws(k.c, 24, (n ? n : 1) * sizeof(Affine<F>));
   if (n)
     hipLaunchKernelGGL(msm_to_internal_kernel<F>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, k.s(),
@@ -2023,6 +2162,6 @@ void to_affine_run(Call& k, const void* jac, void* out, size_t n) {
 #define DG16_MSM_EXTERN(CT)                                                                                       \
   DG16_MSM_EXTERN_GROUP(CT::Fq)                                                                                   \
   DG16_MSM_EXTERN_GROUP(CT::Fq2)                                                                                  \
-  extern template MsmSort msm_sort_on<CT::Fr, CT::SCALAR_BITS>(hipStream_t, Channel&, const void*, size_t, bool, bool, \
+  extern template MsmSort msm_sort_on<CT::Fr, CT::SCALAR_BITS>(hipStream_t, Channel&, const void*, size_t, unsigned, bool, \
                                                               unsigned, unsigned);
 

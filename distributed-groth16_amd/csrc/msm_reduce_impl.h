@@ -377,12 +377,10 @@ void msm_bucket_phase(hipStream_t s, const MsmSort& st, const MsmBuffers<F>& b, 
   constexpr int CH_LANES = sizeof(XYZZ29<F>) * 2 * 256 <= 150 * 1024 ? 256 : 128;
   constexpr unsigned CH_LL = CH_LANES == 256 ? 8u : 7u;
   unsigned k_log = 0;
-  static const int chunk_force = [] { const char* e = getenv("DG16_ROW_CHUNK"); return e ? atoi(e) : -1; }();   // -1 auto, 0 off, 1..3 = k
   if (b.rg.row_log == kRowLog && g.log_nb >= CH_LL + 1) {
     const size_t total_rows = (size_t)bwi << b.rg.rows_log;
     while (k_log < 3 && (total_rows >> (k_log + 1)) >= 256 && g.log_nb >= CH_LL + k_log + 1) k_log++;
     if (total_rows < 1024) k_log = 0;
-    if (chunk_force >= 0) k_log = (unsigned)chunk_force <= g.log_nb - CH_LL ? (unsigned)chunk_force : g.log_nb - CH_LL;
     if (k_log > 3) k_log = 3;
     // the top kernel's folded mode takes <= 256 chunk workgroups per bucket-window: beyond that (one bucket set of
     // 2^20 buckets: the table of a 2^24-point key) the rows + msm_rowfold_kernel path serves

@@ -495,10 +495,7 @@ static void pk_build(dg16_ctx* ctx, PkDev& d, const void* a_query, const void* b
     d.c_ab = msm_window_bits(n_ab + 3, true);
     d.c_l = d.c_ab;
     d.c_h = msm_window_bits(n_h ? n_h : 1, true);
-    if (const char* e = getenv("DG16_MSM_TABLE_C_H")) {      // experiment: H's window width on its own (4..20)
-      const int c = atoi(e);
-      if (c >= 4 && c <= 20) d.c_h = (unsigned)c;
-    }
+    // (H's window width on its own was swept in round 4, profiles/r4w_table_window_sweep.txt: log2(n) - 3 for it too)
     // HBM budget (dg16_ctx_set_table_budget): one row stride for all five tables -- A, B1, B and L share a digit sort
     const size_t full_bytes = (size_t)nwin_of(d.c_ab) * (n_ab + 3) * (3 * p1 + p2) +
                               (size_t)nwin_of(d.c_h) * (n_h ? n_h : 1) * p1;

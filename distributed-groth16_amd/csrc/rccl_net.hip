@@ -247,9 +247,14 @@ bool make_channel_comms(dg16_rccl* h) {
     g_err = "hipMalloc (channel ids)";
     return false;
   }
-  bool ok = hipMemcpy(dbuf, ids, kIds, hipMemcpyHostToDevice) == hipSuccess &&
-            h->check(a.Broadcast(dbuf, dbuf, kIds, kNcclInt8, 0, h->comm[0], (hipStream_t) nullptr), "ncclBroadcast") &&
-            hipStreamSynchronize(nullptr) == hipSuccess && hipMemcpy(ids, dbuf, kIds, hipMemcpyDeviceToHost) == hipSuccess;
+  // on a private NON-BLOCKING stream: the NULL stream would synchronise with every blocking stream of the process
+  hipStream_t bs = nullptr;
+  bool ok = hipStreamCreateWithFlags(&bs, hipStreamNonBlocking) == hipSuccess &&
+            hipMemcpyAsync(dbuf, ids, kIds, hipMemcpyHostToDevice, bs) == hipSuccess &&
+            h->check(a.Broadcast(dbuf, dbuf, kIds, kNcclInt8, 0, h->comm[0], bs), "ncclBroadcast") &&
+            hipMemcpyAsync(ids, dbuf, kIds, hipMemcpyDeviceToHost, bs) == hipSuccess &&
+            hipStreamSynchronize(bs) == hipSuccess;
+  if (bs) hipStreamDestroy(bs);
   hipFree(dbuf);
   if (!ok) {
     if (g_err.empty()) g_err = "broadcast of the channel ids failed";
@@ -270,6 +275,14 @@ void destroy_comms(dg16_rccl* h) {
 }
 
 }  // namespace
+
+namespace dg16 {
+// Is `net` the vtable of a dg16_rccl handle (dg16_rccl_net)?  dg16_prove_c orders its three d_msm on such a net:
+// RCCL guarantees progress of communicators used CONCURRENTLY on one device only if all their kernels can be co-resident
+// and the ranks enqueue on them in a consistent order -- three host threads per rank, each enqueueing on its own
+// communicator in an order that differs from rank to rank, is the pattern NCCL documents as a deadlock hazard.
+bool net_is_rccl(const dg16_net* net) { return net && net->gather_to_king == &rc_gather; }
+}  // namespace dg16
 
 extern "C" {
 

@@ -126,13 +126,14 @@ def d_ifft(ctx, pp, net, share, log_m, rearrange, pad, degree2, sid=0):
     return d_fft(ctx, pp, net, share, log_m, rearrange, pad, degree2, inverse=True, sid=sid)
 
 
-def d_msm(ctx, pp, net, group, bases, scalars, scalars_mont=True, sid=0):
+def d_msm(ctx, pp, net, group, bases, scalars, scalars_mont=True, sid=0, in_subgroup=True):
+    """in_subgroup: DG16_F_BASES_IN_SUBGROUP (base shares are combinations of CRS points: in the order-r group)."""
     bases = np.ascontiguousarray(bases, dtype=np.uint64)
     scalars = _fr(scalars)
     nl = FQ_LIMBS64[pp.curve] * (2 if group == 2 else 1)
     out = np.zeros((1, 3 * nl), dtype=np.uint64)
     ctx._chk(ctx.L.dg16_d_msm(ctx.h, pp.h, net, group, _ptr(bases), _ptr(scalars), bases.shape[0], scalars.shape[0],
-                              1 if scalars_mont else 0, sid, _ptr(out)))
+                              (1 if scalars_mont else 0) | (64 if in_subgroup else 0), sid, _ptr(out)))
     return out
 
 

@@ -96,7 +96,7 @@ class A:
         S, a = _shares(self.S, nl), _shares(self.a, 4)
         out = np.zeros((1, 3 * nl // 2), dtype=np.uint64)
         ctx._chk(ctx.L.dg16_prove_a(ctx.h, self.pp.h, net, _ptr(_pt(curve, 1, self.L)), _ptr(_pt(curve, 1, self.N)),
-                                    _ptr(_sc(self.r)), _ptr(S), _ptr(a), S.shape[0], a.shape[0], 1, sid, _ptr(out)))
+                                    _ptr(_sc(self.r)), _ptr(S), _ptr(a), S.shape[0], a.shape[0], 1 | 64, sid, _ptr(out)))
         return out
 
 
@@ -112,7 +112,7 @@ class B:
         V, a = _shares(self.V, nl), _shares(self.a, 4)
         out = np.zeros((1, 3 * nl // 2), dtype=np.uint64)
         ctx._chk(ctx.L.dg16_prove_b(ctx.h, self.pp.h, net, _ptr(_pt(curve, 2, self.Z)), _ptr(_pt(curve, 2, self.K)),
-                                    _ptr(_sc(self.s)), _ptr(V), _ptr(a), V.shape[0], a.shape[0], 1, sid, _ptr(out)))
+                                    _ptr(_sc(self.s)), _ptr(V), _ptr(a), V.shape[0], a.shape[0], 1 | 64, sid, _ptr(out)))
         return out
 
 
@@ -124,7 +124,9 @@ class C:
         self.A, self.M, self.s, self.r, self.pp = A, M, s, r, pp
         self.W, self.U, self.H, self.a, self.ax, self.h = W, U, H, a, ax, h
 
-    def compute(self, ctx, net):
+    def compute(self, ctx, net, serial_channels=False):
+        """serial_channels: DG16_F_SERIAL_CHANNELS -- the three d_msm one after another (channels 0, 1, 2 in that order
+        on every party) for a transport whose channels are not independent; lib.probe_channels decides it collectively."""
         curve = self.pp.curve
         nl = FQ_LIMBS64[curve] * 2
         W, U, H = (_shares(v, nl) for v in (self.W, self.U, self.H))
@@ -133,12 +135,13 @@ class C:
         out = np.zeros((1, 3 * nl // 2), dtype=np.uint64)
         ctx._chk(ctx.L.dg16_prove_c(ctx.h, self.pp.h, net, _ptr(Aj), _ptr(_pt(curve, 1, self.M)), _ptr(_sc(self.s)),
                                     _ptr(_sc(self.r)), _ptr(W), _ptr(ax), W.shape[0], ax.shape[0], _ptr(U), _ptr(h),
-                                    U.shape[0], h.shape[0], _ptr(H), _ptr(a), H.shape[0], a.shape[0], 1, _ptr(out)))
+                                    U.shape[0], h.shape[0], _ptr(H), _ptr(a), H.shape[0], a.shape[0],
+                                    1 | 64 | (16 if serial_channels else 0), _ptr(out)))
         return out
 
 
 def party_prove(ctx, pp, net, crs_share, qap_share, a_share, ax_share, log_m, r=None, s=None, L=None, N=None,
-                Z=None, K=None, M=None):
+                Z=None, K=None, M=None, serial_channels=False):
     """One party of the reference's example (`dsha256`, groth16/examples/sha256.rs:26-95): h = ext_wit::h, then
     A::compute, B::compute, C::compute exactly as there.  The example passes r = s = 0 and Default points
     (:46-48, :60-62, :77-79) -- the defaults here; any other values go through the same native entry points.
@@ -150,5 +153,5 @@ def party_prove(ctx, pp, net, crs_share, qap_share, a_share, ax_share, log_m, r=
     pi_a = A(L, N, r, pp, crs_share["s"], a_share).compute(ctx, net, 0)                      # :45-57
     pi_b = B(Z, K, s, pp, crs_share["v"], a_share).compute(ctx, net, 0)                      # :59-71
     pi_c = C(pi_a, M, s, r, pp, crs_share["w"], crs_share["u"], crs_share["h"], a_share, ax_share,
-             h_share).compute(ctx, net)                                                      # :73-92
+             h_share).compute(ctx, net, serial_channels=serial_channels)                     # :73-92
     return pi_a, pi_b, pi_c

@@ -21,6 +21,7 @@ F_OUT_AFFINE = 4
 F_H_CYCLIC = 8
 F_SERIAL_CHANNELS = 16
 F_OVERLAP_TAIL = 32
+F_BASES_IN_SUBGROUP = 64
 
 STATUS = {1: "LENGTH_MISMATCH", 2: "BAD_CURVE", 3: "BAD_ARG", 4: "OOM", 5: "HIP", 6: "NET",
           7: "UNSUPPORTED"}
@@ -393,12 +394,17 @@ class Context:
                                      channel))
         return out
 
-    def msm(self, curve, group, bases, scalars, scalars_mont=False, affine=False, channel=0):
+    def msm(self, curve, group, bases, scalars, scalars_mont=False, affine=False, channel=0, in_subgroup=True):
+        """in_subgroup: DG16_F_BASES_IN_SUBGROUP -- the bases are elements of the order-r group (an arkworks
+        G1Affine / G2Affine that came through Validate::Yes or CRS generation is), so the library may split the
+        scalars with the curve's endomorphism.  Pass False for arbitrary points of the curve (plain Pippenger, like
+        VariableBaseMSM::msm).  The C ABI's default is the flag NOT set."""
         bases = np.ascontiguousarray(bases, dtype=np.uint64)
         scalars = np.ascontiguousarray(scalars, dtype=np.uint64)
         nl = FQ_LIMBS64[curve] * (2 if group == 2 else 1)
         out = np.zeros((1, nl * (2 if affine else 3)), dtype=np.uint64)
-        flags = (F_SCALARS_MONT if scalars_mont else 0) | (F_OUT_AFFINE if affine else 0)
+        flags = ((F_SCALARS_MONT if scalars_mont else 0) | (F_OUT_AFFINE if affine else 0) |
+                 (F_BASES_IN_SUBGROUP if in_subgroup else 0))
         self._chk(self.L.dg16_msm(self.h, CURVES[curve], group, _ptr(bases), _ptr(scalars), bases.shape[0],
                                   scalars.shape[0], flags, channel, _ptr(out)))
         return out
@@ -623,8 +629,9 @@ class Context:
 
     # ---- device-pointer API (stream-ordered) ----------------------------------------------------------
     def msm_dev(self, curve, group, bases_ptr, scalars_ptr, n, out_ptr, scalars_mont=False, affine=False,
-                channel=0, n_scalars=None):
-        flags = F_DEVICE_PTRS | (F_SCALARS_MONT if scalars_mont else 0) | (F_OUT_AFFINE if affine else 0)
+                channel=0, n_scalars=None, in_subgroup=True):
+        flags = (F_DEVICE_PTRS | (F_SCALARS_MONT if scalars_mont else 0) | (F_OUT_AFFINE if affine else 0) |
+                 (F_BASES_IN_SUBGROUP if in_subgroup else 0))
         self._chk(self.L.dg16_msm(self.h, CURVES[curve], group, _ptr(bases_ptr), _ptr(scalars_ptr), n,
                                   n if n_scalars is None else n_scalars, flags, channel, _ptr(out_ptr)))
 
@@ -765,6 +772,63 @@ class TorchComm:
             else:
                 self.dist.all_to_all_single(dst, src)
         return self._run(stream, fn)
+
+
+def probe_channels(net_struct, n_parties, party_id, dist, soft_s=2.0, hard_s=120.0, rounds=2):
+    """Watchdog for the JOINED form of prove::C (groth16/src/prove.rs:113-125: three d_msm in flight on channels 0 / 1
+    / 2, which dg16_prove_c drives from three host threads): before the first proof every party runs a tiny
+    gather-to-king + scatter-from-king on each channel of its dg16_net AT ONCE, its three threads started in an order
+    that differs from party to party -- the access pattern of the real call.  A transport whose channels are
+    independent finishes in a round trip; one whose channels share an ordered pipe (or whose concurrent use deadlocks)
+    does not.  The decision is COLLECTIVE (one all-reduce over `dist`'s default group, the pattern of
+    parallel.make_prover): if ANY party misses the soft deadline, EVERY party gets "serial" and passes
+    DG16_F_SERIAL_CHANNELS from then on (the three d_msm one after another, in the order 0, 1, 2 on every party: same
+    proof).  A probe that has not finished by the hard deadline is a dead transport: DG16_ERR_NET on every party.
+    -> "joined" | "serial".   net_struct: a NetStruct (TorchNet.struct, or the struct behind dg16_rccl_net)."""
+    import threading
+    import time
+    import torch
+    nbytes = 8
+    done = [None] * 3
+    errs = []
+    selfp = getattr(net_struct, "self")          # the vtable's `self` member (NULL for a Python-implemented net)
+
+    def one(c):
+        t0 = time.monotonic()
+        try:
+            for it in range(rounds):
+                send = np.full(nbytes, (16 * c + party_id + it) & 0xFF, dtype=np.uint8)
+                gathered = np.zeros(nbytes * n_parties, dtype=np.uint8)
+                rc = net_struct.gather_to_king(selfp, c, send.ctypes.data, nbytes,
+                                               gathered.ctypes.data if party_id == 0 else None, None)
+                back = np.repeat(np.arange(n_parties, dtype=np.uint8) + 3 * c + it, nbytes) if party_id == 0 else None
+                got = np.zeros(nbytes, dtype=np.uint8)
+                rc2 = net_struct.scatter_from_king(selfp, c, back.ctypes.data if party_id == 0 else None, nbytes,
+                                                   got.ctypes.data, None)
+                if rc or rc2 or not bool((got == (party_id + 3 * c + it) & 0xFF).all()):
+                    errs.append("channel %d: rc %d / %d or a payload of another channel" % (c, rc, rc2))
+                    return
+            done[c] = time.monotonic() - t0
+        except Exception as e:        # noqa: BLE001 -- reported through the collective decision
+            errs.append("channel %d: %r" % (c, e))
+
+    order = [(party_id + i) % 3 for i in range(3)]
+    ths = [threading.Thread(target=one, args=(c,), daemon=True) for c in order]
+    t_start = time.monotonic()
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join(max(0.0, soft_s - (time.monotonic() - t_start)))
+    in_time = all(d is not None and d <= soft_s for d in done) and not errs
+    for t in ths:                     # a stalled channel: wait it out (its messages must not meet the real protocol's)
+        t.join(max(0.0, hard_s - (time.monotonic() - t_start)))
+    alive = any(t.is_alive() for t in ths)
+    flag = torch.tensor([0 if (alive or errs) else (2 if in_time else 1)], dtype=torch.int32)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    v = int(flag.item())
+    if v == 0:
+        raise Dg16Error(6, "channel probe: a channel of the transport never completed (%s)" % (errs or "hard deadline"))
+    return "joined" if v == 2 else "serial"
 
 
 class TorchNet:

@@ -71,12 +71,20 @@ enum dg16_flags {
   DG16_F_SERIAL_CHANNELS = 16u, /* dg16_prove_c: run the three d_msm one after another (channel 0, 1, 2 in that order
                                on every party) instead of joined from three host threads -- for a dg16_net whose
                                channels are not independent (one ordered pipe); the result is the same */
-  DG16_F_OVERLAP_TAIL = 32u /* dg16_groth16_prove with DG16_F_DEVICE_PTRS, for a queue of proofs on one context: the last
+  DG16_F_OVERLAP_TAIL = 32u, /* dg16_groth16_prove with DG16_F_DEVICE_PTRS, for a queue of proofs on one context: the last
                                MSM's bucket reduction, the assembly and the copy to proof_out are ordered on CHANNEL 2's
                                stream instead of channel 0's, so the work enqueued next on channel 0 (the next proof's
                                dg16_qap and h-polynomial) starts under that latency-bound tail.  proof_out is complete
                                after dg16_sync(ctx, 2) (or stream-ordered work on channel 2); every other call on the
                                context orders itself behind the tail.  Ignored with host pointers. */
+  DG16_F_BASES_IN_SUBGROUP = 64u /* dg16_msm, dg16_d_msm, dg16_prove_a / _b / _c: the caller guarantees that every base is
+                               in the order-r subgroup (true of any arkworks G1Affine / G2Affine obtained through
+                               Validate::Yes or from CRS generation).  The library may then split the scalars with the
+                               curve's endomorphism (GLV: phi(P) = lambda P holds only in that subgroup), which is what
+                               its headline MSM rates are measured with.  Without the flag only cofactor-one groups
+                               (BN254 G1) take that path and every other group runs plain Pippenger, which -- like
+                               VariableBaseMSM::msm -- is correct for ANY point of the curve.  Resident keys / tables
+                               (dg16_pk_create*, dg16_bases_upload) never split and ignore the flag. */
 };
 
 /* field ids for dg16_field_op: curve for the base field Fq, 16 + curve for the scalar field Fr */
@@ -136,7 +144,8 @@ int dg16_qap_rows(dg16_ctx *ctx, int curve, size_t num_constraints, size_t num_i
 /* ---- MSM ----------------------------------------------------------------------------------------
  * out = sum_i scalars[i] * bases[i] in G1 (group = 1) or G2 (group = 2).
  * n_bases != n_scalars returns DG16_ERR_LENGTH_MISMATCH.  out: Jacobian (3 field elements of the
- * group's coordinate field) or affine with DG16_F_OUT_AFFINE. */
+ * group's coordinate field) or affine with DG16_F_OUT_AFFINE.  Scalars are integers below 2^255 (canonical field
+ * elements are; a set bit 255 is not part of the contract).  DG16_F_BASES_IN_SUBGROUP: see enum dg16_flags. */
 int dg16_msm(dg16_ctx *ctx, int curve, int group, const void *bases, const void *scalars,
              size_t n_bases, size_t n_scalars, unsigned flags, int channel, void *out);
 

@@ -26,15 +26,55 @@ def test_header_symbols_exported():
     assert sorted(EXPORTED) == decl, "python binding list and header disagree"
 
 
+RUST_SYS = os.path.join(ROOT, "bindings", "dg16-sys", "src", "lib.rs")
+
+
 def test_rust_extern_block_lists_the_header_symbols():
-    """INTEGRATION.md section 1 (the `extern "C"` block a maintainer would paste into dg16-sys) == include/dg16.h."""
-    rust = open(os.path.join(ROOT, "INTEGRATION.md")).read()
-    assert sorted(set(re.findall(r"pub fn (dg16_[a-z0-9_]+)\s*\(", rust))) == declared_symbols()
+    """bindings/dg16-sys/src/lib.rs (the crate a maintainer builds where cargo exists) declares exactly the functions of
+    include/dg16.h, once each, and the shim only calls functions the sys crate declares."""
+    rust = open(RUST_SYS).read()
+    fns = re.findall(r"pub fn (dg16_[a-z0-9_]+)\s*\(", rust)
+    assert sorted(fns) == declared_symbols(), "dg16-sys and include/dg16.h disagree"
+    shim = os.path.join(ROOT, "bindings", "dg16-shim", "src")
+    used = set()
+    for f in os.listdir(shim):
+        used |= set(re.findall(r"sys::(dg16_[a-z0-9_]+)\s*\(", open(os.path.join(shim, f)).read()))
+    assert used and used <= set(fns), sorted(used - set(fns))
+    # every patch names a file of the reference by the path the survey cites
+    for f in os.listdir(os.path.join(ROOT, "bindings", "patches")):
+        txt = open(os.path.join(ROOT, "bindings", "patches", f)).read()
+        assert re.search(r"^--- a/(dist-primitives|groth16|ark-circom)/", txt, flags=re.M), f
+
+
+def test_rust_struct_mirrors_have_the_fields_of_the_header():
+    """#[repr(C)] mirrors: same field names in the same order as the C structs (types are checked by a maintainer's
+    `cargo build --features static-check`; the order is what a silent ABI break would change)."""
+    hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "dg16.h")).read(), flags=re.S)
+    rust = open(RUST_SYS).read()
+    pairs = {"dg16_pk_info": "Dg16PkInfo", "dg16_r1cs_header": "Dg16R1csHeader", "dg16_zkey_header": "Dg16ZkeyHeader",
+             "dg16_csr": "Dg16Csr", "dg16_arkkey_layout_t": "Dg16ArkKeyLayout", "dg16_comm": "Dg16Comm", "dg16_net": "Dg16Net"}
+    for cname, rname in pairs.items():
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (cname, cname), hdr, flags=re.S).group(1)
+        cfields = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            m = re.search(r"\(\*(\w+)\)", decl)            # function pointer member
+            if m:
+                cfields.append(m.group(1))
+                continue
+            for nm in decl.split(","):
+                cfields.append(re.findall(r"\w+", nm)[-1])          # the declarator's last identifier is the member name
+        rbody = re.search(r"pub struct %s \{(.*?)\n\}" % rname, rust, flags=re.S).group(1)
+        rbody = re.sub(r"//.*", "", rbody)
+        rfields = [f.rstrip("_") for f in re.findall(r"pub (\w+):", rbody)]
+        assert [c for c in cfields if c] == rfields, (cname, cfields, rfields)
 
 
 def test_flag_constants_agree_with_the_header():
     """enum dg16_flags of include/dg16.h == the F_* constants the Python binding passes (and the Rust block of
-    INTEGRATION.md, for the flags it lists)."""
+    dg16-sys crate)."""
     from dg16_amd import lib
     txt = open(os.path.join(ROOT, "include", "dg16.h")).read()
     body = re.search(r"enum dg16_flags \{(.*?)\};", txt, flags=re.S).group(1)
@@ -45,9 +85,9 @@ def test_flag_constants_agree_with_the_header():
         assert v & (v - 1) == 0, "flags are single bits"
     for name, value in hdr.items():
         assert getattr(lib, name) == value, name
-    rust = open(os.path.join(ROOT, "INTEGRATION.md")).read()
-    for name, value in re.findall(r"pub const DG16_(F_[A-Z_]+): c_uint = (\d+);", rust):
-        assert hdr[name] == int(value), name
+    rust = open(RUST_SYS).read()
+    rflags = {n: int(v) for n, v in re.findall(r"pub const DG16_(F_[A-Z_]+): c_uint = (\d+);", rust)}
+    assert rflags == hdr, "dg16-sys flag constants"
 
 
 def test_no_cpu_fallback():

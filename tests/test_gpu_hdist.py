@@ -135,6 +135,26 @@ def test_sharded_h_prove_all_ranks_in_process_vs_oracle(curve, log_m, world):
         wl.pk.close()
 
 
+@pytest.mark.parametrize("curve,log_m,world", [("bls12_381", 20, 8), ("bn254", 20, 8), ("bls12_381", 22, 8)])
+def test_config5_sharded_proof_at_size_vs_oracle(curve, log_m, world):
+    """BASELINE config 5 on ITS OWN data path at sizes where every shard runs the large-MSM paths (2^17 / 2^19 points
+    per shard: partitioned sort, 16-bit table windows, giant buckets of the top window): eight DG16_F_H_CYCLIC shard
+    keys of one key in this process, dg16_qap_rows, the three stages of the sharded h-polynomial, dg16_groth16_msms_h
+    per shard, eight records, assembly (bench.ShardedInProcess) == the C oracle's proof of the same instance.
+    (local_groth_bench.rs:83-158: FFTs + five MSMs on a BLS curve.)  The 2^24 x 8 form:
+    `python bench.py --curve bls12_381 --log-m 24 --shards-in-process 8 --full-parity` (profiles/)."""
+    import bench
+    dev = torch.device(DEV)
+    sp = bench.ShardedInProcess(ctx(), dev, curve, log_m, world)
+    proof, per_rank, _ = sp.prove()
+    assert len(per_rank) == world
+    (A, B, C), _ = bench.oracle_prove(sp.shards[0], bench.cpu_threads())
+    gA, gB, gC = bench.gpu_proof_affine(curve, proof.cpu().numpy())
+    sp.close()
+    torch.cuda.empty_cache()
+    assert np.array_equal(A, gA) and np.array_equal(B, gB) and np.array_equal(C, gC)
+
+
 @pytest.mark.parametrize("curve,log_n,n_ranks,inverse", [("bn254", 4, 2, False), ("bn254", 6, 8, True), ("bn254", 12, 4, False),
                                                          ("bls12_381", 13, 8, True), ("bls12_377", 10, 2, False),
                                                          ("bn254", 20, 8, False), ("bn254", 20, 8, True)])

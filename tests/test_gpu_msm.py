@@ -37,37 +37,96 @@ def test_msm_matches_oracle(curve, group, n):
     check(curve, group, bases, scalars)
 
 
-def test_msm_without_the_scalar_split_in_a_process_of_its_own():
-    """dg16_msm with DG16_MSM_GLV=0 (read once per process, hence the child): the plain Pippenger over n points and all
-    the windows -- the path that also serves MSMs too large for the split's index range -- equals the oracle's MSM for
-    G1 and G2 of BN254 and the G2 of BLS12-381, and equals what the splitting path of THIS process returns."""
-    import subprocess
-    import sys
-    import os
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = (
-        "import sys, numpy as np\n"
-        "sys.path.insert(0, %r)\n"
-        "import dg16_amd\n"
-        "from oracle import corc\n"
-        "c = dg16_amd.Context(0)\n"
-        "for curve, group, n in (('bn254', 1, 1 << 15), ('bn254', 2, 1 << 14), ('bls12_381', 2, 1 << 13), ('bn254', 1, 33)):\n"
-        "    bases = corc.gen_points(curve, group, 40 + n, n) if n < 1 << 14 else c.gen_bases(curve, group, 40 + n, n)\n"
-        "    sc = corc.rand_field(curve, 'fr', 50 + n, n, mont=False)\n"
-        "    got = corc.jac_to_affine(curve, group, c.msm(curve, group, bases, sc))\n"
-        "    assert np.array_equal(got, corc.msm(curve, group, bases, sc)), (curve, group, n)\n"
-        "    print('NOSPLIT', curve, group, n, got.tobytes().hex()[:32])\n" % root)
-    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, DG16_MSM_GLV="0"), cwd=root,
-                         capture_output=True, text=True, timeout=280)
-    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
-    lines = [ln.split() for ln in out.stdout.splitlines() if ln.startswith("NOSPLIT")]
-    assert len(lines) == 4
-    for _, curve, group, n, head in lines:
-        group, n = int(group), int(n)
-        bases = corc.gen_points(curve, group, 40 + n, n) if n < 1 << 14 else ctx().gen_bases(curve, group, 40 + n, n)
-        sc = corc.rand_field(curve, "fr", 50 + n, n, mont=False)
-        mine = corc.jac_to_affine(curve, group, ctx().msm(curve, group, bases, sc))
-        assert mine.tobytes().hex()[:32] == head
+@pytest.mark.parametrize("curve,group,n", [("bn254", 2, 1 << 14), ("bls12_381", 1, 1 << 14), ("bls12_381", 2, 1 << 13),
+                                           ("bls12_377", 2, 1 << 10), ("bls12_377", 1, 33)])
+def test_msm_without_the_subgroup_flag_is_the_unsplit_pippenger(curve, group, n):
+    """dg16_msm WITHOUT DG16_F_BASES_IN_SUBGROUP (the C ABI's default): every group of cofactor != 1 runs the plain
+    Pippenger over n points and all the windows -- the path that also serves MSMs too large for the split's index
+    range -- and must equal the oracle's MSM and what the splitting path (flag set) returns."""
+    bases = corc.gen_points(curve, group, 40 + n, n) if n < 1 << 14 else ctx().gen_bases(curve, group, 40 + n, n)
+    sc = corc.rand_field(curve, "fr", 50 + n, n, mont=False)
+    plain = check(curve, group, bases, sc, in_subgroup=False)
+    split = check(curve, group, bases, sc, in_subgroup=True)
+    assert np.array_equal(plain, split)
+
+
+def _curve_points_outside_the_subgroup(curve, group, n, seed):
+    """n points of E(Fq) (G1) / E'(Fq2) (G2) found by trying x = seed, seed + 1, ..: almost surely NOT in the order-r
+    subgroup (cofactor ~2^125 for BLS12-381 G1, ~2^254 for BN254 G2) -- checked."""
+    from oracle.pyref.curves import CURVES
+    C = CURVES[curve, "g%d" % group]
+    F, p = C.F, C.F.p
+    assert p % 4 == 3
+    pts, x = [], seed
+    while len(pts) < n:
+        x += 1
+        if group == 1:
+            rhs = (x * x * x + C.b) % p
+            y = pow(rhs, (p + 1) // 4, p)
+            if y * y % p != rhs:
+                continue
+            P = (x % p, y)
+        else:
+            xx = (x % p, 1)
+            rhs = F.add(F.mul(F.sqr(xx), xx), C.b)
+            # sqrt in Fq2 = Fq[u] / (u^2 + 1), p = 3 mod 4: candidate a^((q + 1) / 4)-style via the norm
+            n0 = (rhs[0] * rhs[0] + rhs[1] * rhs[1]) % p
+            s = pow(n0, (p + 1) // 4, p)
+            if s * s % p != n0:
+                continue
+            y = None
+            for sg in (s, (-s) % p):
+                t = (rhs[0] + sg) * pow(2, p - 2, p) % p
+                y0 = pow(t, (p + 1) // 4, p)
+                if y0 * y0 % p != t or y0 == 0:
+                    continue
+                y1 = rhs[1] * pow(2 * y0, p - 2, p) % p
+                if F.sqr((y0, y1)) == rhs:
+                    y = (y0, y1)
+                    break
+            if y is None:
+                continue
+            P = (xx, y)
+        assert C.on_curve(P)
+        assert C.mul(P, C.order) is not None, "landed in the subgroup"
+        pts.append(P)
+    return C, pts
+
+
+@pytest.mark.parametrize("curve,group", [("bls12_381", 1), ("bn254", 2)])
+def test_msm_of_curve_points_outside_the_order_r_subgroup(curve, group):
+    """VariableBaseMSM::msm is correct for ANY points of the curve; the endomorphism split is not (phi(P) = lambda P
+    only in the order-r subgroup).  Without DG16_F_BASES_IN_SUBGROUP the library must return the group element the
+    plain double-and-add gives for points of the curve that are NOT in the subgroup (what a caller gets from a decode
+    with validate = 0)."""
+    n = 40
+    C, pts = _curve_points_outside_the_subgroup(curve, group, n, 1234)
+    rng = np.random.default_rng(5)
+    ks = [int.from_bytes(rng.bytes(31), "little") for _ in range(n)]
+    exp = None
+    for P, k in zip(pts, ks):
+        exp = C.add(exp, C.mul(P, k))
+    nl = 4 if curve == "bn254" else 6
+    R = 1 << (64 * nl)
+    p = C.F.p
+
+    def limbs(v):
+        v = v * R % p
+        return [(v >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(nl)]
+
+    rows = []
+    for P in pts:
+        if group == 1:
+            rows.append(limbs(P[0]) + limbs(P[1]))
+        else:
+            rows.append(limbs(P[0][0]) + limbs(P[0][1]) + limbs(P[1][0]) + limbs(P[1][1]))
+    bases = np.array(rows, dtype=np.uint64)
+    scal = np.array([[(k >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)] for k in ks], dtype=np.uint64)
+    jac = ctx().msm(curve, group, bases, scal, in_subgroup=False)
+    got = corc.jac_to_affine(curve, group, jac)
+    want = np.array([limbs(exp[0]) + limbs(exp[1])] if group == 1 else
+                    [limbs(exp[0][0]) + limbs(exp[0][1]) + limbs(exp[1][0]) + limbs(exp[1][1])], dtype=np.uint64)
+    assert np.array_equal(got.reshape(-1), want.reshape(-1))
 
 
 def test_gen_bases_equals_oracle_generator():

@@ -38,17 +38,24 @@ def source_key():
             h.update(f.encode())
             h.update(open(os.path.join(CSRC, f), "rb").read())
     h.update(open(os.path.join(ROOT, "include", "dg16.h"), "rb").read())
+    h.update(open(os.path.join(ROOT, STEPS_PROBE), "rb").read())
     return h.hexdigest()[:16]
 
 
+STEPS_PROBE = "tests/isa/steps_probe.hip"            # msm_accumulate_steps_kernel alone (seconds of hipcc)
 CASES = [
     ("bn254", 2, "msm_accumulate_lds_kernel"),        # LDS-staged accumulator, four-product Y3, next point fetched ahead
     ("bn254", 1, "msm_accumulate_kernel"),            # fused Y3, one-compare zero test; the bucket tree degenerates (one lane)
     ("bls12_381", 1, "msm_accumulate_kernel"),        # 14 limbs: the other limb shape of the instruction sequences
+    # the 14-limb G2 accumulation: three product sites visited by a step loop, temporaries in accumulation registers
+    ("bls12_381", 2, "msm_accumulate_steps_kernel"), ("bls12_377", 2, "msm_accumulate_steps_kernel"),
 ]
-if os.environ.get("DG16_EMU_ALL"):                    # the other three accumulation kernels: +3 minutes of hipcc on a cold cache
-    CASES += [("bls12_381", 2, "msm_accumulate_lds_kernel"), ("bls12_377", 1, "msm_accumulate_kernel"),
-              ("bls12_377", 2, "msm_accumulate_lds_kernel")]
+if os.environ.get("DG16_EMU_ALL"):                    # +2 minutes of hipcc on a cold cache
+    CASES += [("bls12_377", 1, "msm_accumulate_kernel")]
+
+
+def case_source(kernel):
+    return STEPS_PROBE if kernel == "msm_accumulate_steps_kernel" else "msm_group.hip"
 
 
 def assembly(curve, group, source="msm_group.hip"):
@@ -57,8 +64,8 @@ def assembly(curve, group, source="msm_group.hip"):
     msm_reduce.hip is built as the Makefile builds it (G2: out-of-line field products)."""
     cache = os.path.join("/tmp", "dg16_emu_cache", source_key())
     os.makedirs(cache, exist_ok=True)
-    path = lambda c, g, f: os.path.join(cache, "%s_%s_g%d.s" % (f.split(".")[0], c, g))     # noqa: E731
-    units = [(c, g, "msm_group.hip") for c, g, _ in CASES] + [("bn254", 1, "msm_reduce.hip")]
+    path = lambda c, g, f: os.path.join(cache, "%s_%s_g%d.s" % (os.path.basename(f).split(".")[0], c, g))     # noqa: E731
+    units = [(c, g, case_source(k)) for c, g, k in CASES] + [("bn254", 1, "msm_reduce.hip")]
     if (curve, group, source) not in units:
         units.append((curve, group, source))
     jobs = []
@@ -74,8 +81,9 @@ def assembly(curve, group, source="msm_group.hip"):
         flags = ["-DDG_CURVE=%d" % CURVE_ID[c], "-DDG_GROUP=%d" % g, "-DDG_NAME=%s_g%d" % (c, g)]
         if f == "msm_reduce.hip" and g == 2:
             flags.append("-DDG29_OUTLINE_MUL")
-        proc = subprocess.Popen([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17"] + flags + ["--cuda-device-only", "-S",
-                                 os.path.join(CSRC, f), "-o", out + ".tmp"],
+        src = os.path.join(ROOT, f) if "/" in f else os.path.join(CSRC, f)
+        proc = subprocess.Popen([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I", CSRC] + flags +
+                                ["--cuda-device-only", "-S", src, "-o", out + ".tmp"],
                                 stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         jobs.append((proc, out))
     for proc, out in jobs:
@@ -189,7 +197,7 @@ SPECS = [
 def test_accumulation_kernel_on_the_cpu(curve, group, kernel):
     from oracle.pyref.curves import CURVES
     C = CURVES[curve, "g%d" % group]
-    text = assembly(curve, group)
+    text = assembly(curve, group, case_source(kernel))
     for spec in SPECS:
         got, pts, count = run_bucket(text, kernel, curve, group, spec)
         exp = None

@@ -89,3 +89,42 @@ def test_ntt_step_has_no_scratch_and_no_column_joins():
         # v_lshl_add_u64 is now address arithmetic only: a product no longer joins its columns with 64-bit additions
         # (443 in this kernel before the chains)
         assert s["lshl_add_u64"] <= 260 and s["mads"] >= 17 * 162   # (229-240 with the direct twiddle tables: two more address chains)
+
+
+@pytest.mark.parametrize("curve", ["bls12_381", "bls12_377"])
+def test_14_limb_g2_accumulation_is_a_step_loop_over_three_product_sites(curve):
+    """msm_accumulate_steps_kernel: ONE product site (2 dual products = 6 N^2 mads), ONE squaring site (4 N^2) and ONE
+    fused Y3 site (2 x 5 N^2) inside the step loop -- not eleven inlined products (round 4: a 100-KB loop against a
+    64-KB instruction cache).  The loop must fit that cache, and the temporaries' accumulation registers
+    (a[kAccFileBase ..]: fixed numbers in asm statements, invisible to the compiler) must not collide with AGPRs
+    hipcc allocates itself."""
+    import re
+    n = 14
+    blks = kernel("msm_%s_g2.o" % curve, "msm_accumulate_steps_kernel")
+    mul, sqr = block_with(blks, 6 * n * n), block_with(blks, 4 * n * n)
+    # (BLS12-377, u^2 = -5: the multiplications by 5 of the fused site are 13 more v_mad_u64_u32)
+    fused = [b for b in blks if 10 * n * n <= b["mads"] <= 10 * n * n + 2 * n]
+    assert len(mul) == 1 and len(sqr) == 1 and len(fused) == 1, "a site was cloned"
+    assert sum(b["scratch"] for b in blks) == 0
+    # everything in front of the doubling branch (the one big cold block: dbl_affine, 3 products + 4 squares + the fused Y3)
+    cold = max(blks, key=lambda b: b["instr"])
+    assert cold["mads"] > 6000 and cold["addr"] > fused[0]["addr"]
+    first = min(b["addr"] for b in blks)
+    assert cold["addr"] - first <= 62 * 1024, "the step loop no longer fits the instruction cache: %d bytes" % (cold["addr"] - first)
+    ins = [v for k, v in isa_report.instructions(os.path.join(CSRC, "msm_%s_g2.o" % curve)).items()
+           if "msm_accumulate_steps_kernel" in k]
+    assert len(ins) == 1
+    file_regs, other = set(), set()
+    for _, text in ins[0]:
+        regs = [int(x) for x in re.findall(r"\ba(\d+)\b", text)]
+        for lo, hi in re.findall(r"\ba\[(\d+):(\d+)\]", text):
+            regs += list(range(int(lo), int(hi) + 1))
+        if not regs:
+            continue
+        op = text.split()[0]
+        if op in ("v_accvgpr_write_b32", "v_accvgpr_read_b32") and all(r >= 144 for r in regs):
+            file_regs.update(regs)
+        else:
+            other.update(regs)
+    assert file_regs == set(range(144, 144 + 4 * 2 * n)), sorted(file_regs)[:4]
+    assert all(r < 144 for r in other), "hipcc allocated an AGPR inside the temporaries' file: %s" % sorted(other)[-4:]

@@ -39,14 +39,11 @@ def test_g2_bucket_accumulation_stages_through_lds_without_spilling():
     (r,) = find("msm_accumulate_lds_kernel<Fp2<bn254_fq>,256,0>").values()
     assert r["lds"] == 4 * 18 * 256 * 4 and r["occupancy"] == 2   # 4 coordinates x 2 x 9 limbs x 256 lanes: 2 blocks / CU
     assert r["scratch"] == 0 and r["agprs"] == 0
-    # the 14-limb G2 accumulation has TWO forms in the library (the device picks: msm_accumulate_phase): inline products
-    # (TU 0: no scratch, no AGPRs, a 180-KB loop) and out-of-line products (TU 1, msm_group_outl.hip: a 176-byte call
-    # frame per lane, a loop that fits the instruction cache)
+    # the 14-limb G2 accumulation: a step loop over three product sites with its four temporaries in accumulation
+    # registers a[144..255] (declared clobbered: AGPRs = 256), one wave per SIMD, no scratch
     for curve in ("bls12_381", "bls12_377"):
-        (r,) = find("msm_accumulate_lds_kernel<Fp2<%s_fq>,128,0>" % curve).values()
-        assert r["scratch"] == 0 and r["agprs"] <= (0 if curve == "bls12_381" else 32) and r["lds"] == 4 * 28 * 128 * 4   # (BLS12-377: u^2 = -5 costs 25 AGPRs at one wave per SIMD, where they are free)
-        (r,) = find("msm_accumulate_lds_kernel<Fp2<%s_fq>,128,1>" % curve).values()
-        assert r["scratch"] <= 192 and r["lds"] == 4 * 28 * 128 * 4
+        (r,) = find("msm_accumulate_steps_kernel<Fp2<%s_fq>,128>" % curve).values()
+        assert r["scratch"] == 0 and r["agprs"] == 256 and r["vgprs"] <= 256 and r["lds"] == 4 * 28 * 128 * 4
     # the throughput finalize of G2 (two lanes per bucket, add_into with the four-product Y3): two waves per SIMD, and
     # since the products are chains neither scratch (BN254: was 16 B) nor a full AGPR file + scratch (BLS12-377)
     for k, r in find("msm_finalize_lds_kernel<Fp2<bn254_fq>,256>").items():

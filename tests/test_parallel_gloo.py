@@ -382,3 +382,57 @@ def test_torchnet_channels_are_independent():
     for p in procs:
         p.join(timeout=60)
     assert res == [(r, True, [], 6) for r in range(world)]
+
+
+def _probe_worker(rank, world, port, q, stall):
+    """One party of the channel watchdog (lib.probe_channels).  stall: the party whose channel 1 sleeps past the soft
+    deadline on first use (a transport whose channels share a pipe looks like this from every party), or None."""
+    import threading
+    import time
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    try:
+        from dg16_amd import lib
+        first = {"seen": False}
+        lock = threading.Lock()
+
+        def before(channel, op):
+            if stall == rank and channel == 1:
+                with lock:
+                    hit, first["seen"] = not first["seen"], True
+                if hit:
+                    time.sleep(2.5)
+
+        net = lib.TorchNet(dist, torch.device("cpu"), world, rank, before=before)
+        mode = lib.probe_channels(net.struct, world, rank, dist, soft_s=1.0, hard_s=60.0)
+        # the net is usable afterwards: a gather + scatter on every channel in the decided mode's order
+        ok = True
+        for c in range(3):
+            send = np.full(16, 10 * c + rank, dtype=np.uint8)
+            gathered = np.zeros(16 * world, dtype=np.uint8)
+            rc = net.struct.gather_to_king(None, c, send.ctypes.data, 16, gathered.ctypes.data if rank == 0 else None, None)
+            ok &= rc == 0 and (rank != 0 or bool((gathered.reshape(world, 16)[:, 0] == 10 * c + np.arange(world)).all()))
+        q.put((rank, mode, ok, net.errors))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("stall", [None, 1])
+def test_channel_watchdog_lands_every_party_on_the_serial_form(stall):
+    """The three-communicator form of prove::C (dg16_prove_c: three host threads, one per MultiplexedStreamID) is only
+    safe on a transport whose channels make progress independently.  lib.probe_channels exercises exactly that access
+    pattern on tiny payloads before the first proof and decides COLLECTIVELY: with healthy channels every party gets
+    "joined"; when ONE party's channel 1 stalls past the soft deadline, EVERY party -- also those whose own probe was
+    in time -- lands on "serial" (DG16_F_SERIAL_CHANNELS), and the transport is intact afterwards."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    world = 3
+    procs = [ctx.Process(target=_probe_worker, args=(r, world, port, q, stall)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    want = "joined" if stall is None else "serial"
+    assert res == [(r, want, True, []) for r in range(world)]

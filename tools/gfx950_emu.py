@@ -135,6 +135,9 @@ class Lane:
     # ---- operands ------------------------------------------------------------------------------------------------
     def rd(self, tok, width=32):
         tok = tok.strip()
+        m = re.fullmatch(r"a\[(0x[0-9a-fA-F]+|\d+)\]", tok)     # a[0x90]: one register, index syntax (inline asm "n" operand)
+        if m:
+            tok = "a%d" % int(m.group(1), 0)
         if tok in self.tmp:
             return self.tmp[tok]
         neg = False
@@ -179,6 +182,9 @@ class Lane:
 
     def wr(self, tok, val):
         tok = tok.strip()
+        m = re.fullmatch(r"a\[(0x[0-9a-fA-F]+|\d+)\]", tok)
+        if m:
+            tok = "a%d" % int(m.group(1), 0)
         m = re.fullmatch(r"v\[(\d+):(\d+)\]", tok)
         if m:
             lo, hi = int(m.group(1)), int(m.group(2))

@@ -35,6 +35,24 @@ def disassemble(obj_path):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def instructions(obj_path):
+    """-> {mangled name: [(address, instruction text)]} of every function in the object's gfx950 bundle"""
+    text = disassemble(obj_path)
+    out, cur = {}, None
+    for line in text.split("\n"):
+        m = re.match(r"^[0-9a-f]+ <(\S+)>:$", line)
+        if m:
+            cur = out.setdefault(m.group(1), [])
+            continue
+        if cur is None or not line.startswith("\t"):
+            continue
+        body = line.strip()
+        am = ADDR.search(body)
+        if am:
+            cur.append((int(am.group(1), 16), body.split("//")[0].strip()))
+    return {k: v for k, v in out.items() if v}
+
+
 def kernels(obj_path):
     text = disassemble(obj_path)
     out, cur, name = {}, None, None
