@@ -626,8 +626,13 @@ def msm_sweep(ctx, dev):
 
 def host_pointer_figure(ctx, wl, prover, steps):
     """The reference entry point takes host memory (create_proof_with_reduction_and_matrices: matrices and key fixed per
-    circuit, the full assignment new per proof, groth16/examples/sha256.rs:159).  Secondary figure: the same step with
-    the assignment copied host -> device (pinned source) and the proof copied device -> host INSIDE the step."""
+    circuit, the full assignment new per proof, groth16/examples/sha256.rs:159).  Two secondary figures:
+      ms_per_step            one statement at a time: H2D copy of the assignment (pinned source), R1CS x witness, proof,
+                             D2H copy of the proof, a host synchronisation after every step;
+      pipelined_ms_per_step  a QUEUE of statements (what mpc-api/src/main.rs:393 serves, one job after another): two
+                             device buffers for the assignment -- the H2D copy of statement k + 1 runs on a copy stream
+                             under the proof of statement k, ordered by events, no host synchronisation inside the
+                             queue; the proofs' D2H copies ride on the same copy stream behind each proof."""
     w_host = wl.w.cpu().pin_memory()
     torch.cuda.synchronize()
     ts = []
@@ -642,10 +647,80 @@ def host_pointer_figure(ctx, wl, prover, steps):
         proof.cpu()
         ts.append(time.perf_counter() - t0)
     dt = sum(ts[1:]) / steps
-    return {"ms_per_step": dt * 1e3, "constraints_per_s": wl.nc / dt, "steps": steps,
-            "includes": "H2D copy of the %d-byte full assignment from pinned host memory, R1CS x witness, the proof, D2H "
-                        "copy of the %d-byte proof; matrices and proving key resident (fixed per circuit)"
-                        % (w_host.numel() * 8, wl.proof_bytes())}
+    out = {"ms_per_step": dt * 1e3, "constraints_per_s": wl.nc / dt, "steps": steps,
+           "includes": "H2D copy of the %d-byte full assignment from pinned host memory, R1CS x witness, the proof, D2H "
+                       "copy of the %d-byte proof; matrices and proving key resident (fixed per circuit)"
+                       % (w_host.numel() * 8, wl.proof_bytes())}
+    try:
+        out.update(host_pointer_pipelined(ctx, wl, prover, steps, w_host, proof.cpu()))
+    except Exception as e:      # noqa: BLE001 -- a secondary figure must not take the line with it
+        out["pipelined_error"] = repr(e)
+    return out
+
+
+def host_pointer_pipelined(ctx, wl, prover, steps, w_host, want_proof_host):
+    """The double-buffered queue behind host_pointer_step.pipelined_ms_per_step.  The library's three channels run on
+    torch streams for the duration (dg16_set_stream), so that torch events order the copy stream against them."""
+    dev = wl.dev
+    chans = [torch.cuda.Stream(device=dev) for _ in range(3)]
+    copy = torch.cuda.Stream(device=dev)
+    bufs = [wl.w, torch.empty_like(wl.w)]
+    keep_w = wl.w
+    copied = [torch.cuda.Event() for _ in range(2)]
+    freed = [[torch.cuda.Event() for _ in range(3)] for _ in range(2)]     # per buffer: last proof done on channel c
+    for ch in range(3):
+        ctx.sync(ch)
+    torch.cuda.synchronize()
+    for ch in range(3):
+        ctx.set_stream(ch, chans[ch].cuda_stream)
+    try:
+        def run(n):
+            host_proofs = [torch.empty(wl.proof_bytes(), dtype=torch.uint8).pin_memory() for _ in range(n)]
+            used = [False, False]
+            with torch.cuda.stream(copy):
+                bufs[0].copy_(w_host, non_blocking=True)
+                copied[0].record(copy)
+            t0 = time.perf_counter()
+            for k in range(n):
+                cur, oth = k % 2, (k + 1) % 2
+                if k + 1 < n:
+                    with torch.cuda.stream(copy):
+                        if used[oth]:
+                            for e in freed[oth]:
+                                copy.wait_event(e)           # the proof that last read this buffer is complete
+                        bufs[oth].copy_(w_host, non_blocking=True)
+                        copied[oth].record(copy)
+                for st in chans:
+                    st.wait_event(copied[cur])
+                wl.w = bufs[cur]
+                wl.qap()
+                proof = prover.prove(wl.a, wl.b, wl.c, wl.w, wl.rs, scalars_mont=False)
+                for c_, st in enumerate(chans):
+                    freed[cur][c_].record(st)
+                used[cur] = True
+                with torch.cuda.stream(copy):
+                    for e in freed[cur]:
+                        copy.wait_event(e)
+                    host_proofs[k].copy_(proof, non_blocking=True)
+            copy.synchronize()
+            for st in chans:
+                st.synchronize()
+            return (time.perf_counter() - t0) / n, host_proofs
+
+        run(2)
+        dt, proofs = run(steps)
+        same = all(np.array_equal(x, y) for x, y in zip(gpu_proof_affine(wl.curve, proofs[-1].numpy()),
+                                                       gpu_proof_affine(wl.curve, want_proof_host.numpy())))
+        return {"pipelined_ms_per_step": dt * 1e3, "pipelined_constraints_per_s": wl.nc / dt,
+                "pipelined_last_proof_equals_synchronous": bool(same),
+                "pipelined": "queue of %d statements, assignment double-buffered: H2D of statement k + 1 on a copy stream "
+                             "under the proof of statement k (events, no host synchronisation inside the queue)" % steps}
+    finally:
+        for st in chans:
+            st.synchronize()
+        for ch in range(3):
+            ctx.set_stream(ch, None)
+        wl.w = keep_w
 
 
 def timed_prove_with_parity(ctx, dev, curve, log_m, steps):
@@ -840,6 +915,7 @@ def main():
     n_g2 = info["n_ab"]                              # points of this rank's A / B1 / B launches (slice + 2 delta slots)
     nwin = (SCALAR_BITS[curve] + 1 + info["c_ab"] - 1) // info["c_ab"]
     g2_alg = {"bn254": 160.0, "bls12_381": 224.0}[curve]
+    g1_alg = {"bn254": 96.0, "bls12_381": 128.0}[curve]          # G1 affine point + 32-byte scalar
     alg_bytes = g2_alg * n_g2
     achieved = alg_bytes / (g2_acc_ms * 1e-3) / 1e9 if g2_acc_ms else 0.0
     # one XYZZ mixed addition per nonzero digit, counted in the instruction that bounds it (add_mads)
@@ -849,12 +925,12 @@ def main():
     _, mul_rate_g, mul_src = valu_constants(curve)   # measured G products/s of the C++-compiled product (auxiliary)
     prods = proof_products(curve, info, args.log_m, wl.nc, world=world)
     whole_t = prods["total"] / (ms_per_step * 1e-3) / 1e12     # per GPU: `prods` is this rank's share
-    g2_kernel = "msm_accumulate_lds_kernel<Fp2<%s_fq>>" % curve
+    g2_kernel = ("msm_accumulate_lds_kernel<Fp2<%s_fq>>" if curve == "bn254" else "msm_accumulate_steps_kernel<Fp2<%s_fq>>") % curve
 
     # HBM traffic of that kernel: PMC counters cannot be read from inside the process; the committed summary of
     # the separate rocprofv3 --pmc passes over the same launch (same curve, group, size) supplies it.
     traffic, traffic_src = None, None
-    for name in ("r4v_pmc_g2_accumulate.json", "r4p_pmc_g2_accumulate.json", "r4l_pmc_g2_accumulate.json", "r4f_pmc_g2_accumulate.json", "r4a_pmc_g2_accumulate.json", "r3_pmc_g2_accumulate.json", "r2_pmc_g2_accumulate.json",
+    for name in ("r5_pmc_g2_accumulate.json", "r4v_pmc_g2_accumulate.json", "r4p_pmc_g2_accumulate.json", "r4l_pmc_g2_accumulate.json", "r4f_pmc_g2_accumulate.json", "r4a_pmc_g2_accumulate.json", "r3_pmc_g2_accumulate.json", "r2_pmc_g2_accumulate.json",
                  "r1_pmc_g2_accumulate.json"):
         pmc_path = os.path.join(ROOT, "profiles", name)
         if args.log_m == 20 and curve == "bn254" and world == 1 and os.path.exists(pmc_path):
@@ -919,6 +995,26 @@ def main():
                                   "headroom of the whole pipeline, not of one kernel"
                                   % (g2_add_mads, n_g2, nwin, MAD_ISSUE_T, mul_cost)},
         "g1_accumulate_ms": g1_acc_ms,
+        # the G1 accumulation: four launches per proof (A, B1, L, H), more TOTAL time than the G2 launch and further from
+        # the issue roof -- on the line next to the G2 figures since round 5
+        "roofline_g1": {"bound": "hbm", "kernel": "msm_accumulate_kernel<Fp<%s_fq>> (A's G1 bucket accumulation, table mode, "
+                        "inside the timed proofs; B1, L, H are launches of the same kernel)" % curve,
+                        "achieved": (g1_alg * n_g2 / (g1_acc_ms * 1e-3) / 1e9) if g1_acc_ms else 0.0, "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": (g1_alg * n_g2 / (g1_acc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if g1_acc_ms else 0.0,
+                        "kernel_ms": g1_acc_ms, "points_per_launch": n_g2, "launches_per_proof": 4,
+                        "note": "%d B/point algorithmic (point + scalar once)" % int(g1_alg)},
+        "valu_roofline_g1": {"unit": "T v_mad_u64_u32 lane-op/s",
+                             "achieved": (float(g1_add_mads) * n_g2 * nwin / (g1_acc_ms * 1e-3) / 1e12) if g1_acc_ms else 0.0,
+                             "peak": MAD_ISSUE_T,
+                             "frac": (float(g1_add_mads) * n_g2 * nwin / (g1_acc_ms * 1e-3) / 1e12 / MAD_ISSUE_T) if g1_acc_ms else 0.0,
+                             "mads_per_g1_add": g1_add_mads,
+                             "valu_slots_per_g1_add": {"bn254": 2089}.get(curve),
+                             "note": "every integer VALU instruction of the loop (mads, column shifts / masks, m[k] products) "
+                                     "issues at about the same ~35 T lane-op/s (profiles/r5c_ubench_instr_rate.txt): the "
+                                     "loop's 2089 issue slots per addition, not its 1467 mads, are what the time buys -- "
+                                     "SQ counters (profiles/r5a_pmc_sq_bn254.md): VALU busy 74 % of the cycles at the nominal "
+                                     "2.4 GHz = 83 % at the ~2.13 GHz the chip holds under this kernel "
+                                     "(profiles/r5c_clock_under_kernels.txt)"},
         "host": {"cpu_model": cpu_model(), "nproc": os.cpu_count()},
     }
     if world > 1 and not args.no_replicas:

@@ -759,8 +759,7 @@ msm_accumulate_kernel(MsmBases bases, size_t n,
 // SIMD, AGPR spills); with the coordinates in LDS between uses (layout [coordinate word][lane]: consecutive lanes ->
 // consecutive banks, conflict-free ds_read/write_b32) the live set is the loaded point and ~6 temporaries.
 // 4 coordinates x 2 N words x BLOCK lanes = 72 KiB for BN254 Fq2 at BLOCK = 256 (two workgroups per CU, 160 KiB LDS).
-// TU: 0 = instantiated in msm_group.hip (products as that unit compiles them: inline by default), 1 = in
-// msm_group_outl.hip (the 14-limb curves' second form, field products out of line) -- distinct symbols, both in the library
+// (9-limb Fq2 -- BN254 -- only: the 14-limb curves run msm_accumulate_steps_kernel below)
 template <class F, int BLOCK, int TU = 0>
 __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 ? 2 : 1))
 msm_accumulate_lds_kernel(MsmBases bases, size_t n, MsmGeom g,
@@ -808,11 +807,6 @@ msm_accumulate_lds_kernel(MsmBases bases, size_t n, MsmGeom g,
   unsigned nxt = cnt > 1 ? e[1] : 0u;
   RawPoint<F> raw_cur{};
   if (PREFETCH && cnt) raw_cur = load_raw<F>(base_tab, cur & 0x7fffffffu);
-  // (14-limb Fq2: the loop body is 22 300 instructions = 180 KB against a 64 KB instruction cache shared by two CUs, at one
-  // wave per SIMD: 9.4 ms per 2^20-point launch on some boxes of the pool, 18.9 on others.  Measured on a slow box and
-  // removed: the waves of a workgroup in LOCKSTEP behind a barrier per iteration, so that one stream of instruction
-  // fetches serves all of them -- 17.87 ms against 17.86 with two waves per workgroup, 20.8 with four: the fetches are
-  // latency-, not bandwidth-bound.  Out-of-line products: 14.4 ms on both kinds of box (Makefile: OUTLINE_GROUPS).)
   for (unsigned j = 0; j < cnt; j++) {
     const unsigned nn = (j + 2 < cnt) ? e[j + 2] : 0u;
     RawPoint<F> raw_nxt{};
@@ -914,6 +908,100 @@ __device__ __forceinline__ Fe2<P, B, 1> acc_get() {
   }
   return v;
 }
+// d += b (full XYZZ addition, XYZZ29::add_into) as a STEP LOOP over the same three product sites: the 14-limb G2 finalize
+// (msm_finalize_lds_kernel: two lanes per bucket summing the bucket's partials) inlined a 144-KB addition -- 35 900
+// instructions with its doubling branch -- and ran at 16 % of its issue rate on the slow boxes of the pool.
+//     0  U1 = X1 ZZ2 -> X1      1  S1 = Y1 ZZZ2 -> Y1      2  P = X2 ZZ1 - U1      3  R = Y2 ZZZ1 - S1
+//     4  PP = P^2               5  PPP = P PP              6  T = ZZ1 ZZ2          7  ZZ3 = T PP
+//     8  T = ZZZ1 ZZZ2          9  ZZZ3 = T PPP           10  Q = U1 PP           11  X3 = R^2 - PPP - 2 Q
+//    12  Y3 = R (Q - X3) - PPP S1
+// d: accumulator in LDS columns (get / put); b: read-only operand behind an accessor (memory or LDS), intact throughout, so
+// the rare d == b case doubles b.  Needs the accumulation-register file of the calling kernel (kAccFileBase).
+template <class F, class D, class B>
+__device__ __forceinline__ void xyzz_add_into_steps(const D& d, const B& b_) {
+  using FO = FieldOf<F>;
+  using P = typename FO::Params;
+  constexpr int BS = FO::BS;
+  constexpr int BG = 640;
+  using G = Fe2<P, BG, 1>;
+  if (limbs_all_zero(b_.get(2))) return;
+  if (limbs_all_zero(d.get(2))) {
+    d.put(0, b_.get(0)); d.put(1, b_.get(1)); d.put(2, b_.get(2)); d.put(3, b_.get(3));
+    return;
+  }
+  B b = b_;
+  auto dg = [&](int c) { return d.get(c).template as<BG, 1>(); };
+  auto bg = [&](int c) { return b.get(c).template as<BG, 1>(); };
+  int special = 0;
+  bool p_zero = false;
+#pragma unroll 1
+  for (int step = 0; step < 13; step++) {
+    asm volatile("" : "+s"(step));          // opaque: the sites must not be cloned per step
+    b.launder();                            // ... and the operand's 112 word addresses not hoisted out of the loop (they
+                                            // were: 224 registers of pointers, 932 B of scratch per lane)
+    if (step == 4 || step == 11) {
+      const G a = step == 4 ? acc_get<0, P, BG>() : acc_get<1, P, BG>();
+      const auto c = sqr(a);
+      if (step == 4) {
+        acc_set<2>(c.template as<BG, 1>());                             // PP
+      } else {
+        const auto ppp = acc_get<3, P, 128>(), q_ = acc_get<0, P, 128>();
+        const auto x3 = fit<BS>(c - (ppp + dbl(q_)));
+        d.put(0, x3);
+        acc_set<2>(fit<BG>(q_ - x3));                                   // Q - X3
+      }
+    } else if (step == 12) {
+      const auto r_ = acc_get<1, P, BG>(), t_ = acc_get<2, P, BG>();
+      const auto ppp = acc_get<3, P, 128>();
+      d.put(1, fit<BS>(mul_sub(r_, t_, ppp, d.get(1))));                // R (Q - X3) - PPP S1
+    } else {
+      G a, bb;
+      switch (step) {
+        case 0: a = dg(0); bb = bg(2); break;                            // X1 ZZ2
+        case 1: a = dg(1); bb = bg(3); break;                            // Y1 ZZZ2
+        case 2: a = bg(0); bb = dg(2); break;                            // X2 ZZ1
+        case 3: a = bg(1); bb = dg(3); break;                            // Y2 ZZZ1
+        case 5: a = acc_get<0, P, BG>(); bb = acc_get<2, P, BG>(); break;   // P PP
+        case 6: a = dg(2); bb = bg(2); break;                            // ZZ1 ZZ2
+        case 7: a = acc_get<0, P, BG>(); bb = acc_get<2, P, BG>(); break;   // (ZZ1 ZZ2) PP
+        case 8: a = dg(3); bb = bg(3); break;                            // ZZZ1 ZZZ2
+        case 9: a = acc_get<0, P, BG>(); bb = acc_get<3, P, BG>(); break;   // (ZZZ1 ZZZ2) PPP
+        default: a = dg(0); bb = acc_get<2, P, BG>(); break;             // U1 PP
+      }
+      const auto c = a * bb;
+      switch (step) {
+        case 0: d.put(0, c.template as<BS, 1>()); break;                 // U1
+        case 1: d.put(1, c.template as<BS, 1>()); break;                 // S1
+        case 2: {
+          const auto p_ = fit<BG>(c - d.get(0));
+          p_zero = is_zero_compact(p_);
+          acc_set<0>(p_);
+          break;
+        }
+        case 3: {
+          const auto r_ = fit<BG>(c - d.get(1));
+          if (p_zero) special = is_zero_compact(r_) ? 1 : 2;
+          acc_set<1>(r_);
+          break;
+        }
+        case 5: acc_set<3>(c.template as<BG, 1>()); break;               // PPP
+        case 6: acc_set<0>(c.template as<BG, 1>()); break;
+        case 7: d.put(2, c.template as<BS, 1>()); break;                 // ZZ3
+        case 8: acc_set<0>(c.template as<BG, 1>()); break;
+        case 9: d.put(3, c.template as<BS, 1>()); break;                 // ZZZ3
+        default: acc_set<0>(c.template as<BG, 1>()); break;              // Q
+      }
+      if (special) break;
+    }
+  }
+  if (special == 1) {
+    const XYZZ29<F> t = XYZZ29<F>{b.get(0), b.get(1), b.get(2), b.get(3)}.dbl_pt();
+    d.put(0, t.x); d.put(1, t.y); d.put(2, t.zz); d.put(3, t.zzz);
+  } else if (special == 2) {
+    d.put(2, FO::zero());                                              // the identity: zz = 0
+  }
+}
+
 template <class F, int BLOCK>
 __global__ void __launch_bounds__(BLOCK, 1)
 msm_accumulate_steps_kernel(MsmBases bases, size_t n, MsmGeom g,
@@ -1388,13 +1476,18 @@ MsmSort msm_sort_on(hipStream_t s, Channel& wsch, const void* scalars, size_t n,
   r.seg_off = r.offsets + nbw;
   r.cursor = r.seg_off + nbw;
   r.seg_total = r.cursor + nbw;
+  unsigned* blockoff = nullptr;
+  if (n && partitioned) {
+    const size_t len = (size_t)pg.nparts * pg.nblk1 + 1;
+    blockoff = (unsigned*)ws(wsch, 25, (len + (unsigned)((len + 4095) / 4096)) * 4);
+  }
+  const unsigned scan_nblocks = ((1u << g.log_nb) + kScanBlock - 1) / kScanBlock;
+  unsigned* block_tot = (unsigned*)ws(wsch, 9, (size_t)g.bw * scan_nblocks * 2 * 4);
   DG_HIP(hipMemsetAsync(r.counts, 0, nbw * 4, s));
   uint2* part = (uint2*)r.digits;
-  unsigned* blockoff = nullptr;
   if (n && partitioned) {
     const size_t len = (size_t)pg.nparts * pg.nblk1 + 1;      // + sentinel = total entries
     const unsigned nchunks = (unsigned)((len + 4095) / 4096);
-    blockoff = (unsigned*)ws(wsch, 25, (len + nchunks) * 4);
     unsigned* tot = blockoff + len;
     DG_HIP(hipMemsetAsync(blockoff + len - 1, 0, 4, s));
     hipLaunchKernelGGL(msm_part_hist_kernel<Fr>, dim3(pg.nblk1), dim3(256), 0, s, (const Fr*)scalars, n,
@@ -1412,7 +1505,6 @@ MsmSort msm_sort_on(hipStream_t s, Channel& wsch, const void* scalars, size_t n,
   }
   {
     const unsigned nblocks = ((1u << g.log_nb) + kScanBlock - 1) / kScanBlock;   // <= 512 for c <= 22
-    unsigned* block_tot = (unsigned*)ws(wsch, 9, (size_t)g.bw * nblocks * 2 * 4);
     hipLaunchKernelGGL(msm_scan_local_kernel<0>, dim3(nblocks, g.bw), dim3(1024), 0, s, r.counts, r.offsets,
                        r.seg_off, block_tot, g.log_nb, g.seg_log);
     hipLaunchKernelGGL(msm_scan_tops_kernel<0>, dim3(g.bw), dim3(1024), 0, s, block_tot, nblocks, r.seg_total);
@@ -1488,20 +1580,16 @@ void msm_accumulate_phase(hipStream_t s, const MsmSort& st, const MsmBuffers<F>&
     // G2 (Fq2 coordinates): LDS-staged accumulator; two workgroups per CU must fit the 160 KiB of LDS
     constexpr int BLOCK = 1 << msm_acc_block_log<F>();
     const dim3 grid((g.seg_cap + BLOCK - 1) / BLOCK, g.bw * b.ninst);
-    auto inline_form = [&] {
+    if constexpr (sizeof(F) > 64) {
+      // 14-limb Fq2: ONE form -- three product sites visited by a step loop (msm_accumulate_steps_kernel: a loop that fits
+      // the instruction cache).  Measured against round 4's straight-line loop, same call: 8.84-8.90 ms against 8.85-8.93
+      // per 2^20-point launch on a fast box of the pool, 8.93-9.17 against 18.0-18.1 on a slow one
+      // (profiles/r5b_*, r5c_*); both round-4 forms and the timing-based choice between them are gone.
+      hipLaunchKernelGGL((msm_accumulate_steps_kernel<F, BLOCK>), grid, dim3(BLOCK), 0, s, mb, st.n, g, st.offsets,
+                         st.counts, st.seg_off, st.seg_total, st.entries, b.seg_sum, b.buckets);
+    } else {
       hipLaunchKernelGGL((msm_accumulate_lds_kernel<F, BLOCK>), grid, dim3(BLOCK), 0, s, mb, st.n, g, st.offsets, st.counts,
                          st.seg_off, st.seg_total, st.entries, b.seg_sum, b.buckets);
-    };
-    if constexpr (sizeof(F) > 64) {
-      // 14-limb Fq2: ONE product site visited ten times per addition (msm_accumulate_steps_kernel: a loop that fits the
-      // instruction cache).  DG16_G2_14LIMB=inline runs round 4's straight-line loop instead (A/B only).
-      static const bool straight = [] { const char* e = getenv("DG16_G2_14LIMB"); return e && e[0] == 'i'; }();
-      if (straight) inline_form();
-      else
-        hipLaunchKernelGGL((msm_accumulate_steps_kernel<F, BLOCK>), grid, dim3(BLOCK), 0, s, mb, st.n, g, st.offsets,
-                           st.counts, st.seg_off, st.seg_total, st.entries, b.seg_sum, b.buckets);
-    } else {
-      inline_form();
     }
     if (b.acc_done) DG_HIP(hipEventRecord(b.acc_done, s));
     if (msm_finalize_lds_lpb()) msm_finalize_lds_phase<F>(s, st, b);
@@ -1648,6 +1736,8 @@ struct PartialAcc {      // an XYZZ29 behind the accessor interface of XYZZ29::a
     if (p) return coord == 0 ? p->x : coord == 1 ? p->y : coord == 2 ? p->zz : p->zzz;
     return col.get(coord);
   }
+  // the pointer as a value the compiler cannot trace (xyzz_add_into_steps: keeps address arithmetic inside the step)
+  __device__ __forceinline__ void launder() { asm volatile("" : "+v"(p)); }
 };
 template <class F, int BLOCK>
 __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 ? 2 : 1))
@@ -1660,6 +1750,7 @@ msm_finalize_lds_kernel(MsmGeom g, size_t total, unsigned wg_log, unsigned lpb_l
   constexpr int WORDS = sizeof(typename FO::Store) / 4;
   __shared__ uint32_t sh[4 * WORDS][BLOCK];
   __shared__ unsigned max_serial;
+  if constexpr (sizeof(F) > 64) asm volatile("" ::: "a144", "a255");   // xyzz_add_into_steps' temporaries (acc_set / acc_get)
   const unsigned LPB = 1u << lpb_log;
   const unsigned lane = threadIdx.x, sub = lane & (LPB - 1);
   const size_t gid = ((size_t)blockIdx.x * BLOCK + lane) >> lpb_log;
@@ -1714,7 +1805,8 @@ msm_finalize_lds_kernel(MsmGeom g, size_t total, unsigned wg_log, unsigned lpb_l
     if (on) {
       const PartialAcc<F, BLOCK> b{tree ? nullptr : &sp[msm_part_slot(first, lo + 1 + step, wg_log)],
                                    ColAcc<F, BLOCK>{sh, lane + d}};
-      XYZZ29<F>::add_into(me, b);
+      if constexpr (sizeof(F) > 64) xyzz_add_into_steps<F>(me, b);     // 14-limb Fq2: the addition as a step loop
+      else XYZZ29<F>::add_into(me, b);
     }
   }
   if (work && sub == 0) {

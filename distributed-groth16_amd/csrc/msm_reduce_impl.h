@@ -347,6 +347,9 @@ inline void trace_point(hipStream_t s, const char* what) {
   last = now;
 }
 
+// (Round 5 measured this chain and the digit sort as hipGraphs -- captured once per argument set, replayed with one
+// hipGraphLaunch: no gain, profiles/r5e_hipgraph_chains_ab.txt -- the host spends 0.3-0.4 ms enqueueing a whole proof
+// outside a profiler; the 3 ms seen under rocprofv3 are the tracer's.  Removed.)
 template <class F>
 void msm_bucket_phase(hipStream_t s, const MsmSort& st, const MsmBuffers<F>& b, bool out_affine, void* out_dev) {
   const MsmGeom& g = st.g;

@@ -39,10 +39,12 @@ def source_key():
             h.update(open(os.path.join(CSRC, f), "rb").read())
     h.update(open(os.path.join(ROOT, "include", "dg16.h"), "rb").read())
     h.update(open(os.path.join(ROOT, STEPS_PROBE), "rb").read())
+    h.update(open(os.path.join(ROOT, FINALIZE_PROBE), "rb").read())
     return h.hexdigest()[:16]
 
 
 STEPS_PROBE = "tests/isa/steps_probe.hip"            # msm_accumulate_steps_kernel alone (seconds of hipcc)
+FINALIZE_PROBE = "tests/isa/finalize_probe.hip"      # msm_finalize_lds_kernel of a 14-limb G2 alone
 CASES = [
     ("bn254", 2, "msm_accumulate_lds_kernel"),        # LDS-staged accumulator, four-product Y3, next point fetched ahead
     ("bn254", 1, "msm_accumulate_kernel"),            # fused Y3, one-compare zero test; the bucket tree degenerates (one lane)
@@ -65,7 +67,8 @@ def assembly(curve, group, source="msm_group.hip"):
     cache = os.path.join("/tmp", "dg16_emu_cache", source_key())
     os.makedirs(cache, exist_ok=True)
     path = lambda c, g, f: os.path.join(cache, "%s_%s_g%d.s" % (os.path.basename(f).split(".")[0], c, g))     # noqa: E731
-    units = [(c, g, case_source(k)) for c, g, k in CASES] + [("bn254", 1, "msm_reduce.hip")]
+    units = [(c, g, case_source(k)) for c, g, k in CASES] + [("bn254", 1, "msm_reduce.hip"),
+                                                             ("bls12_381", 2, FINALIZE_PROBE)]
     if (curve, group, source) not in units:
         units.append((curve, group, source))
     jobs = []
@@ -273,22 +276,30 @@ def test_g1_accumulation_workgroup_with_the_bucket_tree():
         assert got == exp, "bucket %d" % b
 
 
-def test_g2_finalize_workgroup():
-    """msm_finalize_lds_kernel<Fp2<bn254>, 256> with two lanes per bucket (the throughput finalize behind the G2
+@pytest.mark.parametrize("curve", ["bn254", "bls12_381"])
+def test_g2_finalize_workgroup(curve):
+    """(bls12_381: the 14-limb kernel, BLOCK = 128, whose addition is the step loop xyzz_add_into_steps with its
+    temporaries in accumulation registers.)  msm_finalize_lds_kernel<Fp2<bn254>, 256> with two lanes per bucket (the throughput finalize behind the G2
     accumulation: each lane adds its share of the bucket's partial sums into an accumulator in LDS columns --
     XYZZ29::add_into with the four-product Y3, ONE addition site for the serial partials and the tree partners --, then
     one tree step across the two lanes behind a barrier) on the Workgroup emulator:
     buckets with 5, 2, 1 and 0 partials, partials in XYZZ form with Z != 1 -> the buckets the oracle's sums predict."""
     import random
     from oracle.pyref.curves import CURVES
-    C = CURVES["bn254", "g2"]
+    C = CURVES[curve, "g2"]
     F2 = C.F
     p = F2.p
     n_limbs, w = limb_shape(p)
     R = 1 << (w * n_limbs)
-    prog = E.Program(assembly("bn254", 2), "msm_finalize_lds_kernelINS_3Fp2INS_2FpINS_15bn254_fq_paramsEEEEELi256EE")
+    block = 256 if curve == "bn254" else 128
+    xb = 4 * 2 * n_limbs * 4                                       # bytes of an XYZZ29 over Fq2
+    if curve == "bn254":
+        prog = E.Program(assembly("bn254", 2), "msm_finalize_lds_kernelINS_3Fp2INS_2FpINS_15bn254_fq_paramsEEEEELi256EE")
+    else:
+        prog = E.Program(assembly(curve, 2, FINALIZE_PROBE),
+                         "msm_finalize_lds_kernelINS_3Fp2INS_2FpINS_19bls12_381_fq_paramsEEEEELi128EE")
     CNTS, SOFF, SSUM, BUCK, GCNT, GLIST, KARG = (0x100000 * k for k in range(1, 8))
-    wg = E.Workgroup(prog, 256, wg_id=(0, 0), kernarg_addr=KARG)
+    wg = E.Workgroup(prog, block, wg_id=(0, 0), kernarg_addr=KARG)
     mem = wg.mem
     rng = random.Random(11)
     log_nb, seg_log = 4, 4
@@ -314,7 +325,7 @@ def test_g2_finalize_workgroup():
             for c in coords:
                 words += limbs(c[0]) + limbs(c[1])
             for i, v in enumerate(words):
-                mem[SSUM + 288 * (slot + s) + 4 * i] = v
+                mem[SSUM + xb * (slot + s) + 4 * i] = v
             total = C.add(total, P)
         expect[b] = total
         slot += k
@@ -340,13 +351,14 @@ def test_g2_finalize_workgroup():
     for b, k in parts.items():
         if k == 1:
             continue                                               # a one-segment bucket is written by the accumulation itself
-        out = [mem.get(BUCK + 288 * b + 4 * i) for i in range(72)]
+        out = [mem.get(BUCK + xb * b + 4 * i) for i in range(8 * n_limbs)]
         assert all(v is not None for v in out), "bucket %d was not written" % b
 
         def fe(ws):
             return sum(v << (w * i) for i, v in enumerate(ws)) % p
 
-        co = [(fe(out[18 * c:18 * c + 9]), fe(out[18 * c + 9:18 * c + 18])) for c in range(4)]
+        nn = n_limbs
+        co = [(fe(out[2 * nn * c:2 * nn * c + nn]), fe(out[2 * nn * c + nn:2 * nn * (c + 1)])) for c in range(4)]
         got = None if co[2] == (0, 0) else (F2.mul(co[0], F2.inv(co[2])), F2.mul(co[1], F2.inv(co[3])))
         assert got == expect[b], "bucket %d" % b
 

@@ -4,6 +4,7 @@
 #   gpurun_out/<tag>/bench_line.json                 python bench.py --steps 20 --warmup 3
 #   gpurun_out/<tag>/bench_prove_2e20_kernel_stats.md, timeline_one_proof.md
 #                                                    rocprofv3 --kernel-trace --stats of the same bench (no extras)
+#   gpurun_out/<tag>/bench_line_bls12_381_2e20.json, bench_shards_in_process_bls12_381_2e20.json, shard_timing.txt
 #   gpurun_out/<tag>/pmc_raw.txt, pmc_g2_accumulate.json
 #                                                    separate --pmc FETCH_SIZE / WRITE_SIZE passes over three proofs
 #                                                    (tools/pmc_sum.py): what bench.py reads roofline.traffic from
@@ -13,7 +14,7 @@ sel=${*:-tests}
 O=gpurun_out/$tag; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp; cd - > /dev/null
 git_head=$(cat .git_head 2>/dev/null || echo unknown)
-(timeout 600 python -X faulthandler -m pytest $sel -m gpu -q -o faulthandler_timeout=300 2>&1 | tail -40) > $O/gputest.txt
+(timeout 900 python -X faulthandler -m pytest $sel -m gpu -q -o faulthandler_timeout=400 2>&1 | tail -40) > $O/gputest.txt
 tail -3 $O/gputest.txt
 (timeout 300 python bench.py --steps 20 --warmup 3) > $O/bench_line.json 2> $O/bench.err
 rm -rf $O/prof
@@ -30,6 +31,11 @@ for ctr in FETCH_SIZE WRITE_SIZE; do
   rm -rf $O/pmc
 done
 python tools/pmc_json.py $O/pmc_raw.txt "$tag" > $O/pmc_g2_accumulate.json
+# config 5's curve and data path: BLS12-381 2^20 (timed, parity on the timed instance) and the sharded proof over 8 shard
+# keys in this process against the oracle
+(timeout 300 python bench.py --curve bls12_381 --log-m 20 --steps 5 --warmup 2 --no-extras) > $O/bench_line_bls12_381_2e20.json 2>> $O/bench.err
+(timeout 300 python bench.py --curve bls12_381 --log-m 20 --shards-in-process 8 --steps 3) > $O/bench_shards_in_process_bls12_381_2e20.json 2>> $O/bench.err
+(timeout 120 python tools/shard_timing.py 20 10 bn254 1,2,4,8 2>&1 | grep -E "^world|per_rank") > $O/shard_timing.txt
 python - "$O" <<'PY'
 import json, sys
 d = json.loads(open(sys.argv[1] + '/bench_line.json').read().strip().splitlines()[-1])
