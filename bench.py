@@ -929,13 +929,15 @@ def main():
 
     # HBM traffic of that kernel: PMC counters cannot be read from inside the process; the committed summary of
     # the separate rocprofv3 --pmc passes over the same launch (same curve, group, size) supplies it.
-    traffic, traffic_src = None, None
+    traffic, traffic_src, traffic_g1 = None, None, None
     for name in ("r5_pmc_g2_accumulate.json", "r4v_pmc_g2_accumulate.json", "r4p_pmc_g2_accumulate.json", "r4l_pmc_g2_accumulate.json", "r4f_pmc_g2_accumulate.json", "r4a_pmc_g2_accumulate.json", "r3_pmc_g2_accumulate.json", "r2_pmc_g2_accumulate.json",
                  "r1_pmc_g2_accumulate.json"):
         pmc_path = os.path.join(ROOT, "profiles", name)
         if args.log_m == 20 and curve == "bn254" and world == 1 and os.path.exists(pmc_path):
             with open(pmc_path) as f:
-                traffic = json.load(f)["traffic_bytes_per_launch"]
+                pj = json.load(f)
+            traffic = pj["traffic_bytes_per_launch"]
+            traffic_g1 = pj.get("g1_traffic_bytes_per_launch")
             traffic_src = "profiles/%s (2 x FETCH_SIZE + WRITE_SIZE, separate --pmc passes)" % name
             break
 
@@ -1001,6 +1003,7 @@ def main():
                         "inside the timed proofs; B1, L, H are launches of the same kernel)" % curve,
                         "achieved": (g1_alg * n_g2 / (g1_acc_ms * 1e-3) / 1e9) if g1_acc_ms else 0.0, "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": (g1_alg * n_g2 / (g1_acc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if g1_acc_ms else 0.0,
+                        "traffic": traffic_g1, "traffic_source": traffic_src,
                         "kernel_ms": g1_acc_ms, "points_per_launch": n_g2, "launches_per_proof": 4,
                         "note": "%d B/point algorithmic (point + scalar once)" % int(g1_alg)},
         "valu_roofline_g1": {"unit": "T v_mad_u64_u32 lane-op/s",

@@ -28,6 +28,11 @@ namespace dg16 {
 constexpr unsigned kTileLog = 10;         // 1024 elements per workgroup
 constexpr unsigned kTile = 1u << kTileLog;
 constexpr unsigned kMaxStepLog = 10;      // sub-FFT size limit per step: 2^20 = 2^10 x 2^10 is TWO passes over the data
+// (2^21 / 2^22 as two passes on a 2048-element tile -- 72 KB of LDS + 32 KB of packed twiddles, one 512-lane workgroup
+// per CU, steps of 2^11 points whose tile lines are single 32-byte elements -- was built and measured in round 5: 2^22
+// 0.757 ms against 0.516-0.522 for the three passes below, 2^21 0.326 against 0.274, same call
+// (profiles/r5h_ntt_two_pass_2048_tile_ab.txt).  The pass it saves is 11 % of the instructions; one workgroup per CU and
+// uncoalesced lines cost more.  Removed.)
 constexpr unsigned kLoBits = 11;          // twiddle table split
 
 template <class F>

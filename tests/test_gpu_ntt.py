@@ -14,8 +14,9 @@ ALL = ["bn254", "bls12_381", "bls12_377"]
 
 # no skips: bn254 and bls12_381 (BASELINE configs 3 and 5) run every plan shape (1, 2 and 3 steps, odd and even
 # splits); bls12_377 (the reference's dfft tests, dfft/mod.rs:277) runs one size per plan shape
-SWEEP = [(c, k) for c in ("bn254", "bls12_381") for k in (0, 1, 3, 9, 10, 11, 13, 18, 19, 20)] + \
-        [("bls12_377", k) for k in (3, 10, 13, 19)]
+# 21 and 22: the smallest three-pass plans (BASELINE config 3's size against the oracle, forward and inverse)
+SWEEP = [(c, k) for c in ("bn254", "bls12_381") for k in (0, 1, 3, 9, 10, 11, 13, 18, 19, 20, 21, 22)] + \
+        [("bls12_377", k) for k in (3, 10, 13, 19, 21)]
 
 
 @pytest.mark.parametrize("curve,log_n", SWEEP)
@@ -27,7 +28,7 @@ def test_ntt_matches_oracle(curve, log_n):
     assert np.array_equal(c.ntt(curve, X, inverse=True), corc.ntt(curve, X, inverse=True))
 
 
-@pytest.mark.parametrize("log_n", [4, 10, 12, 19])
+@pytest.mark.parametrize("log_n", [4, 10, 12, 19, 21, 22])
 def test_coset_ntt_matches_oracle(log_n):
     curve = "bn254"
     F = FR[curve]
@@ -49,7 +50,8 @@ def test_ntt_x_equals_i():
 
 
 @pytest.mark.parametrize("curve,log_m", [("bn254", 3), ("bn254", 10), ("bn254", 15), ("bn254", 20),
-                                         ("bls12_381", 12), ("bls12_381", 16), ("bls12_381", 20)])
+                                         ("bls12_381", 12), ("bls12_381", 16), ("bls12_381", 20), ("bn254", 21),
+                                         ("bn254", 22)])
 def test_h_poly_matches_oracle(curve, log_m):
     m = 1 << log_m
     a, b, c_ = (corc.rand_field(curve, "fr", 40 + i, m) for i in range(3))

@@ -24,5 +24,14 @@ print(json.dumps({
     "WRITE_SIZE_KB_raw_per_launch": write,
     "traffic_bytes_per_launch": (2 * fetch + write) * 1024,
     "launches": g2.get("FETCH_SIZE", {}).get("launches", 0),
+    # G1 accumulation (msm_accumulate_kernel): 64-byte point gathers.  Calibration of the counter for THIS width: the
+    # kernel must gather 64 B x 15 windows x 1 048 578 points = 1.007 GB of points + 63 MB of entry indices per launch;
+    # raw FETCH_SIZE reads 1.14-1.17 GB -- the requests are tallied at their true 64 bytes, NO x2 (the x2 of the guide
+    # applies to the 128-byte gathers of the G2 kernel: raw 1.12 GB for 2.01 GB of points)
+    "g1_kernel": "msm_accumulate_kernel<Fp<bn254_fq>> (A / B1 / L / H: four launches per proof)",
+    "g1_FETCH_SIZE_KB_raw_per_launch": raw.get("msm_accumulate_kernel", {}).get("FETCH_SIZE", {}).get("KB_per_launch", 0.0),
+    "g1_WRITE_SIZE_KB_raw_per_launch": raw.get("msm_accumulate_kernel", {}).get("WRITE_SIZE", {}).get("KB_per_launch", 0.0),
+    "g1_traffic_bytes_per_launch": (raw.get("msm_accumulate_kernel", {}).get("FETCH_SIZE", {}).get("KB_per_launch", 0.0) +
+                                    raw.get("msm_accumulate_kernel", {}).get("WRITE_SIZE", {}).get("KB_per_launch", 0.0)) * 1024,
     "other_kernels_raw": {k: v for k, v in raw.items() if k != "msm_accumulate_lds_kernel"},
 }, indent=1))

@@ -69,7 +69,17 @@ for world in worlds:
             ctx.sync(ch)
         torch.cuda.synchronize()
 
-    for _ in range(3):
+    for _ in range(5):
+        step()
+    sync()
+    # settle: the previous world's key (gigabytes of tables) was just freed and this one built -- one call of this tool
+    # printed 4 ms of host time per proof for whichever world came third or fourth (profiles/r5f_shard_timing.txt,
+    # r5g_shard_timing_a.txt), 0.4 ms when the same world ran alone
+    import gc
+    gc.collect()
+    torch.cuda.synchronize()
+    time.sleep(0.5)
+    for _ in range(2):
         step()
     sync()
     t0 = time.perf_counter()
