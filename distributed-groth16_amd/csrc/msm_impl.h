@@ -96,8 +96,18 @@ inline MsmGeom msm_geometry(size_t n, unsigned scalar_bits, bool table = false, 
     size_t mean = g.region >> g.log_nb;   // entries per bucket
     unsigned lm = 0;
     while (((size_t)2 << lm) <= mean) lm++;
-    int sl = (int)lm - 3;      // mean/8: 2^20-point table, mean 240 -> 16 (measured 18.8 ms per proof; 32: 19.5; 8: 19.6;
-                               // round 4, profiles/r4seg_segment_length_ab.txt: 16: 10.01-10.04 ms, 32: 10.14-10.19)
+    // Segment length: 16 entries while the launch has ~2^20 segments, 32 beyond -- short segments balance the last rounds of
+    // a launch, long ones leave fewer partials per bucket for the tree / finalize, and which matters more is a matter of
+    // how many rounds the launch runs.  Measured (profiles/r4seg_*, r5k_*, r5l_*, same call each): BN254 2^20 (2^23.9
+    // entries) 16: 10.01-10.04 ms per proof, 32: 10.14-10.19; BLS12-381 2^20 (2^24 entries) 8: 22.4-23.1, **16: 21.2-21.6**,
+    // 32: 22.3-22.4 (the rule before round 5 -- mean occupancy / 8 -- gave 32 there: 256 entries per bucket exactly),
+    // 64: 24.2; BN254 2^22 (2^25.8) 16: 36.8-37.1, **32: 36.0-36.6**; BLS12-381 2^22 16: 83.5-83.8, 32: 82.0-82.1.
+    unsigned le_all = 0;
+    while (((size_t)2 << le_all) <= g.region * g.bw) le_all++;   // floor(log2(entries of the launch: all bucket-windows))
+    int sl = (int)le_all - 20;
+    if (sl < 4) sl = 4;
+    if (sl > 5) sl = 5;
+    if (sl > (int)lm - 2) sl = (int)lm - 2;                      // ... and at least four segments per mean bucket
     if (sl < 4) sl = 4;
     // ... but never so long that the launch runs out of lanes (a 2^17-point shard with 32-entry segments has
     // 1.2 waves per SIMD: measured 0.62 ms per G1 accumulation instead of 0.25)

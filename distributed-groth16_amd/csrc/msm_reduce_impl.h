@@ -384,6 +384,17 @@ void msm_bucket_phase(hipStream_t s, const MsmSort& st, const MsmBuffers<F>& b, 
     const size_t total_rows = (size_t)bwi << b.rg.rows_log;
     while (k_log < 3 && (total_rows >> (k_log + 1)) >= 256 && g.log_nb >= CH_LL + k_log + 1) k_log++;
     if (total_rows < 1024) k_log = 0;
+    // ... except for the 14-limb fields over a LARGE table (one bucket set of 2^16 buckets = 256 rows: the MSMs of a
+    // 2^20 BLS12-381 proof): there the 16-step suffix scan + tree of msm_row_kernel is ~0.5 M full additions per MSM on
+    // 65 536 lanes at 256 VGPRs -- work and SIMD slots taken from the accumulation running beside it -- while chunks of
+    // 8 buckets do ~0.19 M on 8 192 lanes in 32 dependent steps that hide behind that accumulation anyway.  Same call,
+    // chunks of 1 / 2 / 4 / 8 buckets: 25.6-25.7 / 25.6-25.7 / 24.9-25.0 / **24.4-24.6 ms** per BLS12-381 2^20 proof on one
+    // box, 23.05-23.13 -> **22.19-22.23** on another; BN254 (9 limbs: a third of the work per addition) 10.54-10.60 /
+    // 10.58-10.75 / 10.54-10.65: nothing, the rows stay (profiles/r5i_*, r5j_*).  Short shards keep the rows: their
+    // reductions are the critical path, not hidden work.
+    if (total_rows < 1024 && RR<typename FieldOf<F>::Params>::N > 9 && g.table && g.region >= ((size_t)1 << 23)) {
+      k_log = g.log_nb - CH_LL < 3 ? g.log_nb - CH_LL : 3;
+    }
     if (k_log > 3) k_log = 3;
     // the top kernel's folded mode takes <= 256 chunk workgroups per bucket-window: beyond that (one bucket set of
     // 2^20 buckets: the table of a 2^24-point key) the rows + msm_rowfold_kernel path serves
