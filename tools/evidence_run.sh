@@ -14,7 +14,8 @@ sel=${*:-tests}
 O=gpurun_out/$tag; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp; cd - > /dev/null
 git_head=$(cat .git_head 2>/dev/null || echo unknown)
-(timeout 900 python -X faulthandler -m pytest $sel -m gpu -q -o faulthandler_timeout=400 2>&1 | tail -40) > $O/gputest.txt
+timeout 900 python -X faulthandler -m pytest $sel -m gpu -q -o faulthandler_timeout=400 > $O/gputest_full.txt 2>&1
+(grep -E "passed|failed|error|Fatal|File \"/root/repo|File \"/tmp/code" $O/gputest_full.txt | tail -30; grep -E "^tests/|^\.+|^=+" $O/gputest_full.txt | tail -12) > $O/gputest.txt
 tail -3 $O/gputest.txt
 (timeout 300 python bench.py --steps 20 --warmup 3) > $O/bench_line.json 2> $O/bench.err
 rm -rf $O/prof
