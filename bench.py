@@ -3,6 +3,8 @@
 2^20-constraint synthetic R1CS, at 1/2/4/8 GPUs).
 
     python bench.py --gpus N --steps K --warmup W [--curve bn254|bls12_381] [--log-m 20]
+    python bench.py --curve bls12_381 --log-m 24 --shards-in-process 8 [--full-parity]   config 5's data path on one GPU
+    python bench.py --gpus 8 --dry-run                                                   the plan of an N-GPU run, no GPU touched
     (N > 1 without WORLD_SIZE in the environment re-executes itself under
      python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
 
@@ -23,6 +25,10 @@ One JSON line is printed by rank 0:
   cpu_baseline   the oracle ("port": arkworks-structured CPU restatement, NOT arkworks) proving THE TIMED INSTANCE on
                  this box's host cores (all cores, bounded to 32 OpenMP threads; plus a 1-thread run on a smaller
                  sample) -- its proof is compared with the GPU's proof of the timed loop (live parity gate).
+  roofline_g1    the same for A's G1 bucket accumulation (four launches of that kernel per proof: more total time than
+                 the G2 launch), with valu_roofline_g1.
+  host_pointer_step  the step with the assignment coming from host memory: one statement at a time, and as a
+                 double-buffered queue (pipelined_ms_per_step).
   extras         ntt_2^22 (BASELINE config 3), plain / resident MSM points/s for G1 and G2 (config 2), the
                  sha256-shaped prove (config 4), key table bytes and build time.
 """
