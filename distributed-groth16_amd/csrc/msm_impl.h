@@ -1602,7 +1602,7 @@ void msm_accumulate_phase(hipStream_t s, const MsmSort& st, const MsmBuffers<F>&
                          st.seg_off, st.seg_total, st.entries, b.seg_sum, b.buckets);
     }
     if (b.acc_done) DG_HIP(hipEventRecord(b.acc_done, s));
-    if (msm_finalize_lds_lpb()) msm_finalize_lds_phase<F>(s, st, b);
+    msm_finalize_lds_phase<F>(s, st, b);
   } else {
     constexpr int BLOCK = 1 << msm_acc_block_log<F>();
     hipLaunchKernelGGL((msm_accumulate_kernel<F, BLOCK>), dim3((g.seg_cap + BLOCK - 1) / BLOCK, g.bw * b.ninst),

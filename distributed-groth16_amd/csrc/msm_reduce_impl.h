@@ -356,14 +356,7 @@ void msm_bucket_phase(hipStream_t s, const MsmSort& st, const MsmBuffers<F>& b, 
   const unsigned bwi = g.bw * b.ninst;      // bucket-windows over all instances
   trace_point(s, "(before bucket phase)");
   if constexpr (FieldOf<F>::EXT) {
-    // G2: the throughput finalize ran behind the accumulation (msm_finalize_lds_phase); DG16_FINALIZE_LDS=0: the
-    // one-lane-per-bucket finalize of THIS translation unit (out-of-line products: small code)
-    if (!msm_finalize_lds_lpb()) {
-      DG_HIP(hipMemsetAsync(b.giant, 0, 8, s));
-      hipLaunchKernelGGL((msm_finalize_thr_kernel<F, 1>), dim3((unsigned)((b.nbw + 255) / 256)), dim3(256), 0, s, st.g,
-                       b.nbw, msm_acc_wg_log<F>(), st.counts, st.seg_off, b.seg_sum, b.buckets, b.giant, b.giant + 2,
-                       b.giant_cap);
-    }
+    // G2: the throughput finalize ran behind the accumulation, on its stream (msm_impl.h: msm_finalize_lds_phase)
   } else {
     DG_HIP(hipMemsetAsync(b.giant, 0, 8, s));
     msm_finalize_phase<F>(s, st, b);        // inline products (msm_group.hip)

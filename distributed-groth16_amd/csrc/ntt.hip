@@ -478,7 +478,14 @@ static const TwiddleSet& get_twiddles(Call& k, int curve, unsigned log_n, int in
     unsigned consumed = 0;
     for (unsigned j = 0; j + 1 < pl.nsteps && log_n <= kFullTwiddleMaxLog && log_n >= full_twiddle_min_log(); j++) {
       const size_t cnt = (size_t)1 << (log_n - consumed);
-      DG_HIP(hipMalloc(&ts.full[j], cnt * sizeof(F)));
+      // an optimisation, not a requirement: when HBM is short (0.5 GB per table at 2^24 next to 126 GB of window
+      // tables) the step multiplies by the composed lo x hi twiddles instead
+      if (hipMalloc(&ts.full[j], cnt * sizeof(F)) != hipSuccess) {
+        (void)hipGetLastError();
+        ts.full[j] = nullptr;
+        consumed += pl.s[j];
+        continue;
+      }
       hipLaunchKernelGGL(full_twiddle_kernel<F>, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, s, (F*)ts.full[j], cnt,
                          consumed, log_n - consumed - pl.s[j], (const F*)ts.lo_i,
                          (const F*)((inverse && j == 0) ? ts.hi_scaled_i : ts.hi_i), ts.lb);
@@ -629,7 +636,11 @@ static const F* flat_shift_table(Call& k, const TwiddleSet& t2, unsigned log_m) 
   TwiddleSet& w = const_cast<TwiddleSet&>(t2);       // (the cache entry; guarded by ctx->mu like its creation)
   if (!w.shift_full) {
     const size_t m = (size_t)1 << log_m;
-    DG_HIP(hipMalloc(&w.shift_full, m * sizeof(F)));
+    if (hipMalloc(&w.shift_full, m * sizeof(F)) != hipSuccess) {      // optional table: the split lo x hi form serves
+      (void)hipGetLastError();
+      w.shift_full = nullptr;
+      return nullptr;
+    }
     hipLaunchKernelGGL(flat_powers_kernel<F>, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, k.s(), (F*)w.shift_full, m,
                        (const F*)t2.lo_i, (const F*)t2.hi_i, t2.lb);
     DG_HIP(hipGetLastError());
