@@ -436,3 +436,29 @@ def test_channel_watchdog_lands_every_party_on_the_serial_form(stall):
         p.join(timeout=60)
     want = "joined" if stall is None else "serial"
     assert res == [(r, want, True, []) for r in range(world)]
+
+
+def test_bench_dry_run_plan_matches_the_keys_the_gpu_built():
+    """`bench.py --gpus N --dry-run` touches no GPU and prints the plan of the run: per-rank shard sizes, window bits and
+    table bytes by the formulas of csrc/prover_impl.h / msm_impl.h.  Pinned against what the library itself reported for
+    keys it built on the GPU (profiles/): BN254 2^20 one key 6 039 807 360 B (r5z_bench_line.json), BLS12-381 2^20 over 8
+    shards 9 663 853 056 B, 2^24 over 8 shards 144 955 311 840 B (r5g_*_full_parity.json)."""
+    import json
+    import subprocess
+    bench = os.path.join(ROOT, "bench.py")
+
+    def plan(*args):
+        out = subprocess.run([sys.executable, bench, "--dry-run"] + list(args), capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0, out.stderr[-2000:]
+        return json.loads(out.stdout)
+
+    d = plan()
+    assert d["dry_run"] and d["n_gpus"] == 1 and d["ranks"][0]["table_bytes"] == 6039807360 and d["exchanges_per_proof"] == {}
+    d = plan("--gpus", "8", "--curve", "bls12_381", "--log-m", "20")
+    assert sum(r["table_bytes"] for r in d["ranks"]) == 9663853056 and d["h_polynomial_sharded"]
+    d = plan("--gpus", "8", "--curve", "bls12_381", "--log-m", "24")
+    assert sum(r["table_bytes"] for r in d["ranks"]) == 144955311840
+    assert d["table_bytes_per_rank_max"] < d["hbm_per_gpu_bytes"]
+    assert "--nproc-per-node 8" in d["commands"]["this_run"] and "--master-addr 127.0.0.1" in d["commands"]["this_run"]
+    d = plan("--gpus", "3")            # not a rank count the sharded h-polynomial takes: replicated
+    assert not d["h_polynomial_sharded"] and "replicated" in d["exchanges_per_proof"]["h_polynomial"]
