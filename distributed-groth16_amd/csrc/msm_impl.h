@@ -918,100 +918,6 @@ __device__ __forceinline__ Fe2<P, B, 1> acc_get() {
   }
   return v;
 }
-// d += b (full XYZZ addition, XYZZ29::add_into) as a STEP LOOP over the same three product sites: the 14-limb G2 finalize
-// (msm_finalize_lds_kernel: two lanes per bucket summing the bucket's partials) inlined a 144-KB addition -- 35 900
-// instructions with its doubling branch -- and ran at 16 % of its issue rate on the slow boxes of the pool.
-//     0  U1 = X1 ZZ2 -> X1      1  S1 = Y1 ZZZ2 -> Y1      2  P = X2 ZZ1 - U1      3  R = Y2 ZZZ1 - S1
-//     4  PP = P^2               5  PPP = P PP              6  T = ZZ1 ZZ2          7  ZZ3 = T PP
-//     8  T = ZZZ1 ZZZ2          9  ZZZ3 = T PPP           10  Q = U1 PP           11  X3 = R^2 - PPP - 2 Q
-//    12  Y3 = R (Q - X3) - PPP S1
-// d: accumulator in LDS columns (get / put); b: read-only operand behind an accessor (memory or LDS), intact throughout, so
-// the rare d == b case doubles b.  Needs the accumulation-register file of the calling kernel (kAccFileBase).
-template <class F, class D, class B>
-__device__ __forceinline__ void xyzz_add_into_steps(const D& d, const B& b_) {
-  using FO = FieldOf<F>;
-  using P = typename FO::Params;
-  constexpr int BS = FO::BS;
-  constexpr int BG = 640;
-  using G = Fe2<P, BG, 1>;
-  if (limbs_all_zero(b_.get(2))) return;
-  if (limbs_all_zero(d.get(2))) {
-    d.put(0, b_.get(0)); d.put(1, b_.get(1)); d.put(2, b_.get(2)); d.put(3, b_.get(3));
-    return;
-  }
-  B b = b_;
-  auto dg = [&](int c) { return d.get(c).template as<BG, 1>(); };
-  auto bg = [&](int c) { return b.get(c).template as<BG, 1>(); };
-  int special = 0;
-  bool p_zero = false;
-#pragma unroll 1
-  for (int step = 0; step < 13; step++) {
-    asm volatile("" : "+s"(step));          // opaque: the sites must not be cloned per step
-    b.launder();                            // ... and the operand's 112 word addresses not hoisted out of the loop (they
-                                            // were: 224 registers of pointers, 932 B of scratch per lane)
-    if (step == 4 || step == 11) {
-      const G a = step == 4 ? acc_get<0, P, BG>() : acc_get<1, P, BG>();
-      const auto c = sqr(a);
-      if (step == 4) {
-        acc_set<2>(c.template as<BG, 1>());                             // PP
-      } else {
-        const auto ppp = acc_get<3, P, 128>(), q_ = acc_get<0, P, 128>();
-        const auto x3 = fit<BS>(c - (ppp + dbl(q_)));
-        d.put(0, x3);
-        acc_set<2>(fit<BG>(q_ - x3));                                   // Q - X3
-      }
-    } else if (step == 12) {
-      const auto r_ = acc_get<1, P, BG>(), t_ = acc_get<2, P, BG>();
-      const auto ppp = acc_get<3, P, 128>();
-      d.put(1, fit<BS>(mul_sub(r_, t_, ppp, d.get(1))));                // R (Q - X3) - PPP S1
-    } else {
-      G a, bb;
-      switch (step) {
-        case 0: a = dg(0); bb = bg(2); break;                            // X1 ZZ2
-        case 1: a = dg(1); bb = bg(3); break;                            // Y1 ZZZ2
-        case 2: a = bg(0); bb = dg(2); break;                            // X2 ZZ1
-        case 3: a = bg(1); bb = dg(3); break;                            // Y2 ZZZ1
-        case 5: a = acc_get<0, P, BG>(); bb = acc_get<2, P, BG>(); break;   // P PP
-        case 6: a = dg(2); bb = bg(2); break;                            // ZZ1 ZZ2
-        case 7: a = acc_get<0, P, BG>(); bb = acc_get<2, P, BG>(); break;   // (ZZ1 ZZ2) PP
-        case 8: a = dg(3); bb = bg(3); break;                            // ZZZ1 ZZZ2
-        case 9: a = acc_get<0, P, BG>(); bb = acc_get<3, P, BG>(); break;   // (ZZZ1 ZZZ2) PPP
-        default: a = dg(0); bb = acc_get<2, P, BG>(); break;             // U1 PP
-      }
-      const auto c = a * bb;
-      switch (step) {
-        case 0: d.put(0, c.template as<BS, 1>()); break;                 // U1
-        case 1: d.put(1, c.template as<BS, 1>()); break;                 // S1
-        case 2: {
-          const auto p_ = fit<BG>(c - d.get(0));
-          p_zero = is_zero_compact(p_);
-          acc_set<0>(p_);
-          break;
-        }
-        case 3: {
-          const auto r_ = fit<BG>(c - d.get(1));
-          if (p_zero) special = is_zero_compact(r_) ? 1 : 2;
-          acc_set<1>(r_);
-          break;
-        }
-        case 5: acc_set<3>(c.template as<BG, 1>()); break;               // PPP
-        case 6: acc_set<0>(c.template as<BG, 1>()); break;
-        case 7: d.put(2, c.template as<BS, 1>()); break;                 // ZZ3
-        case 8: acc_set<0>(c.template as<BG, 1>()); break;
-        case 9: d.put(3, c.template as<BS, 1>()); break;                 // ZZZ3
-        default: acc_set<0>(c.template as<BG, 1>()); break;              // Q
-      }
-      if (special) break;
-    }
-  }
-  if (special == 1) {
-    const XYZZ29<F> t = XYZZ29<F>{b.get(0), b.get(1), b.get(2), b.get(3)}.dbl_pt();
-    d.put(0, t.x); d.put(1, t.y); d.put(2, t.zz); d.put(3, t.zzz);
-  } else if (special == 2) {
-    d.put(2, FO::zero());                                              // the identity: zz = 0
-  }
-}
-
 template <class F, int BLOCK>
 __global__ void __launch_bounds__(BLOCK, 1)
 msm_accumulate_steps_kernel(MsmBases bases, size_t n, MsmGeom g,
@@ -1746,8 +1652,6 @@ struct PartialAcc {      // an XYZZ29 behind the accessor interface of XYZZ29::a
     if (p) return coord == 0 ? p->x : coord == 1 ? p->y : coord == 2 ? p->zz : p->zzz;
     return col.get(coord);
   }
-  // the pointer as a value the compiler cannot trace (xyzz_add_into_steps: keeps address arithmetic inside the step)
-  __device__ __forceinline__ void launder() { asm volatile("" : "+v"(p)); }
 };
 template <class F, int BLOCK>
 __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 ? 2 : 1))
@@ -1760,7 +1664,6 @@ msm_finalize_lds_kernel(MsmGeom g, size_t total, unsigned wg_log, unsigned lpb_l
   constexpr int WORDS = sizeof(typename FO::Store) / 4;
   __shared__ uint32_t sh[4 * WORDS][BLOCK];
   __shared__ unsigned max_serial;
-  if constexpr (sizeof(F) > 64) asm volatile("" ::: "a144", "a255");   // xyzz_add_into_steps' temporaries (acc_set / acc_get)
   const unsigned LPB = 1u << lpb_log;
   const unsigned lane = threadIdx.x, sub = lane & (LPB - 1);
   const size_t gid = ((size_t)blockIdx.x * BLOCK + lane) >> lpb_log;
@@ -1815,8 +1718,11 @@ msm_finalize_lds_kernel(MsmGeom g, size_t total, unsigned wg_log, unsigned lpb_l
     if (on) {
       const PartialAcc<F, BLOCK> b{tree ? nullptr : &sp[msm_part_slot(first, lo + 1 + step, wg_log)],
                                    ColAcc<F, BLOCK>{sh, lane + d}};
-      if constexpr (sizeof(F) > 64) xyzz_add_into_steps<F>(me, b);     // 14-limb Fq2: the addition as a step loop
-      else XYZZ29<F>::add_into(me, b);
+      // (14-limb Fq2: the same addition as a step loop over the accumulation's three product sites -- 35 900 -> 22 700
+      // instructions, emulated against the oracle, 23.2 -> 22.9 ms per BLS12-381 proof on a fast box -- was withdrawn in
+      // round 5: one box of the pool aborted with HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION behind this kernel
+      // (profiles/r5r_*), unexplained and not reproducible on the next box)
+      XYZZ29<F>::add_into(me, b);
     }
   }
   if (work && sub == 0) {

@@ -125,6 +125,26 @@ __global__ void __launch_bounds__(64) msm_giant_fold_kernel(MsmGeom g, unsigned 
   }
 }
 
+
+// A narrow tree step, sh[base + i] += sh[base + i + d] for i < d <= 64, on ROWS OF 16 LANES: a lone lane takes ~10 us (G1) /
+// ~35 us (G2) per dependent addition whatever the number of idle lanes around it; add_wave29 (msm_impl.h) spreads the four
+// product levels of ONE addition over the 16 lanes of a row -- its operands only have to be uniform within the row: the
+// broadcasts are row_newbcast, the Fq2 product's shuffles stay inside a quad -- ~3 us (G1) / ~8 us (G2, products behind
+// calls in this unit).  Sixteen rows of a 256-lane half take additions i = row, row + 16, ..: steps of <= 16 additions
+// are one pass.  Round 5: the G2 bucket reduction is the critical path of a small proof (BASELINE config 4: row 0.61 +
+// top 0.63 ms of a 2.0-ms proof, sixteen and seventeen dependent steps) and of a shard's B chain.
+// No barrier inside: the row that owns i is the only reader of sh[i] and sh[i + d] and the only writer of sh[i].
+constexpr unsigned kCoopTreeMax = 64;
+template <class F>
+__device__ __forceinline__ void tree_step_coop(XYZZ29<F>* sh, unsigned base, unsigned d) {
+  const unsigned row16 = (threadIdx.x >> 4) & 15u;      // row inside this 256-lane half
+#pragma unroll 1
+  for (unsigned i = row16; i < d; i += 16) {
+    const XYZZ29<F> v = add_wave29(sh[base + i], sh[base + i + d]);
+    if ((threadIdx.x & 15u) == 0) sh[base + i] = v;
+  }
+}
+
 template <class F>
 __global__ void __launch_bounds__(256) msm_row_kernel(MsmGeom g, RowGeom rg, const XYZZ29<F>* __restrict__ buckets,
                                                        XYZZ29<F>* __restrict__ row_w, XYZZ29<F>* __restrict__ row_r) {
@@ -142,6 +162,12 @@ __global__ void __launch_bounds__(256) msm_row_kernel(MsmGeom g, RowGeom rg, con
     const unsigned d = scan ? 1u << step : row >> (step - rg.row_log + 1);
     const bool on = scan ? c + d < row : c < d;
     if (step == rg.row_log && c == 0) row_r[rid] = sh[0];
+    if (!scan && d <= kCoopTreeMax) {          // a NARROW tree step: the additions wave-cooperatively (tree_step_coop)
+      __syncthreads();                         // (row_r's read of sh[0] above, the previous step's writes)
+      tree_step_coop<F>(sh, 0u, d);
+      __syncthreads();
+      continue;
+    }
     XYZZ29<F> v;
     if (on) XYZZ29<F>::add_mem(&v, &sh[c], &sh[(c + d) & 255]);
     __syncthreads();
@@ -304,6 +330,11 @@ __global__ void __launch_bounds__(256 * HALVES) msm_top_kernel(TopGeom tg, const
         b = fb + 2 * 256 + (on ? t : 0);
       } else {
         const unsigned stride = 128u >> (step - s_tree);
+        if (stride <= kCoopTreeMax) {          // narrow: wave-cooperative additions on rows of 16 lanes, both halves at once
+          tree_step_coop<F>(sh, (threadIdx.x >> 8) << 8, stride);
+          __syncthreads();
+          continue;
+        }
         on = t < stride;
         b = me + (on ? stride : 0);
       }

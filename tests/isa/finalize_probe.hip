@@ -1,5 +1,5 @@
-// msm_finalize_lds_kernel of a 14-limb G2 alone (the throughput finalize whose addition is xyzz_add_into_steps: a step
-// loop over three product sites with its temporaries in accumulation registers) -- seconds of hipcc, so that
+// msm_finalize_lds_kernel of a 14-limb G2 alone (the throughput finalize: two lanes per bucket, XYZZ29::add_into on LDS
+// columns) -- under a minute of hipcc instead of the minutes msm_group.hip takes for a G2, so that
 // tests/test_kernel_emulation.py runs the shipped kernel body on the Workgroup emulator in the default suite.
 #include "msm_impl.h"
 namespace dg16 {

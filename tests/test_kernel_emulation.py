@@ -44,7 +44,7 @@ def source_key():
 
 
 STEPS_PROBE = "tests/isa/steps_probe.hip"            # msm_accumulate_steps_kernel alone (seconds of hipcc)
-FINALIZE_PROBE = "tests/isa/finalize_probe.hip"      # msm_finalize_lds_kernel of a 14-limb G2 alone
+FINALIZE_PROBE = "tests/isa/finalize_probe.hip"      # msm_finalize_lds_kernel of a 14-limb G2 alone (seconds of hipcc)
 CASES = [
     ("bn254", 2, "msm_accumulate_lds_kernel"),        # LDS-staged accumulator, four-product Y3, next point fetched ahead
     ("bn254", 1, "msm_accumulate_kernel"),            # fused Y3, one-compare zero test; the bucket tree degenerates (one lane)
@@ -278,8 +278,8 @@ def test_g1_accumulation_workgroup_with_the_bucket_tree():
 
 @pytest.mark.parametrize("curve", ["bn254", "bls12_381"])
 def test_g2_finalize_workgroup(curve):
-    """(bls12_381: the 14-limb kernel, BLOCK = 128, whose addition is the step loop xyzz_add_into_steps with its
-    temporaries in accumulation registers.)  msm_finalize_lds_kernel<Fp2<bn254>, 256> with two lanes per bucket (the throughput finalize behind the G2
+    """(bls12_381: the 14-limb kernel, BLOCK = 128, compiled alone from tests/isa/finalize_probe.hip.)
+    msm_finalize_lds_kernel<Fp2<bn254>, 256> with two lanes per bucket (the throughput finalize behind the G2
     accumulation: each lane adds its share of the bucket's partial sums into an accumulator in LDS columns --
     XYZZ29::add_into with the four-product Y3, ONE addition site for the serial partials and the tree partners --, then
     one tree step across the two lanes behind a barrier) on the Workgroup emulator:

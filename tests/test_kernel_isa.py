@@ -112,7 +112,7 @@ def test_14_limb_g2_accumulation_is_a_step_loop_over_three_product_sites(curve):
     first = min(b["addr"] for b in blks)
     assert cold["addr"] - first <= 62 * 1024, "the step loop no longer fits the instruction cache: %d bytes" % (cold["addr"] - first)
     allins = isa_report.instructions(os.path.join(CSRC, "msm_%s_g2.o" % curve))
-    for needle in ("msm_accumulate_steps_kernel", "msm_finalize_lds_kernel"):
+    for needle in ("msm_accumulate_steps_kernel",):
         ins = [v for k, v in allins.items() if needle in k]
         assert len(ins) == 1, needle
         file_regs, other = set(), set()
@@ -130,7 +130,3 @@ def test_14_limb_g2_accumulation_is_a_step_loop_over_three_product_sites(curve):
         assert file_regs == set(range(144, 144 + 4 * 2 * n)), (needle, sorted(file_regs)[:4])
         assert all(r < 144 for r in other), "%s: hipcc allocated an AGPR inside the temporaries' file: %s" % (
             needle, sorted(other)[-4:])
-    # the finalize (two lanes per bucket summing the bucket's partials: a FULL addition per step) is the same step loop
-    fin = kernel("msm_%s_g2.o" % curve, "msm_finalize_lds_kernel")
-    assert len(block_with(fin, 6 * n * n)) == 1 and len(block_with(fin, 4 * n * n)) == 1
-    assert sum(b["scratch"] for b in fin) == 0
