@@ -1250,21 +1250,36 @@ __device__ __forceinline__ Fe<P, B, 1> lane_get29(const Fe<P, B, 1>& v, int src)
 // three lanes of the quad (Karatsuba), joined with ds_bpermute
 template <class P, int B>
 __device__ __forceinline__ Fe<P, B, 1> slot_mul29(const Fe<P, B, 1>& a, const Fe<P, B, 1>& b) { return fit<B>(a * b); }
-template <class P, int B>
-__device__ __forceinline__ Fe2<P, B, 1> slot_mul29(const Fe2<P, B, 1>& a, const Fe2<P, B, 1>& b) {
+// (BM: the base-field product of the three lanes -- inline, or behind a call: SlotMulCall in prover_impl.h)
+template <class BM, class P, int B>
+__device__ __forceinline__ Fe2<P, B, 1> slot_mul29_fe2(const Fe2<P, B, 1>& a, const Fe2<P, B, 1>& b) {
   constexpr int BETA = Fq2Beta<P>::value;
   const unsigned q = __lane_id() & 3;
   const Fe<P, B, 1> sa = fit<B>(a.c0 + a.c1), sb = fit<B>(b.c0 + b.c1);
   const Fe<P, B, 1> x = select(q == 0, a.c0, select(q == 1, a.c1, sa));
   const Fe<P, B, 1> y = select(q == 0, b.c0, select(q == 1, b.c1, sb));
-  const Fe<P, B, 1> t = fit<B>(x * y);
+  const Fe<P, B, 1> t = BM::mul(x, y);
   const int base = (int)(__lane_id() & ~3u);
   const Fe<P, B, 1> t0 = lane_get29(t, base), t1 = lane_get29(t, base + 1), t2 = lane_get29(t, base + 2);
   if constexpr (BETA == 1) return {fit<B>(t0 - t1), fit<B>(t2 - (t0 + t1))};          // u^2 = -BETA (fp2.h)
   else return {fit<B>(t0 - mul_small<BETA>(t1)), fit<B>(t2 - (t0 + t1))};
 }
+// M: how a level's product is issued -- inline (the chains that loop: Horner tail, scalar multiples, tree steps) or behind
+// a call (prover_impl.h: SlotMulCall -- chains that run ONCE per proof, whose cost is the fetch of cold code)
+struct SlotMulInline {
+  template <class P, int B>
+  static __device__ __forceinline__ Fe<P, B, 1> mul(const Fe<P, B, 1>& a, const Fe<P, B, 1>& b) { return fit<B>(a * b); }
+  template <class P, int B>
+  static __device__ __forceinline__ Fe2<P, B, 1> mul(const Fe2<P, B, 1>& a, const Fe2<P, B, 1>& b) {
+    return slot_mul29_fe2<SlotMulInline>(a, b);
+  }
+};
+template <class P, int B>
+__device__ __forceinline__ Fe2<P, B, 1> slot_mul29(const Fe2<P, B, 1>& a, const Fe2<P, B, 1>& b) {
+  return slot_mul29_fe2<SlotMulInline>(a, b);
+}
 // 2 p, p (and the result) uniform across the wave                       (dbl-2008-s-1, a = 0)
-template <class F>
+template <class F, class M = SlotMulInline>
 __device__ __forceinline__ XYZZ29<F> dbl_wave29(const XYZZ29<F>& p) {
   constexpr int BS = XYZZ29<F>::BS;
   if (p.is_inf()) return p;
@@ -1272,24 +1287,24 @@ __device__ __forceinline__ XYZZ29<F> dbl_wave29(const XYZZ29<F>& p) {
   const auto u = fit<BS>(dbl(p.y));
   // level 1: v = u^2 | xx = x^2
   const auto a1 = select(slot == 0, u, p.x);
-  const auto r1 = slot_mul29(a1, a1);
+  const auto r1 = M::mul(a1, a1);
   const auto v = bcast29<0>(r1), xx = bcast29<4>(r1);
   const auto m = fit<BS>(dbl(xx) + xx);
   // level 2: w = u v | s = x v | m^2 | zz' = v zz
   const auto a2 = select(slot == 0, u, select(slot == 1, p.x, select(slot == 2, m, v)));
   const auto b2 = select(slot <= 1, v, select(slot == 2, m, p.zz));
-  const auto r2 = slot_mul29(a2, b2);
+  const auto r2 = M::mul(a2, b2);
   const auto w = bcast29<0>(r2), sv = bcast29<4>(r2), mm = bcast29<8>(r2), zz3 = bcast29<12>(r2);
   const auto x3 = fit<BS>(mm - dbl(sv));
   // level 3: m (s - x3) | w y | zzz' = w zzz
   const auto a3 = select(slot == 0, m, w);
   const auto b3 = select(slot == 0, fit<BS>(sv - x3), select(slot == 1, p.y, p.zzz));
-  const auto r3 = slot_mul29(a3, b3);
+  const auto r3 = M::mul(a3, b3);
   const auto y3 = fit<BS>(bcast29<0>(r3) - bcast29<4>(r3));
   return {x3, y3, zz3, bcast29<8>(r3)};
 }
 // p + o, both (and the result) uniform across the wave: 14 products in 4 levels       (add-2008-s)
-template <class F>
+template <class F, class M = SlotMulInline>
 __device__ __forceinline__ XYZZ29<F> add_wave29(const XYZZ29<F>& p, const XYZZ29<F>& o) {
   constexpr int BS = XYZZ29<F>::BS;
   if (o.is_inf()) return p;
@@ -1298,27 +1313,27 @@ __device__ __forceinline__ XYZZ29<F> add_wave29(const XYZZ29<F>& p, const XYZZ29
   // level 1: u1 = x1 zz2 | u2 = x2 zz1 | s1 = y1 zzz2 | s2 = y2 zzz1
   const auto a1 = select(slot == 0, p.x, select(slot == 1, o.x, select(slot == 2, p.y, o.y)));
   const auto b1 = select(slot == 0, o.zz, select(slot == 1, p.zz, select(slot == 2, o.zzz, p.zzz)));
-  const auto r1 = slot_mul29(a1, b1);
+  const auto r1 = M::mul(a1, b1);
   const auto u1 = bcast29<0>(r1), u2 = bcast29<4>(r1), s1 = bcast29<8>(r1), s2 = bcast29<12>(r1);
   const auto pd = fit<BS>(u2 - u1), rd = fit<BS>(s2 - s1);
   if (is_zero(pd)) {
-    if (is_zero(rd)) return dbl_wave29(p);
+    if (is_zero(rd)) return dbl_wave29<F, M>(p);
     return XYZZ29<F>::inf();
   }
   // level 2: pp = p^2 | rr = r^2 | zz1 zz2 | zzz1 zzz2
   const auto a2 = select(slot == 0, pd, select(slot == 1, rd, select(slot == 2, p.zz, p.zzz)));
   const auto b2 = select(slot == 0, pd, select(slot == 1, rd, select(slot == 2, o.zz, o.zzz)));
-  const auto r2 = slot_mul29(a2, b2);
+  const auto r2 = M::mul(a2, b2);
   const auto pp = bcast29<0>(r2), rr = bcast29<4>(r2), zzp = bcast29<8>(r2), zzzp = bcast29<12>(r2);
   // level 3: ppp = p pp | q = u1 pp | zz3 = (zz1 zz2) pp
   const auto a3 = select(slot == 0, pd, select(slot == 1, u1, zzp));
-  const auto r3 = slot_mul29(a3, pp);
+  const auto r3 = M::mul(a3, pp);
   const auto ppp = bcast29<0>(r3), q = bcast29<4>(r3), zz3 = bcast29<8>(r3);
   const auto x3 = fit<BS>(rr - (ppp + dbl(q)));
   // level 4: r (q - x3) | s1 ppp | zzz3 = (zzz1 zzz2) ppp
   const auto a4 = select(slot == 0, rd, select(slot == 1, s1, zzzp));
   const auto b4 = select(slot == 0, fit<BS>(q - x3), ppp);
-  const auto r4 = slot_mul29(a4, b4);
+  const auto r4 = M::mul(a4, b4);
   return {x3, fit<BS>(bcast29<0>(r4) - bcast29<4>(r4)), zz3, bcast29<8>(r4)};
 }
 // k p by double-and-add on one wave; k = NW little-endian 32-bit words (plain integer), uniform

@@ -90,42 +90,160 @@ __global__ void __launch_bounds__(64) prover_stage1_g2_kernel(Jacobian<Fq2>* msm
   if (threadIdx.x == 0) *msm_b2 = b.to_jacobian();
 }
 
+// ---- the assembly's chains: wave-cooperative operations on the reduced-radix types, products behind a call ----------
+// The assembly runs ONCE per proof on a few waves: what it costs is dependent issue plus the fetch of cold code, so every
+// level's product goes through one out-of-line copy per field (msm_impl.h: add_wave29<F, SlotMulCall>) and the kernel
+// stays a few KB.
+// (operands as 16-lane vectors: hipcc passes aggregates beyond 16 dwords per call through scratch, vectors in VGPRs)
+typedef uint32_t limbs16_t __attribute__((ext_vector_type(16)));
+template <class P, int B>
+__device__ __attribute__((noinline)) limbs16_t fe_mul_call(limbs16_t a, limbs16_t b) {
+  static_assert(RR<P>::N <= 16, "limbs per element");
+  Fe<P, B, 1> x, y;
+#pragma unroll
+  for (int i = 0; i < RR<P>::N; i++) { x.l[i] = a[i]; y.l[i] = b[i]; }
+  const Fe<P, B, 1> r = fit<B>(x * y);
+  limbs16_t o = a;
+#pragma unroll
+  for (int i = 0; i < RR<P>::N; i++) o[i] = r.l[i];
+  return o;
+}
+struct SlotMulCall {
+  template <class P, int B>
+  static __device__ __forceinline__ Fe<P, B, 1> mul(const Fe<P, B, 1>& a, const Fe<P, B, 1>& b) {
+    limbs16_t x = {}, y = {};
+#pragma unroll
+    for (int i = 0; i < RR<P>::N; i++) { x[i] = a.l[i]; y[i] = b.l[i]; }
+    const limbs16_t o = fe_mul_call<P, B>(x, y);
+    Fe<P, B, 1> r;
+#pragma unroll
+    for (int i = 0; i < RR<P>::N; i++) r.l[i] = o[i];
+    return r;
+  }
+  template <class P, int B>
+  static __device__ __forceinline__ Fe2<P, B, 1> mul(const Fe2<P, B, 1>& a, const Fe2<P, B, 1>& b) {
+    return slot_mul29_fe2<SlotMulCall>(a, b);
+  }
+};
+// the words of an arkworks-form element re-sliced into the internal limbs (NO form change: still x R32), a constant in
+// the storage type, and canonical words back
+template <class P>
+__device__ __forceinline__ typename FieldOf<Fp<P>>::Store raw29(const Fp<P>& a) {
+  return fe_from_words<P>(a.l).template as<FieldOf<Fp<P>>::BS, 1>();
+}
+template <class P>
+__device__ __forceinline__ typename FieldOf<Fp2<Fp<P>>>::Store raw29(const Fp2<Fp<P>>& a) {
+  constexpr int BS = FieldOf<Fp2<Fp<P>>>::BS;
+  return {fe_from_words<P>(a.c0.l).template as<BS, 1>(), fe_from_words<P>(a.c1.l).template as<BS, 1>()};
+}
+template <class P, class L>
+__device__ __forceinline__ typename FieldOf<Fp<P>>::Store konst29(const Fp<P>*, const L& c) {
+  return fe_const<P>(c).template as<FieldOf<Fp<P>>::BS, 1>();
+}
+template <class P, class L>
+__device__ __forceinline__ typename FieldOf<Fp2<Fp<P>>>::Store konst29(const Fp2<Fp<P>>*, const L& c) {
+  constexpr int BS = FieldOf<Fp2<Fp<P>>>::BS;
+  return {fe_const<P>(c).template as<BS, 1>(), Fe<P, BS, 1>::zero()};
+}
+template <class P, int B>
+__device__ __forceinline__ Fp<P> words32(const Fe<P, B, 1>& v) {
+  Fp<P> r;
+  fe_to_words<P>(canon(v), r.l);
+  return r;
+}
+template <class P, int B>
+__device__ __forceinline__ Fp2<Fp<P>> words32(const Fe2<P, B, 1>& v) { return {words32(v.c0), words32(v.c1)}; }
+// a record's point (Jacobian, arkworks form; uniform across the wave) -> XYZZ29: the three form changes x R32 -> x R are
+// ONE level of products (slots 0..2), zz = z^2 and zzz = z zz two more (ec.h: XYZZ::from_jacobian, ec29.h: from_xyzz32
+// do the same on one lane: 4 + 2 dependent products for G1, three times that for G2)
+template <class F>
+__device__ __forceinline__ XYZZ29<F> record_to_xyzz29_wave(const Jacobian<F>& j) {
+  using P = typename FieldOf<F>::Params;
+  if (j.z.is_zero()) return XYZZ29<F>::inf();
+  const unsigned slot = (__lane_id() & 15) >> 2;
+  const auto w = select(slot == 0, raw29(j.x), select(slot == 1, raw29(j.y), raw29(j.z)));
+  const auto r1 = SlotMulCall::mul(w, konst29((const F*)nullptr, RR<P>::FROM32));
+  const auto z = bcast29<8>(r1);
+  const auto zz = SlotMulCall::mul(z, z);
+  return {bcast29<0>(r1), bcast29<4>(r1), zz, SlotMulCall::mul(z, zz)};
+}
+// ... and back: X = x zz | Y = y zzz | Z = zz (ec.h: XYZZ::to_jacobian), then x R -> x R32, canonical words
+template <class F>
+__device__ __forceinline__ Jacobian<F> xyzz29_to_record_wave(const XYZZ29<F>& a) {
+  using FO = FieldOf<F>;
+  using P = typename FO::Params;
+  if (a.is_inf()) return {F::one(), F::one(), F::zero()};
+  const unsigned slot = (__lane_id() & 15) >> 2;
+  const auto a1 = select(slot == 0, a.x, select(slot == 1, a.y, a.zz));
+  const auto b1 = select(slot == 0, a.zz, select(slot == 1, a.zzz, FO::one()));
+  const auto r1 = SlotMulCall::mul(a1, b1);
+  const auto r2 = SlotMulCall::mul(r1, konst29((const F*)nullptr, RR<P>::TO32));
+  return {words32(bcast29<0>(r2)), words32(bcast29<4>(r2)), words32(bcast29<8>(r2))};
+}
+
 // after the gather: per-slot sums over the shards, C = L + H + s*A + r*B1 (-rs*delta is inside L).
-// This kernel is the exposed tail of every proof, so each sum is a chain on its own WAVE with wave-cooperative
-// additions (msm_impl.h: add_wave, ~2.5 us per addition against ~15 us on a lone lane): waves 0 / 1 sum A / B,
-// waves 2..5 sum L, H, s*A, r*B1 into LDS and wave 2 adds those four -- n_shards + 3 dependent additions instead of
-// 4 n_shards (0.5 ms at 8 shards before).
+// This kernel is the exposed tail of every proof (and, on N GPUs, of the all-gather), so each sum is a chain on its own
+// WAVE: chain 0 sums A, chains 1 and 6 the two halves of B, chains 2..5 L, H, s*A, r*B1 into LDS, and behind the ONE barrier
+// chain 1 adds B's other half, chain 2 the three other partials of C -- ceil(n_shards / 2) + 1 dependent G2 additions and
+// n_shards + 3 G1 additions.  Two workgroups of four waves (block 0: chains 2..5 = C; block 1: A and B's halves), so that
+// a wave has a SIMD's whole register file: seven waves in one workgroup left 256 registers each and the 14-limb curves
+// spilled 536 B per lane into scratch.  Round 5: the chains run on the reduced-radix wave-cooperative operations (seven
+// product levels per record: three to load it, four to add it; ~0.6 us a level for G1, ~1 us for G2) instead of the
+// 32-bit-limb ones (~2.5 us per G1 addition, ~20 us per G2 addition: B's chain alone was 0.18 ms at 8 shards); emulated
+// against the oracle in tests/test_kernel_emulation.py::test_proof_assembly_workgroup.
 template <class Fq, class Fq2>
-__global__ void __launch_bounds__(384) prover_assemble_kernel(const uint8_t* gathered, size_t n_shards, size_t rec_bytes,
-                                                               Jacobian<Fq>* out_a, Jacobian<Fq2>* out_b,
-                                                               Jacobian<Fq>* out_c) {
-  __shared__ Jacobian<Fq> part[4];
+__global__ void __launch_bounds__(256, 1) prover_assemble_kernel(const uint8_t* gathered, size_t n_shards, size_t rec_bytes,
+                                                                  Jacobian<Fq>* out_a, Jacobian<Fq2>* out_b,
+                                                                  Jacobian<Fq>* out_c) {
+  __shared__ XYZZ29<Fq> part[4];
+  __shared__ XYZZ29<Fq2> part_b;
   __builtin_amdgcn_s_setprio(3);     // exposed tail: ahead of whatever else is resident on the SIMD
-  const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  if (wave == 1) {
-    XYZZ<Fq2> b = XYZZ<Fq2>::inf();
+  const unsigned w4 = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const unsigned wave = blockIdx.x == 0 ? 2 + w4 : w4 == 2 ? 6u : w4;      // the chain this wave runs
+  if (blockIdx.x == 1 && w4 == 3) return;                                 // (block 1 has three chains)
+  if (wave == 1 || wave == 6) {
+    const size_t half = (n_shards + 1) / 2;
+    const size_t lo = wave == 1 ? 0 : half, cnt = wave == 1 ? half : n_shards - half;
+    const size_t steps = cnt + (wave == 1 ? 1 : 0);
+    XYZZ29<Fq2> b = XYZZ29<Fq2>::inf();
 #pragma unroll 1
-    for (size_t k = 0; k < n_shards; k++)
-      b = add_wave(b, XYZZ<Fq2>::from_jacobian(*(const Jacobian<Fq2>*)(gathered + k * rec_bytes + kRecG1 * sizeof(Jacobian<Fq>))));
-    if (lane == 0) *out_b = b.to_jacobian();
-    __syncthreads();
+    for (size_t k = 0; k < steps; k++) {
+      if (k == cnt) __syncthreads();               // (wave 1 only: wave 6 is at the barrier below)
+      XYZZ29<Fq2> o;
+      if (k < cnt)
+        o = record_to_xyzz29_wave(*(const Jacobian<Fq2>*)(gathered + (lo + k) * rec_bytes + kRecG1 * sizeof(Jacobian<Fq>)));
+      else
+        o = part_b;
+      b = add_wave29<Fq2, SlotMulCall>(b, o);
+    }
+    if (wave == 6) {
+      if (lane == 0) part_b = b;
+      __syncthreads();
+      return;
+    }
+    const Jacobian<Fq2> r = xyzz29_to_record_wave(b);
+    if (lane == 0) *out_b = r;
     return;
   }
   // one addition site for every G1 sum: n_shards records, then (wave 2 only, after the barrier) the other partials
   const int slot = wave == 0 ? kRecA : wave == 2 ? kRecL : wave == 3 ? kRecH : wave == 4 ? kRecSA : kRecRB1;
-  XYZZ<Fq> a = XYZZ<Fq>::inf();
+  XYZZ29<Fq> a = XYZZ29<Fq>::inf();
   const size_t steps = n_shards + (wave == 2 ? 3 : 0);
 #pragma unroll 1
   for (size_t k = 0; k < steps; k++) {
     if (k == n_shards) __syncthreads();            // (wave 2 only: the other waves are past their loop, at the barrier below)
-    const Jacobian<Fq>* src = k < n_shards ? (const Jacobian<Fq>*)(gathered + k * rec_bytes) + slot : &part[k - n_shards + 1];
-    a = add_wave(a, XYZZ<Fq>::from_jacobian(*src));
-    if (k + 1 == n_shards && wave >= 3 && lane == 0) part[wave - 2] = a.to_jacobian();
+    XYZZ29<Fq> o;
+    if (k < n_shards)
+      o = record_to_xyzz29_wave(*((const Jacobian<Fq>*)(gathered + k * rec_bytes) + slot));
+    else
+      o = part[k - n_shards + 1];
+    a = add_wave29<Fq, SlotMulCall>(a, o);
+    if (k + 1 == n_shards && wave >= 3 && lane == 0) part[wave - 2] = a;
   }
   if (wave != 2) __syncthreads();
-  if (lane == 0) {
-    if (wave == 0) *out_a = a.to_jacobian();
-    if (wave == 2) *out_c = a.to_jacobian();
+  if (wave == 0 || wave == 2) {
+    const Jacobian<Fq> r = xyzz29_to_record_wave(a);
+    if (lane == 0) *(wave == 0 ? out_a : out_c) = r;
   }
 }
 
@@ -344,7 +462,7 @@ static void assemble_typed(Call& k0, const uint8_t* gathered_dev, size_t n_shard
   using Fq = typename CT::Fq;
   using Fq2 = typename CT::Fq2;
   const size_t g1j = sizeof(Jacobian<Fq>), g2j = sizeof(Jacobian<Fq2>);
-  hipLaunchKernelGGL((prover_assemble_kernel<Fq, Fq2>), dim3(1), dim3(384), 0, stream ? stream : k0.s(), gathered_dev, n_shards,
+  hipLaunchKernelGGL((prover_assemble_kernel<Fq, Fq2>), dim3(2), dim3(256), 0, stream ? stream : k0.s(), gathered_dev, n_shards,
                      msm_results_bytes<CURVE>(), (Jacobian<Fq>*)proof_dev, (Jacobian<Fq2>*)(proof_dev + g1j),
                      (Jacobian<Fq>*)(proof_dev + g1j + g2j));
   DG_HIP(hipGetLastError());

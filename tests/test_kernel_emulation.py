@@ -40,11 +40,13 @@ def source_key():
     h.update(open(os.path.join(ROOT, "include", "dg16.h"), "rb").read())
     h.update(open(os.path.join(ROOT, STEPS_PROBE), "rb").read())
     h.update(open(os.path.join(ROOT, FINALIZE_PROBE), "rb").read())
+    h.update(open(os.path.join(ROOT, ASSEMBLE_PROBE), "rb").read())
     return h.hexdigest()[:16]
 
 
 STEPS_PROBE = "tests/isa/steps_probe.hip"            # msm_accumulate_steps_kernel alone (seconds of hipcc)
 FINALIZE_PROBE = "tests/isa/finalize_probe.hip"      # msm_finalize_lds_kernel of a 14-limb G2 alone (seconds of hipcc)
+ASSEMBLE_PROBE = "tests/isa/assemble_probe.hip"      # prover_assemble_kernel alone (seconds of hipcc)
 CASES = [
     ("bn254", 2, "msm_accumulate_lds_kernel"),        # LDS-staged accumulator, four-product Y3, next point fetched ahead
     ("bn254", 1, "msm_accumulate_kernel"),            # fused Y3, one-compare zero test; the bucket tree degenerates (one lane)
@@ -68,7 +70,8 @@ def assembly(curve, group, source="msm_group.hip"):
     os.makedirs(cache, exist_ok=True)
     path = lambda c, g, f: os.path.join(cache, "%s_%s_g%d.s" % (os.path.basename(f).split(".")[0], c, g))     # noqa: E731
     units = [(c, g, case_source(k)) for c, g, k in CASES] + [("bn254", 1, "msm_reduce.hip"),
-                                                             ("bls12_381", 2, FINALIZE_PROBE)]
+                                                             ("bls12_381", 2, FINALIZE_PROBE),
+                                                             ("bn254", 1, ASSEMBLE_PROBE)]
     if (curve, group, source) not in units:
         units.append((curve, group, source))
     jobs = []
@@ -500,3 +503,98 @@ def test_horner_tail_on_one_wave():
     X, Y, Z = (sum(v << (32 * i) for i, v in enumerate(out[8 * k:8 * k + 8])) * r32_inv % p for k in range(3))
     zi = pow(Z, p - 2, p)
     assert (X * zi * zi % p, Y * zi * zi * zi % p) == expect
+
+
+@pytest.mark.parametrize("curve,n_shards", [("bn254", 1), ("bn254", 3)] +
+                         ([("bn254", 8), ("bls12_381", 2)] if os.environ.get("DG16_EMU_ALL") else []))
+def test_proof_assembly_workgroup(curve, n_shards):
+    """prover_assemble_kernel (prover_impl.h; compiled alone from tests/isa/assemble_probe.hip) on the Workgroup emulator:
+    seven waves in two workgroups sum the gathered records of n_shards shards per slot -- L, H, s A, r B1 | A and the
+    two halves of B (G2) -- on the reduced-radix wave-cooperative operations with the products behind a call, one
+    barrier, then B's other half and C = L + H + s A + r B1.  Records are Jacobian points in arkworks form with Z != 1; one record slot holds the
+    identity, one pair of slots the same point (the addition's doubling branch).  (A, B, C) == the oracle's sums."""
+    import random
+    from oracle.pyref.curves import CURVES
+    G1, G2 = CURVES[curve, "g1"], CURVES[curve, "g2"]
+    F2 = G2.F
+    p = G1.F.p
+    nw = (p.bit_length() + 31) // 32
+    R32 = 1 << (32 * nw)
+    g1j, g2j = 3 * nw * 4, 6 * nw * 4
+    rec_bytes = 6 * g1j + g2j
+    text = assembly(curve, 1, ASSEMBLE_PROBE)
+    GATH, OUTA, OUTB, OUTC, KARG = (0x100000 * k for k in range(1, 6))
+    mem = {}
+    rng = random.Random(5 + n_shards)
+
+    def words(v):
+        v = v * R32 % p
+        return [(v >> (32 * i)) & 0xFFFFFFFF for i in range(nw)]
+
+    def put_g1(addr, P):
+        if P is None:
+            ws = words(1) + words(1) + [0] * nw
+        else:
+            z = rng.randrange(1, p)
+            ws = words(P[0] * z * z % p) + words(P[1] * z * z * z % p) + words(z)
+        for i, v in enumerate(ws):
+            mem[addr + 4 * i] = v
+
+    def put_g2(addr, P):
+        z = (rng.randrange(1, p), rng.randrange(p))
+        zz = F2.sqr(z)
+        co = [F2.mul(P[0], zz), F2.mul(P[1], F2.mul(zz, z)), z]
+        ws = []
+        for c in co:
+            ws += words(c[0]) + words(c[1])
+        for i, v in enumerate(ws):
+            mem[addr + 4 * i] = v
+
+    sums = [None] * 7
+    same = G1.mul(G1.gen, 77)
+    for k in range(n_shards):
+        for slot in range(6):
+            P = G1.mul(G1.gen, rng.randrange(1, 10 ** 6))
+            if slot == 3 and k == 0:
+                P = None                                            # H of shard 0: the identity (Z = 0)
+            if slot in (4, 5) and k == 0:
+                P = same                                            # s A == r B1 on shard 0: C's last addition may double
+            put_g1(GATH + k * rec_bytes + slot * g1j, P)
+            sums[slot] = G1.add(sums[slot], P) if P is not None else sums[slot]
+        P2 = G2.mul(G2.gen, rng.randrange(1, 10 ** 6))
+        put_g2(GATH + k * rec_bytes + 6 * g1j, P2)
+        sums[6] = G2.add(sums[6], P2)
+    exp_c = None
+    for slot in (2, 3, 4, 5):
+        exp_c = G1.add(exp_c, sums[slot]) if sums[slot] is not None else exp_c
+    karg = []
+    for v in (GATH, n_shards, rec_bytes, OUTA, OUTB, OUTC):
+        karg += [v & 0xFFFFFFFF, v >> 32]
+    for k, v in enumerate(karg):
+        mem[KARG + 4 * k] = v
+    prog = E.Program(text, "prover_assemble_kernel")
+    for block in (0, 1):                                            # block 0: C's four chains; block 1: A and B's halves
+        wg = E.Workgroup(prog, 256, wg_id=(block, 0), kernarg_addr=KARG)
+        wg.mem.update(mem)
+        wg.run()
+        mem.update({a: v for a, v in wg.mem.items() if OUTA <= a < KARG})
+    r32_inv = pow(R32, p - 2, p)
+
+    def fe(addr, k):
+        out = [mem.get(addr + 4 * (nw * k + i)) for i in range(nw)]
+        assert all(v is not None for v in out), "the proof element was not written"
+        v = sum(x << (32 * i) for i, x in enumerate(out))
+        assert v < p, "not canonical"
+        return v * r32_inv % p
+
+    def g1_out(addr):
+        X, Y, Z = fe(addr, 0), fe(addr, 1), fe(addr, 2)
+        zi = pow(Z, p - 2, p)
+        return (X * zi * zi % p, Y * zi * zi * zi % p)
+
+    assert g1_out(OUTA) == sums[0]
+    assert g1_out(OUTC) == exp_c
+    X, Y, Z = ((fe(OUTB, 2 * k), fe(OUTB, 2 * k + 1)) for k in range(3))
+    zi = F2.inv(Z)
+    zi2 = F2.sqr(zi)
+    assert (F2.mul(X, zi2), F2.mul(Y, F2.mul(zi2, zi))) == sums[6]

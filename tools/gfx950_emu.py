@@ -266,7 +266,7 @@ class Lane:
         op, _, rest = text.partition(" ")
         mods = {}
         for key in ("offset0", "offset1", "offset"):
-            m = re.search(r"\s%s:(\d+)" % key, rest)
+            m = re.search(r"\s%s:(-?\d+)" % key, rest)      # (global / scratch offsets are signed)
             if m:
                 mods[key] = int(m.group(1))
                 rest = rest[:m.start()] + rest[m.end():]
@@ -353,6 +353,12 @@ class Lane:
         elif op == "s_mulk_i32":
             v = int(a[1], 0) & 0xFFFF
             self.wr(a[0], s32(self.rd(a[0])) * (v - 0x10000 if v & 0x8000 else v))
+        elif op == "s_addk_i32":
+            v = int(a[1], 0) & 0xFFFF
+            v = v - 0x10000 if v & 0x8000 else v
+            r = s32(self.rd(a[0])) + v
+            self.scc = int(not (-2**31 <= r < 2**31))
+            self.wr(a[0], r & M32)
         elif op == "s_brev_b32":
             self.wr(a[0], int("{:032b}".format(self.rd(a[1]) & M32)[::-1], 2))
         elif op in ("s_add_u32", "s_add_i32"):
