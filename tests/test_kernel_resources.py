@@ -52,6 +52,14 @@ def test_g2_bucket_accumulation_stages_through_lds_without_spilling():
         assert r["scratch"] <= 192 and r["agprs"] <= 128, k
 
 
+def test_proof_assembly_keeps_its_chains_in_registers():
+    """prover_assemble_kernel (the exposed tail of every proof: seven chains of wave-cooperative additions in two
+    workgroups of four waves): no scratch beyond the call frame of its one out-of-line product per field -- as ONE
+    workgroup of seven waves the 14-limb curves had 256 registers per wave and spilled 536 B per lane."""
+    for k, r in find("prover_assemble_kernel<").items():
+        assert r["scratch"] <= 16 and r["lds"] <= 2048, k
+
+
 def test_ntt_and_sort_kernels_are_register_and_lds_only():
     for k, r in find("ntt_step_kernel<").items():
         # 1024 tile elements of 9 limbs + 512 staged twiddles of 8 packed words: three workgroups per CU
