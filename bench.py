@@ -56,6 +56,34 @@ HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md
 MAD_ISSUE_T = 34.4                 # T lane-op/s of v_mad_u64_u32, chip-wide (profiles/r1_ubench_instr_rate.txt)
 
 
+def calibrate(device):
+    """In-run calibration (distributed-groth16_amd/libdg16_calib.so, csrc/calib.hip): the chip-wide issue rate of
+    v_mad_u64_u32 at 8 and at 2 waves per SIMD and the shader clock the chip holds under that load, measured in THIS
+    process right before the timed loop (< 0.2 s).  `peak` of the valu rooflines is the 8-wave figure of this run;
+    box_factor = that / MAD_ISSUE_T (the round-1 constant), so two boxes of the pool that differ in ms_per_step can be
+    told apart from two builds that differ.  Returns None if the library is not built (older trees)."""
+    import ctypes
+    path = os.path.join(ROOT, "distributed-groth16_amd", "libdg16_calib.so")
+    if not os.path.exists(path):
+        return None
+    lib = ctypes.CDLL(path)
+    lib.dg16_calib_mad_rate.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]
+    out = {}
+    t0 = time.perf_counter()
+    for wps in (8, 2):
+        buf = (ctypes.c_double * 4)()
+        rc = lib.dg16_calib_mad_rate(device, wps, 4096, buf)
+        if rc != 0:
+            return None
+        out[wps] = (buf[0], buf[1], buf[2])
+    return {"mad_issue_T_lane_ops_per_s": out[8][0], "mad_issue_T_at_2_waves_per_simd": out[2][0],
+            "sclk_under_mad_load_mhz": out[8][1], "sclk_under_mad_load_mhz_at_2_waves_per_simd": out[2][1],
+            "kernel_ms": out[8][2], "box_factor": out[8][0] / MAD_ISSUE_T, "reference_T": MAD_ISSUE_T,
+            "seconds": time.perf_counter() - t0,
+            "source": "in-run: csrc/calib.hip (16 independent v_mad_u64_u32 x 4096 rounds per lane, 8 waves per SIMD on "
+                      "every CU, best of three after a warm-up; clock = s_memtime / s_memrealtime x 100 MHz over the kernel)"}
+
+
 def valu_constants(curve):
     """(v_mad_u64_u32 per base-field product, measured chip-wide G products/s) of the reduced-radix product
     (csrc/fp29.h), from the committed micro-benchmark output -- measured constants live under profiles/, not in the
@@ -874,6 +902,12 @@ def main():
     for _ in range(args.warmup):
         step()
     full_sync()
+    # the roof of THIS box in THIS run (every rank measures its own GPU; rank 0's figures go on the line)
+    calib = calibrate(local_rank)
+    mad_peak = calib["mad_issue_T_lane_ops_per_s"] if calib else MAD_ISSUE_T
+    for _ in range(1 if calib else 0):     # (one more untimed step: the calibration kernel evicted the proof's working set)
+        step()
+    full_sync()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -949,7 +983,9 @@ def main():
 
     # The peak is an instruction issue rate: a fraction above 1 can only mean a wrong count or a wrong clock.  The line is
     # still printed (a timed run must not vanish in an accounting check), with the fact on it.
-    valu_over = valu_t > MAD_ISSUE_T * 1.0001 or whole_t > MAD_ISSUE_T
+    valu_over = valu_t > mad_peak * 1.0001 or whole_t > mad_peak
+    peak_src = ("in-run calibration (calibration.mad_issue_T_lane_ops_per_s of this line)" if calib else
+                "profiles/r1_ubench_instr_rate.txt (libdg16_calib.so not built)")
     rccl_ranks = prover.rccl_ranks() if hasattr(prover, "rccl_ranks") and world > 1 else None
     if rccl_ranks is not None and rccl_ranks != world:
         raise SystemExit("the RCCL communicator reports %s ranks, the job has %d" % (rccl_ranks, world))
@@ -987,13 +1023,15 @@ def main():
                      "note": "%d B/point algorithmic (each point and scalar once); Pippenger gathers every point once "
                              "per window, which is what the PMC traffic shows -- the kernel is integer-VALU-bound "
                              "(see valu_roofline)" % int(g2_alg)},
-        "valu_roofline": {"unit": "T v_mad_u64_u32 lane-op/s", "achieved": valu_t, "peak": MAD_ISSUE_T,
-                          "frac": valu_t / MAD_ISSUE_T, "peak_source": "profiles/r1_ubench_instr_rate.txt",
+        "calibration": calib,
+        "valu_roofline": {"unit": "T v_mad_u64_u32 lane-op/s", "achieved": valu_t, "peak": mad_peak,
+                          "frac": valu_t / mad_peak, "peak_source": peak_src,
+                          "frac_vs_round1_constant": valu_t / MAD_ISSUE_T,
                           "mads_per_g1_add": g1_add_mads, "mads_per_g2_add": g2_add_mads, "mads_per_product": mul_cost,
                           "product_equivalents_G_per_s": valu_t * 1e3 / mul_cost,
                           "measured_product_rate_G_per_s": mul_rate_g, "measured_product_rate_source": mul_src,
                           "whole_proof_mads": prods, "whole_proof_achieved": whole_t,
-                          "whole_proof_valu_frac": whole_t / MAD_ISSUE_T,
+                          "whole_proof_valu_frac": whole_t / mad_peak,
                           "exceeds_peak": valu_over,
                           "note": "%d v_mad_u64_u32 per G2 mixed add x %d points x %d windows / kernel time against the "
                                   "chip-wide issue rate of that instruction (%.1f T lane-op/s: the bound no rewrite of the "
@@ -1001,7 +1039,7 @@ def main():
                                   "tools/ubench/fe_rate (a dependent chain of the library's own product per lane). "
                                   "whole_proof_* = every v_mad_u64_u32 a proof must issue (per GPU) / ms_per_step: the "
                                   "headroom of the whole pipeline, not of one kernel"
-                                  % (g2_add_mads, n_g2, nwin, MAD_ISSUE_T, mul_cost)},
+                                  % (g2_add_mads, n_g2, nwin, mad_peak, mul_cost)},
         "g1_accumulate_ms": g1_acc_ms,
         # the G1 accumulation: four launches per proof (A, B1, L, H), more TOTAL time than the G2 launch and further from
         # the issue roof -- on the line next to the G2 figures since round 5
@@ -1014,8 +1052,8 @@ def main():
                         "note": "%d B/point algorithmic (point + scalar once)" % int(g1_alg)},
         "valu_roofline_g1": {"unit": "T v_mad_u64_u32 lane-op/s",
                              "achieved": (float(g1_add_mads) * n_g2 * nwin / (g1_acc_ms * 1e-3) / 1e12) if g1_acc_ms else 0.0,
-                             "peak": MAD_ISSUE_T,
-                             "frac": (float(g1_add_mads) * n_g2 * nwin / (g1_acc_ms * 1e-3) / 1e12 / MAD_ISSUE_T) if g1_acc_ms else 0.0,
+                             "peak": mad_peak, "peak_source": peak_src,
+                             "frac": (float(g1_add_mads) * n_g2 * nwin / (g1_acc_ms * 1e-3) / 1e12 / mad_peak) if g1_acc_ms else 0.0,
                              "mads_per_g1_add": g1_add_mads,
                              "valu_slots_per_g1_add": {"bn254": 2089}.get(curve),
                              "note": "every integer VALU instruction of the loop (mads, column shifts / masks, m[k] products) "

@@ -1,8 +1,10 @@
 // C ABI of libdg16 (include/dg16.h): argument checking, host<->device staging, error mapping.
 // All compute is in the HIP translation units next to this file; there is no CPU path.
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
+#include "bounds.h"
 #include "ctx.h"
 
 using namespace dg16;
@@ -10,6 +12,18 @@ using namespace dg16;
 namespace dg16 {
 size_t fq_bytes(int curve) { return curve == DG16_BN254 ? 32 : 48; }
 size_t affine_bytes(int curve, int group) { return 2 * fq_bytes(curve) * (group == 2 ? 2 : 1); }
+#ifdef DG16_BOUNDS
+// the violation record of the bounds-checked build (bounds.h): one zeroed device buffer per process
+unsigned* bounds_sink_device() {
+  static unsigned* sink = [] {
+    unsigned* p = nullptr;
+    if (hipMalloc((void**)&p, kBoundsWords * sizeof(unsigned)) != hipSuccess) return (unsigned*)nullptr;
+    (void)hipMemset(p, 0, kBoundsWords * sizeof(unsigned));
+    return p;
+  }();
+  return sink;
+}
+#endif
 static void check_curve_group(int curve, int group) {
   DG_REQUIRE(curve >= 0 && curve <= 2, DG16_ERR_BAD_CURVE, "unknown curve id");
   DG_REQUIRE(group == 1 || group == 2, DG16_ERR_BAD_ARG, "group must be 1 (G1) or 2 (G2)");
@@ -123,6 +137,22 @@ int dg16_sync(dg16_ctx* ctx, int channel) {
       throw StatusError{DG16_ERR_BAD_ARG, f & 1 ? "dg16_qap: coefficient out of range (column >= num_vars or bad row_ptr)"
                                                 : "device-side argument check failed"};
     }
+#ifdef DG16_BOUNDS
+    if (unsigned* sink = bounds_sink_device()) {
+      unsigned rec[kBoundsWords] = {};
+      DG_HIP(hipDeviceSynchronize());
+      DG_HIP(hipMemcpy(rec, sink, sizeof rec, hipMemcpyDeviceToHost));
+      if (rec[0]) {
+        DG_HIP(hipMemset(sink, 0, sizeof rec));
+        char msg[256];
+        snprintf(msg, sizeof msg, "DG16_BOUNDS: %u violation(s); first: site %u index %llu limit %llu (workgroup %u, lane %u)", rec[0],
+                 rec[1], (unsigned long long)(rec[2] | ((uint64_t)rec[3] << 32)),
+                 (unsigned long long)(rec[4] | ((uint64_t)rec[5] << 32)), rec[6], rec[7]);
+        fprintf(stderr, "[dg16] %s\n", msg);
+        throw StatusError{DG16_ERR_HIP, msg};
+      }
+    }
+#endif
   });
 }
 

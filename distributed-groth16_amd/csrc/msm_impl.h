@@ -24,11 +24,13 @@
 // buckets XYZZ [W][2^(c-1)].
 #pragma once
 #include <atomic>
+#include <utility>
 #include "glv.h"
 #include <stdio.h>
 
 #include <chrono>
 
+#include "bounds.h"
 #include "ctx.h"
 #include "ec29.h"
 #include "types.h"
@@ -44,6 +46,8 @@ namespace dg16 {
 constexpr unsigned kMinSegLog = 3, kMaxSegLog = 9;
 constexpr unsigned kMinLanesLog = 18;    // want >= 2^18 segments (4 waves per SIMD) in an accumulation launch
 constexpr unsigned kGiantSegs = 64;      // buckets with more segments are reduced by a whole workgroup
+constexpr unsigned kGiantSlices = 64;    // ... in at most this many slices (one workgroup each) of about
+constexpr unsigned kGiantSliceSegs = 512;   // ... this many partials (giant_geometry)
 
 struct MsmGeom {
   unsigned c;        // window bits
@@ -296,7 +300,7 @@ __global__ void __launch_bounds__(256) msm_scatter_kernel(const int* __restrict_
     unsigned rank = wave_atomic_inc(cursor, slot, act);
     if (!act) continue;
     unsigned ref = (unsigned)((size_t)(w / g.bw) * n + i);   // table row w / bw = 2^(c*bw*(w/bw)) * P_i (plain: row 0)
-    entries[(size_t)bwin * g.region + offsets[slot] + rank] = ref | (d < 0 ? 0x80000000u : 0u);
+    entries[DG_IDX(15, (size_t)bwin * g.region + offsets[slot] + rank, (size_t)g.bw * g.region)] = ref | (d < 0 ? 0x80000000u : 0u);
   }
 }
 
@@ -380,7 +384,7 @@ __global__ void __launch_bounds__(256) msm_part_scatter_kernel(const Fr* __restr
       unsigned slot = ((w % g.bw) << g.log_nb) + (unsigned)(d < 0 ? -d : d) - 1;
       unsigned ref = (unsigned)((size_t)(w / g.bw) * n + i);   // table row w / bw (plain mode: bw = W, row 0)
       unsigned pos = atomicAdd(&cur[slot >> pg.low_bits], 1u);
-      part[pos] = make_uint2(ref | (((d < 0) != flip) ? 0x80000000u : 0u), slot);
+      part[DG_IDX(14, pos, (size_t)g.nwin * n)] = make_uint2(ref | (((d < 0) != flip) ? 0x80000000u : 0u), slot);
     }
   }
 }
@@ -513,7 +517,7 @@ __global__ void __launch_bounds__(256) msm_part_place_kernel(const uint2* __rest
       if (e[j].y == 0xFFFFFFFFu) continue;
       const unsigned slot = e[j].y, b = slot & (nlow - 1);
       const unsigned rank = rank0[b] + lr[j];
-      entries[dst0[b] + rank] = e[j].x;
+      entries[DG_IDX(13, dst0[b] + rank, (size_t)g.bw * g.region)] = e[j].x;
     }
     __syncthreads();
   }
@@ -583,7 +587,7 @@ __device__ __forceinline__ SegRange msm_segment(const MsmGeom& g, unsigned w, un
     if (so[mid] <= t) lo = mid; else hi = mid;
   }
   SegRange r;
-  r.bslot = ((size_t)w << g.log_nb) + lo;
+  r.bslot = DG_IDX(1, ((size_t)w << g.log_nb) + lo, (size_t)g.bw << g.log_nb);
   const unsigned c = counts[r.bslot];
   const unsigned k = (c + (1u << g.seg_log) - 1) >> g.seg_log;
   const unsigned j = t - so[lo];
@@ -657,7 +661,7 @@ __device__ __forceinline__ void wg_bucket_tree(uint32_t (*sh)[BLOCK], unsigned s
     __syncthreads();
     if (lane < total) {
       const unsigned a = list[lane];
-      XYZZ29<F>::add_acc(ColAcc<F, BLOCK>{sh, a}, ColAcc<F, BLOCK>{sh, a}, ColAcc<F, BLOCK>{sh, a + d});
+      XYZZ29<F>::add_acc(ColAcc<F, BLOCK>{sh, a}, ColAcc<F, BLOCK>{sh, a}, ColAcc<F, BLOCK>{sh, (unsigned)DG_IDX(16, a + d, BLOCK)});
     }
     __syncthreads();
   }
@@ -728,7 +732,7 @@ msm_accumulate_kernel(MsmBases bases, size_t n,
   XYZZ29<F> acc = XYZZ29<F>::inf();
   if (live) {
     sr = msm_segment(g, w, t, counts, seg_off);
-    const unsigned cnt = sr.cnt;
+    const unsigned cnt = DG_OK(2, (size_t)offsets[sr.bslot] + sr.first + sr.cnt, g.region + 1) ? sr.cnt : 0u;
     const unsigned* e = entries + (size_t)w * g.region + offsets[sr.bslot] + sr.first;
     // Latency hiding: several waves per SIMD cover the dependent (entry -> point) gathers; only the 4-byte entry
     // index is fetched one iteration ahead (a second point in registers costs the whole 128-register budget of four
@@ -736,7 +740,7 @@ msm_accumulate_kernel(MsmBases bases, size_t n,
     unsigned cur = e[0];
     for (unsigned j = 0; j < cnt; j++) {
       unsigned nxt = (j + 1 < cnt) ? e[j + 1] : 0u;
-      const Affine29<F> p = load_internal<F>(base_tab, cur & 0x7fffffffu);
+      const Affine29<F> p = load_internal<F>(base_tab, DG_IDX(3, cur & 0x7fffffffu, g.region));
       acc = acc.madd(p, cur >> 31);
       cur = nxt;
     }
@@ -755,12 +759,12 @@ msm_accumulate_kernel(MsmBases bases, size_t n,
     wg_bucket_tree<F, BLOCK>(sh, list, wcnt, lane, lane - hl, el);
     if (live && lane == hl) {
       const XYZZ29<F> v{me.get(0), me.get(1), me.get(2), me.get(3)};
-      if (sr.j == 0 && lane + sr.k <= (unsigned)BLOCK) buckets[bucket_slot] = v;   // the whole bucket
-      else seg_sum[(size_t)blockIdx.y * g.seg_cap + t] = v;      // one partial per (bucket, workgroup): msm_part_slot
+      if (sr.j == 0 && lane + sr.k <= (unsigned)BLOCK) buckets[DG_IDX(5, bucket_slot, (size_t)gridDim.y << g.log_nb)] = v;   // the whole bucket
+      else seg_sum[(size_t)blockIdx.y * g.seg_cap + DG_IDX(4, t, g.seg_cap)] = v;      // one partial per (bucket, workgroup): msm_part_slot
     }
   } else if (live) {
-    if (sr.k == 1) buckets[bucket_slot] = acc;                     // a one-segment bucket needs no finalize
-    else seg_sum[(size_t)blockIdx.y * g.seg_cap + t] = acc;
+    if (sr.k == 1) buckets[DG_IDX(5, bucket_slot, (size_t)gridDim.y << g.log_nb)] = acc;   // a one-segment bucket needs no finalize
+    else seg_sum[(size_t)blockIdx.y * g.seg_cap + DG_IDX(4, t, g.seg_cap)] = acc;
   }
 }
 
@@ -802,7 +806,7 @@ msm_accumulate_lds_kernel(MsmBases bases, size_t n, MsmGeom g,
   const bool live = t < seg_total[w];
   SegRange sr{};
   if (live) sr = msm_segment(g, w, t, counts, seg_off);
-  const unsigned cnt = live ? sr.cnt : 0u;
+  const unsigned cnt = live && DG_OK(2, (size_t)offsets[sr.bslot] + sr.first + sr.cnt, g.region + 1) ? sr.cnt : 0u;
   const unsigned* e = entries + (size_t)w * g.region + (live ? offsets[sr.bslot] + sr.first : 0u);
   bool inf = true;
   // Gather latency.  This kernel runs two waves per SIMD (LDS-bound) with registers to spare (175 of 256 for BN254), so
@@ -816,12 +820,12 @@ msm_accumulate_lds_kernel(MsmBases bases, size_t n, MsmGeom g,
   unsigned cur = cnt ? e[0] : 0u;
   unsigned nxt = cnt > 1 ? e[1] : 0u;
   RawPoint<F> raw_cur{};
-  if (PREFETCH && cnt) raw_cur = load_raw<F>(base_tab, cur & 0x7fffffffu);
+  if (PREFETCH && cnt) raw_cur = load_raw<F>(base_tab, DG_IDX(3, cur & 0x7fffffffu, g.region));
   for (unsigned j = 0; j < cnt; j++) {
     const unsigned nn = (j + 2 < cnt) ? e[j + 2] : 0u;
     RawPoint<F> raw_nxt{};
-    if (PREFETCH) raw_nxt = load_raw<F>(base_tab, nxt & 0x7fffffffu);
-    else raw_cur = load_raw<F>(base_tab, cur & 0x7fffffffu);
+    if (PREFETCH) raw_nxt = load_raw<F>(base_tab, DG_IDX(3, nxt & 0x7fffffffu, g.region));
+    else raw_cur = load_raw<F>(base_tab, DG_IDX(3, cur & 0x7fffffffu, g.region));
     const Affine29<F> q = unpack_raw<F>(raw_cur);
     const bool negate = cur >> 31;
     cur = nxt;
@@ -869,7 +873,7 @@ msm_accumulate_lds_kernel(MsmBases bases, size_t n, MsmGeom g,
     XYZZ29<F> out = XYZZ29<F>::inf();
     if (!inf) out = XYZZ29<F>{ld(0), ld(1), ld(2), ld(3)};
     if (sr.k == 1) buckets[((size_t)blockIdx.y << g.log_nb) + (sr.bslot & (((size_t)1 << g.log_nb) - 1))] = out;
-    else seg_sum[(size_t)blockIdx.y * g.seg_cap + t] = out;
+    else seg_sum[(size_t)blockIdx.y * g.seg_cap + DG_IDX(4, t, g.seg_cap)] = out;
   }
 #undef DG_STAGE
 }
@@ -898,26 +902,152 @@ msm_accumulate_lds_kernel(MsmBases bases, size_t n, MsmGeom g,
 // wave is allocated them); the compiler's own AGPR use (spills) must stay below kAccFileBase --
 // tests/test_kernel_isa.py checks every AGPR reference of the built kernel.
 constexpr int kAccFileBase = 144;
+// Round 6 -- what round 5's abort was: a clobber list is NOT a reservation.  The first form named
+// two registers ("a144", "a255": enough for the resource accounting) and hipcc, which needed 160 spill registers in the
+// step-loop form of the 14-limb G2 FINALIZE, put sixteen of its own values -- hoisted operand addresses -- into
+// a[144..159]; acc_set<0> then overwrote them and the next reload used field limbs as an address
+// (HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION; reproduced at the first call on the all-equal-points shape of
+// dmsm/mod.rs:155-159, profiles/r6a_*).  tests/test_kernel_isa.py could not see it: in a disassembly the compiler's
+// v_accvgpr_write looks like acc_set's.  Now (i) every write NAMES its register as clobbered, so the compiler never keeps a
+// value of its own in a file register across an acc_set; (ii) the kernel declares all 112; (iii) tools/check_agpr_file.py
+// reads the compiler's assembly (-save-temps), where the asm statements are bracketed by ASMSTART / ASMEND, and FAILS THE
+// BUILD (csrc/Makefile) if any instruction of the compiler's own touches a[144..255] in a kernel that uses the file.
+#define DG_ACC_REGS_LO(X) X(144) X(145) X(146) X(147) X(148) X(149) X(150) X(151) X(152) X(153) X(154) X(155) X(156) X(157) X(158) X(159) X(160) X(161) X(162) X(163) X(164) X(165) X(166) X(167) X(168) X(169) X(170) X(171) X(172) X(173) X(174) X(175) X(176) X(177) X(178) X(179) X(180) X(181) X(182) X(183) X(184) X(185) X(186) X(187) X(188) X(189) X(190) X(191) X(192) X(193) X(194) X(195) X(196) X(197) X(198) X(199)
+#define DG_ACC_REGS_HI(X) X(200) X(201) X(202) X(203) X(204) X(205) X(206) X(207) X(208) X(209) X(210) X(211) X(212) X(213) X(214) X(215) X(216) X(217) X(218) X(219) X(220) X(221) X(222) X(223) X(224) X(225) X(226) X(227) X(228) X(229) X(230) X(231) X(232) X(233) X(234) X(235) X(236) X(237) X(238) X(239) X(240) X(241) X(242) X(243) X(244) X(245) X(246) X(247) X(248) X(249) X(250) X(251) X(252) X(253) X(254)
+template <int R> struct AccReg;
+#define X(n)                                                                                             \
+  template <> struct AccReg<n> {                                                                         \
+    static __device__ __forceinline__ void w(uint32_t v) {                                               \
+      asm volatile("v_accvgpr_write_b32 a" #n ", %0" ::"v"(v) : "a" #n);                                 \
+    }                                                                                                    \
+    static __device__ __forceinline__ uint32_t r() {                                                     \
+      uint32_t v;                                                                                        \
+      asm volatile("v_accvgpr_read_b32 %0, a" #n : "=v"(v));                                             \
+      return v;                                                                                          \
+    }                                                                                                    \
+  };
+DG_ACC_REGS_LO(X) DG_ACC_REGS_HI(X) X(255)
+#undef X
+// all registers of the file, for the kernel's one declaration (resource accounting: the wave is allocated them)
+#define X(n) "a" #n,
+#define DG_ACC_FILE_CLOBBERS DG_ACC_REGS_LO(X) DG_ACC_REGS_HI(X) "a255"
+template <int BASE, int N, class P, int B, int... I>
+__device__ __forceinline__ void acc_set_seq(const Fe2<P, B, 1>& v, std::integer_sequence<int, I...>) {
+  ((AccReg<BASE + I>::w(v.c0.l[I]), AccReg<BASE + N + I>::w(v.c1.l[I])), ...);
+}
+template <int BASE, int N, class P, int B, int... I>
+__device__ __forceinline__ void acc_get_seq(Fe2<P, B, 1>& v, std::integer_sequence<int, I...>) {
+  ((v.c0.l[I] = AccReg<BASE + I>::r(), v.c1.l[I] = AccReg<BASE + N + I>::r()), ...);
+}
 template <int SLOT, class P, int B>
 __device__ __forceinline__ void acc_set(const Fe2<P, B, 1>& v) {
   constexpr int N = RR<P>::N;
-#pragma unroll
-  for (int i = 0; i < N; i++) {
-    asm volatile("v_accvgpr_write_b32 a[%1], %0" ::"v"(v.c0.l[i]), "n"(kAccFileBase + 2 * N * SLOT + i));
-    asm volatile("v_accvgpr_write_b32 a[%1], %0" ::"v"(v.c1.l[i]), "n"(kAccFileBase + 2 * N * SLOT + N + i));
-  }
+  static_assert(kAccFileBase + 2 * N * (SLOT + 1) <= 256, "slot inside the file");
+  acc_set_seq<kAccFileBase + 2 * N * SLOT, N>(v, std::make_integer_sequence<int, N>{});
 }
 template <int SLOT, class P, int B>
 __device__ __forceinline__ Fe2<P, B, 1> acc_get() {
   constexpr int N = RR<P>::N;
   Fe2<P, B, 1> v;
-#pragma unroll
-  for (int i = 0; i < N; i++) {
-    asm volatile("v_accvgpr_read_b32 %0, a[%1]" : "=v"(v.c0.l[i]) : "n"(kAccFileBase + 2 * N * SLOT + i));
-    asm volatile("v_accvgpr_read_b32 %0, a[%1]" : "=v"(v.c1.l[i]) : "n"(kAccFileBase + 2 * N * SLOT + N + i));
-  }
+  acc_get_seq<kAccFileBase + 2 * N * SLOT, N>(v, std::make_integer_sequence<int, N>{});
   return v;
 }
+#ifdef DG16_FINALIZE_STEPS   // the withdrawn round-5 form of the 14-limb G2 finalize, for the abort repro only
+// d += b (full XYZZ addition, XYZZ29::add_into) as a STEP LOOP over the same three product sites: the 14-limb G2 finalize
+// (msm_finalize_lds_kernel: two lanes per bucket summing the bucket's partials) inlined a 144-KB addition -- 35 900
+// instructions with its doubling branch -- and ran at 16 % of its issue rate on the slow boxes of the pool.
+//     0  U1 = X1 ZZ2 -> X1      1  S1 = Y1 ZZZ2 -> Y1      2  P = X2 ZZ1 - U1      3  R = Y2 ZZZ1 - S1
+//     4  PP = P^2               5  PPP = P PP              6  T = ZZ1 ZZ2          7  ZZ3 = T PP
+//     8  T = ZZZ1 ZZZ2          9  ZZZ3 = T PPP           10  Q = U1 PP           11  X3 = R^2 - PPP - 2 Q
+//    12  Y3 = R (Q - X3) - PPP S1
+// d: accumulator in LDS columns (get / put); b: read-only operand behind an accessor (memory or LDS), intact throughout, so
+// the rare d == b case doubles b.  Needs the accumulation-register file of the calling kernel (kAccFileBase).
+template <class F, class D, class B>
+__device__ __forceinline__ void xyzz_add_into_steps(const D& d, const B& b_) {
+  using FO = FieldOf<F>;
+  using P = typename FO::Params;
+  constexpr int BS = FO::BS;
+  constexpr int BG = 640;
+  using G = Fe2<P, BG, 1>;
+  if (limbs_all_zero(b_.get(2))) return;
+  if (limbs_all_zero(d.get(2))) {
+    d.put(0, b_.get(0)); d.put(1, b_.get(1)); d.put(2, b_.get(2)); d.put(3, b_.get(3));
+    return;
+  }
+  B b = b_;
+  auto dg = [&](int c) { return d.get(c).template as<BG, 1>(); };
+  auto bg = [&](int c) { return b.get(c).template as<BG, 1>(); };
+  int special = 0;
+  bool p_zero = false;
+#pragma unroll 1
+  for (int step = 0; step < 13; step++) {
+    asm volatile("" : "+s"(step));          // opaque: the sites must not be cloned per step
+    b.launder();                            // ... and the operand's 112 word addresses not hoisted out of the loop (they
+                                            // were: 224 registers of pointers, 932 B of scratch per lane)
+    if (step == 4 || step == 11) {
+      const G a = step == 4 ? acc_get<0, P, BG>() : acc_get<1, P, BG>();
+      const auto c = sqr(a);
+      if (step == 4) {
+        acc_set<2>(c.template as<BG, 1>());                             // PP
+      } else {
+        const auto ppp = acc_get<3, P, 128>(), q_ = acc_get<0, P, 128>();
+        const auto x3 = fit<BS>(c - (ppp + dbl(q_)));
+        d.put(0, x3);
+        acc_set<2>(fit<BG>(q_ - x3));                                   // Q - X3
+      }
+    } else if (step == 12) {
+      const auto r_ = acc_get<1, P, BG>(), t_ = acc_get<2, P, BG>();
+      const auto ppp = acc_get<3, P, 128>();
+      d.put(1, fit<BS>(mul_sub(r_, t_, ppp, d.get(1))));                // R (Q - X3) - PPP S1
+    } else {
+      G a, bb;
+      switch (step) {
+        case 0: a = dg(0); bb = bg(2); break;                            // X1 ZZ2
+        case 1: a = dg(1); bb = bg(3); break;                            // Y1 ZZZ2
+        case 2: a = bg(0); bb = dg(2); break;                            // X2 ZZ1
+        case 3: a = bg(1); bb = dg(3); break;                            // Y2 ZZZ1
+        case 5: a = acc_get<0, P, BG>(); bb = acc_get<2, P, BG>(); break;   // P PP
+        case 6: a = dg(2); bb = bg(2); break;                            // ZZ1 ZZ2
+        case 7: a = acc_get<0, P, BG>(); bb = acc_get<2, P, BG>(); break;   // (ZZ1 ZZ2) PP
+        case 8: a = dg(3); bb = bg(3); break;                            // ZZZ1 ZZZ2
+        case 9: a = acc_get<0, P, BG>(); bb = acc_get<3, P, BG>(); break;   // (ZZZ1 ZZZ2) PPP
+        default: a = dg(0); bb = acc_get<2, P, BG>(); break;             // U1 PP
+      }
+      const auto c = a * bb;
+      switch (step) {
+        case 0: d.put(0, c.template as<BS, 1>()); break;                 // U1
+        case 1: d.put(1, c.template as<BS, 1>()); break;                 // S1
+        case 2: {
+          const auto p_ = fit<BG>(c - d.get(0));
+          p_zero = is_zero_compact(p_);
+          acc_set<0>(p_);
+          break;
+        }
+        case 3: {
+          const auto r_ = fit<BG>(c - d.get(1));
+          if (p_zero) special = is_zero_compact(r_) ? 1 : 2;
+          acc_set<1>(r_);
+          break;
+        }
+        case 5: acc_set<3>(c.template as<BG, 1>()); break;               // PPP
+        case 6: acc_set<0>(c.template as<BG, 1>()); break;
+        case 7: d.put(2, c.template as<BS, 1>()); break;                 // ZZ3
+        case 8: acc_set<0>(c.template as<BG, 1>()); break;
+        case 9: d.put(3, c.template as<BS, 1>()); break;                 // ZZZ3
+        default: acc_set<0>(c.template as<BG, 1>()); break;              // Q
+      }
+      if (special) break;
+    }
+  }
+  if (special == 1) {
+    const XYZZ29<F> t = XYZZ29<F>{b.get(0), b.get(1), b.get(2), b.get(3)}.dbl_pt();
+    d.put(0, t.x); d.put(1, t.y); d.put(2, t.zz); d.put(3, t.zzz);
+  } else if (special == 2) {
+    d.put(2, FO::zero());                                              // the identity: zz = 0
+  }
+}
+
+#endif
 template <class F, int BLOCK>
 __global__ void __launch_bounds__(BLOCK, 1)
 msm_accumulate_steps_kernel(MsmBases bases, size_t n, MsmGeom g,
@@ -954,9 +1084,9 @@ msm_accumulate_steps_kernel(MsmBases bases, size_t n, MsmGeom g,
   const bool live = t < seg_total[w];
   SegRange sr{};
   if (live) sr = msm_segment(g, w, t, counts, seg_off);
-  const unsigned cnt = live ? sr.cnt : 0u;
+  const unsigned cnt = live && DG_OK(2, (size_t)offsets[sr.bslot] + sr.first + sr.cnt, g.region + 1) ? sr.cnt : 0u;
   const unsigned* e = entries + (size_t)w * g.region + (live ? offsets[sr.bslot] + sr.first : 0u);
-  asm volatile("" ::: "a144", "a255");   // the temporaries' registers belong to this wave (acc_set / acc_get)
+  asm volatile("" ::: DG_ACC_FILE_CLOBBERS);   // the temporaries' registers belong to this wave (acc_set / acc_get)
   bool inf = true;
   unsigned cur = cnt ? e[0] : 0u;
   for (unsigned j = 0; j < cnt; j++) {
@@ -965,7 +1095,7 @@ msm_accumulate_steps_kernel(MsmBases bases, size_t n, MsmGeom g,
     cur = nxt;
     const bool negate = ent >> 31;
     {
-      const Affine29<F> q = load_internal<F>(base_tab, ent & 0x7fffffffu);
+      const Affine29<F> q = load_internal<F>(base_tab, DG_IDX(3, ent & 0x7fffffffu, g.region));
       if (q.is_inf()) continue;
       const auto nqy = neg(q.y);
       const auto qy = select(negate, nqy, q.y.template as<decltype(nqy)::Bound, decltype(nqy)::Limb>());
@@ -1046,7 +1176,7 @@ msm_accumulate_steps_kernel(MsmBases bases, size_t n, MsmGeom g,
     XYZZ29<F> out = XYZZ29<F>::inf();
     if (!inf) out = XYZZ29<F>{ld(0), ld(1), ld(2), ld(3)};
     if (sr.k == 1) buckets[((size_t)blockIdx.y << g.log_nb) + (sr.bslot & (((size_t)1 << g.log_nb) - 1))] = out;
-    else seg_sum[(size_t)blockIdx.y * g.seg_cap + t] = out;
+    else seg_sum[(size_t)blockIdx.y * g.seg_cap + DG_IDX(4, t, g.seg_cap)] = out;
   }
 }
 
@@ -1336,14 +1466,118 @@ __device__ __forceinline__ XYZZ29<F> add_wave29(const XYZZ29<F>& p, const XYZZ29
   const auto r4 = M::mul(a4, b4);
   return {x3, fit<BS>(bcast29<0>(r4) - bcast29<4>(r4)), zz3, bcast29<8>(r4)};
 }
-// k p by double-and-add on one wave; k = NW little-endian 32-bit words (plain integer), uniform
+// ---- k p on one wave: interleaved width-4 NAFs, and the endomorphism split where the group allows it -----------------
+// The plain double-and-add chain (round 4) ran NW * 32 doublings and ~NW * 16 additions -- 254 x 3 + 127 x 4 = 1 270
+// dependent product levels for s A' / r B1' of a proof: 0.52 ms of an 8-shard rank's 3.0 ms.  Here the scalar is recoded
+// as a width-4 NAF (digits 0, +-1, +-3, +-5, +-7, one nonzero digit in five on average) over the odd multiples P, 3P, 5P,
+// 7P kept in LDS, and for a group of cofactor one (BN254 G1: phi(P) = LAMBDA P holds for EVERY point of the curve;
+// GlvCofactorOne below) k is first split k = k1 + k2 LAMBDA with 127-bit halves (glv.h) whose NAFs are interleaved
+// over (P, phi P) (Straus): 127 doublings + ~51 additions + the table = ~600 levels.  Groups with a cofactor keep the
+// unsplit scalar (a key's A' / B1' are in the order-r subgroup only if the key is valid, and a proof must equal
+// arkworks' for any key): 254 doublings + ~51 additions = ~980 levels.
+template <class F> struct GlvOf;
+template <class F> struct GlvCofactorOne;
+constexpr int kNafMax = 8 * 32 + 8;        // digits of one NAF (an NW-word integer has at most NW * 32 + 1)
+template <class F>
+struct ScalarMulLds {                      // per chain (one wave)
+  XYZZ29<F> tab[8];                        // (2 j + 1) P, j < 4; then phi of them
+  signed char naf[2][kNafMax];
+};
+// width-4 NAF of the NB-bit integer k[0 .. NW) (little-endian words): out[i] in {0, +-1, +-3, +-5, +-7}, i <= NB; returns
+// the number of digits (highest nonzero position + 1).  One bit of carry instead of a multi-word subtraction: the window
+// at a set bit is taken with the carry added, a window value >= 8 becomes value - 16 and carries into the bit after it.
+template <int NW>
+__device__ __forceinline__ int wnaf4_words(const uint32_t* k, int nbits, bool negate, signed char* out) {
+  auto bits = [&](int at, int cnt) -> unsigned {      // k[at .. at + cnt), cnt <= 4 (bits past the top are zero)
+    uint32_t lo = 0, hi = 0;
+#pragma unroll
+    for (int j = 0; j < NW; j++) {
+      lo = (at >> 5) == j ? k[j] : lo;
+      hi = (at >> 5) + 1 == j ? k[j] : hi;
+    }
+    const uint64_t v = ((uint64_t)hi << 32 | lo) >> (at & 31);
+    return (unsigned)v & ((1u << cnt) - 1u);
+  };
+  int len = 0;
+  unsigned carry = 0;
+  for (int i = 0; i <= nbits + 4; i++) out[i] = 0;
+  int bit = 0;
+  while (bit <= nbits) {
+    if (bits(bit, 1) == carry) { bit++; continue; }
+    int word = (int)(bits(bit, 4) + carry);
+    carry = (unsigned)(word >> 3) & 1u;
+    word -= (int)(carry << 4);
+    out[bit] = (signed char)(negate ? -word : word);
+    len = bit + 1;
+    bit += 4;
+  }
+  return len;
+}
+// k p; p, k (NW canonical little-endian words) and the result uniform across the wave; `lds` is this wave's alone
 template <class F, int NW>
-__device__ __forceinline__ XYZZ29<F> scalar_mul_wave29(const XYZZ29<F>& p, const uint32_t* k) {
+__device__ __forceinline__ XYZZ29<F> scalar_mul_wave29(const XYZZ29<F>& p, const uint32_t* k, ScalarMulLds<F>* lds) {
+  constexpr int BS = XYZZ29<F>::BS;
+  constexpr bool SPLIT = GlvOf<F>::enabled && GlvCofactorOne<F>::value && NW == 8;
+  const unsigned lane = __lane_id();
+  if (p.is_inf()) return p;
+  // the table of odd multiples (a doubling and three additions on the wave)
+  {
+    const XYZZ29<F> p2 = dbl_wave29(p);
+    XYZZ29<F> m = p;
+#pragma unroll 1
+    for (int j = 0; j < 4; j++) {
+      if (j) m = add_wave29(m, p2);
+      if (lane == 0) lds->tab[j] = m;
+    }
+  }
+  int len = 0;
+  if constexpr (SPLIT) {
+    using GC = typename GlvOf<F>::C;
+    uint32_t h[2][8];
+    glv::split<GC>(k, h[0], h[1]);
+    // lanes 0 and 1 recode one half each; phi(x, y) = (BETA x, y): x_affine = X / ZZ, so only X changes
+    if (lane < 2) {
+      uint32_t w[5];
+#pragma unroll
+      for (int i = 0; i < 4; i++) w[i] = lane ? h[1][i] : h[0][i];
+      w[4] = 0;
+      const bool neg_half = ((lane ? h[1][7] : h[0][7]) >> 31) != 0;
+      len = wnaf4_words<5>(w, 128, neg_half, lds->naf[lane]);
+    }
+    __syncthreads();
+    {
+      Fp<typename FieldOf<F>::Params> beta32;
+#pragma unroll
+      for (int i = 0; i < Fp<typename FieldOf<F>::Params>::NL; i++) beta32.l[i] = GC::BETA[i];
+      const auto beta = FieldOf<F>::from32(beta32);
+      const unsigned slot = (lane & 15) >> 2;
+      const XYZZ29<F> t = lds->tab[slot];
+      const auto bx = fit<BS>(t.x * beta);
+      if ((lane & 3) == 0 && lane < 16) {
+        XYZZ29<F> e = t;
+        e.x = bx;
+        lds->tab[4 + slot] = e;
+      }
+    }
+    len = max(__shfl(len, 0), __shfl(len, 1));
+  } else {
+    if (lane == 0) len = wnaf4_words<NW>(k, NW * 32, false, lds->naf[0]);
+    len = __shfl(len, 0);
+  }
+  __syncthreads();
   XYZZ29<F> acc = XYZZ29<F>::inf();
 #pragma unroll 1
-  for (int i = NW * 32 - 1; i >= 0; i--) {
+  for (int i = len - 1; i >= 0; i--) {
     acc = dbl_wave29(acc);
-    if ((k[i / 32] >> (i % 32)) & 1) acc = add_wave29(acc, p);
+#pragma unroll 1
+    for (int hf = 0; hf < (SPLIT ? 2 : 1); hf++) {
+      const int d = lds->naf[hf][i];
+      if (d == 0) continue;
+      XYZZ29<F> o = lds->tab[4 * hf + ((d < 0 ? -d : d) >> 1)];
+      const auto ny = fit<BS>(neg(o.y));
+      o.y = select(d < 0, ny, o.y);
+      acc = add_wave29(acc, o);
+    }
   }
   return acc;
 }
@@ -1384,6 +1618,7 @@ template <class Fr, int SCALAR_BITS>
 MsmSort msm_sort_on(hipStream_t s, Channel& wsch, const void* scalars, size_t n, unsigned scalars_mont, bool table,
                     unsigned c_fixed, unsigned stride) {
   MsmSort r;
+  DG_BOUNDS_BIND();
   r.n = n;
   r.g = msm_geometry(n ? n : 1, SCALAR_BITS, table, c_fixed, stride);
   const MsmGeom& g = r.g;
@@ -1479,6 +1714,12 @@ MsmBuffers<F> msm_buffers(Channel& wsch, const MsmGeom& g, unsigned ninst = 1) {
   b.nbw = bwi << g.log_nb;
   const size_t nseg_slots = bwi * g.seg_cap;
   b.giant_cap = (unsigned)(nseg_slots / kGiantSegs + 1);
+  // capacities of the giant work list (msm_register_giant): ids < giant_cap, work items <= 2 giant_cap
+  DG_REQUIRE(nseg_slots / kGiantSegs + 1 < ((size_t)1 << 26), DG16_ERR_BAD_ARG, "giant list: id slot must fit 26 bits");
+  static_assert(kGiantSlices <= 64, "a work item keeps its slice in six bits");
+  static_assert(kGiantSliceSegs >= kGiantSegs, "work items <= 2 giant_cap needs slices no shorter than kGiantSegs partials");
+  DG_REQUIRE(nseg_slots / kGiantSliceSegs + 1 + b.giant_cap <= 2 * (size_t)b.giant_cap + 1, DG16_ERR_BAD_ARG,
+             "giant list: work-item capacity");
   b.buckets = (XYZZ29<F>*)ws(wsch, 7, b.nbw * sizeof(XYZZ29<F>));
   b.seg_sum = (XYZZ29<F>*)ws(wsch, 17, nseg_slots * sizeof(XYZZ29<F>));
   b.rg = row_geometry(g);
@@ -1505,6 +1746,7 @@ void msm_finalize_lds_phase(hipStream_t s, const MsmSort& st, const MsmBuffers<F
 template <class F>
 void msm_accumulate_phase(hipStream_t s, const MsmSort& st, const MsmBuffers<F>& b, const void* const* bases) {
   const MsmGeom& g = st.g;
+  DG_BOUNDS_BIND();
   MsmBases mb{};
   for (unsigned i = 0; i < b.ninst; i++) mb.p[i] = (const uint32_t*)bases[i];
   if constexpr (sizeof(F) > 48) {
@@ -1588,13 +1830,29 @@ void msm_tail_phase(hipStream_t s, const MsmSort& st, const MsmBuffers<F>& b, bo
 // Giant buckets (a boolean witness puts half of ALL entries into bucket 0; the short top window of a c that does
 // not divide the scalar width does the same) go on a device-side work list: stage 1 cuts the bucket's segment
 // partials into <= kGiantSlices slices, one workgroup each; stage 2 adds the slice sums (msm_reduce_impl.h).
-constexpr unsigned kGiantSlices = 64;
-constexpr unsigned kGiantSliceSegs = 512;
 __device__ __forceinline__ void giant_geometry(unsigned nseg, unsigned& slices, unsigned& per) {
   slices = (nseg + kGiantSliceSegs - 1) / kGiantSliceSegs;
   if (slices > kGiantSlices) slices = kGiantSlices;
   per = (nseg + slices - 1) / slices;
   slices = (nseg + per - 1) / per;
+}
+// A giant bucket (np > kGiantSegs partials) goes on the device-side work list: giant[0] = giants, giant[1] = work items,
+// giant_list[0 .. giant_cap) = bucket ids, giant_list[giant_cap .. 3 giant_cap) = (id slot << 6 | slice) items.  Both
+// capacities hold by construction (msm_buffers asserts the arithmetic; MSM_INVARIANTS.md): the giants of a launch own
+// disjoint sets of > kGiantSegs of its <= nseg_slots partials, so there are < nseg_slots / kGiantSegs + 1 = giant_cap of
+// them, and their slices number sum ceil(np / per) <= sum (np / kGiantSliceSegs + 1) < nseg_slots / kGiantSliceSegs +
+// giant_cap <= 2 giant_cap.  The guards below keep a violated invariant from writing outside the list anyway.
+__device__ __forceinline__ void msm_register_giant(unsigned gid, unsigned np, unsigned* __restrict__ giant_count,
+                                                   unsigned* __restrict__ giant_list, unsigned giant_cap) {
+  const unsigned slot = atomicAdd(giant_count, 1u);
+  if (!DG_OK(8, slot, giant_cap) || slot >= giant_cap) return;
+  giant_list[slot] = gid;
+  unsigned slices, per;
+  giant_geometry(np, slices, per);
+  const unsigned wb = atomicAdd(giant_count + 1, slices);   // work items: (giant, slice)
+  if (!DG_OK(9, (size_t)wb + slices, 2 * (size_t)giant_cap + 1) || (size_t)wb + slices > 2 * (size_t)giant_cap) return;
+  unsigned* work = giant_list + giant_cap;
+  for (unsigned i = 0; i < slices; i++) work[wb + i] = (slot << 6) | i;
 }
 
 
@@ -1629,21 +1887,13 @@ __global__ void __launch_bounds__(256) msm_finalize_thr_kernel(MsmGeom g, size_t
   }
   if (np == 1) return;                                  // one workgroup held the whole bucket and wrote it
   if (np > kGiantSegs) {
-    unsigned slot = atomicAdd(giant_count, 1u);
-    if (slot < giant_cap) {               // (always: giant_cap >= total segments / kGiantSegs)
-      giant_list[slot] = (unsigned)gid;
-      unsigned slices, per;
-      giant_geometry(np, slices, per);
-      unsigned wb = atomicAdd(giant_count + 1, slices);   // work items: (giant, slice)
-      unsigned* work = giant_list + giant_cap;
-      for (unsigned i = 0; i < slices; i++) work[wb + i] = (slot << 6) | i;
-    }
+    msm_register_giant((unsigned)gid, np, giant_count, giant_list, giant_cap);
     return;
   }
   const XYZZ29<F>* sp = seg_sum + (size_t)wy * g.seg_cap;
-  XYZZ29<F> acc = sp[first];
+  XYZZ29<F> acc = sp[DG_IDX(7, first, g.seg_cap)];
 #pragma unroll 1
-  for (unsigned s = 1; s < np; s++) acc = acc.add(sp[msm_part_slot(first, s, wg_log)]);
+  for (unsigned s = 1; s < np; s++) acc = acc.add(sp[DG_IDX(7, msm_part_slot(first, s, wg_log), g.seg_cap)]);
   buckets[gid] = acc;
 }
 // The same finalize as a THROUGHPUT kernel (G2): LPB lanes per bucket, each summing its share of the bucket's partials
@@ -1667,6 +1917,10 @@ struct PartialAcc {      // an XYZZ29 behind the accessor interface of XYZZ29::a
     if (p) return coord == 0 ? p->x : coord == 1 ? p->y : coord == 2 ? p->zz : p->zzz;
     return col.get(coord);
   }
+#ifdef DG16_FINALIZE_STEPS
+  // the pointer as a value the compiler cannot trace (xyzz_add_into_steps: keeps address arithmetic inside the step)
+  __device__ __forceinline__ void launder() { asm volatile("" : "+v"(p)); }
+#endif
 };
 template <class F, int BLOCK>
 __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 ? 2 : 1))
@@ -1679,6 +1933,9 @@ msm_finalize_lds_kernel(MsmGeom g, size_t total, unsigned wg_log, unsigned lpb_l
   constexpr int WORDS = sizeof(typename FO::Store) / 4;
   __shared__ uint32_t sh[4 * WORDS][BLOCK];
   __shared__ unsigned max_serial;
+#ifdef DG16_FINALIZE_STEPS
+  if constexpr (sizeof(F) > 64) asm volatile("" ::: DG_ACC_FILE_CLOBBERS);   // xyzz_add_into_steps' temporaries (acc_set / acc_get)
+#endif
   const unsigned LPB = 1u << lpb_log;
   const unsigned lane = threadIdx.x, sub = lane & (LPB - 1);
   const size_t gid = ((size_t)blockIdx.x * BLOCK + lane) >> lpb_log;
@@ -1688,23 +1945,13 @@ msm_finalize_lds_kernel(MsmGeom g, size_t total, unsigned wg_log, unsigned lpb_l
   if (lane == 0) max_serial = 0;
   if (gid < total) {
     wy = (unsigned)(gid >> g.log_nb);
-    const size_t gs = ((size_t)(wy % g.bw) << g.log_nb) + (gid & (((size_t)1 << g.log_nb) - 1));
+    const size_t gs = DG_IDX(6, ((size_t)(wy % g.bw) << g.log_nb) + (gid & (((size_t)1 << g.log_nb) - 1)), (size_t)g.bw << g.log_nb);
     const unsigned k = (counts[gs] + (1u << g.seg_log) - 1) >> g.seg_log;
     first = seg_off[gs];
     np = msm_nparts(first, k, wg_log);
     if (sub == 0) {
       if (np == 0) buckets[gid] = XYZZ29<F>::inf();
-      if (np > kGiantSegs) {
-        unsigned slot = atomicAdd(giant_count, 1u);
-        if (slot < giant_cap) {
-          giant_list[slot] = (unsigned)gid;
-          unsigned slices, per;
-          giant_geometry(np, slices, per);
-          unsigned wb = atomicAdd(giant_count + 1, slices);
-          unsigned* work = giant_list + giant_cap;
-          for (unsigned i = 0; i < slices; i++) work[wb + i] = (slot << 6) | i;
-        }
-      }
+      if (np > kGiantSegs) msm_register_giant((unsigned)gid, np, giant_count, giant_list, giant_cap);
     }
   }
   const bool work = np >= 2 && np <= kGiantSegs;      // np == 1: the accumulation wrote the bucket itself
@@ -1712,7 +1959,7 @@ msm_finalize_lds_kernel(MsmGeom g, size_t total, unsigned wg_log, unsigned lpb_l
   const unsigned lo = work ? (unsigned)(((uint64_t)sub * np) >> lpb_log) : 0u;
   const unsigned hi = work ? (unsigned)(((uint64_t)(sub + 1) * np) >> lpb_log) : 0u;
   if (lo < hi) {
-    const XYZZ29<F>* q = &sp[msm_part_slot(first, lo, wg_log)];
+    const XYZZ29<F>* q = &sp[DG_IDX(7, msm_part_slot(first, lo, wg_log), g.seg_cap)];
     me.put(0, q->x); me.put(1, q->y); me.put(2, q->zz); me.put(3, q->zzz);
   } else {
     me.put(2, FO::zero());                              // the identity for add_into: zz = 0
@@ -1731,12 +1978,16 @@ msm_finalize_lds_kernel(MsmGeom g, size_t total, unsigned wg_log, unsigned lpb_l
     const unsigned d = tree ? 1u << (step - ms) : 0u;
     const bool on = tree ? (work && (sub & (2 * d - 1)) == 0) : step < nser;
     if (on) {
-      const PartialAcc<F, BLOCK> b{tree ? nullptr : &sp[msm_part_slot(first, lo + 1 + step, wg_log)],
-                                   ColAcc<F, BLOCK>{sh, lane + d}};
+      const PartialAcc<F, BLOCK> b{tree ? nullptr : &sp[DG_IDX(7, msm_part_slot(first, lo + 1 + step, wg_log), g.seg_cap)],
+                                   ColAcc<F, BLOCK>{sh, (unsigned)DG_IDX(10, lane + d, BLOCK)}};
       // (14-limb Fq2: the same addition as a step loop over the accumulation's three product sites -- 35 900 -> 22 700
       // instructions, emulated against the oracle, 23.2 -> 22.9 ms per BLS12-381 proof on a fast box -- was withdrawn in
       // round 5: one box of the pool aborted with HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION behind this kernel
       // (profiles/r5r_*), unexplained and not reproducible on the next box)
+#ifdef DG16_FINALIZE_STEPS
+      if constexpr (sizeof(F) > 64) xyzz_add_into_steps<F>(me, b);
+      else
+#endif
       XYZZ29<F>::add_into(me, b);
     }
   }
@@ -1792,21 +2043,13 @@ __global__ void __launch_bounds__(256) msm_stitch_kernel(MsmGeom g, unsigned wg_
   const unsigned k = (counts[gs] + (1u << g.seg_log) - 1) >> g.seg_log;
   const unsigned np = msm_nparts(first, k, wg_log);
   if (np > kGiantSegs) {
-    unsigned gslot = atomicAdd(giant_count, 1u);
-    if (gslot < giant_cap) {
-      giant_list[gslot] = (unsigned)gid;
-      unsigned slices, per;
-      giant_geometry(np, slices, per);
-      unsigned wb = atomicAdd(giant_count + 1, slices);
-      unsigned* work = giant_list + giant_cap;
-      for (unsigned i = 0; i < slices; i++) work[wb + i] = (gslot << 6) | i;
-    }
+    msm_register_giant((unsigned)gid, np, giant_count, giant_list, giant_cap);
     return;
   }
   const XYZZ29<F>* sp = seg_sum + (size_t)wy * g.seg_cap;
-  XYZZ29<F> acc = sp[first];
+  XYZZ29<F> acc = sp[DG_IDX(7, first, g.seg_cap)];
 #pragma unroll 1
-  for (unsigned s = 1; s < np; s++) acc = acc.add(sp[msm_part_slot(first, s, wg_log)]);
+  for (unsigned s = 1; s < np; s++) acc = acc.add(sp[DG_IDX(7, msm_part_slot(first, s, wg_log), g.seg_cap)]);
   buckets[gid] = acc;
 }
 // ... and the empty buckets are set to the identity by a kernel of a dozen registers per lane (it fits next to any
@@ -1827,6 +2070,7 @@ __global__ void __launch_bounds__(256) msm_empty_buckets_kernel(MsmGeom g, size_
 }
 template <class F>
 void msm_finalize_phase(hipStream_t s, const MsmSort& st, const MsmBuffers<F>& b) {
+  DG_BOUNDS_BIND();
   if constexpr (msm_acc_tree<F>()) {
     hipLaunchKernelGGL(msm_empty_buckets_kernel<F>, dim3((unsigned)((b.nbw + 255) / 256)), dim3(256), 0, s, st.g, b.nbw,
                        st.counts, b.buckets);

@@ -53,11 +53,12 @@ __global__ void __launch_bounds__(256) msm_giant_kernel(MsmGeom g, unsigned wg_l
                                                          const unsigned* __restrict__ giant_list, unsigned giant_cap) {
   __builtin_amdgcn_s_setprio(3);   // latency-bound chain: issue ahead of the accumulation waves sharing the SIMD
   __shared__ XYZZ29<F> sh[256];
-  const unsigned nwork = giant_count[1];
+  unsigned nwork = giant_count[1];
+  if (nwork > 2 * giant_cap) nwork = 2 * giant_cap;          // (never: msm_register_giant)
   const unsigned* work = giant_list + giant_cap;
   for (unsigned wi = blockIdx.x; wi < nwork; wi += gridDim.x) {
     const unsigned item = work[wi];
-    const unsigned gid = giant_list[item >> 6], slice = item & 63;
+    const unsigned gid = giant_list[DG_IDX(11, item >> 6, giant_cap)], slice = item & 63;
     const unsigned wy = gid >> g.log_nb;                                   // instance * bw + bucket-window
     const size_t gs = ((size_t)(wy % g.bw) << g.log_nb) + (gid & ((1u << g.log_nb) - 1));   // the sort's bucket slot
     const unsigned k = (counts[gs] + (1u << g.seg_log) - 1) >> g.seg_log, first = seg_off[gs];
@@ -78,7 +79,7 @@ __global__ void __launch_bounds__(256) msm_giant_kernel(MsmGeom g, unsigned wg_l
       if (step < iters) {
         const unsigned s = lo + step * 256 + threadIdx.x;
         on = s < hi;
-        b = &sp[msm_part_slot(first, on ? s : lo, wg_log)];
+        b = &sp[DG_IDX(12, msm_part_slot(first, on ? s : lo, wg_log), g.seg_cap)];
       } else {
         const unsigned stride = 128u >> (step - iters);
         on = threadIdx.x < stride;
@@ -87,7 +88,7 @@ __global__ void __launch_bounds__(256) msm_giant_kernel(MsmGeom g, unsigned wg_l
       if (on) XYZZ29<F>::add_mem(&sh[threadIdx.x], &sh[threadIdx.x], b);
       __syncthreads();
     }
-    if (threadIdx.x == 0) sp[msm_part_slot(first, lo, wg_log)] = sh[0];
+    if (threadIdx.x == 0) sp[DG_IDX(12, msm_part_slot(first, lo, wg_log), g.seg_cap)] = sh[0];
     __syncthreads();
   }
 }
@@ -113,7 +114,7 @@ __global__ void __launch_bounds__(64) msm_giant_fold_kernel(MsmGeom g, unsigned 
     unsigned slices, per;
     giant_geometry(nseg, slices, per);
     const XYZZ29<F>* sp = seg_sum + (size_t)wy * g.seg_cap;
-    sh[threadIdx.x] = threadIdx.x < slices ? sp[msm_part_slot(first, threadIdx.x * per, wg_log)] : XYZZ29<F>::inf();
+    sh[threadIdx.x] = threadIdx.x < slices ? sp[DG_IDX(12, msm_part_slot(first, threadIdx.x * per, wg_log), g.seg_cap)] : XYZZ29<F>::inf();
     __syncthreads();
 #pragma unroll 1
     for (unsigned stride = kGiantSlices / 2; stride > 0; stride >>= 1) {
@@ -385,6 +386,7 @@ template <class F>
 void msm_bucket_phase(hipStream_t s, const MsmSort& st, const MsmBuffers<F>& b, bool out_affine, void* out_dev) {
   const MsmGeom& g = st.g;
   const unsigned bwi = g.bw * b.ninst;      // bucket-windows over all instances
+  DG_BOUNDS_BIND();
   trace_point(s, "(before bucket phase)");
   if constexpr (FieldOf<F>::EXT) {
     // G2: the throughput finalize ran behind the accumulation, on its stream (msm_impl.h: msm_finalize_lds_phase)

@@ -56,8 +56,8 @@ __device__ XYZZ<F> mul_by_fr(const XYZZ<F>& p, const Fr& k_canon) {
 constexpr int kRecA = 0, kRecB1 = 1, kRecL = 2, kRecH = 3, kRecSA = 4, kRecRB1 = 5, kRecG1 = 6;
 
 // which = 0: A' = msm (+ alpha_g1 + a_query[0] on shard 0), s*A';  which = 1: B1' (+ beta_g1 + b_g1_query[0]),
-// r*B1'.  One wave each: the 254 doublings + ~127 additions of the scalar multiple run wave-cooperatively
-// (msm_impl.h: dbl_wave / add_wave), 0.8 ms instead of 2.5 ms on one lane.
+// r*B1'.  One wave each: the doublings and additions of the scalar multiple run wave-cooperatively (msm_impl.h:
+// scalar_mul_wave29 -- round 6: 127 doublings + ~51 additions for BN254 instead of 254 + ~127).
 template <class Fq, class Fr>
 __global__ void __launch_bounds__(64) prover_stage1_g1_kernel(Jacobian<Fq>* rec, const Affine<Fq>* fixed_g1,
                                                                const Fr* r_s, int mont, int first_shard) {
@@ -71,8 +71,10 @@ __global__ void __launch_bounds__(64) prover_stage1_g1_kernel(Jacobian<Fq>* rec,
     if (first_shard) v = v.madd(fixed_g1[2 * which], false).madd(fixed_g1[2 * which + 1], false);
   }
   const Fr k = which == 0 ? s : r;
-  // (the chain runs on the reduced-radix types: 1.3 us per doubling instead of 4.4 -- msm_impl.h: dbl_wave29)
-  const XYZZ<Fq> kv = scalar_mul_wave29<Fq, Fr::NL>(XYZZ29<Fq>::from_xyzz32(v), k.l).to_xyzz32();
+  // (the chain runs on the reduced-radix types, over width-4 NAF digits and -- BN254 -- the two halves of the endomorphism
+  // split: msm_impl.h: scalar_mul_wave29)
+  __shared__ ScalarMulLds<Fq> lds;
+  const XYZZ<Fq> kv = scalar_mul_wave29<Fq, Fr::NL>(XYZZ29<Fq>::from_xyzz32(v), k.l, &lds).to_xyzz32();
   if (threadIdx.x != 0) return;
   rec[which == 0 ? kRecA : kRecB1] = v.to_jacobian();
   rec[which == 0 ? kRecSA : kRecRB1] = kv.to_jacobian();
