@@ -53,6 +53,7 @@ struct TwiddleSet {   // all device pointers, 32-byte Fr elements
   // (ntt.hip: full_twiddle_kernel), and w^o for o < n / 2 flattened (the w_2m shift of the h-polynomial); null = not built
   void* full[2] = {nullptr, nullptr};
   void* shift_full = nullptr;
+  bool shift_full_tried = false;   // the optional table's allocation is attempted once per cache entry
 };
 
 }  // namespace dg16

@@ -914,11 +914,20 @@ constexpr int kAccFileBase = 144;
 // BUILD (csrc/Makefile) if any instruction of the compiler's own touches a[144..255] in a kernel that uses the file.
 #define DG_ACC_REGS_LO(X) X(144) X(145) X(146) X(147) X(148) X(149) X(150) X(151) X(152) X(153) X(154) X(155) X(156) X(157) X(158) X(159) X(160) X(161) X(162) X(163) X(164) X(165) X(166) X(167) X(168) X(169) X(170) X(171) X(172) X(173) X(174) X(175) X(176) X(177) X(178) X(179) X(180) X(181) X(182) X(183) X(184) X(185) X(186) X(187) X(188) X(189) X(190) X(191) X(192) X(193) X(194) X(195) X(196) X(197) X(198) X(199)
 #define DG_ACC_REGS_HI(X) X(200) X(201) X(202) X(203) X(204) X(205) X(206) X(207) X(208) X(209) X(210) X(211) X(212) X(213) X(214) X(215) X(216) X(217) X(218) X(219) X(220) X(221) X(222) X(223) X(224) X(225) X(226) X(227) X(228) X(229) X(230) X(231) X(232) X(233) X(234) X(235) X(236) X(237) X(238) X(239) X(240) X(241) X(242) X(243) X(244) X(245) X(246) X(247) X(248) X(249) X(250) X(251) X(252) X(253) X(254)
+// -DDG16_ACC_CLOBBER_R5: round 5's declaration (two registers named, nothing on the writes) -- the NEGATIVE CONTROL of
+// tools/abort_hunt.sh and tests/test_kernel_isa.py: built that way the 14-limb G2 finalize collides again, and
+// tools/check_agpr_file.py must say so (the Makefile then refuses the object: pass AGPR_CHECK=../../tools/true.py to get the
+// library anyway).
+#ifdef DG16_ACC_CLOBBER_R5
+#define DG_ACC_WRITE_CLOBBER(n)
+#else
+#define DG_ACC_WRITE_CLOBBER(n) : "a" #n
+#endif
 template <int R> struct AccReg;
 #define X(n)                                                                                             \
   template <> struct AccReg<n> {                                                                         \
     static __device__ __forceinline__ void w(uint32_t v) {                                               \
-      asm volatile("v_accvgpr_write_b32 a" #n ", %0" ::"v"(v) : "a" #n);                                 \
+      asm volatile("v_accvgpr_write_b32 a" #n ", %0" ::"v"(v) DG_ACC_WRITE_CLOBBER(n));                  \
     }                                                                                                    \
     static __device__ __forceinline__ uint32_t r() {                                                     \
       uint32_t v;                                                                                        \
@@ -930,7 +939,11 @@ DG_ACC_REGS_LO(X) DG_ACC_REGS_HI(X) X(255)
 #undef X
 // all registers of the file, for the kernel's one declaration (resource accounting: the wave is allocated them)
 #define X(n) "a" #n,
+#ifdef DG16_ACC_CLOBBER_R5
+#define DG_ACC_FILE_CLOBBERS "a144", "a255"
+#else
 #define DG_ACC_FILE_CLOBBERS DG_ACC_REGS_LO(X) DG_ACC_REGS_HI(X) "a255"
+#endif
 template <int BASE, int N, class P, int B, int... I>
 __device__ __forceinline__ void acc_set_seq(const Fe2<P, B, 1>& v, std::integer_sequence<int, I...>) {
   ((AccReg<BASE + I>::w(v.c0.l[I]), AccReg<BASE + N + I>::w(v.c1.l[I])), ...);
@@ -952,7 +965,6 @@ __device__ __forceinline__ Fe2<P, B, 1> acc_get() {
   acc_get_seq<kAccFileBase + 2 * N * SLOT, N>(v, std::make_integer_sequence<int, N>{});
   return v;
 }
-#ifdef DG16_FINALIZE_STEPS   // the withdrawn round-5 form of the 14-limb G2 finalize, for the abort repro only
 // d += b (full XYZZ addition, XYZZ29::add_into) as a STEP LOOP over the same three product sites: the 14-limb G2 finalize
 // (msm_finalize_lds_kernel: two lanes per bucket summing the bucket's partials) inlined a 144-KB addition -- 35 900
 // instructions with its doubling branch -- and ran at 16 % of its issue rate on the slow boxes of the pool.
@@ -1047,7 +1059,6 @@ __device__ __forceinline__ void xyzz_add_into_steps(const D& d, const B& b_) {
   }
 }
 
-#endif
 template <class F, int BLOCK>
 __global__ void __launch_bounds__(BLOCK, 1)
 msm_accumulate_steps_kernel(MsmBases bases, size_t n, MsmGeom g,
@@ -1917,10 +1928,8 @@ struct PartialAcc {      // an XYZZ29 behind the accessor interface of XYZZ29::a
     if (p) return coord == 0 ? p->x : coord == 1 ? p->y : coord == 2 ? p->zz : p->zzz;
     return col.get(coord);
   }
-#ifdef DG16_FINALIZE_STEPS
   // the pointer as a value the compiler cannot trace (xyzz_add_into_steps: keeps address arithmetic inside the step)
   __device__ __forceinline__ void launder() { asm volatile("" : "+v"(p)); }
-#endif
 };
 template <class F, int BLOCK>
 __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 ? 2 : 1))
@@ -1933,9 +1942,7 @@ msm_finalize_lds_kernel(MsmGeom g, size_t total, unsigned wg_log, unsigned lpb_l
   constexpr int WORDS = sizeof(typename FO::Store) / 4;
   __shared__ uint32_t sh[4 * WORDS][BLOCK];
   __shared__ unsigned max_serial;
-#ifdef DG16_FINALIZE_STEPS
   if constexpr (sizeof(F) > 64) asm volatile("" ::: DG_ACC_FILE_CLOBBERS);   // xyzz_add_into_steps' temporaries (acc_set / acc_get)
-#endif
   const unsigned LPB = 1u << lpb_log;
   const unsigned lane = threadIdx.x, sub = lane & (LPB - 1);
   const size_t gid = ((size_t)blockIdx.x * BLOCK + lane) >> lpb_log;
@@ -1980,15 +1987,12 @@ msm_finalize_lds_kernel(MsmGeom g, size_t total, unsigned wg_log, unsigned lpb_l
     if (on) {
       const PartialAcc<F, BLOCK> b{tree ? nullptr : &sp[DG_IDX(7, msm_part_slot(first, lo + 1 + step, wg_log), g.seg_cap)],
                                    ColAcc<F, BLOCK>{sh, (unsigned)DG_IDX(10, lane + d, BLOCK)}};
-      // (14-limb Fq2: the same addition as a step loop over the accumulation's three product sites -- 35 900 -> 22 700
-      // instructions, emulated against the oracle, 23.2 -> 22.9 ms per BLS12-381 proof on a fast box -- was withdrawn in
-      // round 5: one box of the pool aborted with HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION behind this kernel
-      // (profiles/r5r_*), unexplained and not reproducible on the next box)
-#ifdef DG16_FINALIZE_STEPS
+      // 14-limb Fq2: the addition as a step loop over the accumulation's three product sites (35 900 -> 22 700
+      // instructions; 21.8 -> 21.5 ms per BLS12-381 2^20 proof, same call, twice: profiles/r6b_finalize_steps_ab.txt).
+      // Withdrawn in round 5 behind an HSA aperture violation, back in round 6 with its cause removed: hipcc had put
+      // sixteen of its own spills into the temporaries' register file (kAccFileBase).
       if constexpr (sizeof(F) > 64) xyzz_add_into_steps<F>(me, b);
-      else
-#endif
-      XYZZ29<F>::add_into(me, b);
+      else XYZZ29<F>::add_into(me, b);
     }
   }
   if (work && sub == 0) {
@@ -2227,7 +2231,16 @@ void msm_run(Call& k, const void* bases, const void* scalars, size_t n, unsigned
       if constexpr (DIM == 2) {
         hipLaunchKernelGGL((glv_split_kernel<Fr, GC>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, k.s(),
                            (const Fr*)scalars, n, (int)scalars_mont, halves);
-        st = msm_sort<Fr, kGlvBits>(k, halves, 2 * n, 2u, false);
+        // Window width at SMALL sizes (round 6, profiles/r6b_msm_window_sweep.txt): the halves have 127 + 1 bits, and a
+        // width of 7 or 9 (what log2(2 n) - 4 gives at n = 2^10 / 2^12) leaves a top window of two bits whose few buckets
+        // turn giant -- 8 divides 128: BN254 G1 2^10 0.663 -> 0.606 ms, 2^12 0.685 -> 0.649; G2 1.68 -> 1.47, 1.92 -> 1.62
+        // (same call).  The 14-limb G1 groups measured the other way (2^12: 1.33 -> 1.49 ms) and keep the rule.
+        unsigned c_small = 0;
+        if constexpr (RR<typename FieldOf<F>::Params>::N == 9) {
+          const unsigned c0 = msm_window_bits(2 * n, false);
+          if ((c0 == 7 || c0 == 9) && !getenv("DG16_MSM_C")) c_small = 8;
+        }
+        st = msm_sort<Fr, kGlvBits>(k, halves, 2 * n, 2u, false, c_small);
       } else {
         hipLaunchKernelGGL((glv_split4_kernel<Fr, GC>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, k.s(),
                            (const Fr*)scalars, n, (int)scalars_mont, halves);

@@ -18,12 +18,21 @@
 //
 // Roofline: 64 B/element algorithmic traffic, but ~10 Montgomery multiplications per element -- the kernel is
 // VALU-bound, not HBM-bound.
+#include <cstdio>
 #include <cstdlib>
 #include "ctx.h"
 #include "fp29.h"
 #include "types.h"
 
 namespace dg16 {
+
+// DG16_VERBOSE=1: say so when an OPTIONAL table could not be allocated (the transform then runs its composed-twiddle
+// form: correct, a few percent slower) -- otherwise that path is indistinguishable from the fast one
+static void optional_table_skipped(const char* what, size_t bytes) {
+  static const bool verbose = [] { const char* e = getenv("DG16_VERBOSE"); return e && atoi(e) != 0; }();
+  if (verbose) fprintf(stderr, "[dg16] %s (%zu bytes) not built: hipMalloc failed; using the composed form\n", what, bytes);
+}
+
 
 constexpr unsigned kTileLog = 10;         // 1024 elements per workgroup
 constexpr unsigned kTile = 1u << kTileLog;
@@ -483,6 +492,7 @@ static const TwiddleSet& get_twiddles(Call& k, int curve, unsigned log_n, int in
       if (hipMalloc(&ts.full[j], cnt * sizeof(F)) != hipSuccess) {
         (void)hipGetLastError();
         ts.full[j] = nullptr;
+        optional_table_skipped("inter-step twiddle table", cnt * sizeof(F));
         consumed += pl.s[j];
         continue;
       }
@@ -634,11 +644,14 @@ template <class F>
 static const F* flat_shift_table(Call& k, const TwiddleSet& t2, unsigned log_m) {
   std::lock_guard<std::mutex> g(k.ctx->mu);
   TwiddleSet& w = const_cast<TwiddleSet&>(t2);       // (the cache entry; guarded by ctx->mu like its creation)
-  if (!w.shift_full) {
+  if (!w.shift_full && !w.shift_full_tried) {
+    w.shift_full_tried = true;      // ONE attempt per cache entry: a failing hipMalloc of up to 0.5 GB under ctx->mu on every
+                                    // h-polynomial call is a silent slow path
     const size_t m = (size_t)1 << log_m;
     if (hipMalloc(&w.shift_full, m * sizeof(F)) != hipSuccess) {      // optional table: the split lo x hi form serves
       (void)hipGetLastError();
       w.shift_full = nullptr;
+      optional_table_skipped("w_2m shift table", m * sizeof(F));
       return nullptr;
     }
     hipLaunchKernelGGL(flat_powers_kernel<F>, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, k.s(), (F*)w.shift_full, m,

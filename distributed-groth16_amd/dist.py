@@ -126,8 +126,10 @@ def d_ifft(ctx, pp, net, share, log_m, rearrange, pad, degree2, sid=0):
     return d_fft(ctx, pp, net, share, log_m, rearrange, pad, degree2, inverse=True, sid=sid)
 
 
-def d_msm(ctx, pp, net, group, bases, scalars, scalars_mont=True, sid=0, in_subgroup=True):
-    """in_subgroup: DG16_F_BASES_IN_SUBGROUP (base shares are combinations of CRS points: in the order-r group)."""
+def d_msm(ctx, pp, net, group, bases, scalars, scalars_mont=True, sid=0, in_subgroup=False):
+    """in_subgroup: DG16_F_BASES_IN_SUBGROUP -- pass True when the base shares are combinations of CRS points (packed
+    shares of a proving key are: in the order-r group), so that the local MSM may split its scalars; the default is the
+    C ABI's (flag not set: the result VariableBaseMSM::msm gives for any points of the curve)."""
     bases = np.ascontiguousarray(bases, dtype=np.uint64)
     scalars = _fr(scalars)
     nl = FQ_LIMBS64[pp.curve] * (2 if group == 2 else 1)
@@ -148,12 +150,12 @@ def d_msm_resident(ctx, pp, net, resident_bases, scalars, scalars_mont=True, sid
     return out
 
 
-def dpoly_commit(ctx, pp, net, srs_shares, coeff_shares, scalars_mont=True, sid=0):
+def dpoly_commit(ctx, pp, net, srs_shares, coeff_shares, scalars_mont=True, sid=0, in_subgroup=False):
     """KZG-style commitment to a polynomial held as packed coefficient shares: one `d_msm` of the coefficient
     shares against the packed-in-the-exponent SRS powers [tau^i]_1.  The north star names `dpoly_commit`, but the
     reference has no such module (only the launcher scripts/dpoly_commit_test.zsh:5-7; dist-primitives/src/lib.rs:2-6
     lists dfft, dmsm, dpp, utils, channel) -- there is no behaviour to match beyond d_msm's (dmsm/mod.rs:70-98)."""
-    return d_msm(ctx, pp, net, 1, srs_shares, coeff_shares, scalars_mont=scalars_mont, sid=sid)
+    return d_msm(ctx, pp, net, 1, srs_shares, coeff_shares, scalars_mont=scalars_mont, sid=sid, in_subgroup=in_subgroup)
 
 
 def deg_red(ctx, pp, net, px, sid=0):

@@ -394,11 +394,12 @@ class Context:
                                      channel))
         return out
 
-    def msm(self, curve, group, bases, scalars, scalars_mont=False, affine=False, channel=0, in_subgroup=True):
-        """in_subgroup: DG16_F_BASES_IN_SUBGROUP -- the bases are elements of the order-r group (an arkworks
-        G1Affine / G2Affine that came through Validate::Yes or CRS generation is), so the library may split the
-        scalars with the curve's endomorphism.  Pass False for arbitrary points of the curve (plain Pippenger, like
-        VariableBaseMSM::msm).  The C ABI's default is the flag NOT set."""
+    def msm(self, curve, group, bases, scalars, scalars_mont=False, affine=False, channel=0, in_subgroup=False):
+        """in_subgroup: DG16_F_BASES_IN_SUBGROUP -- the caller's word that the bases are elements of the order-r group
+        (an arkworks G1Affine / G2Affine that came through Validate::Yes or CRS generation is), so the library may split
+        the scalars with the curve's endomorphism (half the Horner tail: 15-20 % of a plain 2^20 MSM).  The default is the
+        C ABI's: flag NOT set, plain Pippenger for every group of cofactor != 1, the group element VariableBaseMSM::msm
+        gives for ANY points of the curve (decoded with validate = 0, say).  BN254 G1 (cofactor one) splits either way."""
         bases = np.ascontiguousarray(bases, dtype=np.uint64)
         scalars = np.ascontiguousarray(scalars, dtype=np.uint64)
         nl = FQ_LIMBS64[curve] * (2 if group == 2 else 1)
@@ -629,7 +630,7 @@ class Context:
 
     # ---- device-pointer API (stream-ordered) ----------------------------------------------------------
     def msm_dev(self, curve, group, bases_ptr, scalars_ptr, n, out_ptr, scalars_mont=False, affine=False,
-                channel=0, n_scalars=None, in_subgroup=True):
+                channel=0, n_scalars=None, in_subgroup=False):
         flags = (F_DEVICE_PTRS | (F_SCALARS_MONT if scalars_mont else 0) | (F_OUT_AFFINE if affine else 0) |
                  (F_BASES_IN_SUBGROUP if in_subgroup else 0))
         self._chk(self.L.dg16_msm(self.h, CURVES[curve], group, _ptr(bases_ptr), _ptr(scalars_ptr), n,
@@ -774,7 +775,7 @@ class TorchComm:
         return self._run(stream, fn)
 
 
-def probe_channels(net_struct, n_parties, party_id, dist, soft_s=2.0, hard_s=120.0, rounds=2):
+def probe_channels(net_struct, n_parties, party_id, dist, soft_s=2.0, hard_s=120.0, rounds=2, device=None):
     """Watchdog for the JOINED form of prove::C (groth16/src/prove.rs:113-125: three d_msm in flight on channels 0 / 1
     / 2, which dg16_prove_c drives from three host threads): before the first proof every party runs a tiny
     gather-to-king + scatter-from-king on each channel of its dg16_net AT ONCE, its three threads started in an order
@@ -784,7 +785,13 @@ def probe_channels(net_struct, n_parties, party_id, dist, soft_s=2.0, hard_s=120
     parallel.make_prover): if ANY party misses the soft deadline, EVERY party gets "serial" and passes
     DG16_F_SERIAL_CHANNELS from then on (the three d_msm one after another, in the order 0, 1, 2 on every party: same
     proof).  A probe that has not finished by the hard deadline is a dead transport: DG16_ERR_NET on every party.
-    -> "joined" | "serial".   net_struct: a NetStruct (TorchNet.struct, or the struct behind dg16_rccl_net)."""
+    -> "joined" | "serial".   net_struct: a NetStruct (TorchNet.struct, or the struct behind dg16_rccl_net).
+
+    device: where the payloads of the net live -- the dg16_net contract is DEVICE pointers plus the stream they were
+    produced on for a GPU net (a TorchNet made with a cuda device, the library's RCCL net: ncclSend from pageable host
+    memory faults), host pointers and a NULL stream only for a CPU-device TorchNet (the gloo tests).  None / "cpu": host
+    buffers; a cuda device: the probe's payloads are torch tensors on it, each channel's thread issues on a stream of its
+    own, and the decision tensor goes to the device when the default group's backend is nccl."""
     import threading
     import time
     import torch
@@ -792,20 +799,39 @@ def probe_channels(net_struct, n_parties, party_id, dist, soft_s=2.0, hard_s=120
     done = [None] * 3
     errs = []
     selfp = getattr(net_struct, "self")          # the vtable's `self` member (NULL for a Python-implemented net)
+    on_gpu = device is not None and torch.device(device).type == "cuda"
 
     def one(c):
         t0 = time.monotonic()
         try:
+            if on_gpu:
+                torch.cuda.set_device(device)
+                stream = torch.cuda.Stream(device=device)
+                sptr = ctypes.c_void_p(stream.cuda_stream)
             for it in range(rounds):
-                send = np.full(nbytes, (16 * c + party_id + it) & 0xFF, dtype=np.uint8)
-                gathered = np.zeros(nbytes * n_parties, dtype=np.uint8)
-                rc = net_struct.gather_to_king(selfp, c, send.ctypes.data, nbytes,
-                                               gathered.ctypes.data if party_id == 0 else None, None)
-                back = np.repeat(np.arange(n_parties, dtype=np.uint8) + 3 * c + it, nbytes) if party_id == 0 else None
-                got = np.zeros(nbytes, dtype=np.uint8)
-                rc2 = net_struct.scatter_from_king(selfp, c, back.ctypes.data if party_id == 0 else None, nbytes,
-                                                   got.ctypes.data, None)
-                if rc or rc2 or not bool((got == (party_id + 3 * c + it) & 0xFF).all()):
+                send_h = np.full(nbytes, (16 * c + party_id + it) & 0xFF, dtype=np.uint8)
+                back_h = np.repeat(np.arange(n_parties, dtype=np.uint8) + 3 * c + it, nbytes) if party_id == 0 else None
+                if on_gpu:
+                    with torch.cuda.stream(stream):
+                        send = torch.from_numpy(send_h).to(device)
+                        gathered = torch.zeros(nbytes * n_parties, dtype=torch.uint8, device=device)
+                        back = torch.from_numpy(back_h).to(device) if party_id == 0 else None
+                        got = torch.zeros(nbytes, dtype=torch.uint8, device=device)
+                    stream.synchronize()
+                    rc = net_struct.gather_to_king(selfp, c, send.data_ptr(), nbytes,
+                                                   gathered.data_ptr() if party_id == 0 else None, sptr)
+                    rc2 = net_struct.scatter_from_king(selfp, c, back.data_ptr() if party_id == 0 else None, nbytes,
+                                                       got.data_ptr(), sptr)
+                    stream.synchronize()
+                    got_h = got.cpu().numpy()
+                else:
+                    gathered = np.zeros(nbytes * n_parties, dtype=np.uint8)
+                    rc = net_struct.gather_to_king(selfp, c, send_h.ctypes.data, nbytes,
+                                                   gathered.ctypes.data if party_id == 0 else None, None)
+                    got_h = np.zeros(nbytes, dtype=np.uint8)
+                    rc2 = net_struct.scatter_from_king(selfp, c, back_h.ctypes.data if party_id == 0 else None, nbytes,
+                                                       got_h.ctypes.data, None)
+                if rc or rc2 or not bool((got_h == (party_id + 3 * c + it) & 0xFF).all()):
                     errs.append("channel %d: rc %d / %d or a payload of another channel" % (c, rc, rc2))
                     return
             done[c] = time.monotonic() - t0
@@ -823,7 +849,8 @@ def probe_channels(net_struct, n_parties, party_id, dist, soft_s=2.0, hard_s=120
     for t in ths:                     # a stalled channel: wait it out (its messages must not meet the real protocol's)
         t.join(max(0.0, hard_s - (time.monotonic() - t_start)))
     alive = any(t.is_alive() for t in ths)
-    flag = torch.tensor([0 if (alive or errs) else (2 if in_time else 1)], dtype=torch.int32)
+    flag_dev = device if (on_gpu and dist.get_backend() == "nccl") else "cpu"    # an nccl group reduces device tensors only
+    flag = torch.tensor([0 if (alive or errs) else (2 if in_time else 1)], dtype=torch.int32, device=flag_dev)
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     v = int(flag.item())
     if v == 0:

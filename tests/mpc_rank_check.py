@@ -66,6 +66,10 @@ if transport == "rccl":
 else:
     net = lib.TorchNet(dist, dev, world, rank, before=before)
     net_ptr = net.net_ptr
+    # the channel watchdog on a GPU net: device payloads, one stream per channel (lib.probe_channels; the CPU form runs in
+    # tests/test_parallel_gloo.py) -- this transport's channels are independent groups, so every party must get "joined"
+    probed = lib.probe_channels(net.struct, world, rank, dist, soft_s=20.0, hard_s=60.0, device=dev)
+    assert probed == "joined", probed
 
 # the statement: the same on every party (seeded), each keeps its own shares
 m = 1 << log_m

@@ -124,7 +124,7 @@ def test_d_msm_equals_clear_msm(curve, group):
     packed_bases = pps[0].packexp_from_public(group, pts_arr.reshape(M // 2, 2, -1))    # [M/l][n][..]
     packed_sc = pps[0].pack_from_public(enc(F, sc).reshape(M // 2, 2, 4))               # [M/l][n][4]
     got = net.simulate_network_round(
-        lambda i, h: D.d_msm(ctxs[i], pps[i], h, group, packed_bases[:, i], packed_sc[:, i]))
+        lambda i, h: D.d_msm(ctxs[i], pps[i], h, group, packed_bases[:, i], packed_sc[:, i], in_subgroup=True))
     aff = [corc.jac_to_affine(curve, group, g) for g in got]
     assert all(np.array_equal(a, clear) for a in aff)
     # unpackexp(packexp(x)) == x (dmsm/mod.rs:127-145)
@@ -174,7 +174,7 @@ def test_dpoly_commit_is_the_kzg_commitment():
     packed_srs = pps[0].packexp_from_public(1, srs.reshape(M // 2, 2, -1))
     packed_c = pps[0].pack_from_public(enc(F, coeffs).reshape(M // 2, 2, 4))
     got = net.simulate_network_round(
-        lambda i, h: D.dpoly_commit(ctxs[i], pps[i], h, packed_srs[:, i], packed_c[:, i]))
+        lambda i, h: D.dpoly_commit(ctxs[i], pps[i], h, packed_srs[:, i], packed_c[:, i], in_subgroup=True))
     p_tau = sum(c * pow(tau, i, F.p) for i, c in enumerate(coeffs)) % F.p
     exp = corc.point_mul(curve, 1, g, p_tau)
     assert all(np.array_equal(corc.jac_to_affine(curve, 1, x), exp) for x in got)
@@ -316,7 +316,7 @@ def test_d_msm_reference_size(curve, log_M):
     packed_sc = pps[0].pack_from_public(sc.reshape(M // 2, 2, 4))                   # [M/l][n][4]
     got = net.simulate_network_round(
         lambda i, h: D.d_msm(ctxs[i], pps[i], h, 1, np.ascontiguousarray(packed_bases[:, i]),
-                             np.ascontiguousarray(packed_sc[:, i])))
+                             np.ascontiguousarray(packed_sc[:, i]), in_subgroup=True))
     assert all(np.array_equal(corc.jac_to_affine(curve, 1, g), clear) for g in got)
 
 

@@ -12,8 +12,16 @@ pytestmark = pytest.mark.gpu
 GROUPS = [("bn254", 1), ("bn254", 2), ("bls12_381", 1), ("bls12_381", 2), ("bls12_377", 1), ("bls12_377", 2)]
 
 
+def gmsm(c, *a, **kw):
+    """dg16_msm WITH DG16_F_BASES_IN_SUBGROUP (the Python default is the C ABI's: flag not set): the test points are
+    multiples of the generator, and the split path is the one a prover's bases take; the tests of the unsplit path pass
+    in_subgroup=False themselves."""
+    kw.setdefault("in_subgroup", True)
+    return c.msm(*a, **kw)
+
+
 def check(curve, group, bases, scalars, **kw):
-    jac = ctx().msm(curve, group, bases, scalars, **kw)
+    jac = gmsm(ctx(), curve, group, bases, scalars, **kw)
     got = corc.jac_to_affine(curve, group, jac)
     exp = corc.msm(curve, group, bases, scalars, scalars_mont=kw.get("scalars_mont", False))
     assert np.array_equal(got, exp)
@@ -144,8 +152,8 @@ def test_msm_2_20_bls12_381(group):
     scalars = corc.rand_field(curve, "fr", 6, n, mont=False)
     full = check(curve, group, bases, scalars)
     h = n // 2 + 12345
-    a = corc.jac_to_affine(curve, group, ctx().msm(curve, group, bases[:h], scalars[:h]))
-    b = corc.jac_to_affine(curve, group, ctx().msm(curve, group, bases[h:], scalars[h:]))
+    a = corc.jac_to_affine(curve, group, gmsm(ctx(), curve, group, bases[:h], scalars[:h]))
+    b = corc.jac_to_affine(curve, group, gmsm(ctx(), curve, group, bases[h:], scalars[h:]))
     assert np.array_equal(corc.point_add(curve, group, a, b), full)
 
 
@@ -169,8 +177,8 @@ def test_msm_edge_cases():
     check(curve, group, bases, corc.field_op(curve, "fr", "to_mont", scalars), scalars_mont=True)
     # all scalars zero -> identity; all-identity bases -> identity
     z = np.zeros_like(scalars)
-    assert not corc.jac_to_affine(curve, group, ctx().msm(curve, group, bases, z)).any()
-    assert not corc.jac_to_affine(curve, group, ctx().msm(curve, group, np.zeros_like(bases), scalars)).any()
+    assert not corc.jac_to_affine(curve, group, gmsm(ctx(), curve, group, bases, z)).any()
+    assert not corc.jac_to_affine(curve, group, gmsm(ctx(), curve, group, np.zeros_like(bases), scalars)).any()
 
 
 def test_msm_reference_degenerate_shape():
@@ -182,6 +190,22 @@ def test_msm_reference_degenerate_shape():
     scalars = corc.ints_to_arr([1] * M, 4)
     got = check(curve, group, bases, scalars)
     assert np.array_equal(got, corc.point_mul(curve, group, g, M))
+
+
+@pytest.mark.parametrize("curve,group,n", [("bls12_381", 2, 1 << 12), ("bls12_377", 2, 1 << 11), ("bn254", 2, 1 << 12),
+                                           ("bls12_381", 1, 1 << 12)])
+def test_all_equal_points_at_a_size_with_giant_buckets(curve, group, n):
+    """dmsm/mod.rs:155-159's shape (M copies of one point) with random scalars at a size where every window has giant
+    buckets and every bucket's partial sums are multiples of ONE point: the finalize's additions keep hitting their
+    doubling and identity branches.  This is the call on which round 5's form of the 14-limb G2 finalize aborted with an
+    HSA aperture violation (a spill register inside the asm statements' register file: DESIGN.md section 7.2;
+    tools/repro_abort.py) -- on both paths, unsplit and split."""
+    one = corc.gen_points(curve, group, 7, 1)
+    bases = np.repeat(one, n, axis=0)
+    sc = corc.rand_field(curve, "fr", 60 + n, n, mont=False)
+    plain = check(curve, group, bases, sc, in_subgroup=False)
+    split = check(curve, group, bases, sc, in_subgroup=True)
+    assert np.array_equal(plain, split)
 
 
 def _doubling_chain(curve, group, seed, n):
@@ -234,12 +258,12 @@ def test_msm_length_mismatch_and_affine_out():
     bases = corc.gen_points(curve, group, 1, 8)
     scalars = corc.rand_field(curve, "fr", 1, 8, mont=False)
     with pytest.raises(dg16_amd.Dg16Error) as e:
-        ctx().msm(curve, group, bases, scalars[:7])
+        gmsm(ctx(), curve, group, bases, scalars[:7])
     assert e.value.code == 1       # DG16_ERR_LENGTH_MISMATCH, like Err(usize) from G::msm
-    aff = ctx().msm(curve, group, bases, scalars, affine=True)
+    aff = gmsm(ctx(), curve, group, bases, scalars, affine=True)
     assert np.array_equal(aff, corc.msm(curve, group, bases, scalars))
     # empty MSM is the identity
-    e0 = ctx().msm(curve, group, bases[:0], scalars[:0])
+    e0 = gmsm(ctx(), curve, group, bases[:0], scalars[:0])
     assert not corc.jac_to_affine(curve, group, e0).any()
 
 
@@ -259,8 +283,8 @@ def test_msm_2_20_config2_and_linearity():
     full = check(curve, group, bases, scalars)
     # size-independent property: MSM(first half) + MSM(second half) == MSM(all)
     h = n // 2
-    a = corc.jac_to_affine(curve, group, ctx().msm(curve, group, bases[:h], scalars[:h]))
-    b = corc.jac_to_affine(curve, group, ctx().msm(curve, group, bases[h:], scalars[h:]))
+    a = corc.jac_to_affine(curve, group, gmsm(ctx(), curve, group, bases[:h], scalars[:h]))
+    b = corc.jac_to_affine(curve, group, gmsm(ctx(), curve, group, bases[h:], scalars[h:]))
     assert np.array_equal(corc.point_add(curve, group, a, b), full)
 
 
@@ -305,7 +329,7 @@ def test_resident_msm_matches_oracle(curve, group, log_n):
         want = corc.msm(curve, group, bases, sc, scalars_mont=mont)
         got = c.msm_resident(hb, sc, scalars_mont=mont, affine=True)
         assert np.array_equal(got.reshape(-1), np.asarray(want).reshape(-1))
-        plain = c.msm(curve, group, bases, sc, scalars_mont=mont, affine=True)
+        plain = gmsm(c, curve, group, bases, sc, scalars_mont=mont, affine=True)
         assert np.array_equal(plain, got)
     if n > 1:
         with pytest.raises(dg16_amd.Dg16Error) as e:
@@ -357,7 +381,7 @@ def test_resident_msm_2e22_rows_in_chunks():
     out = torch.empty((2, 64), dtype=torch.uint8, device=dev)
     hb = c.bases_upload(curve, 1, bases.data_ptr(), n=n, device_ptrs=True)
     c.msm_resident_dev(hb, sc.data_ptr(), n, out[0].data_ptr(), affine=True)
-    c.msm_dev(curve, 1, bases.data_ptr(), sc.data_ptr(), n, out[1].data_ptr(), affine=True)
+    c.msm_dev(curve, 1, bases.data_ptr(), sc.data_ptr(), n, out[1].data_ptr(), affine=True, in_subgroup=True)
     c.sync(0)
     o = out.cpu().numpy()
     assert np.array_equal(o[0], o[1]) and o[0].any()
@@ -381,7 +405,7 @@ def test_resident_msm_2e20_equals_plain_msm():
         out = torch.empty((2, pb), dtype=torch.uint8, device=dev)
         hb = c.bases_upload(curve, group, bases.data_ptr(), n=n, device_ptrs=True)
         c.msm_resident_dev(hb, sc.data_ptr(), n, out[0].data_ptr(), affine=True)
-        c.msm_dev(curve, group, bases.data_ptr(), sc.data_ptr(), n, out[1].data_ptr(), affine=True)
+        c.msm_dev(curve, group, bases.data_ptr(), sc.data_ptr(), n, out[1].data_ptr(), affine=True, in_subgroup=True)
         c.sync(0)
         o = out.cpu().numpy()
         assert np.array_equal(o[0], o[1]) and o[0].any()

@@ -286,7 +286,10 @@ def test_g2_finalize_workgroup(curve):
     accumulation: each lane adds its share of the bucket's partial sums into an accumulator in LDS columns --
     XYZZ29::add_into with the four-product Y3, ONE addition site for the serial partials and the tree partners --, then
     one tree step across the two lanes behind a barrier) on the Workgroup emulator:
-    buckets with 5, 2, 1 and 0 partials, partials in XYZZ form with Z != 1 -> the buckets the oracle's sums predict."""
+    buckets with 5, 2, 1 and 0 partials, partials in XYZZ form with Z != 1 -> the buckets the oracle's sums predict.
+    Round 6: also a bucket whose two partials are THE SAME group element in two representations (the addition's doubling
+    branch: what the all-equal-points shape of dmsm/mod.rs:155-159 does to every bucket, and where round 5's form of the
+    14-limb kernel used a clobbered spill register as an address) and one whose partials are P and -P (the identity)."""
     import random
     from oracle.pyref.curves import CURVES
     C = CURVES[curve, "g2"]
@@ -306,7 +309,8 @@ def test_g2_finalize_workgroup(curve):
     mem = wg.mem
     rng = random.Random(11)
     log_nb, seg_log = 4, 4
-    parts = {2: 5, 5: 2, 9: 1, 12: 0}                         # bucket -> number of partial sums (segments)
+    parts = {2: 5, 5: 2, 7: 2, 9: 1, 11: 2, 12: 0}            # bucket -> number of partial sums (segments)
+    same, opposite = 7, 11                                    # ... whose two partials are P, P / P, -P
     expect, slot = {}, 0
 
     def limbs(v):
@@ -319,7 +323,10 @@ def test_g2_finalize_workgroup(curve):
         mem[SOFF + 4 * b] = slot
         total = None
         for s in range(k):
-            P = C.mul(C.gen, rng.randrange(1, 1000))
+            if s == 0 or b not in (same, opposite):
+                P = C.mul(C.gen, rng.randrange(1, 1000))
+            elif b == opposite:
+                P = C.neg(P)
             z = (rng.randrange(1, p), rng.randrange(p))
             zz = F2.sqr(z)
             zzz = F2.mul(zz, z)

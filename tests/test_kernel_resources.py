@@ -48,8 +48,12 @@ def test_g2_bucket_accumulation_stages_through_lds_without_spilling():
     # since the products are chains neither scratch (BN254: was 16 B) nor a full AGPR file + scratch (BLS12-377)
     for k, r in find("msm_finalize_lds_kernel<Fp2<bn254_fq>,256>").items():
         assert r["occupancy"] == 2 and r["scratch"] == 0 and r["agprs"] == 0, k
+    # 14-limb G2: the addition is a step loop again (xyzz_add_into_steps; round 6) with its temporaries in a[144..255]: the
+    # kernel is allocated the whole file, hipcc's own spills stay below it (csrc/Makefile checks the assembly) and what does
+    # not fit there is a few words of scratch -- round 5's form had NO scratch because sixteen of the compiler's spills sat
+    # inside the file (the aperture violation)
     for k, r in find("msm_finalize_lds_kernel<Fp2<bls12_").items():
-        assert r["scratch"] <= 192 and r["agprs"] <= 128, k
+        assert r["scratch"] <= 96 and r["agprs"] == 256 and r["vgprs"] <= 256, (k, r)
 
 
 def test_proof_assembly_keeps_its_chains_in_registers():

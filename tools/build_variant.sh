@@ -9,7 +9,7 @@ work=/tmp/dg16_variant_$name
 rm -rf $work; mkdir -p $work/distributed-groth16_amd $work/include
 cp -r $root/distributed-groth16_amd/csrc $work/distributed-groth16_amd/
 cp $root/include/*.h $work/include/
-mkdir -p $work/tools && cp $root/tools/check_agpr_file.py $work/tools/
+mkdir -p $work/tools && cp $root/tools/check_agpr_file.py $root/tools/true.py $work/tools/
 rm -f $work/distributed-groth16_amd/csrc/*.o $work/distributed-groth16_amd/csrc/*.usage.txt
 make -s -j"$(nproc)" -C $work/distributed-groth16_amd/csrc XFLAGS="$xflags" "$@"
 cp $work/distributed-groth16_amd/libdg16.so $root/distributed-groth16_amd/libdg16_$name.so

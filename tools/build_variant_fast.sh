@@ -8,7 +8,7 @@ work=/tmp/dg16_variant_$name
 rm -rf $work; mkdir -p $work/distributed-groth16_amd $work/include
 cp -a $root/distributed-groth16_amd/csrc $work/distributed-groth16_amd/
 cp -a $root/include/*.h $work/include/
-mkdir -p $work/tools && cp $root/tools/check_agpr_file.py $work/tools/
+mkdir -p $work/tools && cp $root/tools/check_agpr_file.py $root/tools/true.py $work/tools/
 cd $work/distributed-groth16_amd/csrc
 for o in "$@"; do rm -f $o; done
 make -s -j"$(nproc)" XFLAGS="$xflags"

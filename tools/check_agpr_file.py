@@ -6,7 +6,9 @@ compiler's own v_accvgpr_write from acc_set's) and fails if, in any kernel whose
 instruction OF THE COMPILER'S OWN names an accumulation register inside it.  That collision was round 5's
 HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION.  csrc/Makefile runs this on every msm_group object.
 
-usage: check_agpr_file.py file.s [file base, default 144]      exit status 1 on a collision
+usage: check_agpr_file.py file.s [report.txt]      exit status 1 on a collision
+(report: one line per kernel that names accumulation registers -- kernel, asm range, highest register of the compiler's
+own; tests/test_kernel_isa.py reads it)
 import: collisions(path, base) -> {kernel: sorted registers}, usage(path) -> {kernel: (asm regs, compiler regs)}"""
 import re
 import sys
@@ -53,7 +55,12 @@ def collisions(path, base=144):
 
 
 if __name__ == "__main__":
-    base = int(sys.argv[2]) if len(sys.argv) > 2 else 144
+    base = 144
+    if len(sys.argv) > 2:
+        with open(sys.argv[2], "w") as f:
+            for fn, (asm, cc) in sorted(usage(sys.argv[1]).items()):
+                f.write("%s asm %s compiler_max %s\n" % (fn, ("%d-%d" % (min(asm), max(asm))) if asm else "-",
+                                                       max(cc) if cc else "-"))
     bad = collisions(sys.argv[1], base)
     for fn, regs in bad.items():
         print("check_agpr_file: %s: the compiler allocated a[%d..%d] (%d registers) inside the asm statements' file a[%d..255]"

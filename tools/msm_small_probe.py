@@ -29,16 +29,16 @@ for log_n in logs:
     out = torch.empty(3 * FQB * group, dtype=torch.uint8, device=dev)
     torch.cuda.synchronize()
     for _ in range(3):
-        ctx.msm_dev(curve, group, bases.data_ptr(), sc.data_ptr(), n, out.data_ptr())
+        ctx.msm_dev(curve, group, bases.data_ptr(), sc.data_ptr(), n, out.data_ptr(), in_subgroup=True)
     ctx.sync(0)
     t0 = time.perf_counter()
     for _ in range(reps):
-        ctx.msm_dev(curve, group, bases.data_ptr(), sc.data_ptr(), n, out.data_ptr())
+        ctx.msm_dev(curve, group, bases.data_ptr(), sc.data_ptr(), n, out.data_ptr(), in_subgroup=True)
     ctx.sync(0)
     queued = (time.perf_counter() - t0) / reps * 1e3
     t0 = time.perf_counter()
     for _ in range(reps):
-        ctx.msm_dev(curve, group, bases.data_ptr(), sc.data_ptr(), n, out.data_ptr())
+        ctx.msm_dev(curve, group, bases.data_ptr(), sc.data_ptr(), n, out.data_ptr(), in_subgroup=True)
         ctx.sync(0)
     single = (time.perf_counter() - t0) / reps * 1e3
     print("%s G%d 2^%d: %.3f ms per call queued, %.3f ms synchronised (event-timed call %.3f ms)"

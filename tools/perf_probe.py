@@ -65,7 +65,7 @@ if what in ("msm", "msm2"):
     ctx.gen_bases_dev(curve, group, int(os.environ.get('SEED', '2')), n, bases.data_ptr())
     scal = witness_fr(n)
     out = torch.empty(3 * FQB * group, dtype=torch.uint8, device=dev)
-    best, avg = timed(lambda: ctx.msm_dev(curve, group, bases.data_ptr(), scal.data_ptr(), n, out.data_ptr()))
+    best, avg = timed(lambda: ctx.msm_dev(curve, group, bases.data_ptr(), scal.data_ptr(), n, out.data_ptr(), in_subgroup=True))
     print("msm G%d 2^%d: best %.3f ms avg %.3f ms  -> %.1f Mpts/s ; accumulate kernel %.3f ms" %
           (group, log_n, best * 1e3, avg * 1e3, n / best / 1e6, ctx.last_kernel_ms(0, 1)))
 elif what == "ntt":

@@ -19,7 +19,8 @@ def load():
     for path in sorted(glob.glob(os.path.join(CSRC, "*.usage.txt"))):
         cur = None
         for line in open(path, errors="replace"):
-            m = re.search(r"remark:\s+(.*?): (\S+) \[-Rpass-analysis", line)
+            # ("file:line:col: remark: key: value" from a plain compile, "remark: file:line:col: key: value" under -save-temps)
+            m = re.search(r"remark:\s+(?:\S+:\d+:\d+:\s+)?(.*?): (\S+) \[-Rpass-analysis", line)
             if not m:
                 continue
             key, val = m.group(1).strip(), m.group(2)
