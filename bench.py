@@ -71,17 +71,21 @@ def calibrate(device):
     out = {}
     t0 = time.perf_counter()
     for wps in (8, 2):
-        buf = (ctypes.c_double * 4)()
-        rc = lib.dg16_calib_mad_rate(device, wps, 4096, buf)
+        buf = (ctypes.c_double * 6)()
+        rc = lib.dg16_calib_mad_rate(device, wps, 12288, buf)      # ~3 ms per run: the length of the kernels it prices
         if rc != 0:
             return None
-        out[wps] = (buf[0], buf[1], buf[2])
-    return {"mad_issue_T_lane_ops_per_s": out[8][0], "mad_issue_T_at_2_waves_per_simd": out[2][0],
+        out[wps] = tuple(buf)
+    cus = int(out[8][3])
+    return {"mad_issue_T_lane_ops_per_s": out[8][0], "mad_issue_T_fastest_slowest_of_5": [out[8][4], out[8][5]],
+            "mad_issue_T_at_2_waves_per_simd": out[2][0],
             "sclk_under_mad_load_mhz": out[8][1], "sclk_under_mad_load_mhz_at_2_waves_per_simd": out[2][1],
+            "issue_bound_at_that_clock_T": 16.0 * 4 * cus * out[8][1] * 1e6 / 1e12,
             "kernel_ms": out[8][2], "box_factor": out[8][0] / MAD_ISSUE_T, "reference_T": MAD_ISSUE_T,
             "seconds": time.perf_counter() - t0,
-            "source": "in-run: csrc/calib.hip (16 independent v_mad_u64_u32 x 4096 rounds per lane, 8 waves per SIMD on "
-                      "every CU, best of three after a warm-up; clock = s_memtime / s_memrealtime x 100 MHz over the kernel)"}
+            "source": "in-run: csrc/calib.hip (16 independent v_mad_u64_u32 x 12288 rounds per lane, 8 waves per SIMD on every "
+                      "CU, a warm-up then the median of five ~3-ms runs; clock = s_memtime / s_memrealtime x 100 MHz over the "
+                      "kernel; issue_bound = 16 lanes per SIMD-cycle x 4 SIMDs x CUs x that clock)"}
 
 
 def valu_constants(curve):
@@ -579,9 +583,42 @@ def extras(ctx, dev, wl, curve, res):
     res["msm_pts_per_s"] = msm
     res["msm_cpu_port"] = msm_cpu_port(curve, wl, w_host)
     res["msm_sweep"] = msm_sweep(ctx, dev)
-    if not msm_ok or "FAIL" in json.dumps(res["msm_sweep"]):
+    try:
+        res["dmsm_sweep"] = dmsm_sweep(dev)
+    except Exception as e:      # noqa: BLE001 -- a secondary figure must not take the line with it
+        res["dmsm_sweep"] = {"error": repr(e)}
+    if not msm_ok or "FAIL" in json.dumps(res["msm_sweep"]) or "FAIL" in json.dumps(res["dmsm_sweep"]):
         print(json.dumps(res))
         raise SystemExit("a timed MSM differs from the oracle's")
+    # A proof WITHOUT window tables (dg16_ctx_set_table_budget below one row: the key keeps the plain bases, every MSM is
+    # the fresh-bases Pippenger with its bucket sets per window and its Horner tail) -- what the resident tables buy,
+    # and what a key that does not fit HBM costs; same instance, must be the same proof
+    user_budget = getattr(ctx, "table_budget", 0)
+    try:
+        ctx.set_table_budget(1)
+        cold = Workload(ctx, dev, wl.log_m, 0, 1, curve=curve, share=wl, h_sharded=False)
+        ctx.set_table_budget(user_budget)
+        want = gpu_proof_affine(curve, prove_once(ctx, wl))
+        got = prove_once(ctx, cold)
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            got = prove_once(ctx, cold)
+            ts.append(time.perf_counter() - t0)
+        ok = all(np.array_equal(x, y) for x, y in zip(gpu_proof_affine(curve, got), want))
+        cinfo = cold.pk.info()
+        res["tableless_proof"] = {"ms_per_proof": min(ts) * 1e3, "constraints_per_s": wl.nc / min(ts),
+                                  "key_bytes": cinfo["table_bytes"], "key_table_stride": cinfo["table_stride"],
+                                  "key_build_s": cold.pk_build_s,
+                                  "parity_check": "pass (== the proof of the resident-table key)" if ok else "FAIL",
+                                  "note": "one row per table = the plain bases (table budget 1 byte); each step includes "
+                                          "the device-to-host copy of the proof"}
+        cold.pk.close()
+        del cold
+        if not ok:
+            raise SystemExit("the table-less proof differs from the resident-table proof")
+    finally:
+        ctx.set_table_budget(user_budget)
     # BASELINE config 4: sha256-shaped prove (29 823 wires, 2 instance variables, domain 2^15; the real r1cs is a
     # missing blob of the reference tree: SURVEY.md section 0), parity against the oracle, r = s = 0 and random
     if curve == "bn254":
@@ -662,6 +699,63 @@ def msm_sweep(ctx, dev):
         rows.append({"log_n": log_n, "gpu_ms": call_ms, "gpu_pts_per_s": n / (call_ms * 1e-3), "cpu_port_ms": t_cpu * 1e3,
                      "cpu_port_pts_per_s": n / t_cpu, "parity": "pass" if ok else "FAIL"})
     return {"curve": "bls12_377 G1 (msm_bench.rs)", "cpu_port_cores": cpu_threads(), "rows": rows}
+
+
+def dmsm_sweep(dev, budget_s=25.0):
+    """dist-primitives/examples/dmsm_bench.rs:40-53: d_msm over BLS12-377 G1 for domains 2^10 .. 2^19, packed sharing
+    with l = 2 (PackedSharingParams::new(2): n = 8 parties -- the example's local testnet of 4 cannot feed an 8-share
+    unpack, dmsm_test.rs:62-77 runs the same call with 8), every party's bases and scalars `dom.size()` long.  Here: the
+    8 parties are host threads with a context each on THIS GPU (dist.LocalTestNet = mpc-net's LocalTestNet), shares in
+    host memory as in the example; a row = wall time of one network round (all parties' local MSMs, gather to the king,
+    unpack / pack in the exponent, scatter), best of 3.  The shares are PACKINGS of 2 x dom.size() clear points and
+    scalars, so every round is checked: each party's result == the oracle's clear MSM (dmsm/mod.rs:147-193).  Sizes stop
+    early when the sweep has used `budget_s` seconds (the default bench run must stay within minutes)."""
+    import dg16_amd
+    from dg16_amd import dist as D
+    from oracle import corc
+    curve, l = "bls12_377", 2
+    n = 4 * l
+    ctxs = [dg16_amd.Context(dev.index or 0) for _ in range(n)]
+    pps = [D.PackedSharingParams(c, curve, l) for c in ctxs]
+    net = D.LocalTestNet(n)
+    rows, t_start = [], time.perf_counter()
+    try:
+        for log_d in range(10, 20):
+            if time.perf_counter() - t_start > budget_s:
+                break
+            d = 1 << log_d
+            M = d * l
+            pts = ctxs[0].gen_bases(curve, 1, 1000 + log_d, M)
+            sc = corc.rand_field(curve, "fr", 2000 + log_d, M, mont=True)
+            t0 = time.perf_counter()
+            clear = corc.msm(curve, 1, pts, sc, scalars_mont=True, threads=cpu_threads())
+            t_cpu = time.perf_counter() - t0
+            pb = pps[0].packexp_from_public(1, pts.reshape(d, l, -1))          # [d][n][..]
+            ps = pps[0].pack_from_public(sc.reshape(d, l, 4))                  # [d][n][4]
+            shares = [(np.ascontiguousarray(pb[:, i]), np.ascontiguousarray(ps[:, i])) for i in range(n)]
+            del pb, ps
+            best, got = None, None
+            for _ in range(3):
+                t0 = time.perf_counter()
+                got = net.simulate_network_round(
+                    lambda i, h: D.d_msm(ctxs[i], pps[i], h, 1, shares[i][0], shares[i][1], in_subgroup=True))
+                dt = time.perf_counter() - t0
+                best = dt if best is None else min(best, dt)
+            ok = all(np.array_equal(corc.jac_to_affine(curve, 1, g), clear) for g in got)
+            rows.append({"log_domain": log_d, "points_per_party": d, "round_ms": best * 1e3,
+                         "party_pts_per_s": n * d / best, "clear_msm_cpu_port_ms": t_cpu * 1e3,
+                         "parity": "pass" if ok else "FAIL"})
+            if not ok:
+                break
+    finally:
+        net.close()
+        for p_ in pps:
+            p_.close()
+        for c in ctxs:
+            c.close()
+    return {"shape": "d_msm, BLS12-377 G1, l = 2, 8 parties as host threads on one GPU (dmsm_bench.rs:40-53), host-memory "
+                     "shares; round_ms = one simulate_network_round, best of 3",
+            "cpu_port_cores": cpu_threads(), "rows": rows}
 
 
 def host_pointer_figure(ctx, wl, prover, steps):
@@ -763,6 +857,19 @@ def host_pointer_pipelined(ctx, wl, prover, steps, w_host, want_proof_host):
         wl.w = keep_w
 
 
+def pmc_traffic(curve):
+    """(G2 traffic, G1 traffic, source) per launch from the committed summary of the separate rocprofv3 --pmc passes over
+    2^20 proofs of `curve` (tools/evidence_run.sh, tools/pmc_json.py); (None, None, None) if there is none."""
+    for name in {"bls12_381": ("r6_pmc_bls12_381_accumulate.json",)}.get(curve, ()):
+        path = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(path):
+            with open(path) as f:
+                pj = json.load(f)
+            return (pj["traffic_bytes_per_launch"], pj.get("g1_traffic_bytes_per_launch"),
+                    "profiles/%s (%s)" % (name, pj.get("correction", "")))
+    return None, None, None
+
+
 def timed_prove_with_parity(ctx, dev, curve, log_m, steps):
     wl5 = Workload(ctx, dev, log_m, 0, 1, seed=21, curve=curve)
     prove_once(ctx, wl5)
@@ -771,6 +878,7 @@ def timed_prove_with_parity(ctx, dev, curve, log_m, steps):
     for _ in range(steps):
         gp = prove_once(ctx, wl5)
     dt = (time.perf_counter() - t0) / steps
+    g2_ms, g1_ms = ctx.last_kernel_ms(2, 1), ctx.last_kernel_ms(1, 1)      # the accumulations of the last timed proof
     (A, B, C), t_cpu = oracle_prove(wl5, cpu_threads())
     gA, gB, gC = gpu_proof_affine(curve, gp)
     ok = bool(np.array_equal(A, gA) and np.array_equal(B, gB) and np.array_equal(C, gC))
@@ -780,6 +888,22 @@ def timed_prove_with_parity(ctx, dev, curve, log_m, steps):
            "key_table_bytes": info["table_bytes"], "key_table_build_s": wl5.pk_build_s,
            "workload": "%s Groth16 prove from the matrices, 2^%d - 2 constraints, 2^%d wires, r, s != 0; each step "
                        "includes the device-to-host copy of the proof" % (curve.upper(), log_m, log_m)}
+    if curve == "bls12_381":
+        # the dominant kernels of THIS curve against both roofs (the 14-limb forms: 10 584 / 3 542 v_mad_u64_u32 per G2 / G1
+        # mixed addition, 224 / 128 algorithmic bytes per point), traffic from the committed PMC passes when log_m = 20
+        g1_mads, g2_mads, _ = add_mads(curve)
+        n_pts = info["n_ab"]
+        nwin = (SCALAR_BITS[curve] + 1 + info["c_ab"] - 1) // info["c_ab"]
+        tr2, tr1, src = pmc_traffic(curve) if log_m == 20 else (None, None, None)
+        for key, ms, alg, mads, tr, kern in (("roofline", g2_ms, 224.0, g2_mads, tr2, "msm_accumulate_steps_kernel<Fp2<bls12_381_fq>>"),
+                                             ("roofline_g1", g1_ms, 128.0, g1_mads, tr1, "msm_accumulate_kernel<Fp<bls12_381_fq>>")):
+            if not ms:
+                continue
+            ach = alg * n_pts / (ms * 1e-3) / 1e9
+            out[key] = {"bound": "hbm", "kernel": kern, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": ach / HBM_PEAK_GBS, "traffic": tr, "traffic_source": src, "kernel_ms": ms,
+                        "points_per_launch": n_pts,
+                        "mad_T_lane_ops_per_s": float(mads) * n_pts * nwin / (ms * 1e-3) / 1e12}
     wl5.pk.close()
     del wl5
     torch.cuda.empty_cache()
@@ -823,6 +947,9 @@ def main():
     ap.add_argument("--no-overlap", action="store_true",
                     help="N = 1: do not pass DG16_F_OVERLAP_TAIL (each proof's last bucket reduction and assembly then "
                          "finish on channel 0 before the next proof's first kernel, as in rounds 1-3)")
+    ap.add_argument("--dist-overlap", action="store_true",
+                    help="N > 1: pass DG16_F_OVERLAP_TAIL to dg16_groth16_prove_dist (the queue of sharded proofs overlaps each "
+                         "proof's last reduction, all-gather and assembly with the next proof's first stage)")
     ap.add_argument("--shards-in-process", type=int, default=0, metavar="N",
                     help="N = 1 only: prove the instance over N shard keys (2, 4, 8) held by THIS process -- config 5's "
                          "data path (cyclic h shards, dg16_qap_rows, three h stages, N records, assembly) with device "
@@ -892,7 +1019,11 @@ def main():
     # N = 1: the timed region is a QUEUE of proofs on one context, so each is issued with DG16_F_OVERLAP_TAIL -- its
     # last (H) bucket reduction, assembly and copy-out run on channel 2's stream under the next proof's R1CS x witness
     # and h-polynomial.  `single_proof_ms` of the line is the same call followed by a synchronisation every time.
-    overlap = world == 1 and not args.no_overlap and hasattr(prover, "overlap_tail")
+    # N > 1: the same flag on dg16_groth16_prove_dist (round 6: H's reduction, the all-gather and the assembly under the next
+    # proof's first stage) -- only with --dist-overlap: the all-gather then shares a communicator with the all-to-alls from
+    # another stream, which no run between two devices has exercised yet (per-rank work on one GPU, loopback comm: 3.0 ->
+    # 2.6 ms at 8 shards, tools/shard_timing.py with DG16_OVERLAP=1)
+    overlap = (world == 1 or args.dist_overlap) and not args.no_overlap and hasattr(prover, "overlap_tail")
     if overlap:
         prover.overlap_tail = True
 
@@ -905,7 +1036,13 @@ def main():
             ctx.sync(ch)
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    # time to first proof: what a prover that has just loaded a key waits for -- the window tables (pk_build_s, in
+    # Workload) plus the first proof on a cold context (workspace allocations, twiddle tables, code objects)
+    t_first = time.perf_counter()
+    step()
+    full_sync()
+    first_proof_s = time.perf_counter() - t_first
+    for _ in range(max(0, args.warmup - 1)):
         step()
     full_sync()
     # the roof of THIS box in THIS run (every rank measures its own GPU; rank 0's figures go on the line)
@@ -976,7 +1113,9 @@ def main():
     # HBM traffic of that kernel: PMC counters cannot be read from inside the process; the committed summary of
     # the separate rocprofv3 --pmc passes over the same launch (same curve, group, size) supplies it.
     traffic, traffic_src, traffic_g1 = None, None, None
-    for name in ("r5_pmc_g2_accumulate.json", "r4v_pmc_g2_accumulate.json", "r4p_pmc_g2_accumulate.json", "r4l_pmc_g2_accumulate.json", "r4f_pmc_g2_accumulate.json", "r4a_pmc_g2_accumulate.json", "r3_pmc_g2_accumulate.json", "r2_pmc_g2_accumulate.json",
+    if curve == "bls12_381" and args.log_m == 20 and world == 1:
+        traffic, traffic_g1, traffic_src = pmc_traffic("bls12_381")
+    for name in ("r6_pmc_g2_accumulate.json", "r5_pmc_g2_accumulate.json", "r4v_pmc_g2_accumulate.json", "r4p_pmc_g2_accumulate.json", "r4l_pmc_g2_accumulate.json", "r4f_pmc_g2_accumulate.json", "r4a_pmc_g2_accumulate.json", "r3_pmc_g2_accumulate.json", "r2_pmc_g2_accumulate.json",
                  "r1_pmc_g2_accumulate.json"):
         pmc_path = os.path.join(ROOT, "profiles", name)
         if args.log_m == 20 and curve == "bn254" and world == 1 and os.path.exists(pmc_path):
@@ -1020,7 +1159,8 @@ def main():
                              "assembly run under the next proof's first kernels" if overlap else
                              "K proofs queued on one context, each complete on channel 0 before the next starts"),
                    "key_table_bytes": info["table_bytes"], "key_table_stride": info["table_stride"],
-                   "key_table_build_s": wl.pk_build_s,
+                   "key_table_build_s": wl.pk_build_s, "first_proof_s": first_proof_s,
+                   "time_to_first_proof_s": wl.pk_build_s + first_proof_s,
                    "key_window_bits": {"ab": info["c_ab"], "l": info["c_l"], "h": info["c_h"]}},
         "roofline": {"bound": "hbm", "kernel": g2_kernel + " (G2 bucket accumulation, table mode, inside the "
                      "timed proofs)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -52,8 +52,9 @@ __global__ void __launch_bounds__(256) calib_mad_kernel(uint64_t* out, int iters
 extern "C" {
 
 // waves_per_simd: 1..8 (256-lane workgroups = one wave on each SIMD of a CU; that many workgroups per CU)
-// out[0] = T v_mad_u64_u32 lane-op/s chip-wide, out[1] = shader clock under the load in MHz (0 if the counters do not
-// separate), out[2] = kernel time in ms, out[3] = compute units.  Returns 0, or a hipError_t.
+// out[0] = T v_mad_u64_u32 lane-op/s chip-wide (median of five runs), out[1] = shader clock under the load in MHz (0 if the
+// counters do not separate), out[2] = kernel time in ms, out[3] = compute units, out[4] / out[5] = the fastest / slowest
+// run's rate.  out: 6 doubles.  Returns 0, or a hipError_t.
 int dg16_calib_mad_rate(int device, int waves_per_simd, int iters, double* out) {
   if (!out || waves_per_simd < 1 || waves_per_simd > 8 || iters < 1) return -1;
   hipError_t e = hipSetDevice(device);
@@ -69,8 +70,12 @@ int dg16_calib_mad_rate(int device, int waves_per_simd, int iters, double* out) 
   auto ok = [&](hipError_t x) { if (x != hipSuccess && !rc) rc = (int)x; return x == hipSuccess; };
   if (ok(hipMalloc((void**)&d_out, (size_t)blocks * threads * 8)) && ok(hipMalloc((void**)&d_ticks, (size_t)blocks * 16)) &&
       ok(hipStreamCreateWithFlags(&s, hipStreamNonBlocking)) && ok(hipEventCreate(&e0)) && ok(hipEventCreate(&e1))) {
-    double best_ms = 1e30, best_mhz = 0;
-    for (int rep = 0; rep < 4 && !rc; rep++) {       // rep 0 warms the clocks up; best of the other three
+    // DVFS makes single runs differ by up to 10 % (profiles/r6c_calibration_check.txt: 30.3 / 35.6 / 32.3 T for one kernel
+    // length on one box): one warm-up, then the MEDIAN of five, each about as long as the accumulation kernels it prices
+    constexpr int REPS = 5;
+    double ms_v[REPS], mhz_v[REPS];
+    int got = 0;
+    for (int rep = 0; rep < REPS + 1 && !rc; rep++) {
       ok(hipEventRecord(e0, s));
       hipLaunchKernelGGL(calib_mad_kernel, dim3(blocks), dim3(threads), 0, s, d_out, iters, 12345u + rep, 6789u, d_ticks);
       ok(hipEventRecord(e1, s));
@@ -83,10 +88,23 @@ int dg16_calib_mad_rate(int device, int waves_per_simd, int iters, double* out) 
       double sc = 0, wc = 0;
       for (int i = 0; i < blocks; i++) { sc += (double)h[2 * i]; wc += (double)h[2 * i + 1]; }
       delete[] h;
-      if (ms < best_ms) {
-        best_ms = ms;
-        best_mhz = wc > 0 ? sc / wc * 100.0 : 0.0;
-      }
+      ms_v[got] = ms;
+      mhz_v[got] = wc > 0 ? sc / wc * 100.0 : 0.0;
+      got++;
+    }
+    double best_ms = 0, best_mhz = 0;
+    if (!rc && got == REPS) {
+      int idx[REPS];
+      for (int i = 0; i < REPS; i++) idx[i] = i;
+      for (int i = 0; i < REPS; i++)
+        for (int j = i + 1; j < REPS; j++)
+          if (ms_v[idx[j]] < ms_v[idx[i]]) { int t = idx[i]; idx[i] = idx[j]; idx[j] = t; }
+      best_ms = ms_v[idx[REPS / 2]];
+      best_mhz = mhz_v[idx[REPS / 2]];
+      out[4] = (double)blocks * threads * iters * 16.0 / (ms_v[idx[0]] * 1e-3) / 1e12;          // fastest
+      out[5] = (double)blocks * threads * iters * 16.0 / (ms_v[idx[REPS - 1]] * 1e-3) / 1e12;   // slowest
+    } else if (!rc) {
+      rc = -2;
     }
     if (!rc) {
       out[0] = (double)blocks * threads * iters * 16.0 / (best_ms * 1e-3) / 1e12;

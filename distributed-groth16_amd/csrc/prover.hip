@@ -12,7 +12,7 @@ namespace dg16 {
   void msms_##name(dg16_ctx*, Call&, Call&, Call&, const PkDev&, const void*, const void*, const void*, const void*,    \
                    const void*, bool, bool, uint8_t*, const dg16_comm*, const void*);                                   \
   void prove_dist_##name(dg16_ctx*, const PkDev&, const dg16_comm*, const void*, const void*, const void*, const void*, \
-                         const void*, bool, bool, void*);                                                               \
+                         const void*, bool, bool, void*, bool);                                                         \
   void assemble_##name(Call&, const uint8_t*, size_t, uint8_t*);                                                        \
   size_t results_bytes_##name();                                                                                        \
   size_t proof_bytes_##name();
@@ -169,10 +169,11 @@ int dg16_groth16_prove_dist(dg16_ctx* ctx, const dg16_pk* pk, const dg16_comm* c
     DG_REQUIRE(pk->ctx == ctx, DG16_ERR_BAD_ARG, "proving key belongs to another context");
     DG_REQUIRE(a_rows && b_rows && c_rows && full_assignment && r_s && proof_out, DG16_ERR_BAD_ARG, "null operand");
     bool mont = flags & DG16_F_SCALARS_MONT, dev = flags & DG16_F_DEVICE_PTRS;
+    const bool overlap = (flags & DG16_F_OVERLAP_TAIL) && dev;
     if (pk->d.curve == DG16_BN254)
-      prove_dist_bn254(ctx, pk->d, comm, a_rows, b_rows, c_rows, full_assignment, r_s, mont, dev, proof_out);
+      prove_dist_bn254(ctx, pk->d, comm, a_rows, b_rows, c_rows, full_assignment, r_s, mont, dev, proof_out, overlap);
     else
-      prove_dist_bls12_381(ctx, pk->d, comm, a_rows, b_rows, c_rows, full_assignment, r_s, mont, dev, proof_out);
+      prove_dist_bls12_381(ctx, pk->d, comm, a_rows, b_rows, c_rows, full_assignment, r_s, mont, dev, proof_out, overlap);
   });
 }
 

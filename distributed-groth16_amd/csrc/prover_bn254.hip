@@ -19,8 +19,8 @@ void msms_bn254(dg16_ctx* ctx, Call& k0, Call& k1, Call& k2, const PkDev& pk, co
   msms_typed<0>(ctx, k0, k1, k2, pk, a, b, c, w, rs, mont, dev, res, comm, h_given);
 }
 void prove_dist_bn254(dg16_ctx* ctx, const PkDev& pk, const dg16_comm* comm, const void* a, const void* b, const void* c,
-              const void* w, const void* rs, bool mont, bool dev, void* out) {
-  prove_dist_typed<0>(ctx, pk, comm, a, b, c, w, rs, mont, dev, out);
+              const void* w, const void* rs, bool mont, bool dev, void* out, bool overlap) {
+  prove_dist_typed<0>(ctx, pk, comm, a, b, c, w, rs, mont, dev, out, overlap);
 }
 void assemble_bn254(Call& k0, const uint8_t* gathered, size_t n_shards, uint8_t* proof) {
   assemble_typed<0>(k0, gathered, n_shards, proof);

@@ -414,6 +414,9 @@ static bool msms_typed(dg16_ctx* ctx, Call& k0, Call& k1, Call& k2, const PkDev&
     msm_accumulate_phase<Fq>(main, st_ab, buf_l, pk.l_q);
     DG_HIP(hipEventRecord(ev[6], main));
     DG_HIP(hipStreamWaitEvent(side, ev[0], 0));
+    if (tail_fence) DG_HIP(hipStreamWaitEvent(side, ev[18], 0));    // tail fence: rec[kRecA] / rec[kRecL] (the single-GPU form
+                                                                     // has it in front of the sort of h already; the sharded
+                                                                     // form sorts h on main)
     msm_bucket_phase<Fq>(side, st_ab, buf_a, false, rec + kRecA);
     DG_HIP(hipEventRecord(ev[12], side));
     DG_HIP(hipStreamWaitEvent(xch, ev[1], 0));
@@ -434,6 +437,7 @@ static bool msms_typed(dg16_ctx* ctx, Call& k0, Call& k1, Call& k2, const PkDev&
     const void* in2[1] = {xbuf_b};
     DG_HIP(hipStreamWaitEvent(main, ev[11], 0));
     h_poly_dist_stage(k0, CURVE, log_m, rank, n_ranks, 2, in2, h_dev);
+    if (tail_fence) DG_HIP(hipStreamWaitEvent(main, ev[18], 0));    // tail fence: the digit-sort metadata of h
     st_h = msm_sort_on<Fr, CT::SCALAR_BITS>(main, k0.c, h_dev, n_h, true, true, pk.c_h, pk.stride);
   } else {
     DG_HIP(hipStreamWaitEvent(main, ev[15], 0));
@@ -441,7 +445,7 @@ static bool msms_typed(dg16_ctx* ctx, Call& k0, Call& k1, Call& k2, const PkDev&
   MsmBuffers<Fq> buf_h = msm_buffers<Fq>(ctx->xws[0], st_h.g);
   if (tail_fence) DG_HIP(hipStreamWaitEvent(main, ev[18], 0));     // tail fence: H's buckets
   msm_accumulate_phase<Fq>(main, st_h, buf_h, pk.h_q);
-  const bool tail_on_side2 = overlap_tail && !dist && !h_given;
+  const bool tail_on_side2 = overlap_tail && !h_given;      // (round 6: the sharded proof too -- prove_dist_typed)
   if (tail_on_side2) {
     DG_HIP(hipEventRecord(ev[17], main));
     DG_HIP(hipStreamWaitEvent(side2, ev[17], 0));
@@ -512,28 +516,43 @@ static void prove_typed(dg16_ctx* ctx, const PkDev& pk, const void* a, const voi
 template <int CURVE>
 static void prove_dist_typed(dg16_ctx* ctx, const PkDev& pk, const dg16_comm* comm, const void* a, const void* b,
                              const void* c, const void* witness, const void* r_s_host, bool mont, bool dev_ptrs,
-                             void* proof_out) {
+                             void* proof_out, bool overlap_tail = false) {
   using CT = CurveTypes<CURVE>;
   const size_t g1j = sizeof(Jacobian<typename CT::Fq>), g2j = sizeof(Jacobian<typename CT::Fq2>);
   const unsigned n = comm ? comm->n_ranks(comm->self) : 1;
   DG_REQUIRE(pk.nshards == n, DG16_ERR_BAD_ARG, "distributed prove: key shards != ranks");
-  Call k0(ctx, 0), k1(ctx, 1), k2(ctx, 2);
+  overlap_tail = overlap_tail && dev_ptrs;      // a host-pointer call ends in a synchronisation anyway
+  Call k0(ctx, 0, overlap_tail), k1(ctx, 1, overlap_tail), k2(ctx, 2, overlap_tail);
   uint8_t* buf = (uint8_t*)ws(k0.c, 16, 8192);
   uint8_t* res_dev = buf;
   uint8_t* proof_dev = buf + 4096;
   const size_t rec = msm_results_bytes<CURVE>();
   uint8_t* gathered = n > 1 ? (uint8_t*)ws(k0.c, 28, n * rec) : res_dev;
   k0.begin_dominant();
-  msms_typed<CURVE>(ctx, k0, k1, k2, pk, a, b, c, witness, r_s_host, mont, dev_ptrs, res_dev, comm, nullptr);
+  const bool tail = msms_typed<CURVE>(ctx, k0, k1, k2, pk, a, b, c, witness, r_s_host, mont, dev_ptrs, res_dev, comm, nullptr,
+                                      overlap_tail);
+  // DG16_F_OVERLAP_TAIL (round 6: the sharded proof of a QUEUE): H's bucket reduction, the all-gather and the assembly --
+  // the exposed tail of a rank, ~0.4 of its 3.0 ms at 8 shards -- are ordered on channel 2's stream, so the next proof's
+  // first stage and its B accumulation start under them.  The all-gather is then issued on another stream than the
+  // all-to-alls of the h-polynomial (the aux stream): every rank enqueues its collectives in the same program order, which
+  // is what one communicator needs; the transport serialises them in that order.
+  hipStream_t ts = tail ? k2.s() : k0.s();
   if (n > 1) {
     // the "all-reduce of bucket sums": RCCL has no user-defined reduction, so the N records (768 B each for BN254)
     // are gathered and every rank adds them (assemble)
-    int rc = comm->all_gather(comm->self, res_dev, rec, gathered, k0.s());
+    int rc = comm->all_gather(comm->self, res_dev, rec, gathered, ts);
     DG_REQUIRE(rc == DG16_OK, DG16_ERR_NET, "all-gather of the MSM records failed");
   }
-  assemble_typed<CURVE>(k0, gathered, n, proof_dev);
+  assemble_typed<CURVE>(k0, gathered, n, proof_dev, ts);
   k0.end_dominant();
-  stage_out(k0, proof_out, proof_dev, 2 * g1j + g2j, dev_ptrs);
+  if (tail) {
+    if (proof_out != proof_dev)
+      DG_HIP(hipMemcpyAsync(proof_out, proof_dev, 2 * g1j + g2j, hipMemcpyDeviceToDevice, ts));
+    DG_HIP(hipEventRecord(ctx->pipe_ev[18], ts));
+    ctx->tail_pending.store(true, std::memory_order_release);
+  } else {
+    stage_out(k0, proof_out, proof_dev, 2 * g1j + g2j, dev_ptrs);
+  }
   k0.finish();
   k1.finish();
   k2.finish();

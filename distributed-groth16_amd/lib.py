@@ -347,6 +347,7 @@ class Context:
     def set_table_budget(self, nbytes):
         """HBM budget of the window tables of one resident key / base set built from now on (0 = unlimited)."""
         self._chk(self.L.dg16_ctx_set_table_budget(self.h, int(nbytes)))
+        self.table_budget = int(nbytes)
 
     def sync(self, channel=0):
         self._chk(self.L.dg16_sync(self.h, channel))
@@ -549,12 +550,14 @@ class Context:
         self._chk(self.L.dg16_groth16_msms_h(self.h, pk.h, _ptr(h_ptr), _ptr(w_ptr), _ptr(rs_host),
                                              F_DEVICE_PTRS | (F_SCALARS_MONT if scalars_mont else 0), _ptr(results_ptr)))
 
-    def prove_dist_dev(self, pk, comm, a_ptr, b_ptr, c_ptr, w_ptr, rs_host, out_ptr, scalars_mont=True):
+    def prove_dist_dev(self, pk, comm, a_ptr, b_ptr, c_ptr, w_ptr, rs_host, out_ptr, scalars_mont=True, overlap_tail=False):
+        """overlap_tail (DG16_F_OVERLAP_TAIL): H's bucket reduction, the all-gather of the records and the assembly run on
+        channel 2's stream; the proof is complete after sync(2)."""
         rs_host = np.ascontiguousarray(rs_host, dtype=np.uint64)
+        flags = F_DEVICE_PTRS | (F_SCALARS_MONT if scalars_mont else 0) | (F_OVERLAP_TAIL if overlap_tail else 0)
         self._chk(self.L.dg16_groth16_prove_dist(self.h, pk.h, comm.comm_ptr if comm is not None else None,
                                                  _ptr(a_ptr), _ptr(b_ptr), _ptr(c_ptr), _ptr(w_ptr), _ptr(rs_host),
-                                                 F_DEVICE_PTRS | (F_SCALARS_MONT if scalars_mont else 0),
-                                                 _ptr(out_ptr)))
+                                                 flags, _ptr(out_ptr)))
 
     # ---- Groth16 prover ---------------------------------------------------------------------------------
     def pk_create(self, curve, num_vars, num_inputs, domain_size, a_query, b_g1_query, b_g2_query, h_query,

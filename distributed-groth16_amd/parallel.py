@@ -171,7 +171,8 @@ class NativeProver:
         self.rank, self.world = rank, world
         self.device = torch.device("cuda", ctx.device)
         self.nl = 4 if curve == "bn254" else 6
-        # one GPU, a queue of proofs: DG16_F_OVERLAP_TAIL (the proof is then complete on channel 2's stream)
+        # a queue of proofs: DG16_F_OVERLAP_TAIL (the proof is then complete on channel 2's stream) -- one GPU, and since
+        # round 6 the sharded proof too (H's reduction, the all-gather and the assembly under the next proof's first stage)
         self.overlap_tail = False
 
     def describe(self):
@@ -195,7 +196,7 @@ class NativeProver:
                                scalars_mont=scalars_mont, overlap_tail=True)
             return proof
         self.ctx.prove_dist_dev(self.pk, self.comm, a.data_ptr(), b.data_ptr(), c.data_ptr(), w.data_ptr(), rs_host,
-                                proof.data_ptr(), scalars_mont=scalars_mont)
+                                proof.data_ptr(), scalars_mont=scalars_mont, overlap_tail=self.overlap_tail)
         return proof
 
 

@@ -71,7 +71,8 @@ enum dg16_flags {
   DG16_F_SERIAL_CHANNELS = 16u, /* dg16_prove_c: run the three d_msm one after another (channel 0, 1, 2 in that order
                                on every party) instead of joined from three host threads -- for a dg16_net whose
                                channels are not independent (one ordered pipe); the result is the same */
-  DG16_F_OVERLAP_TAIL = 32u, /* dg16_groth16_prove with DG16_F_DEVICE_PTRS, for a queue of proofs on one context: the last
+  DG16_F_OVERLAP_TAIL = 32u, /* dg16_groth16_prove and dg16_groth16_prove_dist with DG16_F_DEVICE_PTRS, for a queue of proofs on
+                               one context (prove_dist: also the all-gather of the records, on channel 2's stream): the last
                                MSM's bucket reduction, the assembly and the copy to proof_out are ordered on CHANNEL 2's
                                stream instead of channel 0's, so the work enqueued next on channel 0 (the next proof's
                                dg16_qap and h-polynomial) starts under that latency-bound tail.  proof_out is complete

@@ -32,6 +32,15 @@ for ctr in FETCH_SIZE WRITE_SIZE; do
   rm -rf $O/pmc
 done
 python tools/pmc_json.py $O/pmc_raw.txt "$tag" > $O/pmc_g2_accumulate.json
+# ... and the same two passes over BLS12-381 proofs (config 5's curve: the 14-limb kernels)
+: > $O/pmc_raw_bls12_381.txt
+for ctr in FETCH_SIZE WRITE_SIZE; do
+  rm -rf $O/pmc
+  timeout 300 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $O/pmc -o run -- python tools/shard_timing.py 20 3 bls12_381 1 > $O/pmc_bls_$ctr.log 2>&1
+  python tools/pmc_sum.py $O/pmc $ctr msm_accumulate_steps_kernel msm_accumulate_kernel ntt_step_kernel msm_finalize msm_row msm_top_kernel qap_kernel >> $O/pmc_raw_bls12_381.txt
+  rm -rf $O/pmc
+done
+python tools/pmc_json.py $O/pmc_raw_bls12_381.txt "$tag" bls12_381 > $O/pmc_bls12_381_accumulate.json
 # config 5's curve and data path: BLS12-381 2^20 (timed, parity on the timed instance) and the sharded proof over 8 shard
 # keys in this process against the oracle
 (timeout 300 python bench.py --curve bls12_381 --log-m 20 --steps 5 --warmup 2 --no-extras) > $O/bench_line_bls12_381_2e20.json 2>> $O/bench.err

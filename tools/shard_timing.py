@@ -59,6 +59,8 @@ for world in worlds:
     wl = bench.Workload(ctx, dev, log_m, 0, world, curve=curve)
     comm = LoopbackComm(world) if world > 1 else None
     p = NativeProver(ctx, wl.pk, curve, comm, 0, world)
+    # DG16_OVERLAP=1: the queue of proofs with DG16_F_OVERLAP_TAIL (one GPU: round 4; the sharded proof: round 6)
+    p.overlap_tail = os.environ.get("DG16_OVERLAP") == "1"
 
     def step():
         wl.qap()
@@ -89,8 +91,8 @@ for world in worlds:
     sync()
     ms = (time.perf_counter() - t0) / steps * 1e3
     out["x%d" % world] = round(ms, 3)
-    print("world %d: %.3f ms per proof on rank 0, host enqueue %.3f ms (n_ab %d, n_h %d)%s" % (
-        world, ms, host_ms, wl.pk.info()["n_ab"], wl.pk.info()["n_h"], "  comm errors: %s" % comm.errors if comm and comm.errors else ""),
+    print("world %d%s: %.3f ms per proof on rank 0, host enqueue %.3f ms (n_ab %d, n_h %d)%s" % (
+        world, " overlap" if p.overlap_tail else "", ms, host_ms, wl.pk.info()["n_ab"], wl.pk.info()["n_h"], "  comm errors: %s" % comm.errors if comm and comm.errors else ""),
         flush=True)
     wl.pk.close()
     del wl
