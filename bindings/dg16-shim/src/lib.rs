@@ -92,6 +92,20 @@ pub trait Dg16Scalar: ark_ff::PrimeField {
 pub fn curve_of<F: Dg16Scalar>() -> c_int {
     F::CURVE
 }
+/// The same for a field that is only known as `F: PrimeField` -- the reference's transforms and dist-primitives are
+/// generic over the scalar field (`witness_map_from_matrices<F: PrimeField, ..>`, `d_fft<F: FftField + PrimeField, ..>`)
+/// and a `#[cfg(feature = "dg16")]` block cannot add a bound to them -- by its modulus: the low limb and the bit length
+/// tell the three scalar fields apart.  None: not a field of this library (the call site falls through to arkworks).
+pub fn curve_id_of<F: ark_ff::PrimeField>() -> Option<c_int> {
+    let m = F::MODULUS;
+    let limbs: &[u64] = m.as_ref();
+    match (F::MODULUS_BIT_SIZE, limbs.first().copied()) {
+        (254, Some(0x43E1_F593_F000_0001)) => Some(sys::DG16_BN254),
+        (255, Some(0xFFFF_FFFF_0000_0001)) => Some(sys::DG16_BLS12_381),
+        (253, Some(0x0A11_8000_0000_0001)) => Some(sys::DG16_BLS12_377),
+        _ => None,
+    }
+}
 macro_rules! curve_impls {
     ($feat:literal, $krate:ident, $id:expr) => {
         #[cfg(feature = $feat)]

@@ -14,6 +14,7 @@
 #![cfg(feature = "mpc")]
 use crate::pack::{pack_affine, scalars_as_bytes, scalars_as_bytes_mut, unpack_projective, FieldBytes};
 use crate::{check, sys, Dg16Config, Dg16Error, Dg16Scalar, CTX};
+use mpc_net::MpcNet as _;
 use ark_ec::short_weierstrass::{Affine, Projective, SWCurveConfig};
 use ark_ff::PrimeField;
 use mpc_net::MultiplexedStreamID;
@@ -25,8 +26,11 @@ unsafe impl Send for Pss {}
 unsafe impl Sync for Pss {}
 impl Pss {
     pub fn new<F: Dg16Scalar>(l: usize) -> Result<Self, Dg16Error> {
+        Self::new_for_curve(F::CURVE, l)
+    }
+    pub fn new_for_curve(curve: c_int, l: usize) -> Result<Self, Dg16Error> {
         let mut p = core::ptr::null_mut();
-        check(unsafe { sys::dg16_pss_create(CTX.0, F::CURVE, l as c_uint, &mut p) })?;
+        check(unsafe { sys::dg16_pss_create(CTX.0, curve, l as c_uint, &mut p) })?;
         Ok(Self(p))
     }
 }
@@ -237,9 +241,8 @@ where
 }
 
 /// A transport the library can drive: anything that hands out the `dg16_net` vtable (MpcNet's required methods and its
-/// two provided collectives on device buffers).  `RcclNet` is the native one; a caller that keeps its own `MpcNet`
-/// (e.g. `ProdNet` to a remote party) implements the eight callbacks over it, staging through pinned host memory, and
-/// sets `serial_channels` if its channels share one pipe.
+/// two provided collectives on device buffers).  `RcclNet` is the native one; [`MpcNetAdapter`] wraps ANY `MpcNet` of
+/// the reference (`LocalTestNet`'s connections, `ProdNet`), which is what the generic call sites of the patches hold.
 pub trait AsDg16Net {
     fn vtable(&self) -> *const sys::Dg16Net;
 }
@@ -252,14 +255,169 @@ pub fn vtable_of<N: AsDg16Net>(net: &N) -> *const sys::Dg16Net {
     net.vtable()
 }
 
-/// The device-side twin of a `PackedSharingParams<F>` (one per packing factor l, made on first use).
-pub fn pss_of<F: Dg16Scalar>(pp: &secret_sharing::pss::PackedSharingParams<F>) -> &'static Pss {
+// the HIP runtime libdg16.so is linked against (payloads of the vtable are device buffers)
+extern "C" {
+    fn hipMemcpyAsync(dst: *mut core::ffi::c_void, src: *const core::ffi::c_void, bytes: usize, kind: c_int,
+                      stream: *mut core::ffi::c_void) -> c_int;
+    fn hipStreamSynchronize(stream: *mut core::ffi::c_void) -> c_int;
+}
+const HIP_MEMCPY_HOST_TO_DEVICE: c_int = 1;
+const HIP_MEMCPY_DEVICE_TO_HOST: c_int = 2;
+
+/// `dg16_net` over any `MpcNet` of the reference: the eight callbacks stage the device payload through host memory
+/// (`hipMemcpyAsync` on the stream the library hands over + a stream synchronisation) and drive the trait's async methods
+/// on the tokio runtime the adapter was made on.  Made INSIDE an async fn of the reference (`MpcNetAdapter::new(net)`
+/// captures `Handle::current()`); the library's calls then run under `tokio::task::block_in_place` (see [`blocking`]), so the
+/// callbacks may `block_on` without starving the worker threads that drive the other parties' tasks.
+/// A transport whose three `MultiplexedStreamID`s share one ordered pipe passes `serial_channels = true` to `prove_c`.
+pub struct MpcNetAdapter<'a, N: mpc_net::MpcNet> {
+    net: &'a N,
+    rt: tokio::runtime::Handle,
+    table: Box<sys::Dg16Net>,
+}
+impl<'a, N: mpc_net::MpcNet> MpcNetAdapter<'a, N> {
+    pub fn new(net: &'a N) -> Box<Self> {
+        let mut me = Box::new(Self {
+            net,
+            rt: tokio::runtime::Handle::current(),
+            table: Box::new(sys::Dg16Net {
+                self_: core::ptr::null_mut(),
+                n_parties: Self::cb_n_parties,
+                party_id: Self::cb_party_id,
+                gather_to_king: Self::cb_gather,
+                scatter_from_king: Self::cb_scatter,
+                is_init: Self::cb_is_init,
+                send_to: Self::cb_send_to,
+                recv_from: Self::cb_recv_from,
+            }),
+        });
+        let p: *mut Self = &mut *me;
+        me.table.self_ = p.cast();
+        me
+    }
+    unsafe fn this<'b>(p: *mut core::ffi::c_void) -> &'b Self {
+        &*(p as *const Self)
+    }
+    fn sid(channel: c_int) -> Option<MultiplexedStreamID> {
+        match channel {
+            0 => Some(MultiplexedStreamID::Zero),
+            1 => Some(MultiplexedStreamID::One),
+            2 => Some(MultiplexedStreamID::Two),
+            _ => None,
+        }
+    }
+    unsafe fn d2h(src: *const core::ffi::c_void, bytes: usize, stream: *mut core::ffi::c_void) -> Option<Vec<u8>> {
+        let mut v = vec![0u8; bytes];
+        if hipMemcpyAsync(v.as_mut_ptr().cast(), src, bytes, HIP_MEMCPY_DEVICE_TO_HOST, stream) != 0 { return None; }
+        if hipStreamSynchronize(stream) != 0 { return None; }
+        Some(v)
+    }
+    unsafe fn h2d(dst: *mut core::ffi::c_void, src: &[u8], stream: *mut core::ffi::c_void) -> bool {
+        hipMemcpyAsync(dst, src.as_ptr().cast(), src.len(), HIP_MEMCPY_HOST_TO_DEVICE, stream) == 0
+            && hipStreamSynchronize(stream) == 0        // `src` is dropped by the caller right after
+    }
+    extern "C" fn cb_n_parties(p: *mut core::ffi::c_void) -> c_uint {
+        unsafe { Self::this(p) }.net.n_parties() as c_uint
+    }
+    extern "C" fn cb_party_id(p: *mut core::ffi::c_void) -> c_uint {
+        unsafe { Self::this(p) }.net.party_id()
+    }
+    extern "C" fn cb_is_init(p: *mut core::ffi::c_void) -> c_int {
+        unsafe { Self::this(p) }.net.is_init() as c_int
+    }
+    // client_send_or_king_receive (mpc-net/src/lib.rs:61-99): king's recv = n_parties x bytes, party-major
+    extern "C" fn cb_gather(p: *mut core::ffi::c_void, channel: c_int, send: *const core::ffi::c_void, bytes: usize,
+                            recv: *mut core::ffi::c_void, stream: *mut core::ffi::c_void) -> c_int {
+        let me = unsafe { Self::this(p) };
+        let (Some(sid), Some(out)) = (Self::sid(channel), unsafe { Self::d2h(send, bytes, stream) }) else {
+            return sys::DG16_ERR_BAD_ARG;
+        };
+        match me.rt.block_on(me.net.client_send_or_king_receive(&out, sid)) {
+            Ok(Some(parts)) => {
+                let mut all = Vec::with_capacity(bytes * parts.len());
+                for b in &parts {
+                    if b.len() != bytes { return sys::DG16_ERR_NET; }
+                    all.extend_from_slice(b);
+                }
+                if unsafe { Self::h2d(recv, &all, stream) } { sys::DG16_OK } else { sys::DG16_ERR_HIP }
+            }
+            Ok(None) => sys::DG16_OK,
+            Err(_) => sys::DG16_ERR_NET,
+        }
+    }
+    // client_receive_or_king_send (mpc-net/src/lib.rs:102-140): the king passes n_parties x bytes
+    extern "C" fn cb_scatter(p: *mut core::ffi::c_void, channel: c_int, send: *const core::ffi::c_void, bytes: usize,
+                             recv: *mut core::ffi::c_void, stream: *mut core::ffi::c_void) -> c_int {
+        let me = unsafe { Self::this(p) };
+        let Some(sid) = Self::sid(channel) else { return sys::DG16_ERR_BAD_ARG };
+        let out = if me.net.is_king() {
+            let n = me.net.n_parties();
+            let Some(all) = (unsafe { Self::d2h(send, bytes * n, stream) }) else { return sys::DG16_ERR_HIP };
+            Some(all.chunks(bytes).map(bytes::Bytes::copy_from_slice).collect::<Vec<_>>())
+        } else {
+            None
+        };
+        match me.rt.block_on(me.net.client_receive_or_king_send(out, sid)) {
+            Ok(mine) if mine.len() == bytes => {
+                if unsafe { Self::h2d(recv, &mine, stream) } { sys::DG16_OK } else { sys::DG16_ERR_HIP }
+            }
+            _ => sys::DG16_ERR_NET,
+        }
+    }
+    extern "C" fn cb_send_to(p: *mut core::ffi::c_void, peer: c_uint, channel: c_int, send: *const core::ffi::c_void,
+                             bytes: usize, stream: *mut core::ffi::c_void) -> c_int {
+        let me = unsafe { Self::this(p) };
+        let (Some(sid), Some(out)) = (Self::sid(channel), unsafe { Self::d2h(send, bytes, stream) }) else {
+            return sys::DG16_ERR_BAD_ARG;
+        };
+        match me.rt.block_on(me.net.send_to(peer, bytes::Bytes::from(out), sid)) {
+            Ok(()) => sys::DG16_OK,
+            Err(_) => sys::DG16_ERR_NET,
+        }
+    }
+    extern "C" fn cb_recv_from(p: *mut core::ffi::c_void, peer: c_uint, channel: c_int, recv: *mut core::ffi::c_void,
+                               bytes: usize, stream: *mut core::ffi::c_void) -> c_int {
+        let me = unsafe { Self::this(p) };
+        let Some(sid) = Self::sid(channel) else { return sys::DG16_ERR_BAD_ARG };
+        match me.rt.block_on(me.net.recv_from(peer, sid)) {
+            Ok(b) if b.len() == bytes => {
+                if unsafe { Self::h2d(recv, &b, stream) } { sys::DG16_OK } else { sys::DG16_ERR_HIP }
+            }
+            _ => sys::DG16_ERR_NET,
+        }
+    }
+}
+impl<'a, N: mpc_net::MpcNet> AsDg16Net for MpcNetAdapter<'a, N> {
+    fn vtable(&self) -> *const sys::Dg16Net {
+        &*self.table
+    }
+}
+/// The vtable for whatever `MpcNet` a generic call site of the reference holds (the patches' `net: &Net`).
+pub fn adapter_of<N: mpc_net::MpcNet>(net: &N) -> Box<MpcNetAdapter<'_, N>> {
+    MpcNetAdapter::new(net)
+}
+/// Runs a blocking library call from inside an async fn of the reference without stalling the tokio worker it is on
+/// (the 8 party tasks of `simulate_network_round` share those workers; the library's collectives wait for the peers).
+pub fn blocking<T>(f: impl FnOnce() -> T) -> T {
+    tokio::task::block_in_place(f)
+}
+
+/// The device-side twin of a `PackedSharingParams<F>` (one per curve and packing factor l, made on first use); `F` is
+/// only known as a `PrimeField` at the reference's generic call sites: identified by its modulus (`crate::curve_id_of`).
+pub fn pss_of<F: PrimeField>(pp: &secret_sharing::pss::PackedSharingParams<F>) -> Result<&'static Pss, Dg16Error> {
     use once_cell::sync::Lazy;
     use std::collections::HashMap;
     use std::sync::Mutex;
     static CACHE: Lazy<Mutex<HashMap<(c_int, usize), &'static Pss>>> = Lazy::new(|| Mutex::new(HashMap::new()));
+    let curve = crate::curve_id_of::<F>()
+        .ok_or_else(|| Dg16Error::Status(sys::DG16_ERR_BAD_CURVE, "scalar field of no curve of libdg16".into()))?;
     let mut m = CACHE.lock().unwrap();
-    *m.entry((F::CURVE, pp.l)).or_insert_with(|| Box::leak(Box::new(Pss::new::<F>(pp.l).expect("dg16_pss_create"))))
+    if let Some(p) = m.get(&(curve, pp.l)) {
+        return Ok(*p);
+    }
+    let made: &'static Pss = Box::leak(Box::new(Pss::new_for_curve(curve, pp.l)?));
+    m.insert((curve, pp.l), made);
+    Ok(made)
 }
 
 /// `prove::C::compute` with the reference's own types (`E::G1`, `E::G1Affine`): groth16/src/prove.rs:104-136.

@@ -53,6 +53,54 @@ void DG_FN(msm_resident_)(Call& k, const void* table, size_t n, unsigned c, unsi
   msm_reduce<GF>(k, st, table, affine, out);
 }
 
+// The king's combination "in the exponent" when there are FEW outputs (d_msm: one; unpackexp of a handful of elements):
+// out[e][r] = sum_c M[r][c] P[e][c] with one WORKGROUP per output and one WAVE per term -- the scalar multiples run side
+// by side as wave-cooperative width-4 NAF chains on the reduced-radix types (msm_impl.h: scalar_mul_wave29), then wave 0
+// adds the terms.  Round 6: the lane-per-output kernel of dist_impl.h (matvec_points_kernel: right for thousands of
+// outputs) ran d_msm's single output as EIGHT full scalar multiplications one after another on ONE lane on 32-bit limbs --
+// ~80 ms for BLS12-377 G1 whatever the size of the MSM in front of it (bench.py's dmsm_sweep: 81-99 ms per round at
+// 2^10 .. 2^17 points per party, profiles/r6d_bench_line.json).
+template <class F, class Fr>
+__global__ void __launch_bounds__(512) matvec_points_wave_kernel(const Fr* __restrict__ Mc, unsigned rows, unsigned cols,
+                                                                   const Affine<F>* __restrict__ in,
+                                                                   Affine<F>* __restrict__ out) {
+  __shared__ ScalarMulLds<F> lds[8];
+  __shared__ XYZZ29<F> part[8];
+  const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const size_t e = blockIdx.x / rows;
+  const unsigned r = blockIdx.x % rows;
+  __builtin_amdgcn_s_setprio(3);
+  {
+    const Affine<F> q = in[e * cols + wave];
+    XYZZ29<F> v = XYZZ29<F>::inf();
+    if (!q.is_inf()) v = XYZZ29<F>::from_xyzz32(XYZZ<F>::from_affine(q));
+    const Fr k = Mc[(size_t)r * cols + wave];
+    // the NAF recoding and the table of odd multiples of a chain live in THIS wave's slice of LDS; the barriers inside
+    // scalar_mul_wave29 are workgroup barriers that every wave reaches the same number of times (the chain's length
+    // differs between waves, its barriers do not)
+    v = scalar_mul_wave29<F, Fr::NL, false>(v, k.l, &lds[wave]);
+    if (lane == 0) part[wave] = v;
+  }
+  __syncthreads();
+  if (wave != 0) return;
+  XYZZ29<F> acc = XYZZ29<F>::inf();
+#pragma unroll 1
+  for (unsigned c = 0; c < cols; c++) acc = add_wave29(acc, part[c]);
+  if (lane == 0) out[blockIdx.x] = acc.to_xyzz32().to_affine();
+}
+// out[e][r] = sum_c M[r][c] P[e][c]: few outputs -> a workgroup each (<= 8 terms: two waves per SIMD, 256 registers each),
+// many -> a lane each
+template <class F, class Fr>
+static void matvec_points(hipStream_t s, const Fr* Mc, unsigned rows, unsigned cols, const Affine<F>* in, Affine<F>* out,
+                          size_t count) {
+  if (count * rows <= 256 && cols >= 1 && cols <= 8)
+    hipLaunchKernelGGL((matvec_points_wave_kernel<F, Fr>), dim3((unsigned)(count * rows)), dim3(64 * cols), 0, s, Mc, rows, cols,
+                       in, out);
+  else
+    hipLaunchKernelGGL((matvec_points_kernel<F, Fr>), dim3((unsigned)((count * rows + 63) / 64)), dim3(64), 0, s, Mc, rows,
+                       cols, in, out, count);
+}
+
 // d_msm (dist-primitives/src/dmsm/mod.rs:70-98): local MSM of the share vectors, gather to the king, who
 // interpolates in the exponent (unpackexp, degree2) and sums the l secrets -- one n-term combination with
 // the constant scalars v_j = sum_i unpack2[i][j] -- then sends the same point to every party.
@@ -76,7 +124,7 @@ void DG_FN(d_msm_)(Call& k, const dg16_pss* pp, const dg16_net* net, int sid, co
   if (king) {
     send = (Affine<F>*)ws(k.c, 20, np * sizeof(Affine<F>));
     const Fr* v2 = (const Fr*)pp->mats + 6 * pp->n * pp->l;
-    hipLaunchKernelGGL((matvec_points_kernel<F, Fr>), dim3(1), dim3(64), 0, k.s(), v2, 1u, np, shares, send, (size_t)1);
+    matvec_points<F, Fr>(k.s(), v2, 1u, np, shares, send, (size_t)1);
     for (unsigned p = 1; p < np; p++)   // vec![output; n_parties] (dmsm/mod.rs:94)
       DG_HIP(hipMemcpyAsync(send + p, send, sizeof(Affine<F>), hipMemcpyDeviceToDevice, k.s()));
     DG_HIP(hipGetLastError());
@@ -95,21 +143,29 @@ template <class F, class Fr>
 __global__ void __launch_bounds__(512) mpc_combine_kernel(const Jacobian<F>* __restrict__ terms,
                                                            const Fr* __restrict__ scalars, unsigned n_terms,
                                                            unsigned mask, int mont, Jacobian<F>* __restrict__ out) {
-  __shared__ XYZZ<F> part[8];
+  __shared__ XYZZ29<F> part[8];
+  __shared__ ScalarMulLds<F> lds[8];
   const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  XYZZ<F> v = XYZZ<F>::from_jacobian(terms[wave]);
-  if ((mask >> wave) & 1) {
-    Fr kk = scalars[wave];
-    if (mont) kk = kk.from_mont();
-    v = scalar_mul_wave<F, Fr::NL>(v, kk.l);
+  XYZZ29<F> v = XYZZ29<F>::from_xyzz32(XYZZ<F>::from_jacobian(terms[wave]));
+  {
+    // (every wave runs the chain -- its workgroup barriers must be reached by all -- an unmasked term with the scalar 1)
+    Fr kk = Fr::zero();
+    kk.l[0] = 1;
+    if ((mask >> wave) & 1) {
+      kk = scalars[wave];
+      if (mont) kk = kk.from_mont();
+    }
+    // round 6: width-4 NAF chains on the reduced-radix types (254 doublings + ~51 additions at ~1.3 us a level instead of
+    // 254 + ~127 on the 32-bit-limb wave operations at ~4 us); no endomorphism split: the terms are arbitrary points
+    v = scalar_mul_wave29<F, Fr::NL, false>(v, kk.l, &lds[wave]);
   }
   if (lane == 0) part[wave] = v;
   __syncthreads();
   if (wave != 0) return;
-  XYZZ<F> acc = XYZZ<F>::inf();
+  XYZZ29<F> acc = XYZZ29<F>::inf();
 #pragma unroll 1
-  for (unsigned i = 0; i < n_terms; i++) acc = add_wave(acc, part[i]);
-  if (lane == 0) *out = acc.to_jacobian();
+  for (unsigned i = 0; i < n_terms; i++) acc = add_wave29(acc, part[i]);
+  if (lane == 0) *out = acc.to_xyzz32().to_jacobian();
 }
 // terms: n_terms Jacobian points; scalars: n_terms Fr (only those under `mask` are read); all device pointers
 void DG_FN(mpc_combine_)(Call& k, const void* terms, const void* scalars, unsigned n_terms, unsigned mask, bool mont,
@@ -129,8 +185,7 @@ void DG_FN(packexp_)(Call& k, const dg16_pss* pp, int which, const void* in, siz
   using Fr = CT::Fr;
   const unsigned cols = which == 0 ? pp->l : pp->n, rows = which == 0 ? pp->n : pp->l;
   const Fr* Mc = (const Fr*)pp->mats + 3 * pp->n * pp->l + (size_t)which * pp->n * pp->l;
-  hipLaunchKernelGGL((matvec_points_kernel<F, Fr>), dim3((unsigned)((count * rows + 63) / 64)), dim3(64), 0, k.s(), Mc,
-                     rows, cols, (const Affine<F>*)in, (Affine<F>*)out, count);
+  matvec_points<F, Fr>(k.s(), Mc, rows, cols, (const Affine<F>*)in, (Affine<F>*)out, count);
   DG_HIP(hipGetLastError());
 }
 }  // namespace dg16

@@ -1525,12 +1525,19 @@ __device__ __forceinline__ int wnaf4_words(const uint32_t* k, int nbits, bool ne
   return len;
 }
 // k p; p, k (NW canonical little-endian words) and the result uniform across the wave; `lds` is this wave's alone
-template <class F, int NW>
-__device__ __forceinline__ XYZZ29<F> scalar_mul_wave29(const XYZZ29<F>& p, const uint32_t* k, ScalarMulLds<F>* lds) {
+// ALLOW_SPLIT = false: never split (a caller whose points need not be in the order-r subgroup of a cofactor-one group
+// either -- there is none today -- or that wants one code path for all groups).
+// Several waves of one workgroup may run chains side by side, each on its own `lds`: the two barriers below are WORKGROUP
+// barriers, reached by every wave exactly twice whatever its point and scalar (no early return in front of them).
+template <class F, int NW, bool ALLOW_SPLIT = true>
+__device__ __forceinline__ XYZZ29<F> scalar_mul_wave29(const XYZZ29<F>& p_in, const uint32_t* k, ScalarMulLds<F>* lds) {
   constexpr int BS = XYZZ29<F>::BS;
-  constexpr bool SPLIT = GlvOf<F>::enabled && GlvCofactorOne<F>::value && NW == 8;
+  constexpr bool SPLIT = ALLOW_SPLIT && GlvOf<F>::enabled && GlvCofactorOne<F>::value && NW == 8;
   const unsigned lane = __lane_id();
-  if (p.is_inf()) return p;
+  const bool p_inf = p_in.is_inf();
+  // (the identity runs the chain on a stand-in so that the barriers are reached; the result is discarded)
+  XYZZ29<F> p = p_in;
+  if (p_inf) { p.x = FieldOf<F>::one(); p.y = FieldOf<F>::one(); p.zz = FieldOf<F>::one(); p.zzz = FieldOf<F>::one(); }
   // the table of odd multiples (a doubling and three additions on the wave)
   {
     const XYZZ29<F> p2 = dbl_wave29(p);
@@ -1590,7 +1597,7 @@ __device__ __forceinline__ XYZZ29<F> scalar_mul_wave29(const XYZZ29<F>& p, const
       acc = add_wave29(acc, o);
     }
   }
-  return acc;
+  return p_inf ? p_in : acc;
 }
 
 // rows of 2^kRowLog buckets

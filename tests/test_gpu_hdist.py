@@ -336,6 +336,82 @@ def test_prove_dist_through_rccl_world_one_equals_prove():
     wl.pk.close()
 
 
+@pytest.mark.parametrize("curve,world", [("bn254", 8), ("bls12_381", 4)])
+def test_overlapped_queue_of_sharded_proofs_equals_the_synchronised_calls(curve, world):
+    """DG16_F_OVERLAP_TAIL on dg16_groth16_prove_dist (round 6): rank 0's shard of a `world`-way proof, driven through a
+    STREAM-ORDERED loopback dg16_comm (the exchanges are device copies on the stream the library hands over, like RCCL's;
+    the records of the other ranks are copies of rank 0's, so the proof is not a proof -- but it is a deterministic function
+    of everything the call reads).  A queue of proofs with different (r, s) and witnesses, no host synchronisation between
+    them, H's reduction + all-gather + assembly of proof k on channel 2's stream under the first stage of proof k + 1, must
+    give exactly the points the same calls give one at a time: a record, a gathered buffer or the digit-sort metadata of h
+    read after the next proof overwrote it would show here.  (Real exchanges: tools/two_rank_check.py, several processes.)"""
+    import bench
+    from dg16_amd import lib
+    from dg16_amd.parallel import NativeProver
+    c = ctx()
+    dev = torch.device(DEV)
+
+    class Loopback(lib.TorchComm):
+        def __init__(self, n):
+            self.torch, self.device, self.n_ranks, self.rank, self.errors = torch, dev, n, 0, []
+            self._cb = (lib._COMM_N(lambda _s: n), lib._COMM_N(lambda _s: 0), lib._COMM_GATHER(self._all_gather),
+                        lib._COMM_A2A(self._all_to_all))
+            self.struct = lib.CommStruct(None, *self._cb)
+            self.comm_ptr = ctypes.cast(ctypes.pointer(self.struct), ctypes.c_void_p)
+
+        def _on(self, stream, fn):
+            try:
+                with torch.cuda.stream(torch.cuda.ExternalStream(int(stream), device=dev)):
+                    fn()
+                return 0
+            except Exception as e:      # noqa: BLE001
+                self.errors.append(repr(e))
+                return 6
+
+        def _all_gather(self, _s, send, nbytes, recv, stream):
+            return self._on(stream, lambda: self._tensor(recv, nbytes * self.n_ranks).view(self.n_ranks, -1).copy_(
+                self._tensor(send, nbytes).view(1, -1).expand(self.n_ranks, -1)))
+
+        def _all_to_all(self, _s, send, recv, per_peer, stream):
+            return self._on(stream, lambda: self._tensor(recv, per_peer * self.n_ranks).copy_(
+                self._tensor(send, per_peer * self.n_ranks)))
+
+    wl = bench.Workload(c, dev, 14, 0, world, seed=41, curve=curve)
+    comm = Loopback(world)
+    p = NativeProver(c, wl.pk, curve, comm, 0, world)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(5)
+    ws = [wl.w] + [bench.rand_fr(wl.nv, dev, gen, curve) for _ in range(3)]
+    for w in ws[1:]:
+        w[0] = 0
+        w[0, 0] = 1
+    rss = [np.array([[7 + k, 11, 13 * k + 1, 1], [5, 9 + k, 2, 3 + k]], dtype=np.uint64) for k in range(4)]
+
+    def run(overlap):
+        p.overlap_tail = overlap
+        outs = []
+        for w, rs in zip(ws, rss):
+            wl.w = w
+            wl.qap()
+            outs.append(p.prove(wl.a, wl.b, wl.c, wl.w, rs, scalars_mont=False))
+            if not overlap:
+                for ch in range(3):
+                    c.sync(ch)
+        for ch in range(3):
+            c.sync(ch)
+        return [bench.gpu_proof_affine(curve, o.cpu().numpy()) for o in outs]
+
+    alone = run(False)
+    for _ in range(2):
+        queued = run(True)
+        for q, a in zip(queued, alone):
+            assert all(np.array_equal(x, y) for x, y in zip(q, a))
+    assert not all(np.array_equal(x, y) for x, y in zip(alone[0], alone[1]))
+    assert not comm.errors
+    p.overlap_tail = False
+    wl.pk.close()
+
+
 def test_localnet_send_to_recv_from():
     """MpcNet::send_to / recv_from (mpc-net/src/lib.rs:48-58) on the in-process net: a ring of three parties, and a
     length mismatch that fails on both sides."""

@@ -51,6 +51,28 @@ def affine(p):
 
 
 ok = all(np.array_equal(affine(p), affine(ref)) for p in proofs)
+# Round 6: a QUEUE of sharded proofs with DG16_F_OVERLAP_TAIL (H's reduction, the all-gather and the assembly of proof k on
+# channel 2's stream under the first stage of proof k + 1), different (r, s) per proof so that a record or a gathered buffer
+# read too late shows: every queued proof == the same statement proved alone with a synchronisation behind it
+if transport == "torch" and hasattr(prover, "overlap_tail"):
+    rss = [np.array([[7 + k, 11, 13 * k + 1, 1], [5, 9 + k, 2, 3 + k]], dtype=np.uint64) for k in range(4)]
+    alone = []
+    for rs in rss:
+        wl.qap()
+        pr = prover.prove(wl.a, wl.b, wl.c, wl.w, rs, scalars_mont=False)
+        for ch in range(3):
+            ctx.sync(ch)
+        alone.append(pr.cpu().numpy().copy())
+    prover.overlap_tail = True
+    queued = []
+    for rs in rss:
+        wl.qap()
+        queued.append(prover.prove(wl.a, wl.b, wl.c, wl.w, rs, scalars_mont=False))
+    for ch in range(3):
+        ctx.sync(ch)
+    prover.overlap_tail = False
+    ok = ok and all(np.array_equal(affine(q.cpu().numpy()), affine(a_)) for q, a_ in zip(queued, alone))
+    ok = ok and not np.array_equal(affine(alone[0]), affine(alone[1]))
 flag = torch.tensor([1 if ok else 0])
 dist.all_reduce(flag, op=dist.ReduceOp.MIN)
 if rank == 0:
