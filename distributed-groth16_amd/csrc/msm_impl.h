@@ -633,6 +633,22 @@ struct ColAcc {       // one lane's XYZZ29 in the LDS columns
     for (int i = 0; i < WORDS; i++) sh[coord * WORDS + i][lane] = w[i];
   }
 };
+// Round-6 experiment switches for the tree's addition (same-call A/B in profiles/r6f_g1_tree_experiments.txt; none is the
+// default): DG16_TREE_ADD_OUTLINE = the addition behind a call (the loop then compiles without the tree's 304 B of scratch),
+// DG16_TREE_ADD_INTO = XYZZ29::add_into (U1 / S1 overwrite X1 / Y1 in place: the smallest live set).
+template <class F, int BLOCK>
+#ifdef DG16_TREE_ADD_OUTLINE
+__device__ __attribute__((noinline))
+#else
+__device__ __forceinline__
+#endif
+void wg_tree_add(uint32_t (*sh)[BLOCK], unsigned a, unsigned b) {
+#ifdef DG16_TREE_ADD_INTO
+  XYZZ29<F>::add_into(ColAcc<F, BLOCK>{sh, a}, ColAcc<F, BLOCK>{sh, b});
+#else
+  XYZZ29<F>::add_acc(ColAcc<F, BLOCK>{sh, a}, ColAcc<F, BLOCK>{sh, a}, ColAcc<F, BLOCK>{sh, b});
+#endif
+}
 // q: my index inside my run, el: end (exclusive, a lane index) of my run; lanes outside every run pass q = 0, el = lane + 1
 template <class F, int BLOCK>
 __device__ __forceinline__ void wg_bucket_tree(uint32_t (*sh)[BLOCK], unsigned short* list, unsigned* wcnt,
@@ -661,7 +677,7 @@ __device__ __forceinline__ void wg_bucket_tree(uint32_t (*sh)[BLOCK], unsigned s
     __syncthreads();
     if (lane < total) {
       const unsigned a = list[lane];
-      XYZZ29<F>::add_acc(ColAcc<F, BLOCK>{sh, a}, ColAcc<F, BLOCK>{sh, a}, ColAcc<F, BLOCK>{sh, (unsigned)DG_IDX(16, a + d, BLOCK)});
+      wg_tree_add<F, BLOCK>(sh, a, (unsigned)DG_IDX(16, a + d, BLOCK));
     }
     __syncthreads();
   }
@@ -682,7 +698,11 @@ template <class F>
 constexpr unsigned msm_acc_block_log() {
   if constexpr (sizeof(F) > 48) return sizeof(typename FieldOf<F>::Store) * 4 * 256 <= 80 * 1024 ? 8u : 7u;
   else if constexpr (!msm_acc_tree<F>()) return 8u;
+#ifdef DG16_G1_BLOCK_LOG     // (round-6 experiment: workgroups of 128 lanes -- a smoother last round, more buckets to stitch)
+  else return DG16_G1_BLOCK_LOG;
+#else
   else return sizeof(typename FieldOf<F>::Store) * 4 * 256 <= 40 * 1024 ? 8u : 7u;   // G1: four workgroups' trees per CU
+#endif
 }
 // Does the accumulation kernel of F add the partials of a bucket inside the workgroup (wg_bucket_tree)?  G1: yes.
 // G2: no -- its loop already takes 173 VGPRs (BN254) / 252 (BLS12-381) with the accumulator in LDS, and the tree's full
