@@ -1620,6 +1620,74 @@ __device__ __forceinline__ XYZZ29<F> scalar_mul_wave29(const XYZZ29<F>& p_in, co
   return p_inf ? p_in : acc;
 }
 
+// The same product on TWO waves of one workgroup, for a group whose scalars split (GlvOf + GlvCofactorOne): wave h runs the
+// NAF chain of half h alone -- 127 doublings + ~25 additions each instead of 127 + ~51 on one wave -- over its own table (wave
+// 1's entries are phi of wave 0's: X times BETA), and wave 0 adds the two results.  The chain was the critical path of a
+// small proof (BASELINE config 4: prover_stage1_g1_kernel 0.61 of 1.95 ms, profiles/r6f_timeline_config4.md).
+// Both waves call this with the same arguments; the result is valid in wave 0 (threadIdx.x < 64).
+template <class F>
+constexpr bool scalar_mul_splits() {
+#ifdef DG16_STAGE1_ONE_WAVE      // (A/B switch of round 6: both halves interleaved on one wave, profiles/r6h_*)
+  return false;
+#else
+  return GlvOf<F>::enabled && GlvCofactorOne<F>::value;
+#endif
+}
+template <class F, int NW>
+__device__ __forceinline__ XYZZ29<F> scalar_mul_two_waves29(const XYZZ29<F>& p_in, const uint32_t* k, ScalarMulLds<F>* lds,
+                                                            XYZZ29<F>* xchg) {
+  static_assert(NW == 8, "eight-word scalars");
+  constexpr int BS = XYZZ29<F>::BS;
+  using GC = typename GlvOf<F>::C;
+  const unsigned lane = __lane_id(), h = (threadIdx.x >> 6) & 1u;
+  const bool p_inf = p_in.is_inf();
+  XYZZ29<F> p = p_in;      // (the identity runs the chain on a stand-in so that the barriers are reached)
+  if (p_inf) { p.x = FieldOf<F>::one(); p.y = FieldOf<F>::one(); p.zz = FieldOf<F>::one(); p.zzz = FieldOf<F>::one(); }
+  {
+    Fp<typename FieldOf<F>::Params> beta32;
+#pragma unroll
+    for (int i = 0; i < Fp<typename FieldOf<F>::Params>::NL; i++) beta32.l[i] = GC::BETA[i];
+    const auto beta = FieldOf<F>::from32(beta32);
+    const XYZZ29<F> p2 = dbl_wave29(p);
+    XYZZ29<F> m = p;
+#pragma unroll 1
+    for (int j = 0; j < 4; j++) {
+      if (j) m = add_wave29(m, p2);
+      XYZZ29<F> e = m;
+      const auto bx = fit<BS>(m.x * beta);            // phi(x, y) = (BETA x, y): x_affine = X / ZZ, so only X changes
+      e.x = select(h != 0, bx, m.x);
+      if (lane == 0) lds->tab[4 * h + j] = e;
+    }
+  }
+  uint32_t hv[2][8];
+  glv::split<GC>(k, hv[0], hv[1]);
+  int len = 0;
+  if (lane == 0) {
+    uint32_t w[5];
+#pragma unroll
+    for (int i = 0; i < 4; i++) w[i] = h ? hv[1][i] : hv[0][i];
+    w[4] = 0;
+    len = wnaf4_words<5>(w, 128, ((h ? hv[1][7] : hv[0][7]) >> 31) != 0, lds->naf[h]);
+  }
+  len = __shfl(len, 0);
+  __syncthreads();
+  XYZZ29<F> acc = XYZZ29<F>::inf();
+#pragma unroll 1
+  for (int i = len - 1; i >= 0; i--) {
+    acc = dbl_wave29(acc);
+    const int d = lds->naf[h][i];
+    if (d == 0) continue;
+    XYZZ29<F> o = lds->tab[4 * h + ((d < 0 ? -d : d) >> 1)];
+    const auto ny = fit<BS>(neg(o.y));
+    o.y = select(d < 0, ny, o.y);
+    acc = add_wave29(acc, o);
+  }
+  if (h == 1 && lane == 0) *xchg = acc;
+  __syncthreads();
+  if (h == 0) acc = add_wave29(acc, *xchg);
+  return p_inf ? p_in : acc;
+}
+
 // rows of 2^kRowLog buckets
 constexpr unsigned kRowLog = 8;
 struct RowGeom {

@@ -59,7 +59,7 @@ constexpr int kRecA = 0, kRecB1 = 1, kRecL = 2, kRecH = 3, kRecSA = 4, kRecRB1 =
 // r*B1'.  One wave each: the doublings and additions of the scalar multiple run wave-cooperatively (msm_impl.h:
 // scalar_mul_wave29 -- round 6: 127 doublings + ~51 additions for BN254 instead of 254 + ~127).
 template <class Fq, class Fr>
-__global__ void __launch_bounds__(64) prover_stage1_g1_kernel(Jacobian<Fq>* rec, const Affine<Fq>* fixed_g1,
+__global__ void __launch_bounds__(128) prover_stage1_g1_kernel(Jacobian<Fq>* rec, const Affine<Fq>* fixed_g1,
                                                                const Fr* r_s, int mont, int first_shard) {
   const int which = (int)blockIdx.x;     // two workgroups of one wave: s*A' and r*B1' side by side
   __builtin_amdgcn_s_setprio(3);     // a serial chain on one wave: ahead of the accumulation waves it shares a SIMD with
@@ -74,7 +74,13 @@ __global__ void __launch_bounds__(64) prover_stage1_g1_kernel(Jacobian<Fq>* rec,
   // (the chain runs on the reduced-radix types, over width-4 NAF digits and -- BN254 -- the two halves of the endomorphism
   // split: msm_impl.h: scalar_mul_wave29)
   __shared__ ScalarMulLds<Fq> lds;
-  const XYZZ<Fq> kv = scalar_mul_wave29<Fq, Fr::NL>(XYZZ29<Fq>::from_xyzz32(v), k.l, &lds).to_xyzz32();
+  XYZZ<Fq> kv;
+  if constexpr (scalar_mul_splits<Fq>()) {       // two waves per chain: one half of the split scalar each (msm_impl.h)
+    __shared__ XYZZ29<Fq> xchg;
+    kv = scalar_mul_two_waves29<Fq, Fr::NL>(XYZZ29<Fq>::from_xyzz32(v), k.l, &lds, &xchg).to_xyzz32();
+  } else {
+    kv = scalar_mul_wave29<Fq, Fr::NL>(XYZZ29<Fq>::from_xyzz32(v), k.l, &lds).to_xyzz32();
+  }
   if (threadIdx.x != 0) return;
   rec[which == 0 ? kRecA : kRecB1] = v.to_jacobian();
   rec[which == 0 ? kRecSA : kRecRB1] = kv.to_jacobian();
@@ -423,8 +429,8 @@ static bool msms_typed(dg16_ctx* ctx, Call& k0, Call& k1, Call& k2, const PkDev&
     if (tail_fence) DG_HIP(hipStreamWaitEvent(xch, ev[18], 0));     // tail fence: rec[kRecB1] is read by the last assembly
     msm_bucket_phase<Fq>(xch, st_ab, buf_b1, false, rec + kRecB1);
     DG_HIP(hipStreamWaitEvent(xch, ev[12], 0));
-    hipLaunchKernelGGL((prover_stage1_g1_kernel<Fq, Fr>), dim3(2), dim3(64), 0, xch, rec, fixed_g1, r_s, (int)mont,
-                       first_shard);
+    hipLaunchKernelGGL((prover_stage1_g1_kernel<Fq, Fr>), dim3(2), dim3(scalar_mul_splits<Fq>() ? 128 : 64), 0, xch, rec,
+                       fixed_g1, r_s, (int)mont, first_shard);
     DG_HIP(hipEventRecord(ev[7], xch));
     DG_HIP(hipStreamWaitEvent(side, ev[6], 0));
     msm_bucket_phase<Fq>(side, st_ab, buf_l, false, rec + kRecL);
