@@ -1,27 +1,16 @@
-// Pippenger MSM for gfx950 -- replaces `G::msm(bases, scalars)` at
-// dist-primitives/src/dmsm/mod.rs:82 (ark-ec VariableBaseMSM).  Any correct algorithm yields the
-// same group element; parity is checked in affine form.
+// Pippenger MSM for gfx950 -- replaces `G::msm(bases, scalars)` at dist-primitives/src/dmsm/mod.rs:82 (ark-ec
+// VariableBaseMSM).  Any correct algorithm yields the same group element; parity is checked in affine form.
 //
-// Pipeline (all on the GPU, one stream):
-//   1 digits      scalar -> W signed c-bit digits (carry iff digit > 2^(c-1)); per-(window,bucket)
-//                 histogram with global atomics.                               HBM: 32 B/scalar in
-//   2 scan        exclusive prefix sums of the histogram (entry offsets) and of the per-bucket
-//                 segment counts ceil(cnt/16), one workgroup per window
-//   3 scatter     counting-sort placement of (point index | sign) into per-window bucket order;
-//                 the lane that lands on rank 0, 16, 32, .. of a bucket also records the segment
-//   4 accumulate  one lane per SEGMENT (<= 16 consecutive entries of one bucket): XYZZ mixed
-//                 additions (8M+2S).  Load-balanced for any digit distribution (the top window and
-//                 real witnesses are heavily skewed; lane-per-bucket ran 4.7x below the VALU rate).
-//                 THE dominant kernel: ~N*W*10 Montgomery multiplications, VALU-bound; the
-//                 64 B/point gather is served mostly from the 256 MiB Infinity Cache
-//   4b finalize   per bucket: sum of its segment partials (giant buckets: one workgroup each)
-//   5 reduce      sum_b (b+1)*B[w][b]: chunks of 8 buckets by running sums + a <=16-bit scalar
-//                 multiple per chunk, then an LDS tree per window
-//   6 tail        Horner over the W window sums (W*c doublings, inherently serial), -> Jacobian
-//
-// Data layout in HBM: bases n x (x||y) Montgomery as handed over; digits/entries int32 [W][n];
-// histogram/offsets uint32 [W][2^(c-1)]; segment map uint32 and segment sums XYZZ [W][2^(c-1)+n/16];
-// buckets XYZZ [W][2^(c-1)].
+// Pipeline (DESIGN.md section 2.2 has the table; MSM_INVARIANTS.md every array's size, writer and capacity):
+//   1-3 sort        scalar -> W signed c-bit digits, counted and placed per (bucket-window, bucket) by a two-level LDS-
+//                   partitioned counting sort (msm_part_*; the direct atomic path msm_digits / msm_scatter for small inputs)
+//   4   accumulate  one lane per SEGMENT of a bucket: XYZZ mixed additions on the reduced-radix types -- THE dominant kernels,
+//                   VALU-issue-bound (msm_accumulate_kernel / _lds_kernel / _steps_kernel)
+//   4b  finalize    bucket = sum of its partials (in-workgroup tree + stitch for BN254 G1, throughput finalize otherwise;
+//                   buckets with > 64 partials through the giant work list)
+//   5   reduce      sum_b (b + 1) B_b per bucket-window: rows of 256 buckets, then one workgroup per window (msm_reduce_impl.h)
+//   6   tail        Horner over the window sums on ONE wave (fresh bases only; resident tables have one bucket set)
+// What was measured and removed on the way is in CHANGELOG.md, not here.
 #pragma once
 #include <atomic>
 #include <utility>
@@ -633,7 +622,7 @@ struct ColAcc {       // one lane's XYZZ29 in the LDS columns
     for (int i = 0; i < WORDS; i++) sh[coord * WORDS + i][lane] = w[i];
   }
 };
-// Round-6 experiment switches for the tree's addition (same-call A/B in profiles/r6f_g1_tree_experiments.txt; none is the
+// Round-6 experiment switches for the tree's addition (same-call A/B in profiles/r6g_g1_tree_experiments.txt; none is the
 // default): DG16_TREE_ADD_OUTLINE = the addition behind a call (the loop then compiles without the tree's 304 B of scratch),
 // DG16_TREE_ADD_INTO = XYZZ29::add_into (U1 / S1 overwrite X1 / Y1 in place: the smallest live set).
 template <class F, int BLOCK>
@@ -704,17 +693,10 @@ constexpr unsigned msm_acc_block_log() {
   else return sizeof(typename FieldOf<F>::Store) * 4 * 256 <= 40 * 1024 ? 8u : 7u;   // G1: four workgroups' trees per CU
 #endif
 }
-// Does the accumulation kernel of F add the partials of a bucket inside the workgroup (wg_bucket_tree)?  G1: yes.
-// G2: no -- its loop already takes 173 VGPRs (BN254) / 252 (BLS12-381) with the accumulator in LDS, and the tree's full
-// Fq2 addition inlined next to it spilled 0.9-1.4 KB per lane (the proof got 15 % SLOWER).  Round 4 tried it again
-// with XYZZ29::add_into on the LDS columns (U1 / S1 overwrite X1 / Y1 in place: 215 VGPRs, NO scratch, still two waves
-// per SIMD): the accumulation went 2.91 -> 3.50 ms per 2^20-point launch for a 0.45-ms finalize saved -- a 2^20 proof
-// 10.36 -> 10.59 ms, same box, same call (profiles/r4d_ab.md): the tree's 92 KB of code run five times per workgroup
-// next to a 47-KB loop costs more than the separate throughput finalize.  Removed; every lane writes its partial and
-// msm_finalize_lds_kernel adds the ~15 of a bucket.
-// Coordinate fields up to this size get the tree: the G1 of BN254.  The 48-byte fields (BLS12-381 / -377 G1: 14 limbs,
-// 168 VGPRs in the loop already) were measured with it, same box, same call: 39.4 vs 36.8 ms per 2^20 proof, 131.9 vs
-// 126.5 ms at 2^22 -- the tree's LDS columns and spills cost the loop more than the per-segment finalize they replace.
+// Does the accumulation kernel of F add the partials of a bucket inside the workgroup (wg_bucket_tree)?  Coordinate fields
+// up to this size do: the G1 of BN254.  G2 (the tree's Fq2 addition next to a loop at its register limit) and the 48-byte
+// G1 fields were measured with it and are slower (CHANGELOG.md: rounds 3-4, profiles/r4d_ab.md): there every lane writes its
+// partial and a throughput finalize adds the ~15 of a bucket.
 #ifndef DG16_TREE_MAX_BYTES
 #define DG16_TREE_MAX_BYTES 32
 #endif
@@ -898,29 +880,22 @@ msm_accumulate_lds_kernel(MsmBases bases, size_t n, MsmGeom g,
 #undef DG_STAGE
 }
 
-// ---- 4 (G2 of the 14-limb curves): the same accumulation as ONE Fq2-product site visited ten times -------------------
-// msm_accumulate_lds_kernel<Fp2<bls12_381>> is a 100-KB loop (12 700 instructions: eleven inlined 14-limb Fq2 products)
-// run by one wave per SIMD against the 64-KB instruction cache two CUs share: every iteration streams the loop from L2
-// again -- 9.4 ms per 2^20-point launch on some boxes of the pool and 18.9 on others with the same binary, 26-51 % of
-// the v_mad_u64_u32 issue roof (BN254's 47-KB loop: 68-72 %).  Products behind calls (round 4's second form) cost a
-// dozen scratch accesses per call for the calling convention: 14.4 ms everywhere.
-// Here a mixed addition is a loop of TEN visits of one generic product c = a b on operands of one static type
-// (Fe2<P, BG, 1>): a wave-uniform switch in front of the site routes the operands (four register temporaries t0..t3 and
-// the accumulator's LDS columns), a second one behind it routes the result:
-//     0  P   = x2 ZZ  - X1        1  R  = y2 ZZZ - Y1        2  PP = P P         3  PPP = P PP
-//     4  ZZ  = ZZ PP              5  ZZZ = ZZZ PPP           6  Q  = X1 PP       7  X3 = R R - PPP - 2 Q
-//     8  T   = R (Q - X3)         9  Y3 = T - PPP Y1
-// -- the two squarings run as products and the fused four-product Y3 as two products: 11 760 v_mad_u64_u32 per addition
-// instead of 10 584 (+11 %), for a loop of ~2 600 instructions (21 KB) that stays in the instruction cache.  Values and
-// the order of operations inside a product are those of the straight-line form; results are congruent, and equal after
-// the final canonicalisation (parity tests unchanged).  Replaces BOTH round-4 forms and the timing-based choice.
-// A file of field elements parked in ACCUMULATION registers (gfx950: 256 AGPRs next to the 256 VGPRs of a wave at one wave
-// per SIMD), at FIXED register numbers a[kAccFileBase + 28 slot + i] named in asm statements: the temporaries of
-// msm_accumulate_steps_kernel are machine state the compiler does not see -- as C++ values (in VGPRs, or in AGPRs through
-// "=a" / "+a" operands) the step switch turned them into phis that hipcc merged with 270-330 copies per visit of a site
-// against the 84 the routing needs.  The kernel declares the file's registers clobbered once (resource accounting: the
-// wave is allocated them); the compiler's own AGPR use (spills) must stay below kAccFileBase --
-// tests/test_kernel_isa.py checks every AGPR reference of the built kernel.
+// ---- 4 (G2 of the 14-limb curves): the same accumulation as a STEP LOOP over three product sites ---------------------
+// Inlined, an Fq2 mixed addition of a 14-limb curve is a 100-KB loop (eleven Fq2 products) run by one wave per SIMD against
+// the 64-KB instruction cache two CUs share: 9 ms per 2^20-point launch on some boxes of the pool, 18 on others, same
+// binary; products behind calls cost a dozen scratch accesses each (14.4 ms everywhere).  Here a mixed addition is a loop
+// of NINE steps over THREE sites -- one Fq2 product (visited six times), one Fq2 square (twice) and the fused
+// Y3 = R (Q - X3) - PPP Y1 (once) -- with a wave-uniform switch in front of a site to route its operands and one behind it
+// to route the result:
+//     0  P = x2 ZZ - X1      1  R = y2 ZZZ - Y1      2  PP = P^2      3  PPP = P PP      4  ZZ <- ZZ PP
+//     5  ZZZ <- ZZZ PPP      6  Q = X1 PP            7  X3 = R^2 - PPP - 2 Q (-> X1), T = Q - X3      8  Y1 <- R T - PPP Y1
+// The same 10 584 v_mad_u64_u32 per addition as the straight-line form, in a loop that stays in the instruction cache;
+// values and the order of operations inside a product are those of the straight-line form (parity tests unchanged).
+// The accumulator (X1, Y1, ZZ, ZZZ) lives in LDS columns; the four temporaries (P -> Q, R, PP -> T, PPP) in a FILE of
+// accumulation registers at FIXED numbers a[kAccFileBase + 28 slot + i] named in asm statements (gfx950: 256 AGPRs next to
+// the 256 VGPRs of a wave at one wave per SIMD) -- machine state the compiler does not see: as C++ values (in VGPRs, or in
+// AGPRs through "=a" / "+a" operands) the step switch turned them into phis that hipcc merged with 270-330 copies per visit
+// of a site against the 84 the routing needs.
 constexpr int kAccFileBase = 144;
 // Round 6 -- what round 5's abort was: a clobber list is NOT a reservation.  The first form named
 // two registers ("a144", "a255": enough for the resource accounting) and hipcc, which needed 160 spill registers in the
@@ -1334,23 +1309,16 @@ __device__ __forceinline__ XYZZ<F> scalar_mul_wave(const XYZZ<F>& p, const uint3
 }
 
 // ---- the same wave-cooperative operations on the reduced-radix types (XYZZ29, internal Montgomery form) -------------
-// The 32-bit forms above pay a 454-slot out-of-line product per dependency level (128 mads behind carry chains): 4.4 us
-// per doubling on a lone wave, 1.12 ms for the 240 doublings of a 2^20-point G1 Horner tail -- as long as the bucket
-// accumulation itself (profiles/r4b_msm_g1_2e20_kernel_stats.md).  Here a level is ONE 162-mad column-chain product
-// (fp29_asm_gen.h) per lane; coordinates stay below the storage bound BS p between levels (fit<BS>: a carry pass, or one
-// multiply-subtract pass where a sum exceeds it), so every slot's operand has the same static type.
-// the value lane SRC (< 16) of every row of 16 lanes holds -> all lanes of the row: v_mov_b32_dpp row_newbcast:SRC, one
-// VALU instruction per limb (the operands of these chains are uniform across the wave and every row holds the same four
-// slots, so a row-local broadcast is a wave-wide one).  History (profiles/r4b_ab_variants.md, r4h_dpp.md):
-//   * v_readlane (first form): the results are SGPRs and hipcc runs the additions / reductions between the levels on
-//     the scalar unit -- ~190 SALU instructions per level, a doubling 1 440 instructions;
-//   * __builtin_amdgcn_update_dpp: 1 230 instructions per doubling, every emulated run passed -- and every MSM on the
-//     device was WRONG: hipcc's DPP combiner folds the broadcast into the subtraction that consumes it,
-//     v_subrev_u32_dpp ... row_newbcast, and that instruction does not compute S1 - dpp(S0) on gfx950 (60 of 64 lanes
-//     wrong in tools/ubench/dpp_probe.hip; v_mov_b32_dpp and v_sub_u32_dpp with the same control are right);
-//   * shipped: the moves as ONE opaque asm statement per element -- two wait states first (a DPP read needs them after
-//     the VALU write of its source and hipcc cannot see a DPP inside an asm), then a v_mov_b32_dpp per limb; nothing for
-//     the combiner to fold.  Same call, same box: plain 2^20 MSM 3.41 -> 3.15 ms (G1), 9.63 -> 9.00 ms (G2).
+// A level is ONE 162-mad (392 for 14 limbs) column-chain product (fp29_asm_gen.h) per lane instead of the 454-slot out-of-line
+// 32-bit product of the forms above; coordinates stay below the storage bound BS p between levels (fit<BS>), so every
+// slot's operand has the same static type.
+// bcast29<SRC>: the value lane SRC (< 16) of every row of 16 lanes holds -> all lanes of the row, v_mov_b32_dpp
+// row_newbcast:SRC, one VALU instruction per limb (the operands of these chains are uniform across the wave and every row
+// holds the same four slots, so a row-local broadcast is a wave-wide one).  The moves are ONE OPAQUE asm statement per
+// element ON PURPOSE -- two wait states first (a DPP read needs them after the VALU write of its source and hipcc cannot
+// see a DPP inside an asm), then a v_mov_b32_dpp per limb: through __builtin_amdgcn_update_dpp hipcc's DPP combiner folds
+// the broadcast into a consuming subtraction, v_subrev_u32_dpp ... row_newbcast, which does not compute S1 - dpp(S0) on
+// gfx950 (the v_readlane form before it ran the glue on the scalar unit: CHANGELOG.md, round 4).
 template <int SRC, class P, int B>
 __device__ __forceinline__ Fe<P, B, 1> bcast29(const Fe<P, B, 1>& v) {
   static_assert(SRC >= 0 && SRC < 16, "row_newbcast takes a lane of the row");
@@ -2005,15 +1973,10 @@ __global__ void __launch_bounds__(256) msm_finalize_thr_kernel(MsmGeom g, size_t
 // The same finalize as a THROUGHPUT kernel (G2): LPB lanes per bucket, each summing its share of the bucket's partials
 // into an accumulator that lives in LDS columns between the products (the layout and register budget of
 // msm_accumulate_lds_kernel: two workgroups per CU, ~175 VGPRs), then a log2(LPB)-step tree over neighbouring columns.
-// One lane per bucket at 256 VGPRs ran ~15 dependent Fq2 additions at 70 us each on one wave per SIMD (1.0 ms alone,
-// 2.2 ms inside a proof, where its waves also take the slots of two accumulation waves each: the G1 accumulation next
-// to it stretched by 0.6 ms); here a 2^20-point table MSM is one round of 2 waves per SIMD with 8 + 1 additions per
-// lane.  Runs on the accumulation's own stream, right behind it (msm_accumulate_phase).
-// One addition SITE: the serial partials (global memory) and the tree partners (LDS columns) go through the same
-// accessor, told apart at run time -- the kernel with one add_into per operand kind and LPB as a template parameter was
-// 227 KB of code (two inlined Fq2 additions, each with its inlined doubling branch) against the 64 KB instruction cache
-// two CUs share, and ran at a quarter of its issue rate (0.68 ms per 2^20-point G2 MSM; 0.42 ms before the products
-// became longer instruction sequences).
+// A 2^20-point table MSM is one round of 2 waves per SIMD with 8 + 1 additions per lane; runs on the accumulation's own
+// stream, right behind it (msm_accumulate_phase).  ONE addition site: the serial partials (global memory) and the tree
+// partners (LDS columns) go through the same accessor, told apart at run time -- one site per operand kind was 227 KB of
+// code against the 64-KB instruction cache (CHANGELOG.md, round 4).
 template <class F, int BLOCK>
 struct PartialAcc {      // an XYZZ29 behind the accessor interface of XYZZ29::add_into: memory if p, else LDS column
   using S = typename FieldOf<F>::Store;
@@ -2354,11 +2317,8 @@ void msm_run(Call& k, const void* bases, const void* scalars, size_t n, unsigned
   if (n)
     hipLaunchKernelGGL(msm_to_internal_kernel<F>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, k.s(),
                        (const Affine<F>*)bases, n, internal);
-  // (Measured and removed in round 4: the accumulation as two launches, upper half of the windows first, with that half's
-  // bucket reduction and its share of the Horner chain on a side stream underneath the lower half's accumulation.  The
-  // split costs the accumulation 0.19 ms (two ramp-downs), and the side chain runs 1.7 ms instead of 0.9 next to a
-  // saturating launch -- it becomes the critical path: 3.71 against 3.45 ms per 2^20 G1 MSM, 10.1 against 9.8 for G2,
-  // same box, same call: profiles/r4e_msm_pipeline_ab.md.)
+  // (ONE accumulation launch, then the reduction chain: the two-launch pipeline that overlapped the upper windows' chain with
+  // the lower windows' accumulation was slower -- CHANGELOG.md round 4, profiles/r4e_msm_pipeline_ab.md)
   msm_reduce<F>(k, st, internal, out_affine, out_dev);
 }
 

@@ -46,6 +46,9 @@ python tools/pmc_json.py $O/pmc_raw_bls12_381.txt "$tag" bls12_381 > $O/pmc_bls1
 (timeout 300 python bench.py --curve bls12_381 --log-m 20 --steps 5 --warmup 2 --no-extras) > $O/bench_line_bls12_381_2e20.json 2>> $O/bench.err
 (timeout 300 python bench.py --curve bls12_381 --log-m 20 --shards-in-process 8 --steps 3) > $O/bench_shards_in_process_bls12_381_2e20.json 2>> $O/bench.err
 (timeout 120 python tools/shard_timing.py 20 10 bn254 1,2,4,8 2>&1 | grep -E "^world|per_rank") > $O/shard_timing.txt
+(DG16_OVERLAP=1 timeout 120 python tools/shard_timing.py 20 10 bn254 1,2,4,8 2>&1 | grep -E "^world|per_rank") >> $O/shard_timing.txt
+(timeout 120 python tools/config4_timing.py 2>&1 | tail -1) > $O/config4_timing.txt
+(hostname; cat /proc/sys/kernel/random/boot_id; rocm-smi --showuniqueid 2>/dev/null | grep -i "unique"; uptime) > $O/box.txt 2>&1
 python - "$O" <<'PY'
 import json, sys
 d = json.loads(open(sys.argv[1] + '/bench_line.json').read().strip().splitlines()[-1])
