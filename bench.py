@@ -1094,6 +1094,21 @@ def main():
     # the stream it ran on: dg16_last_kernel_ms, channel 2 = G2 accumulation, channel 1 = A's G1 accumulation) ----
     g2_acc_ms = ctx.last_kernel_ms(2, 1)
     g1_acc_ms = ctx.last_kernel_ms(1, 1)            # A's accumulation
+    # ... and the shader clock the chip held UNDER each of them, measured by the kernels themselves (ClkProbe, msm_impl.h):
+    # 16 lanes per SIMD-cycle x 4 SIMDs x CUs x that clock is the issue bound no DVFS state can move
+    g2_mhz = ctx.last_kernel_mhz(2) if hasattr(ctx, "last_kernel_mhz") else 0.0
+    g1_mhz = ctx.last_kernel_mhz(1) if hasattr(ctx, "last_kernel_mhz") else 0.0
+    n_cus = ctx.device_info()[1]
+
+    def cycle_view(mhz, mads_t, mads_per_add, slots_per_add):
+        if not mhz:
+            return None
+        bound = 16.0 * 4 * n_cus * mhz * 1e6 / 1e12
+        out = {"sclk_under_kernel_mhz": mhz, "issue_bound_at_kernel_clock_T": bound, "mads_frac_of_issue_bound": mads_t / bound}
+        if slots_per_add:
+            out["valu_slots_per_add"] = slots_per_add
+            out["all_valu_frac_of_issue_bound"] = mads_t * slots_per_add / mads_per_add / bound
+        return out
     info = wl.pk.info()
     n_g2 = info["n_ab"]                              # points of this rank's A / B1 / B launches (slice + 2 delta slots)
     nwin = (SCALAR_BITS[curve] + 1 + info["c_ab"] - 1) // info["c_ab"]
@@ -1173,6 +1188,7 @@ def main():
         "valu_roofline": {"unit": "T v_mad_u64_u32 lane-op/s", "achieved": valu_t, "peak": mad_peak,
                           "frac": valu_t / mad_peak, "peak_source": peak_src,
                           "frac_vs_round1_constant": valu_t / MAD_ISSUE_T,
+                          "cycle_view": cycle_view(g2_mhz, valu_t, g2_add_mads, {"bn254": 5900}.get(curve)),
                           "mads_per_g1_add": g1_add_mads, "mads_per_g2_add": g2_add_mads, "mads_per_product": mul_cost,
                           "product_equivalents_G_per_s": valu_t * 1e3 / mul_cost,
                           "measured_product_rate_G_per_s": mul_rate_g, "measured_product_rate_source": mul_src,
@@ -1202,6 +1218,8 @@ def main():
                              "frac": (float(g1_add_mads) * n_g2 * nwin / (g1_acc_ms * 1e-3) / 1e12 / mad_peak) if g1_acc_ms else 0.0,
                              "mads_per_g1_add": g1_add_mads,
                              "valu_slots_per_g1_add": {"bn254": 2089}.get(curve),
+                             "cycle_view": cycle_view(g1_mhz, (float(g1_add_mads) * n_g2 * nwin / (g1_acc_ms * 1e-3) / 1e12) if g1_acc_ms else 0.0,
+                                                      g1_add_mads, {"bn254": 2089}.get(curve)),
                              "note": "every integer VALU instruction of the loop (mads, column shifts / masks, m[k] products) "
                                      "issues at about the same ~35 T lane-op/s (profiles/r5c_ubench_instr_rate.txt): the "
                                      "loop's 2089 issue slots per addition, not its 1467 mads, are what the time buys -- "

@@ -64,6 +64,8 @@ int dg16_ctx_create(int device, dg16_ctx** out) {
     DG_HIP(hipHostMalloc((void**)&ctx->dev_flag_host, sizeof(unsigned), hipHostMallocMapped));
     *ctx->dev_flag_host = 0;
     DG_HIP(hipHostGetDevicePointer((void**)&ctx->dev_flag, ctx->dev_flag_host, 0));
+    DG_HIP(hipMalloc((void**)&ctx->kclk, kChannels * 2 * sizeof(unsigned long long)));
+    DG_HIP(hipMemset(ctx->kclk, 0, kChannels * 2 * sizeof(unsigned long long)));
   });
   if (rc != DG16_OK) {
     // keep the message reachable for the caller that failed to get a context
@@ -95,6 +97,7 @@ void dg16_ctx_destroy(dg16_ctx* ctx) {
   for (auto& st : ctx->aux)
     if (st) hipStreamDestroy(st);
   if (ctx->dev_flag_host) hipHostFree(ctx->dev_flag_host);
+  if (ctx->kclk) hipFree(ctx->kclk);
   for (auto& kv : ctx->twiddles) {
     hipFree(kv.second.lo);
     hipFree(kv.second.hi);
@@ -169,11 +172,20 @@ int dg16_device_info(dg16_ctx* ctx, char* name, size_t name_len, int* compute_un
 int dg16_last_kernel_ms(dg16_ctx* ctx, int channel, int which, float* ms) {
   int rc = guard_channel(ctx, channel);
   if (rc) return rc;
-  if (!ms || which < 0 || which > 1) return DG16_ERR_BAD_ARG;
+  if (!ms || which < 0 || which > 2) return DG16_ERR_BAD_ARG;
   return guarded(ctx, [&] {
     Channel& c = ctx->ch[channel];
     std::lock_guard<std::mutex> g(c.mu);
     *ms = 0.f;
+    if (which == 2) {      // the shader clock (MHz) the chip held under that accumulation kernel, measured by the kernel
+      if (!c.ev_valid[1] || !ctx->kclk) return;
+      DG_HIP(hipSetDevice(ctx->device));
+      DG_HIP(hipEventSynchronize(c.ev[3]));
+      unsigned long long t[2] = {0, 0};
+      DG_HIP(hipMemcpy(t, ctx->kclk + 2 * channel, sizeof t, hipMemcpyDeviceToHost));
+      if (t[1]) *ms = (float)((double)t[0] / (double)t[1] * 100.0);
+      return;
+    }
     if (!c.ev_valid[which]) return;
     DG_HIP(hipSetDevice(ctx->device));
     hipEvent_t a = c.ev[which == 0 ? 0 : 2], b = c.ev[which == 0 ? 1 : 3];

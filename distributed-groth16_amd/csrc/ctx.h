@@ -82,6 +82,9 @@ struct dg16_ctx {
   // bits into it, dg16_sync reads it after the stream has drained).  bit 0: dg16_qap index out of range.
   unsigned* dev_flag_host = nullptr;
   unsigned* dev_flag = nullptr;
+  // ClkProbe counters of the accumulation kernels (msm_impl.h): two device words per channel -- shader ticks, 100-MHz ticks
+  // of the most recent accumulation whose timing events live on that channel (dg16_last_kernel_ms, which = 2)
+  unsigned long long* kclk = nullptr;
   // HBM budget of the window tables of ONE resident key / base set built from here on (dg16_ctx_set_table_budget);
   // 0 = unlimited (one table row per window)
   size_t table_budget = 0;

@@ -143,6 +143,24 @@ __device__ __forceinline__ unsigned wave_atomic_inc(unsigned* __restrict__ ctr, 
   return old;
 }
 
+// The shader clock UNDER a kernel, measured by the kernel (round 6): s_memtime ticks once per shader cycle, s_memrealtime at
+// a constant 100 MHz (MI355X_MICROARCH.md); lane 0 of every workgroup adds its two deltas to clk[0], clk[1] (two atomics per
+// workgroup, outside every loop), so clk[0] / clk[1] x 100 MHz is the duration-weighted clock the chip held while the
+// kernel ran.  bench.py prices the accumulations against 16 lanes x 4 SIMDs x CUs x THAT clock (dg16_last_kernel_ms,
+// which = 2) next to the calibrated issue rate -- a cycle-based utilisation that does not move with DVFS.  clk may be null.
+struct ClkProbe {
+  unsigned long long c0 = 0, w0 = 0;
+  __device__ __forceinline__ void begin(const unsigned long long* clk) {
+    if (clk && threadIdx.x == 0) { c0 = __builtin_readcyclecounter(); w0 = wall_clock64(); }
+  }
+  __device__ __forceinline__ void end(unsigned long long* clk) const {
+    if (clk && threadIdx.x == 0) {
+      atomicAdd(&clk[0], (unsigned long long)__builtin_readcyclecounter() - c0);
+      atomicAdd(&clk[1], (unsigned long long)wall_clock64() - w0);
+    }
+  }
+};
+
 // ---- 1: digits + histogram -------------------------------------------------------------------
 template <class Fr>
 __global__ void __launch_bounds__(256) msm_digits_kernel(const Fr* __restrict__ scalars, size_t n, int mont,
@@ -724,7 +742,10 @@ msm_accumulate_kernel(MsmBases bases, size_t n,
                                                               const unsigned* __restrict__ seg_total,
                                                               const unsigned* __restrict__ entries,
                                                               XYZZ29<F>* __restrict__ seg_sum,
-                                                              XYZZ29<F>* __restrict__ buckets) {
+                                                              XYZZ29<F>* __restrict__ buckets,
+                                                              unsigned long long* __restrict__ clk) {
+  ClkProbe probe;
+  probe.begin(clk);
   const unsigned w = blockIdx.y % g.bw;
   const uint32_t* __restrict__ base_tab = bases.p[blockIdx.y / g.bw];
   const unsigned lane = threadIdx.x;
@@ -768,6 +789,7 @@ msm_accumulate_kernel(MsmBases bases, size_t n,
     if (sr.k == 1) buckets[DG_IDX(5, bucket_slot, (size_t)gridDim.y << g.log_nb)] = acc;   // a one-segment bucket needs no finalize
     else seg_sum[(size_t)blockIdx.y * g.seg_cap + DG_IDX(4, t, g.seg_cap)] = acc;
   }
+  probe.end(clk);
 }
 
 // ---- 4 (G2): the same segment accumulation with the accumulator staged through LDS -------------------------
@@ -782,12 +804,14 @@ msm_accumulate_lds_kernel(MsmBases bases, size_t n, MsmGeom g,
                           const unsigned* __restrict__ offsets, const unsigned* __restrict__ counts,
                           const unsigned* __restrict__ seg_off, const unsigned* __restrict__ seg_total,
                           const unsigned* __restrict__ entries, XYZZ29<F>* __restrict__ seg_sum,
-                          XYZZ29<F>* __restrict__ buckets) {
+                          XYZZ29<F>* __restrict__ buckets, unsigned long long* __restrict__ clk) {
   using FO = FieldOf<F>;
   using S = typename FO::Store;
   constexpr int BS = FO::BS;
   constexpr int WORDS = sizeof(S) / 4;
   __shared__ uint32_t sh[4 * WORDS][BLOCK];
+  ClkProbe probe;
+  probe.begin(clk);
   const unsigned lane = threadIdx.x;
   auto ld = [&](int coord) {
     S v;
@@ -877,6 +901,7 @@ msm_accumulate_lds_kernel(MsmBases bases, size_t n, MsmGeom g,
     if (sr.k == 1) buckets[((size_t)blockIdx.y << g.log_nb) + (sr.bslot & (((size_t)1 << g.log_nb) - 1))] = out;
     else seg_sum[(size_t)blockIdx.y * g.seg_cap + DG_IDX(4, t, g.seg_cap)] = out;
   }
+  probe.end(clk);
 #undef DG_STAGE
 }
 
@@ -1060,7 +1085,9 @@ msm_accumulate_steps_kernel(MsmBases bases, size_t n, MsmGeom g,
                             const unsigned* __restrict__ offsets, const unsigned* __restrict__ counts,
                             const unsigned* __restrict__ seg_off, const unsigned* __restrict__ seg_total,
                             const unsigned* __restrict__ entries, XYZZ29<F>* __restrict__ seg_sum,
-                            XYZZ29<F>* __restrict__ buckets) {
+                            XYZZ29<F>* __restrict__ buckets, unsigned long long* __restrict__ clk) {
+  ClkProbe probe;
+  probe.begin(clk);
   using FO = FieldOf<F>;
   using P = typename FO::Params;
   using S = typename FO::Store;
@@ -1184,6 +1211,7 @@ msm_accumulate_steps_kernel(MsmBases bases, size_t n, MsmGeom g,
     if (sr.k == 1) buckets[((size_t)blockIdx.y << g.log_nb) + (sr.bslot & (((size_t)1 << g.log_nb) - 1))] = out;
     else seg_sum[(size_t)blockIdx.y * g.seg_cap + DG_IDX(4, t, g.seg_cap)] = out;
   }
+  probe.end(clk);
 }
 
 // arkworks-form bases (C ABI) -> internal form for the accumulation kernels (plain dg16_msm: one pass per call,
@@ -1775,6 +1803,7 @@ struct MsmBuffers {
   size_t nbw, nrows;     // over all instances
   unsigned ninst;        // MSMs sharing the sort (msm_accumulate_kernel): bucket-window index wy = inst * bw + w
   RowGeom rg;
+  unsigned long long* clk = nullptr;   // ClkProbe counters of the accumulation kernel (two device words), or null
   hipEvent_t acc_done = nullptr;   // recorded right behind the accumulation KERNEL (in front of the G2 finalize that
                                    // msm_accumulate_phase launches after it): the end of dg16_last_kernel_ms's bracket
 };
@@ -1823,6 +1852,7 @@ void msm_accumulate_phase(hipStream_t s, const MsmSort& st, const MsmBuffers<F>&
   DG_BOUNDS_BIND();
   MsmBases mb{};
   for (unsigned i = 0; i < b.ninst; i++) mb.p[i] = (const uint32_t*)bases[i];
+  if (b.clk) DG_HIP(hipMemsetAsync(b.clk, 0, 16, s));
   if constexpr (sizeof(F) > 48) {
     // G2 (Fq2 coordinates): LDS-staged accumulator; two workgroups per CU must fit the 160 KiB of LDS
     constexpr int BLOCK = 1 << msm_acc_block_log<F>();
@@ -1833,10 +1863,10 @@ void msm_accumulate_phase(hipStream_t s, const MsmSort& st, const MsmBuffers<F>&
       // per 2^20-point launch on a fast box of the pool, 8.93-9.17 against 18.0-18.1 on a slow one
       // (profiles/r5b_*, r5c_*); both round-4 forms and the timing-based choice between them are gone.
       hipLaunchKernelGGL((msm_accumulate_steps_kernel<F, BLOCK>), grid, dim3(BLOCK), 0, s, mb, st.n, g, st.offsets,
-                         st.counts, st.seg_off, st.seg_total, st.entries, b.seg_sum, b.buckets);
+                         st.counts, st.seg_off, st.seg_total, st.entries, b.seg_sum, b.buckets, b.clk);
     } else {
       hipLaunchKernelGGL((msm_accumulate_lds_kernel<F, BLOCK>), grid, dim3(BLOCK), 0, s, mb, st.n, g, st.offsets, st.counts,
-                         st.seg_off, st.seg_total, st.entries, b.seg_sum, b.buckets);
+                         st.seg_off, st.seg_total, st.entries, b.seg_sum, b.buckets, b.clk);
     }
     if (b.acc_done) DG_HIP(hipEventRecord(b.acc_done, s));
     msm_finalize_lds_phase<F>(s, st, b);
@@ -1844,7 +1874,7 @@ void msm_accumulate_phase(hipStream_t s, const MsmSort& st, const MsmBuffers<F>&
     constexpr int BLOCK = 1 << msm_acc_block_log<F>();
     hipLaunchKernelGGL((msm_accumulate_kernel<F, BLOCK>), dim3((g.seg_cap + BLOCK - 1) / BLOCK, g.bw * b.ninst),
                        dim3(BLOCK), 0, s, mb, st.n, g, st.offsets, st.counts, st.seg_off, st.seg_total, st.entries,
-                       b.seg_sum, b.buckets);
+                       b.seg_sum, b.buckets, b.clk);
     if (b.acc_done) DG_HIP(hipEventRecord(b.acc_done, s));
   }
   DG_HIP(hipGetLastError());
@@ -2162,6 +2192,7 @@ void msm_reduce(Call& k, const MsmSort& st, const void* bases, bool out_affine, 
   MsmBuffers<F> b = msm_buffers<F>(k.c, st.g);
   k.begin_dominant();
   b.acc_done = k.c.ev[3];                    // = end_dominant(), but in front of the G2 finalize
+  if (k.ctx->kclk) b.clk = k.ctx->kclk + 2 * (&k.c - k.ctx->ch);
   msm_accumulate_phase<F>(k.s(), st, b, bases);
   k.c.ev_valid[1] = true;
   msm_bucket_phase<F>(k.s(), st, b, out_affine, out_dev);

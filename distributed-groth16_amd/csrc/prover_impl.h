@@ -390,6 +390,7 @@ static bool msms_typed(dg16_ctx* ctx, Call& k0, Call& k1, Call& k2, const PkDev&
   DG_HIP(hipStreamWaitEvent(main, ev[13], 0));
   DG_HIP(hipEventRecord(k2.c.ev[2], main));
   buf_b2.acc_done = k2.c.ev[3];              // the accumulation kernel alone; its finalize follows on the same stream
+  if (ctx->kclk) buf_b2.clk = ctx->kclk + 2 * 2;      // its clock under the kernel (dg16_last_kernel_ms(ctx, 2, 2))
   msm_accumulate_phase<Fq2>(main, st_ab, buf_b2, pk.b2_q);
   k2.c.ev_valid[1] = true;
   DG_HIP(hipEventRecord(ev[2], main));
@@ -411,6 +412,7 @@ static bool msms_typed(dg16_ctx* ctx, Call& k0, Call& k1, Call& k2, const PkDev&
     MsmBuffers<Fq> buf_b1 = msm_buffers<Fq>(k1.c, st_ab.g);
     MsmBuffers<Fq> buf_l = msm_buffers<Fq>(ctx->xws[1], st_ab.g);
     DG_HIP(hipEventRecord(k1.c.ev[2], main));
+    if (ctx->kclk) buf_a.clk = ctx->kclk + 2 * 1;     // (dg16_last_kernel_ms(ctx, 1, 2))
     msm_accumulate_phase<Fq>(main, st_ab, buf_a, pk.a_q);
     DG_HIP(hipEventRecord(k1.c.ev[3], main));
     k1.c.ev_valid[1] = true;

@@ -358,6 +358,10 @@ class Context:
         self._chk(self.L.dg16_device_info(self.h, buf, 64, ctypes.byref(cu)))
         return buf.value.decode(), cu.value
 
+    def last_kernel_mhz(self, channel=0):
+        """Shader clock (MHz) under the bucket accumulation last_kernel_ms(channel, 1) timed, measured by the kernel itself."""
+        return self.last_kernel_ms(channel, 2)
+
     def last_kernel_ms(self, channel=0, which=1):
         ms = ctypes.c_float()
         self._chk(self.L.dg16_last_kernel_ms(self.h, channel, which, ctypes.byref(ms)))

@@ -540,7 +540,9 @@ int dg16_groth16_verify(int curve, const void *alpha_g1, const void *beta_g2, co
 
 /* Duration in milliseconds of the dominant kernel(s) of the most recent call on `channel`
  * (HIP events recorded on the channel's stream); 0 if none.  which: 0 = whole call,
- * 1 = bucket accumulation (MSM) / butterfly passes (NTT). */
+ * 1 = bucket accumulation (MSM) / butterfly passes (NTT); 2 = NOT a duration: the shader clock in MHz the chip held
+ * under the bucket accumulation of `which = 1` (the kernel measures it: s_memtime against the 100-MHz s_memrealtime,
+ * summed over its workgroups), 0 if that call had none. */
 int dg16_last_kernel_ms(dg16_ctx *ctx, int channel, int which, float *ms);
 
 #ifdef __cplusplus

@@ -7,5 +7,5 @@ namespace dg16 {
 using GF = CurveTypes<DG_CURVE>::Fq2;
 template __global__ void msm_accumulate_steps_kernel<GF, 128>(MsmBases, size_t, MsmGeom, const unsigned*, const unsigned*,
                                                               const unsigned*, const unsigned*, const unsigned*,
-                                                              XYZZ29<GF>*, XYZZ29<GF>*);
+                                                              XYZZ29<GF>*, XYZZ29<GF>*, unsigned long long*);
 }  // namespace dg16

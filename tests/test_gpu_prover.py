@@ -130,6 +130,11 @@ def test_prove_medium_sizes_vs_oracle(curve, log_m):
     import bench
     cb, ok = bench.cpu_baseline_and_parity(ctx(), torch.device("cuda", 0), log_m, curve)
     assert ok
+    # the accumulation kernels of that proof measured the clock they ran under (ClkProbe: dg16_last_kernel_ms, which = 2):
+    # a plausible shader clock for the G2 launch (channel 2) and A's G1 launch (channel 1)
+    for ch in (2, 1):
+        mhz = ctx().last_kernel_mhz(ch)
+        assert 500.0 < mhz < 3000.0, (ch, mhz)
 
 
 @pytest.mark.parametrize("curve,log_m,frac", [("bn254", 14, 0.5), ("bn254", 14, 0.26), ("bn254", 12, 0.01),

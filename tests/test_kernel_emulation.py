@@ -149,7 +149,7 @@ def run_bucket(text, kernel, curve, group, spec):
     lane.mem[STOT] = 1
     for j, (idx, neg) in enumerate(spec):
         lane.mem[ENT + 4 * j] = idx | (0x80000000 if neg else 0)
-    karg = [0] * 34
+    karg = [0] * 36                                                # (.. + the null ClkProbe pointer at 0x88)
 
     def put64(off, v):
         karg[off // 4], karg[off // 4 + 1] = v & 0xFFFFFFFF, v >> 32
@@ -252,7 +252,7 @@ def test_g1_accumulation_workgroup_with_the_bucket_tree():
         seg_running += (cnt + (1 << seg_log) - 1) >> seg_log
     mem[STOT] = seg_running
     assert seg_running == 4
-    karg = [0] * 34
+    karg = [0] * 36                                                # (.. + the null ClkProbe pointer at 0x88)
 
     def put64(off, v):
         karg[off // 4], karg[off // 4 + 1] = v & 0xFFFFFFFF, v >> 32
