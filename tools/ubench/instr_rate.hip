@@ -55,6 +55,8 @@ __global__ void NAME(uint64_t* out, int iters, uint32_t a, uint32_t b, long long
 }
 KERNEL64(k_mad_u64_u32, "v_mad_u64_u32 %0, vcc, %16, %17, %0\n\tv_mad_u64_u32 %1, vcc, %16, %17, %1\n\tv_mad_u64_u32 %2, vcc, %16, %17, %2\n\tv_mad_u64_u32 %3, vcc, %16, %17, %3\n\tv_mad_u64_u32 %4, vcc, %16, %17, %4\n\tv_mad_u64_u32 %5, vcc, %16, %17, %5\n\tv_mad_u64_u32 %6, vcc, %16, %17, %6\n\tv_mad_u64_u32 %7, vcc, %16, %17, %7\n\tv_mad_u64_u32 %8, vcc, %16, %17, %8\n\tv_mad_u64_u32 %9, vcc, %16, %17, %9\n\tv_mad_u64_u32 %10, vcc, %16, %17, %10\n\tv_mad_u64_u32 %11, vcc, %16, %17, %11\n\tv_mad_u64_u32 %12, vcc, %16, %17, %12\n\tv_mad_u64_u32 %13, vcc, %16, %17, %13\n\tv_mad_u64_u32 %14, vcc, %16, %17, %14\n\tv_mad_u64_u32 %15, vcc, %16, %17, %15")
 KERNEL64(k_lshl_add_u64, "v_lshl_add_u64 %0, %0, 0, %0\n\tv_lshl_add_u64 %1, %1, 0, %1\n\tv_lshl_add_u64 %2, %2, 0, %2\n\tv_lshl_add_u64 %3, %3, 0, %3\n\tv_lshl_add_u64 %4, %4, 0, %4\n\tv_lshl_add_u64 %5, %5, 0, %5\n\tv_lshl_add_u64 %6, %6, 0, %6\n\tv_lshl_add_u64 %7, %7, 0, %7\n\tv_lshl_add_u64 %8, %8, 0, %8\n\tv_lshl_add_u64 %9, %9, 0, %9\n\tv_lshl_add_u64 %10, %10, 0, %10\n\tv_lshl_add_u64 %11, %11, 0, %11\n\tv_lshl_add_u64 %12, %12, 0, %12\n\tv_lshl_add_u64 %13, %13, 0, %13\n\tv_lshl_add_u64 %14, %14, 0, %14\n\tv_lshl_add_u64 %15, %15, 0, %15")
+KERNEL64(k_lshrrev_b64, "v_lshrrev_b64 %0, 29, %0\n\tv_lshrrev_b64 %1, 29, %1\n\tv_lshrrev_b64 %2, 29, %2\n\tv_lshrrev_b64 %3, 29, %3\n\tv_lshrrev_b64 %4, 29, %4\n\tv_lshrrev_b64 %5, 29, %5\n\tv_lshrrev_b64 %6, 29, %6\n\tv_lshrrev_b64 %7, 29, %7\n\tv_lshrrev_b64 %8, 29, %8\n\tv_lshrrev_b64 %9, 29, %9\n\tv_lshrrev_b64 %10, 29, %10\n\tv_lshrrev_b64 %11, 29, %11\n\tv_lshrrev_b64 %12, 29, %12\n\tv_lshrrev_b64 %13, 29, %13\n\tv_lshrrev_b64 %14, 29, %14\n\tv_lshrrev_b64 %15, 29, %15")
+KERNEL32(k_and_b32_e32, "v_and_b32 %0, %16, %0\n\tv_and_b32 %1, %16, %1\n\tv_and_b32 %2, %16, %2\n\tv_and_b32 %3, %16, %3\n\tv_and_b32 %4, %16, %4\n\tv_and_b32 %5, %16, %5\n\tv_and_b32 %6, %16, %6\n\tv_and_b32 %7, %16, %7\n\tv_and_b32 %8, %16, %8\n\tv_and_b32 %9, %16, %9\n\tv_and_b32 %10, %16, %10\n\tv_and_b32 %11, %16, %11\n\tv_and_b32 %12, %16, %12\n\tv_and_b32 %13, %16, %13\n\tv_and_b32 %14, %16, %14\n\tv_and_b32 %15, %16, %15")
 KERNEL32(k_mul_lo_u32, "v_mul_lo_u32 %0, %16, %0\n\tv_mul_lo_u32 %1, %16, %1\n\tv_mul_lo_u32 %2, %16, %2\n\tv_mul_lo_u32 %3, %16, %3\n\tv_mul_lo_u32 %4, %16, %4\n\tv_mul_lo_u32 %5, %16, %5\n\tv_mul_lo_u32 %6, %16, %6\n\tv_mul_lo_u32 %7, %16, %7\n\tv_mul_lo_u32 %8, %16, %8\n\tv_mul_lo_u32 %9, %16, %9\n\tv_mul_lo_u32 %10, %16, %10\n\tv_mul_lo_u32 %11, %16, %11\n\tv_mul_lo_u32 %12, %16, %12\n\tv_mul_lo_u32 %13, %16, %13\n\tv_mul_lo_u32 %14, %16, %14\n\tv_mul_lo_u32 %15, %16, %15")
 KERNEL32(k_mul_hi_u32, "v_mul_hi_u32 %0, %16, %0\n\tv_mul_hi_u32 %1, %16, %1\n\tv_mul_hi_u32 %2, %16, %2\n\tv_mul_hi_u32 %3, %16, %3\n\tv_mul_hi_u32 %4, %16, %4\n\tv_mul_hi_u32 %5, %16, %5\n\tv_mul_hi_u32 %6, %16, %6\n\tv_mul_hi_u32 %7, %16, %7\n\tv_mul_hi_u32 %8, %16, %8\n\tv_mul_hi_u32 %9, %16, %9\n\tv_mul_hi_u32 %10, %16, %10\n\tv_mul_hi_u32 %11, %16, %11\n\tv_mul_hi_u32 %12, %16, %12\n\tv_mul_hi_u32 %13, %16, %13\n\tv_mul_hi_u32 %14, %16, %14\n\tv_mul_hi_u32 %15, %16, %15")
 KERNEL32(k_mul_u32_u24, "v_mul_u32_u24 %0, %16, %0\n\tv_mul_u32_u24 %1, %16, %1\n\tv_mul_u32_u24 %2, %16, %2\n\tv_mul_u32_u24 %3, %16, %3\n\tv_mul_u32_u24 %4, %16, %4\n\tv_mul_u32_u24 %5, %16, %5\n\tv_mul_u32_u24 %6, %16, %6\n\tv_mul_u32_u24 %7, %16, %7\n\tv_mul_u32_u24 %8, %16, %8\n\tv_mul_u32_u24 %9, %16, %9\n\tv_mul_u32_u24 %10, %16, %10\n\tv_mul_u32_u24 %11, %16, %11\n\tv_mul_u32_u24 %12, %16, %12\n\tv_mul_u32_u24 %13, %16, %13\n\tv_mul_u32_u24 %14, %16, %14\n\tv_mul_u32_u24 %15, %16, %15")
@@ -104,7 +106,7 @@ int main() {
 CHECK(hipMalloc(&d_cyc, 8));
 #define R(k) run(#k, k, d_out, cus, mhz, 32); run(#k, k, d_out, cus, mhz, 8);
   R(k_add_u32) R(k_add_co_u32) R(k_addc_co_u32) R(k_add3_u32) R(k_alignbit) R(k_and_or) R(k_fma_f32)
-  R(k_mul_lo_u32) R(k_mul_hi_u32) R(k_mad_u64_u32) R(k_lshl_add_u64)
+  R(k_mul_lo_u32) R(k_mul_hi_u32) R(k_mad_u64_u32) R(k_lshl_add_u64) R(k_lshrrev_b64) R(k_and_b32_e32)
   R(k_mul_u32_u24) R(k_mul_hi_u32_u24) R(k_mad_u32_u24) R(k_mad_i32_i24) R(k_dot4_u32_u8)
   R(k_fma_f64) R(k_mul_f64) R(k_add_f64)
   return 0;
