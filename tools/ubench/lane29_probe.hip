@@ -1,0 +1,210 @@
+// Limb-per-lane field / group arithmetic (csrc/lane29.h) against the one-product-per-lane chains it replaces
+// (msm_impl.h: dbl_wave29 / add_wave29): semantics of the row primitives on this device, parity of products and group
+// operations on random operands and on the special cases, and the time of a dependent chain in both forms.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I distributed-groth16_amd/csrc -I include tools/ubench/lane29_probe.hip -o tools/ubench/lane29_probe
+#include "msm_impl.h"
+#include "lane29.h"
+#include <cstdio>
+#include <vector>
+
+using namespace dg16;
+using F = bn254_fq;
+using P = typename FieldOf<F>::Params;
+constexpr int BS = XYZZ29<F>::BS;
+using S = Fe<P, BS, 1>;
+
+__device__ uint32_t mix(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+  return x;
+}
+// a pseudo-random element < 4 p (normalised limbs), the same in every lane
+__device__ S rnd_fe(uint32_t seed) {
+  S r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) r.l[i] = mix(seed * 16u + i) & lane29::MASK;
+  r.l[8] &= (1u << 23) - 1;       // p >> 232 ~ 2^21.6: below 4 p
+  return r;
+}
+__device__ bool same(const S& a, const S& b) {
+  const auto ca = canon(a), cb = canon(b);
+  bool ok = true;
+#pragma unroll
+  for (int i = 0; i < 9; i++) ok = ok && ca.l[i] == cb.l[i];
+  return ok;
+}
+
+__global__ void __launch_bounds__(64) k_prims(uint32_t* out) {
+  const uint32_t lane = threadIdx.x, v = 100 + lane, w = 1000 + lane;
+  uint32_t r0, r1, r2, r3;
+  asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %1 row_shr:3 row_mask:0xf bank_mask:0xf bound_ctrl:0" : "=&v"(r0) : "v"(v));
+  asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %1 row_shl:8 row_mask:0xf bank_mask:0xf bound_ctrl:0" : "=&v"(r1) : "v"(v));
+  asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %1 row_ror:7 row_mask:0xf bank_mask:0xf" : "=&v"(r2) : "v"(v));
+  asm volatile("s_nop 1\n\tv_add_u32_dpp %0, %1, %2 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0" : "=&v"(r3) : "v"(v), "v"(w));
+  const auto s16 = __builtin_amdgcn_permlane16_swap(v, w, false, false);
+  const auto s32 = __builtin_amdgcn_permlane32_swap(v, w, false, false);
+  out[lane] = r0; out[64 + lane] = r1; out[128 + lane] = r2; out[192 + lane] = r3;
+  out[256 + lane] = s16[0]; out[320 + lane] = s16[1]; out[384 + lane] = s32[0]; out[448 + lane] = s32[1];
+}
+
+__global__ void __launch_bounds__(64) k_check_mul(unsigned* bad) {
+  lane29::K<P> k;
+  k.init();
+  const S a = rnd_fe(2 * blockIdx.x + 1), b = rnd_fe(2 * blockIdx.x + 2);
+  const S ref = fit<BS>(a * b);
+  const uint32_t la = lane29::to_lane(k, a), lb = lane29::to_lane(k, b);
+  const S got = lane29::from_lane<P, BS>(lane29::full_norm(lane29::mul(k, la, lb)));
+  // a subtraction and a doubled operand as well
+  const S ref2 = fit<BS>((a - b) * dbl(b));
+  const S got2 = lane29::from_lane<P, BS>(lane29::full_norm(lane29::mul(k, lane29::sub<1>(k, la, lb), lb << 1)));
+  if (!same(ref, got) && threadIdx.x == 0) atomicAdd(bad, 1u);
+  if (!same(ref2, got2) && threadIdx.x == 0) atomicAdd(bad + 1, 1u);
+}
+
+__device__ XYZZ29<F> rnd_pt(uint32_t seed) { return {rnd_fe(4 * seed), rnd_fe(4 * seed + 1), rnd_fe(4 * seed + 2), rnd_fe(4 * seed + 3)}; }
+__device__ bool same_pt(const XYZZ29<F>& a, const XYZZ29<F>& b) {
+  if (a.is_inf() || b.is_inf()) return a.is_inf() == b.is_inf();
+  return same(a.x, b.x) && same(a.y, b.y) && same(a.zz, b.zz) && same(a.zzz, b.zzz);
+}
+__global__ void __launch_bounds__(64) k_check_pt(unsigned* bad) {
+  lane29::K<P> k;
+  k.init();
+  const XYZZ29<F> p = rnd_pt(2 * blockIdx.x + 1), o = rnd_pt(2 * blockIdx.x + 2);
+  const lane29::Pt lp = lane29::to_pt<F>(k, p), lo = lane29::to_pt<F>(k, o);
+  const bool d_ok = same_pt(dbl_wave29(p), lane29::from_pt<F>(k, lane29::dbl_pt(k, lp)));
+  const bool a_ok = same_pt(add_wave29(p, o), lane29::from_pt<F>(k, lane29::add_pt(k, lp, lo)));
+  // special cases: p + p (the doubling branch), p + (-p) (the identity), identity operands
+  const bool pp_ok = same_pt(add_wave29(p, p), lane29::from_pt<F>(k, lane29::add_pt(k, lp, lp)));
+  const XYZZ29<F> n = p.neg_pt();
+  const bool pn_ok = lane29::add_pt(k, lp, lane29::to_pt<F>(k, n)).inf;
+  const lane29::Pt inf = lane29::to_pt<F>(k, XYZZ29<F>::inf());
+  const bool id_ok = same_pt(p, lane29::from_pt<F>(k, lane29::add_pt(k, lp, inf))) &&
+                     same_pt(o, lane29::from_pt<F>(k, lane29::add_pt(k, inf, lo))) && lane29::dbl_pt(k, inf).inf;
+  // a chain: 16 doublings and an addition, three times (bounds of the steady state)
+  XYZZ29<F> r = p;
+  lane29::Pt lr = lp;
+  for (int it = 0; it < 3; it++) {
+    for (int j = 0; j < 16; j++) { r = dbl_wave29(r); lr = lane29::dbl_pt(k, lr); }
+    r = add_wave29(r, o);
+    lr = lane29::add_pt(k, lr, lo);
+  }
+  const bool c_ok = same_pt(r, lane29::from_pt<F>(k, lr));
+  if (threadIdx.x == 0) {
+    if (!d_ok) atomicAdd(bad, 1u);
+    if (!a_ok) atomicAdd(bad + 1, 1u);
+    if (!pp_ok) atomicAdd(bad + 2, 1u);
+    if (!pn_ok) atomicAdd(bad + 3, 1u);
+    if (!id_ok) atomicAdd(bad + 4, 1u);
+    if (!c_ok) atomicAdd(bad + 5, 1u);
+  }
+}
+
+template <bool NEW>
+__global__ void __launch_bounds__(64) k_chain(uint32_t* out, int iters, int dbls) {
+  const XYZZ29<F> p = rnd_pt(2 * blockIdx.x + 1), o = rnd_pt(2 * blockIdx.x + 2);
+  if constexpr (NEW) {
+    lane29::K<P> k;
+    k.init();
+    lane29::Pt r = lane29::to_pt<F>(k, p);
+    const lane29::Pt lo = lane29::to_pt<F>(k, o);
+#pragma unroll 1
+    for (int it = 0; it < iters; it++) {
+#pragma unroll 1
+      for (int j = 0; j < dbls; j++) r = lane29::dbl_pt(k, r);
+      r = lane29::add_pt(k, r, lo);
+    }
+    const XYZZ29<F> res = lane29::from_pt<F>(k, r);
+    if (threadIdx.x == 0) out[blockIdx.x] = res.x.l[0] ^ res.y.l[3] ^ res.zz.l[1];
+  } else {
+    XYZZ29<F> r = p;
+#pragma unroll 1
+    for (int it = 0; it < iters; it++) {
+#pragma unroll 1
+      for (int j = 0; j < dbls; j++) r = dbl_wave29(r);
+      r = add_wave29(r, o);
+    }
+    if (threadIdx.x == 0) out[blockIdx.x] = r.x.l[0] ^ r.y.l[3] ^ r.zz.l[1];
+  }
+}
+template <bool NEW>
+__global__ void __launch_bounds__(64) k_mulchain(uint32_t* out, int iters) {
+  S a = rnd_fe(2 * blockIdx.x + 1);
+  const S b = rnd_fe(2 * blockIdx.x + 2);
+  if constexpr (NEW) {
+    lane29::K<P> k;
+    k.init();
+    uint32_t x = lane29::to_lane(k, a);
+    const uint32_t y = lane29::to_lane(k, b);
+#pragma unroll 1
+    for (int it = 0; it < iters; it++) x = lane29::mul(k, x, y);
+    out[blockIdx.x * 64 + threadIdx.x] = x;
+  } else {
+#pragma unroll 1
+    for (int it = 0; it < iters; it++) a = fit<BS>(a * b);
+    if (threadIdx.x == 0) out[blockIdx.x] = a.l[0] ^ a.l[5];
+  }
+}
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
+template <class Fn>
+static float timed(Fn launch) {
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  launch();
+  hipDeviceSynchronize();
+  hipEventRecord(e0);
+  launch();
+  hipEventRecord(e1);
+  hipEventSynchronize(e1);
+  float ms = 0;
+  hipEventElapsedTime(&ms, e0, e1);
+  return ms;
+}
+int main() {
+  uint32_t* d;
+  CK(hipMalloc(&d, 1 << 20));
+  CK(hipMemset(d, 0, 1 << 20));
+  hipLaunchKernelGGL(k_prims, dim3(1), dim3(64), 0, 0, d);
+  std::vector<uint32_t> h(512);
+  CK(hipMemcpy(h.data(), d, 512 * 4, hipMemcpyDeviceToHost));
+  int bad = 0;
+  for (int l = 0; l < 64; l++) {
+    const int r = l & 15, base = l & ~15;
+    bad += h[l] != (r >= 3 ? 100u + l - 3 : 0u);
+    bad += h[64 + l] != (r + 8 < 16 ? 100u + l + 8 : 0u);
+    bad += h[128 + l] != 100u + base + ((r - 7 + 16) & 15);
+    bad += h[192 + l] != (r >= 1 ? 100u + l - 1 : 0u) + 1000u + l;
+    const int row = l >> 4;
+    // permlane16_swap(v, w): odd rows of the first <-> even rows of the second
+    bad += h[256 + l] != ((row & 1) ? 1000u + l - 16 : 100u + l);
+    bad += h[320 + l] != ((row & 1) ? 1000u + l : 100u + l + 16);
+    // permlane32_swap(v, w): upper half of the first <-> lower half of the second
+    bad += h[384 + l] != (l >= 32 ? 1000u + l - 32 : 100u + l);
+    bad += h[448 + l] != (l >= 32 ? 1000u + l : 100u + l + 32);
+  }
+  printf("row primitives (row_shr / row_shl / row_ror / add_dpp / permlane16_swap / permlane32_swap): %d mismatches\n", bad);
+  if (bad) {
+    for (int s = 0; s < 8; s++) { printf("set %d:", s); for (int l = 0; l < 64; l++) printf(" %u", h[64 * s + l]); printf("\n"); }
+  }
+  CK(hipMemset(d, 0, 64));
+  hipLaunchKernelGGL(k_check_mul, dim3(4096), dim3(64), 0, 0, d);
+  CK(hipDeviceSynchronize());
+  CK(hipMemcpy(h.data(), d, 64, hipMemcpyDeviceToHost));
+  printf("products: %u of 4096 wrong; (a - b)(2 b): %u wrong\n", h[0], h[1]);
+  CK(hipMemset(d, 0, 64));
+  hipLaunchKernelGGL(k_check_pt, dim3(1024), dim3(64), 0, 0, d);
+  CK(hipDeviceSynchronize());
+  CK(hipMemcpy(h.data(), d, 64, hipMemcpyDeviceToHost));
+  printf("of 1024: doubling %u wrong, addition %u, p + p %u, p - p %u, identity operands %u, chain of 48 doublings + 3 additions %u\n",
+         h[0], h[1], h[2], h[3], h[4], h[5]);
+  for (int blocks : {1, 256, 1024}) {
+    const int iters = 200;
+    const float m_old = timed([&] { hipLaunchKernelGGL(k_mulchain<false>, dim3(blocks), dim3(64), 0, 0, d, 4 * iters); });
+    const float m_new = timed([&] { hipLaunchKernelGGL(k_mulchain<true>, dim3(blocks), dim3(64), 0, 0, d, 4 * iters); });
+    const float t_old = timed([&] { hipLaunchKernelGGL(k_chain<false>, dim3(blocks), dim3(64), 0, 0, d, iters, 16); });
+    const float t_new = timed([&] { hipLaunchKernelGGL(k_chain<true>, dim3(blocks), dim3(64), 0, 0, d, iters, 16); });
+    printf("%4d waves: dependent product %.3f -> %.3f us; 16 doublings + 1 addition: %.2f -> %.2f us (%.2fx)\n", blocks,
+           1e3 * m_old / (4 * iters), 1e3 * m_new / (4 * iters), 1e3 * t_old / iters, 1e3 * t_new / iters, t_old / t_new);
+  }
+  CK(hipDeviceSynchronize());
+  return 0;
+}
