@@ -390,10 +390,64 @@ __device__ __forceinline__ XYZZ29<F> from_pt(const K<typename FieldOf<F>::Params
   using P = typename FieldOf<F>::Params;
   constexpr int BS = XYZZ29<F>::BS;
   if (p.inf) return XYZZ29<F>::inf();
-  // bring the coordinates under the storage bound: a product with R mod p (x3, y3 are differences below 16 p)
+  // x3 < 11.25 p goes under the storage bound through a product with R mod p; y3 < 6.7 p, zz3, zzz3 < 3.3 p fit
   const uint32_t one = k.one();
-  return {from_lane<P, BS>(full_norm(mul(k, p.x, one))), from_lane<P, BS>(full_norm(mul(k, p.y, one))),
+  static_assert(BS >= 448, "y3 < 6.7 p is stored as it is");
+  return {from_lane<P, BS>(full_norm(mul(k, p.x, one))), from_lane<P, BS>(full_norm(p.y)),
           from_lane<P, BS>(full_norm(p.zz)), from_lane<P, BS>(full_norm(p.zzz))};
+}
+// which coordinate fields run their chains in this form: nine-limb base fields (BN254 Fq)
+template <class F>
+constexpr bool enabled() {
+#ifdef DG16_NO_LANE_CHAINS        // (A/B switch: the one-product-per-lane chains of msm_impl.h everywhere)
+  return false;
+#else
+  return !FieldOf<F>::EXT && RR<typename FieldOf<F>::Params>::N == N && RR<typename FieldOf<F>::Params>::W == W;
+#endif
+}
+
+// ---- lane form in memory: the words of an XYZZ29<F> (nine per coordinate), read and written by the lanes that own the
+// limbs.  What the chains store for THEMSELVES may hold tight limbs and coordinates up to ~12 p (raw); what other code
+// reads as an XYZZ29 must come from from_pt (normalised limbs, below the storage bound).  Identity: ZZ all zero. --------
+template <class F>
+__device__ __forceinline__ Pt load_pt(const K<typename FieldOf<F>::Params>& k, const XYZZ29<F>* src) {
+  const uint32_t* w = reinterpret_cast<const uint32_t*>(src);
+  const unsigned i = k.l16 < (unsigned)N ? k.l16 : 0u;
+  const bool on = k.l16 < (unsigned)N;
+  Pt p;
+  p.x = on ? w[i] : 0u;
+  p.y = on ? w[N + i] : 0u;
+  p.zz = on ? w[2 * N + i] : 0u;
+  p.zzz = on ? w[3 * N + i] : 0u;
+  p.inf = __builtin_amdgcn_ballot_w64(p.zz != 0u) == 0;
+  return p;
+}
+template <class F>
+__device__ __forceinline__ void store_pt_raw(const K<typename FieldOf<F>::Params>& k, XYZZ29<F>* dst, const Pt& p) {
+  uint32_t* w = reinterpret_cast<uint32_t*>(dst);
+  if (k.row == 0 && k.l16 < (unsigned)N) {
+    w[k.l16] = p.x;
+    w[N + k.l16] = p.y;
+    w[2 * N + k.l16] = p.inf ? 0u : p.zz;
+    w[3 * N + k.l16] = p.inf ? 0u : p.zzz;
+  }
+}
+// the same, as a proper XYZZ29 (normalised limbs, coordinates below the storage bound: x through a product with R mod p)
+template <class F>
+__device__ __forceinline__ void store_pt(const K<typename FieldOf<F>::Params>& k, XYZZ29<F>* dst, const Pt& p) {
+  Pt q = p;
+  if (!p.inf) {
+    q.x = full_norm(mul(k, p.x, k.one()));
+    q.y = full_norm(p.y);          // y3 < 6.7 p (dbl_pt / add_pt), below the storage bound of 7 p
+    q.zz = full_norm(p.zz);
+    q.zzz = full_norm(p.zzz);
+  }
+  store_pt_raw<F>(k, dst, q);
+}
+// -p (y < 6.7 p -> 9 p - y)
+template <class P>
+__device__ __forceinline__ Pt neg_pt(const K<P>& k, const Pt& p) {
+  return {p.x, sub<2>(k, 0u, p.y), p.zz, p.zzz, p.inf};
 }
 #endif  // __HIPCC__
 

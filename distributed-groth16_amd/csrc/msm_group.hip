@@ -83,9 +83,7 @@ __global__ void __launch_bounds__(512) matvec_points_wave_kernel(const Fr* __res
   }
   __syncthreads();
   if (wave != 0) return;
-  XYZZ29<F> acc = XYZZ29<F>::inf();
-#pragma unroll 1
-  for (unsigned c = 0; c < cols; c++) acc = add_wave29(acc, part[c]);
+  const XYZZ29<F> acc = sum_points_wave<F>(part, cols);
   if (lane == 0) out[blockIdx.x] = acc.to_xyzz32().to_affine();
 }
 // out[e][r] = sum_c M[r][c] P[e][c]: few outputs -> a workgroup each (<= 8 terms: two waves per SIMD, 256 registers each),
@@ -162,9 +160,7 @@ __global__ void __launch_bounds__(512) mpc_combine_kernel(const Jacobian<F>* __r
   if (lane == 0) part[wave] = v;
   __syncthreads();
   if (wave != 0) return;
-  XYZZ29<F> acc = XYZZ29<F>::inf();
-#pragma unroll 1
-  for (unsigned i = 0; i < n_terms; i++) acc = add_wave29(acc, part[i]);
+  const XYZZ29<F> acc = sum_points_wave<F>(part, n_terms);
   if (lane == 0) *out = acc.to_xyzz32().to_jacobian();
 }
 // terms: n_terms Jacobian points; scalars: n_terms Fr (only those under `mask` are read); all device pointers

@@ -22,6 +22,7 @@
 #include "bounds.h"
 #include "ctx.h"
 #include "ec29.h"
+#include "lane29.h"
 #include "types.h"
 
 namespace dg16 {
@@ -1545,8 +1546,14 @@ __device__ __forceinline__ int wnaf4_words(const uint32_t* k, int nbits, bool ne
 // either -- there is none today -- or that wants one code path for all groups).
 // Several waves of one workgroup may run chains side by side, each on its own `lds`: the two barriers below are WORKGROUP
 // barriers, reached by every wave exactly twice whatever its point and scalar (no early return in front of them).
+template <class F, int NW, bool ALLOW_SPLIT>
+__device__ __forceinline__ XYZZ29<F> scalar_mul_lane29(const XYZZ29<F>& p_in, const uint32_t* k, ScalarMulLds<F>* lds);
+template <class F, int NW>
+__device__ __forceinline__ XYZZ29<F> scalar_mul_two_waves_lane29(const XYZZ29<F>& p_in, const uint32_t* k,
+                                                                 ScalarMulLds<F>* lds, XYZZ29<F>* xchg);
 template <class F, int NW, bool ALLOW_SPLIT = true>
 __device__ __forceinline__ XYZZ29<F> scalar_mul_wave29(const XYZZ29<F>& p_in, const uint32_t* k, ScalarMulLds<F>* lds) {
+  if constexpr (lane29::enabled<F>()) return scalar_mul_lane29<F, NW, ALLOW_SPLIT>(p_in, k, lds);   // (lane29.h)
   constexpr int BS = XYZZ29<F>::BS;
   constexpr bool SPLIT = ALLOW_SPLIT && GlvOf<F>::enabled && GlvCofactorOne<F>::value && NW == 8;
   const unsigned lane = __lane_id();
@@ -1633,6 +1640,7 @@ template <class F, int NW>
 __device__ __forceinline__ XYZZ29<F> scalar_mul_two_waves29(const XYZZ29<F>& p_in, const uint32_t* k, ScalarMulLds<F>* lds,
                                                             XYZZ29<F>* xchg) {
   static_assert(NW == 8, "eight-word scalars");
+  if constexpr (lane29::enabled<F>()) return scalar_mul_two_waves_lane29<F, NW>(p_in, k, lds, xchg);   // (lane29.h)
   constexpr int BS = XYZZ29<F>::BS;
   using GC = typename GlvOf<F>::C;
   const unsigned lane = __lane_id(), h = (threadIdx.x >> 6) & 1u;
@@ -1682,6 +1690,155 @@ __device__ __forceinline__ XYZZ29<F> scalar_mul_two_waves29(const XYZZ29<F>& p_i
   __syncthreads();
   if (h == 0) acc = add_wave29(acc, *xchg);
   return p_inf ? p_in : acc;
+}
+
+// ---- the same chains in LIMB-PER-LANE form (lane29.h) for the nine-limb base fields ----------------------------------
+// One register per coordinate, a column-parallel product on each row of 16 lanes, the four products of a level on the four
+// rows: a doubling 0.85 us instead of 2.1, an addition ~1.1 instead of 3.2 (profiles/r6l_lane29_probe.txt).  The table
+// of odd multiples lives in the same LDS slots in raw lane form (lane29::store_pt_raw); p_in, k and the result are what
+// the forms above take and return.
+template <class F, int NW, bool ALLOW_SPLIT>
+__device__ __forceinline__ XYZZ29<F> scalar_mul_lane29(const XYZZ29<F>& p_in, const uint32_t* k, ScalarMulLds<F>* lds) {
+  using P = typename FieldOf<F>::Params;
+  constexpr bool SPLIT = ALLOW_SPLIT && GlvOf<F>::enabled && GlvCofactorOne<F>::value && NW == 8;
+  const unsigned lane = __lane_id();
+  lane29::K<P> kc;
+  kc.init();
+  const bool p_inf = p_in.is_inf();
+  lane29::Pt p = lane29::to_pt<F>(kc, p_in);
+  if (p_inf) p = {kc.one(), kc.one(), kc.one(), kc.one(), false};     // (stand-in: the barriers below must be reached)
+  {
+    const lane29::Pt p2 = lane29::dbl_pt(kc, p);
+    lane29::Pt m = p;
+#pragma unroll 1
+    for (int j = 0; j < 4; j++) {
+      if (j) m = lane29::add_pt(kc, m, p2);
+      lane29::store_pt_raw<F>(kc, &lds->tab[j], m);
+    }
+  }
+  int len = 0;
+  if constexpr (SPLIT) {
+    using GC = typename GlvOf<F>::C;
+    uint32_t h[2][8];
+    glv::split<GC>(k, h[0], h[1]);
+    if (lane < 2) {
+      uint32_t w[5];
+#pragma unroll
+      for (int i = 0; i < 4; i++) w[i] = lane ? h[1][i] : h[0][i];
+      w[4] = 0;
+      const bool neg_half = ((lane ? h[1][7] : h[0][7]) >> 31) != 0;
+      len = wnaf4_words<5>(w, 128, neg_half, lds->naf[lane]);
+    }
+    __syncthreads();
+    {
+      // phi(x, y) = (BETA x, y): row j of the wave takes entry j -- one product for the four entries
+      Fp<P> beta32;
+#pragma unroll
+      for (int i = 0; i < Fp<P>::NL; i++) beta32.l[i] = GC::BETA[i];
+      const uint32_t beta = lane29::to_lane(kc, FieldOf<F>::from32(beta32));
+      const uint32_t* src = reinterpret_cast<const uint32_t*>(&lds->tab[kc.row]);
+      uint32_t* dst = reinterpret_cast<uint32_t*>(&lds->tab[4 + kc.row]);
+      const bool on = kc.l16 < 9u;
+      const unsigned i = on ? kc.l16 : 0u;
+      const uint32_t bx = lane29::mul(kc, on ? src[i] : 0u, beta);
+      if (on) {
+        dst[i] = bx;
+        dst[9 + i] = src[9 + i];
+        dst[18 + i] = src[18 + i];
+        dst[27 + i] = src[27 + i];
+      }
+    }
+    len = max(__shfl(len, 0), __shfl(len, 1));
+  } else {
+    if (lane == 0) len = wnaf4_words<NW>(k, NW * 32, false, lds->naf[0]);
+    len = __shfl(len, 0);
+  }
+  __syncthreads();
+  lane29::Pt acc = {kc.one(), kc.one(), 0u, 0u, true};
+#pragma unroll 1
+  for (int i = len - 1; i >= 0; i--) {
+    acc = lane29::dbl_pt(kc, acc);
+#pragma unroll 1
+    for (int hf = 0; hf < (SPLIT ? 2 : 1); hf++) {
+      const int d = lds->naf[hf][i];
+      if (d == 0) continue;
+      lane29::Pt o = lane29::load_pt<F>(kc, &lds->tab[4 * hf + ((d < 0 ? -d : d) >> 1)]);
+      if (d < 0) o = lane29::neg_pt(kc, o);
+      acc = lane29::add_pt(kc, acc, o);
+    }
+  }
+  return p_inf ? p_in : lane29::from_pt<F>(kc, acc);
+}
+template <class F, int NW>
+__device__ __forceinline__ XYZZ29<F> scalar_mul_two_waves_lane29(const XYZZ29<F>& p_in, const uint32_t* k,
+                                                                 ScalarMulLds<F>* lds, XYZZ29<F>* xchg) {
+  using P = typename FieldOf<F>::Params;
+  using GC = typename GlvOf<F>::C;
+  const unsigned lane = __lane_id(), h = (threadIdx.x >> 6) & 1u;
+  lane29::K<P> kc;
+  kc.init();
+  const bool p_inf = p_in.is_inf();
+  lane29::Pt p = lane29::to_pt<F>(kc, p_in);
+  if (p_inf) p = {kc.one(), kc.one(), kc.one(), kc.one(), false};
+  {
+    Fp<P> beta32;
+#pragma unroll
+    for (int i = 0; i < Fp<P>::NL; i++) beta32.l[i] = GC::BETA[i];
+    const uint32_t beta = lane29::to_lane(kc, FieldOf<F>::from32(beta32));
+    if (h) p.x = lane29::mul(kc, p.x, beta);          // wave 1 runs its chain over phi(P) = (BETA x, y)
+    const lane29::Pt p2 = lane29::dbl_pt(kc, p);
+    lane29::Pt m = p;
+#pragma unroll 1
+    for (int j = 0; j < 4; j++) {
+      if (j) m = lane29::add_pt(kc, m, p2);
+      lane29::store_pt_raw<F>(kc, &lds->tab[4 * h + j], m);
+    }
+  }
+  uint32_t hv[2][8];
+  glv::split<GC>(k, hv[0], hv[1]);
+  int len = 0;
+  if (lane == 0) {
+    uint32_t w[5];
+#pragma unroll
+    for (int i = 0; i < 4; i++) w[i] = h ? hv[1][i] : hv[0][i];
+    w[4] = 0;
+    len = wnaf4_words<5>(w, 128, ((h ? hv[1][7] : hv[0][7]) >> 31) != 0, lds->naf[h]);
+  }
+  len = __shfl(len, 0);
+  __syncthreads();
+  lane29::Pt acc = {kc.one(), kc.one(), 0u, 0u, true};
+#pragma unroll 1
+  for (int i = len - 1; i >= 0; i--) {
+    acc = lane29::dbl_pt(kc, acc);
+    const int d = lds->naf[h][i];
+    if (d == 0) continue;
+    lane29::Pt o = lane29::load_pt<F>(kc, &lds->tab[4 * h + ((d < 0 ? -d : d) >> 1)]);
+    if (d < 0) o = lane29::neg_pt(kc, o);
+    acc = lane29::add_pt(kc, acc, o);
+  }
+  if (h == 1) lane29::store_pt_raw<F>(kc, xchg, acc);
+  __syncthreads();
+  if (h == 0) acc = lane29::add_pt(kc, acc, lane29::load_pt<F>(kc, xchg));
+  return p_inf ? p_in : lane29::from_pt<F>(kc, acc);
+}
+// sum of n points in memory (proper XYZZ29s), uniform result: the chains that only add (the king's combination, the
+// terms of prove::A / B / C)
+template <class F>
+__device__ __forceinline__ XYZZ29<F> sum_points_wave(const XYZZ29<F>* pts, unsigned n) {
+  if constexpr (lane29::enabled<F>()) {
+    using P = typename FieldOf<F>::Params;
+    lane29::K<P> kc;
+    kc.init();
+    lane29::Pt acc = {kc.one(), kc.one(), 0u, 0u, true};
+#pragma unroll 1
+    for (unsigned i = 0; i < n; i++) acc = lane29::add_pt(kc, acc, lane29::load_pt<F>(kc, &pts[i]));
+    return lane29::from_pt<F>(kc, acc);
+  } else {
+    XYZZ29<F> acc = XYZZ29<F>::inf();
+#pragma unroll 1
+    for (unsigned i = 0; i < n; i++) acc = add_wave29(acc, pts[i]);
+    return acc;
+  }
 }
 
 // rows of 2^kRowLog buckets
@@ -1899,11 +2056,25 @@ __global__ void __launch_bounds__(64) msm_tail_kernel(const XYZZ29<F>* __restric
   window_sums += (size_t)blockIdx.x * g.bw;
   out += (size_t)blockIdx.x * (affine ? 2 : 3);
   XYZZ29<F> acc = XYZZ29<F>::inf();
+  if constexpr (lane29::enabled<F>()) {          // limb-per-lane chain (lane29.h): 0.85 us per doubling instead of 2.1
+    using P = typename FieldOf<F>::Params;
+    lane29::K<P> kc;
+    kc.init();
+    lane29::Pt a = {kc.one(), kc.one(), 0u, 0u, true};
 #pragma unroll 1
-  for (int w = (int)g.bw - 1; w >= 0; w--) {
+    for (int w = (int)g.bw - 1; w >= 0; w--) {
 #pragma unroll 1
-    for (unsigned k = 0; k < g.c; k++) acc = dbl_wave29(acc);
-    acc = add_wave29(acc, window_sums[w]);
+      for (unsigned k = 0; k < g.c; k++) a = lane29::dbl_pt(kc, a);
+      a = lane29::add_pt(kc, a, lane29::load_pt<F>(kc, &window_sums[w]));
+    }
+    acc = lane29::from_pt<F>(kc, a);
+  } else {
+#pragma unroll 1
+    for (int w = (int)g.bw - 1; w >= 0; w--) {
+#pragma unroll 1
+      for (unsigned k = 0; k < g.c; k++) acc = dbl_wave29(acc);
+      acc = add_wave29(acc, window_sums[w]);
+    }
   }
   if (threadIdx.x != 0) return;
   using FO = FieldOf<F>;

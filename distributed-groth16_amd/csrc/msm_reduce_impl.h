@@ -357,11 +357,22 @@ __global__ void __launch_bounds__(256 * HALVES) msm_top_kernel(TopGeom tg, const
   // (msm_impl.h: dbl_wave29 / add_wave29 -- ~1.5 us per G1 operation against ~11 us for a lone lane's, G2 3 against 25)
   constexpr unsigned RES = HALVES == 2 ? 256u : 0u;
   if ((threadIdx.x >> 6) == (RES >> 6)) {
-    XYZZ29<F> acc = sh[RES];
+    if constexpr (lane29::enabled<F>()) {        // limb-per-lane chain (lane29.h)
+      using P = typename FieldOf<F>::Params;
+      lane29::K<P> kc;
+      kc.init();
+      lane29::Pt a = lane29::load_pt<F>(kc, &sh[RES]);
 #pragma unroll 1
-    for (unsigned k = 0; k < tg.final_log; k++) acc = dbl_wave29(acc);
-    acc = add_wave29(acc, HALVES == 2 ? sh[0] : keep);
-    if ((threadIdx.x & 63) == 0) window_sums[blockIdx.x] = acc;
+      for (unsigned k = 0; k < tg.final_log; k++) a = lane29::dbl_pt(kc, a);
+      a = lane29::add_pt(kc, a, lane29::load_pt<F>(kc, HALVES == 2 ? &sh[0] : &keep));
+      lane29::store_pt<F>(kc, &window_sums[blockIdx.x], a);
+    } else {
+      XYZZ29<F> acc = sh[RES];
+#pragma unroll 1
+      for (unsigned k = 0; k < tg.final_log; k++) acc = dbl_wave29(acc);
+      acc = add_wave29(acc, HALVES == 2 ? sh[0] : keep);
+      if ((threadIdx.x & 63) == 0) window_sums[blockIdx.x] = acc;
+    }
   }
 }
 
