@@ -72,25 +72,40 @@ constexpr LimbArr<N> kp_norm(int k) {
   return r;
 }
 
-// multiples of p the chains subtract with (value bound of the subtrahend + 1) and the spread every one of them uses:
-// 4 x 2^29 moved from each limb into the one below, so that every limb below the top is >= 2^31 - 4
+// Multiples of p the group law subtracts with, per class of field (tools/lane_bounds.py walks dbl_pt / add_pt with these
+// and checks that the bounds of a chain's running point close below R): SUB[i] = the K of sub<i> (K > value bound of the
+// subtrahend), NEG = the multiple a quadratic-extension product negates b.c1 with, ZERO = how many multiples of p a zero
+// test compares against (its argument is below ZERO p).  Every constant is used in a "spread" form: 4 x 2^29 moved from
+// each limb into the one below, so that every limb below the top is >= 2^31 - 4 and dominates the subtrahend's.
 constexpr int kSpread = 4;
-constexpr int kSubKs[4] = {4, 6, 9, 13};
-constexpr int kZeroMultiples = 7;       // is_zero compares against 0, p, ..., 6 p (its argument is < 6.5 p)
+template <bool EXT> struct LawK;
+template <> struct LawK<false> {
+  static constexpr int SUB[4] = {4, 6, 9, 13};
+  static constexpr int NEG = 0;
+  static constexpr int ZERO = 7;
+};
+template <> struct LawK<true> {
+  static constexpr int SUB[4] = {4, 8, 10, 14};
+  static constexpr int NEG = 19;
+  static constexpr int ZERO = 8;
+};
+constexpr int kMaxZero = 8;
 
 enum Row : int {
   ROW_PS = 0,                  // 9 rows: PS[i][l] = p_(l - i)
   ROW_PP = 9,                  // 9 rows: PP[i][l] = p'_(l - i), l < 9
   ROW_P16 = 18,                // p_8 on lane 0
-  ROW_SUB = 19,                // 4 rows: spread k p
-  ROW_JP = 23,                 // 7 rows: j p, normalised
-  ROW_ONE = 30,                // R mod p
-  ROW_COUNT = 31
+  ROW_SUB = 19,                // 4 rows: spread K p
+  ROW_NEG = 23,                // spread NEG p
+  ROW_JP = 24,                 // kMaxZero rows: j p, normalised
+  ROW_ONE = 32,                // R mod p
+  ROW_RMP = 33,                // 2^261 - p (adding it and dropping the carry subtracts p)
+  ROW_COUNT = 34
 };
 struct TabData {
   uint32_t t[ROW_COUNT][16];
 };
-template <class P>
+template <class P, bool EXT>
 constexpr TabData make_tab() {
   TabData d{};
   const LimbArr<N> pp = pprime_limbs<P>();
@@ -101,19 +116,32 @@ constexpr TabData make_tab() {
     }
   d.t[ROW_P16][0] = RR<P>::PL.v[N - 1];
   for (int s = 0; s < 4; s++) {
-    const LimbArr<N> kp = rr::kp_limbs<P>(kSubKs[s], kSpread);
+    const LimbArr<N> kp = rr::kp_limbs<P>(LawK<EXT>::SUB[s], kSpread);
     for (int l = 0; l < N; l++) d.t[ROW_SUB + s][l] = kp.v[l];
   }
-  for (int j = 0; j < kZeroMultiples; j++) {
+  if (EXT) {
+    const LimbArr<N> kp = rr::kp_limbs<P>(LawK<EXT>::NEG, kSpread);
+    for (int l = 0; l < N; l++) d.t[ROW_NEG][l] = kp.v[l];
+  }
+  for (int j = 0; j < LawK<EXT>::ZERO; j++) {
     const LimbArr<N> jp = kp_norm<P>(j);
     for (int l = 0; l < N; l++) d.t[ROW_JP + j][l] = jp.v[l];
   }
   for (int l = 0; l < N; l++) d.t[ROW_ONE][l] = RR<P>::ONE.v[l];
+  {
+    // 2^261 - p = (all-ones) - p + 1
+    uint64_t carry = 1;
+    for (int l = 0; l < N; l++) {
+      const uint64_t v = (uint64_t)(MASK - RR<P>::PL.v[l]) + carry;
+      d.t[ROW_RMP][l] = (uint32_t)(v & MASK);
+      carry = v >> W;
+    }
+  }
   return d;
 }
-template <class P>
+template <class P, bool EXT>
 struct Tab {
-  static constexpr TabData v = make_tab<P>();
+  static constexpr TabData v = make_tab<P, EXT>();
 };
 
 #if defined(__HIPCC__)
@@ -184,10 +212,11 @@ __device__ __forceinline__ uint32_t three_piece(uint64_t c, uint32_t* p1_out = n
 // one parallel carry pass: limbs <= 2^29 + (largest limb >> 29) afterwards; the value (< 2^261) is unchanged
 __device__ __forceinline__ uint32_t renorm(uint32_t v) { return add_shr1(v & MASK, v >> W); }
 
-// per-lane constant registers of one field (built once per kernel)
-template <class P>
+// per-lane constant registers of one field (built once per kernel); EXT: the constants of the quadratic-extension law
+template <class P, bool EXT>
 struct K {
-  uint32_t ps[N], pp[N], p16, sub[4], lane8, jpv[kZeroMultiples];
+  using L = LawK<EXT>;
+  uint32_t ps[N], pp[N], p16, sub[4], neg, lane8, jpv[L::ZERO];
   unsigned l16, row;
   __device__ __forceinline__ void init() {
     const unsigned lane = __lane_id();
@@ -195,51 +224,50 @@ struct K {
     row = lane >> 4;
 #pragma unroll
     for (int i = 0; i < N; i++) {
-      ps[i] = Tab<P>::v.t[ROW_PS + i][l16];
-      pp[i] = Tab<P>::v.t[ROW_PP + i][l16];
+      ps[i] = Tab<P, EXT>::v.t[ROW_PS + i][l16];
+      pp[i] = Tab<P, EXT>::v.t[ROW_PP + i][l16];
     }
-    p16 = Tab<P>::v.t[ROW_P16][l16];
+    p16 = Tab<P, EXT>::v.t[ROW_P16][l16];
 #pragma unroll
-    for (int s = 0; s < 4; s++) sub[s] = Tab<P>::v.t[ROW_SUB + s][l16];
+    for (int s = 0; s < 4; s++) sub[s] = Tab<P, EXT>::v.t[ROW_SUB + s][l16];
+    neg = Tab<P, EXT>::v.t[ROW_NEG][l16];
 #pragma unroll
-    for (int j = 0; j < kZeroMultiples; j++) jpv[j] = Tab<P>::v.t[ROW_JP + j][l16];
+    for (int j = 0; j < L::ZERO; j++) jpv[j] = Tab<P, EXT>::v.t[ROW_JP + j][l16];
     lane8 = l16 == 8 ? 0xFFFFFFFFu : 0u;
   }
-  __device__ __forceinline__ uint32_t jp(int j) const { return jpv[j]; }
-  __device__ __forceinline__ uint32_t one() const { return Tab<P>::v.t[ROW_ONE][l16]; }
+  __device__ __forceinline__ uint32_t one() const { return Tab<P, EXT>::v.t[ROW_ONE][l16]; }
+  __device__ __forceinline__ uint32_t r_minus_p() const { return Tab<P, EXT>::v.t[ROW_RMP][l16]; }
 };
 
-// (a b) / R mod p.  Limbs of a, b <= LOOSE, values < 2^261; result tight (limbs <= 2^29 + 2), value < a b / R + 2.2 p
-template <class P>
-__device__ __forceinline__ uint32_t mul(const K<P>& k, uint32_t a, uint32_t b) {
-  uint32_t ab[N], bs[N], b16;
-  bcast9(ab, a);
-  shifts9(bs, b16, b);
-  uint64_t main = 0;
+// columns of a b (+ c d): lane l owns column l; column 16 on lane 0 of `hi`
+struct Cols {
+  uint64_t main, hi;
+};
+__device__ __forceinline__ void cols_mad(Cols& c, const uint32_t (&ab)[N], const uint32_t (&bs)[N], uint32_t b16) {
 #pragma unroll
-  for (int i = 0; i < N; i++) main += (uint64_t)ab[i] * bs[i];
-  uint64_t hi = (uint64_t)ab[N - 1] * b16;
-  // B1, B2
-  const uint32_t t = three_piece(main);
+  for (int i = 0; i < N; i++) c.main += (uint64_t)ab[i] * bs[i];
+  c.hi += (uint64_t)ab[N - 1] * b16;
+}
+// T -> T / R mod p (B1 .. B6 of the header): tight limbs, value < T / R + 2.01 p
+template <class KT>
+__device__ __forceinline__ uint32_t reduce(const KT& k, Cols c) {
+  const uint32_t t = three_piece(c.main);
   uint32_t tb[N];
   bcast9(tb, t);
   uint64_t mc = 0;
 #pragma unroll
   for (int i = 0; i < N; i++) mc += (uint64_t)tb[i] * k.pp[i];
-  // B3, B4
   const uint32_t m = three_piece(mc);
   uint32_t mb[N];
   bcast9(mb, m);
 #pragma unroll
-  for (int i = 0; i < N; i++) main += (uint64_t)mb[i] * k.ps[i];
-  hi += (uint64_t)mb[N - 1] * k.p16;
-  // B5
+  for (int i = 0; i < N; i++) c.main += (uint64_t)mb[i] * k.ps[i];
+  c.hi += (uint64_t)mb[N - 1] * k.p16;
   uint32_t p1, p2;
-  uint32_t L = three_piece(main, &p1, &p2);
+  uint32_t L = three_piece(c.main, &p1, &p2);
   const uint32_t e = ((L + 2u) >> W) & k.lane8;
   L = add_shr1(L, e);
-  // B6
-  const uint32_t h0 = (uint32_t)hi & MASK, h1 = (uint32_t)(hi >> W) & MASK;
+  const uint32_t h0 = (uint32_t)c.hi & MASK, h1 = (uint32_t)(c.hi >> W) & MASK;
   uint32_t top, rot;
   asm volatile(
       "s_nop 1\n\t"
@@ -253,18 +281,36 @@ __device__ __forceinline__ uint32_t mul(const K<P>& k, uint32_t a, uint32_t b) {
   const uint32_t res = k.l16 < 7u ? rot : top;
   return renorm(res);
 }
-
-// ---- additions: limb-wise, then one carry pass ------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t add(uint32_t a, uint32_t b) { return renorm(a + b); }
-__device__ __forceinline__ uint32_t dbl(uint32_t a) { return renorm(a << 1); }
-__device__ __forceinline__ uint32_t tpl(uint32_t a) { return renorm(a + (a << 1)); }
-// a - b + k p, SUB = index into kSubKs (k > value bound of b in p; limbs of b < 2^31 - 4, of a <= 2^30)
-template <int SUB, class P>
-__device__ __forceinline__ uint32_t sub(const K<P>& k, uint32_t a, uint32_t b) { return renorm(a + (k.sub[SUB] - b)); }
+// (a b) / R mod p.  Limbs of a, b <= LOOSE, values < 2^261; result tight (limbs <= 2^29 + 2), value < a b / R + 2.01 p
+template <class KT>
+__device__ __forceinline__ uint32_t mul(const KT& k, uint32_t a, uint32_t b) {
+  uint32_t ab[N], bs[N], b16;
+  bcast9(ab, a);
+  shifts9(bs, b16, b);
+  Cols c = {0, 0};
+  cols_mad(c, ab, bs, b16);
+  return reduce(k, c);
+}
+// carry passes until every limb is below 2^29 (the form Fe<P, B, 1> holds); usually one or two
+__device__ __forceinline__ uint32_t full_norm(uint32_t v) {
+  while (__builtin_amdgcn_ballot_w64(v > MASK)) v = renorm(v);
+  return v;
+}
+// v (normalised limbs, every row the same) -> v - p when v >= p: the limb-wise comparison as two 9-bit integers (bit l =
+// limb l differs upwards / downwards: the highest differing limb decides)
+template <class KT>
+__device__ __forceinline__ uint32_t cond_sub_p(const KT& k, uint32_t v) {
+  const uint32_t pl = k.ps[0];                       // PS[0][l] = p_l
+  const unsigned gt = (unsigned)__builtin_amdgcn_ballot_w64(v > pl) & 0x1FFu;
+  const unsigned lt = (unsigned)__builtin_amdgcn_ballot_w64(v < pl) & 0x1FFu;
+  if (gt < lt) return v;
+  uint32_t r = full_norm(v + k.r_minus_p());        // + (2^261 - p); the carry out of limb 8 lands on lane 9 and is dropped
+  return k.l16 < (unsigned)N ? r : 0u;
+}
 
 // ---- rows ---------------------------------------------------------------------------------------------------------------
 // r holds one value per row: every row gets all four
-__device__ __forceinline__ void rows_to_all(uint32_t r, uint32_t& r0, uint32_t& r1, uint32_t& r2, uint32_t& r3) {
+__device__ __forceinline__ void rows_to_all32(uint32_t r, uint32_t& r0, uint32_t& r1, uint32_t& r2, uint32_t& r3) {
   // odd rows of the first operand <-> even rows of the second: [A B C D], [A B C D] -> [A A C C], [B B D D]
   const auto s = __builtin_amdgcn_permlane16_swap(r, r, false, false);
   const auto e = __builtin_amdgcn_permlane32_swap(s[0], s[0], false, false);   // [A A C C] x2 -> [A A A A], [C C C C]
@@ -274,180 +320,334 @@ __device__ __forceinline__ void rows_to_all(uint32_t r, uint32_t& r0, uint32_t& 
   r1 = o[0];
   r3 = o[1];
 }
-// element-wise select by row
-__device__ __forceinline__ uint32_t by_row(unsigned row, uint32_t v0, uint32_t v1, uint32_t v2, uint32_t v3) {
-  return row == 0 ? v0 : row == 1 ? v1 : row == 2 ? v2 : v3;
-}
 
-// carry passes until every limb is below 2^29 (the form Fe<P, B, 1> holds); usually one or two
-__device__ __forceinline__ uint32_t full_norm(uint32_t v) {
-  while (__builtin_amdgcn_ballot_w64(v > MASK)) v = renorm(v);
-  return v;
-}
-// is the value (tight limbs, < 6.5 p) zero mod p?  Uniform across the wave when the operand is (every row holds it).
-template <class P>
-__device__ __forceinline__ bool is_zero(const K<P>& k, uint32_t v) {
-  v = full_norm(v);
-  bool z = false;
+// ---- field policies: what the group law below is written against ----------------------------------------------------
+// E: an element (registers, the same in every row unless a product has just put four different ones on the four rows);
+// every E handed around has TIGHT limbs (<= 2^29 + 16).
+template <class P_>
+struct Fq9 {
+  using P = P_;
+  static constexpr bool EXT = false;
+  static constexpr int WORDS = N;
+  using E = uint32_t;
+  using KT = K<P, false>;
+  static __device__ __forceinline__ E zero() { return 0u; }
+  static __device__ __forceinline__ E one(const KT& k) { return k.one(); }
+  static __device__ __forceinline__ E mul(const KT& k, E a, E b) { return lane29::mul(k, a, b); }
+  static __device__ __forceinline__ E dbl(E a) { return renorm(a << 1); }
+  static __device__ __forceinline__ E tpl(E a) { return renorm(a + (a << 1)); }
+  static __device__ __forceinline__ E dbl_raw(E a) { return a << 1; }
+  static __device__ __forceinline__ E add_raw(E a, E b) { return a + b; }
+  // a - b + K p (limbs of b < 2^31 - 4, of a <= 2^30)
+  template <int I>
+  static __device__ __forceinline__ E sub(const KT& k, E a, E b) { return renorm(a + (k.sub[I] - b)); }
+  static __device__ __forceinline__ E sel(bool c, E a, E b) { return c ? a : b; }
+  static __device__ __forceinline__ bool is_zero(const KT& k, E v) {
+    v = full_norm(v);
+    bool z = false;
 #pragma unroll
-  for (int j = 0; j < kZeroMultiples; j++) z = z || (__builtin_amdgcn_ballot_w64(v != k.jp(j)) & 0xFFFFull) == 0;
-  return z;
-}
-
-// ---- XYZZ points, one register per coordinate, the same in every row -------------------------------------------------
-struct Pt {
-  uint32_t x, y, zz, zzz;
-  bool inf;               // uniform
-};
-
-// Fe (nine registers, the same in every lane) <-> lane form
-template <class P, int B>
-__device__ __forceinline__ uint32_t to_lane(const K<P>& k, const Fe<P, B, 1>& f) {
-  uint32_t v = 0;
-#pragma unroll
-  for (int i = 0; i < N; i++) v = k.l16 == (unsigned)i ? f.l[i] : v;
-  return v;
-}
-template <class P, int B>
-__device__ __forceinline__ Fe<P, B, 1> from_lane(uint32_t v) {
-  uint32_t o[N];
-  bcast9(o, v);
-  Fe<P, B, 1> f;
-#pragma unroll
-  for (int i = 0; i < N; i++) f.l[i] = o[i];
-  return f;
-}
-
-// 2 p                                                                                         (dbl-2008-s-1, a = 0)
-// value bounds (in p): coordinates in < 7, out < 2.5 + 13 (x3, y3), < 2.5 (zz3, zzz3); tools/lane29_model.py
-template <class P>
-__device__ __forceinline__ Pt dbl_pt(const K<P>& k, const Pt& p) {
-  if (p.inf) return p;
-  const unsigned row = k.row;
-  const uint32_t u = p.y << 1;                                   // loose
-  // level 1: rows 0, 2: v = u^2 | rows 1, 3: xx = x^2
-  const uint32_t a1 = (row & 1u) ? p.x : u;
-  const uint32_t r1 = mul(k, a1, a1);
-  const auto s1 = __builtin_amdgcn_permlane16_swap(r1, r1, false, false);
-  const uint32_t v = s1[0], xx = s1[1];
-  const uint32_t m = tpl(xx);
-  // level 2: w = u v | s = x v | m^2 | zz3 = v zz
-  const uint32_t a2 = by_row(row, u, p.x, m, p.zz);
-  const uint32_t b2 = row == 2 ? m : v;
-  const uint32_t r2 = mul(k, a2, b2);
-  uint32_t w, s, mm, zz3;
-  rows_to_all(r2, w, s, mm, zz3);
-  const uint32_t x3 = sub<1>(k, mm, s << 1);                     // 2 s < 5 p
-  const uint32_t sx = sub<3>(k, s, x3);                          // x3 < 2.5 p + 6 p
-  // level 3: m (s - x3) | w y | zzz3 = w zzz
-  const uint32_t a3 = row == 0 ? m : w;
-  const uint32_t b3 = by_row(row, sx, p.y, p.zzz, p.zzz);
-  const uint32_t r3 = mul(k, a3, b3);
-  uint32_t t0, t1, zzz3, unused;
-  rows_to_all(r3, t0, t1, zzz3, unused);
-  return {x3, sub<0>(k, t0, t1), zz3, zzz3, false};
-}
-
-// p + o, complete                                                                                       (add-2008-s)
-template <class P>
-__device__ __forceinline__ Pt add_pt(const K<P>& k, const Pt& p, const Pt& o) {
-  if (o.inf) return p;
-  if (p.inf) return o;
-  const unsigned row = k.row;
-  // level 1: u1 = x1 zz2 | u2 = x2 zz1 | s1 = y1 zzz2 | s2 = y2 zzz1
-  const uint32_t r1 = mul(k, by_row(row, p.x, o.x, p.y, o.y), by_row(row, o.zz, p.zz, o.zzz, p.zzz));
-  uint32_t u1, u2, s1, s2;
-  rows_to_all(r1, u1, u2, s1, s2);
-  const uint32_t pd = sub<0>(k, u2, u1), rd = sub<0>(k, s2, s1);          // < 2.5 p + 4 p
-  if (is_zero(k, pd)) {
-    if (is_zero(k, rd)) return dbl_pt(k, p);
-    return {k.one(), k.one(), 0u, 0u, true};
+    for (int j = 0; j < KT::L::ZERO; j++) z = z || (__builtin_amdgcn_ballot_w64(v != k.jpv[j]) & 0xFFFFull) == 0;
+    return z;
   }
-  // level 2: pp = p^2 | rr = r^2 | zz1 zz2 | zzz1 zzz2
-  const uint32_t r2 = mul(k, by_row(row, pd, rd, p.zz, p.zzz), by_row(row, pd, rd, o.zz, o.zzz));
-  uint32_t pp, rr, zzp, zzzp;
-  rows_to_all(r2, pp, rr, zzp, zzzp);
-  // level 3: ppp = p pp | q = u1 pp | zz3 = (zz1 zz2) pp
-  const uint32_t r3 = mul(k, by_row(row, pd, u1, zzp, zzp), pp);
-  uint32_t ppp, q, zz3, unused;
-  rows_to_all(r3, ppp, q, zz3, unused);
-  const uint32_t x3 = sub<2>(k, rr, ppp + (q << 1));                      // ppp + 2 q < 7.5 p
-  const uint32_t qx = sub<3>(k, q, x3);                                   // x3 < 2.5 p + 9 p
-  // level 4: r (q - x3) | s1 ppp | zzz3 = (zzz1 zzz2) ppp
-  const uint32_t r4 = mul(k, by_row(row, rd, s1, zzzp, zzzp), row == 0 ? qx : ppp);
-  uint32_t t0, t1, zzz3;
-  rows_to_all(r4, t0, t1, zzz3, unused);
-  return {x3, sub<0>(k, t0, t1), zz3, zzz3, false};
-}
+  static __device__ __forceinline__ void swap16(E r, E& even, E& odd) {
+    const auto s = __builtin_amdgcn_permlane16_swap(r, r, false, false);
+    even = s[0];
+    odd = s[1];
+  }
+  static __device__ __forceinline__ void rows_to_all(E r, E& r0, E& r1, E& r2, E& r3) { rows_to_all32(r, r0, r1, r2, r3); }
+  static __device__ __forceinline__ bool any_nonzero(E v) { return __builtin_amdgcn_ballot_w64(v != 0u) != 0; }
+  static __device__ __forceinline__ E load(const KT& k, const uint32_t* w) { return k.l16 < (unsigned)N ? w[k.l16] : 0u; }
+  static __device__ __forceinline__ void store(const KT& k, uint32_t* w, E v) {
+    if (k.row == 0 && k.l16 < (unsigned)N) w[k.l16] = v;
+  }
+  // normalised limbs and a value below the storage bound BS / 64 p (through a product with R mod p: < 2.1 p; then at
+  // most one subtraction of p when the bound is that tight)
+  template <int BS>
+  static __device__ __forceinline__ E exit_norm(const KT& k, E v, bool reduce_it) {
+    if (!reduce_it) return full_norm(v);
+    v = full_norm(lane29::mul(k, v, k.one()));
+    if constexpr (BS < 192) v = cond_sub_p(k, v);
+    return v;
+  }
+  template <int B>
+  static __device__ __forceinline__ E from_regs(const KT& k, const Fe<P, B, 1>& f) {
+    uint32_t v = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) v = k.l16 == (unsigned)i ? f.l[i] : v;
+    return v;
+  }
+  template <int B>
+  static __device__ __forceinline__ Fe<P, B, 1> to_regs(E v) {
+    uint32_t o[N];
+    bcast9(o, v);
+    Fe<P, B, 1> f;
+#pragma unroll
+    for (int i = 0; i < N; i++) f.l[i] = o[i];
+    return f;
+  }
+};
+struct E2 {
+  uint32_t c0, c1;
+};
+// quadratic extension u^2 = -1 over a nine-limb field (BN254 Fq2): both components of a product on the SAME row --
+// c0 = a0 b0 + a1 (NEG p - b1), c1 = a0 b1 + a1 b0 as two dual-column accumulations over shared broadcasts of a, one
+// reduction each: ~235 issues against 2 x 3 base products on three lanes + joins in the form it replaces
+template <class P_>
+struct Fq9x2 {
+  using P = P_;
+  static_assert(Fq2Beta<P>::value == 1, "u^2 = -1");
+  static constexpr bool EXT = true;
+  static constexpr int WORDS = 2 * N;
+  using E = E2;
+  using KT = K<P, true>;
+  using B = Fq9<P>;
+  static __device__ __forceinline__ E zero() { return {0u, 0u}; }
+  static __device__ __forceinline__ E one(const KT& k) { return {k.one(), 0u}; }
+  static __device__ __forceinline__ E mul(const KT& k, E a, E b) {
+    const uint32_t nb1 = renorm(k.neg - b.c1);
+    uint32_t a0[N], a1[N], b0s[N], b1s[N], n1s[N], b0h, b1h, n1h;
+    bcast9(a0, a.c0);
+    bcast9(a1, a.c1);
+    shifts9(b0s, b0h, b.c0);
+    shifts9(b1s, b1h, b.c1);
+    shifts9(n1s, n1h, nb1);
+    Cols x = {0, 0}, y = {0, 0};
+    cols_mad(x, a0, b0s, b0h);
+    cols_mad(x, a1, n1s, n1h);
+    cols_mad(y, a0, b1s, b1h);
+    cols_mad(y, a1, b0s, b0h);
+    return {reduce(k, x), reduce(k, y)};
+  }
+  static __device__ __forceinline__ E dbl(E a) { return {renorm(a.c0 << 1), renorm(a.c1 << 1)}; }
+  static __device__ __forceinline__ E tpl(E a) { return {renorm(a.c0 + (a.c0 << 1)), renorm(a.c1 + (a.c1 << 1))}; }
+  static __device__ __forceinline__ E dbl_raw(E a) { return {a.c0 << 1, a.c1 << 1}; }
+  static __device__ __forceinline__ E add_raw(E a, E b) { return {a.c0 + b.c0, a.c1 + b.c1}; }
+  template <int I>
+  static __device__ __forceinline__ E sub(const KT& k, E a, E b) {
+    return {renorm(a.c0 + (k.sub[I] - b.c0)), renorm(a.c1 + (k.sub[I] - b.c1))};
+  }
+  static __device__ __forceinline__ E sel(bool c, E a, E b) { return {c ? a.c0 : b.c0, c ? a.c1 : b.c1}; }
+  static __device__ __forceinline__ bool is_zero1(const KT& k, uint32_t v) {
+    v = full_norm(v);
+    bool z = false;
+#pragma unroll
+    for (int j = 0; j < KT::L::ZERO; j++) z = z || (__builtin_amdgcn_ballot_w64(v != k.jpv[j]) & 0xFFFFull) == 0;
+    return z;
+  }
+  static __device__ __forceinline__ bool is_zero(const KT& k, E v) { return is_zero1(k, v.c0) && is_zero1(k, v.c1); }
+  static __device__ __forceinline__ void swap16(E r, E& even, E& odd) {
+    const auto s = __builtin_amdgcn_permlane16_swap(r.c0, r.c0, false, false);
+    const auto t = __builtin_amdgcn_permlane16_swap(r.c1, r.c1, false, false);
+    even = {s[0], t[0]};
+    odd = {s[1], t[1]};
+  }
+  static __device__ __forceinline__ void rows_to_all(E r, E& r0, E& r1, E& r2, E& r3) {
+    rows_to_all32(r.c0, r0.c0, r1.c0, r2.c0, r3.c0);
+    rows_to_all32(r.c1, r0.c1, r1.c1, r2.c1, r3.c1);
+  }
+  static __device__ __forceinline__ bool any_nonzero(E v) { return __builtin_amdgcn_ballot_w64((v.c0 | v.c1) != 0u) != 0; }
+  static __device__ __forceinline__ E load(const KT& k, const uint32_t* w) {
+    const bool on = k.l16 < (unsigned)N;
+    const unsigned i = on ? k.l16 : 0u;
+    return {on ? w[i] : 0u, on ? w[N + i] : 0u};
+  }
+  static __device__ __forceinline__ void store(const KT& k, uint32_t* w, E v) {
+    if (k.row == 0 && k.l16 < (unsigned)N) {
+      w[k.l16] = v.c0;
+      w[N + k.l16] = v.c1;
+    }
+  }
+  template <int BS>
+  static __device__ __forceinline__ E exit_norm(const KT& k, E v, bool reduce_it) {
+    if (!reduce_it) return {full_norm(v.c0), full_norm(v.c1)};
+    E r = {full_norm(lane29::mul(k, v.c0, k.one())), full_norm(lane29::mul(k, v.c1, k.one()))};
+    if constexpr (BS < 192) r = {cond_sub_p(k, r.c0), cond_sub_p(k, r.c1)};
+    return r;
+  }
+  template <int BB>
+  static __device__ __forceinline__ E from_regs(const KT& k, const Fe2<P, BB, 1>& f) {
+    uint32_t v0 = 0, v1 = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      v0 = k.l16 == (unsigned)i ? f.c0.l[i] : v0;
+      v1 = k.l16 == (unsigned)i ? f.c1.l[i] : v1;
+    }
+    return {v0, v1};
+  }
+  template <int BB>
+  static __device__ __forceinline__ Fe2<P, BB, 1> to_regs(E v) {
+    uint32_t o0[N], o1[N];
+    bcast9(o0, v.c0);
+    bcast9(o1, v.c1);
+    Fe2<P, BB, 1> f;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      f.c0.l[i] = o0[i];
+      f.c1.l[i] = o1[i];
+    }
+    return f;
+  }
+};
+template <class F> struct PolicyOf;
+template <class P> struct PolicyOf<Fp<P>> { using type = Fq9<P>; };
+template <class P> struct PolicyOf<Fp2<Fp<P>>> { using type = Fq9x2<P>; };
+template <class F> using Ops = typename PolicyOf<F>::type;
 
-// XYZZ29 (nine registers per coordinate, uniform across the wave) <-> Pt
-template <class F>
-__device__ __forceinline__ Pt to_pt(const K<typename FieldOf<F>::Params>& k, const XYZZ29<F>& p) {
-  return {to_lane(k, p.x), to_lane(k, p.y), to_lane(k, p.zz), to_lane(k, p.zzz), p.is_inf()};
-}
-template <class F>
-__device__ __forceinline__ XYZZ29<F> from_pt(const K<typename FieldOf<F>::Params>& k, const Pt& p) {
-  using P = typename FieldOf<F>::Params;
-  constexpr int BS = XYZZ29<F>::BS;
-  if (p.inf) return XYZZ29<F>::inf();
-  // x3 < 11.25 p goes under the storage bound through a product with R mod p; y3 < 6.7 p, zz3, zzz3 < 3.3 p fit
-  const uint32_t one = k.one();
-  static_assert(BS >= 448, "y3 < 6.7 p is stored as it is");
-  return {from_lane<P, BS>(full_norm(mul(k, p.x, one))), from_lane<P, BS>(full_norm(p.y)),
-          from_lane<P, BS>(full_norm(p.zz)), from_lane<P, BS>(full_norm(p.zzz))};
-}
-// which coordinate fields run their chains in this form: nine-limb base fields (BN254 Fq)
+// which coordinate fields run their chains in this form: nine-limb fields (BN254: Fq, and Fq2 with u^2 = -1)
 template <class F>
 constexpr bool enabled() {
 #ifdef DG16_NO_LANE_CHAINS        // (A/B switch: the one-product-per-lane chains of msm_impl.h everywhere)
   return false;
 #else
-  return !FieldOf<F>::EXT && RR<typename FieldOf<F>::Params>::N == N && RR<typename FieldOf<F>::Params>::W == W;
+  using P = typename FieldOf<F>::Params;
+  if constexpr (RR<P>::N != N || RR<P>::W != W) return false;
+  else if constexpr (FieldOf<F>::EXT) return Fq2Beta<P>::value == 1;
+  else return true;
 #endif
 }
 
-// ---- lane form in memory: the words of an XYZZ29<F> (nine per coordinate), read and written by the lanes that own the
-// limbs.  What the chains store for THEMSELVES may hold tight limbs and coordinates up to ~12 p (raw); what other code
-// reads as an XYZZ29 must come from from_pt (normalised limbs, below the storage bound).  Identity: ZZ all zero. --------
+// ---- XYZZ points: coordinates as elements, the same in every row -----------------------------------------------------
+template <class FO>
+struct Pt {
+  typename FO::E x, y, zz, zzz;
+  bool inf;               // uniform
+};
+template <class FO>
+__device__ __forceinline__ Pt<FO> inf_pt(const typename FO::KT& k) {
+  return {FO::one(k), FO::one(k), FO::zero(), FO::zero(), true};
+}
+template <class FO>
+__device__ __forceinline__ typename FO::E by_row(unsigned row, typename FO::E v0, typename FO::E v1, typename FO::E v2,
+                                                 typename FO::E v3) {
+  return FO::sel(row == 0, v0, FO::sel(row == 1, v1, FO::sel(row == 2, v2, v3)));
+}
+
+// 2 p                                                                                         (dbl-2008-s-1, a = 0)
+// (value bounds of every temporary: tools/lane_bounds.py)
+template <class FO>
+__device__ __forceinline__ Pt<FO> dbl_pt(const typename FO::KT& k, const Pt<FO>& p) {
+  using E = typename FO::E;
+  if (p.inf) return p;
+  const unsigned row = k.row;
+  const E u = FO::dbl(p.y);
+  // level 1: rows 0, 2: v = u^2 | rows 1, 3: xx = x^2
+  const E a1 = FO::sel((row & 1u) != 0, p.x, u);
+  const E r1 = FO::mul(k, a1, a1);
+  E v, xx;
+  FO::swap16(r1, v, xx);
+  const E m = FO::tpl(xx);
+  // level 2: w = u v | s = x v | m^2 | zz3 = zz v
+  const E a2 = by_row<FO>(row, u, p.x, m, p.zz);
+  const E b2 = FO::sel(row == 2, m, v);
+  const E r2 = FO::mul(k, a2, b2);
+  E w, s, mm, zz3;
+  FO::rows_to_all(r2, w, s, mm, zz3);
+  const E x3 = FO::template sub<1>(k, mm, FO::dbl_raw(s));
+  const E sx = FO::template sub<3>(k, s, x3);
+  // level 3: (s - x3) m | w y | zzz3 = zzz w
+  const E a3 = by_row<FO>(row, sx, w, p.zzz, p.zzz);
+  const E b3 = by_row<FO>(row, m, p.y, w, w);
+  const E r3 = FO::mul(k, a3, b3);
+  E t0, t1, zzz3, unused;
+  FO::rows_to_all(r3, t0, t1, zzz3, unused);
+  return {x3, FO::template sub<0>(k, t0, t1), zz3, zzz3, false};
+}
+
+// p + o, complete                                                                                       (add-2008-s)
+template <class FO>
+__device__ __forceinline__ Pt<FO> add_pt(const typename FO::KT& k, const Pt<FO>& p, const Pt<FO>& o) {
+  using E = typename FO::E;
+  if (o.inf) return p;
+  if (p.inf) return o;
+  const unsigned row = k.row;
+  // level 1: u1 = x1 zz2 | u2 = x2 zz1 | s1 = y1 zzz2 | s2 = y2 zzz1
+  const E r1 = FO::mul(k, by_row<FO>(row, p.x, o.x, p.y, o.y), by_row<FO>(row, o.zz, p.zz, o.zzz, p.zzz));
+  E u1, u2, s1, s2;
+  FO::rows_to_all(r1, u1, u2, s1, s2);
+  const E pd = FO::template sub<0>(k, u2, u1), rd = FO::template sub<0>(k, s2, s1);
+  if (FO::is_zero(k, pd)) {
+    if (FO::is_zero(k, rd)) return dbl_pt<FO>(k, p);
+    return inf_pt<FO>(k);
+  }
+  // level 2: pp = p^2 | rr = r^2 | zz1 zz2 | zzz1 zzz2
+  const E r2 = FO::mul(k, by_row<FO>(row, pd, rd, p.zz, p.zzz), by_row<FO>(row, pd, rd, o.zz, o.zzz));
+  E pp, rr, zzp, zzzp;
+  FO::rows_to_all(r2, pp, rr, zzp, zzzp);
+  // level 3: ppp = p pp | q = u1 pp | zz3 = (zz1 zz2) pp
+  const E r3 = FO::mul(k, by_row<FO>(row, pd, u1, zzp, zzp), pp);
+  E ppp, q, zz3, unused;
+  FO::rows_to_all(r3, ppp, q, zz3, unused);
+  const E x3 = FO::template sub<2>(k, rr, FO::add_raw(ppp, FO::dbl_raw(q)));
+  const E qx = FO::template sub<3>(k, q, x3);
+  // level 4: (q - x3) r | s1 ppp | zzz3 = (zzz1 zzz2) ppp
+  const E r4 = FO::mul(k, by_row<FO>(row, qx, s1, zzzp, zzzp), FO::sel(row == 0, rd, ppp));
+  E t0, t1, zzz3;
+  FO::rows_to_all(r4, t0, t1, zzz3, unused);
+  return {x3, FO::template sub<0>(k, t0, t1), zz3, zzz3, false};
+}
+// -p (y -> K2 p - y)
+template <class FO>
+__device__ __forceinline__ Pt<FO> neg_pt(const typename FO::KT& k, const Pt<FO>& p) {
+  return {p.x, FO::template sub<2>(k, FO::zero(), p.y), p.zz, p.zzz, p.inf};
+}
+
+// XYZZ29 (registers, uniform across the wave) <-> Pt
 template <class F>
-__device__ __forceinline__ Pt load_pt(const K<typename FieldOf<F>::Params>& k, const XYZZ29<F>* src) {
+__device__ __forceinline__ Pt<Ops<F>> to_pt(const typename Ops<F>::KT& k, const XYZZ29<F>& p) {
+  using FO = Ops<F>;
+  constexpr int BS = XYZZ29<F>::BS;
+  return {FO::template from_regs<BS>(k, p.x), FO::template from_regs<BS>(k, p.y), FO::template from_regs<BS>(k, p.zz),
+          FO::template from_regs<BS>(k, p.zzz), p.is_inf()};
+}
+// coordinates under the storage bound with normalised limbs: x always through a product with R mod p (x3 < 13.2 p); y, zz,
+// zzz as they are when the bound is 7 p (y3 < 7 p, zz3, zzz3 < 3.3 p: tools/lane_bounds.py), reduced when it is ~2 p
+template <class F>
+__device__ __forceinline__ Pt<Ops<F>> exit_pt(const typename Ops<F>::KT& k, const Pt<Ops<F>>& p) {
+  using FO = Ops<F>;
+  constexpr int BS = XYZZ29<F>::BS;
+  constexpr bool TIGHT = BS < 448;
+  static_assert(BS >= 448 || BS >= 130, "storage bound");
+  if (p.inf) return p;
+  return {FO::template exit_norm<BS>(k, p.x, true), FO::template exit_norm<BS>(k, p.y, TIGHT),
+          FO::template exit_norm<BS>(k, p.zz, TIGHT), FO::template exit_norm<BS>(k, p.zzz, TIGHT), false};
+}
+template <class F>
+__device__ __forceinline__ XYZZ29<F> from_pt(const typename Ops<F>::KT& k, const Pt<Ops<F>>& p_) {
+  using FO = Ops<F>;
+  constexpr int BS = XYZZ29<F>::BS;
+  if (p_.inf) return XYZZ29<F>::inf();
+  const Pt<FO> p = exit_pt<F>(k, p_);
+  return {FO::template to_regs<BS>(p.x), FO::template to_regs<BS>(p.y), FO::template to_regs<BS>(p.zz),
+          FO::template to_regs<BS>(p.zzz)};
+}
+
+// ---- lane form in memory: the words of an XYZZ29<F> (WORDS per coordinate), read and written by the lanes that own the
+// limbs.  What the chains store for THEMSELVES may hold tight limbs and coordinates up to ~13 p (raw); what other code
+// reads as an XYZZ29 goes through store_pt (normalised limbs, below the storage bound).  Identity: ZZ all zero. ----------
+template <class F>
+__device__ __forceinline__ Pt<Ops<F>> load_pt(const typename Ops<F>::KT& k, const XYZZ29<F>* src) {
+  using FO = Ops<F>;
   const uint32_t* w = reinterpret_cast<const uint32_t*>(src);
-  const unsigned i = k.l16 < (unsigned)N ? k.l16 : 0u;
-  const bool on = k.l16 < (unsigned)N;
-  Pt p;
-  p.x = on ? w[i] : 0u;
-  p.y = on ? w[N + i] : 0u;
-  p.zz = on ? w[2 * N + i] : 0u;
-  p.zzz = on ? w[3 * N + i] : 0u;
-  p.inf = __builtin_amdgcn_ballot_w64(p.zz != 0u) == 0;
+  Pt<FO> p;
+  p.x = FO::load(k, w);
+  p.y = FO::load(k, w + FO::WORDS);
+  p.zz = FO::load(k, w + 2 * FO::WORDS);
+  p.zzz = FO::load(k, w + 3 * FO::WORDS);
+  p.inf = !FO::any_nonzero(p.zz);
   return p;
 }
 template <class F>
-__device__ __forceinline__ void store_pt_raw(const K<typename FieldOf<F>::Params>& k, XYZZ29<F>* dst, const Pt& p) {
+__device__ __forceinline__ void store_pt_raw(const typename Ops<F>::KT& k, XYZZ29<F>* dst, const Pt<Ops<F>>& p) {
+  using FO = Ops<F>;
   uint32_t* w = reinterpret_cast<uint32_t*>(dst);
-  if (k.row == 0 && k.l16 < (unsigned)N) {
-    w[k.l16] = p.x;
-    w[N + k.l16] = p.y;
-    w[2 * N + k.l16] = p.inf ? 0u : p.zz;
-    w[3 * N + k.l16] = p.inf ? 0u : p.zzz;
-  }
+  FO::store(k, w, p.x);
+  FO::store(k, w + FO::WORDS, p.y);
+  FO::store(k, w + 2 * FO::WORDS, p.inf ? FO::zero() : p.zz);
+  FO::store(k, w + 3 * FO::WORDS, p.inf ? FO::zero() : p.zzz);
 }
-// the same, as a proper XYZZ29 (normalised limbs, coordinates below the storage bound: x through a product with R mod p)
 template <class F>
-__device__ __forceinline__ void store_pt(const K<typename FieldOf<F>::Params>& k, XYZZ29<F>* dst, const Pt& p) {
-  Pt q = p;
-  if (!p.inf) {
-    q.x = full_norm(mul(k, p.x, k.one()));
-    q.y = full_norm(p.y);          // y3 < 6.7 p (dbl_pt / add_pt), below the storage bound of 7 p
-    q.zz = full_norm(p.zz);
-    q.zzz = full_norm(p.zzz);
-  }
-  store_pt_raw<F>(k, dst, q);
-}
-// -p (y < 6.7 p -> 9 p - y)
-template <class P>
-__device__ __forceinline__ Pt neg_pt(const K<P>& k, const Pt& p) {
-  return {p.x, sub<2>(k, 0u, p.y), p.zz, p.zzz, p.inf};
+__device__ __forceinline__ void store_pt(const typename Ops<F>::KT& k, XYZZ29<F>* dst, const Pt<Ops<F>>& p) {
+  store_pt_raw<F>(k, dst, exit_pt<F>(k, p));
 }
 #endif  // __HIPCC__
 

@@ -1700,19 +1700,21 @@ __device__ __forceinline__ XYZZ29<F> scalar_mul_two_waves29(const XYZZ29<F>& p_i
 template <class F, int NW, bool ALLOW_SPLIT>
 __device__ __forceinline__ XYZZ29<F> scalar_mul_lane29(const XYZZ29<F>& p_in, const uint32_t* k, ScalarMulLds<F>* lds) {
   using P = typename FieldOf<F>::Params;
-  constexpr bool SPLIT = ALLOW_SPLIT && GlvOf<F>::enabled && GlvCofactorOne<F>::value && NW == 8;
+  using FO = lane29::Ops<F>;
+  using LPt = lane29::Pt<FO>;
+  constexpr bool SPLIT = ALLOW_SPLIT && GlvOf<F>::enabled && GlvCofactorOne<F>::value && NW == 8 && !FO::EXT;
   const unsigned lane = __lane_id();
-  lane29::K<P> kc;
+  typename FO::KT kc;
   kc.init();
   const bool p_inf = p_in.is_inf();
-  lane29::Pt p = lane29::to_pt<F>(kc, p_in);
-  if (p_inf) p = {kc.one(), kc.one(), kc.one(), kc.one(), false};     // (stand-in: the barriers below must be reached)
+  LPt p = lane29::to_pt<F>(kc, p_in);
+  if (p_inf) p = {FO::one(kc), FO::one(kc), FO::one(kc), FO::one(kc), false};   // (stand-in: the barriers below must be reached)
   {
-    const lane29::Pt p2 = lane29::dbl_pt(kc, p);
-    lane29::Pt m = p;
+    const LPt p2 = lane29::dbl_pt<FO>(kc, p);
+    LPt m = p;
 #pragma unroll 1
     for (int j = 0; j < 4; j++) {
-      if (j) m = lane29::add_pt(kc, m, p2);
+      if (j) m = lane29::add_pt<FO>(kc, m, p2);
       lane29::store_pt_raw<F>(kc, &lds->tab[j], m);
     }
   }
@@ -1735,7 +1737,7 @@ __device__ __forceinline__ XYZZ29<F> scalar_mul_lane29(const XYZZ29<F>& p_in, co
       Fp<P> beta32;
 #pragma unroll
       for (int i = 0; i < Fp<P>::NL; i++) beta32.l[i] = GC::BETA[i];
-      const uint32_t beta = lane29::to_lane(kc, FieldOf<F>::from32(beta32));
+      const uint32_t beta = FO::template from_regs<XYZZ29<F>::BS>(kc, FieldOf<F>::from32(beta32));
       const uint32_t* src = reinterpret_cast<const uint32_t*>(&lds->tab[kc.row]);
       uint32_t* dst = reinterpret_cast<uint32_t*>(&lds->tab[4 + kc.row]);
       const bool on = kc.l16 < 9u;
@@ -1754,17 +1756,17 @@ __device__ __forceinline__ XYZZ29<F> scalar_mul_lane29(const XYZZ29<F>& p_in, co
     len = __shfl(len, 0);
   }
   __syncthreads();
-  lane29::Pt acc = {kc.one(), kc.one(), 0u, 0u, true};
+  LPt acc = lane29::inf_pt<FO>(kc);
 #pragma unroll 1
   for (int i = len - 1; i >= 0; i--) {
-    acc = lane29::dbl_pt(kc, acc);
+    acc = lane29::dbl_pt<FO>(kc, acc);
 #pragma unroll 1
     for (int hf = 0; hf < (SPLIT ? 2 : 1); hf++) {
       const int d = lds->naf[hf][i];
       if (d == 0) continue;
-      lane29::Pt o = lane29::load_pt<F>(kc, &lds->tab[4 * hf + ((d < 0 ? -d : d) >> 1)]);
-      if (d < 0) o = lane29::neg_pt(kc, o);
-      acc = lane29::add_pt(kc, acc, o);
+      LPt o = lane29::load_pt<F>(kc, &lds->tab[4 * hf + ((d < 0 ? -d : d) >> 1)]);
+      if (d < 0) o = lane29::neg_pt<FO>(kc, o);
+      acc = lane29::add_pt<FO>(kc, acc, o);
     }
   }
   return p_inf ? p_in : lane29::from_pt<F>(kc, acc);
@@ -1774,23 +1776,26 @@ __device__ __forceinline__ XYZZ29<F> scalar_mul_two_waves_lane29(const XYZZ29<F>
                                                                  ScalarMulLds<F>* lds, XYZZ29<F>* xchg) {
   using P = typename FieldOf<F>::Params;
   using GC = typename GlvOf<F>::C;
+  using FO = lane29::Ops<F>;
+  using LPt = lane29::Pt<FO>;
+  static_assert(!FO::EXT, "the endomorphism split of a cofactor-one G1");
   const unsigned lane = __lane_id(), h = (threadIdx.x >> 6) & 1u;
-  lane29::K<P> kc;
+  typename FO::KT kc;
   kc.init();
   const bool p_inf = p_in.is_inf();
-  lane29::Pt p = lane29::to_pt<F>(kc, p_in);
-  if (p_inf) p = {kc.one(), kc.one(), kc.one(), kc.one(), false};
+  LPt p = lane29::to_pt<F>(kc, p_in);
+  if (p_inf) p = {FO::one(kc), FO::one(kc), FO::one(kc), FO::one(kc), false};
   {
     Fp<P> beta32;
 #pragma unroll
     for (int i = 0; i < Fp<P>::NL; i++) beta32.l[i] = GC::BETA[i];
-    const uint32_t beta = lane29::to_lane(kc, FieldOf<F>::from32(beta32));
+    const uint32_t beta = FO::template from_regs<XYZZ29<F>::BS>(kc, FieldOf<F>::from32(beta32));
     if (h) p.x = lane29::mul(kc, p.x, beta);          // wave 1 runs its chain over phi(P) = (BETA x, y)
-    const lane29::Pt p2 = lane29::dbl_pt(kc, p);
-    lane29::Pt m = p;
+    const LPt p2 = lane29::dbl_pt<FO>(kc, p);
+    LPt m = p;
 #pragma unroll 1
     for (int j = 0; j < 4; j++) {
-      if (j) m = lane29::add_pt(kc, m, p2);
+      if (j) m = lane29::add_pt<FO>(kc, m, p2);
       lane29::store_pt_raw<F>(kc, &lds->tab[4 * h + j], m);
     }
   }
@@ -1806,19 +1811,19 @@ __device__ __forceinline__ XYZZ29<F> scalar_mul_two_waves_lane29(const XYZZ29<F>
   }
   len = __shfl(len, 0);
   __syncthreads();
-  lane29::Pt acc = {kc.one(), kc.one(), 0u, 0u, true};
+  LPt acc = lane29::inf_pt<FO>(kc);
 #pragma unroll 1
   for (int i = len - 1; i >= 0; i--) {
-    acc = lane29::dbl_pt(kc, acc);
+    acc = lane29::dbl_pt<FO>(kc, acc);
     const int d = lds->naf[h][i];
     if (d == 0) continue;
-    lane29::Pt o = lane29::load_pt<F>(kc, &lds->tab[4 * h + ((d < 0 ? -d : d) >> 1)]);
-    if (d < 0) o = lane29::neg_pt(kc, o);
-    acc = lane29::add_pt(kc, acc, o);
+    LPt o = lane29::load_pt<F>(kc, &lds->tab[4 * h + ((d < 0 ? -d : d) >> 1)]);
+    if (d < 0) o = lane29::neg_pt<FO>(kc, o);
+    acc = lane29::add_pt<FO>(kc, acc, o);
   }
   if (h == 1) lane29::store_pt_raw<F>(kc, xchg, acc);
   __syncthreads();
-  if (h == 0) acc = lane29::add_pt(kc, acc, lane29::load_pt<F>(kc, xchg));
+  if (h == 0) acc = lane29::add_pt<FO>(kc, acc, lane29::load_pt<F>(kc, xchg));
   return p_inf ? p_in : lane29::from_pt<F>(kc, acc);
 }
 // sum of n points in memory (proper XYZZ29s), uniform result: the chains that only add (the king's combination, the
@@ -1826,12 +1831,12 @@ __device__ __forceinline__ XYZZ29<F> scalar_mul_two_waves_lane29(const XYZZ29<F>
 template <class F>
 __device__ __forceinline__ XYZZ29<F> sum_points_wave(const XYZZ29<F>* pts, unsigned n) {
   if constexpr (lane29::enabled<F>()) {
-    using P = typename FieldOf<F>::Params;
-    lane29::K<P> kc;
+    using FO = lane29::Ops<F>;
+    typename FO::KT kc;
     kc.init();
-    lane29::Pt acc = {kc.one(), kc.one(), 0u, 0u, true};
+    lane29::Pt<FO> acc = lane29::inf_pt<FO>(kc);
 #pragma unroll 1
-    for (unsigned i = 0; i < n; i++) acc = lane29::add_pt(kc, acc, lane29::load_pt<F>(kc, &pts[i]));
+    for (unsigned i = 0; i < n; i++) acc = lane29::add_pt<FO>(kc, acc, lane29::load_pt<F>(kc, &pts[i]));
     return lane29::from_pt<F>(kc, acc);
   } else {
     XYZZ29<F> acc = XYZZ29<F>::inf();
@@ -2057,15 +2062,15 @@ __global__ void __launch_bounds__(64) msm_tail_kernel(const XYZZ29<F>* __restric
   out += (size_t)blockIdx.x * (affine ? 2 : 3);
   XYZZ29<F> acc = XYZZ29<F>::inf();
   if constexpr (lane29::enabled<F>()) {          // limb-per-lane chain (lane29.h): 0.85 us per doubling instead of 2.1
-    using P = typename FieldOf<F>::Params;
-    lane29::K<P> kc;
+    using FO = lane29::Ops<F>;
+    typename FO::KT kc;
     kc.init();
-    lane29::Pt a = {kc.one(), kc.one(), 0u, 0u, true};
+    lane29::Pt<FO> a = lane29::inf_pt<FO>(kc);
 #pragma unroll 1
     for (int w = (int)g.bw - 1; w >= 0; w--) {
 #pragma unroll 1
-      for (unsigned k = 0; k < g.c; k++) a = lane29::dbl_pt(kc, a);
-      a = lane29::add_pt(kc, a, lane29::load_pt<F>(kc, &window_sums[w]));
+      for (unsigned k = 0; k < g.c; k++) a = lane29::dbl_pt<FO>(kc, a);
+      a = lane29::add_pt<FO>(kc, a, lane29::load_pt<F>(kc, &window_sums[w]));
     }
     acc = lane29::from_pt<F>(kc, a);
   } else {

@@ -358,13 +358,13 @@ __global__ void __launch_bounds__(256 * HALVES) msm_top_kernel(TopGeom tg, const
   constexpr unsigned RES = HALVES == 2 ? 256u : 0u;
   if ((threadIdx.x >> 6) == (RES >> 6)) {
     if constexpr (lane29::enabled<F>()) {        // limb-per-lane chain (lane29.h)
-      using P = typename FieldOf<F>::Params;
-      lane29::K<P> kc;
+      using FO = lane29::Ops<F>;
+      typename FO::KT kc;
       kc.init();
-      lane29::Pt a = lane29::load_pt<F>(kc, &sh[RES]);
+      lane29::Pt<FO> a = lane29::load_pt<F>(kc, &sh[RES]);
 #pragma unroll 1
-      for (unsigned k = 0; k < tg.final_log; k++) a = lane29::dbl_pt(kc, a);
-      a = lane29::add_pt(kc, a, lane29::load_pt<F>(kc, HALVES == 2 ? &sh[0] : &keep));
+      for (unsigned k = 0; k < tg.final_log; k++) a = lane29::dbl_pt<FO>(kc, a);
+      a = lane29::add_pt<FO>(kc, a, lane29::load_pt<F>(kc, HALVES == 2 ? &sh[0] : &keep));
       lane29::store_pt<F>(kc, &window_sums[blockIdx.x], a);
     } else {
       XYZZ29<F> acc = sh[RES];

@@ -9,9 +9,11 @@
 
 using namespace dg16;
 using F = bn254_fq;
+using F2 = Fp2<bn254_fq>;
 using P = typename FieldOf<F>::Params;
 constexpr int BS = XYZZ29<F>::BS;
 using S = Fe<P, BS, 1>;
+using FO = lane29::Ops<F>;
 
 __device__ uint32_t mix(uint32_t x) {
   x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
@@ -47,47 +49,74 @@ __global__ void __launch_bounds__(64) k_prims(uint32_t* out) {
 }
 
 __global__ void __launch_bounds__(64) k_check_mul(unsigned* bad) {
-  lane29::K<P> k;
+  FO::KT k;
   k.init();
   const S a = rnd_fe(2 * blockIdx.x + 1), b = rnd_fe(2 * blockIdx.x + 2);
   const S ref = fit<BS>(a * b);
-  const uint32_t la = lane29::to_lane(k, a), lb = lane29::to_lane(k, b);
-  const S got = lane29::from_lane<P, BS>(lane29::full_norm(lane29::mul(k, la, lb)));
-  // a subtraction and a doubled operand as well
+  const uint32_t la = FO::from_regs<BS>(k, a), lb = FO::from_regs<BS>(k, b);
+  const S got = FO::to_regs<BS>(lane29::full_norm(lane29::mul(k, la, lb)));
+  // a subtraction and a doubled operand as well; then the conditional subtraction of p
   const S ref2 = fit<BS>((a - b) * dbl(b));
-  const S got2 = lane29::from_lane<P, BS>(lane29::full_norm(lane29::mul(k, lane29::sub<1>(k, la, lb), lb << 1)));
+  const uint32_t l2 = lane29::mul(k, FO::sub<1>(k, la, lb), lb << 1);
+  const S got2 = FO::to_regs<BS>(lane29::cond_sub_p(k, lane29::full_norm(l2)));
   if (!same(ref, got) && threadIdx.x == 0) atomicAdd(bad, 1u);
   if (!same(ref2, got2) && threadIdx.x == 0) atomicAdd(bad + 1, 1u);
 }
 
-__device__ XYZZ29<F> rnd_pt(uint32_t seed) { return {rnd_fe(4 * seed), rnd_fe(4 * seed + 1), rnd_fe(4 * seed + 2), rnd_fe(4 * seed + 3)}; }
-__device__ bool same_pt(const XYZZ29<F>& a, const XYZZ29<F>& b) {
-  if (a.is_inf() || b.is_inf()) return a.is_inf() == b.is_inf();
-  return same(a.x, b.x) && same(a.y, b.y) && same(a.zz, b.zz) && same(a.zzz, b.zzz);
-}
-__global__ void __launch_bounds__(64) k_check_pt(unsigned* bad) {
-  lane29::K<P> k;
-  k.init();
-  const XYZZ29<F> p = rnd_pt(2 * blockIdx.x + 1), o = rnd_pt(2 * blockIdx.x + 2);
-  const lane29::Pt lp = lane29::to_pt<F>(k, p), lo = lane29::to_pt<F>(k, o);
-  const bool d_ok = same_pt(dbl_wave29(p), lane29::from_pt<F>(k, lane29::dbl_pt(k, lp)));
-  const bool a_ok = same_pt(add_wave29(p, o), lane29::from_pt<F>(k, lane29::add_pt(k, lp, lo)));
-  // special cases: p + p (the doubling branch), p + (-p) (the identity), identity operands
-  const bool pp_ok = same_pt(add_wave29(p, p), lane29::from_pt<F>(k, lane29::add_pt(k, lp, lp)));
-  const XYZZ29<F> n = p.neg_pt();
-  const bool pn_ok = lane29::add_pt(k, lp, lane29::to_pt<F>(k, n)).inf;
-  const lane29::Pt inf = lane29::to_pt<F>(k, XYZZ29<F>::inf());
-  const bool id_ok = same_pt(p, lane29::from_pt<F>(k, lane29::add_pt(k, lp, inf))) &&
-                     same_pt(o, lane29::from_pt<F>(k, lane29::add_pt(k, inf, lo))) && lane29::dbl_pt(k, inf).inf;
-  // a chain: 16 doublings and an addition, three times (bounds of the steady state)
-  XYZZ29<F> r = p;
-  lane29::Pt lr = lp;
-  for (int it = 0; it < 3; it++) {
-    for (int j = 0; j < 16; j++) { r = dbl_wave29(r); lr = lane29::dbl_pt(k, lr); }
-    r = add_wave29(r, o);
-    lr = lane29::add_pt(k, lr, lo);
+template <class G> struct Rnd;
+template <> struct Rnd<F> {
+  static __device__ S get(uint32_t seed) { return rnd_fe(seed); }
+  static __device__ bool eq(const S& a, const S& b) { return same(a, b); }
+};
+template <> struct Rnd<F2> {
+  using S2 = typename FieldOf<F2>::Store;
+  static __device__ S2 get(uint32_t seed) {
+    const S a = rnd_fe(2 * seed + 1000003u), b = rnd_fe(2 * seed + 1000004u);   // (< 4 p: squeeze under the Fq2 storage bound)
+    return {fit<XYZZ29<F2>::BS>(a * fe_one<P>()), fit<XYZZ29<F2>::BS>(b * fe_one<P>())};
   }
-  const bool c_ok = same_pt(r, lane29::from_pt<F>(k, lr));
+  static __device__ bool eq(const S2& a, const S2& b) {
+    const auto ca0 = canon(a.c0), cb0 = canon(b.c0), ca1 = canon(a.c1), cb1 = canon(b.c1);
+    bool ok = true;
+#pragma unroll
+    for (int i = 0; i < 9; i++) ok = ok && ca0.l[i] == cb0.l[i] && ca1.l[i] == cb1.l[i];
+    return ok;
+  }
+};
+template <class G>
+__device__ XYZZ29<G> rnd_pt(uint32_t seed) {
+  return {Rnd<G>::get(4 * seed), Rnd<G>::get(4 * seed + 1), Rnd<G>::get(4 * seed + 2), Rnd<G>::get(4 * seed + 3)};
+}
+template <class G>
+__device__ bool same_pt(const XYZZ29<G>& a, const XYZZ29<G>& b) {
+  if (a.is_inf() || b.is_inf()) return a.is_inf() == b.is_inf();
+  return Rnd<G>::eq(a.x, b.x) && Rnd<G>::eq(a.y, b.y) && Rnd<G>::eq(a.zz, b.zz) && Rnd<G>::eq(a.zzz, b.zzz);
+}
+template <class G>
+__global__ void __launch_bounds__(64) k_check_pt(unsigned* bad) {
+  using GO = lane29::Ops<G>;
+  using LPt = lane29::Pt<GO>;
+  typename GO::KT k;
+  k.init();
+  const XYZZ29<G> p = rnd_pt<G>(2 * blockIdx.x + 1), o = rnd_pt<G>(2 * blockIdx.x + 2);
+  const LPt lp = lane29::to_pt<G>(k, p), lo = lane29::to_pt<G>(k, o);
+  const bool d_ok = same_pt(dbl_wave29(p), lane29::from_pt<G>(k, lane29::dbl_pt<GO>(k, lp)));
+  const bool a_ok = same_pt(add_wave29(p, o), lane29::from_pt<G>(k, lane29::add_pt<GO>(k, lp, lo)));
+  // special cases: p + p (the doubling branch), p + (-p) (the identity), identity operands
+  const bool pp_ok = same_pt(add_wave29(p, p), lane29::from_pt<G>(k, lane29::add_pt<GO>(k, lp, lp)));
+  const XYZZ29<G> n = p.neg_pt();
+  const bool pn_ok = lane29::add_pt<GO>(k, lp, lane29::to_pt<G>(k, n)).inf && lane29::add_pt<GO>(k, lp, lane29::neg_pt<GO>(k, lp)).inf;
+  const LPt inf = lane29::to_pt<G>(k, XYZZ29<G>::inf());
+  const bool id_ok = same_pt(p, lane29::from_pt<G>(k, lane29::add_pt<GO>(k, lp, inf))) &&
+                     same_pt(o, lane29::from_pt<G>(k, lane29::add_pt<GO>(k, inf, lo))) && lane29::dbl_pt<GO>(k, inf).inf;
+  // a chain: 16 doublings and an addition (of o, then of -o), three times (bounds of the steady state)
+  XYZZ29<G> r = p;
+  LPt lr = lp;
+  for (int it = 0; it < 3; it++) {
+    for (int j = 0; j < 16; j++) { r = dbl_wave29(r); lr = lane29::dbl_pt<GO>(k, lr); }
+    r = add_wave29(r, (it & 1) ? o.neg_pt() : o);
+    lr = lane29::add_pt<GO>(k, lr, (it & 1) ? lane29::neg_pt<GO>(k, lo) : lo);
+  }
+  const bool c_ok = same_pt(r, lane29::from_pt<G>(k, lr));
   if (threadIdx.x == 0) {
     if (!d_ok) atomicAdd(bad, 1u);
     if (!a_ok) atomicAdd(bad + 1, 1u);
@@ -98,31 +127,34 @@ __global__ void __launch_bounds__(64) k_check_pt(unsigned* bad) {
   }
 }
 
-template <bool NEW>
+__device__ uint32_t digest(const XYZZ29<F>& r) { return r.x.l[0] ^ r.y.l[3] ^ r.zz.l[1]; }
+__device__ uint32_t digest(const XYZZ29<F2>& r) { return r.x.c0.l[0] ^ r.y.c1.l[3] ^ r.zz.c0.l[1]; }
+template <class G, bool NEW>
 __global__ void __launch_bounds__(64) k_chain(uint32_t* out, int iters, int dbls) {
-  const XYZZ29<F> p = rnd_pt(2 * blockIdx.x + 1), o = rnd_pt(2 * blockIdx.x + 2);
+  const XYZZ29<G> p = rnd_pt<G>(2 * blockIdx.x + 1), o = rnd_pt<G>(2 * blockIdx.x + 2);
   if constexpr (NEW) {
-    lane29::K<P> k;
+    using GO = lane29::Ops<G>;
+    typename GO::KT k;
     k.init();
-    lane29::Pt r = lane29::to_pt<F>(k, p);
-    const lane29::Pt lo = lane29::to_pt<F>(k, o);
+    lane29::Pt<GO> r = lane29::to_pt<G>(k, p);
+    const lane29::Pt<GO> lo = lane29::to_pt<G>(k, o);
 #pragma unroll 1
     for (int it = 0; it < iters; it++) {
 #pragma unroll 1
-      for (int j = 0; j < dbls; j++) r = lane29::dbl_pt(k, r);
-      r = lane29::add_pt(k, r, lo);
+      for (int j = 0; j < dbls; j++) r = lane29::dbl_pt<GO>(k, r);
+      r = lane29::add_pt<GO>(k, r, lo);
     }
-    const XYZZ29<F> res = lane29::from_pt<F>(k, r);
-    if (threadIdx.x == 0) out[blockIdx.x] = res.x.l[0] ^ res.y.l[3] ^ res.zz.l[1];
+    const XYZZ29<G> res = lane29::from_pt<G>(k, r);
+    if (threadIdx.x == 0) out[blockIdx.x] = digest(res);
   } else {
-    XYZZ29<F> r = p;
+    XYZZ29<G> r = p;
 #pragma unroll 1
     for (int it = 0; it < iters; it++) {
 #pragma unroll 1
       for (int j = 0; j < dbls; j++) r = dbl_wave29(r);
       r = add_wave29(r, o);
     }
-    if (threadIdx.x == 0) out[blockIdx.x] = r.x.l[0] ^ r.y.l[3] ^ r.zz.l[1];
+    if (threadIdx.x == 0) out[blockIdx.x] = digest(r);
   }
 }
 template <bool NEW>
@@ -130,10 +162,10 @@ __global__ void __launch_bounds__(64) k_mulchain(uint32_t* out, int iters) {
   S a = rnd_fe(2 * blockIdx.x + 1);
   const S b = rnd_fe(2 * blockIdx.x + 2);
   if constexpr (NEW) {
-    lane29::K<P> k;
+    FO::KT k;
     k.init();
-    uint32_t x = lane29::to_lane(k, a);
-    const uint32_t y = lane29::to_lane(k, b);
+    uint32_t x = FO::from_regs<BS>(k, a);
+    const uint32_t y = FO::from_regs<BS>(k, b);
 #pragma unroll 1
     for (int it = 0; it < iters; it++) x = lane29::mul(k, x, y);
     out[blockIdx.x * 64 + threadIdx.x] = x;
@@ -190,20 +222,26 @@ int main() {
   CK(hipDeviceSynchronize());
   CK(hipMemcpy(h.data(), d, 64, hipMemcpyDeviceToHost));
   printf("products: %u of 4096 wrong; (a - b)(2 b): %u wrong\n", h[0], h[1]);
-  CK(hipMemset(d, 0, 64));
-  hipLaunchKernelGGL(k_check_pt, dim3(1024), dim3(64), 0, 0, d);
-  CK(hipDeviceSynchronize());
-  CK(hipMemcpy(h.data(), d, 64, hipMemcpyDeviceToHost));
-  printf("of 1024: doubling %u wrong, addition %u, p + p %u, p - p %u, identity operands %u, chain of 48 doublings + 3 additions %u\n",
-         h[0], h[1], h[2], h[3], h[4], h[5]);
+  for (int g = 1; g <= 2; g++) {
+    CK(hipMemset(d, 0, 64));
+    if (g == 1) hipLaunchKernelGGL(k_check_pt<F>, dim3(1024), dim3(64), 0, 0, d);
+    else hipLaunchKernelGGL(k_check_pt<F2>, dim3(1024), dim3(64), 0, 0, d);
+    CK(hipDeviceSynchronize());
+    CK(hipMemcpy(h.data(), d, 64, hipMemcpyDeviceToHost));
+    printf("G%d, of 1024: doubling %u wrong, addition %u, p + p %u, p - p %u, identity operands %u, chain of 48 doublings + 3 additions %u\n",
+           g, h[0], h[1], h[2], h[3], h[4], h[5]);
+  }
   for (int blocks : {1, 256, 1024}) {
     const int iters = 200;
     const float m_old = timed([&] { hipLaunchKernelGGL(k_mulchain<false>, dim3(blocks), dim3(64), 0, 0, d, 4 * iters); });
     const float m_new = timed([&] { hipLaunchKernelGGL(k_mulchain<true>, dim3(blocks), dim3(64), 0, 0, d, 4 * iters); });
-    const float t_old = timed([&] { hipLaunchKernelGGL(k_chain<false>, dim3(blocks), dim3(64), 0, 0, d, iters, 16); });
-    const float t_new = timed([&] { hipLaunchKernelGGL(k_chain<true>, dim3(blocks), dim3(64), 0, 0, d, iters, 16); });
-    printf("%4d waves: dependent product %.3f -> %.3f us; 16 doublings + 1 addition: %.2f -> %.2f us (%.2fx)\n", blocks,
-           1e3 * m_old / (4 * iters), 1e3 * m_new / (4 * iters), 1e3 * t_old / iters, 1e3 * t_new / iters, t_old / t_new);
+    const float t_old = timed([&] { hipLaunchKernelGGL((k_chain<F, false>), dim3(blocks), dim3(64), 0, 0, d, iters, 16); });
+    const float t_new = timed([&] { hipLaunchKernelGGL((k_chain<F, true>), dim3(blocks), dim3(64), 0, 0, d, iters, 16); });
+    const float u_old = timed([&] { hipLaunchKernelGGL((k_chain<F2, false>), dim3(blocks), dim3(64), 0, 0, d, iters / 4, 16); });
+    const float u_new = timed([&] { hipLaunchKernelGGL((k_chain<F2, true>), dim3(blocks), dim3(64), 0, 0, d, iters / 4, 16); });
+    printf("%4d waves: dependent product %.3f -> %.3f us; 16 doublings + 1 addition: G1 %.2f -> %.2f us (%.2fx), G2 %.2f -> %.2f us (%.2fx)\n",
+           blocks, 1e3 * m_old / (4 * iters), 1e3 * m_new / (4 * iters), 1e3 * t_old / iters, 1e3 * t_new / iters, t_old / t_new,
+           1e3 * u_old / (iters / 4), 1e3 * u_new / (iters / 4), u_old / u_new);
   }
   CK(hipDeviceSynchronize());
   return 0;
