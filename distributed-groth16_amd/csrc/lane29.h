@@ -24,6 +24,7 @@
 // product a b + c d needs b, d <= TIGHT = 2^29 + 2^4), values < 2^261; it returns tight limbs and a value
 // < T / R + 2.2 p.  Subtraction adds k p in a "spread" form whose limbs dominate the subtrahend's.
 #pragma once
+#include <type_traits>
 #include "fp29.h"
 #include "ec29.h"
 
@@ -143,6 +144,94 @@ template <class P, bool EXT>
 struct Tab {
   static constexpr TabData v = make_tab<P, EXT>();
 };
+
+// ---- fourteen limbs of 28 bits (BLS12-377 / BLS12-381 Fq): an element is TWO registers on one row, `lo` = limbs 0..6 and
+// `hi` = limbs 7..13, both on lanes 0..6, so that nothing crosses a row: a product is three column sets C0 = lo lo
+// (columns 0..12), C1 = lo hi + hi lo (7..19), C2 = hi hi (14..26) on lanes 0..12 and the Montgomery reduction runs over
+// the two digits of base B = 2^196 (m_j = digit_j p'0 mod B; T += m_j p B^j; carry the digit out), each step
+// column-parallel on seven lanes: ~190 issues against 392 mads + ~140 on one lane (tools/lane29_model.py: mont14).
+namespace l14 {
+constexpr int W = 28, N = 14, H = 7;
+constexpr uint32_t MASK = (1u << W) - 1;
+template <class P>
+constexpr LimbArr<H> pprime0_limbs() {       // -p^-1 mod 2^196
+  static_assert(RR<P>::N == N && RR<P>::W == W, "fourteen limbs of 28 bits");
+  uint64_t acc[2 * H + 2] = {};
+  acc[0] = 1;
+  LimbArr<H> x{};
+  for (int k = 0; k < H; k++) {
+    const uint32_t xk = (uint32_t)((acc[k] & MASK) * (uint64_t)RR<P>::INV) & MASK;
+    x.v[k] = xk;
+    uint64_t carry = 0;
+    for (int j = 0; j < H; j++) {            // only the low seven limbs of p matter mod 2^196
+      if (k + j >= H) break;
+      const uint64_t t = acc[k + j] + (uint64_t)xk * RR<P>::PL.v[j] + carry;
+      acc[k + j] = t & MASK;
+      carry = t >> W;
+    }
+  }
+  return x;
+}
+template <class P>
+constexpr LimbArr<N> kp_norm(int k) {
+  LimbArr<N> r{};
+  uint64_t carry = 0;
+  for (int i = 0; i < N; i++) {
+    const uint64_t v = (uint64_t)RR<P>::PL.v[i] * (uint32_t)k + carry;
+    r.v[i] = (uint32_t)(v & MASK);
+    carry = v >> W;
+  }
+  r.v[N - 1] += (uint32_t)(carry << W);
+  return r;
+}
+enum Row : int {
+  ROW_PL = 0,                  // 7 rows: PL[i][l] = p_(l - i), limbs 0..6
+  ROW_PH = 7,                  // 7 rows: PH[i][l] = p_(7 + l - i)
+  ROW_PP = 14,                 // 7 rows: p'0_(l - i), l < 7
+  ROW_SUB = 21,                // 4 x (lo, hi): spread K p
+  ROW_JP = 29,                 // 7 x (lo, hi): j p, normalised
+  ROW_ONE = 43,                // (lo, hi): R mod p
+  ROW_COUNT = 45
+};
+struct TabData {
+  uint32_t t[ROW_COUNT][16];
+};
+template <class P>
+constexpr TabData make_tab() {
+  TabData d{};
+  const LimbArr<H> pp = pprime0_limbs<P>();
+  for (int i = 0; i < H; i++)
+    for (int l = 0; l < 16; l++) {
+      const bool in = l - i >= 0 && l - i < H;
+      d.t[ROW_PL + i][l] = in ? RR<P>::PL.v[l - i] : 0u;
+      d.t[ROW_PH + i][l] = in ? RR<P>::PL.v[H + l - i] : 0u;
+      d.t[ROW_PP + i][l] = (in && l < H) ? pp.v[l - i] : 0u;
+    }
+  for (int s = 0; s < 4; s++) {
+    const LimbArr<N> kp = rr::kp_limbs<P>(LawK<false>::SUB[s], kSpread);
+    for (int l = 0; l < H; l++) {
+      d.t[ROW_SUB + 2 * s][l] = kp.v[l];
+      d.t[ROW_SUB + 2 * s + 1][l] = kp.v[H + l];
+    }
+  }
+  for (int j = 0; j < LawK<false>::ZERO; j++) {
+    const LimbArr<N> jp = kp_norm<P>(j);
+    for (int l = 0; l < H; l++) {
+      d.t[ROW_JP + 2 * j][l] = jp.v[l];
+      d.t[ROW_JP + 2 * j + 1][l] = jp.v[H + l];
+    }
+  }
+  for (int l = 0; l < H; l++) {
+    d.t[ROW_ONE][l] = RR<P>::ONE.v[l];
+    d.t[ROW_ONE + 1][l] = RR<P>::ONE.v[H + l];
+  }
+  return d;
+}
+template <class P>
+struct Tab {
+  static constexpr TabData v = make_tab<P>();
+};
+}  // namespace l14
 
 #if defined(__HIPCC__)
 // ---- row primitives: opaque asm (a DPP read needs two wait states after the VALU write of its source, which hipcc
@@ -334,8 +423,8 @@ struct Fq9 {
   static __device__ __forceinline__ E zero() { return 0u; }
   static __device__ __forceinline__ E one(const KT& k) { return k.one(); }
   static __device__ __forceinline__ E mul(const KT& k, E a, E b) { return lane29::mul(k, a, b); }
-  static __device__ __forceinline__ E dbl(E a) { return renorm(a << 1); }
-  static __device__ __forceinline__ E tpl(E a) { return renorm(a + (a << 1)); }
+  static __device__ __forceinline__ E dbl(const KT&, E a) { return renorm(a << 1); }
+  static __device__ __forceinline__ E tpl(const KT&, E a) { return renorm(a + (a << 1)); }
   static __device__ __forceinline__ E dbl_raw(E a) { return a << 1; }
   static __device__ __forceinline__ E add_raw(E a, E b) { return a + b; }
   // a - b + K p (limbs of b < 2^31 - 4, of a <= 2^30)
@@ -418,8 +507,8 @@ struct Fq9x2 {
     cols_mad(y, a1, b0s, b0h);
     return {reduce(k, x), reduce(k, y)};
   }
-  static __device__ __forceinline__ E dbl(E a) { return {renorm(a.c0 << 1), renorm(a.c1 << 1)}; }
-  static __device__ __forceinline__ E tpl(E a) { return {renorm(a.c0 + (a.c0 << 1)), renorm(a.c1 + (a.c1 << 1))}; }
+  static __device__ __forceinline__ E dbl(const KT&, E a) { return {renorm(a.c0 << 1), renorm(a.c1 << 1)}; }
+  static __device__ __forceinline__ E tpl(const KT&, E a) { return {renorm(a.c0 + (a.c0 << 1)), renorm(a.c1 + (a.c1 << 1))}; }
   static __device__ __forceinline__ E dbl_raw(E a) { return {a.c0 << 1, a.c1 << 1}; }
   static __device__ __forceinline__ E add_raw(E a, E b) { return {a.c0 + b.c0, a.c1 + b.c1}; }
   template <int I>
@@ -488,8 +577,226 @@ struct Fq9x2 {
     return f;
   }
 };
+// ---- fourteen limbs: the same interface on two registers ---------------------------------------------------------------
+namespace l14 {
+__device__ __forceinline__ void bcast7(uint32_t (&o)[H], uint32_t v) {
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_mov_b32_dpp %0, %7 row_newbcast:0 " DG_DPP_FULL "\n\t"
+      "v_mov_b32_dpp %1, %7 row_newbcast:1 " DG_DPP_FULL "\n\t"
+      "v_mov_b32_dpp %2, %7 row_newbcast:2 " DG_DPP_FULL "\n\t"
+      "v_mov_b32_dpp %3, %7 row_newbcast:3 " DG_DPP_FULL "\n\t"
+      "v_mov_b32_dpp %4, %7 row_newbcast:4 " DG_DPP_FULL "\n\t"
+      "v_mov_b32_dpp %5, %7 row_newbcast:5 " DG_DPP_FULL "\n\t"
+      "v_mov_b32_dpp %6, %7 row_newbcast:6 " DG_DPP_FULL
+      : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6])
+      : "v"(v));
+}
+__device__ __forceinline__ void shifts7(uint32_t (&o)[H], uint32_t v) {
+  o[0] = v;
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_mov_b32_dpp %0, %6 row_shr:1 " DG_DPP_ZERO "\n\t"
+      "v_mov_b32_dpp %1, %6 row_shr:2 " DG_DPP_ZERO "\n\t"
+      "v_mov_b32_dpp %2, %6 row_shr:3 " DG_DPP_ZERO "\n\t"
+      "v_mov_b32_dpp %3, %6 row_shr:4 " DG_DPP_ZERO "\n\t"
+      "v_mov_b32_dpp %4, %6 row_shr:5 " DG_DPP_ZERO "\n\t"
+      "v_mov_b32_dpp %5, %6 row_shr:6 " DG_DPP_ZERO
+      : "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6])
+      : "v"(v));
+}
+__device__ __forceinline__ uint32_t shl7(uint32_t v) {
+  uint32_t r;
+  asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %1 row_shl:7 " DG_DPP_ZERO : "=&v"(r) : "v"(v));
+  return r;
+}
+// a + shl7(b)
+__device__ __forceinline__ uint32_t add_shl7(uint32_t a, uint32_t b) {
+  uint32_t r;
+  asm volatile("s_nop 1\n\tv_add_u32_dpp %0, %1, %2 row_shl:7 " DG_DPP_ZERO : "=&v"(r) : "v"(b), "v"(a));
+  return r;
+}
+__device__ __forceinline__ uint32_t three_piece(uint64_t c) {
+  const uint32_t p0 = (uint32_t)c & MASK;
+  const uint32_t p1 = (uint32_t)(c >> W) & MASK;
+  const uint32_t p2 = (uint32_t)(c >> (2 * W));
+  return add_pieces(p0, p1, p2);
+}
+struct E14 {
+  uint32_t lo, hi;
+};
+template <class P>
+struct K14 {
+  using L = LawK<false>;
+  uint32_t pl[H], ph[H], pp[H], sublo[4], subhi[4], jplo[L::ZERO], jphi[L::ZERO], lane6;
+  unsigned l16, row;
+  __device__ __forceinline__ void init() {
+    const unsigned lane = __lane_id();
+    l16 = lane & 15u;
+    row = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < H; i++) {
+      pl[i] = Tab<P>::v.t[ROW_PL + i][l16];
+      ph[i] = Tab<P>::v.t[ROW_PH + i][l16];
+      pp[i] = Tab<P>::v.t[ROW_PP + i][l16];
+    }
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+      sublo[s] = Tab<P>::v.t[ROW_SUB + 2 * s][l16];
+      subhi[s] = Tab<P>::v.t[ROW_SUB + 2 * s + 1][l16];
+    }
+#pragma unroll
+    for (int j = 0; j < L::ZERO; j++) {
+      jplo[j] = Tab<P>::v.t[ROW_JP + 2 * j][l16];
+      jphi[j] = Tab<P>::v.t[ROW_JP + 2 * j + 1][l16];
+    }
+    lane6 = l16 == 6 ? 0xFFFFFFFFu : 0u;
+  }
+  __device__ __forceinline__ E14 one() const { return {Tab<P>::v.t[ROW_ONE][l16], Tab<P>::v.t[ROW_ONE + 1][l16]}; }
+};
+// one carry pass over both registers: the carry out of limb 6 (lane 7 of lo) goes to lane 0 of hi
+__device__ __forceinline__ E14 renorm(E14 v, unsigned l16) {
+  const uint32_t lo2 = add_shr1(v.lo & MASK, v.lo >> W);
+  const uint32_t hi2 = add_shl7(add_shr1(v.hi & MASK, v.hi >> W), lo2);
+  return {l16 < (unsigned)H ? lo2 : 0u, hi2};
+}
+__device__ __forceinline__ E14 full_norm(E14 v, unsigned l16) {
+  while (__builtin_amdgcn_ballot_w64((v.lo | v.hi) > MASK)) v = renorm(v, l16);
+  return v;
+}
+struct Cols14 {
+  uint64_t c0, c1, c2;
+};
+// one digit of the reduction: cl's low seven columns are cleared (mod B) and carried into cm
+template <class KT>
+__device__ __forceinline__ void digit(const KT& k, uint64_t cl, uint64_t& cm) {
+  const uint32_t t = three_piece(cl);
+  uint32_t tb[H];
+  bcast7(tb, t);
+  uint64_t mc = 0;
+#pragma unroll
+  for (int i = 0; i < H; i++) mc += (uint64_t)tb[i] * k.pp[i];
+  const uint32_t m = three_piece(mc);
+  uint32_t mb[H];
+  bcast7(mb, m);
+#pragma unroll
+  for (int i = 0; i < H; i++) {
+    cl += (uint64_t)mb[i] * k.pl[i];
+    cm += (uint64_t)mb[i] * k.ph[i];
+  }
+  uint32_t L = three_piece(cl);
+  const uint32_t e = ((L + 2u) >> W) & k.lane6;
+  L = add_shr1(L, e);
+  cm += (uint64_t)shl7(L);
+}
+template <class KT>
+__device__ __forceinline__ E14 reduce(const KT& k, Cols14 c) {
+  digit(k, c.c0, c.c1);
+  digit(k, c.c1, c.c2);
+  const uint32_t res = three_piece(c.c2);
+  const E14 r = {k.l16 < (unsigned)H ? res : 0u, shl7(res)};
+  return renorm(r, k.l16);
+}
+template <class KT>
+__device__ __forceinline__ E14 mul(const KT& k, E14 a, E14 b) {
+  uint32_t al[H], ah[H], bl[H], bh[H];
+  bcast7(al, a.lo);
+  bcast7(ah, a.hi);
+  shifts7(bl, b.lo);
+  shifts7(bh, b.hi);
+  Cols14 c = {0, 0, 0};
+#pragma unroll
+  for (int i = 0; i < H; i++) {
+    c.c0 += (uint64_t)al[i] * bl[i];
+    c.c1 += (uint64_t)al[i] * bh[i];
+    c.c1 += (uint64_t)ah[i] * bl[i];
+    c.c2 += (uint64_t)ah[i] * bh[i];
+  }
+  return reduce(k, c);
+}
+}  // namespace l14
+template <class P_>
+struct Fq14 {
+  using P = P_;
+  static constexpr bool EXT = false;
+  static constexpr int WORDS = l14::N;
+  using E = l14::E14;
+  using KT = l14::K14<P>;
+  static constexpr int H = l14::H;
+  static __device__ __forceinline__ E zero() { return {0u, 0u}; }
+  static __device__ __forceinline__ E one(const KT& k) { return k.one(); }
+  static __device__ __forceinline__ E mul(const KT& k, E a, E b) { return l14::mul(k, a, b); }
+  static __device__ __forceinline__ E dbl(const KT& k, E a) { return l14::renorm({a.lo << 1, a.hi << 1}, k.l16); }
+  static __device__ __forceinline__ E tpl(const KT& k, E a) { return l14::renorm({a.lo + (a.lo << 1), a.hi + (a.hi << 1)}, k.l16); }
+  static __device__ __forceinline__ E dbl_raw(E a) { return {a.lo << 1, a.hi << 1}; }
+  static __device__ __forceinline__ E add_raw(E a, E b) { return {a.lo + b.lo, a.hi + b.hi}; }
+  template <int I>
+  static __device__ __forceinline__ E sub(const KT& k, E a, E b) {
+    return l14::renorm({a.lo + (k.sublo[I] - b.lo), a.hi + (k.subhi[I] - b.hi)}, k.l16);
+  }
+  static __device__ __forceinline__ E sel(bool c, E a, E b) { return {c ? a.lo : b.lo, c ? a.hi : b.hi}; }
+  static __device__ __forceinline__ bool is_zero(const KT& k, E v) {
+    v = l14::full_norm(v, k.l16);
+    bool z = false;
+#pragma unroll
+    for (int j = 0; j < KT::L::ZERO; j++)
+      z = z || (__builtin_amdgcn_ballot_w64(v.lo != k.jplo[j] || v.hi != k.jphi[j]) & 0xFFFFull) == 0;
+    return z;
+  }
+  static __device__ __forceinline__ void swap16(E r, E& even, E& odd) {
+    const auto s = __builtin_amdgcn_permlane16_swap(r.lo, r.lo, false, false);
+    const auto t = __builtin_amdgcn_permlane16_swap(r.hi, r.hi, false, false);
+    even = {s[0], t[0]};
+    odd = {s[1], t[1]};
+  }
+  static __device__ __forceinline__ void rows_to_all(E r, E& r0, E& r1, E& r2, E& r3) {
+    rows_to_all32(r.lo, r0.lo, r1.lo, r2.lo, r3.lo);
+    rows_to_all32(r.hi, r0.hi, r1.hi, r2.hi, r3.hi);
+  }
+  static __device__ __forceinline__ bool any_nonzero(E v) { return __builtin_amdgcn_ballot_w64((v.lo | v.hi) != 0u) != 0; }
+  static __device__ __forceinline__ E load(const KT& k, const uint32_t* w) {
+    const bool on = k.l16 < (unsigned)H;
+    const unsigned i = on ? k.l16 : 0u;
+    return {on ? w[i] : 0u, on ? w[H + i] : 0u};
+  }
+  static __device__ __forceinline__ void store(const KT& k, uint32_t* w, E v) {
+    if (k.row == 0 && k.l16 < (unsigned)H) {
+      w[k.l16] = v.lo;
+      w[H + k.l16] = v.hi;
+    }
+  }
+  template <int BS>
+  static __device__ __forceinline__ E exit_norm(const KT& k, E v, bool reduce_it) {
+    static_assert(BS >= 192, "a storage bound of ~2 p would need the conditional subtraction");
+    if (reduce_it) v = l14::mul(k, v, k.one());
+    return l14::full_norm(v, k.l16);
+  }
+  template <int BB>
+  static __device__ __forceinline__ E from_regs(const KT& k, const Fe<P, BB, 1>& f) {
+    uint32_t v0 = 0, v1 = 0;
+#pragma unroll
+    for (int i = 0; i < H; i++) {
+      v0 = k.l16 == (unsigned)i ? f.l[i] : v0;
+      v1 = k.l16 == (unsigned)i ? f.l[H + i] : v1;
+    }
+    return {v0, v1};
+  }
+  template <int BB>
+  static __device__ __forceinline__ Fe<P, BB, 1> to_regs(E v) {
+    uint32_t o0[H], o1[H];
+    l14::bcast7(o0, v.lo);
+    l14::bcast7(o1, v.hi);
+    Fe<P, BB, 1> f;
+#pragma unroll
+    for (int i = 0; i < H; i++) {
+      f.l[i] = o0[i];
+      f.l[H + i] = o1[i];
+    }
+    return f;
+  }
+};
 template <class F> struct PolicyOf;
-template <class P> struct PolicyOf<Fp<P>> { using type = Fq9<P>; };
+template <class P> struct PolicyOf<Fp<P>> { using type = std::conditional_t<RR<P>::N == N, Fq9<P>, Fq14<P>>; };
 template <class P> struct PolicyOf<Fp2<Fp<P>>> { using type = Fq9x2<P>; };
 template <class F> using Ops = typename PolicyOf<F>::type;
 
@@ -500,9 +807,10 @@ constexpr bool enabled() {
   return false;
 #else
   using P = typename FieldOf<F>::Params;
-  if constexpr (RR<P>::N != N || RR<P>::W != W) return false;
-  else if constexpr (FieldOf<F>::EXT) return Fq2Beta<P>::value == 1;
-  else return true;
+  if constexpr (RR<P>::N == l14::N && RR<P>::W == l14::W) return !FieldOf<F>::EXT;       // BLS12 G1
+  else if constexpr (RR<P>::N != N || RR<P>::W != W) return false;
+  else if constexpr (FieldOf<F>::EXT) return Fq2Beta<P>::value == 1;                      // BN254 G2
+  else return true;                                                                        // BN254 G1
 #endif
 }
 
@@ -529,13 +837,13 @@ __device__ __forceinline__ Pt<FO> dbl_pt(const typename FO::KT& k, const Pt<FO>&
   using E = typename FO::E;
   if (p.inf) return p;
   const unsigned row = k.row;
-  const E u = FO::dbl(p.y);
+  const E u = FO::dbl(k, p.y);
   // level 1: rows 0, 2: v = u^2 | rows 1, 3: xx = x^2
   const E a1 = FO::sel((row & 1u) != 0, p.x, u);
   const E r1 = FO::mul(k, a1, a1);
   E v, xx;
   FO::swap16(r1, v, xx);
-  const E m = FO::tpl(xx);
+  const E m = FO::tpl(k, xx);
   // level 2: w = u v | s = x v | m^2 | zz3 = zz v
   const E a2 = by_row<FO>(row, u, p.x, m, p.zz);
   const E b2 = FO::sel(row == 2, m, v);

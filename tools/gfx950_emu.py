@@ -81,7 +81,7 @@ class Program:
         self.data = {}
         cur = None
         for l in lines:
-            m = re.match(r"^(_Z\w+):\s*(;.*)?$", l)
+            m = re.match(r"^(_Z[\w.]+):\s*(;.*)?$", l)
             if m:
                 cur = self.data.setdefault(m.group(1), [])
                 continue
@@ -322,7 +322,7 @@ class Lane:
             if m:
                 assert ins[pc + 3].startswith("s_setpc_b64")
                 return labels[m.group(1)]
-            m = re.search(r"(\w+)@rel32@lo\+(\d+)", add)          # sym@rel32@lo+4 = the symbol itself, +36 = sym + 32
+            m = re.search(r"([\w.]+)@rel32@lo\+(\d+)", add)          # sym@rel32@lo+4 = the symbol itself, +36 = sym + 32
             assert m, "s_getpc_b64 followed by %r" % add
             if m.group(1) not in self.sym_addr:               # a function of the file
                 assert m.group(1) in self.p.funcs, "unknown symbol %r" % m.group(1)
@@ -820,20 +820,44 @@ class Workgroup:
             sc.wr(a[0], lanes[sc.rd(a[2]) & 63].rd(a[1]))
         elif op == "v_writelane_b32":
             lanes[sc.rd(a[2]) & 63].wr(a[0], sc.rd(a[1]))
-        elif op.endswith("_dpp"):                           # row_newbcast:N only: src0 = lane N of the lane's row of 16
-            m = re.search(r"row_newbcast:(\d+)", text)
+        elif op.endswith("_dpp"):       # src0 through a row-of-16 data path: row_newbcast / row_shr / row_shl / row_ror : N
+            m = re.search(r"(row_newbcast|row_shr|row_shl|row_ror):(\d+)", text)
             assert m and "row_mask:0xf" in text and "bank_mask:0xf" in text, text
+            kind, n = m.group(1), int(m.group(2))
+            zero_fill = "bound_ctrl:0" in text or "bound_ctrl:1" in text      # (both spellings set BOUND_CTRL: 0 for a lane out of the row)
             args = a[:-1] + [a[-1].split()[0]]
             vals = [ln.rd(args[1]) & M32 for ln in lanes]
+
+            def source(l):
+                r = l & 15
+                if kind == "row_newbcast":
+                    return (l & ~15) + n
+                if kind == "row_ror":
+                    return (l & ~15) + ((r - n) & 15)
+                q = r - n if kind == "row_shr" else r + n
+                return (l & ~15) + q if 0 <= q < 16 else None
             for l in range(64):
                 if (sc.exec >> l) & 1:
+                    src = source(l)
+                    if src is None and not zero_fill:
+                        continue                                # the lane is disabled: its destination keeps its value
                     ln = lanes[l]
                     ln.bitop3, ln.clamp, ln.mods = mods["bitop3"], mods["clamp"], mods
-                    ln.tmp = {"__s0": vals[(l & ~15) + int(m.group(1))]}
+                    ln.tmp = {"__s0": 0 if src is None else vals[src]}
                     try:
                         ln.valu(op[:-4], [args[0], "__s0"] + args[2:], text)
                     finally:
                         ln.tmp = {}
+        elif op in ("v_permlane16_swap_b32_e32", "v_permlane32_swap_b32_e32", "v_permlane16_swap_b32", "v_permlane32_swap_b32"):
+            # gfx950: odd rows of vdst <-> even rows of vsrc (16), upper half of vdst <-> lower half of vsrc (32)
+            assert sc.exec == M64, "permlane swap under a partial EXEC"
+            d = [ln.rd(a[0]) & M32 for ln in lanes]
+            v = [ln.rd(a[1]) & M32 for ln in lanes]
+            step = 16 if "permlane16" in op else 32
+            for l in range(64):
+                if (l // step) & 1:
+                    lanes[l].wr(a[0], v[l - step])
+                    lanes[l - step].wr(a[1], d[l])
         elif op == "ds_bpermute_b32":                       # dst[l] = data[(addr[l] / 4) % 64], all reads before any write
             vals = [ln.rd(a[2]) & M32 for ln in lanes]
             off = int(str(mods.get("offset", 0)), 0)

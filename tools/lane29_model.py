@@ -181,3 +181,135 @@ def self_test(p=BN254_Q, iters=2000, seed=1):
 if __name__ == "__main__":
     w = self_test()
     print("ok; largest output limb 2^%.3f" % (__import__("math").log2(w)))
+
+
+# =========================================================================================================================
+# Fourteen limbs of 28 bits (BLS12-377 / BLS12-381 Fq): an element is TWO registers on one row -- `lo` holds limbs 0..6
+# on lanes 0..6, `hi` limbs 7..13 on lanes 0..6 -- so that nothing ever crosses a row: the product is three column sets
+# C0 = lo lo (columns 0..12), C1 = lo hi + hi lo (columns 7..19), C2 = hi hi (columns 14..26), each on lanes 0..12, and the
+# Montgomery reduction runs digit-serially over the two digits of base B = 2^196: m_j = (digit j) p'0 mod B,
+# T += m_j p B^j, carry the (now zero mod B) digit out -- each step column-parallel on seven lanes.
+W14, N14, H14 = 28, 14, 7
+MASK14 = (1 << W14) - 1
+B14 = 1 << (W14 * H14)
+R14 = B14 * B14
+BLS12_381_Q = 0x1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaab
+BLS12_377_Q = 0x01ae3a4617c510eac63b05c06ca1493b1a22d9f300f5138f1ef3622fba094800170b5d44300000008508c00000000001
+LOOSE14 = (1 << 29) + (1 << 10)
+TIGHT14 = (1 << 28) + (1 << 4)
+
+
+def limbs14(x):
+    return [(x >> (W14 * i)) & MASK14 for i in range(N14)]
+
+
+def to_rows14(x):
+    l = limbs14(x)
+    return (l[:7] + [0] * 9, l[7:] + [0] * 9)
+
+
+def value14(e):
+    lo, hi = e
+    return sum(int(v) << (W14 * i) for i, v in enumerate(lo[:9])) + (sum(int(v) << (W14 * i) for i, v in enumerate(hi[:9])) << (W14 * 7))
+
+
+def pieces14(c):
+    return [x & MASK14 for x in c], [(x >> W14) & MASK14 for x in c], [x >> (2 * W14) for x in c]
+
+
+def three14(c):
+    p0, p1, p2 = pieces14(c)
+    return add(p0, shr(p1, 1), shr(p2, 2))
+
+
+class Consts14:
+    def __init__(self, p):
+        self.p = p
+        pl = limbs14(p)
+        pp0 = limbs14((-pow(p, -1, B14)) % B14)[:7]
+        z = lambda f: [[f(l, i) for l in range(ROW)] for i in range(7)]
+        self.PL = z(lambda l, i: pl[l - i] if 0 <= l - i < 7 else 0)
+        self.PH = z(lambda l, i: pl[7 + l - i] if 0 <= l - i < 7 else 0)
+        self.PP = z(lambda l, i: pp0[l - i] if 0 <= l - i < 7 and l < 7 else 0)
+        self.LANE6 = [M32 if l == 6 else 0 for l in range(ROW)]
+        self.ONE = [1] * ROW
+
+
+def renorm14(e):
+    lo, hi = e
+    lo2 = add([x & MASK14 for x in lo], shr([x >> W14 for x in lo], 1))          # lane 7: the carry out of limb 6
+    hi2 = add([x & MASK14 for x in hi], shr([x >> W14 for x in hi], 1), shl(lo2, 7))
+    lo2 = [v if l < 7 else 0 for l, v in enumerate(lo2)]
+    return lo2, hi2
+
+
+def mont14(a, b, K):
+    """a b / R mod p, R = 2^392; a: limbs <= LOOSE14, b: limbs <= TIGHT14 ... LOOSE14 (see the asserts), values < 2^392"""
+    zero = [0] * ROW
+    (al, ah), (bl, bh) = a, b
+    for v in al + ah + bl + bh:
+        assert v <= LOOSE14
+    for r in (al, ah, bl, bh):
+        assert all(v == 0 for v in r[7:])
+    C0, C1, C2 = zero, zero, zero
+    for i in range(7):
+        C0 = mad(bc(al, i), shr(bl, i), C0)
+        C1 = mad(bc(al, i), shr(bh, i), C1)
+        C1 = mad(bc(ah, i), shr(bl, i), C1)
+        C2 = mad(bc(ah, i), shr(bh, i), C2)
+
+    def digit(Cl, Cm):
+        t = three14(Cl)                                   # lanes 0..6: the digit, loose
+        mc = zero
+        for i in range(7):
+            mc = mad(bc(t, i), K.PP[i], mc)
+        m = three14(mc)                                   # lanes 0..6 (7, 8: spill, never read)
+        for i in range(7):
+            Cl = mad(bc(m, i), K.PL[i], Cl)
+            Cm = mad(bc(m, i), K.PH[i], Cm)
+        L = three14(Cl)
+        e = [((x + 2) >> W14) & K.LANE6[l] for l, x in enumerate(L)]
+        L = add(L, shr(e, 1))
+        U = shl(L, 7)                                     # the digit is zero mod B: what is left starts at lane 7
+        Cm = mad(U, K.ONE, Cm)
+        return Cm
+    C1 = digit(C0, C1)
+    C2 = digit(C1, C2)
+    res = three14(C2)
+    assert all(v == 0 for v in res[14:]), "result does not fit 392 bits"
+    lo = [v if l < 7 else 0 for l, v in enumerate(res)]
+    hi = shl(res, 7)
+    out = renorm14((lo, hi))
+    assert all(v <= TIGHT14 for v in out[0] + out[1])
+    return out
+
+
+def self_test14(p, iters=1500, seed=2):
+    rng = random.Random(seed)
+    K = Consts14(p)
+    Rinv = pow(R14, -1, p)
+    top = (16 * p) >> (W14 * 13)
+    for it in range(iters):
+        def rnd():
+            mode = rng.randrange(4)
+            if mode == 0:
+                return to_rows14(rng.randrange(7 * p))
+            if mode == 1:
+                return ([LOOSE14] * 7 + [0] * 9, [LOOSE14] * 6 + [rng.randrange(top)] + [0] * 9)
+            if mode == 2:
+                return ([rng.choice((0, 1, MASK14, LOOSE14)) for _ in range(7)] + [0] * 9,
+                        [rng.choice((0, 1, MASK14, LOOSE14)) for _ in range(6)] + [rng.randrange(top)] + [0] * 9)
+            return to_rows14(rng.choice((0, 1, p - 1, p, 7 * p - 1)))
+        a, b = rnd(), rnd()
+        r = mont14(a, b, K)
+        T = value14(a) * value14(b)
+        got = value14(r)
+        assert got % p == T * Rinv % p, (it,)
+        assert got < T // R14 + 3 * p
+    return True
+
+
+if __name__ == "__main__":
+    for q in (BLS12_381_Q, BLS12_377_Q):
+        self_test14(q)
+    print("ok: fourteen-limb product (two registers per element)")

@@ -68,6 +68,29 @@ template <> struct Rnd<F> {
   static __device__ S get(uint32_t seed) { return rnd_fe(seed); }
   static __device__ bool eq(const S& a, const S& b) { return same(a, b); }
 };
+// the fourteen-limb base fields: random limbs, the top one below 4 p's
+template <class QP, uint32_t TOPMASK>
+struct Rnd14 {
+  using S14 = typename FieldOf<Fp<QP>>::Store;
+  static __device__ S14 get(uint32_t seed) {
+    S14 r;
+#pragma unroll
+    for (int i = 0; i < 14; i++) r.l[i] = mix(seed * 16u + i) & ((1u << 28) - 1);
+    r.l[13] &= TOPMASK;
+    return r;
+  }
+  static __device__ bool eq(const S14& a, const S14& b) {
+    const auto ca = canon(a), cb = canon(b);
+    bool ok = true;
+#pragma unroll
+    for (int i = 0; i < 14; i++) ok = ok && ca.l[i] == cb.l[i];
+    return ok;
+  }
+};
+using F381 = bls12_381_fq;
+using F377 = bls12_377_fq;
+template <> struct Rnd<F381> : Rnd14<bls12_381_fq_params, (1u << 18) - 1> {};
+template <> struct Rnd<F377> : Rnd14<bls12_377_fq_params, (1u << 14) - 1> {};
 template <> struct Rnd<F2> {
   using S2 = typename FieldOf<F2>::Store;
   static __device__ S2 get(uint32_t seed) {
@@ -129,6 +152,8 @@ __global__ void __launch_bounds__(64) k_check_pt(unsigned* bad) {
 
 __device__ uint32_t digest(const XYZZ29<F>& r) { return r.x.l[0] ^ r.y.l[3] ^ r.zz.l[1]; }
 __device__ uint32_t digest(const XYZZ29<F2>& r) { return r.x.c0.l[0] ^ r.y.c1.l[3] ^ r.zz.c0.l[1]; }
+__device__ uint32_t digest(const XYZZ29<F381>& r) { return r.x.l[0] ^ r.y.l[3] ^ r.zz.l[1]; }
+__device__ uint32_t digest(const XYZZ29<F377>& r) { return r.x.l[0] ^ r.y.l[3] ^ r.zz.l[1]; }
 template <class G, bool NEW>
 __global__ void __launch_bounds__(64) k_chain(uint32_t* out, int iters, int dbls) {
   const XYZZ29<G> p = rnd_pt<G>(2 * blockIdx.x + 1), o = rnd_pt<G>(2 * blockIdx.x + 2);
@@ -222,14 +247,17 @@ int main() {
   CK(hipDeviceSynchronize());
   CK(hipMemcpy(h.data(), d, 64, hipMemcpyDeviceToHost));
   printf("products: %u of 4096 wrong; (a - b)(2 b): %u wrong\n", h[0], h[1]);
-  for (int g = 1; g <= 2; g++) {
+  const char* names[4] = {"BN254 G1", "BN254 G2", "BLS12-381 G1", "BLS12-377 G1"};
+  for (int g = 0; g < 4; g++) {
     CK(hipMemset(d, 0, 64));
-    if (g == 1) hipLaunchKernelGGL(k_check_pt<F>, dim3(1024), dim3(64), 0, 0, d);
-    else hipLaunchKernelGGL(k_check_pt<F2>, dim3(1024), dim3(64), 0, 0, d);
+    if (g == 0) hipLaunchKernelGGL(k_check_pt<F>, dim3(1024), dim3(64), 0, 0, d);
+    else if (g == 1) hipLaunchKernelGGL(k_check_pt<F2>, dim3(1024), dim3(64), 0, 0, d);
+    else if (g == 2) hipLaunchKernelGGL(k_check_pt<F381>, dim3(1024), dim3(64), 0, 0, d);
+    else hipLaunchKernelGGL(k_check_pt<F377>, dim3(1024), dim3(64), 0, 0, d);
     CK(hipDeviceSynchronize());
     CK(hipMemcpy(h.data(), d, 64, hipMemcpyDeviceToHost));
-    printf("G%d, of 1024: doubling %u wrong, addition %u, p + p %u, p - p %u, identity operands %u, chain of 48 doublings + 3 additions %u\n",
-           g, h[0], h[1], h[2], h[3], h[4], h[5]);
+    printf("%s, of 1024: doubling %u wrong, addition %u, p + p %u, p - p %u, identity operands %u, chain of 48 doublings + 3 additions %u\n",
+           names[g], h[0], h[1], h[2], h[3], h[4], h[5]);
   }
   for (int blocks : {1, 256, 1024}) {
     const int iters = 200;
@@ -239,9 +267,13 @@ int main() {
     const float t_new = timed([&] { hipLaunchKernelGGL((k_chain<F, true>), dim3(blocks), dim3(64), 0, 0, d, iters, 16); });
     const float u_old = timed([&] { hipLaunchKernelGGL((k_chain<F2, false>), dim3(blocks), dim3(64), 0, 0, d, iters / 4, 16); });
     const float u_new = timed([&] { hipLaunchKernelGGL((k_chain<F2, true>), dim3(blocks), dim3(64), 0, 0, d, iters / 4, 16); });
-    printf("%4d waves: dependent product %.3f -> %.3f us; 16 doublings + 1 addition: G1 %.2f -> %.2f us (%.2fx), G2 %.2f -> %.2f us (%.2fx)\n",
+    const float v_old = timed([&] { hipLaunchKernelGGL((k_chain<F377, false>), dim3(blocks), dim3(64), 0, 0, d, iters / 4, 16); });
+    const float v_new = timed([&] { hipLaunchKernelGGL((k_chain<F377, true>), dim3(blocks), dim3(64), 0, 0, d, iters / 4, 16); });
+    printf("%4d waves: dependent product %.3f -> %.3f us; 16 doublings + 1 addition: G1 %.2f -> %.2f us (%.2fx), G2 %.2f -> %.2f us (%.2fx), "
+           "BLS12-377 G1 %.2f -> %.2f us (%.2fx)\n",
            blocks, 1e3 * m_old / (4 * iters), 1e3 * m_new / (4 * iters), 1e3 * t_old / iters, 1e3 * t_new / iters, t_old / t_new,
-           1e3 * u_old / (iters / 4), 1e3 * u_new / (iters / 4), u_old / u_new);
+           1e3 * u_old / (iters / 4), 1e3 * u_new / (iters / 4), u_old / u_new, 1e3 * v_old / (iters / 4), 1e3 * v_new / (iters / 4),
+           v_old / v_new);
   }
   CK(hipDeviceSynchronize());
   return 0;
