@@ -1952,6 +1952,17 @@ MsmSort msm_sort_on(hipStream_t s, Channel& wsch, const void* scalars, size_t n,
 }
 
 // Workspace of one MSM's bucket phases (lives in `wsch`'s slots 7, 17, 15, 10 until the reduction is done).
+// Small bucket sets (a short shard, BASELINE config 4, a plain MSM of <= 2^15 points) are reduced by the radix-16 / radix-8
+// lane-form kernel of msm_reduce_impl.h (msm_lane_reduce_kernel): one WAVE per bucket at the first level
+constexpr size_t kLaneReduceMaxBuckets = 32768;
+template <class F>
+inline bool lane_reduce_applies(size_t buckets_over_all_windows) {
+  if constexpr (!lane29::enabled<F>()) return false;
+  else {
+    static const bool off = [] { const char* e = getenv("DG16_NO_LANE_REDUCE"); return e && atoi(e) != 0; }();
+    return !off && buckets_over_all_windows <= kLaneReduceMaxBuckets;
+  }
+}
 template <class F>
 struct MsmBuffers {
   XYZZ29<F>* buckets;
@@ -1960,6 +1971,9 @@ struct MsmBuffers {
   XYZZ29<F>* row_r;
   XYZZ29<F>* fold;
   XYZZ29<F>* window_sums;    // internal form: the tail's wave-cooperative chain runs on the reduced-radix types
+  XYZZ29<F>* lane_tmp;       // (W, R) pairs between the levels of msm_lane_reduce_kernel, or null (msm_reduce_impl.h)
+  bool busy_chip = false;    // the reduction runs beside saturating kernels of other streams (a proof's MSMs): small
+                             // workgroups only (msm_lane_reduce_serial_kernel instead of the 16-wave form)
   unsigned* giant;
   unsigned giant_cap;
   size_t nbw, nrows;     // over all instances
@@ -1990,11 +2004,13 @@ MsmBuffers<F> msm_buffers(Channel& wsch, const MsmGeom& g, unsigned ninst = 1) {
   b.rg = row_geometry(g);
   b.nrows = bwi << b.rg.rows_log;
   const size_t nfold = bwi * 3 * 256;
-  uint8_t* p15 = (uint8_t*)ws(wsch, 15, (2 * b.nrows + nfold + bwi) * sizeof(XYZZ29<F>));
+  const size_t nlane = lane_reduce_applies<F>(b.nbw) ? b.nbw / 2 + 4 : 0;
+  uint8_t* p15 = (uint8_t*)ws(wsch, 15, (2 * b.nrows + nfold + bwi + nlane) * sizeof(XYZZ29<F>));
   b.row_w = (XYZZ29<F>*)p15;
   b.row_r = b.row_w + b.nrows;
   b.fold = b.row_r + b.nrows;
   b.window_sums = b.fold + nfold;
+  b.lane_tmp = nlane ? b.window_sums + bwi : nullptr;
   // [0] giants, [1] work items, then giant_cap bucket ids, then <= 2 * giant_cap (giant, slice) work items
   b.giant = (unsigned*)ws(wsch, 10, ((size_t)b.giant_cap * 3 + 2) * 4);
   return b;

@@ -376,6 +376,171 @@ __global__ void __launch_bounds__(256 * HALVES) msm_top_kernel(TopGeom tg, const
   }
 }
 
+
+// ---- small bucket sets: sum_b (b + 1) B_b as a radix-2^RB reduction in LANE form (lane29.h) --------------------------
+// The row / top kernels above take 2 log2(nb) dependent additions of ~9 us (G1; a lone lane's) to ~35 us (G2) each: 0.29 ms
+// (G1) and 1.0 ms (G2) for the 2 048 buckets of BASELINE config 4, the critical path of a short shard.  Here an addition
+// is a WAVE's (lane29::add_pt: ~1.1 us G1, ~2.6 us Fq2) and a workgroup of G = 2^g waves reduces G consecutive entries:
+//     entries j = 0 .. G-1 carry (W_j, R_j) and stand u = 2^u_log buckets apart;   R' = sum_j R_j,
+//     W' = sum_j W_j + u sum_j j R_j,        sum_j j R_j = sum_{t >= 1} suffix_t(R)
+// (level 0: W_j = R_j = B_j, u = 1: W' = sum_j (j + 1) B_j) -- g steps of a suffix scan over the waves' R, g steps of
+// two trees side by side (the suffix sums on waves [0, d), the W_j on waves [d, 2 d)), u_log doublings and one addition
+// on wave 0: 2 g + 1 additions deep per level, log2(nb) / g levels, one launch each.  Between steps the waves exchange
+// points through LDS in raw lane form (one barrier per step, two buffers).
+template <class F>
+constexpr int lane_reduce_radix_log() {
+  return (FieldOf<F>::EXT || RR<typename FieldOf<F>::Params>::N > 9) ? 3 : 4;     // 8 waves x 256 registers, or 16 x 128
+}
+template <class F, int RB>
+__global__ void __launch_bounds__(64 << RB) msm_lane_reduce_kernel(const XYZZ29<F>* __restrict__ in, unsigned in_per_bw_log,
+                                                                    unsigned g_log, unsigned u_log, int level0,
+                                                                    XYZZ29<F>* __restrict__ out,
+                                                                    XYZZ29<F>* __restrict__ window_sums) {
+  if constexpr (lane29::enabled<F>()) {
+    using FO = lane29::Ops<F>;
+    using LPt = lane29::Pt<FO>;
+    __shared__ XYZZ29<F> sA[2][1 << RB];     // the scan's R, then the suffix-sum tree
+    __shared__ XYZZ29<F> sB[2][1 << RB];     // the W tree
+    __builtin_amdgcn_s_setprio(3);
+    const unsigned w = threadIdx.x >> 6, G = 1u << g_log;
+    typename FO::KT kc;
+    kc.init();
+    const size_t e = ((size_t)blockIdx.y << in_per_bw_log) + ((size_t)blockIdx.x << g_log) + w;
+    LPt R, Y;
+    if (level0) {
+      R = lane29::load_pt<F>(kc, &in[e]);
+      Y = R;
+    } else {
+      Y = lane29::load_pt<F>(kc, &in[2 * e]);
+      R = lane29::load_pt<F>(kc, &in[2 * e + 1]);
+    }
+    unsigned buf = 0;
+#pragma unroll 1
+    for (unsigned d = 1; d < G; d <<= 1) {           // inclusive suffix scan: R_w <- sum_{j >= w} R_j
+      lane29::store_pt_raw<F>(kc, &sA[buf][w], R);
+      __syncthreads();
+      if (w + d < G) R = lane29::add_pt<FO>(kc, R, lane29::load_pt<F>(kc, &sA[buf][w + d]));
+      buf ^= 1;
+    }
+    LPt X = R;                                       // suffix_w; the weighted sum drops suffix_0 (= R')
+    if (w == 0) X = lane29::inf_pt<FO>(kc);
+    bool first = true;
+#pragma unroll 1
+    for (unsigned d = G >> 1; d >= 1; d >>= 1) {
+      lane29::store_pt_raw<F>(kc, &sA[buf][w], X);
+      if (!level0) {
+        if (first) lane29::store_pt_raw<F>(kc, &sB[buf][w], Y);
+        else if (w >= 2 * d && w < 4 * d) lane29::store_pt_raw<F>(kc, &sB[buf][w - 2 * d], Y);
+      }
+      __syncthreads();
+      if (w < d) X = lane29::add_pt<FO>(kc, X, lane29::load_pt<F>(kc, &sA[buf][w + d]));
+      else if (!level0 && w < 2 * d)
+        Y = lane29::add_pt<FO>(kc, lane29::load_pt<F>(kc, &sB[buf][w - d]), lane29::load_pt<F>(kc, &sB[buf][w]));
+      buf ^= 1;
+      first = false;
+    }
+    // wave 0: X = sum_j j R_j, R = R'; wave 1 (G >= 2): Y = sum_j W_j
+    if (!level0 && G >= 2) {
+      if (w == 1) lane29::store_pt_raw<F>(kc, &sB[buf][0], Y);
+      __syncthreads();
+      if (w == 0) Y = lane29::load_pt<F>(kc, &sB[buf][0]);
+    }
+    if (w != 0) return;
+#pragma unroll 1
+    for (unsigned k = 0; k < u_log; k++) X = lane29::dbl_pt<FO>(kc, X);
+    const LPt Wp = lane29::add_pt<FO>(kc, level0 ? R : Y, X);
+    if (window_sums) {
+      lane29::store_pt<F>(kc, &window_sums[blockIdx.y], Wp);
+    } else {
+      const size_t o = ((size_t)blockIdx.y << (in_per_bw_log - g_log)) + blockIdx.x;
+      lane29::store_pt_raw<F>(kc, &out[2 * o], Wp);
+      lane29::store_pt_raw<F>(kc, &out[2 * o + 1], R);
+    }
+  }
+}
+// The same reduction on ONE wave per group, for a chip that is busy with other streams' saturating kernels (the MSMs of
+// a proof): a 16-wave workgroup waits for a whole compute unit to drain while 256-lane accumulation workgroups keep taking
+// the slots that free up, and a wave per bucket costs ~6x the issue slots of the row kernels (measured: config 4 1.70 ->
+// 1.86 ms, 8-shard rank 2.57 -> 2.79 with the form above inside proofs; profiles/r6s_lane_reduce_ab.txt).  Here the group's
+// sums are running sums from the top entry down -- run += R_j; acc += run -- 2 G + 1 additions (3 G above level 0) on a
+// 64-lane workgroup, entries prefetched one ahead.
+template <class F>
+__global__ void __launch_bounds__(64) msm_lane_reduce_serial_kernel(const XYZZ29<F>* __restrict__ in, unsigned in_per_bw_log,
+                                                                     unsigned g_log, unsigned u_log, int level0,
+                                                                     XYZZ29<F>* __restrict__ out,
+                                                                     XYZZ29<F>* __restrict__ window_sums) {
+  if constexpr (lane29::enabled<F>()) {
+    using FO = lane29::Ops<F>;
+    using LPt = lane29::Pt<FO>;
+    __builtin_amdgcn_s_setprio(3);
+    const unsigned G = 1u << g_log;
+    typename FO::KT kc;
+    kc.init();
+    const size_t e0 = ((size_t)blockIdx.y << in_per_bw_log) + ((size_t)blockIdx.x << g_log);
+    const XYZZ29<F>* base = level0 ? in + e0 : in + 2 * e0;
+    const unsigned stride = level0 ? 1u : 2u, roff = level0 ? 0u : 1u;
+    LPt run = lane29::inf_pt<FO>(kc), acc = run, wsum = run;
+    LPt rj = lane29::load_pt<F>(kc, base + (size_t)(G - 1) * stride + roff), wj = rj;
+    if (!level0) wj = lane29::load_pt<F>(kc, base + (size_t)(G - 1) * stride);
+#pragma unroll 1
+    for (unsigned j = G - 1; j >= 1; j--) {
+      const LPt rn = lane29::load_pt<F>(kc, base + (size_t)(j - 1) * stride + roff);       // (one ahead)
+      LPt wn = rn;
+      if (!level0) wn = lane29::load_pt<F>(kc, base + (size_t)(j - 1) * stride);
+      run = lane29::add_pt<FO>(kc, run, rj);
+      acc = lane29::add_pt<FO>(kc, acc, run);
+      if (!level0) wsum = lane29::add_pt<FO>(kc, wsum, wj);
+      rj = rn;
+      wj = wn;
+    }
+    const LPt Rp = lane29::add_pt<FO>(kc, run, rj);                  // R' = sum_j R_j;  acc = sum_j j R_j
+    if (!level0) wsum = lane29::add_pt<FO>(kc, wsum, wj);
+#pragma unroll 1
+    for (unsigned k = 0; k < u_log; k++) acc = lane29::dbl_pt<FO>(kc, acc);
+    const LPt Wp = lane29::add_pt<FO>(kc, level0 ? Rp : wsum, acc);
+    if (window_sums) {
+      lane29::store_pt<F>(kc, &window_sums[blockIdx.y], Wp);
+    } else {
+      const size_t o = ((size_t)blockIdx.y << (in_per_bw_log - g_log)) + blockIdx.x;
+      lane29::store_pt_raw<F>(kc, &out[2 * o], Wp);
+      lane29::store_pt_raw<F>(kc, &out[2 * o + 1], Rp);
+    }
+  }
+}
+// buckets[bwi][2^log_nb] -> window_sums[bwi]; false when the set is not one this path takes
+template <class F>
+bool msm_lane_reduce(hipStream_t s, const MsmGeom& g, const MsmBuffers<F>& b) {
+  if constexpr (!lane29::enabled<F>()) return false;
+  else {
+    const unsigned bwi = g.bw * b.ninst;
+    if (!b.lane_tmp || !lane_reduce_applies<F>((size_t)bwi << g.log_nb)) return false;
+    static const bool busy_off = [] { const char* e = getenv("DG16_NO_LANE_REDUCE_BUSY"); return e && atoi(e) != 0; }();
+    if (b.busy_chip && busy_off) return false;
+    constexpr int RB = lane_reduce_radix_log<F>();
+    // level 0 writes at most a quarter of the bucket count (pairs of an eighth), level 1 a 32nd, ... : two buffers in turn
+    XYZZ29<F>* pong[2] = {b.lane_tmp, b.lane_tmp + (((size_t)bwi << g.log_nb) / 4 + 2)};
+    const XYZZ29<F>* in = b.buckets;
+    unsigned rem = g.log_nb, u_log = 0, per_log = g.log_nb, lvl = 0;
+    do {
+      const unsigned g_log = rem < (unsigned)RB ? rem : (unsigned)RB;
+      const bool last = rem == g_log;
+      XYZZ29<F>* out = pong[lvl & 1];
+      if (b.busy_chip)
+        hipLaunchKernelGGL((msm_lane_reduce_serial_kernel<F>), dim3(1u << (per_log - g_log), bwi), dim3(64), 0, s, in, per_log,
+                           g_log, u_log, (int)(lvl == 0), out, last ? b.window_sums : (XYZZ29<F>*)nullptr);
+      else
+        hipLaunchKernelGGL((msm_lane_reduce_kernel<F, RB>), dim3(1u << (per_log - g_log), bwi), dim3(64u << g_log), 0, s, in,
+                           per_log, g_log, u_log, (int)(lvl == 0), out, last ? b.window_sums : (XYZZ29<F>*)nullptr);
+      in = out;
+      rem -= g_log;
+      per_log -= g_log;
+      u_log += g_log;
+      lvl++;
+    } while (rem);
+    return true;
+  }
+}
+
 // Phase B (latency-bound, few waves): finalize -> giants -> rows -> top -> tail.  May run on another stream than
 // phase A so that it hides behind the next MSM's accumulation.
 // DG16_TRACE=1: synchronise after every launch of the bucket phase and print its wall time (debugging aid)
@@ -412,6 +577,13 @@ void msm_bucket_phase(hipStream_t s, const MsmSort& st, const MsmBuffers<F>& b, 
   hipLaunchKernelGGL(msm_giant_fold_kernel<F>, dim3(64), dim3(64), 0, s, g, msm_acc_wg_log<F>(), st.counts, st.seg_off,
                      b.seg_sum, b.buckets, b.giant, b.giant + 2, b.giant_cap);
   trace_point(s, "giant + fold");
+  if (msm_lane_reduce<F>(s, g, b)) {        // small bucket sets: the lane-form reduction (msm_lane_reduce_kernel)
+    trace_point(s, "lane reduce");
+    msm_tail_phase<F>(s, st, b, out_affine, out_dev);
+    trace_point(s, "tail");
+    DG_HIP(hipGetLastError());
+    return;
+  }
   // many rows over all bucket-windows (plain MSMs): lanes that own 2^k buckets each (msm_rowchunk_kernel), k so that
   // ~256 workgroups remain; few rows (one bucket set of a resident table): one lane per bucket, 16 steps
   constexpr int CH_LANES = sizeof(XYZZ29<F>) * 2 * 256 <= 150 * 1024 ? 256 : 128;

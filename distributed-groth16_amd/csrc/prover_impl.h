@@ -361,6 +361,7 @@ static bool msms_typed(dg16_ctx* ctx, Call& k0, Call& k1, Call& k2, const PkDev&
   MsmSort st_ab = msm_sort_on<Fr, CT::SCALAR_BITS>(side, k1.c, sc_ab, n_ab + 3, mont, true, pk.c_ab, pk.stride);
   DG_HIP(hipEventRecord(ev[13], side));
   MsmBuffers<Fq2> buf_b2 = msm_buffers<Fq2>(k2.c, st_ab.g);
+  buf_b2.busy_chip = true;
 
   // main: h (whole, or stage 0 of the sharded form)
   Fr* h_dev = h_given ? nullptr : (Fr*)ws(k0.c, 3, rows * sizeof(Fr));
@@ -411,6 +412,7 @@ static bool msms_typed(dg16_ctx* ctx, Call& k0, Call& k1, Call& k2, const PkDev&
     MsmBuffers<Fq> buf_a = msm_buffers<Fq>(k0.c, st_ab.g);
     MsmBuffers<Fq> buf_b1 = msm_buffers<Fq>(k1.c, st_ab.g);
     MsmBuffers<Fq> buf_l = msm_buffers<Fq>(ctx->xws[1], st_ab.g);
+    buf_a.busy_chip = buf_b1.busy_chip = buf_l.busy_chip = true;
     DG_HIP(hipEventRecord(k1.c.ev[2], main));
     if (ctx->kclk) buf_a.clk = ctx->kclk + 2 * 1;     // (dg16_last_kernel_ms(ctx, 1, 2))
     msm_accumulate_phase<Fq>(main, st_ab, buf_a, pk.a_q);
@@ -451,6 +453,7 @@ static bool msms_typed(dg16_ctx* ctx, Call& k0, Call& k1, Call& k2, const PkDev&
     DG_HIP(hipStreamWaitEvent(main, ev[15], 0));
   }
   MsmBuffers<Fq> buf_h = msm_buffers<Fq>(ctx->xws[0], st_h.g);
+  buf_h.busy_chip = true;
   if (tail_fence) DG_HIP(hipStreamWaitEvent(main, ev[18], 0));     // tail fence: H's buckets
   msm_accumulate_phase<Fq>(main, st_h, buf_h, pk.h_q);
   const bool tail_on_side2 = overlap_tail && !h_given;      // (round 6: the sharded proof too -- prove_dist_typed)
