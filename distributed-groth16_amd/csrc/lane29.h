@@ -944,6 +944,19 @@ __device__ __forceinline__ Pt<Ops<F>> load_pt(const typename Ops<F>::KT& k, cons
   p.inf = !FO::any_nonzero(p.zz);
   return p;
 }
+// the same in two halves, for a loop that fetches one entry ahead: the identity flag needs the data (a ballot), so taking
+// it at once would put the load's latency back on the chain
+template <class F>
+__device__ __forceinline__ Pt<Ops<F>> load_pt_words(const typename Ops<F>::KT& k, const XYZZ29<F>* src) {
+  using FO = Ops<F>;
+  const uint32_t* w = reinterpret_cast<const uint32_t*>(src);
+  return {FO::load(k, w), FO::load(k, w + FO::WORDS), FO::load(k, w + 2 * FO::WORDS), FO::load(k, w + 3 * FO::WORDS), false};
+}
+template <class FO>
+__device__ __forceinline__ Pt<FO> with_inf_flag(Pt<FO> p) {
+  p.inf = !FO::any_nonzero(p.zz);
+  return p;
+}
 template <class F>
 __device__ __forceinline__ void store_pt_raw(const typename Ops<F>::KT& k, XYZZ29<F>* dst, const Pt<Ops<F>>& p) {
   using FO = Ops<F>;

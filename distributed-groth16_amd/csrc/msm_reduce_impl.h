@@ -387,6 +387,7 @@ __global__ void __launch_bounds__(256 * HALVES) msm_top_kernel(TopGeom tg, const
 // two trees side by side (the suffix sums on waves [0, d), the W_j on waves [d, 2 d)), u_log doublings and one addition
 // on wave 0: 2 g + 1 additions deep per level, log2(nb) / g levels, one launch each.  Between steps the waves exchange
 // points through LDS in raw lane form (one barrier per step, two buffers).
+constexpr size_t kLaneParallelMaxEntries = 4096;
 template <class F>
 constexpr int lane_reduce_radix_log() {
   return (FieldOf<F>::EXT || RR<typename FieldOf<F>::Params>::N > 9) ? 3 : 4;     // 8 waves x 256 registers, or 16 x 128
@@ -480,19 +481,22 @@ __global__ void __launch_bounds__(64) msm_lane_reduce_serial_kernel(const XYZZ29
     const XYZZ29<F>* base = level0 ? in + e0 : in + 2 * e0;
     const unsigned stride = level0 ? 1u : 2u, roff = level0 ? 0u : 1u;
     LPt run = lane29::inf_pt<FO>(kc), acc = run, wsum = run;
-    LPt rj = lane29::load_pt<F>(kc, base + (size_t)(G - 1) * stride + roff), wj = rj;
-    if (!level0) wj = lane29::load_pt<F>(kc, base + (size_t)(G - 1) * stride);
+    LPt rj = lane29::load_pt_words<F>(kc, base + (size_t)(G - 1) * stride + roff), wj = rj;
+    if (!level0) wj = lane29::load_pt_words<F>(kc, base + (size_t)(G - 1) * stride);
 #pragma unroll 1
     for (unsigned j = G - 1; j >= 1; j--) {
-      const LPt rn = lane29::load_pt<F>(kc, base + (size_t)(j - 1) * stride + roff);       // (one ahead)
+      // (one ahead: the words only -- the identity flag is taken when the entry is used)
+      const LPt rn = lane29::load_pt_words<F>(kc, base + (size_t)(j - 1) * stride + roff);
       LPt wn = rn;
-      if (!level0) wn = lane29::load_pt<F>(kc, base + (size_t)(j - 1) * stride);
-      run = lane29::add_pt<FO>(kc, run, rj);
+      if (!level0) wn = lane29::load_pt_words<F>(kc, base + (size_t)(j - 1) * stride);
+      run = lane29::add_pt<FO>(kc, run, lane29::with_inf_flag<FO>(rj));
       acc = lane29::add_pt<FO>(kc, acc, run);
-      if (!level0) wsum = lane29::add_pt<FO>(kc, wsum, wj);
+      if (!level0) wsum = lane29::add_pt<FO>(kc, wsum, lane29::with_inf_flag<FO>(wj));
       rj = rn;
       wj = wn;
     }
+    rj = lane29::with_inf_flag<FO>(rj);
+    wj = lane29::with_inf_flag<FO>(wj);
     const LPt Rp = lane29::add_pt<FO>(kc, run, rj);                  // R' = sum_j R_j;  acc = sum_j j R_j
     if (!level0) wsum = lane29::add_pt<FO>(kc, wsum, wj);
 #pragma unroll 1
@@ -525,7 +529,10 @@ bool msm_lane_reduce(hipStream_t s, const MsmGeom& g, const MsmBuffers<F>& b) {
       const unsigned g_log = rem < (unsigned)RB ? rem : (unsigned)RB;
       const bool last = rem == g_log;
       XYZZ29<F>* out = pong[lvl & 1];
-      if (b.busy_chip)
+      // a wave per entry pays while the level's waves fit the chip a few times over: 8 192 buckets took 180 us there, the
+      // issue slots of 74 000 wave-additions (profiles/r6x_timeline_config4.md); one wave per group beyond that
+      const bool one_wave = b.busy_chip || ((size_t)bwi << per_log) > kLaneParallelMaxEntries;
+      if (one_wave)
         hipLaunchKernelGGL((msm_lane_reduce_serial_kernel<F>), dim3(1u << (per_log - g_log), bwi), dim3(64), 0, s, in, per_log,
                            g_log, u_log, (int)(lvl == 0), out, last ? b.window_sums : (XYZZ29<F>*)nullptr);
       else

@@ -453,10 +453,12 @@ static bool msms_typed(dg16_ctx* ctx, Call& k0, Call& k1, Call& k2, const PkDev&
     DG_HIP(hipStreamWaitEvent(main, ev[15], 0));
   }
   MsmBuffers<Fq> buf_h = msm_buffers<Fq>(ctx->xws[0], st_h.g);
-  buf_h.busy_chip = true;
+  const bool tail_on_side2 = overlap_tail && !h_given;      // (round 6: the sharded proof too -- prove_dist_typed)
+  // H's reduction on the main stream is the exposed tail of the proof: nothing saturating runs beside it, the 16-wave form
+  // of the lane reduction serves (msm_reduce_impl.h); under the next proof's first kernels (side2) the one-wave form
+  buf_h.busy_chip = tail_on_side2;
   if (tail_fence) DG_HIP(hipStreamWaitEvent(main, ev[18], 0));     // tail fence: H's buckets
   msm_accumulate_phase<Fq>(main, st_h, buf_h, pk.h_q);
-  const bool tail_on_side2 = overlap_tail && !h_given;      // (round 6: the sharded proof too -- prove_dist_typed)
   if (tail_on_side2) {
     DG_HIP(hipEventRecord(ev[17], main));
     DG_HIP(hipStreamWaitEvent(side2, ev[17], 0));
