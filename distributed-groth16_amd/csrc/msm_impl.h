@@ -1972,6 +1972,7 @@ struct MsmBuffers {
   XYZZ29<F>* fold;
   XYZZ29<F>* window_sums;    // internal form: the tail's wave-cooperative chain runs on the reduced-radix types
   XYZZ29<F>* lane_tmp;       // (W, R) pairs between the levels of msm_lane_reduce_kernel, or null (msm_reduce_impl.h)
+  XYZZ29<F>* top_tmp;        // the same for the lane-form levels that stand in for msm_top_kernel (msm_lane_top), or null
   bool busy_chip = false;    // the reduction runs beside saturating kernels of other streams (a proof's MSMs): small
                              // workgroups only (msm_lane_reduce_serial_kernel instead of the 16-wave form)
   unsigned* giant;
@@ -2005,12 +2006,14 @@ MsmBuffers<F> msm_buffers(Channel& wsch, const MsmGeom& g, unsigned ninst = 1) {
   b.nrows = bwi << b.rg.rows_log;
   const size_t nfold = bwi * 3 * 256;
   const size_t nlane = lane_reduce_applies<F>(b.nbw) ? b.nbw / 2 + 4 : 0;
-  uint8_t* p15 = (uint8_t*)ws(wsch, 15, (2 * b.nrows + nfold + bwi + nlane) * sizeof(XYZZ29<F>));
+  const size_t ntop = lane29::enabled<F>() ? bwi * 96 + 8 : 0;      // <= 256 entries per bucket-window: 64 + 8 pairs' slots
+  uint8_t* p15 = (uint8_t*)ws(wsch, 15, (2 * b.nrows + nfold + bwi + nlane + ntop) * sizeof(XYZZ29<F>));
   b.row_w = (XYZZ29<F>*)p15;
   b.row_r = b.row_w + b.nrows;
   b.fold = b.row_r + b.nrows;
   b.window_sums = b.fold + nfold;
   b.lane_tmp = nlane ? b.window_sums + bwi : nullptr;
+  b.top_tmp = ntop ? b.window_sums + bwi + nlane : nullptr;
   // [0] giants, [1] work items, then giant_cap bucket ids, then <= 2 * giant_cap (giant, slice) work items
   b.giant = (unsigned*)ws(wsch, 10, ((size_t)b.giant_cap * 3 + 2) * 4);
   return b;

@@ -393,10 +393,19 @@ constexpr int lane_reduce_radix_log() {
   return (FieldOf<F>::EXT || RR<typename FieldOf<F>::Params>::N > 9) ? 3 : 4;     // 8 waves x 256 registers, or 16 x 128
 }
 template <class F, int RB>
-__global__ void __launch_bounds__(64 << RB) msm_lane_reduce_kernel(const XYZZ29<F>* __restrict__ in, unsigned in_per_bw_log,
-                                                                    unsigned g_log, unsigned u_log, int level0,
+__global__ void __launch_bounds__(64 << RB) msm_lane_reduce_kernel(const XYZZ29<F>* __restrict__ in,
+                                                                    const XYZZ29<F>* __restrict__ in2, unsigned in_per_bw_log,
+                                                                    unsigned g_log, unsigned u_log, int mode, unsigned k_log,
                                                                     XYZZ29<F>* __restrict__ out,
                                                                     XYZZ29<F>* __restrict__ window_sums) {
+  // mode: where entry t of bucket-window y comes from --
+  //   0  a bucket: W = R = in[e]                                   (level 0 of a bucket set)
+  //   1  a pair of the level below: W = in[2 e], R = in[2 e + 1]
+  //   2  a row of msm_row_kernel: W = in[e] (row_w), R = in2[e] (row_r)
+  //   3  a chunk of msm_rowchunk_kernel / msm_rowfold_kernel, fold[y][3][256]: W = fold[0][t] + 2^k_log fold[2][t] (the
+  //      chunk's own weighted part), R = fold[1][t]
+  // (2, 3: the work of msm_top_kernel -- 16 + per_log lone-lane steps, 0.16 ms behind a 2^20-point G1 MSM -- as two levels)
+  const int level0 = mode == 0;
   if constexpr (lane29::enabled<F>()) {
     using FO = lane29::Ops<F>;
     using LPt = lane29::Pt<FO>;
@@ -408,12 +417,23 @@ __global__ void __launch_bounds__(64 << RB) msm_lane_reduce_kernel(const XYZZ29<
     kc.init();
     const size_t e = ((size_t)blockIdx.y << in_per_bw_log) + ((size_t)blockIdx.x << g_log) + w;
     LPt R, Y;
-    if (level0) {
+    if (mode == 0) {
       R = lane29::load_pt<F>(kc, &in[e]);
       Y = R;
-    } else {
+    } else if (mode == 1) {
       Y = lane29::load_pt<F>(kc, &in[2 * e]);
       R = lane29::load_pt<F>(kc, &in[2 * e + 1]);
+    } else if (mode == 2) {
+      Y = lane29::load_pt<F>(kc, &in[e]);
+      R = lane29::load_pt<F>(kc, &in2[e]);
+    } else {
+      const size_t t = ((size_t)blockIdx.x << g_log) + w;
+      const XYZZ29<F>* f = in + (size_t)blockIdx.y * 3 * 256;
+      LPt loc = lane29::load_pt<F>(kc, &f[2 * 256 + t]);
+#pragma unroll 1
+      for (unsigned k = 0; k < k_log; k++) loc = lane29::dbl_pt<FO>(kc, loc);
+      Y = lane29::add_pt<FO>(kc, lane29::load_pt<F>(kc, &f[t]), loc);
+      R = lane29::load_pt<F>(kc, &f[256 + t]);
     }
     unsigned buf = 0;
 #pragma unroll 1
@@ -537,8 +557,45 @@ bool msm_lane_reduce(hipStream_t s, const MsmGeom& g, const MsmBuffers<F>& b) {
                            g_log, u_log, (int)(lvl == 0), out, last ? b.window_sums : (XYZZ29<F>*)nullptr);
       else
         hipLaunchKernelGGL((msm_lane_reduce_kernel<F, RB>), dim3(1u << (per_log - g_log), bwi), dim3(64u << g_log), 0, s, in,
-                           per_log, g_log, u_log, (int)(lvl == 0), out, last ? b.window_sums : (XYZZ29<F>*)nullptr);
+                           (const XYZZ29<F>*)nullptr, per_log, g_log, u_log, lvl == 0 ? 0 : 1, 0u, out,
+                           last ? b.window_sums : (XYZZ29<F>*)nullptr);
       in = out;
+      rem -= g_log;
+      per_log -= g_log;
+      u_log += g_log;
+      lvl++;
+    } while (rem);
+    return true;
+  }
+}
+
+// What msm_top_kernel does, as lane-form levels over its <= 256 entries per bucket-window (modes 2 / 3 above); for an idle
+// chip only (a plain MSM, H's exposed reduction): false when the path does not apply
+template <class F>
+bool msm_lane_top(hipStream_t s, const MsmGeom& g, const MsmBuffers<F>& b, const TopGeom& tg) {
+  if constexpr (!lane29::enabled<F>()) return false;
+  else {
+    const unsigned bwi = g.bw * b.ninst;
+    static const bool off = [] { const char* e = getenv("DG16_NO_LANE_TOP"); return e && atoi(e) != 0; }();
+    if (off || !b.top_tmp || b.busy_chip || (size_t)bwi * tg.lanes > kLaneParallelMaxEntries) return false;
+    unsigned ll = 0;
+    while ((1u << ll) < tg.lanes) ll++;
+    if ((1u << ll) != tg.lanes) return false;
+    constexpr int RB = lane_reduce_radix_log<F>();
+    XYZZ29<F>* pong[2] = {b.top_tmp, b.top_tmp + (size_t)bwi * 64 + 4};
+    const XYZZ29<F>* in = tg.folded ? b.fold : b.row_w;
+    const XYZZ29<F>* in2 = tg.folded ? nullptr : b.row_r;
+    unsigned rem = ll, per_log = ll, lvl = 0;
+    unsigned u_log = tg.folded ? tg.final_log + tg.per_log : tg.final_log;
+    do {
+      const unsigned g_log = rem < (unsigned)RB ? rem : (unsigned)RB;
+      const bool last = rem == g_log;
+      XYZZ29<F>* out = pong[lvl & 1];
+      hipLaunchKernelGGL((msm_lane_reduce_kernel<F, RB>), dim3(1u << (per_log - g_log), bwi), dim3(64u << g_log), 0, s, in, in2,
+                         per_log, g_log, u_log, lvl ? 1 : (tg.folded ? 3 : 2), tg.final_log, out,
+                         last ? b.window_sums : (XYZZ29<F>*)nullptr);
+      in = out;
+      in2 = nullptr;
       rem -= g_log;
       per_log -= g_log;
       u_log += g_log;
@@ -640,8 +697,9 @@ void msm_bucket_phase(hipStream_t s, const MsmSort& st, const MsmBuffers<F>& b, 
       hipLaunchKernelGGL(msm_rowfold_kernel<F>, dim3(8, bwi), dim3(64), 0, s, b.rg, b.row_w, b.row_r, b.fold);
   }
   constexpr int HALVES = sizeof(XYZZ29<F>) * 513 <= 160 * 1024 ? 2 : 1;
-  hipLaunchKernelGGL((msm_top_kernel<F, HALVES>), dim3(bwi), dim3(256 * HALVES), 0, s, tg, b.row_w, b.row_r,
-                     b.fold, b.window_sums);
+  if (!msm_lane_top<F>(s, g, b, tg))
+    hipLaunchKernelGGL((msm_top_kernel<F, HALVES>), dim3(bwi), dim3(256 * HALVES), 0, s, tg, b.row_w, b.row_r,
+                       b.fold, b.window_sums);
   trace_point(s, "top");
   msm_tail_phase<F>(s, st, b, out_affine, out_dev);     // msm_group.hip: inline products whatever this unit's are
   trace_point(s, "tail");
