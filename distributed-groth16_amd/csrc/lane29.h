@@ -73,6 +73,23 @@ constexpr LimbArr<N> kp_norm(int k) {
   return r;
 }
 
+// p - 2 as 32-bit words (the Fermat exponent of inv below)
+template <class P>
+constexpr LimbArr<P::NL> p_minus_2_words() {
+  LimbArr<P::NL> r{};
+  uint64_t borrow = 2;
+  for (int i = 0; i < P::NL; i++) {
+    const uint64_t d = (uint64_t)P::P[i] - borrow;
+    r.v[i] = (uint32_t)d;
+    borrow = (d >> 32) & 1;
+  }
+  return r;
+}
+template <class P>
+struct PM2 {
+  static constexpr LimbArr<P::NL> v = p_minus_2_words<P>();
+};
+
 // Multiples of p the group law subtracts with, per class of field (tools/lane_bounds.py walks dbl_pt / add_pt with these
 // and checks that the bounds of a chain's running point close below R): SUB[i] = the K of sub<i> (K > value bound of the
 // subtrahend), NEG = the multiple a quadratic-extension product negates b.c1 with, ZERO = how many multiples of p a zero
@@ -969,6 +986,73 @@ __device__ __forceinline__ void store_pt_raw(const typename Ops<F>::KT& k, XYZZ2
 template <class F>
 __device__ __forceinline__ void store_pt(const typename Ops<F>::KT& k, XYZZ29<F>* dst, const Pt<Ops<F>>& p) {
   store_pt_raw<F>(k, dst, exit_pt<F>(k, p));
+}
+
+// ---- inversion and the affine form of a chain's result -----------------------------------------------------------------
+// x^(p - 2) with 4-bit windows: 15 products for the table, then 4 squarings + at most one product per nibble -- ~1.25
+// products per bit at 0.24 us (nine limbs) / 0.46 us (fourteen) instead of a lone lane's 32-bit-limb Fermat chain (~1 ms for
+// a 377-bit field: what d_msm paid TWICE per round, at the end of every party's MSM and of the king's combination:
+// profiles/r6bb_timeline_dmsm.md).  E: an element of a BASE field; mul / sel / one as the policy's.
+template <class P, class E, class Mul, class Sel>
+__device__ __forceinline__ E pow_p_minus_2(E x, E one, Mul mul, Sel sel) {
+  E tab[16];
+  tab[0] = one;
+  tab[1] = x;
+#pragma unroll
+  for (int j = 2; j < 16; j++) tab[j] = mul(tab[j - 1], x);
+  E acc = one;
+  bool started = false;
+#pragma unroll 1
+  for (int i = 8 * P::NL - 1; i >= 0; i--) {
+    const unsigned nib = (PM2<P>::v.v[i >> 3] >> (4 * (i & 7))) & 15u;
+    if (started) {
+      acc = mul(acc, acc);
+      acc = mul(acc, acc);
+      acc = mul(acc, acc);
+      acc = mul(acc, acc);
+    }
+    if (nib == 0) continue;
+    E t = tab[1];
+#pragma unroll
+    for (int j = 2; j < 16; j++) t = sel(nib == (unsigned)j, tab[j], t);
+    acc = started ? mul(acc, t) : t;
+    started = true;
+  }
+  return acc;
+}
+template <class P>
+__device__ __forceinline__ typename Fq9<P>::E inv(const typename Fq9<P>::KT& k, Fq9<P>, uint32_t x) {
+  return pow_p_minus_2<P, uint32_t>(
+      x, k.one(), [&](uint32_t a, uint32_t b) { return lane29::mul(k, a, b); },
+      [](bool c, uint32_t a, uint32_t b) { return c ? a : b; });
+}
+template <class P>
+__device__ __forceinline__ typename Fq14<P>::E inv(const typename Fq14<P>::KT& k, Fq14<P>, l14::E14 x) {
+  return pow_p_minus_2<P, l14::E14>(
+      x, k.one(), [&](l14::E14 a, l14::E14 b) { return l14::mul(k, a, b); },
+      [](bool c, l14::E14 a, l14::E14 b) { return l14::E14{c ? a.lo : b.lo, c ? a.hi : b.hi}; });
+}
+// 1 / (a + b u) = (a - b u) / (a^2 + b^2) over u^2 = -1
+template <class P>
+__device__ __forceinline__ E2 inv(const typename Fq9x2<P>::KT& k, Fq9x2<P>, E2 x) {
+  const uint32_t n = renorm(lane29::mul(k, x.c0, x.c0) + lane29::mul(k, x.c1, x.c1));
+  const uint32_t ni = pow_p_minus_2<P, uint32_t>(
+      n, k.one(), [&](uint32_t a, uint32_t b) { return lane29::mul(k, a, b); },
+      [](bool c, uint32_t a, uint32_t b) { return c ? a : b; });
+  const uint32_t c1 = lane29::mul(k, x.c1, ni);                         // < 2.1 p: sub<0> (K = 4) serves
+  return {lane29::mul(k, x.c0, ni), renorm(k.sub[0] - c1)};
+}
+// (X / ZZ, Y / ZZZ) in the arkworks form of the C ABI; the identity is (0, 0)
+template <class F>
+__device__ __forceinline__ Affine<F> to_affine(const typename Ops<F>::KT& k, const Pt<Ops<F>>& p) {
+  using FO = Ops<F>;
+  constexpr int BS = XYZZ29<F>::BS;
+  if (p.inf) return Affine<F>::inf();
+  const auto ti = inv(k, FO{}, FO::mul(k, p.zz, p.zzz));
+  const auto xa = FO::mul(k, p.x, FO::mul(k, ti, p.zzz));
+  const auto ya = FO::mul(k, p.y, FO::mul(k, ti, p.zz));
+  return {FieldOf<F>::to32(FO::template to_regs<BS>(FO::template exit_norm<BS>(k, xa, true))),
+          FieldOf<F>::to32(FO::template to_regs<BS>(FO::template exit_norm<BS>(k, ya, true)))};
 }
 #endif  // __HIPCC__
 

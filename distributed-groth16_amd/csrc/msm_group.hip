@@ -83,8 +83,8 @@ __global__ void __launch_bounds__(512) matvec_points_wave_kernel(const Fr* __res
   }
   __syncthreads();
   if (wave != 0) return;
-  const XYZZ29<F> acc = sum_points_wave<F>(part, cols);
-  if (lane == 0) out[blockIdx.x] = acc.to_xyzz32().to_affine();
+  const Affine<F> acc = sum_points_affine_wave<F>(part, cols);
+  if (lane == 0) out[blockIdx.x] = acc;
 }
 // out[e][r] = sum_c M[r][c] P[e][c]: few outputs -> a workgroup each (<= 8 terms: two waves per SIMD, 256 registers each),
 // many -> a lane each

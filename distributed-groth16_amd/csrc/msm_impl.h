@@ -1846,6 +1846,22 @@ __device__ __forceinline__ XYZZ29<F> sum_points_wave(const XYZZ29<F>* pts, unsig
   }
 }
 
+// the same sum as an affine point (the king's combination hands affine points to the parties)
+template <class F>
+__device__ __forceinline__ Affine<F> sum_points_affine_wave(const XYZZ29<F>* pts, unsigned n) {
+  if constexpr (lane29::enabled<F>()) {
+    using FO = lane29::Ops<F>;
+    typename FO::KT kc;
+    kc.init();
+    lane29::Pt<FO> acc = lane29::inf_pt<FO>(kc);
+#pragma unroll 1
+    for (unsigned i = 0; i < n; i++) acc = lane29::add_pt<FO>(kc, acc, lane29::load_pt<F>(kc, &pts[i]));
+    return lane29::to_affine<F>(kc, acc);
+  } else {
+    return sum_points_wave<F>(pts, n).to_xyzz32().to_affine();
+  }
+}
+
 // rows of 2^kRowLog buckets
 constexpr unsigned kRowLog = 8;
 struct RowGeom {
@@ -2090,6 +2106,14 @@ __global__ void __launch_bounds__(64) msm_tail_kernel(const XYZZ29<F>* __restric
 #pragma unroll 1
       for (unsigned k = 0; k < g.c; k++) a = lane29::dbl_pt<FO>(kc, a);
       a = lane29::add_pt<FO>(kc, a, lane29::load_pt<F>(kc, &window_sums[w]));
+    }
+    if (affine) {            // (X / ZZ, Y / ZZZ) with the inversion in lane form as well (lane29::to_affine)
+      const Affine<F> r = lane29::to_affine<F>(kc, a);
+      if (threadIdx.x == 0) {
+        out[0] = r.x;
+        out[1] = r.y;
+      }
+      return;
     }
     acc = lane29::from_pt<F>(kc, a);
   } else {

@@ -140,7 +140,14 @@ __global__ void __launch_bounds__(64) k_check_pt(unsigned* bad) {
     lr = lane29::add_pt<GO>(k, lr, (it & 1) ? lane29::neg_pt<GO>(k, lo) : lo);
   }
   const bool c_ok = same_pt(r, lane29::from_pt<G>(k, lr));
+  // the affine form (one inversion in lane form) of a point whose ZZ, ZZZ are a square and a cube: X / ZZ, Y / ZZZ
+  XYZZ29<G> q = p;
+  q.zz = fit<XYZZ29<G>::BS>(o.x * o.x);
+  q.zzz = fit<XYZZ29<G>::BS>(q.zz * o.x);
+  const Affine<G> want = q.to_xyzz32().to_affine(), got = lane29::to_affine<G>(k, lane29::to_pt<G>(k, q));
+  const bool f_ok = want.x == got.x && want.y == got.y && lane29::to_affine<G>(k, inf).is_inf();
   if (threadIdx.x == 0) {
+    if (!f_ok) atomicAdd(bad + 6, 1u);
     if (!d_ok) atomicAdd(bad, 1u);
     if (!a_ok) atomicAdd(bad + 1, 1u);
     if (!pp_ok) atomicAdd(bad + 2, 1u);
@@ -256,8 +263,8 @@ int main() {
     else hipLaunchKernelGGL(k_check_pt<F377>, dim3(1024), dim3(64), 0, 0, d);
     CK(hipDeviceSynchronize());
     CK(hipMemcpy(h.data(), d, 64, hipMemcpyDeviceToHost));
-    printf("%s, of 1024: doubling %u wrong, addition %u, p + p %u, p - p %u, identity operands %u, chain of 48 doublings + 3 additions %u\n",
-           names[g], h[0], h[1], h[2], h[3], h[4], h[5]);
+    printf("%s, of 1024: doubling %u wrong, addition %u, p + p %u, p - p %u, identity operands %u, chain of 48 doublings + 3 additions %u, "
+           "affine form %u\n", names[g], h[0], h[1], h[2], h[3], h[4], h[5], h[6]);
   }
   for (int blocks : {1, 256, 1024}) {
     const int iters = 200;
