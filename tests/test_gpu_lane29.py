@@ -31,3 +31,32 @@ def test_lane_chains_match_the_wave_chains_on_every_group():
     # the point of the exercise: a chain of 16 doublings + 1 addition at least twice as fast in every group
     speedups = [float(x) for x in re.findall(r"\((\d+\.\d+)x\)", text)]
     assert speedups and min(speedups) > 2.0, text
+
+
+_ENV_CHECK = r"""
+import sys
+import numpy as np
+sys.path.insert(0, %(root)r)
+sys.path.insert(0, %(root)r + "/tests")
+from oracle import corc
+import dg16_amd
+c = dg16_amd.Context(0)
+for curve, group, n in (("bn254", 1, 1 << 10), ("bn254", 2, 1 << 12), ("bls12_377", 1, 1 << 13), ("bn254", 1, 1 << 17)):
+    bases = c.gen_bases(curve, group, 5 + n, n)
+    sc = corc.rand_field(curve, "fr", 6 + n, n, mont=False)
+    got = corc.jac_to_affine(curve, group, c.msm(curve, group, bases, sc, in_subgroup=True))
+    assert np.array_equal(got, corc.msm(curve, group, bases, sc)), (curve, group, n)
+print("ok")
+"""
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env", [{"DG16_NO_LANE_REDUCE": "1", "DG16_NO_LANE_TOP": "1"}, {"DG16_NO_LANE_TOP": "1"}, {}])
+def test_bucket_reduction_is_the_same_through_the_row_and_top_kernels(env):
+    """The lane-form reductions (msm_lane_reduce_kernel, msm_lane_top) can be switched off in one library: the row / top
+    kernels they stand in for (still the path of large bucket sets inside proofs) must give the oracle's MSM as well."""
+    import sys
+    e = dict(os.environ)
+    e.update(env)
+    out = subprocess.run([sys.executable, "-c", _ENV_CHECK % {"root": ROOT}], capture_output=True, text=True, timeout=600, env=e)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout + out.stderr
