@@ -1,5 +1,8 @@
-// Limb-per-lane arithmetic for the LATENCY chains of the 9-limb fields (Horner tail, scalar multiples, the late steps of
-// the bucket trees, the king's combinations, the proof assembly) -- round 6.
+// Limb-per-lane arithmetic for the LATENCY chains (Horner tail, scalar multiples, small bucket reductions, the top level of
+// large ones, the king's combinations, inversions) of all six groups -- round 6.  The nine-limb form is described here;
+// the fourteen-limb one (two registers per element) and the quadratic extensions further down.
+// EVERY function below assumes all 64 lanes of the wave active and its operands uniform across the four rows (unless a
+// product has just put four different results on them): the row primitives are opaque asm that reads other lanes.
 //
 // The wave-cooperative chains of msm_impl.h (dbl_wave29 / add_wave29) run one base-field product per LANE: a level of
 // a group operation is then never shorter than one 162-mad product on one lane (227 dependent VALU issues, 0.45 us) plus
@@ -206,14 +209,17 @@ enum Row : int {
   ROW_PH = 7,                  // 7 rows: PH[i][l] = p_(7 + l - i)
   ROW_PP = 14,                 // 7 rows: p'0_(l - i), l < 7
   ROW_SUB = 21,                // 4 x (lo, hi): spread K p
-  ROW_JP = 29,                 // 7 x (lo, hi): j p, normalised
-  ROW_ONE = 43,                // (lo, hi): R mod p
-  ROW_COUNT = 45
+  ROW_NEG = 29,                // (lo, hi): spread NEG BETA p, the multiple a quadratic-extension product negates BETA b.c1 with
+  ROW_JP = 31,                 // kMaxZero x (lo, hi): j p, normalised
+  ROW_ONE = 47,                // (lo, hi): R mod p
+  ROW_COUNT = 49
 };
+// the spread of the negation constant dominates BETA x a tight limb: BETA + 1 units of 2^28
+template <class P> constexpr int neg_spread() { return Fq2Beta<P>::value + 1 < kSpread ? kSpread : Fq2Beta<P>::value + 1; }
 struct TabData {
   uint32_t t[ROW_COUNT][16];
 };
-template <class P>
+template <class P, bool EXT>
 constexpr TabData make_tab() {
   TabData d{};
   const LimbArr<H> pp = pprime0_limbs<P>();
@@ -225,13 +231,20 @@ constexpr TabData make_tab() {
       d.t[ROW_PP + i][l] = (in && l < H) ? pp.v[l - i] : 0u;
     }
   for (int s = 0; s < 4; s++) {
-    const LimbArr<N> kp = rr::kp_limbs<P>(LawK<false>::SUB[s], kSpread);
+    const LimbArr<N> kp = rr::kp_limbs<P>(LawK<EXT>::SUB[s], kSpread);
     for (int l = 0; l < H; l++) {
       d.t[ROW_SUB + 2 * s][l] = kp.v[l];
       d.t[ROW_SUB + 2 * s + 1][l] = kp.v[H + l];
     }
   }
-  for (int j = 0; j < LawK<false>::ZERO; j++) {
+  if (EXT) {
+    const LimbArr<N> kp = rr::kp_limbs<P>(LawK<EXT>::NEG * Fq2Beta<P>::value, neg_spread<P>());
+    for (int l = 0; l < H; l++) {
+      d.t[ROW_NEG][l] = kp.v[l];
+      d.t[ROW_NEG + 1][l] = kp.v[H + l];
+    }
+  }
+  for (int j = 0; j < LawK<EXT>::ZERO; j++) {
     const LimbArr<N> jp = kp_norm<P>(j);
     for (int l = 0; l < H; l++) {
       d.t[ROW_JP + 2 * j][l] = jp.v[l];
@@ -244,9 +257,9 @@ constexpr TabData make_tab() {
   }
   return d;
 }
-template <class P>
+template <class P, bool EXT>
 struct Tab {
-  static constexpr TabData v = make_tab<P>();
+  static constexpr TabData v = make_tab<P, EXT>();
 };
 }  // namespace l14
 
@@ -642,10 +655,11 @@ __device__ __forceinline__ uint32_t three_piece(uint64_t c) {
 struct E14 {
   uint32_t lo, hi;
 };
-template <class P>
+template <class P, bool EXT>
 struct K14 {
-  using L = LawK<false>;
-  uint32_t pl[H], ph[H], pp[H], sublo[4], subhi[4], jplo[L::ZERO], jphi[L::ZERO], lane6;
+  using L = LawK<EXT>;
+  using T = Tab<P, EXT>;
+  uint32_t pl[H], ph[H], pp[H], sublo[4], subhi[4], neglo, neghi, jplo[L::ZERO], jphi[L::ZERO], lane6;
   unsigned l16, row;
   __device__ __forceinline__ void init() {
     const unsigned lane = __lane_id();
@@ -653,23 +667,25 @@ struct K14 {
     row = lane >> 4;
 #pragma unroll
     for (int i = 0; i < H; i++) {
-      pl[i] = Tab<P>::v.t[ROW_PL + i][l16];
-      ph[i] = Tab<P>::v.t[ROW_PH + i][l16];
-      pp[i] = Tab<P>::v.t[ROW_PP + i][l16];
+      pl[i] = T::v.t[ROW_PL + i][l16];
+      ph[i] = T::v.t[ROW_PH + i][l16];
+      pp[i] = T::v.t[ROW_PP + i][l16];
     }
 #pragma unroll
     for (int s = 0; s < 4; s++) {
-      sublo[s] = Tab<P>::v.t[ROW_SUB + 2 * s][l16];
-      subhi[s] = Tab<P>::v.t[ROW_SUB + 2 * s + 1][l16];
+      sublo[s] = T::v.t[ROW_SUB + 2 * s][l16];
+      subhi[s] = T::v.t[ROW_SUB + 2 * s + 1][l16];
     }
 #pragma unroll
     for (int j = 0; j < L::ZERO; j++) {
-      jplo[j] = Tab<P>::v.t[ROW_JP + 2 * j][l16];
-      jphi[j] = Tab<P>::v.t[ROW_JP + 2 * j + 1][l16];
+      jplo[j] = T::v.t[ROW_JP + 2 * j][l16];
+      jphi[j] = T::v.t[ROW_JP + 2 * j + 1][l16];
     }
+    neglo = T::v.t[ROW_NEG][l16];
+    neghi = T::v.t[ROW_NEG + 1][l16];
     lane6 = l16 == 6 ? 0xFFFFFFFFu : 0u;
   }
-  __device__ __forceinline__ E14 one() const { return {Tab<P>::v.t[ROW_ONE][l16], Tab<P>::v.t[ROW_ONE + 1][l16]}; }
+  __device__ __forceinline__ E14 one() const { return {T::v.t[ROW_ONE][l16], T::v.t[ROW_ONE + 1][l16]}; }
 };
 // one carry pass over both registers: the carry out of limb 6 (lane 7 of lo) goes to lane 0 of hi
 __device__ __forceinline__ E14 renorm(E14 v, unsigned l16) {
@@ -714,6 +730,16 @@ __device__ __forceinline__ E14 reduce(const KT& k, Cols14 c) {
   const E14 r = {k.l16 < (unsigned)H ? res : 0u, shl7(res)};
   return renorm(r, k.l16);
 }
+__device__ __forceinline__ void cols_mad(Cols14& c, const uint32_t (&al)[H], const uint32_t (&ah)[H], const uint32_t (&bl)[H],
+                                         const uint32_t (&bh)[H]) {
+#pragma unroll
+  for (int i = 0; i < H; i++) {
+    c.c0 += (uint64_t)al[i] * bl[i];
+    c.c1 += (uint64_t)al[i] * bh[i];
+    c.c1 += (uint64_t)ah[i] * bl[i];
+    c.c2 += (uint64_t)ah[i] * bh[i];
+  }
+}
 template <class KT>
 __device__ __forceinline__ E14 mul(const KT& k, E14 a, E14 b) {
   uint32_t al[H], ah[H], bl[H], bh[H];
@@ -722,13 +748,7 @@ __device__ __forceinline__ E14 mul(const KT& k, E14 a, E14 b) {
   shifts7(bl, b.lo);
   shifts7(bh, b.hi);
   Cols14 c = {0, 0, 0};
-#pragma unroll
-  for (int i = 0; i < H; i++) {
-    c.c0 += (uint64_t)al[i] * bl[i];
-    c.c1 += (uint64_t)al[i] * bh[i];
-    c.c1 += (uint64_t)ah[i] * bl[i];
-    c.c2 += (uint64_t)ah[i] * bh[i];
-  }
+  cols_mad(c, al, ah, bl, bh);
   return reduce(k, c);
 }
 }  // namespace l14
@@ -738,7 +758,7 @@ struct Fq14 {
   static constexpr bool EXT = false;
   static constexpr int WORDS = l14::N;
   using E = l14::E14;
-  using KT = l14::K14<P>;
+  using KT = l14::K14<P, false>;
   static constexpr int H = l14::H;
   static __device__ __forceinline__ E zero() { return {0u, 0u}; }
   static __device__ __forceinline__ E one(const KT& k) { return k.one(); }
@@ -812,9 +832,139 @@ struct Fq14 {
     return f;
   }
 };
+struct E14x2 {
+  l14::E14 c0, c1;
+};
+// quadratic extension u^2 = -BETA over a fourteen-limb field (G2 of BLS12-381: BETA = 1, of BLS12-377: BETA = 5), both
+// components of a product on the same row like Fq9x2: c0 = a0 b0 + a1 (NEG BETA p - BETA b1), c1 = a0 b1 + a1 b0
+template <class P_>
+struct Fq14x2 {
+  using P = P_;
+  static constexpr bool EXT = true;
+  static constexpr int BETA = Fq2Beta<P>::value;
+  static constexpr int WORDS = 2 * l14::N;
+  static constexpr int H = l14::H;
+  using B1 = l14::E14;
+  using E = E14x2;
+  using KT = l14::K14<P, true>;
+  static __device__ __forceinline__ E zero() { return {{0u, 0u}, {0u, 0u}}; }
+  static __device__ __forceinline__ E one(const KT& k) { return {k.one(), {0u, 0u}}; }
+  static __device__ __forceinline__ B1 rn(const KT& k, B1 v) { return l14::renorm(v, k.l16); }
+  static __device__ __forceinline__ E mul(const KT& k, E a, E b) {
+    const B1 nb1 = rn(k, {k.neglo - b.c1.lo * (uint32_t)BETA, k.neghi - b.c1.hi * (uint32_t)BETA});
+    uint32_t a0l[H], a0h[H], a1l[H], a1h[H], b0l[H], b0h[H], b1l[H], b1h[H], n1l[H], n1h[H];
+    l14::bcast7(a0l, a.c0.lo);
+    l14::bcast7(a0h, a.c0.hi);
+    l14::bcast7(a1l, a.c1.lo);
+    l14::bcast7(a1h, a.c1.hi);
+    l14::shifts7(b0l, b.c0.lo);
+    l14::shifts7(b0h, b.c0.hi);
+    l14::shifts7(b1l, b.c1.lo);
+    l14::shifts7(b1h, b.c1.hi);
+    l14::shifts7(n1l, nb1.lo);
+    l14::shifts7(n1h, nb1.hi);
+    l14::Cols14 x = {0, 0, 0}, y = {0, 0, 0};
+    l14::cols_mad(x, a0l, a0h, b0l, b0h);
+    l14::cols_mad(x, a1l, a1h, n1l, n1h);
+    l14::cols_mad(y, a0l, a0h, b1l, b1h);
+    l14::cols_mad(y, a1l, a1h, b0l, b0h);
+    return {l14::reduce(k, x), l14::reduce(k, y)};
+  }
+  static __device__ __forceinline__ E dbl(const KT& k, E a) {
+    return {rn(k, {a.c0.lo << 1, a.c0.hi << 1}), rn(k, {a.c1.lo << 1, a.c1.hi << 1})};
+  }
+  static __device__ __forceinline__ E tpl(const KT& k, E a) {
+    return {rn(k, {a.c0.lo * 3u, a.c0.hi * 3u}), rn(k, {a.c1.lo * 3u, a.c1.hi * 3u})};
+  }
+  static __device__ __forceinline__ E dbl_raw(E a) { return {{a.c0.lo << 1, a.c0.hi << 1}, {a.c1.lo << 1, a.c1.hi << 1}}; }
+  static __device__ __forceinline__ E add_raw(E a, E b) {
+    return {{a.c0.lo + b.c0.lo, a.c0.hi + b.c0.hi}, {a.c1.lo + b.c1.lo, a.c1.hi + b.c1.hi}};
+  }
+  template <int I>
+  static __device__ __forceinline__ E sub(const KT& k, E a, E b) {
+    return {rn(k, {a.c0.lo + (k.sublo[I] - b.c0.lo), a.c0.hi + (k.subhi[I] - b.c0.hi)}),
+            rn(k, {a.c1.lo + (k.sublo[I] - b.c1.lo), a.c1.hi + (k.subhi[I] - b.c1.hi)})};
+  }
+  static __device__ __forceinline__ B1 sel1(bool c, B1 a, B1 b) { return {c ? a.lo : b.lo, c ? a.hi : b.hi}; }
+  static __device__ __forceinline__ E sel(bool c, E a, E b) { return {sel1(c, a.c0, b.c0), sel1(c, a.c1, b.c1)}; }
+  static __device__ __forceinline__ bool is_zero1(const KT& k, B1 v) {
+    v = l14::full_norm(v, k.l16);
+    bool z = false;
+#pragma unroll
+    for (int j = 0; j < KT::L::ZERO; j++)
+      z = z || (__builtin_amdgcn_ballot_w64(v.lo != k.jplo[j] || v.hi != k.jphi[j]) & 0xFFFFull) == 0;
+    return z;
+  }
+  static __device__ __forceinline__ bool is_zero(const KT& k, E v) { return is_zero1(k, v.c0) && is_zero1(k, v.c1); }
+  static __device__ __forceinline__ void swap16(E r, E& even, E& odd) {
+    const auto s0 = __builtin_amdgcn_permlane16_swap(r.c0.lo, r.c0.lo, false, false);
+    const auto s1 = __builtin_amdgcn_permlane16_swap(r.c0.hi, r.c0.hi, false, false);
+    const auto s2 = __builtin_amdgcn_permlane16_swap(r.c1.lo, r.c1.lo, false, false);
+    const auto s3 = __builtin_amdgcn_permlane16_swap(r.c1.hi, r.c1.hi, false, false);
+    even = {{s0[0], s1[0]}, {s2[0], s3[0]}};
+    odd = {{s0[1], s1[1]}, {s2[1], s3[1]}};
+  }
+  static __device__ __forceinline__ void rows_to_all(E r, E& r0, E& r1, E& r2, E& r3) {
+    rows_to_all32(r.c0.lo, r0.c0.lo, r1.c0.lo, r2.c0.lo, r3.c0.lo);
+    rows_to_all32(r.c0.hi, r0.c0.hi, r1.c0.hi, r2.c0.hi, r3.c0.hi);
+    rows_to_all32(r.c1.lo, r0.c1.lo, r1.c1.lo, r2.c1.lo, r3.c1.lo);
+    rows_to_all32(r.c1.hi, r0.c1.hi, r1.c1.hi, r2.c1.hi, r3.c1.hi);
+  }
+  static __device__ __forceinline__ bool any_nonzero(E v) {
+    return __builtin_amdgcn_ballot_w64((v.c0.lo | v.c0.hi | v.c1.lo | v.c1.hi) != 0u) != 0;
+  }
+  static __device__ __forceinline__ E load(const KT& k, const uint32_t* w) {
+    const bool on = k.l16 < (unsigned)H;
+    const unsigned i = on ? k.l16 : 0u;
+    return {{on ? w[i] : 0u, on ? w[H + i] : 0u}, {on ? w[2 * H + i] : 0u, on ? w[3 * H + i] : 0u}};
+  }
+  static __device__ __forceinline__ void store(const KT& k, uint32_t* w, E v) {
+    if (k.row == 0 && k.l16 < (unsigned)H) {
+      w[k.l16] = v.c0.lo;
+      w[H + k.l16] = v.c0.hi;
+      w[2 * H + k.l16] = v.c1.lo;
+      w[3 * H + k.l16] = v.c1.hi;
+    }
+  }
+  template <int BS>
+  static __device__ __forceinline__ E exit_norm(const KT& k, E v, bool reduce_it) {
+    static_assert(BS >= 192, "a storage bound of ~2 p would need the conditional subtraction");
+    if (reduce_it) v = {l14::mul(k, v.c0, k.one()), l14::mul(k, v.c1, k.one())};
+    return {l14::full_norm(v.c0, k.l16), l14::full_norm(v.c1, k.l16)};
+  }
+  template <int BB>
+  static __device__ __forceinline__ E from_regs(const KT& k, const Fe2<P, BB, 1>& f) {
+    uint32_t v0 = 0, v1 = 0, v2 = 0, v3 = 0;
+#pragma unroll
+    for (int i = 0; i < H; i++) {
+      v0 = k.l16 == (unsigned)i ? f.c0.l[i] : v0;
+      v1 = k.l16 == (unsigned)i ? f.c0.l[H + i] : v1;
+      v2 = k.l16 == (unsigned)i ? f.c1.l[i] : v2;
+      v3 = k.l16 == (unsigned)i ? f.c1.l[H + i] : v3;
+    }
+    return {{v0, v1}, {v2, v3}};
+  }
+  template <int BB>
+  static __device__ __forceinline__ Fe2<P, BB, 1> to_regs(E v) {
+    uint32_t o0[H], o1[H], o2[H], o3[H];
+    l14::bcast7(o0, v.c0.lo);
+    l14::bcast7(o1, v.c0.hi);
+    l14::bcast7(o2, v.c1.lo);
+    l14::bcast7(o3, v.c1.hi);
+    Fe2<P, BB, 1> f;
+#pragma unroll
+    for (int i = 0; i < H; i++) {
+      f.c0.l[i] = o0[i];
+      f.c0.l[H + i] = o1[i];
+      f.c1.l[i] = o2[i];
+      f.c1.l[H + i] = o3[i];
+    }
+    return f;
+  }
+};
 template <class F> struct PolicyOf;
 template <class P> struct PolicyOf<Fp<P>> { using type = std::conditional_t<RR<P>::N == N, Fq9<P>, Fq14<P>>; };
-template <class P> struct PolicyOf<Fp2<Fp<P>>> { using type = Fq9x2<P>; };
+template <class P> struct PolicyOf<Fp2<Fp<P>>> { using type = std::conditional_t<RR<P>::N == N, Fq9x2<P>, Fq14x2<P>>; };
 template <class F> using Ops = typename PolicyOf<F>::type;
 
 // which coordinate fields run their chains in this form: nine-limb fields (BN254: Fq, and Fq2 with u^2 = -1)
@@ -824,7 +974,7 @@ constexpr bool enabled() {
   return false;
 #else
   using P = typename FieldOf<F>::Params;
-  if constexpr (RR<P>::N == l14::N && RR<P>::W == l14::W) return !FieldOf<F>::EXT;       // BLS12 G1
+  if constexpr (RR<P>::N == l14::N && RR<P>::W == l14::W) return true;                    // BLS12 G1 and G2
   else if constexpr (RR<P>::N != N || RR<P>::W != W) return false;
   else if constexpr (FieldOf<F>::EXT) return Fq2Beta<P>::value == 1;                      // BN254 G2
   else return true;                                                                        // BN254 G1
@@ -1041,6 +1191,18 @@ __device__ __forceinline__ E2 inv(const typename Fq9x2<P>::KT& k, Fq9x2<P>, E2 x
       [](bool c, uint32_t a, uint32_t b) { return c ? a : b; });
   const uint32_t c1 = lane29::mul(k, x.c1, ni);                         // < 2.1 p: sub<0> (K = 4) serves
   return {lane29::mul(k, x.c0, ni), renorm(k.sub[0] - c1)};
+}
+// 1 / (a + b u) = (a - b u) / (a^2 + BETA b^2) over u^2 = -BETA
+template <class P>
+__device__ __forceinline__ E14x2 inv(const typename Fq14x2<P>::KT& k, Fq14x2<P>, E14x2 x) {
+  constexpr uint32_t BETA = (uint32_t)Fq2Beta<P>::value;
+  const l14::E14 aa = l14::mul(k, x.c0, x.c0), bb = l14::mul(k, x.c1, x.c1);
+  const l14::E14 n = l14::renorm({aa.lo + bb.lo * BETA, aa.hi + bb.hi * BETA}, k.l16);
+  const l14::E14 ni = pow_p_minus_2<P, l14::E14>(
+      n, k.one(), [&](l14::E14 a, l14::E14 b) { return l14::mul(k, a, b); },
+      [](bool c, l14::E14 a, l14::E14 b) { return l14::E14{c ? a.lo : b.lo, c ? a.hi : b.hi}; });
+  const l14::E14 c1 = l14::mul(k, x.c1, ni);
+  return {l14::mul(k, x.c0, ni), l14::renorm({k.sublo[0] - c1.lo, k.subhi[0] - c1.hi}, k.l16)};
 }
 // (X / ZZ, Y / ZZZ) in the arkworks form of the C ABI; the identity is (0, 0)
 template <class F>

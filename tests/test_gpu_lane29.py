@@ -1,7 +1,7 @@
 """The limb-per-lane chains of csrc/lane29.h on the GPU, against the one-product-per-lane chains they replace
 (msm_impl.h: dbl_wave29 / add_wave29, themselves pinned to the oracle by the MSM and prover suites): the row primitives
 (DPP row shifts / rotations, v_permlane16/32_swap) lane by lane, 4096 products, and for every group the chains cover
-(BN254 G1 and G2, BLS12-381 G1, BLS12-377 G1) 1024 doublings, additions, p + p, p - p, identity operands and a chain of
+(G1 and G2 of BN254, BLS12-381, BLS12-377) 1024 doublings, additions, p + p, p - p, identity operands and a chain of
 48 doublings + 3 additions and the affine form (an inversion in lane form).  The program is tools/ubench/lane29_probe (built by csrc/Makefile).  End-to-end parity of the
 kernels that USE the chains (Horner tail, scalar multiples, king's sums) is in test_gpu_msm / test_gpu_prover /
 test_gpu_dist against the oracle."""
@@ -23,9 +23,9 @@ def test_lane_chains_match_the_wave_chains_on_every_group():
     text = out.stdout
     assert re.search(r"row primitives .*: 0 mismatches", text), text
     assert re.search(r"products: 0 of 4096 wrong; \(a - b\)\(2 b\): 0 wrong", text), text
-    groups = re.findall(r"^(.+), of 1024: doubling (\d+) wrong, addition (\d+), p \+ p (\d+), p - p (\d+), identity operands (\d+), "
+    groups = re.findall(r"^(.+), of 1024 \(256 for the 14-limb G2\): doubling (\d+) wrong, addition (\d+), p \+ p (\d+), p - p (\d+), identity operands (\d+), "
                         r"chain of 48 doublings \+ 3 additions (\d+), affine form (\d+)$", text, re.M)
-    assert [g[0] for g in groups] == ["BN254 G1", "BN254 G2", "BLS12-381 G1", "BLS12-377 G1"], text
+    assert [g[0] for g in groups] == ["BN254 G1", "BN254 G2", "BLS12-381 G1", "BLS12-377 G1", "BLS12-381 G2", "BLS12-377 G2"], text
     for g in groups:
         assert all(int(x) == 0 for x in g[1:]), g
     # the point of the exercise: a chain of 16 doublings + 1 addition at least twice as fast in every group

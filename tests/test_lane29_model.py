@@ -44,7 +44,7 @@ def test_group_law_bounds_close_with_the_headers_constants():
         for ext in (False, True):
             store = 2.04 if (ext and w * n - p.bit_length() < 9) else 7.0
             ks, kneg, nz = LB.LANE29[ext]
-            law, acc = LB.closure(rp, ext, store, ks, kneg)       # asserts that every K dominates its subtrahend
+            law, acc = LB.closure(rp, ext, store, ks, kneg, LB.BETA[name])       # asserts that every K dominates its subtrahend
             assert law.zero_arg < nz and law.maxv < rp
             if not ext:
                 assert acc[1] <= 7.0 and acc[2] <= 7.0 and acc[3] <= 7.0      # y, zz, zzz are stored as they are (exit_pt)

@@ -11,6 +11,6 @@ cp -a $root/include/*.h $work/include/
 mkdir -p $work/tools && cp $root/tools/check_agpr_file.py $root/tools/true.py $work/tools/
 cd $work/distributed-groth16_amd/csrc
 for o in "$@"; do rm -f $o; done
-make -s -j"$(nproc)" XFLAGS="$xflags"
+make -s -j"$(nproc)" XFLAGS="$xflags" ../libdg16.so
 cp $work/distributed-groth16_amd/libdg16.so $root/distributed-groth16_amd/libdg16_$name.so
 echo "built distributed-groth16_amd/libdg16_$name.so with $xflags ($*)"

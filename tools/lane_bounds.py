@@ -18,6 +18,8 @@ FIELDS = {
     "bls12_381_fq": (0x1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaab, 28, 14),
     "bls12_377_fq": (0x01ae3a4617c510eac63b05c06ca1493b1a22d9f300f5138f1ef3622fba094800170b5d44300000008508c00000000001, 28, 14),
 }
+# the quadratic extensions are Fq[u] / (u^2 + BETA): a product's c0 = a0 b0 + a1 (NEG BETA p - BETA b1)
+BETA = {"bn254_fq": 1, "bls12_381_fq": 1, "bls12_377_fq": 5}
 
 
 # the constants lane29.h uses: (kSubKs, negation multiple, multiples of p a zero test compares against)
@@ -28,8 +30,8 @@ LANE29 = {
 
 
 class Law:
-    def __init__(self, rp, ext, store, fixed=None, kneg_fixed=None):
-        self.rp, self.ext, self.store = rp, ext, store
+    def __init__(self, rp, ext, store, fixed=None, kneg_fixed=None, beta=1):
+        self.rp, self.ext, self.store, self.beta = rp, ext, store, beta
         self.fixed, self.kneg_fixed = fixed, kneg_fixed
         self.need = {}          # name of a subtraction -> largest subtrahend bound seen
         self.kneg = 0.0         # largest bound of a negated product operand (quadratic extension)
@@ -48,7 +50,7 @@ class Law:
         if self.kneg_fixed is not None:
             assert b < self.kneg_fixed, "negation constant too small: %.2f" % b
             k = self.kneg_fixed
-        return self.see(max((a * b + a * k) / self.rp, 2 * a * b / self.rp) + 2.01)
+        return self.see(max((a * b + a * k * self.beta) / self.rp, 2 * a * b / self.rp) + 2.01)
 
     def sub(self, name, a, b):
         self.need[name] = max(self.need.get(name, 0.0), b)
@@ -105,8 +107,8 @@ class Law:
         return (X, self.sub("K2", 0.0, Y), ZZ, ZZZ)
 
 
-def closure(rp, ext, store, fixed=None, kneg_fixed=None):
-    law = Law(rp, ext, store, fixed, kneg_fixed)
+def closure(rp, ext, store, fixed=None, kneg_fixed=None, beta=1):
+    law = Law(rp, ext, store, fixed, kneg_fixed, beta)
     S = (store,) * 4
     acc = S
     for _ in range(60):          # the K's only grow; iterate until nothing moves
@@ -128,7 +130,7 @@ def main():
         for ext in (False, True):
             # storage bounds of ec29.h: 7 p, or ~2.03 p for the extension of a field with little slack
             store = 2.04 if (ext and w * n - p.bit_length() < 9) else 7.0
-            law, acc = closure(rp, ext, store)
+            law, acc = closure(rp, ext, store, beta=BETA[name])
             ks = {k: math.floor(v) + 1 for k, v in sorted(law.need.items())}
             print("%-13s %s  R/p = %8.1f  running point < (%.2f, %.2f, %.2f, %.2f) p  K = %s  negation K = %d  "
                   "zero test argument < %.2f p  largest value %.1f p" %
@@ -136,7 +138,7 @@ def main():
             assert law.maxv < rp, "a value would not fit below R"
             # ... and with the constants lane29.h uses for every field (kSubKs, kNegK, kZeroMultiples)
             ks, kneg, nz = LANE29[ext]
-            law, acc = closure(rp, ext, store, ks, kneg)
+            law, acc = closure(rp, ext, store, ks, kneg, BETA[name])
             assert law.zero_arg < nz and law.maxv < rp
             print("   lane29.h: K = %s, negation K = %s: running point < (%.2f, %.2f, %.2f, %.2f) p, zero test argument "
                   "< %.2f p (%d multiples), largest value %.1f p" % (ks, kneg, *acc, law.zero_arg, nz, law.maxv))

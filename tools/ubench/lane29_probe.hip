@@ -91,6 +91,17 @@ using F381 = bls12_381_fq;
 using F377 = bls12_377_fq;
 template <> struct Rnd<F381> : Rnd14<bls12_381_fq_params, (1u << 18) - 1> {};
 template <> struct Rnd<F377> : Rnd14<bls12_377_fq_params, (1u << 14) - 1> {};
+template <class QP, uint32_t TOPMASK>
+struct Rnd14x2 {
+  using B = Rnd14<QP, TOPMASK>;
+  using S2 = typename FieldOf<Fp2<Fp<QP>>>::Store;
+  static __device__ S2 get(uint32_t seed) { return {B::get(2 * seed + 2000003u), B::get(2 * seed + 2000004u)}; }
+  static __device__ bool eq(const S2& a, const S2& b) { return B::eq(a.c0, b.c0) && B::eq(a.c1, b.c1); }
+};
+using F381x2 = Fp2<bls12_381_fq>;
+using F377x2 = Fp2<bls12_377_fq>;
+template <> struct Rnd<F381x2> : Rnd14x2<bls12_381_fq_params, (1u << 18) - 1> {};
+template <> struct Rnd<F377x2> : Rnd14x2<bls12_377_fq_params, (1u << 14) - 1> {};
 template <> struct Rnd<F2> {
   using S2 = typename FieldOf<F2>::Store;
   static __device__ S2 get(uint32_t seed) {
@@ -159,6 +170,8 @@ __global__ void __launch_bounds__(64) k_check_pt(unsigned* bad) {
 
 __device__ uint32_t digest(const XYZZ29<F>& r) { return r.x.l[0] ^ r.y.l[3] ^ r.zz.l[1]; }
 __device__ uint32_t digest(const XYZZ29<F2>& r) { return r.x.c0.l[0] ^ r.y.c1.l[3] ^ r.zz.c0.l[1]; }
+__device__ uint32_t digest(const XYZZ29<F381x2>& r) { return r.x.c0.l[0] ^ r.y.c1.l[3] ^ r.zz.c0.l[1]; }
+__device__ uint32_t digest(const XYZZ29<F377x2>& r) { return r.x.c0.l[0] ^ r.y.c1.l[3] ^ r.zz.c0.l[1]; }
 __device__ uint32_t digest(const XYZZ29<F381>& r) { return r.x.l[0] ^ r.y.l[3] ^ r.zz.l[1]; }
 __device__ uint32_t digest(const XYZZ29<F377>& r) { return r.x.l[0] ^ r.y.l[3] ^ r.zz.l[1]; }
 template <class G, bool NEW>
@@ -254,16 +267,18 @@ int main() {
   CK(hipDeviceSynchronize());
   CK(hipMemcpy(h.data(), d, 64, hipMemcpyDeviceToHost));
   printf("products: %u of 4096 wrong; (a - b)(2 b): %u wrong\n", h[0], h[1]);
-  const char* names[4] = {"BN254 G1", "BN254 G2", "BLS12-381 G1", "BLS12-377 G1"};
-  for (int g = 0; g < 4; g++) {
+  const char* names[6] = {"BN254 G1", "BN254 G2", "BLS12-381 G1", "BLS12-377 G1", "BLS12-381 G2", "BLS12-377 G2"};
+  for (int g = 0; g < 6; g++) {
     CK(hipMemset(d, 0, 64));
     if (g == 0) hipLaunchKernelGGL(k_check_pt<F>, dim3(1024), dim3(64), 0, 0, d);
     else if (g == 1) hipLaunchKernelGGL(k_check_pt<F2>, dim3(1024), dim3(64), 0, 0, d);
     else if (g == 2) hipLaunchKernelGGL(k_check_pt<F381>, dim3(1024), dim3(64), 0, 0, d);
-    else hipLaunchKernelGGL(k_check_pt<F377>, dim3(1024), dim3(64), 0, 0, d);
+    else if (g == 3) hipLaunchKernelGGL(k_check_pt<F377>, dim3(1024), dim3(64), 0, 0, d);
+    else if (g == 4) hipLaunchKernelGGL(k_check_pt<F381x2>, dim3(256), dim3(64), 0, 0, d);
+    else hipLaunchKernelGGL(k_check_pt<F377x2>, dim3(256), dim3(64), 0, 0, d);
     CK(hipDeviceSynchronize());
     CK(hipMemcpy(h.data(), d, 64, hipMemcpyDeviceToHost));
-    printf("%s, of 1024: doubling %u wrong, addition %u, p + p %u, p - p %u, identity operands %u, chain of 48 doublings + 3 additions %u, "
+    printf("%s, of 1024 (256 for the 14-limb G2): doubling %u wrong, addition %u, p + p %u, p - p %u, identity operands %u, chain of 48 doublings + 3 additions %u, "
            "affine form %u\n", names[g], h[0], h[1], h[2], h[3], h[4], h[5], h[6]);
   }
   for (int blocks : {1, 256, 1024}) {
@@ -276,6 +291,10 @@ int main() {
     const float u_new = timed([&] { hipLaunchKernelGGL((k_chain<F2, true>), dim3(blocks), dim3(64), 0, 0, d, iters / 4, 16); });
     const float v_old = timed([&] { hipLaunchKernelGGL((k_chain<F377, false>), dim3(blocks), dim3(64), 0, 0, d, iters / 4, 16); });
     const float v_new = timed([&] { hipLaunchKernelGGL((k_chain<F377, true>), dim3(blocks), dim3(64), 0, 0, d, iters / 4, 16); });
+    const float w_old = timed([&] { hipLaunchKernelGGL((k_chain<F377x2, false>), dim3(blocks), dim3(64), 0, 0, d, iters / 10, 16); });
+    const float w_new = timed([&] { hipLaunchKernelGGL((k_chain<F377x2, true>), dim3(blocks), dim3(64), 0, 0, d, iters / 10, 16); });
+    printf("%4d waves: BLS12-377 G2 16 doublings + 1 addition %.2f -> %.2f us (%.2fx)\n", blocks, 1e3 * w_old / (iters / 10),
+           1e3 * w_new / (iters / 10), w_old / w_new);
     printf("%4d waves: dependent product %.3f -> %.3f us; 16 doublings + 1 addition: G1 %.2f -> %.2f us (%.2fx), G2 %.2f -> %.2f us (%.2fx), "
            "BLS12-377 G1 %.2f -> %.2f us (%.2fx)\n",
            blocks, 1e3 * m_old / (4 * iters), 1e3 * m_new / (4 * iters), 1e3 * t_old / iters, 1e3 * t_new / iters, t_old / t_new,
