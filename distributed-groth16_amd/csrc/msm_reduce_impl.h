@@ -493,7 +493,12 @@ __global__ void __launch_bounds__(64) msm_lane_reduce_serial_kernel(const XYZZ29
   if constexpr (lane29::enabled<F>()) {
     using FO = lane29::Ops<F>;
     using LPt = lane29::Pt<FO>;
-    __builtin_amdgcn_s_setprio(3);
+    // (default priority ON PURPOSE: inside a queue of proofs these reductions have slack and the accumulations they run
+    // beside do not -- at s_setprio 3 an 8-shard rank took 2.56-2.59 ms per proof, at 0 2.50-2.51, a 4-shard rank 3.78 against
+    // 3.63, config 4 in a queue 1.65 against 1.61: profiles/r6hh_serial_reduce_prio_ab.txt)
+#ifdef DG16_SERIAL_REDUCE_PRIO
+    __builtin_amdgcn_s_setprio(DG16_SERIAL_REDUCE_PRIO);
+#endif
     const unsigned G = 1u << g_log;
     typename FO::KT kc;
     kc.init();
