@@ -6,6 +6,13 @@
 #pragma once
 #include "msm_impl.h"
 
+// Priority of the reduction kernels of this file.  Rounds 3-5 ran them at s_setprio 3 (a latency chain ahead of the
+// accumulation waves it shares a SIMD with); with the chains as short as round 6 left them the default priority measures
+// the same or better everywhere -- a queued 2^20 proof 10.11-10.13 -> 10.00-10.10 ms, one at a time 10.22-10.32 -> 10.08-10.14,
+// config 4 queued 1.60 -> 1.58 ms (profiles/r6ii_reduce_prio_ab.txt, same call, three times)
+#ifndef DG16_REDUCE_PRIO
+#define DG16_REDUCE_PRIO 0
+#endif
 namespace dg16 {
 
 // Giant buckets (a boolean witness puts half of ALL entries into bucket 0; the short top window of a c that does
@@ -51,7 +58,7 @@ __global__ void __launch_bounds__(256) msm_giant_kernel(MsmGeom g, unsigned wg_l
                                                          XYZZ29<F>* __restrict__ seg_sum,
                                                          const unsigned* __restrict__ giant_count,
                                                          const unsigned* __restrict__ giant_list, unsigned giant_cap) {
-  __builtin_amdgcn_s_setprio(3);   // latency-bound chain: issue ahead of the accumulation waves sharing the SIMD
+  __builtin_amdgcn_s_setprio(DG16_REDUCE_PRIO);   // latency-bound chain: issue ahead of the accumulation waves sharing the SIMD
   __shared__ XYZZ29<F> sh[256];
   unsigned nwork = giant_count[1];
   if (nwork > 2 * giant_cap) nwork = 2 * giant_cap;          // (never: msm_register_giant)
@@ -101,7 +108,7 @@ __global__ void __launch_bounds__(64) msm_giant_fold_kernel(MsmGeom g, unsigned 
                                                              const unsigned* __restrict__ giant_count,
                                                              const unsigned* __restrict__ giant_list,
                                                              unsigned giant_cap) {
-  __builtin_amdgcn_s_setprio(3);   // latency-bound chain: issue ahead of the accumulation waves sharing the SIMD
+  __builtin_amdgcn_s_setprio(DG16_REDUCE_PRIO);   // latency-bound chain: issue ahead of the accumulation waves sharing the SIMD
   __shared__ XYZZ29<F> sh[kGiantSlices];
   unsigned ng = *giant_count;
   if (ng > giant_cap) ng = giant_cap;
@@ -149,7 +156,7 @@ __device__ __forceinline__ void tree_step_coop(XYZZ29<F>* sh, unsigned base, uns
 template <class F>
 __global__ void __launch_bounds__(256) msm_row_kernel(MsmGeom g, RowGeom rg, const XYZZ29<F>* __restrict__ buckets,
                                                        XYZZ29<F>* __restrict__ row_w, XYZZ29<F>* __restrict__ row_r) {
-  __builtin_amdgcn_s_setprio(3);   // latency-bound chain: issue ahead of the accumulation waves sharing the SIMD
+  __builtin_amdgcn_s_setprio(DG16_REDUCE_PRIO);   // latency-bound chain: issue ahead of the accumulation waves sharing the SIMD
   __shared__ XYZZ29<F> sh[256];
   const unsigned c = threadIdx.x, row = 1u << rg.row_log;
   const size_t rid = ((size_t)blockIdx.y << rg.rows_log) + blockIdx.x;      // (bucket-window, row)
@@ -195,7 +202,7 @@ template <class F, int LANES>
 __global__ void __launch_bounds__(LANES) msm_rowchunk_kernel(unsigned log_nb, unsigned k_log,
                                                               const XYZZ29<F>* __restrict__ buckets,
                                                               XYZZ29<F>* __restrict__ fold /* [bw][3][256]: W1, R, T */) {
-  __builtin_amdgcn_s_setprio(3);   // latency-bound chain: issue ahead of the accumulation waves sharing the SIMD
+  __builtin_amdgcn_s_setprio(DG16_REDUCE_PRIO);   // latency-bound chain: issue ahead of the accumulation waves sharing the SIMD
   constexpr unsigned LL = LANES == 256 ? 8u : 7u;
   static_assert(LANES == 256 || LANES == 128, "workgroup of 256 or 128 lanes");
   __shared__ XYZZ29<F> s_r[LANES];      // run -> r_j -> suffix sums -> tree (T)
@@ -256,7 +263,7 @@ template <class F>
 __global__ void __launch_bounds__(64) msm_rowfold_kernel(RowGeom rg, const XYZZ29<F>* __restrict__ row_w,
                                                           const XYZZ29<F>* __restrict__ row_r,
                                                           XYZZ29<F>* __restrict__ fold /* [bw][3][256]: W, R, local */) {
-  __builtin_amdgcn_s_setprio(3);   // latency-bound chain: issue ahead of the accumulation waves sharing the SIMD
+  __builtin_amdgcn_s_setprio(DG16_REDUCE_PRIO);   // latency-bound chain: issue ahead of the accumulation waves sharing the SIMD
   __shared__ XYZZ29<F> st[64][2];      // [lane][run, acc]
   const unsigned gid = blockIdx.x * 64 + threadIdx.x;   // (half, t)
   const unsigned half = gid >> 8, t = gid & 255;
@@ -296,7 +303,7 @@ __global__ void __launch_bounds__(256 * HALVES) msm_top_kernel(TopGeom tg, const
                                                                 const XYZZ29<F>* __restrict__ row_r,
                                                                 const XYZZ29<F>* __restrict__ fold,
                                                                 XYZZ29<F>* __restrict__ window_sums) {
-  __builtin_amdgcn_s_setprio(3);   // latency-bound chain: issue ahead of the accumulation waves sharing the SIMD
+  __builtin_amdgcn_s_setprio(DG16_REDUCE_PRIO);   // latency-bound chain: issue ahead of the accumulation waves sharing the SIMD
   __shared__ XYZZ29<F> sh[256 * HALVES];
   __shared__ XYZZ29<F> keep;                       // HALVES == 1: sum W while the second pass runs
   const unsigned t = threadIdx.x & 255;
@@ -411,7 +418,7 @@ __global__ void __launch_bounds__(64 << RB) msm_lane_reduce_kernel(const XYZZ29<
     using LPt = lane29::Pt<FO>;
     __shared__ XYZZ29<F> sA[2][1 << RB];     // the scan's R, then the suffix-sum tree
     __shared__ XYZZ29<F> sB[2][1 << RB];     // the W tree
-    __builtin_amdgcn_s_setprio(3);
+    __builtin_amdgcn_s_setprio(DG16_REDUCE_PRIO);
     const unsigned w = threadIdx.x >> 6, G = 1u << g_log;
     typename FO::KT kc;
     kc.init();
