@@ -69,7 +69,7 @@ __global__ void __launch_bounds__(512) matvec_points_wave_kernel(const Fr* __res
   const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const size_t e = blockIdx.x / rows;
   const unsigned r = blockIdx.x % rows;
-  __builtin_amdgcn_s_setprio(3);
+  __builtin_amdgcn_s_setprio(DG16_CHAIN_PRIO);
   {
     const Affine<F> q = in[e * cols + wave];
     XYZZ29<F> v = XYZZ29<F>::inf();

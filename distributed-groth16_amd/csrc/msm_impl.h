@@ -25,6 +25,9 @@
 #include "lane29.h"
 #include "types.h"
 
+#ifndef DG16_CHAIN_PRIO
+#define DG16_CHAIN_PRIO 3       // priority of the one-wave chain kernels (Horner tail, scalar multiples, assembly)
+#endif
 namespace dg16 {
 
 // Accumulation segments: a bucket of cnt entries is cut into k = ceil(cnt / 2^seg_log) segments of EQUAL length
@@ -2091,7 +2094,7 @@ void msm_accumulate_phase(hipStream_t s, const MsmSort& st, const MsmBuffers<F>&
 template <class F>
 __global__ void __launch_bounds__(64) msm_tail_kernel(const XYZZ29<F>* __restrict__ window_sums, MsmGeom g,
                                                        int affine, F* __restrict__ out) {
-  __builtin_amdgcn_s_setprio(3);   // latency-bound chain: issue ahead of the accumulation waves sharing the SIMD
+  __builtin_amdgcn_s_setprio(DG16_CHAIN_PRIO);   // latency-bound chain: issue ahead of the accumulation waves sharing the SIMD
   // one wave per MSM instance (blockIdx.x), every lane carries the same running total (internal form: dbl_wave29)
   window_sums += (size_t)blockIdx.x * g.bw;
   out += (size_t)blockIdx.x * (affine ? 2 : 3);

@@ -62,7 +62,7 @@ template <class Fq, class Fr>
 __global__ void __launch_bounds__(128) prover_stage1_g1_kernel(Jacobian<Fq>* rec, const Affine<Fq>* fixed_g1,
                                                                const Fr* r_s, int mont, int first_shard) {
   const int which = (int)blockIdx.x;     // two workgroups of one wave: s*A' and r*B1' side by side
-  __builtin_amdgcn_s_setprio(3);     // a serial chain on one wave: ahead of the accumulation waves it shares a SIMD with
+  __builtin_amdgcn_s_setprio(DG16_CHAIN_PRIO);     // a serial chain on one wave: ahead of the accumulation waves it shares a SIMD with
   Fr r = r_s[0], s = r_s[1];
   if (mont) { r = r.from_mont(); s = s.from_mont(); }
   XYZZ<Fq> v = XYZZ<Fq>::inf();
@@ -91,7 +91,7 @@ template <class Fq2>
 __global__ void __launch_bounds__(64) prover_stage1_g2_kernel(Jacobian<Fq2>* msm_b2, const Affine<Fq2>* fixed_g2,
                                                                int first_shard) {
   if (!first_shard) return;
-  __builtin_amdgcn_s_setprio(3);
+  __builtin_amdgcn_s_setprio(DG16_CHAIN_PRIO);
   XYZZ<Fq2> b = XYZZ<Fq2>::from_jacobian(*msm_b2);
 #pragma unroll 1
   for (int i = 0; i < 2; i++) b = add_wave(b, XYZZ<Fq2>::from_affine(fixed_g2[i]));
@@ -205,7 +205,7 @@ __global__ void __launch_bounds__(256, 1) prover_assemble_kernel(const uint8_t* 
                                                                   Jacobian<Fq>* out_c) {
   __shared__ XYZZ29<Fq> part[4];
   __shared__ XYZZ29<Fq2> part_b;
-  __builtin_amdgcn_s_setprio(3);     // exposed tail: ahead of whatever else is resident on the SIMD
+  __builtin_amdgcn_s_setprio(DG16_CHAIN_PRIO);     // exposed tail: ahead of whatever else is resident on the SIMD
   const unsigned w4 = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const unsigned wave = blockIdx.x == 0 ? 2 + w4 : w4 == 2 ? 6u : w4;      // the chain this wave runs
   if (blockIdx.x == 1 && w4 == 3) return;                                 // (block 1 has three chains)
