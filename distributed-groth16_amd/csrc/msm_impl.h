@@ -2222,6 +2222,52 @@ __global__ void __launch_bounds__(256) msm_finalize_thr_kernel(MsmGeom g, size_t
   for (unsigned s = 1; s < np; s++) acc = acc.add(sp[DG_IDX(7, msm_part_slot(first, s, wg_log), g.seg_cap)]);
   buckets[gid] = acc;
 }
+// The same sums with a WAVE per bucket in lane form (lane29.h), for the launches where the lone-lane form above is at its
+// worst: a 14-limb G1 addition inlined is ~60 KB of code against the 64-KB instruction cache two CUs share, and the
+// serial loop above ran at ~125 us per dependent addition -- 0.89 ms of a 1.5-ms plain MSM at 2^13 BLS12-377 points,
+// 0.92 of 1.97 at 2^16 (profiles/r6kk_timeline_bls12_377_g1_2e13.md).  A wave per bucket costs ~8x the issue slots of a lane
+// per bucket, so this form takes the launches with at most kLaneFinalizeMaxPartials partial sums in all.
+constexpr size_t kLaneFinalizeMaxPartials = (size_t)1 << 18;
+template <class F>
+__global__ void __launch_bounds__(64) msm_finalize_lane_kernel(MsmGeom g, unsigned wg_log,
+                                                                const unsigned* __restrict__ counts,
+                                                                const unsigned* __restrict__ seg_off,
+                                                                const XYZZ29<F>* __restrict__ seg_sum,
+                                                                XYZZ29<F>* __restrict__ buckets,
+                                                                unsigned* __restrict__ giant_count,
+                                                                unsigned* __restrict__ giant_list, unsigned giant_cap) {
+  if constexpr (lane29::enabled<F>()) {
+    using FO = lane29::Ops<F>;
+    using LPt = lane29::Pt<FO>;
+    const size_t gid = blockIdx.x;                       // one wave per bucket: everything below is uniform across it
+    const unsigned wy = (unsigned)(gid >> g.log_nb);
+    const size_t gs = ((size_t)(wy % g.bw) << g.log_nb) + (gid & (((size_t)1 << g.log_nb) - 1));
+    const unsigned k = (counts[gs] + (1u << g.seg_log) - 1) >> g.seg_log;
+    const unsigned first = seg_off[gs];
+    const unsigned np = msm_nparts(first, k, wg_log);
+    if (np == 0) {
+      if (threadIdx.x == 0) buckets[gid] = XYZZ29<F>::inf();
+      return;
+    }
+    if (np == 1) return;
+    if (np > kGiantSegs) {
+      if (threadIdx.x == 0) msm_register_giant((unsigned)gid, np, giant_count, giant_list, giant_cap);
+      return;
+    }
+    typename FO::KT kc;
+    kc.init();
+    const XYZZ29<F>* sp = seg_sum + (size_t)wy * g.seg_cap;
+    LPt acc = lane29::load_pt<F>(kc, &sp[DG_IDX(7, first, g.seg_cap)]);
+    LPt nx = lane29::load_pt_words<F>(kc, &sp[DG_IDX(7, msm_part_slot(first, 1, wg_log), g.seg_cap)]);
+#pragma unroll 1
+    for (unsigned s = 1; s < np; s++) {
+      const LPt cur = lane29::with_inf_flag<FO>(nx);
+      if (s + 1 < np) nx = lane29::load_pt_words<F>(kc, &sp[DG_IDX(7, msm_part_slot(first, s + 1, wg_log), g.seg_cap)]);
+      acc = lane29::add_pt<FO>(kc, acc, cur);
+    }
+    lane29::store_pt<F>(kc, &buckets[gid], acc);
+  }
+}
 // The same finalize as a THROUGHPUT kernel (G2): LPB lanes per bucket, each summing its share of the bucket's partials
 // into an accumulator that lives in LDS columns between the products (the layout and register budget of
 // msm_accumulate_lds_kernel: two workgroups per CU, ~175 VGPRs), then a log2(LPB)-step tree over neighbouring columns.
@@ -2393,9 +2439,19 @@ void msm_finalize_phase(hipStream_t s, const MsmSort& st, const MsmBuffers<F>& b
                        msm_acc_wg_log<F>(), st.counts, st.seg_off, st.seg_total, b.seg_sum, b.buckets, b.giant,
                        b.giant + 2, b.giant_cap);
   } else {
-    hipLaunchKernelGGL(msm_finalize_thr_kernel<F>, dim3((unsigned)((b.nbw + 255) / 256)), dim3(256), 0, s, st.g, b.nbw,
-                       msm_acc_wg_log<F>(), st.counts, st.seg_off, b.seg_sum, b.buckets, b.giant, b.giant + 2,
-                       b.giant_cap);
+    bool lane = false;
+    if constexpr (lane29::enabled<F>()) {
+      static const bool off = [] { const char* e = getenv("DG16_NO_LANE_FINALIZE"); return e && atoi(e) != 0; }();
+      const size_t partials = ((st.g.region * st.g.bw * b.ninst) >> st.g.seg_log) + b.nbw;      // (an upper bound)
+      lane = !off && !b.busy_chip && partials <= kLaneFinalizeMaxPartials && b.nbw < ((size_t)1 << 31);
+    }
+    if (lane)
+      hipLaunchKernelGGL(msm_finalize_lane_kernel<F>, dim3((unsigned)b.nbw), dim3(64), 0, s, st.g, msm_acc_wg_log<F>(),
+                         st.counts, st.seg_off, b.seg_sum, b.buckets, b.giant, b.giant + 2, b.giant_cap);
+    else
+      hipLaunchKernelGGL(msm_finalize_thr_kernel<F>, dim3((unsigned)((b.nbw + 255) / 256)), dim3(256), 0, s, st.g, b.nbw,
+                         msm_acc_wg_log<F>(), st.counts, st.seg_off, b.seg_sum, b.buckets, b.giant, b.giant + 2,
+                         b.giant_cap);
   }
   DG_HIP(hipGetLastError());
 }

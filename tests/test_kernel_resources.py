@@ -75,3 +75,25 @@ def test_ntt_and_sort_kernels_are_register_and_lds_only():
             assert r["scratch"] == 0 and r["vgprs"] <= 64, k
     (r,) = find("msm_part_place_kernel<").values()
     assert r["lds"] == 3 * 4096 * 4                          # bin counts, bucket ranks, bucket destinations
+
+
+def test_lane_form_reduction_kernels_fit_their_workgroups():
+    """msm_lane_reduce_kernel runs 2^RB waves per workgroup -- 16 for the nine-limb base field, 8 for the others -- so
+    its registers must leave that many waves on one compute unit (4 per SIMD at <= 128 VGPRs, 2 at <= 256), without
+    scratch: every step of its chains is a dependent product, a spill would sit on all of them.  The one-wave form and the
+    Horner tails of the nine-limb groups likewise stay in registers."""
+    (r,) = find("msm_lane_reduce_kernel<bn254_fq,4>").values()
+    assert r["vgprs"] <= 128 and r["scratch"] == 0 and r["agprs"] == 0
+    for name in ("msm_lane_reduce_kernel<Fp2<bn254_fq>,3>", "msm_lane_reduce_kernel<bls12_381_fq,3>",
+                 "msm_lane_reduce_kernel<bls12_377_fq,3>", "msm_lane_reduce_kernel<Fp2<bls12_381_fq>,3>",
+                 "msm_lane_reduce_kernel<Fp2<bls12_377_fq>,3>"):
+        (r,) = find(name).values()
+        assert r["vgprs"] <= 256 and r["scratch"] == 0, (name, r)
+    for k, r in find("msm_lane_reduce_serial_kernel<").items():
+        assert r["scratch"] == 0 and r["vgprs"] <= 256, (k, r)
+    (r,) = find("msm_tail_kernel<bn254_fq>").values()
+    assert r["scratch"] == 0 and r["vgprs"] <= 128
+    # the 14-limb G2 tail was 256 VGPRs + ~140 AGPRs + 160 B of scratch in the one-product-per-lane form
+    for curve in ("bls12_381", "bls12_377"):
+        (r,) = find("msm_tail_kernel<Fp2<%s_fq>>" % curve).values()
+        assert r["vgprs"] <= 200 and r["agprs"] == 0 and r["scratch"] <= 128, r
