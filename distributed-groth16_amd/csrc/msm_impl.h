@@ -1992,6 +1992,8 @@ struct MsmBuffers {
   XYZZ29<F>* window_sums;    // internal form: the tail's wave-cooperative chain runs on the reduced-radix types
   XYZZ29<F>* lane_tmp;       // (W, R) pairs between the levels of msm_lane_reduce_kernel, or null (msm_reduce_impl.h)
   XYZZ29<F>* top_tmp;        // the same for the lane-form levels that stand in for msm_top_kernel (msm_lane_top), or null
+  hipStream_t finalize_stream = nullptr;   // G2: the throughput finalize goes to this stream (behind acc_done) instead of
+                                           // following the accumulation on its own (the prover: B's reduction stream)
   bool busy_chip = false;    // the reduction runs beside saturating kernels of other streams (a proof's MSMs): small
                              // workgroups only (msm_lane_reduce_serial_kernel instead of the 16-wave form)
   unsigned* giant;
@@ -2069,7 +2071,12 @@ void msm_accumulate_phase(hipStream_t s, const MsmSort& st, const MsmBuffers<F>&
                          st.seg_off, st.seg_total, st.entries, b.seg_sum, b.buckets, b.clk);
     }
     if (b.acc_done) DG_HIP(hipEventRecord(b.acc_done, s));
-    msm_finalize_lds_phase<F>(s, st, b);
+    if (b.finalize_stream && b.acc_done) {
+      DG_HIP(hipStreamWaitEvent(b.finalize_stream, b.acc_done, 0));
+      msm_finalize_lds_phase<F>(b.finalize_stream, st, b);
+    } else {
+      msm_finalize_lds_phase<F>(s, st, b);
+    }
   } else {
     constexpr int BLOCK = 1 << msm_acc_block_log<F>();
     hipLaunchKernelGGL((msm_accumulate_kernel<F, BLOCK>), dim3((g.seg_cap + BLOCK - 1) / BLOCK, g.bw * b.ninst),

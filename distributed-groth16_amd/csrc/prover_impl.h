@@ -392,6 +392,13 @@ static bool msms_typed(dg16_ctx* ctx, Call& k0, Call& k1, Call& k2, const PkDev&
   DG_HIP(hipEventRecord(k2.c.ev[2], main));
   buf_b2.acc_done = k2.c.ev[3];              // the accumulation kernel alone; its finalize follows on the same stream
   if (ctx->kclk) buf_b2.clk = ctx->kclk + 2 * 2;      // its clock under the kernel (dg16_last_kernel_ms(ctx, 2, 2))
+  {
+    // B's finalize (a throughput kernel at two waves per SIMD: 8 + 1 dependent Fq2 additions per lane) goes to B's reduction
+    // stream, under A's accumulation, instead of holding the main stream: an 8-shard rank in a queue 2.48 -> 2.36-2.38 ms,
+    // the 2^20 proof and config 4 within the run-to-run spread (profiles/r6oo_g2_finalize_side_ab.txt; =0 puts it back)
+    static const bool main_fin = [] { const char* e = getenv("DG16_G2_FINALIZE_SIDE"); return e && atoi(e) == 0; }();
+    if (!main_fin) buf_b2.finalize_stream = side2;
+  }
   msm_accumulate_phase<Fq2>(main, st_ab, buf_b2, pk.b2_q);
   k2.c.ev_valid[1] = true;
   DG_HIP(hipEventRecord(ev[2], main));
