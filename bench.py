@@ -25,7 +25,7 @@ One JSON line is printed by rank 0:
   cpu_baseline   the oracle ("port": arkworks-structured CPU restatement, NOT arkworks) proving THE TIMED INSTANCE on
                  this box's host cores (all cores, bounded to 32 OpenMP threads; plus a 1-thread run on a smaller
                  sample) -- its proof is compared with the GPU's proof of the timed loop (live parity gate).
-  roofline_g1    the same for A's G1 bucket accumulation (four launches of that kernel per proof: more total time than
+  roofline_g1    the same for B1's G1 bucket accumulation (four launches of that kernel per proof: more total time than
                  the G2 launch), with valu_roofline_g1.
   host_pointer_step  the step with the assignment coming from host memory: one statement at a time, and as a
                  double-buffered queue (pipelined_ms_per_step).
@@ -1091,9 +1091,9 @@ def main():
     del queued
 
     # ---- dominant kernel: the G2 bucket accumulation of the LAST TIMED PROOF (HIP events recorded around it on
-    # the stream it ran on: dg16_last_kernel_ms, channel 2 = G2 accumulation, channel 1 = A's G1 accumulation) ----
+    # the stream it ran on: dg16_last_kernel_ms, channel 2 = G2 accumulation, channel 1 = B1's G1 accumulation) ----
     g2_acc_ms = ctx.last_kernel_ms(2, 1)
-    g1_acc_ms = ctx.last_kernel_ms(1, 1)            # A's accumulation
+    g1_acc_ms = ctx.last_kernel_ms(1, 1)            # B1's accumulation (A's runs beside B's G2 finalize)
     # ... and the shader clock the chip held UNDER each of them, measured by the kernels themselves (ClkProbe, msm_impl.h):
     # 16 lanes per SIMD-cycle x 4 SIMDs x CUs x that clock is the issue bound no DVFS state can move
     g2_mhz = ctx.last_kernel_mhz(2) if hasattr(ctx, "last_kernel_mhz") else 0.0
@@ -1205,7 +1205,7 @@ def main():
         "g1_accumulate_ms": g1_acc_ms,
         # the G1 accumulation: four launches per proof (A, B1, L, H), more TOTAL time than the G2 launch and further from
         # the issue roof -- on the line next to the G2 figures since round 5
-        "roofline_g1": {"bound": "hbm", "kernel": "msm_accumulate_kernel<Fp<%s_fq>> (A's G1 bucket accumulation, table mode, "
+        "roofline_g1": {"bound": "hbm", "kernel": "msm_accumulate_kernel<Fp<%s_fq>> (B1's G1 bucket accumulation, table mode, "
                         "inside the timed proofs; B1, L, H are launches of the same kernel)" % curve,
                         "achieved": (g1_alg * n_g2 / (g1_acc_ms * 1e-3) / 1e9) if g1_acc_ms else 0.0, "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": (g1_alg * n_g2 / (g1_acc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if g1_acc_ms else 0.0,

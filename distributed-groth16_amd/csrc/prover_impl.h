@@ -415,18 +415,49 @@ static bool msms_typed(dg16_ctx* ctx, Call& k0, Call& k1, Call& k2, const PkDev&
 
   // main: A, B1, L -- three launches, three reductions on side streams (A's and L's on `side`, B1's on `xch` followed
   // by the two serial scalar multiples s*A', r*B1')
+  // SHORT MSMs (a shard of a quarter or less of a 2^20 key, BASELINE config 4) run A, B1 and L as three INSTANCES of one
+  // accumulation launch with one reduction chain (MsmBases): their launches are latency-bound -- one round of workgroups
+  // of 8-entry segments each -- and three of them in a row on the main stream is three times that latency.  (At 2^20 the
+  // merged launch was measured slower in round 3: one 4-ms launch starves B's reduction waves where three 1.3-ms launches
+  // do not -- CHANGELOG.md.)
+  static const int abl_env = [] { const char* e = getenv("DG16_ABL_MERGED"); return e ? atoi(e) : -1; }();
+  const bool abl_merged = abl_env >= 0 ? abl_env != 0 : st_ab.g.region * st_ab.g.bw <= ((size_t)1 << 22);
+  if (abl_merged) {
+    MsmBuffers<Fq> buf3 = msm_buffers<Fq>(k0.c, st_ab.g, 3);
+    buf3.busy_chip = true;
+    const void* bases3[3] = {pk.a_q, pk.b1_q, pk.l_q};
+    static_assert(kRecA == 0 && kRecB1 == 1 && kRecL == 2, "the three results land back to back in the record");
+    DG_HIP(hipEventRecord(k1.c.ev[2], main));
+    if (ctx->kclk) buf3.clk = ctx->kclk + 2 * 1;
+    msm_accumulate_phase<Fq>(main, st_ab, buf3, bases3);
+    DG_HIP(hipEventRecord(k1.c.ev[3], main));
+    k1.c.ev_valid[1] = true;
+    DG_HIP(hipEventRecord(ev[6], main));
+    DG_HIP(hipStreamWaitEvent(side, ev[6], 0));
+    if (tail_fence) DG_HIP(hipStreamWaitEvent(side, ev[18], 0));    // tail fence: the record the last assembly reads
+    msm_bucket_phase<Fq>(side, st_ab, buf3, false, rec + kRecA);
+    DG_HIP(hipEventRecord(ev[12], side));
+    DG_HIP(hipStreamWaitEvent(xch, ev[12], 0));
+    hipLaunchKernelGGL((prover_stage1_g1_kernel<Fq, Fr>), dim3(2), dim3(scalar_mul_splits<Fq>() ? 128 : 64), 0, xch, rec,
+                       fixed_g1, r_s, (int)mont, first_shard);
+    DG_HIP(hipEventRecord(ev[7], xch));
+    DG_HIP(hipStreamWaitEvent(side, ev[7], 0));
+    DG_HIP(hipEventRecord(ev[10], side));             // A, B1, L, s*A', r*B1' all done
+  } else
   {
     MsmBuffers<Fq> buf_a = msm_buffers<Fq>(k0.c, st_ab.g);
     MsmBuffers<Fq> buf_b1 = msm_buffers<Fq>(k1.c, st_ab.g);
     MsmBuffers<Fq> buf_l = msm_buffers<Fq>(ctx->xws[1], st_ab.g);
     buf_a.busy_chip = buf_b1.busy_chip = buf_l.busy_chip = true;
-    DG_HIP(hipEventRecord(k1.c.ev[2], main));
-    if (ctx->kclk) buf_a.clk = ctx->kclk + 2 * 1;     // (dg16_last_kernel_ms(ctx, 1, 2))
     msm_accumulate_phase<Fq>(main, st_ab, buf_a, pk.a_q);
+    DG_HIP(hipEventRecord(ev[0], main));
+    // (the timing bracket and the clock probe of channel 1 sit on B1's launch: A's runs beside B's G2 finalize since that
+    // moved to B's reduction stream, B1's beside the light row / top kernels only -- the launch that says what the kernel does)
+    DG_HIP(hipEventRecord(k1.c.ev[2], main));
+    if (ctx->kclk) buf_b1.clk = ctx->kclk + 2 * 1;    // (dg16_last_kernel_ms(ctx, 1, 2))
+    msm_accumulate_phase<Fq>(main, st_ab, buf_b1, pk.b1_q);
     DG_HIP(hipEventRecord(k1.c.ev[3], main));
     k1.c.ev_valid[1] = true;
-    DG_HIP(hipEventRecord(ev[0], main));
-    msm_accumulate_phase<Fq>(main, st_ab, buf_b1, pk.b1_q);
     DG_HIP(hipEventRecord(ev[1], main));
     msm_accumulate_phase<Fq>(main, st_ab, buf_l, pk.l_q);
     DG_HIP(hipEventRecord(ev[6], main));
