@@ -396,8 +396,11 @@ static bool msms_typed(dg16_ctx* ctx, Call& k0, Call& k1, Call& k2, const PkDev&
     // B's finalize (a throughput kernel at two waves per SIMD: 8 + 1 dependent Fq2 additions per lane) goes to B's reduction
     // stream, under A's accumulation, instead of holding the main stream: an 8-shard rank in a queue 2.48 -> 2.36-2.38 ms,
     // the 2^20 proof and config 4 within the run-to-run spread (profiles/r6oo_g2_finalize_side_ab.txt; =0 puts it back)
-    static const bool main_fin = [] { const char* e = getenv("DG16_G2_FINALIZE_SIDE"); return e && atoi(e) == 0; }();
-    if (!main_fin) buf_b2.finalize_stream = side2;
+    // Nine-limb fields only: the 14-limb G2 finalize (a step loop at ONE wave per SIMD with the whole register file) next
+    // to the 14-limb G1 accumulation costs a BLS12-381 2^20 proof 1 ms (21.7 -> 22.7 in a queue: profiles/r6qq_*).
+    static const int fin_env = [] { const char* e = getenv("DG16_G2_FINALIZE_SIDE"); return e ? atoi(e) : -1; }();
+    const bool side_fin = fin_env >= 0 ? fin_env != 0 : RR<typename FieldOf<Fq>::Params>::N == 9;
+    if (side_fin) buf_b2.finalize_stream = side2;
   }
   msm_accumulate_phase<Fq2>(main, st_ab, buf_b2, pk.b2_q);
   k2.c.ev_valid[1] = true;
