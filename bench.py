@@ -735,12 +735,13 @@ def dmsm_sweep(dev, budget_s=25.0):
             shares = [(np.ascontiguousarray(pb[:, i]), np.ascontiguousarray(ps[:, i])) for i in range(n)]
             del pb, ps
             best, got = None, None
-            for _ in range(3):
+            for rep in range(4):       # (the first round of a size is a warm-up: workspaces of eight fresh contexts grow in it)
                 t0 = time.perf_counter()
                 got = net.simulate_network_round(
                     lambda i, h: D.d_msm(ctxs[i], pps[i], h, 1, shares[i][0], shares[i][1], in_subgroup=True))
                 dt = time.perf_counter() - t0
-                best = dt if best is None else min(best, dt)
+                if rep:
+                    best = dt if best is None else min(best, dt)
             ok = all(np.array_equal(corc.jac_to_affine(curve, 1, g), clear) for g in got)
             rows.append({"log_domain": log_d, "points_per_party": d, "round_ms": best * 1e3,
                          "party_pts_per_s": n * d / best, "clear_msm_cpu_port_ms": t_cpu * 1e3,
@@ -754,7 +755,7 @@ def dmsm_sweep(dev, budget_s=25.0):
         for c in ctxs:
             c.close()
     return {"shape": "d_msm, BLS12-377 G1, l = 2, 8 parties as host threads on one GPU (dmsm_bench.rs:40-53), host-memory "
-                     "shares; round_ms = one simulate_network_round, best of 3",
+                     "shares; round_ms = one simulate_network_round, best of 3 after a warm-up round",
             "cpu_port_cores": cpu_threads(), "rows": rows}
 
 
