@@ -422,14 +422,19 @@ def sharded_in_process_line(ctx, dev, curve, log_m, world, steps, parity=True):
 
 
 
-def table_window_bits(n):
-    """csrc/msm_impl.h: msm_window_bits(n, table = true)."""
+def table_window_bits(n, bits=254):
+    """csrc/msm_impl.h: msm_window_bits(n, table = true, scalar bits)."""
     lg = max(n, 1).bit_length() - 1
     if n > (3 << lg) // 2:
         lg += 1
     c = lg - 3
     if c < 16:
         c = min(lg + 1, 16)
+        if lg >= 13:
+            def top(w):
+                return bits + 1 - ((bits + w) // w - 1) * w
+            if top(15) >= top(16):
+                c = 15 if (top(15) > top(16) or lg <= 16) else 16
     return max(4, min(20, c))
 
 
@@ -449,7 +454,7 @@ def dry_run_plan(curve, log_m, world, steps, warmup):
         lo, hi = shard_bounds(nv - 1, r, world)
         n_ab = hi - lo
         n_h = m // world
-        c_ab, c_h = table_window_bits(n_ab + 3), table_window_bits(n_h)
+        c_ab, c_h = table_window_bits(n_ab + 3, bits), table_window_bits(n_h, bits)
         w_ab, w_h = (bits + c_ab) // c_ab, (bits + c_h) // c_h
         ranks.append({"rank": r, "n_ab": n_ab + 3, "n_h": n_h, "window_bits": {"ab": c_ab, "h": c_h},
                       "windows": {"ab": w_ab, "h": w_h},

@@ -37,7 +37,7 @@ void DG_FN(to_affine_)(Call& k, const void* jac, void* out, size_t n) { to_affin
 // budget != 0: at most that many bytes -- the table keeps every stride-th row (msm_geometry) so that it fits
 void* DG_FN(bases_table_)(Call& k, const void* bases_dev, size_t n, size_t budget, unsigned* c_out, unsigned* rows_out,
                           unsigned* stride_out) {
-  const unsigned c = msm_window_bits(n ? n : 1, true);
+  const unsigned c = msm_window_bits(n ? n : 1, true, CT::SCALAR_BITS);
   const unsigned nwin = (CT::SCALAR_BITS + 1 + c - 1) / c;
   const unsigned stride = table_stride_for((size_t)nwin * (n ? n : 1) * sizeof(Affine<GF>), budget, nwin);
   const unsigned rows = (nwin + stride - 1) / stride;

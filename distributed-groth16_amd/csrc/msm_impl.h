@@ -59,15 +59,27 @@ struct MsmGeom {
 // c = log2(n) - 3 keeps the bucket reduction at a few percent of the MSM (measured at 2^20: c = 17 beats
 // both 16 and 20; again in round 4 with the last reduction off the critical path, profiles/r4w_table_window_sweep.txt:
 // 17: 10.19 ms per proof, 18: 11.10, 19: 11.35, 20: 11.83; H alone at 19 / 20: 10.28 / 10.38)
-inline unsigned msm_window_bits(size_t n, bool table) {
+inline unsigned msm_window_bits(size_t n, bool table, unsigned scalar_bits = 0) {
   unsigned lg = 0;
   while (((size_t)1 << (lg + 1)) <= n) lg++;
   if (n > ((size_t)3 << lg) / 2) lg++;     // nearest power of two (2^20 - 5 points are "2^20")
   int c = table ? (int)lg - 3 : (int)lg - 4;
   // short tables (the shards of a multi-GPU key): the bucket reduction's latency does not shrink with the bucket
   // count, the number of bucket entries W*n does shrink with c -- measured on a 2^17-point shard: c = 14: 8.2 ms
-  // per proof, 15: 6.2, 16: 6.2, 17: 6.3
-  if (table && c < 16) c = (int)lg + 1 < 16 ? (int)lg + 1 : 16;
+  // per proof, 15: 6.2, 16: 6.2, 17: 6.3.  Round 6 (lane-form reductions; profiles/r6tt_*, r6uu_*, r6vv_*): on BN254 what
+  // decides between neighbouring widths is the TOP window -- a width that leaves it two or three bits puts a quarter of the
+  // key into a handful of giant buckets (255 digit bits: c = 12 or 14 cost a 2^15-point proof 1.8 / 1.45 ms against 1.36 at
+  // 15 = 255 / 17; 16 leaves 15 bits too and costs 1.56 with twice the buckets).  So where 15 and 16 leave the same top
+  // window (BN254, BLS12-377) 15 up to 2^16 points and 16 beyond; BLS12-381 (256 digit bits: 16 | 256) measured flat to
+  // within 4 % between 14, 15 and 16 at 2^14..2^16 points and 12 % better at 14 for 2^13 -- it keeps lg + 1.
+  if (table && c < 16) {
+    c = (int)lg + 1 < 16 ? (int)lg + 1 : 16;
+    if (scalar_bits && lg >= 13) {   // below 2^13 points nothing was measured: lg + 1 as before
+      auto top = [&](int w) { const int bits = (int)scalar_bits + 1; return bits - ((bits + w - 1) / w - 1) * w; };
+      const int t15 = top(15), t16 = top(16);
+      if (t15 >= t16) c = (t15 > t16 || lg <= 16) ? 15 : 16;
+    }
+  }
   if (const char* e = getenv(table ? "DG16_MSM_TABLE_C" : "DG16_MSM_C")) c = atoi(e);
   int hi = table ? 20 : 16;
   if (c < 4) c = 4;

@@ -685,9 +685,9 @@ static void pk_build(dg16_ctx* ctx, PkDev& d, const void* a_query, const void* b
   {
     using CTc = CurveTypes<CURVE>;
     auto nwin_of = [](unsigned c) { return (unsigned)((CTc::SCALAR_BITS + 1 + c - 1) / c); };
-    d.c_ab = msm_window_bits(n_ab + 3, true);
+    d.c_ab = msm_window_bits(n_ab + 3, true, CTc::SCALAR_BITS);
     d.c_l = d.c_ab;
-    d.c_h = msm_window_bits(n_h ? n_h : 1, true);
+    d.c_h = msm_window_bits(n_h ? n_h : 1, true, CTc::SCALAR_BITS);
     // (H's window width on its own was swept in round 4, profiles/r4w_table_window_sweep.txt: log2(n) - 3 for it too)
     // HBM budget (dg16_ctx_set_table_budget): one row stride for all five tables -- A, B1, B and L share a digit sort
     const size_t full_bytes = (size_t)nwin_of(d.c_ab) * (n_ab + 3) * (3 * p1 + p2) +
