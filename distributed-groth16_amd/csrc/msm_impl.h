@@ -122,9 +122,17 @@ inline MsmGeom msm_geometry(size_t n, unsigned scalar_bits, bool table = false, 
     // 1.2 waves per SIMD: measured 0.62 ms per G1 accumulation instead of 0.25)
     unsigned le = 0;
     while (((size_t)2 << le) <= (size_t)g.nwin * n) le++;
-    const int cap = (int)le - (int)kMinLanesLog;
+    int cap = (int)le - (int)kMinLanesLog;
+    // ... except a PLAIN MSM of 2^20..2^21 entries (2^16 points after the GLV split): 8-entry segments are 1.25 rounds of the
+    // 14-limb G1 accumulation's 2^17 resident lanes and ~4 partials per bucket for the wave-per-bucket finalize, 16-entry
+    // ones are one round of the same length and half the partials -- BLS12-377 G1 2^16 1.51 -> 1.20 ms, BLS12-381 G1 1.26 ->
+    // 1.13, BN254 G2 1.87 -> 1.64, BN254 G1 unchanged; a size down or up 16 is no better or worse
+    // (profiles/r6xx_seg_log_small_plain_msm.txt: DG16_MSM_SEG_LOG sweep, same call)
+    if (!table && le == 20 && cap < 4) cap = 4;
     if (sl > cap) sl = cap;
     g.seg_log = (unsigned)(sl < (int)kMinSegLog ? (int)kMinSegLog : sl > (int)kMaxSegLog ? (int)kMaxSegLog : sl);
+    static const int seg_env = [] { const char* e = getenv("DG16_MSM_SEG_LOG"); return e ? atoi(e) : 0; }();   // (sweeps)
+    if (seg_env >= (int)kMinSegLog && seg_env <= (int)kMaxSegLog) g.seg_log = (unsigned)seg_env;
   }
   g.seg_cap = (1u << g.log_nb) + (unsigned)((g.region + (1u << g.seg_log) - 1) >> g.seg_log);
   return g;
