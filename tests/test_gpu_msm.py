@@ -410,3 +410,37 @@ def test_resident_msm_2e20_equals_plain_msm():
         o = out.cpu().numpy()
         assert np.array_equal(o[0], o[1]) and o[0].any()
         hb.close()
+
+
+@pytest.mark.parametrize("curve,n", [("bn254", 1 << 13), ("bn254", (1 << 15) + 7), ("bn254", 1 << 16), ("bn254", 1 << 17),
+                                      ("bls12_377", 1 << 14), ("bls12_381", 1 << 13), ("bls12_381", 1 << 15)])
+def test_short_table_window_rule_and_its_plan_mirror(curve, n):
+    """The window width of SHORT resident tables (csrc/msm_impl.h: msm_window_bits with the scalar width -- the width whose top
+    window is not a handful of giant buckets: 15 for BN254 / BLS12-377 keys of 2^13 .. 2^16 points, lg + 1 for BLS12-381):
+    the library's own report == the mirror `bench.py --dry-run` plans with, and the resident MSM at that width == dg16_msm
+    (oracle-checked above) for G1."""
+    import os
+    import sys
+    import torch
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    import bench
+    bits = {"bn254": 254, "bls12_381": 255, "bls12_377": 253}[curve]
+    fqb = 32 if curve == "bn254" else 48
+    c = ctx()
+    dev = torch.device("cuda:0")
+    bases = torch.empty(n * 2 * fqb, dtype=torch.uint8, device=dev)
+    c.gen_bases_dev(curve, 1, 81, n, bases.data_ptr())
+    c.sync(0)
+    hb = c.bases_upload(curve, 1, bases.data_ptr(), n=n, device_ptrs=True)
+    info = hb.info()
+    assert info["window_bits"] == bench.table_window_bits(n, bits), (info, bench.table_window_bits(n, bits))
+    if curve != "bls12_381":
+        assert info["window_bits"] == (15 if n <= (3 << 15) else 16)
+    sc = torch.from_numpy(corc.rand_field(curve, "fr", 9, n, mont=False).view(np.int64)).to(dev)
+    out = torch.empty((2, 2 * fqb), dtype=torch.uint8, device=dev)
+    c.msm_resident_dev(hb, sc.data_ptr(), n, out[0].data_ptr(), affine=True)
+    c.msm_dev(curve, 1, bases.data_ptr(), sc.data_ptr(), n, out[1].data_ptr(), affine=True, in_subgroup=True)
+    c.sync(0)
+    o = out.cpu().numpy()
+    assert np.array_equal(o[0], o[1]) and o[0].any()
+    hb.close()
