@@ -320,19 +320,22 @@ __global__ void __launch_bounds__(256) msm_scatter_kernel(const int* __restrict_
                                                            const unsigned* __restrict__ seg_off,
                                                            unsigned* __restrict__ cursor,
                                                            unsigned* __restrict__ entries) {
+  // one thread per (scalar, window) -- blockIdx.y = window: the rank comes back from an atomic, and a thread that walked
+  // its scalar's windows paid W dependent round trips: 34 -> 4 us of a 0.55-ms MSM at 2^10 points (at 2^13 the 2^17.6
+  // returning atomics are the bound either way: 45 -> 38 us; the digits kernel's atomics return nothing and gain nothing
+  // from the same split: profiles/r6zv)
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const bool live = i < n;
-  for (unsigned w = 0; w < g.nwin; w++) {
-    int d = live ? digits[(size_t)w * n + i] : 0;
-    const bool act = d != 0;
-    unsigned b = act ? (unsigned)(d < 0 ? -d : d) - 1 : 0u;
-    const unsigned bwin = w % g.bw;
-    unsigned slot = (bwin << g.log_nb) + b;
-    unsigned rank = wave_atomic_inc(cursor, slot, act);
-    if (!act) continue;
-    unsigned ref = (unsigned)((size_t)(w / g.bw) * n + i);   // table row w / bw = 2^(c*bw*(w/bw)) * P_i (plain: row 0)
-    entries[DG_IDX(15, (size_t)bwin * g.region + offsets[slot] + rank, (size_t)g.bw * g.region)] = ref | (d < 0 ? 0x80000000u : 0u);
-  }
+  const unsigned w = blockIdx.y;
+  int d = live ? digits[(size_t)w * n + i] : 0;
+  const bool act = d != 0;
+  unsigned b = act ? (unsigned)(d < 0 ? -d : d) - 1 : 0u;
+  const unsigned bwin = w % g.bw;
+  unsigned slot = (bwin << g.log_nb) + b;
+  unsigned rank = wave_atomic_inc(cursor, slot, act);
+  if (!act) return;
+  unsigned ref = (unsigned)((size_t)(w / g.bw) * n + i);   // table row w / bw = 2^(c*bw*(w/bw)) * P_i (plain: row 0)
+  entries[DG_IDX(15, (size_t)bwin * g.region + offsets[slot] + rank, (size_t)g.bw * g.region)] = ref | (d < 0 ? 0x80000000u : 0u);
 }
 
 // ---- 1'-3': partitioned digit sort (large MSMs) ------------------------------------------------------
@@ -1984,7 +1987,7 @@ MsmSort msm_sort_on(hipStream_t s, Channel& wsch, const void* scalars, size_t n,
     hipLaunchKernelGGL(msm_part_place_kernel<0>, dim3(kPartBlocks, pg.nparts), dim3(256), 0, s, part, blockoff, pg, g,
                        r.offsets, r.seg_off, r.cursor, r.entries);
   else if (n)
-    hipLaunchKernelGGL(msm_scatter_kernel<0>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, r.digits, n, g,
+    hipLaunchKernelGGL(msm_scatter_kernel<0>, dim3((unsigned)((n + 255) / 256), g.nwin), dim3(256), 0, s, r.digits, n, g,
                        r.offsets, r.seg_off, r.cursor, r.entries);
   DG_HIP(hipGetLastError());
   return r;
