@@ -444,3 +444,16 @@ def test_short_table_window_rule_and_its_plan_mirror(curve, n):
     o = out.cpu().numpy()
     assert np.array_equal(o[0], o[1]) and o[0].any()
     hb.close()
+
+
+@pytest.mark.parametrize("curve,n", [("bn254", (1 << 17) + 3), ("bn254", 1 << 18), ("bls12_377", 1 << 17), ("bls12_381", 1 << 17),
+                                      ("bls12_381", (1 << 18) - 5)])
+def test_plain_g1_msm_at_the_sixteen_bit_window_sizes(curve, n):
+    """Plain G1 MSMs of 2^17 .. 2^18 points run the split halves with c = 16 (eight windows of the 128-bit halves instead of
+    log2(2 n) - 4 = 14 / 15: csrc/msm_impl.h, msm_run): against the oracle's MSM, through the host-pointer entry."""
+    bases = ctx().gen_bases(curve, 1, 2 + n, n)
+    scalars = corc.rand_field(curve, "fr", 9 + n, n, mont=False)
+    jac = gmsm(ctx(), curve, 1, bases, scalars)
+    got = corc.jac_to_affine(curve, 1, jac)
+    exp = corc.msm(curve, 1, bases, scalars, threads=32)
+    assert np.array_equal(got, exp)
